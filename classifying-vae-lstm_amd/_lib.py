@@ -1,0 +1,99 @@
+"""ctypes binding of libclvae_hip.so (the C ABI declared in include/clvae.h).
+
+The product has NO CPU fallback: ``lib()`` raises if the shared library is not
+built, ``require_gpu()`` raises if no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclvae_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_MASKPOS = 0, 1, 2, 3
+GATE_HARD_SIGMOID, GATE_SIGMOID = 0, 1
+
+_f = C.c_float
+_i = C.c_int
+_p = C.c_void_p
+_sz = C.c_size_t
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_u32 = C.c_uint32
+
+
+class ParamDesc(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
+
+
+# name -> (restype, argtypes); must list every function of include/clvae.h
+SIGNATURES = {
+    "clv_version": (_i, []),
+    "clv_device_count": (_i, []),
+    "clv_error_string": (C.c_char_p, [_i]),
+    "clv_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "clv_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p]),
+    "clv_colsum_workspace_bytes": (_sz, [_i, _i]),
+    "clv_colsum_f32": (_i, [_i, _i, _p, _i, _f, _p, _p, _sz, _p]),
+    "clv_lstm_seq_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_lstm_seq_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_label_fwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
+    "clv_label_bwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _i, _p]),
+    "clv_gauss_fwd": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
+    "clv_gauss_bwd": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p]),
+    "clv_bernoulli_nll": (_i, [_i, _i, _p, _p, _i, _f, _p, _p, _p]),
+    "clv_sum_strided": (_i, [_i, _p, _i, _f, _p, _p]),
+    "clv_adam_wn_plan_bytes": (_sz, [_p, _i]),
+    "clv_adam_wn_plan_build": (_i, [_p, _i, _p]),
+    "clv_adam_wn_workspace_bytes": (_sz, [_p, _i]),
+    "clv_adam_wn_step": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _p, _sz, _p]),
+    "clv_philox_normal": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
+    "clv_philox_uniform": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
+    "clv_bernoulli_sample": (_i, [_i64, _p, _p, _p, _p]),
+    "clv_graph_begin_capture": (_i, [_p]),
+    "clv_graph_end_capture": (_i, [_p, C.POINTER(_p)]),
+    "clv_graph_launch": (_i, [_p, _p]),
+    "clv_graph_destroy": (_i, [_p]),
+    "clv_prof_enable": (_i, [_i]),
+    "clv_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
+}
+
+_lib = None
+
+
+class ClvError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ClvError(
+                "libclvae_hip.so is not built (%s). Run `python __graft_entry__.py` or "
+                "`make -C classifying-vae-lstm_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)      # AttributeError if the ABI drifted
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def require_gpu():
+    n = lib().clv_device_count()
+    if n <= 0:
+        raise ClvError("no gfx950 (MI355X) device visible; the HIP path has no CPU fallback")
+    return n
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib().clv_error_string(int(code))
+        raise ClvError("%s failed: %s (%d)" % (what or "clv call", msg.decode() if msg else "?", code))

@@ -1,0 +1,72 @@
+// common.h -- shared host/device helpers for libclvae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/clvae.h"
+
+#define CLV_WAVE 64
+
+#define CLV_HIP_TRY(expr)                         \
+  do {                                            \
+    hipError_t e__ = (expr);                      \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+namespace clv {
+
+// ---- opt-in profiler (clv_prof_*): events on the launch stream -------------
+void prof_begin(const char* name, hipStream_t s);
+void prof_end(hipStream_t s);
+bool prof_on();
+
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(const char* name, hipStream_t st) : s(st), on(prof_on()) {
+    if (on) prof_begin(name, s);
+  }
+  ~ProfScope() {
+    if (on) prof_end(s);
+  }
+};
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CLV_OK : (int)e;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device math ------------------------------------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// tanh(x) = 1 - 2/(1+exp(2x)); v_exp_f32 + v_rcp_f32, abs error ~2e-7
+__device__ __forceinline__ float fast_tanh(float x) {
+  float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+  float e = __expf(2.0f * xc);
+  return 1.0f - 2.0f * fast_rcp(e + 1.0f);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) {
+  float xc = fminf(fmaxf(x, -30.0f), 30.0f);
+  return fast_rcp(1.0f + __expf(-xc));
+}
+
+// Keras 2.0.0 hard_sigmoid: clip(0.2*x + 0.5, 0, 1)
+__device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.0f), 1.0f); }
+// derivative; TF's clip passes the gradient at ties
+__device__ __forceinline__ float hard_sigmoid_grad(float z) {
+  float y = 0.2f * z + 0.5f;
+  return (y >= 0.0f && y <= 1.0f) ? 0.2f : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace clv

@@ -1,0 +1,301 @@
+// gemm.hip -- fp32 GEMM on v_mfma_f32_16x16x4_f32 (gfx950), LDS-tiled, register-prefetched.
+//
+// C[M,N] = act(alpha * op(A) . op(B) + bias + beta * C); optional split-K with
+// deterministic partial slabs.  The MFMA is a bit-exact k-ordered f32 fma chain
+// (MI355X_MICROARCH.md, Matrix cores), so results are deterministic and within
+// fp32 rounding of the fp64 oracle.
+//
+// Tile: BM = 16*WM*WAVES_M, BN = 16*WN*WAVES_N, BK = 16, 256 threads (4 waves).
+// LDS holds both operands k-major ([k][m] / [k][n]) with a row stride == 16
+// (mod 32) floats so the two k-rows a half-wave reads land on disjoint banks.
+#include "common.h"
+
+namespace clv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+  int M, N, K;
+  float alpha, beta;
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  const float* bias;
+  int act;
+  const float* aux;
+  int k_chunk;       // K handled per blockIdx.z slice (multiple of 16)
+  float* partial;    // != nullptr: raw partial sums [z][M][N]
+  int vecA, vecB;    // 16-byte vector loads legal for A / B
+};
+
+template <int BMN>
+struct LdsStride {  // == 16 (mod 32), multiple of 4
+  static constexpr int value = (BMN % 32 == 16) ? BMN : BMN + 16;
+};
+
+// ---- global -> register staging -------------------------------------------
+// MC: the tile dimension (m or n) is contiguous in memory: elem(mn,k) = p[k*ld + mn]
+// KC: k is contiguous:                                  elem(mn,k) = p[mn*ld + k]
+template <int BMN, bool KC>
+struct TileLoader {
+  static constexpr int BK = 16;
+  static constexpr int NV = BMN * BK / 4;              // float4 per tile
+  static constexpr int PER = (NV + 255) / 256;         // float4 per thread
+  static constexpr int LD = LdsStride<BMN>::value;
+
+  __device__ static void load(float4 (&r)[PER], const float* __restrict__ p, int ld, int dim_mn,
+                              int k_end, int mn0, int k0, int vec, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + i * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < NV) {
+        if (KC) {
+          int mn = idx >> 2, k4 = (idx & 3) * 4;
+          int gm = mn0 + mn, gk = k0 + k4;
+          if (gm < dim_mn) {
+            const float* src = p + (size_t)gm * ld + gk;
+            if (vec && gk + 3 < k_end) {
+              v = *reinterpret_cast<const float4*>(src);
+            } else {
+              if (gk + 0 < k_end) v.x = src[0];
+              if (gk + 1 < k_end) v.y = src[1];
+              if (gk + 2 < k_end) v.z = src[2];
+              if (gk + 3 < k_end) v.w = src[3];
+            }
+          }
+        } else {
+          constexpr int RV = BMN / 4;
+          int k = idx / RV, c4 = (idx % RV) * 4;
+          int gk = k0 + k, gm = mn0 + c4;
+          if (gk < k_end) {
+            const float* src = p + (size_t)gk * ld + gm;
+            if (vec && gm + 3 < dim_mn) {
+              v = *reinterpret_cast<const float4*>(src);
+            } else {
+              if (gm + 0 < dim_mn) v.x = src[0];
+              if (gm + 1 < dim_mn) v.y = src[1];
+              if (gm + 2 < dim_mn) v.z = src[2];
+              if (gm + 3 < dim_mn) v.w = src[3];
+            }
+          }
+        }
+      }
+      r[i] = v;
+    }
+  }
+
+  __device__ static void store(const float4 (&r)[PER], float* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + i * 256;
+      if (idx < NV) {
+        if (KC) {
+          int mn = idx >> 2, k4 = (idx & 3) * 4;
+          lds[(k4 + 0) * LD + mn] = r[i].x;
+          lds[(k4 + 1) * LD + mn] = r[i].y;
+          lds[(k4 + 2) * LD + mn] = r[i].z;
+          lds[(k4 + 3) * LD + mn] = r[i].w;
+        } else {
+          constexpr int RV = BMN / 4;
+          int k = idx / RV, c4 = (idx % RV) * 4;
+          *reinterpret_cast<float4*>(&lds[k * LD + c4]) = r[i];
+        }
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float aux) {
+  if (act == CLV_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == CLV_ACT_SIGMOID) return sigmoidf_(v);
+  if (act == CLV_ACT_MASKPOS) return aux > 0.f ? v : 0.f;
+  return v;
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N, BK = 16;
+  using LA = TileLoader<BM, !TA>;   // A row-major [M,K] => k contiguous
+  using LB = TileLoader<BN, TB>;    // B row-major [K,N] => n contiguous
+  constexpr int LDA = LA::LD, LDB = LB::LD;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kend = min(g.K, kbeg + g.k_chunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[LA::PER], rb[LB::PER];
+  if (nk > 0) {
+    LA::load(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
+    LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
+    LA::store(ra, As, tid);
+    LB::store(rb, Bs, tid);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      LA::load(ra, g.A, g.lda, g.M, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid);
+      LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
+    }
+    const float* as = As + cur * BK * LDA + wm * WM * 16 + r;
+    const float* bs = Bs + cur * BK * LDB + wn * WN * 16 + r;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = as[(ks * 4 + q) * LDA + i * 16];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = bs[(ks * 4 + q) * LDB + j * 16];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      LA::store(ra, As + (cur ^ 1) * BK * LDA, tid);
+      LB::store(rb, Bs + (cur ^ 1) * BK * LDB, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + (wn * WN + j) * 16 + r;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + (wm * WM + i) * 16 + q * 4 + reg;
+        if (row >= g.M) continue;
+        float v = acc[i][j][reg];
+        if (g.partial) {
+          g.partial[((size_t)blockIdx.z * g.M + row) * g.N + col] = v;
+        } else {
+          v *= g.alpha;
+          if (g.bias) v += g.bias[col];
+          const size_t o = (size_t)row * g.ldc + col;
+          if (g.beta != 0.f) v += g.beta * g.C[o];
+          v = apply_act(v, g.act, g.act == CLV_ACT_MASKPOS ? g.aux[o] : 0.f);
+          g.C[o] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int splits) {
+  const size_t mn = (size_t)g.M * g.N;
+  for (size_t idx = blockIdx.x * 256 + threadIdx.x; idx < mn; idx += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += g.partial[z * mn + idx];
+    const int row = (int)(idx / g.N), col = (int)(idx % g.N);
+    v *= g.alpha;
+    if (g.bias) v += g.bias[col];
+    const size_t o = (size_t)row * g.ldc + col;
+    if (g.beta != 0.f) v += g.beta * g.C[o];
+    v = apply_act(v, g.act, g.act == CLV_ACT_MASKPOS ? g.aux[o] : 0.f);
+    g.C[o] = v;
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+static void launch_cfg(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
+  constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
+  dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, splits);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, false, false>), grid, dim3(256), 0, s, g);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, false, true>), grid, dim3(256), 0, s, g);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, true, false>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, true, true>), grid, dim3(256), 0, s, g);
+}
+
+// tile choice by output shape (all shapes of the path: N in {2..352}, M in {10..262144})
+static void launch_gemm(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
+  const int M = g.M, N = g.N;
+  if (N <= 16) {
+    launch_cfg<2, 1, 4, 1>(g, ta, tb, splits, s);            // 128 x 16
+  } else if (N <= 32) {
+    launch_cfg<1, 2, 4, 1>(g, ta, tb, splits, s);            // 64 x 32
+  } else if (N <= 64) {
+    launch_cfg<2, 2, 2, 2>(g, ta, tb, splits, s);            // 64 x 64
+  } else if (N <= 96) {
+    if (M <= 96) launch_cfg<3, 3, 2, 2>(g, ta, tb, splits, s);   // 96 x 96
+    else launch_cfg<1, 6, 4, 1>(g, ta, tb, splits, s);           // 64 x 96
+  } else if (N % 176 == 0 || N > 256) {
+    if (M <= 96) launch_cfg<3, 3, 2, 2>(g, ta, tb, splits, s);   // 96 x 96 (weight grads, split-K)
+    else launch_cfg<1, 11, 4, 1>(g, ta, tb, splits, s);          // 64 x 176
+  } else {
+    launch_cfg<2, 2, 2, 2>(g, ta, tb, splits, s);
+  }
+}
+
+}  // namespace clv
+
+extern "C" size_t clv_gemm_workspace_bytes(int M, int N, int split_k) {
+  if (split_k <= 1) return 0;
+  return (size_t)split_k * M * N * sizeof(float);
+}
+
+extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
+                            const float* A, int lda, const float* B, int ldb,
+                            float beta, float* C, int ldc,
+                            const float* bias, int act, const float* aux,
+                            int split_k, void* ws, size_t ws_bytes, void* stream) {
+  using namespace clv;
+  if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return CLV_EINVAL;
+  if (act < CLV_ACT_NONE || act > CLV_ACT_MASKPOS) return CLV_EINVAL;
+  if (act == CLV_ACT_MASKPOS && !aux) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.act = act; g.aux = aux;
+  g.vecA = (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
+  g.vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
+  int splits = split_k < 1 ? 1 : split_k;
+  int kc = (K + splits - 1) / splits;
+  kc = (kc + 15) / 16 * 16;
+  if (kc == 0) kc = 16;
+  splits = (K + kc - 1) / kc;
+  if (splits < 1) splits = 1;
+  g.k_chunk = kc;
+  g.partial = nullptr;
+  if (splits > 1) {
+    size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) return CLV_EWORKSPACE;
+    g.partial = (float*)ws;
+  }
+  {
+    ProfScope p("gemm_f32", s);
+    launch_gemm(g, transa != 0, transb != 0, splits, s);
+  }
+  int st = launch_status();
+  if (st) return st;
+  if (splits > 1) {
+    ProfScope p("gemm_splitk_reduce", s);
+    size_t mn = (size_t)M * N;
+    int blocks = (int)((mn + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, splits);
+    st = launch_status();
+  }
+  return st;
+}

@@ -1,0 +1,322 @@
+// lstm.hip -- persistent LSTM sequence kernels for H = 88 (gfx950).
+//
+// Batch rows are independent, so a workgroup owns R rows for all T steps and no
+// grid-level sync exists.  At the reference's batch sizes (256 rows per GPU) the
+// chip has one CU per row: the recurrent product h.U is a matrix-vector product
+// per CU, which the MFMA (16-row tiles) cannot fill, so it runs on the VALU with
+// the whole recurrent kernel U [88,352] (124 KB) resident in REGISTERS:
+//   704 threads = 11 waves; lane = (unit_local = lane>>3, kslice = lane&7);
+//   unit u = 8*wave + unit_local; thread (u, s) keeps U[11s..11s+10][{i,f,c,o} of u]
+//   (forward) or U[u][44s..44s+43] (backward) = 44 floats.
+// Per step a thread does 44 FMAs per row, the 8 k-slices are summed with three
+// DPP adds (quad_perm, quad_perm, row_half_mirror), and the unit's gate math and
+// cell state stay in that thread group's registers; only h_t (forward) / dz_t
+// (backward) cross lanes through LDS, one barrier per step.
+#include "common.h"
+
+namespace clv {
+
+constexpr int LH = 88;          // hidden units
+constexpr int LG = 4 * LH;      // gate columns
+constexpr int LTHREADS = 704;   // 11 waves
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return v + __builtin_bit_cast(float, t);
+}
+// sum over the 8 consecutive lanes of a k-slice group; every lane gets the total
+__device__ __forceinline__ float reduce8(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  return v;
+}
+
+template <int GATE>
+__device__ __forceinline__ float gate_fn(float z) {
+  return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid(z) : sigmoidf_(z);
+}
+template <int GATE>
+__device__ __forceinline__ float gate_grad(float z, float y) {
+  return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid_grad(z) : y * (1.f - y);
+}
+
+struct LstmFwdArgs {
+  int B, T;
+  const float* xproj;    // [B,T,352]
+  const float* rowbias;  // [B,352] or null
+  const float* U;        // [88,352]
+  const float* h0;       // [B,88] or null
+  const float* c0;
+  float* hs;             // [B,T,88]
+  float* cs;             // [B,T,88]
+  float* gates;          // [B,T,352] (z_i, z_f, tanh(z_c), z_o) or null (inference)
+  float* hT;             // [B,88] or null
+  float* cT;
+};
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <int R, int GATE>
+__global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
+  constexpr int NC = 8 / R;            // lane copies per (row, unit)
+  constexpr int NX = (4 * R + 7) / 8;  // xproj loads per lane per step
+  __shared__ __attribute__((aligned(16))) float hbuf[2][R][96];   // slice s at 12*s (11 used)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = lane & 7, u = wave * 8 + (lane >> 3);
+  const int row0 = blockIdx.x * R;
+  const int myrow = s % R, copy = s / R;     // which row this lane finishes, which outputs it stores
+  const int T = a.T;
+
+  // recurrent kernel slice -> registers
+  float Ur[11][4];
+#pragma unroll
+  for (int kk = 0; kk < 11; ++kk)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Ur[kk][g] = a.U[(size_t)(11 * s + kk) * LG + g * LH + u];
+
+  // per-lane share of xproj / rowbias: element e = s + 8*i -> (row e>>2, gate e&3)
+  float rb[NX];
+  size_t xoff[NX];
+  bool xok[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = s + 8 * i;
+    xok[i] = e < 4 * R;
+    const int rr = xok[i] ? (e >> 2) : 0, gg = e & 3;
+    xoff[i] = (size_t)(row0 + rr) * T * LG + gg * LH + u;
+    rb[i] = (xok[i] && a.rowbias) ? a.rowbias[(size_t)(row0 + rr) * LG + gg * LH + u] : 0.f;
+  }
+
+  // initial state
+  float c = a.c0 ? a.c0[(size_t)(row0 + myrow) * LH + u] : 0.f;
+  if (copy == 0) {
+    float h = a.h0 ? a.h0[(size_t)(row0 + myrow) * LH + u] : 0.f;
+    hbuf[0][myrow][12 * (u / 11) + (u % 11)] = h;
+  }
+  float xn[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xn[i] = (xok[i] && T > 0) ? a.xproj[xoff[i]] : 0.f;
+  __syncthreads();
+
+  float hlast = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    float xv[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      xv[i] = xn[i] + rb[i];
+      if (t + 1 < T && xok[i]) xn[i] = a.xproj[xoff[i] + (size_t)(t + 1) * LG];   // prefetch
+    }
+    // acc[r][g] starts from the lane's xproj share, then 11 FMAs per gate
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        constexpr int dummy = 0; (void)dummy;
+        const int e = r * 4 + g;              // compile-time
+        acc[r][g] = (s == (e & 7)) ? xv[e >> 3] : 0.f;
+      }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][r][12 * s]);
+      float4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+      const float hv[11] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z};
+#pragma unroll
+      for (int kk = 0; kk < 11; ++kk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[r][g] = fmaf(hv[kk], Ur[kk][g], acc[r][g]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[r][g] = reduce8(acc[r][g]);
+    // this lane finishes row `myrow`
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      z[g] = acc[0][g];
+#pragma unroll
+      for (int r = 1; r < R; ++r) z[g] = (myrow == r) ? acc[r][g] : z[g];
+    }
+    const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);
+    const float gg = fast_tanh(z[2]);
+    c = fg * c + ig * gg;
+    const float h = og * fast_tanh(c);
+    hlast = h;
+    if (copy == 0) hbuf[cur ^ 1][myrow][12 * (u / 11) + (u % 11)] = h;
+    // outputs: 6 arrays shared among the NC copies
+    const size_t bt = (size_t)(row0 + myrow) * T + t;
+    if (copy == 0 % NC) a.hs[bt * LH + u] = h;
+    if (copy == 1 % NC) a.cs[bt * LH + u] = c;
+    if (a.gates) {
+      float* gp = a.gates + bt * LG + u;
+      if (copy == 2 % NC) gp[0] = z[0];
+      if (copy == 3 % NC) gp[LH] = z[1];
+      if (copy == 4 % NC) gp[2 * LH] = gg;
+      if (copy == 5 % NC) gp[3 * LH] = z[3];
+    }
+    __syncthreads();
+  }
+  if (copy == 0) {
+    if (a.hT) a.hT[(size_t)(row0 + myrow) * LH + u] = T > 0 ? hlast : (a.h0 ? a.h0[(size_t)(row0 + myrow) * LH + u] : 0.f);
+    if (a.cT) a.cT[(size_t)(row0 + myrow) * LH + u] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward (BPTT); gates buffer is overwritten in place with dz
+// ---------------------------------------------------------------------------
+struct LstmBwdArgs {
+  int B, T;
+  const float* U;       // [88,352]
+  const float* dhs;     // [B,T,88]
+  const float* cs;      // [B,T,88]
+  const float* c0;      // [B,88] or null
+  float* gates;         // in: (z_i,z_f,g,z_o)  out: dz
+  float* dzsum;         // [B,352] or null
+};
+
+template <int R, int GATE>
+__global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
+  constexpr int NC = 8 / R;
+  __shared__ __attribute__((aligned(16))) float dzbuf[2][R][LG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = lane & 7, u = wave * 8 + (lane >> 3);
+  const int row0 = blockIdx.x * R;
+  const int myrow = s % R, copy = s / R;
+  const int T = a.T;
+
+  float Ur[44];   // U[u][44s .. 44s+43]
+  {
+    const float4* up = reinterpret_cast<const float4*>(a.U + (size_t)u * LG + 44 * s);
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      float4 v = up[j];
+      Ur[4 * j] = v.x; Ur[4 * j + 1] = v.y; Ur[4 * j + 2] = v.z; Ur[4 * j + 3] = v.w;
+    }
+  }
+  for (int i = tid; i < 2 * R * LG; i += LTHREADS) (&dzbuf[0][0][0])[i] = 0.f;
+
+  const size_t rowbt = (size_t)(row0 + myrow) * T;
+  float dc = 0.f;
+  float zs[4] = {0.f, 0.f, 0.f, 0.f};   // running sum_t dz (this lane's row/unit)
+  // prefetch registers for step t
+  float p_zi = 0.f, p_zf = 0.f, p_g = 0.f, p_zo = 0.f, p_c = 0.f, p_cp = 0.f, p_dh = 0.f;
+  auto prefetch = [&](int t) {
+    const size_t bt = rowbt + t;
+    const float* gp = a.gates + bt * LG + u;
+    p_zi = gp[0]; p_zf = gp[LH]; p_g = gp[2 * LH]; p_zo = gp[3 * LH];
+    p_c = a.cs[bt * LH + u];
+    p_cp = t > 0 ? a.cs[(bt - 1) * LH + u] : (a.c0 ? a.c0[(size_t)(row0 + myrow) * LH + u] : 0.f);
+    p_dh = a.dhs[bt * LH + u];
+  };
+  if (T > 0) prefetch(T - 1);
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    const int cur = (T - 1 - t) & 1;
+    const float zi = p_zi, zf = p_zf, g = p_g, zo = p_zo, ct = p_c, cp = p_cp, dhh = p_dh;
+    // dh_rec[u] = sum_c dz_{t+1}[c] * U[u][c]
+    float part[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][44 * s]);
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        float4 v = dp[j];
+        acc0 = fmaf(v.x, Ur[4 * j], acc0);
+        acc1 = fmaf(v.y, Ur[4 * j + 1], acc1);
+        acc0 = fmaf(v.z, Ur[4 * j + 2], acc0);
+        acc1 = fmaf(v.w, Ur[4 * j + 3], acc1);
+      }
+      part[r] = acc0 + acc1;
+    }
+    if (t > 0) prefetch(t - 1);   // loads for the next iteration; gates[t-1] is not written this step
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[r] = reduce8(part[r]);
+    float dhrec = part[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) dhrec = (myrow == r) ? part[r] : dhrec;
+
+    const float ig = gate_fn<GATE>(zi), fg = gate_fn<GATE>(zf), og = gate_fn<GATE>(zo);
+    const float tc = fast_tanh(ct);
+    const float dh = dhh + dhrec;
+    const float d_o = dh * tc;
+    dc = dc + dh * og * (1.f - tc * tc);
+    float dz[4];
+    dz[0] = dc * g * gate_grad<GATE>(zi, ig);
+    dz[1] = dc * cp * gate_grad<GATE>(zf, fg);
+    dz[2] = dc * ig * (1.f - g * g);
+    dz[3] = d_o * gate_grad<GATE>(zo, og);
+    dc = dc * fg;
+    float* gp = a.gates + (rowbt + t) * LG + u;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      zs[gi] += dz[gi];
+      if (copy == gi % NC) {
+        dzbuf[cur ^ 1][myrow][gi * LH + u] = dz[gi];
+        gp[gi * LH] = dz[gi];
+      }
+    }
+    __syncthreads();
+  }
+  if (a.dzsum) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+      if (copy == gi % NC) a.dzsum[(size_t)(row0 + myrow) * LG + gi * LH + u] = zs[gi];
+  }
+}
+
+template <int GATE>
+static int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
+  const int B = a.B;
+  if (B % 4 == 0 && B >= 2048) hipLaunchKernelGGL((lstm_fwd_kernel<4, GATE>), dim3(B / 4), dim3(LTHREADS), 0, s, a);
+  else if (B % 2 == 0 && B >= 1024) hipLaunchKernelGGL((lstm_fwd_kernel<2, GATE>), dim3(B / 2), dim3(LTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((lstm_fwd_kernel<1, GATE>), dim3(B), dim3(LTHREADS), 0, s, a);
+  return launch_status();
+}
+template <int GATE>
+static int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
+  const int B = a.B;
+  if (B % 4 == 0 && B >= 2048) hipLaunchKernelGGL((lstm_bwd_kernel<4, GATE>), dim3(B / 4), dim3(LTHREADS), 0, s, a);
+  else if (B % 2 == 0 && B >= 1024) hipLaunchKernelGGL((lstm_bwd_kernel<2, GATE>), dim3(B / 2), dim3(LTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((lstm_bwd_kernel<1, GATE>), dim3(B), dim3(LTHREADS), 0, s, a);
+  return launch_status();
+}
+
+}  // namespace clv
+
+extern "C" int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
+                                const float* xproj, const float* rowbias, const float* U,
+                                const float* h0, const float* c0,
+                                float* hs, float* cs, float* gates, float* hT, float* cT,
+                                void* stream) {
+  using namespace clv;
+  if (H != LH || B <= 0 || T < 0 || !xproj || !U || !hs || !cs) return CLV_EINVAL;
+  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  LstmFwdArgs a{B, T, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("lstm_seq_fwd", s);
+  return gate_act == CLV_GATE_HARD_SIGMOID ? launch_fwd<CLV_GATE_HARD_SIGMOID>(a, s)
+                                           : launch_fwd<CLV_GATE_SIGMOID>(a, s);
+}
+
+extern "C" int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
+                                const float* U, const float* dhs, const float* cs, const float* c0,
+                                float* gates_inout_dz, float* dzsum, void* stream) {
+  using namespace clv;
+  if (H != LH || B <= 0 || T < 0 || !U || !dhs || !cs || !gates_inout_dz) return CLV_EINVAL;
+  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  LstmBwdArgs a{B, T, U, dhs, cs, c0, gates_inout_dz, dzsum};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("lstm_seq_bwd", s);
+  return gate_act == CLV_GATE_HARD_SIGMOID ? launch_bwd<CLV_GATE_HARD_SIGMOID>(a, s)
+                                           : launch_bwd<CLV_GATE_SIGMOID>(a, s);
+}

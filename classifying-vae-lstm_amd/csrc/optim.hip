@@ -1,0 +1,268 @@
+// optim.hip -- Adam with weight normalisation over a flat parameter buffer
+// (restates utils/weightnorm.py:75-178 of the reference; plain Keras Adam when
+// weightnorm == 0).  HBM-bound: ~7 floats moved per parameter per step.
+//
+// Work is cut into units of <= 64 rows of one tensor (all its columns).  The two
+// per-column reductions (||V||^2 and sum g.V before the update, ||V'||^2 after)
+// go through deterministic partial slabs, not atomics:
+//   K1 stats   : partial (sum V^2, sum g.V) per unit and column
+//   K2 columns : per column: ||V||, grad_g, Adam on g  -> column scalars
+//   K3 update  : grad_V, Adam on V, W <- V', partial sum V'^2 ; biases: plain Adam
+//   K4 rescale : s' = g'/||V'||, W <- s'.V', s <- s' ; advances `iterations`
+#include "common.h"
+
+namespace clv {
+
+constexpr int UNIT_ROWS = 64;
+
+struct AdamUnit {
+  int64_t offset;       // element offset of the tensor
+  int64_t col_offset;   // tensor's offset into s/mg/vg
+  int32_t row0, nrows, cols;
+  int32_t is_matrix;
+  int32_t part_off;     // this unit's offset into the partial slabs
+  int32_t pad_;
+};
+struct AdamCol {
+  int64_t col_global;   // index into s/mg/vg
+  int32_t part_base;    // first unit's partial offset for this tensor
+  int32_t nunits;
+  int32_t cols;
+  int32_t col_local;
+};
+struct AdamHyper {
+  float lr, b1, b2, eps;
+  int weightnorm;
+  int step_t;                 // used when iterations == nullptr
+  const int32_t* iterations;  // device counter (Keras `iterations`), t = *iterations + 1
+};
+
+__device__ __forceinline__ float adam_lr_t(const AdamHyper& h) {
+  const int t = h.iterations ? (*h.iterations + 1) : h.step_t;
+  return h.lr * sqrtf(1.f - powf(h.b2, (float)t)) / (1.f - powf(h.b1, (float)t));
+}
+
+__global__ __launch_bounds__(256) void wn_stats_kernel(const AdamUnit* units, const float* params, const float* grads,
+                                                       const float* s, float* partA, float* partB) {
+  const AdamUnit un = units[blockIdx.x];
+  if (!un.is_matrix) return;
+  __shared__ float ra[4][64], rbb[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < un.cols; c0 += 64) {
+    const int col = c0 + cx;
+    float a = 0.f, b = 0.f;
+    if (col < un.cols) {
+      const float inv_s = 1.f / s[un.col_offset + col];
+      for (int r = ry; r < un.nrows; r += 4) {
+        const size_t o = un.offset + (size_t)(un.row0 + r) * un.cols + col;
+        const float V = params[o] * inv_s;
+        a += V * V;
+        b += grads[o] * V;
+      }
+    }
+    ra[ry][cx] = a; rbb[ry][cx] = b;
+    __syncthreads();
+    if (ry == 0 && col < un.cols) {
+      partA[un.part_off + col] = ra[0][cx] + ra[1][cx] + ra[2][cx] + ra[3][cx];
+      partB[un.part_off + col] = rbb[0][cx] + rbb[1][cx] + rbb[2][cx] + rbb[3][cx];
+    }
+    __syncthreads();
+  }
+}
+
+// colscal[4*j + {0,1,2,3}] = {1/s, grad_g/||V||, s, new_g}
+__global__ void wn_cols_kernel(int n_cols, const AdamCol* cols, const float* partA, const float* partB,
+                               const float* s, float* mg, float* vg, float* colscal, AdamHyper h) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_cols) return;
+  const AdamCol c = cols[j];
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < c.nunits; ++k) {
+    a += partA[c.part_base + k * c.cols + c.col_local];
+    b += partB[c.part_base + k * c.cols + c.col_local];
+  }
+  const float lr_t = adam_lr_t(h);
+  const float sc = s[c.col_global];
+  const float Vn = sqrtf(a);
+  const float gparam = sc * Vn;
+  const float grad_g = b / Vn;
+  const float mgn = h.b1 * mg[c.col_global] + (1.f - h.b1) * grad_g;
+  const float vgn = h.b2 * vg[c.col_global] + (1.f - h.b2) * grad_g * grad_g;
+  mg[c.col_global] = mgn;
+  vg[c.col_global] = vgn;
+  colscal[4 * j + 0] = 1.f / sc;
+  colscal[4 * j + 1] = grad_g / Vn;
+  colscal[4 * j + 2] = sc;
+  colscal[4 * j + 3] = gparam - lr_t * mgn / (sqrtf(vgn) + h.eps);
+}
+
+__global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, float* params, const float* grads,
+                                                        float* m, float* v, const float* colscal,
+                                                        const int32_t* colidx0, float* partC, AdamHyper h) {
+  const AdamUnit un = units[blockIdx.x];
+  const float lr_t = adam_lr_t(h);
+  if (!un.is_matrix || !h.weightnorm) {   // plain Adam (biases; everything when weightnorm is off)
+    const int n = un.nrows * un.cols;
+    const size_t base = un.offset + (size_t)un.row0 * un.cols;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float g = grads[base + i];
+      const float mn = h.b1 * m[base + i] + (1.f - h.b1) * g;
+      const float vn = h.b2 * v[base + i] + (1.f - h.b2) * g * g;
+      m[base + i] = mn; v[base + i] = vn;
+      params[base + i] -= lr_t * mn / (sqrtf(vn) + h.eps);
+    }
+    return;
+  }
+  __shared__ float rc[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int cbase = colidx0[blockIdx.x];     // index of this tensor's column 0 in colscal
+  for (int c0 = 0; c0 < un.cols; c0 += 64) {
+    const int col = c0 + cx;
+    float acc = 0.f;
+    if (col < un.cols) {
+      const float inv_s = colscal[4 * (cbase + col) + 0], gov = colscal[4 * (cbase + col) + 1];
+      const float sc = colscal[4 * (cbase + col) + 2];
+      for (int r = ry; r < un.nrows; r += 4) {
+        const size_t o = un.offset + (size_t)(un.row0 + r) * un.cols + col;
+        const float V = params[o] * inv_s;
+        const float gV = sc * (grads[o] - gov * V);
+        const float mn = h.b1 * m[o] + (1.f - h.b1) * gV;
+        const float vn = h.b2 * v[o] + (1.f - h.b2) * gV * gV;
+        m[o] = mn; v[o] = vn;
+        const float Vp = V - lr_t * mn / (sqrtf(vn) + h.eps);
+        params[o] = Vp;
+        acc += Vp * Vp;
+      }
+    }
+    rc[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && col < un.cols) partC[un.part_off + col] = rc[0][cx] + rc[1][cx] + rc[2][cx] + rc[3][cx];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_rescale_kernel(const AdamUnit* units, const AdamCol* cols, float* params,
+                                                         float* s, const float* colscal, const int32_t* colidx0,
+                                                         const float* partC, int weightnorm, int32_t* iterations) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && iterations) *iterations += 1;
+  const AdamUnit un = units[blockIdx.x];
+  if (!un.is_matrix || !weightnorm) return;
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int cbase = colidx0[blockIdx.x];
+  for (int c0 = 0; c0 < un.cols; c0 += 64) {
+    const int col = c0 + cx;
+    if (col >= un.cols) continue;
+    const AdamCol c = cols[cbase + col];
+    float a = 0.f;
+    for (int k = 0; k < c.nunits; ++k) a += partC[c.part_base + k * c.cols + c.col_local];
+    const float snew = colscal[4 * (cbase + col) + 3] / sqrtf(a);
+    for (int r = ry; r < un.nrows; r += 4) {
+      const size_t o = un.offset + (size_t)(un.row0 + r) * un.cols + col;
+      params[o] *= snew;
+    }
+    if (un.row0 == 0 && ry == 0) s[un.col_offset + col] = snew;
+  }
+}
+
+struct PlanCounts { int n_units, n_cols, n_part; };
+
+static PlanCounts plan_counts(const clv_param_desc* t, int n) {
+  PlanCounts c{0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const int units = (t[i].rows + UNIT_ROWS - 1) / UNIT_ROWS;
+    c.n_units += units;
+    if (t[i].is_matrix) { c.n_cols += t[i].cols; c.n_part += units * t[i].cols; }
+  }
+  return c;
+}
+
+}  // namespace clv
+
+using namespace clv;
+
+// device blob: AdamUnit[n_units] | AdamCol[n_cols] | int32 colidx0[n_units]
+extern "C" size_t clv_adam_wn_plan_bytes(const clv_param_desc* host_table, int n_tensors) {
+  if (!host_table || n_tensors <= 0) return 0;
+  PlanCounts c = plan_counts(host_table, n_tensors);
+  return align_up(sizeof(AdamUnit) * c.n_units, 16) + align_up(sizeof(AdamCol) * (c.n_cols > 0 ? c.n_cols : 1), 16) +
+         align_up(sizeof(int32_t) * c.n_units, 16);
+}
+
+extern "C" int clv_adam_wn_plan_build(const clv_param_desc* host_table, int n_tensors, void* host_blob) {
+  if (!host_table || n_tensors <= 0 || !host_blob) return CLV_EINVAL;
+  PlanCounts c = plan_counts(host_table, n_tensors);
+  char* p = (char*)host_blob;
+  AdamUnit* units = (AdamUnit*)p;
+  p += align_up(sizeof(AdamUnit) * c.n_units, 16);
+  AdamCol* cols = (AdamCol*)p;
+  p += align_up(sizeof(AdamCol) * (c.n_cols > 0 ? c.n_cols : 1), 16);
+  int32_t* colidx0 = (int32_t*)p;
+  int ui = 0, ci = 0, part = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    const clv_param_desc& t = host_table[i];
+    if (t.rows <= 0 || t.cols <= 0) return CLV_EINVAL;
+    const int nun = (t.rows + UNIT_ROWS - 1) / UNIT_ROWS;
+    const int part_base = part;
+    for (int k = 0; k < nun; ++k) {
+      AdamUnit& u = units[ui];
+      u.offset = t.offset; u.col_offset = t.col_offset;
+      u.row0 = k * UNIT_ROWS;
+      u.nrows = (t.rows - u.row0) < UNIT_ROWS ? (t.rows - u.row0) : UNIT_ROWS;
+      u.cols = t.cols; u.is_matrix = t.is_matrix;
+      u.part_off = t.is_matrix ? part : 0;
+      u.pad_ = 0;
+      colidx0[ui] = t.is_matrix ? ci : 0;
+      if (t.is_matrix) part += t.cols;
+      ++ui;
+    }
+    if (t.is_matrix) {
+      for (int cidx = 0; cidx < t.cols; ++cidx) {
+        AdamCol& c2 = cols[ci + cidx];
+        c2.col_global = t.col_offset + cidx;
+        c2.part_base = part_base; c2.nunits = nun; c2.cols = t.cols; c2.col_local = cidx;
+      }
+      ci += t.cols;
+    }
+  }
+  return CLV_OK;
+}
+
+extern "C" size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tensors) {
+  if (!host_table || n_tensors <= 0) return 0;
+  PlanCounts c = plan_counts(host_table, n_tensors);
+  return (size_t)(3 * c.n_part + 4 * c.n_cols + 16) * sizeof(float);
+}
+
+extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
+                                float* params, const float* grads, float* m, float* v,
+                                float* mg, float* vg, float* s,
+                                int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
+                                int weightnorm, void* ws, size_t ws_bytes, void* stream) {
+  if (!host_table || n_tensors <= 0 || !plan_dev || !params || !grads || !m || !v) return CLV_EINVAL;
+  if (weightnorm && (!mg || !vg || !s)) return CLV_EINVAL;
+  PlanCounts c = plan_counts(host_table, n_tensors);
+  if (!ws || ws_bytes < clv_adam_wn_workspace_bytes(host_table, n_tensors)) return CLV_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const char* p = (const char*)plan_dev;
+  const AdamUnit* units = (const AdamUnit*)p;
+  p += align_up(sizeof(AdamUnit) * c.n_units, 16);
+  const AdamCol* cols = (const AdamCol*)p;
+  p += align_up(sizeof(AdamCol) * (c.n_cols > 0 ? c.n_cols : 1), 16);
+  const int32_t* colidx0 = (const int32_t*)p;
+  float* partA = (float*)ws;
+  float* partB = partA + c.n_part;
+  float* partC = partB + c.n_part;
+  float* colscal = partC + c.n_part;
+  AdamHyper h{lr, beta1, beta2, eps, weightnorm, step_t, iterations_dev};
+  ProfScope pr("adam_wn_step", st);
+  if (weightnorm && c.n_cols > 0) {
+    hipLaunchKernelGGL(wn_stats_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, s, partA, partB);
+    hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + 127) / 128), dim3(128), 0, st, c.n_cols, cols, partA, partB, s,
+                       mg, vg, colscal, h);
+  }
+  hipLaunchKernelGGL(wn_update_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, m, v, colscal, colidx0,
+                     partC, h);
+  hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, cols, params, s, colscal, colidx0,
+                     partC, weightnorm, iterations_dev);
+  return launch_status();
+}

@@ -1,0 +1,281 @@
+// pointwise.hip -- reparameterisation, the four loss terms and their gradients,
+// deterministic reductions.  All HBM-bound row kernels: one thread per row for the
+// tiny label/latent heads (C <= 32, L <= 64), one wave per row for the 88-note
+// Bernoulli NLL (wave64 reduction), partial-slab column sums for bias gradients.
+#include "common.h"
+
+namespace clv {
+
+constexpr float EPS_K = 1e-7f;                 // keras.backend._EPSILON
+constexpr float W2_SHIFT = 1e-10f;             // cl_vae/model.py:208
+constexpr float LOGIT_CLIP = 16.11809555f;     // log((1-1e-7)/1e-7)
+constexpr int MAXC = 32;
+
+// ------------------------------------------------------------------ label --
+__global__ void label_fwd_kernel(int B, int C, const float* mean, const float* logvar, int ld_in,
+                                 const float* eps, const float* onehot, float prior,
+                                 float* w, float* rowloss) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int C1 = C - 1;
+  float e[MAXC];
+  float S = 1.f;   // exp(0) of the appended zero
+  float klw = 0.f;
+  const float ep = __expf(prior);
+  for (int j = 0; j < C1; ++j) {
+    const float m = mean[(size_t)b * ld_in + j], lv = logvar[(size_t)b * ld_in + j];
+    const float sd = expf(0.5f * lv);
+    e[j] = expf(m + sd * eps[(size_t)b * C1 + j]);
+    S += e[j];
+    klw += 1.f - prior + lv - sd * sd / ep - m * m / ep;
+  }
+  e[C1] = 1.f;
+  const float invS = 1.f / S;
+  float wv[MAXC];
+  float qs = 0.f;
+  int amax = 0, tmax = 0;
+  float wbest = -1.f, tbest = -1.f;
+  for (int j = 0; j < C; ++j) {
+    wv[j] = e[j] * invS;
+    w[(size_t)b * C + j] = wv[j];
+    qs += wv[j] + W2_SHIFT;
+    if (wv[j] > wbest) { wbest = wv[j]; amax = j; }
+    const float tj = onehot ? onehot[(size_t)b * C + j] : 0.f;
+    if (tj > tbest) { tbest = tj; tmax = j; }
+  }
+  if (rowloss) {
+    float wrec = 0.f;
+    if (onehot) {
+      for (int j = 0; j < C; ++j) {
+        const float n = (wv[j] + W2_SHIFT) / qs;
+        const float nc = fminf(fmaxf(n, EPS_K), 1.f - EPS_K);
+        wrec -= onehot[(size_t)b * C + j] * logf(nc);
+      }
+    }
+    rowloss[(size_t)b * 3 + 0] = -0.5f * klw;
+    rowloss[(size_t)b * 3 + 1] = (float)C1 * wrec;
+    rowloss[(size_t)b * 3 + 2] = (onehot && amax == tmax) ? 1.f : 0.f;
+  }
+}
+
+__global__ void label_bwd_kernel(int B, int C, const float* mean, const float* logvar, int ld_in,
+                                 const float* eps, const float* onehot, const float* w, const float* dw,
+                                 float prior, float class_weight, float w_kl_weight, float inv_b,
+                                 float* dmean, float* dlogvar, int ld_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int C1 = C - 1;
+  const float ep = __expf(prior);
+  // d(w_rec)/dw through renormalise + clip
+  float wv[MAXC], d[MAXC];
+  float qs = 0.f;
+  for (int j = 0; j < C; ++j) { wv[j] = w[(size_t)b * C + j]; qs += wv[j] + W2_SHIFT; }
+  float dn[MAXC];
+  float dot = 0.f;
+  for (int j = 0; j < C; ++j) {
+    const float n = (wv[j] + W2_SHIFT) / qs;
+    const bool inside = (n >= EPS_K) && (n <= 1.f - EPS_K);
+    const float nc = fminf(fmaxf(n, EPS_K), 1.f - EPS_K);
+    dn[j] = inside ? -(float)C1 * onehot[(size_t)b * C + j] / nc : 0.f;
+    dot += dn[j] * n;
+  }
+  float dsum = 0.f;
+  for (int j = 0; j < C; ++j) {
+    const float drec = (dn[j] - dot) / qs;
+    d[j] = dw[(size_t)b * C + j] + class_weight * inv_b * drec;
+    dsum += d[j] * wv[j];
+  }
+  for (int j = 0; j < C1; ++j) {
+    const float ds = wv[j] * (d[j] - dsum);          // softmax backward, appended zero dropped
+    const float m = mean[(size_t)b * ld_in + j], lv = logvar[(size_t)b * ld_in + j];
+    const float sd = expf(0.5f * lv);
+    dmean[(size_t)b * ld_out + j] = ds + w_kl_weight * inv_b * (m / ep);
+    dlogvar[(size_t)b * ld_out + j] = ds * eps[(size_t)b * C1 + j] * 0.5f * sd
+                                      + w_kl_weight * inv_b * (-0.5f * (1.f - sd * sd / ep));
+  }
+}
+
+// ------------------------------------------------------------------ gauss --
+__global__ void gauss_fwd_kernel(int R, int L, const float* zargs, const float* eps, float* z, int ldz,
+                                 float* rowkl) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float kl = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const float m = zargs[(size_t)r * 2 * L + j], lv = zargs[(size_t)r * 2 * L + L + j];
+    const float sd = expf(0.5f * lv);
+    z[(size_t)r * ldz + j] = m + sd * eps[(size_t)r * L + j];
+    kl += 1.f + lv - m * m - sd * sd;
+  }
+  if (rowkl) rowkl[r] = -0.5f * kl;
+}
+
+__global__ void gauss_bwd_kernel(int R, int L, const float* zargs, const float* eps, const float* dz, int lddz,
+                                 float kl_scale, float* dzargs) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  for (int j = 0; j < L; ++j) {
+    const float m = zargs[(size_t)r * 2 * L + j], lv = zargs[(size_t)r * 2 * L + L + j];
+    const float sd = expf(0.5f * lv);
+    const float d = dz[(size_t)r * lddz + j];
+    dzargs[(size_t)r * 2 * L + j] = d + kl_scale * m;
+    dzargs[(size_t)r * 2 * L + L + j] = d * eps[(size_t)r * L + j] * 0.5f * sd - 0.5f * kl_scale * (1.f - sd * sd);
+  }
+}
+
+// ------------------------------------------------------- Bernoulli NLL (BCE) --
+// one wave per row, 4 rows per 256-thread block
+__global__ __launch_bounds__(256) void bernoulli_nll_kernel(int R, int D, const float* logits, const float* y, int ldy,
+                                                            float scale, float* rownll, float* dlogits) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float acc = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float a = logits[(size_t)row * D + j];
+    const float t = y[(size_t)row * ldy + j];
+    const float l = fminf(fmaxf(a, -LOGIT_CLIP), LOGIT_CLIP);
+    const float sp = fmaxf(l, 0.f) + log1pf(__expf(-fabsf(l)));
+    acc += sp - l * t;
+    if (dlogits) {
+      const bool inside = (a >= -LOGIT_CLIP) && (a <= LOGIT_CLIP);
+      const float sg = 1.f / (1.f + expf(-l));
+      dlogits[(size_t)row * D + j] = inside ? scale * (sg - t) : 0.f;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && rownll) rownll[row] = acc;
+}
+
+// ------------------------------------------------------------- reductions --
+// single block, fixed order => deterministic
+__global__ __launch_bounds__(1024) void sum_strided_kernel(int n, const float* x, int stride, float scale, float* out) {
+  __shared__ float part[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += x[(size_t)i * stride];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += part[i];
+    out[0] = t * scale;
+  }
+}
+
+// column sums, stage 1: block (64 cols x 4 row-lanes) handles a chunk of rows
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const float* X, int ldx, float* partial) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float acc = 0.f;
+  if (col < N)
+    for (int r = r0 + ry; r < r1; r += 4) acc += X[(size_t)r * ldx + col];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < N) partial[(size_t)blockIdx.y * N + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+__global__ void colsum_final_kernel(int N, int chunks, const float* partial, float beta, float* out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float acc = 0.f;
+  for (int c = 0; c < chunks; ++c) acc += partial[(size_t)c * N + col];
+  out[col] = (beta != 0.f ? beta * out[col] : 0.f) + acc;
+}
+
+__global__ void bernoulli_sample_kernel(int64_t n, const float* p, const float* u, float* x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (u[i] <= p[i]) ? 1.f : 0.f;
+}
+
+}  // namespace clv
+
+using namespace clv;
+
+extern "C" int clv_label_fwd(int B, int C, const float* mean, const float* logvar, int ld_in,
+                             const float* eps, const float* onehot, float prior_logvar,
+                             float* w, float* rowloss, void* stream) {
+  if (B <= 0 || C < 2 || C > MAXC || !mean || !logvar || !eps || !w) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("label_fwd", s);
+  hipLaunchKernelGGL(label_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, C, mean, logvar, ld_in, eps, onehot,
+                     prior_logvar, w, rowloss);
+  return launch_status();
+}
+
+extern "C" int clv_label_bwd(int B, int C, const float* mean, const float* logvar, int ld_in,
+                             const float* eps, const float* onehot, const float* w, const float* dw,
+                             float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
+                             float* dmean, float* dlogvar, int ld_out, void* stream) {
+  if (B <= 0 || C < 2 || C > MAXC || !mean || !logvar || !eps || !onehot || !w || !dw || !dmean || !dlogvar)
+    return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("label_bwd", s);
+  hipLaunchKernelGGL(label_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, C, mean, logvar, ld_in, eps, onehot, w,
+                     dw, prior_logvar, class_weight, w_kl_weight, inv_b, dmean, dlogvar, ld_out);
+  return launch_status();
+}
+
+extern "C" int clv_gauss_fwd(int R, int L, const float* zargs, const float* eps, float* z, int ldz,
+                             float* rowkl, void* stream) {
+  if (R <= 0 || L <= 0 || !zargs || !eps || !z) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("gauss_fwd", s);
+  hipLaunchKernelGGL(gauss_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, L, zargs, eps, z, ldz, rowkl);
+  return launch_status();
+}
+
+extern "C" int clv_gauss_bwd(int R, int L, const float* zargs, const float* eps, const float* dz, int lddz,
+                             float kl_scale, float* dzargs, void* stream) {
+  if (R <= 0 || L <= 0 || !zargs || !eps || !dz || !dzargs) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("gauss_bwd", s);
+  hipLaunchKernelGGL(gauss_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, L, zargs, eps, dz, lddz, kl_scale,
+                     dzargs);
+  return launch_status();
+}
+
+extern "C" int clv_bernoulli_nll(int R, int D, const float* logits, const float* y, int ldy, float scale,
+                                 float* rownll, float* dlogits, void* stream) {
+  if (R <= 0 || D <= 0 || !logits || !y) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("bernoulli_nll", s);
+  hipLaunchKernelGGL(bernoulli_nll_kernel, dim3((R + 3) / 4), dim3(256), 0, s, R, D, logits, y, ldy, scale, rownll,
+                     dlogits);
+  return launch_status();
+}
+
+extern "C" int clv_sum_strided(int n, const float* x, int stride, float scale, float* out, void* stream) {
+  if (n <= 0 || !x || !out) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("sum_strided", s);
+  hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, n, x, stride, scale, out);
+  return launch_status();
+}
+
+extern "C" size_t clv_colsum_workspace_bytes(int M, int N) {
+  const int chunks = (M + CS_ROWS - 1) / CS_ROWS;
+  return (size_t)chunks * N * sizeof(float);
+}
+
+extern "C" int clv_colsum_f32(int M, int N, const float* X, int ldx, float beta, float* out,
+                              void* ws, size_t ws_bytes, void* stream) {
+  if (M <= 0 || N <= 0 || !X || !out) return CLV_EINVAL;
+  const int chunks = (M + CS_ROWS - 1) / CS_ROWS;
+  if (!ws || ws_bytes < (size_t)chunks * N * sizeof(float)) return CLV_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("colsum", s);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, s, M, N, X, ldx, (float*)ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(64), 0, s, N, chunks, (const float*)ws, beta, out);
+  return launch_status();
+}
+
+extern "C" int clv_bernoulli_sample(int64_t n, const float* p, const float* u, float* x, void* stream) {
+  if (n <= 0 || !p || !u || !x) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope pr("bernoulli_sample", s);
+  hipLaunchKernelGGL(bernoulli_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, p, u, x);
+  return launch_status();
+}

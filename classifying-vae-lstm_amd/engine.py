@@ -1,0 +1,443 @@
+"""Device engines: one training / inference step of cl_vae and cl_vrnn as a chain of
+HIP kernels over flat, HBM-resident parameter / gradient buffers.
+
+The math follows cl_vae/model.py:130-219 and cl_vrnn/model.py:164-264 of the
+reference; torch only provides device memory and the
+stream.  Every buffer is allocated once in __init__, so a step enqueues kernels
+only and can be captured into a hipGraph (ops.Graph).
+
+Parameter layout: tensors in the order of ``param_shapes`` (the Keras
+layer/weight order), each starting on a 16-byte boundary of one flat fp32
+buffer; gradients, Adam m/v use the same layout; the weight-norm column state
+(s, m_g, v_g) is a second flat layout over the last axis of every matrix.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .ops import ACT_MASKPOS, ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+
+def vae_param_shapes(cfg):
+    """Keras layer order of cl_vae.get_model (cl_vae/model.py:141-186)."""
+    D, H, L, Hc, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
+    if H <= 0:
+        raise ValueError("intermediate_dim must be > 0")
+    dec_in = Cn + (D if cfg['use_x_prev'] else 0) + L
+    return [('h_w/kernel', (D, Hc)), ('h_w/bias', (Hc,)),
+            ('w_mean/kernel', (Hc, Cn - 1)), ('w_mean/bias', (Cn - 1,)),
+            ('w_log_var/kernel', (Hc, Cn - 1)), ('w_log_var/bias', (Cn - 1,)),
+            ('h/kernel', (D + Cn, H)), ('h/bias', (H,)),
+            ('z_mean/kernel', (H, L)), ('z_mean/bias', (L,)),
+            ('z_log_var/kernel', (H, L)), ('z_log_var/bias', (L,)),
+            ('decoder_h/kernel', (dec_in, H)), ('decoder_h/bias', (H,)),
+            ('x_decoded_mean/kernel', (H, D)), ('x_decoded_mean/bias', (D,))]
+
+
+def vrnn_param_shapes(cfg):
+    """Keras layer order of cl_vrnn.get_model (cl_vrnn/model.py:174-234)."""
+    D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
+    dec_in = (D if cfg['use_x_prev'] else 0) + L + Cn
+    return [('hW/kernel', (T * D, D)), ('hW/bias', (D,)),
+            ('Wargs/kernel', (D, 2 * (Cn - 1))), ('Wargs/bias', (2 * (Cn - 1),)),
+            ('encoder_h/kernel', (D + Cn, 4 * H)), ('encoder_h/recurrent_kernel', (H, 4 * H)),
+            ('encoder_h/bias', (4 * H,)),
+            ('Z_mean/kernel', (H, L)), ('Z_mean/bias', (L,)),
+            ('Z_log_var/kernel', (H, L)), ('Z_log_var/bias', (L,)),
+            ('decoder_h/kernel', (dec_in, 4 * H)), ('decoder_h/recurrent_kernel', (H, 4 * H)),
+            ('decoder_h/bias', (4 * H,)),
+            ('X_decoded_mean/kernel', (H, D)), ('X_decoded_mean/bias', (D,))]
+
+
+class FlatParams:
+    """Flat fp32 parameter / gradient / optimizer-state buffers plus the Adam-WN plan."""
+
+    def __init__(self, shapes, device):
+        self.shapes = list(shapes)
+        self.device = device
+        self.offsets, self.col_offsets = {}, {}
+        off = col = 0
+        table = (_lib.ParamDesc * len(self.shapes))()
+        for i, (name, shp) in enumerate(self.shapes):
+            n = int(np.prod(shp))
+            self.offsets[name] = off
+            is_mat = len(shp) > 1
+            rows = int(np.prod(shp[:-1])) if is_mat else 1
+            table[i] = _lib.ParamDesc(off, rows, int(shp[-1]), col if is_mat else 0, int(is_mat), 0)
+            if is_mat:
+                self.col_offsets[name] = col
+                col += (int(shp[-1]) + 3) // 4 * 4
+            off += (n + 3) // 4 * 4
+        self.n, self.n_cols, self.table = off, max(col, 4), table
+        f = dict(dtype=torch.float32, device=device)
+        self.params = torch.zeros(self.n, **f)
+        self.grads = torch.zeros(self.n, **f)
+        self.m = torch.zeros(self.n, **f)
+        self.v = torch.zeros(self.n, **f)
+        self.mg = torch.zeros(self.n_cols, **f)
+        self.vg = torch.zeros(self.n_cols, **f)
+        self.s = torch.ones(self.n_cols, **f)
+        self.iterations = torch.zeros(1, dtype=torch.int32, device=device)
+        L = _lib.lib()
+        nb = L.clv_adam_wn_plan_bytes(table, len(self.shapes))
+        blob = (C.c_uint8 * nb)()
+        _lib.check(L.clv_adam_wn_plan_build(table, len(self.shapes), blob), "adam plan")
+        self.plan = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(device)
+        self.adam_ws = torch.empty(L.clv_adam_wn_workspace_bytes(table, len(self.shapes)), dtype=torch.uint8,
+                                   device=device)
+
+    # views ---------------------------------------------------------------
+    def view(self, buf, name):
+        shp = dict(self.shapes)[name]
+        o = self.offsets[name]
+        return buf[o:o + int(np.prod(shp))].view(*shp)
+
+    def p(self, name):
+        return self.view(self.params, name)
+
+    def g(self, name):
+        return self.view(self.grads, name)
+
+    def rows(self, buf, name, r0):
+        """1-D view of tensor `name` starting at row r0 (for sub-blocks of a kernel)."""
+        shp = dict(self.shapes)[name]
+        o = self.offsets[name] + r0 * int(shp[-1])
+        return buf[o:]
+
+    # host <-> device -------------------------------------------------------
+    def set_weights(self, weights):
+        for name, _ in self.shapes:
+            self.p(name).copy_(torch.as_tensor(np.asarray(weights[name], dtype=np.float32)))
+
+    def get_weights(self, buf=None):
+        buf = self.params if buf is None else buf
+        return {name: self.view(buf, name).detach().cpu().numpy().copy() for name, _ in self.shapes}
+
+    def reset_optimizer(self):
+        for t in (self.m, self.v, self.mg, self.vg):
+            t.zero_()
+        self.s.fill_(1.0)
+        self.iterations.zero_()
+
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True):
+        """utils/weightnorm.py:75-143; t comes from the device `iterations` counter."""
+        _lib.check(_lib.lib().clv_adam_wn_step(
+            self.table, len(self.shapes), ops._ptr(self.plan), ops._ptr(self.params), ops._ptr(self.grads),
+            ops._ptr(self.m), ops._ptr(self.v), ops._ptr(self.mg), ops._ptr(self.vg), ops._ptr(self.s),
+            ops._ptr(self.iterations), 0, lr, b1, b2, eps, int(weightnorm), ops._ptr(self.adam_ws),
+            self.adam_ws.numel(), ops._stream()), "clv_adam_wn_step")
+
+
+def _f(device, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+class _EngineBase:
+    def __init__(self, cfg, batch_size, shapes, device):
+        _lib.require_gpu()
+        self.cfg = dict(cfg)
+        self.B = int(batch_size)
+        self.device = torch.device(device)
+        self.P = FlatParams(shapes, self.device)
+        self.ws = ops.Workspace(self.device, 8 << 20)
+        self.scal = torch.zeros(8, dtype=torch.float32, device=self.device)   # vae, kl_z, kl_w, w_rec, acc
+        # loss weights may be annealed per epoch (utils/model_utils.py:19-50)
+        self.kl_weight = float(cfg.get('kl_weight', 1.0))
+        self.w_kl_weight = float(cfg.get('w_kl_weight', 1.0))
+        self.class_weight = float(cfg.get('class_weight', 1.0))
+
+    def losses(self):
+        """Host copy of the last step's loss terms (one small D2H)."""
+        s = self.scal.detach().cpu().numpy().astype(np.float64)
+        out = dict(vae=s[0], kl_z=s[1], kl_w=s[2], w_rec=s[3], acc=s[4])
+        out['total'] = (out['vae'] + self.w_kl_weight * out['kl_w'] + self.class_weight * out['w_rec']
+                        + self.kl_weight * out['kl_z'])
+        out['elbo'] = -(out['vae'] + out['kl_z'] + out['kl_w'] + out['w_rec'])
+        return out
+
+    def _mean_into(self, n, x, stride, slot):
+        ops.sum_strided(n, x, stride, 1.0 / n, self.scal[slot:])
+
+
+# --------------------------------------------------------------------------- #
+class VaeEngine(_EngineBase):
+    """cl_vae: Dense encoder/decoder VAE with a logistic-normal label (cl_vae/model.py:130-224).
+
+    Concatenations ([x,w], [w,xp,z]) are never materialised: a Dense over a concatenation is
+    the sum of GEMMs over row blocks of its kernel (beta = 1 accumulation)."""
+
+    def __init__(self, cfg, batch_size, device='cuda:0'):
+        super().__init__(cfg, batch_size, vae_param_shapes(cfg), device)
+        B, D, H, L, Hc, Cn = self.B, cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
+        d = self.device
+        self.xoff = D if cfg['use_x_prev'] else 0      # decoder_h kernel rows: [w | xp | z]
+        self.h_w = _f(d, B, Hc)
+        self.wargs = _f(d, B, 2 * (Cn - 1))          # [w_mean | w_log_var]
+        self.w = _f(d, B, Cn)
+        self.rowloss = _f(d, B, 3)
+        self.h = _f(d, B, H)
+        self.zargs = _f(d, B, 2 * L)
+        self.z = _f(d, B, L)
+        self.h_dec = _f(d, B, H)
+        self.logits = _f(d, B, D)
+        self.dlogits = _f(d, B, D)
+        self.rownll = _f(d, B)
+        self.rowkl = _f(d, B)
+        self.d_hdec = _f(d, B, H)
+        self.dz = _f(d, B, L)
+        self.dzargs = _f(d, B, 2 * L)
+        self.d_h = _f(d, B, H)
+        self.dw = _f(d, B, Cn)
+        self.dwargs = _f(d, B, 2 * (Cn - 1))
+        self.d_hw = _f(d, B, Hc)
+
+    # -- forward pieces (also used by the predict() sub-models) ----------------
+    def encode_w(self, x, B=None):
+        """h_w, w_mean, w_log_var (:141-143) -> self.wargs"""
+        cfg, P = self.cfg, self.P
+        B = self.B if B is None else B
+        D, Hc, C1 = cfg['D'], cfg['Hc'], cfg['C'] - 1
+        g = ops.gemm
+        g(x, P.p('h_w/kernel'), self.h_w, B, Hc, D, bias=P.p('h_w/bias'), act=ACT_RELU, ws=self.ws)
+        g(self.h_w, P.p('w_mean/kernel'), self.wargs, B, C1, Hc, ldc=2 * C1, bias=P.p('w_mean/bias'), ws=self.ws)
+        g(self.h_w, P.p('w_log_var/kernel'), self.wargs[:, C1:], B, C1, Hc, ldc=2 * C1, bias=P.p('w_log_var/bias'),
+          ws=self.ws)
+
+    def encode_z(self, x, w, B=None):
+        """h = relu([x,w].K + b); z_mean, z_log_var (:160-164) -> self.zargs"""
+        cfg, P = self.cfg, self.P
+        B = self.B if B is None else B
+        D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
+        g = ops.gemm
+        g(x, P.p('h/kernel'), self.h, B, H, D, ws=self.ws)
+        g(w, P.rows(P.params, 'h/kernel', D), self.h, B, H, Cn, beta=1.0, bias=P.p('h/bias'), act=ACT_RELU,
+          ws=self.ws)
+        g(self.h, P.p('z_mean/kernel'), self.zargs, B, L, H, ldc=2 * L, bias=P.p('z_mean/bias'), ws=self.ws)
+        g(self.h, P.p('z_log_var/kernel'), self.zargs[:, L:], B, L, H, ldc=2 * L, bias=P.p('z_log_var/bias'),
+          ws=self.ws)
+
+    def decode(self, w, z, xp, B=None, act=ACT_NONE):
+        """logits (or x_hat with act=sigmoid) = Dense(relu([w,xp,z].K + b)) (:177-188) -> self.logits"""
+        cfg, P = self.cfg, self.P
+        B = self.B if B is None else B
+        D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
+        g = ops.gemm
+        g(w, P.p('decoder_h/kernel'), self.h_dec, B, H, Cn, ws=self.ws)
+        if cfg['use_x_prev']:
+            g(xp, P.rows(P.params, 'decoder_h/kernel', Cn), self.h_dec, B, H, D, beta=1.0, ws=self.ws)
+        g(z, P.rows(P.params, 'decoder_h/kernel', Cn + self.xoff), self.h_dec, B, H, L, beta=1.0,
+          bias=P.p('decoder_h/bias'), act=ACT_RELU, ws=self.ws)
+        g(self.h_dec, P.p('x_decoded_mean/kernel'), self.logits, B, D, H, bias=P.p('x_decoded_mean/bias'), act=act,
+          ws=self.ws)
+
+    def forward(self, x, xp, eps_w, eps_z, w_true=None):
+        cfg, B = self.cfg, self.B
+        L, Cn = cfg['L'], cfg['C']
+        C1 = Cn - 1
+        self.encode_w(x)
+        ops.label_fwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_w, w_true, cfg['w_log_var_prior'],
+                      self.w, self.rowloss)
+        self.encode_z(x, self.w)
+        ops.gauss_fwd(B, L, self.zargs, eps_z, self.z, L, self.rowkl)
+        self.decode(self.w, self.z, xp)
+
+    def loss_and_grads(self, x, xp, w_true, eps_w, eps_z, need_grads=True):
+        """One forward + 4 losses (+ gradients of the weighted total into P.grads)."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, Hc, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
+        C1 = Cn - 1
+        inv = 1.0 / B
+        self.forward(x, xp, eps_w, eps_z, w_true)
+        ops.bernoulli_nll(B, D, self.logits, x, D, inv, self.rownll, self.dlogits if need_grads else None)
+        self._mean_into(B, self.rownll, 1, 0)
+        self._mean_into(B, self.rowkl, 1, 1)
+        self._mean_into(B, self.rowloss, 3, 2)
+        self._mean_into(B, self.rowloss[:, 1:], 3, 3)
+        self._mean_into(B, self.rowloss[:, 2:], 3, 4)
+        if not need_grads:
+            return
+        g, ws, xo = ops.gemm, self.ws, self.xoff
+        # decoder
+        g(self.h_dec, self.dlogits, P.g('x_decoded_mean/kernel'), H, D, B, ta=True, ws=ws)
+        ops.colsum(self.dlogits, B, D, P.g('x_decoded_mean/bias'), ws)
+        g(self.dlogits, P.p('x_decoded_mean/kernel'), self.d_hdec, B, H, D, tb=True, act=ACT_MASKPOS, aux=self.h_dec,
+          ws=ws)
+        g(self.w, self.d_hdec, P.g('decoder_h/kernel'), Cn, H, B, ta=True, ws=ws)
+        if cfg['use_x_prev']:
+            g(xp, self.d_hdec, P.rows(P.grads, 'decoder_h/kernel', Cn), D, H, B, ta=True, ws=ws)
+        g(self.z, self.d_hdec, P.rows(P.grads, 'decoder_h/kernel', Cn + xo), L, H, B, ta=True, ws=ws)
+        ops.colsum(self.d_hdec, B, H, P.g('decoder_h/bias'), ws)
+        g(self.d_hdec, P.p('decoder_h/kernel'), self.dw, B, Cn, H, tb=True, ws=ws)
+        g(self.d_hdec, P.rows(P.params, 'decoder_h/kernel', Cn + xo), self.dz, B, L, H, tb=True, ws=ws)
+        # latent heads
+        ops.gauss_bwd(B, L, self.zargs, eps_z, self.dz, L, self.kl_weight * inv, self.dzargs)
+        g(self.h, self.dzargs, P.g('z_mean/kernel'), H, L, B, ta=True, ldb=2 * L, ws=ws)
+        g(self.h, self.dzargs[:, L:], P.g('z_log_var/kernel'), H, L, B, ta=True, ldb=2 * L, ws=ws)
+        ops.colsum(self.dzargs, B, L, P.g('z_mean/bias'), ws, ldx=2 * L)
+        ops.colsum(self.dzargs[:, L:], B, L, P.g('z_log_var/bias'), ws, ldx=2 * L)
+        g(self.dzargs, P.p('z_mean/kernel'), self.d_h, B, H, L, tb=True, lda=2 * L, ws=ws)
+        g(self.dzargs[:, L:], P.p('z_log_var/kernel'), self.d_h, B, H, L, tb=True, lda=2 * L, beta=1.0,
+          act=ACT_MASKPOS, aux=self.h, ws=ws)
+        g(x, self.d_h, P.g('h/kernel'), D, H, B, ta=True, ws=ws)
+        g(self.w, self.d_h, P.rows(P.grads, 'h/kernel', D), Cn, H, B, ta=True, ws=ws)
+        ops.colsum(self.d_h, B, H, P.g('h/bias'), ws)
+        g(self.d_h, P.rows(P.params, 'h/kernel', D), self.dw, B, Cn, H, tb=True, beta=1.0, ws=ws)
+        # label head
+        ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_w, w_true, self.w, self.dw,
+                      cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv,
+                      self.dwargs, self.dwargs[:, C1:], 2 * C1)
+        g(self.h_w, self.dwargs, P.g('w_mean/kernel'), Hc, C1, B, ta=True, ldb=2 * C1, ws=ws)
+        g(self.h_w, self.dwargs[:, C1:], P.g('w_log_var/kernel'), Hc, C1, B, ta=True, ldb=2 * C1, ws=ws)
+        ops.colsum(self.dwargs, B, C1, P.g('w_mean/bias'), ws, ldx=2 * C1)
+        ops.colsum(self.dwargs[:, C1:], B, C1, P.g('w_log_var/bias'), ws, ldx=2 * C1)
+        g(self.dwargs, P.p('w_mean/kernel'), self.d_hw, B, Hc, C1, tb=True, lda=2 * C1, ws=ws)
+        g(self.dwargs[:, C1:], P.p('w_log_var/kernel'), self.d_hw, B, Hc, C1, tb=True, lda=2 * C1, beta=1.0,
+          act=ACT_MASKPOS, aux=self.h_w, ws=ws)
+        g(x, self.d_hw, P.g('h_w/kernel'), D, Hc, B, ta=True, ws=ws)
+        ops.colsum(self.d_hw, B, Hc, P.g('h_w/bias'), ws)
+
+
+# --------------------------------------------------------------------------- #
+class VrnnEngine(_EngineBase):
+    """cl_vrnn: classifying VAE + two LSTMs (cl_vrnn/model.py:164-267)."""
+
+    def __init__(self, cfg, batch_size, device='cuda:0'):
+        super().__init__(cfg, batch_size, vrnn_param_shapes(cfg), device)
+        B, D, H, L, T, Cn = self.B, cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
+        if H != 88:
+            raise ValueError("the LSTM sequence kernels are built for intermediate_dim == 88")
+        d = self.device
+        BT = B * T
+        self.gate_act = _lib.GATE_HARD_SIGMOID if cfg.get('gate_act', 'hard_sigmoid') == 'hard_sigmoid' \
+            else _lib.GATE_SIGMOID
+        self.off = D if cfg['use_x_prev'] else 0     # decoder kernel rows: [Xp | Z | W]
+        self.hW = _f(d, B, D)
+        self.wargs = _f(d, B, 2 * (Cn - 1))
+        self.W = _f(d, B, Cn)
+        self.rowloss = _f(d, B, 3)
+        self.wk_enc = _f(d, B, 4 * H)
+        self.wk_dec = _f(d, B, 4 * H)
+        self.gates_enc = _f(d, BT, 4 * H)           # xproj in, (z_i,z_f,g,z_o) after fwd, dz after bwd
+        self.gates_dec = _f(d, BT, 4 * H)
+        self.hs_enc, self.cs_enc = _f(d, BT, H), _f(d, BT, H)
+        self.hs_dec, self.cs_dec = _f(d, BT, H), _f(d, BT, H)
+        self.zargs = _f(d, BT, 2 * L)
+        self.Z = _f(d, BT, L)
+        self.rowkl = _f(d, BT)
+        self.logits = _f(d, BT, D)
+        self.dlogits = _f(d, BT, D)
+        self.rownll = _f(d, BT)
+        self.dhs = _f(d, BT, H)                     # dL/dh of the decoder, then of the encoder
+        self.dzsum_enc, self.dzsum_dec = _f(d, B, 4 * H), _f(d, B, 4 * H)
+        self.dZ = _f(d, BT, L)
+        self.dzargs = _f(d, BT, 2 * L)
+        self.dW = _f(d, B, Cn)
+        self.dwargs = _f(d, B, 2 * (Cn - 1))
+        self.dhW = _f(d, B, D)
+
+    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True):
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
+        C1, BT, G4 = Cn - 1, B * T, 4 * H
+        g, ws = ops.gemm, self.ws
+        # label path (:174-191)
+        g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
+        g(self.hW, P.p('Wargs/kernel'), self.wargs, B, 2 * C1, D, bias=P.p('Wargs/bias'), ws=ws)
+        ops.label_fwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, cfg['w_log_var_prior'],
+                      self.W, self.rowloss)
+        # encoder LSTM on [X, repeat(W)] (:193-199): per-row bias carries W.K_w + b
+        g(self.W, P.rows(P.params, 'encoder_h/kernel', D), self.wk_enc, B, G4, Cn, bias=P.p('encoder_h/bias'), ws=ws)
+        g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
+        ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
+                         self.cs_enc, self.gates_enc, gate_act=self.gate_act)
+        # latent heads + sample (:200-216)
+        g(self.hs_enc, P.p('Z_mean/kernel'), self.zargs, BT, L, H, ldc=2 * L, bias=P.p('Z_mean/bias'), ws=ws)
+        g(self.hs_enc, P.p('Z_log_var/kernel'), self.zargs[:, L:], BT, L, H, ldc=2 * L, bias=P.p('Z_log_var/bias'),
+          ws=ws)
+        ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, L, self.rowkl)
+        # decoder LSTM on [Xp, Z, repeat(W)] (:218-228)
+        off = self.off
+        g(self.W, P.rows(P.params, 'decoder_h/kernel', off + L), self.wk_dec, B, G4, Cn, bias=P.p('decoder_h/bias'),
+          ws=ws)
+        if cfg['use_x_prev']:
+            g(Xp, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, D, ws=ws)
+        g(self.Z, P.rows(P.params, 'decoder_h/kernel', off), self.gates_dec, BT, G4, L,
+          beta=1.0 if cfg['use_x_prev'] else 0.0, ws=ws)
+        ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
+                         self.cs_dec, self.gates_dec, gate_act=self.gate_act)
+        # output head (:229-234)
+        g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
+
+    def _lstm_wgrads(self, name, X_in, hs, dz, dzsum, in_rows):
+        """dkernel[0:in_rows], drecurrent, dbias of one LSTM from dz [B*T,4H]."""
+        cfg, P, B = self.cfg, self.P, self.B
+        H, T = cfg['H'], cfg['T']
+        BT, G4 = B * T, 4 * H
+        g, ws = ops.gemm, self.ws
+        if X_in is not None:
+            g(X_in, dz, P.g(name + '/kernel'), in_rows, G4, BT, ta=True, ws=ws)
+        # recurrent: sum_{b,t>=1} h[b,t-1]^T dz[b,t] = shifted product minus the rows that cross a batch boundary
+        dU = P.g(name + '/recurrent_kernel')
+        if BT > 1:
+            g(hs, dz.view(-1)[G4:], dU, H, G4, BT - 1, ta=True, ws=ws)
+            if B > 1:
+                g(hs.view(-1)[(T - 1) * H:], dz.view(-1)[T * G4:], dU, H, G4, B - 1, ta=True, lda=T * H, ldb=T * G4,
+                  alpha=-1.0, beta=1.0, split_k=1, ws=ws)
+        else:
+            dU.zero_()
+        ops.colsum(dzsum, B, G4, P.g(name + '/bias'), ws)
+
+    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True):
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
+        C1, BT, G4 = Cn - 1, B * T, 4 * H
+        inv_bt, inv_b = 1.0 / BT, 1.0 / B
+        g, ws, off = ops.gemm, self.ws, self.off
+        self.forward(X, Xp, eps_W, eps_Z, w_true)
+        ops.bernoulli_nll(BT, D, self.logits, X, D, inv_bt, self.rownll, self.dlogits if need_grads else None)
+        self._mean_into(BT, self.rownll, 1, 0)
+        self._mean_into(BT, self.rowkl, 1, 1)
+        self._mean_into(B, self.rowloss, 3, 2)
+        self._mean_into(B, self.rowloss[:, 1:], 3, 3)
+        self._mean_into(B, self.rowloss[:, 2:], 3, 4)
+        if not need_grads:
+            return
+        # output head
+        g(self.hs_dec, self.dlogits, P.g('X_decoded_mean/kernel'), H, D, BT, ta=True, ws=ws)
+        ops.colsum(self.dlogits, BT, D, P.g('X_decoded_mean/bias'), ws)
+        g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
+        # decoder BPTT
+        ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
+                         self.dzsum_dec, gate_act=self.gate_act)
+        dz = self.gates_dec
+        self._lstm_wgrads('decoder_h', Xp if cfg['use_x_prev'] else None, self.hs_dec, dz, self.dzsum_dec, D)
+        g(self.Z, dz, P.rows(P.grads, 'decoder_h/kernel', off), L, G4, BT, ta=True, ws=ws)
+        g(self.W, self.dzsum_dec, P.rows(P.grads, 'decoder_h/kernel', off + L), Cn, G4, B, ta=True, ws=ws)
+        g(dz, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
+        g(self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off + L), self.dW, B, Cn, G4, tb=True, ws=ws)
+        # latent heads
+        ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
+        g(self.hs_enc, self.dzargs, P.g('Z_mean/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws)
+        g(self.hs_enc, self.dzargs[:, L:], P.g('Z_log_var/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws)
+        ops.colsum(self.dzargs, BT, L, P.g('Z_mean/bias'), ws, ldx=2 * L)
+        ops.colsum(self.dzargs[:, L:], BT, L, P.g('Z_log_var/bias'), ws, ldx=2 * L)
+        g(self.dzargs, P.p('Z_mean/kernel'), self.dhs, BT, H, L, tb=True, lda=2 * L, ws=ws)
+        g(self.dzargs[:, L:], P.p('Z_log_var/kernel'), self.dhs, BT, H, L, tb=True, lda=2 * L, beta=1.0, ws=ws)
+        # encoder BPTT
+        ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
+                         self.dzsum_enc, gate_act=self.gate_act)
+        dz = self.gates_enc
+        self._lstm_wgrads('encoder_h', X, self.hs_enc, dz, self.dzsum_enc, D)
+        g(self.W, self.dzsum_enc, P.rows(P.grads, 'encoder_h/kernel', D), Cn, G4, B, ta=True, ws=ws)
+        g(self.dzsum_enc, P.rows(P.params, 'encoder_h/kernel', D), self.dW, B, Cn, G4, tb=True, beta=1.0, ws=ws)
+        # label head
+        ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, self.W, self.dW,
+                      cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
+                      self.dwargs, self.dwargs[:, C1:], 2 * C1)
+        g(self.hW, self.dwargs, P.g('Wargs/kernel'), D, 2 * C1, B, ta=True, ws=ws)
+        ops.colsum(self.dwargs, B, 2 * C1, P.g('Wargs/bias'), ws)
+        g(self.dwargs, P.p('Wargs/kernel'), self.dhW, B, D, 2 * C1, tb=True, act=ACT_MASKPOS, aux=self.hW, ws=ws)
+        g(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)
+        ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)

@@ -1,0 +1,169 @@
+"""Thin torch-tensor wrappers over the C ABI (include/clvae.h).
+
+torch is used for device memory and streams only; every computation below is a
+HIP kernel of libclvae_hip.so.  All tensors must be contiguous float32 CUDA
+tensors (views with a row stride are passed as (tensor, ld)).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_MASKPOS, check  # noqa: F401
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Workspace:
+    """A growable byte buffer on the device handed to ops that need scratch."""
+
+    def __init__(self, device, nbytes=1 << 20):
+        self.device = device
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+    def ensure(self, nbytes):
+        if self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def pick_split_k(M, N, K, cus=256):
+    """Split K so that small-output GEMMs (weight gradients, hW) still fill the chip."""
+    tiles = ((M + 63) // 64) * ((N + 95) // 96)
+    if tiles >= cus or K < 512:
+        return 1
+    s = max(1, min((2 * cus) // max(tiles, 1), K // 128))
+    return int(s)
+
+
+def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None, alpha=1.0, beta=0.0,
+         bias=None, act=ACT_NONE, aux=None, split_k=None, ws=None):
+    """C[M,N] = act(alpha*op(A).op(B) + bias + beta*C); A/B/C are tensors (possibly offset views)."""
+    L = _lib.lib()
+    lda = lda if lda is not None else (M if ta else K)
+    ldb = ldb if ldb is not None else (K if tb else N)
+    ldc = ldc if ldc is not None else N
+    if split_k is None:
+        split_k = pick_split_k(M, N, K)
+    wsp, wsb = None, 0
+    if split_k > 1:
+        need = L.clv_gemm_workspace_bytes(M, N, split_k)
+        buf = ws.ensure(need)
+        wsp, wsb = _ptr(buf), buf.numel()
+    check(L.clv_gemm_f32(int(ta), int(tb), M, N, K, float(alpha), _ptr(A), lda, _ptr(B), ldb, float(beta),
+                         _ptr(C_out), ldc, _ptr(bias), act, _ptr(aux), split_k, wsp, wsb, _stream()), "clv_gemm_f32")
+
+
+def colsum(X, M, N, out, ws, ldx=None, beta=0.0):
+    L = _lib.lib()
+    buf = ws.ensure(L.clv_colsum_workspace_bytes(M, N))
+    check(L.clv_colsum_f32(M, N, _ptr(X), ldx if ldx is not None else N, float(beta), _ptr(out), _ptr(buf),
+                           buf.numel(), _stream()), "clv_colsum_f32")
+
+
+def lstm_seq_fwd(B, T, xproj, rowbias, U, hs, cs, gates, h0=None, c0=None, hT=None, cT=None, gate_act=0, H=88):
+    check(_lib.lib().clv_lstm_seq_fwd(B, T, H, gate_act, _ptr(xproj), _ptr(rowbias), _ptr(U), _ptr(h0), _ptr(c0),
+                                      _ptr(hs), _ptr(cs), _ptr(gates), _ptr(hT), _ptr(cT), _stream()),
+          "clv_lstm_seq_fwd")
+
+
+def lstm_seq_bwd(B, T, U, dhs, cs, gates_inout, dzsum, c0=None, gate_act=0, H=88):
+    check(_lib.lib().clv_lstm_seq_bwd(B, T, H, gate_act, _ptr(U), _ptr(dhs), _ptr(cs), _ptr(c0), _ptr(gates_inout),
+                                      _ptr(dzsum), _stream()), "clv_lstm_seq_bwd")
+
+
+def label_fwd(B, Cn, mean, logvar, ld_in, eps, onehot, prior, w, rowloss):
+    check(_lib.lib().clv_label_fwd(B, Cn, _ptr(mean), _ptr(logvar), ld_in, _ptr(eps), _ptr(onehot), float(prior),
+                                   _ptr(w), _ptr(rowloss), _stream()), "clv_label_fwd")
+
+
+def label_bwd(B, Cn, mean, logvar, ld_in, eps, onehot, w, dw, prior, class_weight, w_kl_weight, inv_b,
+              dmean, dlogvar, ld_out):
+    check(_lib.lib().clv_label_bwd(B, Cn, _ptr(mean), _ptr(logvar), ld_in, _ptr(eps), _ptr(onehot), _ptr(w), _ptr(dw),
+                                   float(prior), float(class_weight), float(w_kl_weight), float(inv_b),
+                                   _ptr(dmean), _ptr(dlogvar), ld_out, _stream()), "clv_label_bwd")
+
+
+def gauss_fwd(R, Ld, zargs, eps, z, ldz, rowkl):
+    check(_lib.lib().clv_gauss_fwd(R, Ld, _ptr(zargs), _ptr(eps), _ptr(z), ldz, _ptr(rowkl), _stream()),
+          "clv_gauss_fwd")
+
+
+def gauss_bwd(R, Ld, zargs, eps, dz, lddz, kl_scale, dzargs):
+    check(_lib.lib().clv_gauss_bwd(R, Ld, _ptr(zargs), _ptr(eps), _ptr(dz), lddz, float(kl_scale), _ptr(dzargs),
+                                   _stream()), "clv_gauss_bwd")
+
+
+def bernoulli_nll(R, D, logits, y, ldy, scale, rownll, dlogits):
+    check(_lib.lib().clv_bernoulli_nll(R, D, _ptr(logits), _ptr(y), ldy, float(scale), _ptr(rownll), _ptr(dlogits),
+                                       _stream()), "clv_bernoulli_nll")
+
+
+def sum_strided(n, x, stride, scale, out):
+    check(_lib.lib().clv_sum_strided(n, _ptr(x), stride, float(scale), _ptr(out), _stream()), "clv_sum_strided")
+
+
+def philox_normal(out, n, seed, step=0, stream_id=0, first_index=0, step_dev=None):
+    check(_lib.lib().clv_philox_normal(_ptr(out), n, seed, step, _ptr(step_dev), stream_id, first_index, _stream()),
+          "clv_philox_normal")
+
+
+def philox_uniform(out, n, seed, step=0, stream_id=0, first_index=0, step_dev=None):
+    check(_lib.lib().clv_philox_uniform(_ptr(out), n, seed, step, _ptr(step_dev), stream_id, first_index, _stream()),
+          "clv_philox_uniform")
+
+
+def bernoulli_sample(n, p, u, x):
+    check(_lib.lib().clv_bernoulli_sample(n, _ptr(p), _ptr(u), _ptr(x), _stream()), "clv_bernoulli_sample")
+
+
+class Graph:
+    """Capture the kernels enqueued inside the ``with`` block on the current stream; replay with launch()."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        self._stream = None
+
+    def __enter__(self):
+        self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self._stream)
+        self._ctx.__enter__()
+        check(_lib.lib().clv_graph_begin_capture(_stream()), "graph begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        code = _lib.lib().clv_graph_end_capture(_stream(), C.byref(self.handle))
+        self._ctx.__exit__(et, ev, tb)
+        torch.cuda.current_stream().wait_stream(self._stream)
+        if et is None:
+            check(code, "graph end")
+        return False
+
+    def launch(self):
+        check(_lib.lib().clv_graph_launch(self.handle, _stream()), "graph launch")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().clv_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def prof_enable(on=True):
+    check(_lib.lib().clv_prof_enable(int(on)))
+
+
+def prof_collect(cap=64):
+    arr = (_lib.ProfRecord * cap)()
+    n = _lib.lib().clv_prof_collect(arr, cap)
+    if n < 0:
+        check(n, "clv_prof_collect")
+    return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms) for i in range(n)]

@@ -1,0 +1,198 @@
+/* clvae.h -- C ABI of libclvae_hip.so: the MI355X (gfx950) hot path of
+ * mobeets/classifying-vae-lstm (cl_vae / cl_vrnn training + sampling arithmetic).
+ *
+ * The reference has no FFI: its arithmetic runs inside Keras 2.0.0 / TF 1.0.1
+ * behind code/cl_vae/model.py and code/cl_vrnn/model.py.  This header is the
+ * boundary a maintainer would bind (ctypes stub in INTEGRATION.md); each entry
+ * point cites the reference lines it replaces (paths relative to
+ * /root/reference/code).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless it is marked
+ *     "host"; tensors are row-major, contiguous, float32 unless stated;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     nothing synchronises (graph-capture safe, no hidden allocation);
+ *   - scratch memory comes from the caller: ask `*_workspace_bytes`, pass `ws`;
+ *   - return value: 0 on success, a negative CLV_E* code or a positive
+ *     hipError_t otherwise; no exceptions cross the ABI;
+ *   - no global state except the opt-in profiler (clv_prof_*).
+ *
+ * Weight layouts are Keras': Dense kernel [in,out], bias [out]; LSTM kernel
+ * [in,4H], recurrent_kernel [H,4H], bias [4H], gate blocks i,f,c,o.
+ */
+#ifndef CLVAE_H
+#define CLVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLV_OK          0
+#define CLV_EINVAL     (-1)   /* bad argument / unsupported shape          */
+#define CLV_EWORKSPACE (-2)   /* workspace too small                       */
+#define CLV_ENOGPU     (-3)   /* no gfx950 device visible                  */
+
+#define CLV_ACT_NONE     0
+#define CLV_ACT_RELU     1
+#define CLV_ACT_SIGMOID  2
+#define CLV_ACT_MASKPOS  3   /* out = acc * (aux[m,n] > 0): relu' through a saved activation */
+
+#define CLV_GATE_HARD_SIGMOID 0   /* Keras 2.0.0 default recurrent_activation */
+#define CLV_GATE_SIGMOID      1
+
+int clv_version(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
+int clv_device_count(void);
+const char* clv_error_string(int code);
+
+/* ------------------------------------------------------------------ GEMM --
+ * C[M,N] = act(alpha * op(A)[M,K] . op(B)[K,N] + bias[N] + beta * C)
+ * op(A) = A (A is [M,K], lda) or A^T (A is [K,M], lda) when transa != 0; same for B.
+ * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32 (bit-exact fma chains).
+ * `aux` (ld = ldc) is only read for CLV_ACT_MASKPOS.  split_k > 1 needs
+ * ws >= clv_gemm_workspace_bytes(M,N,split_k).
+ * Replaces every keras.layers.Dense / TimeDistributed(Dense) / LSTM input
+ * projection matmul and their gradients: cl_vae/model.py:141-143,160-167,
+ * 184-186; cl_vrnn/model.py:174-175,196-209,225-234. */
+size_t clv_gemm_workspace_bytes(int M, int N, int split_k);
+int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
+                 const float* A, int lda, const float* B, int ldb,
+                 float beta, float* C, int ldc,
+                 const float* bias, int act, const float* aux,
+                 int split_k, void* ws, size_t ws_bytes, void* stream);
+
+/* column sums: out[N] = (beta ? out : 0) + sum_m X[m, n]   (bias gradients) */
+size_t clv_colsum_workspace_bytes(int M, int N);
+int clv_colsum_f32(int M, int N, const float* X, int ldx, float beta, float* out,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ LSTM --
+ * Persistent sequence kernels, one workgroup per batch row, recurrent kernel
+ * U [H,4H] resident in registers for all T steps (H must be 88).
+ *   z_t = xproj[b,t,:] + rowbias[b,:] + h_{t-1} . U
+ *   i,f,o = gate_act(z_i,z_f,z_o); g = tanh(z_c); c_t = f*c_{t-1} + i*g; h_t = o*tanh(c_t)
+ * fwd writes hs[B,T,H], cs[B,T,H] and gates[B,T,4H] = (z_i, z_f, tanh(z_c), z_o)
+ * (what BPTT needs); h0/c0 may be NULL (zero state) and hT/cT may be NULL.
+ * bwd consumes dhs[B,T,H] (dL/dh_t from the layers above), overwrites
+ * gates with dz[B,T,4H] (dL/dz_t) and writes dzsum[B,4H] = sum_t dz.
+ * Replaces keras.layers.LSTM (K.rnn loop) at cl_vrnn/model.py:196-199,225-228
+ * and the stateful step models at :122-125,149-152. */
+int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
+                     const float* xproj, const float* rowbias, const float* U,
+                     const float* h0, const float* c0,
+                     float* hs, float* cs, float* gates, float* hT, float* cT,
+                     void* stream);
+int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
+                     const float* U, const float* dhs, const float* cs, const float* c0,
+                     float* gates_inout_dz, float* dzsum, void* stream);
+
+/* ------------------------------------------------------------ pointwise --
+ * logistic-normal label sample + its two losses, one thread per row:
+ *   w = softmax([mean + exp(lv/2)*eps, 0]); kl_w, w_rec = (C-1)*CCE(onehot, w+1e-10), hit
+ * wargs is [B, 2(C-1)] = [mean | log_var] (cl_vrnn "Wargs") or two separate
+ * pointers with ld (cl_vae heads).  rowloss[B,3] = (kl_w, w_rec, hit).
+ * cl_vae/model.py:146-157,198-206; cl_vrnn/model.py:183-191,244-252. */
+int clv_label_fwd(int B, int C, const float* mean, const float* logvar, int ld_in,
+                  const float* eps, const float* onehot, float prior_logvar,
+                  float* w, float* rowloss, void* stream);
+/* backward of the above: dw[B,C] is dL/dw from the layers below (RepeatVector sums
+ * already applied); adds class_weight*inv_b*d(w_rec) and w_kl_weight*inv_b*d(kl_w);
+ * writes dmean/dlogvar (ld_out). */
+int clv_label_bwd(int B, int C, const float* mean, const float* logvar, int ld_in,
+                  const float* eps, const float* onehot, const float* w, const float* dw,
+                  float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
+                  float* dmean, float* dlogvar, int ld_out, void* stream);
+
+/* gaussian reparameterisation rows: zargs[R, 2L] = [mean | log_var];
+ * z[R, ldz] (written at column offset 0..L-1) = mean + exp(lv/2)*eps; rowkl[R] = KL(N(mean,exp(lv))||N(0,1)).
+ * cl_vae/model.py:170-174,193-196; cl_vrnn/model.py:212-216,236-239. */
+int clv_gauss_fwd(int R, int L, const float* zargs, const float* eps, float* z, int ldz,
+                  float* rowkl, void* stream);
+/* dzargs[R,2L] = [dz + kl_scale*mean | dz*eps*0.5*exp(lv/2) - 0.5*kl_scale*(1-exp(lv))] */
+int clv_gauss_bwd(int R, int L, const float* zargs, const float* eps, const float* dz, int lddz,
+                  float kl_scale, float* dzargs, void* stream);
+
+/* Bernoulli NLL on logits with Keras' epsilon-clip semantics (A.3), one wave per row:
+ * rownll[R] = sum_j softplus(l) - l*y, l = clip(a, +-log((1-1e-7)/1e-7));
+ * dlogits[R,D] = scale * (sigmoid(l) - y) * [|a| <= clip]   (dlogits may alias logits,
+ * or be NULL for loss only).  cl_vae/model.py:190-191; cl_vrnn/model.py:241-242. */
+int clv_bernoulli_nll(int R, int D, const float* logits, const float* y, int ldy, float scale,
+                      float* rownll, float* dlogits, void* stream);
+
+/* deterministic sum of n floats with stride: out[0] = scale * sum_i x[i*stride] */
+int clv_sum_strided(int n, const float* x, int stride, float scale, float* out, void* stream);
+
+/* ---------------------------------------------------------------- Adam-WN --
+ * Adam with weight normalisation over a flat parameter buffer
+ * (utils/weightnorm.py:75-178).  `table` is a device array of n_tensors
+ * clv_param_desc; matrices (rows>1 in the sense ndim>1) get the weight-norm
+ * reparameterisation over all axes but the last, vectors plain Adam.
+ * State: m, v (flat, same layout as params); mg, vg, s (flat per-column layout,
+ * s initialised to 1).  step_t = iterations + 1 (1 on the first call).
+ * weightnorm == 0 gives plain Keras Adam ('adam'). */
+typedef struct clv_param_desc {
+  int64_t offset;      /* element offset into params / grads / m / v          */
+  int32_t rows;        /* product of all axes but the last (1 for a bias)     */
+  int32_t cols;        /* last axis                                           */
+  int64_t col_offset;  /* element offset into mg / vg / s (unused for biases) */
+  int32_t is_matrix;   /* ndim > 1                                            */
+  int32_t pad_;
+} clv_param_desc;
+/* plan: a device-resident work table derived from the tensor table.  Build it once on
+ * the host (clv_adam_wn_plan_build into a host blob of clv_adam_wn_plan_bytes), copy the
+ * blob to the device, pass the device pointer as plan_dev on every step. */
+size_t clv_adam_wn_plan_bytes(const clv_param_desc* host_table, int n_tensors);
+int clv_adam_wn_plan_build(const clv_param_desc* host_table, int n_tensors, void* host_blob);
+size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tensors);
+/* iterations_dev (device int32, may be NULL): Keras' `iterations` variable; when given,
+ * t = *iterations_dev + 1 is read on the device and the counter is advanced by the call
+ * (so a captured graph can be replayed); otherwise t = step_t. */
+int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
+                     float* params, const float* grads, float* m, float* v,
+                     float* mg, float* vg, float* s,
+                     int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
+                     int weightnorm, void* ws, size_t ws_bytes, void* stream);
+
+/* -------------------------------------------------------------------- RNG --
+ * Counter-based Philox4x32-10, key = (seed_lo, seed_hi), counter =
+ * ((index>>2)_lo, (index>>2)_hi, stream_id, step): element i of a draw is a pure
+ * function of (seed, step, stream_id, first_index + i), so 1/2/4/8-GPU runs see the
+ * same noise for the same global sample.  Normal = Box-Muller (words 0,1 -> cos,sin;
+ * words 2,3 -> cos,sin).  The effective step is step + *step_dev when step_dev
+ * (device int32, e.g. the Adam `iterations` counter) is not NULL.
+ * Replaces K.random_normal (cl_vae/model.py:152,172; cl_vrnn/model.py:185,214)
+ * and np.random.rand in sample_x (cl_vae/model.py:44-45; cl_vrnn/model.py:62-63). */
+int clv_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, const int32_t* step_dev,
+                      uint32_t stream_id, uint64_t first_index, void* stream);
+int clv_philox_uniform(float* out, int64_t n, uint64_t seed, uint32_t step, const int32_t* step_dev,
+                       uint32_t stream_id, uint64_t first_index, void* stream);
+/* x[i] = (u[i] <= p[i]) ? 1 : 0   -- sample_x */
+int clv_bernoulli_sample(int64_t n, const float* p, const float* u, float* x, void* stream);
+
+/* ----------------------------------------------------------------- graphs --
+ * thin wrappers so a host without HIP bindings can capture a step once and
+ * replay it (launch-bound inner loops: SURVEY.md 7.1 step 8). */
+int clv_graph_begin_capture(void* stream);
+int clv_graph_end_capture(void* stream, void** graph_exec_out);
+int clv_graph_launch(void* graph_exec, void* stream);
+int clv_graph_destroy(void* graph_exec);
+
+/* --------------------------------------------------------------- profiler --
+ * opt-in per-kernel HIP-event timing on the launch stream (bench.py roofline):
+ * enable -> every kernel launched through this library is bracketed by events;
+ * clv_prof_collect synchronises, and fills up to `cap` records. */
+typedef struct clv_prof_record {
+  char name[48];
+  int32_t launches;
+  float total_ms;
+} clv_prof_record;
+int clv_prof_enable(int on);
+int clv_prof_collect(clv_prof_record* host_out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLVAE_H */

@@ -1,0 +1,178 @@
+"""-m gpu: whole cl_vae / cl_vrnn training steps on the HIP path vs the fp64 oracle.
+
+North-star tolerances: |ELBO_gpu - ELBO_oracle| <= 1e-3 nats per frame on
+identical weights, inputs and injected eps; per-note decoder logits max-abs error reported and
+bounded; gradients to 1e-4 relative (of the tensor's max); three Adam-WN steps track the oracle.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import clvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ELBO_TOL = 1e-3
+LOGIT_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import clvae_amd
+    from clvae_amd import _lib
+    _lib.require_gpu()
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def check_grads(got, ref, tol=1e-4):
+    for k in ref:
+        scale = np.abs(ref[k]).max() + 1e-8
+        err = np.abs(got[k] - ref[k]).max() / scale
+        assert err < tol, "%s: rel err %.3e" % (k, err)
+
+
+def frames(rng, *shape):
+    return (rng.random(shape) < 0.0443).astype(np.float64)
+
+
+@pytest.mark.parametrize("B,L,Cn,use_x_prev,weights", [
+    (100, 4, 2, True, (1.0, 1.0, 1.0, 0.0)),       # BASELINE config 1 shape
+    (512, 4, 2, True, (1.0, 1.0, 1.0, 0.0)),       # config 2 shape (fp32 path)
+    (48, 2, 10, False, (0.7, 0.3, 0.9, 0.4)),
+])
+def test_cl_vae_step_matches_oracle(dev, B, L, Cn, use_x_prev, weights):
+    from clvae_amd.engine import VaeEngine
+    cw, klw, wklw, prior = weights
+    cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=use_x_prev, class_weight=cw, kl_weight=klw,
+                       w_kl_weight=wklw, w_log_var_prior=prior)
+    rng = np.random.default_rng(11)
+    p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=1).items()}
+    for k in p:
+        if k.endswith('bias'):
+            p[k] = f32(0.05 * rng.standard_normal(p[k].shape))
+    x, xp = frames(rng, B, 88), frames(rng, B, 88)
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    ew, ez = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, L)))
+    ref = O.vae_loss_and_grads(p, cfg, x, xp, wt, ew, ez)
+
+    eng = VaeEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    args = (T(x, dev), T(xp, dev), T(wt, dev), T(ew, dev), T(ez, dev))
+    eng.loss_and_grads(*args)
+    torch.cuda.synchronize()
+    got = eng.losses()
+    logit_err = np.abs(N(eng.logits) - ref['cache']['logits']).max()
+    print("cl_vae B=%d: ELBO gpu %.6f oracle %.6f |d|=%.2e  logits max-abs err %.2e"
+          % (B, got['elbo'], ref['elbo'], abs(got['elbo'] - ref['elbo']), logit_err))
+    assert abs(got['elbo'] - ref['elbo']) <= ELBO_TOL
+    assert abs(got['total'] - ref['total']) <= ELBO_TOL
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, k
+    assert abs(got['acc'] - ref['acc']) < 1e-6
+    assert logit_err < LOGIT_TOL
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'])
+    # three optimizer steps on the same batch
+    st = O.adam_wn_init(p)
+    for _ in range(3):
+        r = O.vae_loss_and_grads(p, cfg, x, xp, wt, ew, ez)
+        O.adam_wn_step(p, r['grads'], st)
+        eng.loss_and_grads(*args)
+        eng.P.adam_step()
+    w = eng.P.get_weights()
+    for k in p:
+        np.testing.assert_allclose(w[k], p[k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("B,Tn,L,Cn,use_x_prev,gate", [
+    (6, 5, 2, 10, True, 'hard_sigmoid'),
+    (5, 7, 3, 4, False, 'hard_sigmoid'),
+    (4, 9, 2, 10, True, 'sigmoid'),
+    (4, 128, 2, 10, True, 'hard_sigmoid'),      # BASELINE config 3/4 shape at reduced batch
+    (4, 32, 32, 10, True, 'hard_sigmoid'),      # config 5 latent size
+])
+def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate):
+    from clvae_amd.engine import VrnnEngine
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=use_x_prev, class_weight=0.8,
+                        kl_weight=0.6, w_kl_weight=0.9, w_log_var_prior=0.2, gate_act=gate)
+    rng = np.random.default_rng(B * 1000 + Tn)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=2).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    eW, eZ = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, Tn, L)))
+    ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
+
+    eng = VrnnEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    args = (T(X, dev), T(Xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev))
+    eng.loss_and_grads(*args)
+    torch.cuda.synchronize()
+    got = eng.losses()
+    logit_err = np.abs(N(eng.logits).reshape(B, Tn, 88) - ref['cache']['logits']).max()
+    print("cl_vrnn B=%d T=%d L=%d: ELBO gpu %.6f oracle %.6f |d|=%.2e  logits max-abs err %.2e"
+          % (B, Tn, L, got['elbo'], ref['elbo'], abs(got['elbo'] - ref['elbo']), logit_err))
+    assert abs(got['elbo'] - ref['elbo']) <= ELBO_TOL
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, k
+    assert logit_err < LOGIT_TOL
+    np.testing.assert_allclose(N(eng.hs_enc).reshape(B, Tn, 88), ref['cache']['enc_h'], atol=2e-5)
+    np.testing.assert_allclose(N(eng.hs_dec).reshape(B, Tn, 88), ref['cache']['dec_h'], atol=2e-5)
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'], tol=2e-4)
+    st = O.adam_wn_init(p)
+    for _ in range(2):
+        r = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
+        O.adam_wn_step(p, r['grads'], st)
+        eng.loss_and_grads(*args)
+        eng.P.adam_step()
+    w = eng.P.get_weights()
+    for k in p:
+        np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
+
+
+def test_cl_vrnn_step_is_graph_replayable(dev):
+    """The whole step enqueues kernels only: capture once, replay, same numbers."""
+    from clvae_amd import ops
+    from clvae_amd.engine import VrnnEngine
+    cfg = O.vrnn_config(latent_dim=2, seq_length=16, n_classes=10, use_x_prev=True)
+    B, Tn = 8, 16
+    rng = np.random.default_rng(5)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=3).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    args_np = (win[:, 1:].copy(), win[:, :-1].copy(), np.eye(10)[rng.integers(0, 10, B)],
+               rng.standard_normal((B, 9)), rng.standard_normal((B, Tn, 2)))
+    eng = VrnnEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    args = tuple(T(a, dev) for a in args_np)
+    eng.loss_and_grads(*args)              # warm-up: sizes every workspace
+    eng.P.adam_step()
+    torch.cuda.synchronize()
+    eng.P.set_weights(p); eng.P.reset_optimizer()
+    with ops.Graph() as gr:
+        eng.loss_and_grads(*args)
+        eng.P.adam_step()
+    for _ in range(3):
+        gr.launch()
+    torch.cuda.synchronize()
+    w_graph = eng.P.get_weights()
+    eng.P.set_weights(p); eng.P.reset_optimizer()
+    for _ in range(3):
+        eng.loss_and_grads(*args)
+        eng.P.adam_step()
+    torch.cuda.synchronize()
+    w_eager = eng.P.get_weights()
+    for k in w_graph:
+        np.testing.assert_array_equal(w_graph[k], w_eager[k])
+    assert int(eng.P.iterations.item()) == 3

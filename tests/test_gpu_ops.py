@@ -1,0 +1,265 @@
+"""-m gpu: every HIP op of include/clvae.h against the numpy oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import clvae_oracle as O
+from oracle import philox as OP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import clvae_amd
+    from clvae_amd import _lib
+    _lib.require_gpu()          # fail loudly: no CPU fallback
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+GEMM_CASES = [
+    # M, N, K, ta, tb, bias, act, beta, split
+    (37, 29, 53, 0, 0, 1, 0, 0.0, 1),
+    (64, 64, 16, 0, 0, 0, 1, 0.0, 1),
+    (100, 88, 88, 0, 0, 1, 1, 0.0, 1),
+    (100, 1, 88, 0, 0, 1, 0, 0.0, 1),        # w_mean head of cl_vae (N=1)
+    (512, 352, 88, 0, 0, 0, 0, 0.0, 1),      # x-projection tile shape (64x176)
+    (300, 352, 10, 0, 0, 1, 0, 1.0, 1),
+    (256, 88, 1408, 0, 0, 1, 1, 0.0, 11),    # hW forward, split-K
+    (88, 352, 2000, 1, 0, 0, 0, 0.0, 16),    # weight gradient (96x96 tiles), split-K
+    (88, 352, 777, 1, 0, 0, 0, 1.0, 5),
+    (1408, 88, 40, 1, 0, 0, 0, 0.0, 1),      # hW weight gradient
+    (200, 88, 352, 0, 1, 0, 3, 0.0, 1),      # dX with relu mask
+    (130, 2, 352, 0, 1, 0, 0, 0.0, 1),       # dZ (N=L=2)
+    (2, 352, 600, 1, 0, 0, 0, 0.0, 4),       # Z rows of the decoder kernel gradient
+    (45, 70, 33, 1, 1, 1, 2, 0.0, 1),
+    (70, 130, 9, 0, 0, 1, 0, 0.5, 1),
+]
+
+
+@pytest.mark.parametrize("M,Nn,K,ta,tb,bias,act,beta,split", GEMM_CASES)
+def test_gemm(dev, M, Nn, K, ta, tb, bias, act, beta, split):
+    from clvae_amd import ops
+    rng = np.random.default_rng(M * 131 + Nn * 17 + K)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    Bm = rng.standard_normal((Nn, K) if tb else (K, Nn))
+    C0 = rng.standard_normal((M, Nn))
+    b = rng.standard_normal(Nn) if bias else None
+    aux = rng.standard_normal((M, Nn))
+    ref = (A.T if ta else A).astype(np.float32).astype(np.float64) @ (Bm.T if tb else Bm).astype(np.float32).astype(np.float64)
+    ref = 0.75 * ref
+    if bias:
+        ref = ref + b.astype(np.float32)
+    ref = ref + beta * C0.astype(np.float32)
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    elif act == 2:
+        ref = 1 / (1 + np.exp(-ref))
+    elif act == 3:
+        ref = ref * (aux.astype(np.float32) > 0)
+    Cd = T(C0, dev)
+    ws = ops.Workspace(dev)
+    ops.gemm(T(A, dev), T(Bm, dev), Cd, M, Nn, K, ta=bool(ta), tb=bool(tb), alpha=0.75, beta=beta,
+             bias=None if b is None else T(b, dev), act=act, aux=T(aux, dev) if act == 3 else None,
+             split_k=split, ws=ws)
+    torch.cuda.synchronize()
+    scale = np.abs(ref).max() + 1
+    assert np.abs(N(Cd) - ref).max() / scale < 2e-6 * max(1, np.sqrt(K) / 4)
+
+
+def test_gemm_strided_views(dev):
+    """ldc / lda column-block views used for the [mean|log_var] heads."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(0)
+    M, K, L = 50, 88, 4
+    A = rng.standard_normal((M, K)); W1 = rng.standard_normal((K, L)); W2 = rng.standard_normal((K, L))
+    out = torch.zeros(M, 2 * L, device=dev)
+    ws = ops.Workspace(dev)
+    ops.gemm(T(A, dev), T(W1, dev), out, M, L, K, ldc=2 * L, ws=ws)
+    ops.gemm(T(A, dev), T(W2, dev), out[:, L:], M, L, K, ldc=2 * L, ws=ws)
+    ref = np.concatenate([A.astype(np.float32) @ W1.astype(np.float32), A.astype(np.float32) @ W2.astype(np.float32)], 1)
+    np.testing.assert_allclose(N(out), ref, atol=2e-5)
+    back = torch.zeros(M, K, device=dev)
+    ops.gemm(out, T(W1, dev), back, M, K, L, tb=True, lda=2 * L, ws=ws)
+    np.testing.assert_allclose(N(back), ref[:, :L] @ W1.astype(np.float32).T, atol=1e-4)
+
+
+def test_colsum_and_sum(dev):
+    from clvae_amd import ops
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((3000, 90))
+    out = torch.zeros(90, device=dev)
+    ws = ops.Workspace(dev)
+    ops.colsum(T(X, dev), 3000, 90, out, ws)
+    np.testing.assert_allclose(N(out), X.astype(np.float32).astype(np.float64).sum(0), atol=2e-3)
+    out2 = torch.ones(4, device=dev)
+    ops.colsum(T(X, dev)[:, 5:], 3000, 4, out2, ws, ldx=90, beta=1.0)
+    np.testing.assert_allclose(N(out2), 1 + X[:, 5:9].astype(np.float32).astype(np.float64).sum(0), atol=2e-3)
+    s = torch.zeros(2, device=dev)
+    ops.sum_strided(3000, T(X, dev)[:, 2:], 90, 1.0 / 3000, s)
+    assert abs(N(s)[0] - X[:, 2].astype(np.float32).mean()) < 1e-5
+
+
+@pytest.mark.parametrize("B,Tn,gate", [(3, 9, 0), (5, 1, 0), (4, 17, 1), (1024, 3, 0), (2048, 2, 0)])
+def test_lstm_seq_fwd_bwd(dev, B, Tn, gate):
+    from clvae_amd import ops
+    H = 88
+    rng = np.random.default_rng(B + Tn)
+    U = O.orthogonal(rng, (H, 4 * H), np.float64) * 1.5
+    xproj = rng.standard_normal((B, Tn, 4 * H)) * 1.5
+    rb = rng.standard_normal((B, 4 * H)) * 0.3
+    h0 = rng.standard_normal((B, H)) * 0.5
+    c0 = rng.standard_normal((B, H)) * 0.5
+    act = 'hard_sigmoid' if gate == 0 else 'sigmoid'
+    # oracle: identity input kernel so that xs == xproj + rowbias
+    xs = xproj + rb[:, None, :]
+    hs_ref, cache = O.lstm_forward(xs, np.eye(4 * H), U, np.zeros(4 * H), h0=h0, c0=c0, gate_act=act)
+    dHs = rng.standard_normal((B, Tn, H))
+    _, _, _, _, dZ_ref = O.lstm_backward(dHs, cache, np.eye(4 * H), U)
+
+    gates = T(xproj, dev)
+    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
+    hT = torch.empty(B, H, device=dev); cT = torch.empty(B, H, device=dev)
+    Ud = T(U, dev)
+    ops.lstm_seq_fwd(B, Tn, gates, T(rb, dev), Ud, hs, cs, gates, h0=T(h0, dev), c0=T(c0, dev), hT=hT, cT=cT,
+                     gate_act=gate)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(hs), hs_ref, atol=3e-6)
+    np.testing.assert_allclose(N(cs), cache['C'], atol=5e-6)
+    np.testing.assert_allclose(N(hT), hs_ref[:, -1], atol=3e-6)
+    np.testing.assert_allclose(N(cT), cache['C'][:, -1], atol=5e-6)
+    g = N(gates).reshape(B, Tn, 4, H)
+    Zr = cache['Z'].reshape(B, Tn, 4, H)
+    np.testing.assert_allclose(g[:, :, 0], Zr[:, :, 0], atol=1e-5)
+    np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=3e-6)
+    dzsum = torch.empty(B, 4 * H, device=dev)
+    ops.lstm_seq_bwd(B, Tn, Ud, T(dHs, dev), cs, gates, dzsum, c0=T(c0, dev), gate_act=gate)
+    torch.cuda.synchronize()
+    dz = N(gates).reshape(B, Tn, 4 * H)
+    # hard-sigmoid kinks: a pre-activation within fp32 noise of +-2.5 may fall on the other side
+    bad = np.abs(dz - dZ_ref) > 2e-5 * (1 + np.abs(dZ_ref))
+    assert bad.mean() < 1e-4, bad.mean()
+    np.testing.assert_allclose(N(dzsum), dz.sum(1), atol=1e-4)
+
+
+def test_label_gauss_bernoulli(dev):
+    from clvae_amd import ops
+    rng = np.random.default_rng(3)
+    B, Cn, L, D = 37, 10, 3, 88
+    C1 = Cn - 1
+    wargs = rng.standard_normal((B, 2 * C1)) * 0.7
+    eps = rng.standard_normal((B, C1))
+    y = np.eye(Cn)[rng.integers(0, Cn, B)]
+    prior = 0.3
+    m, lv = wargs[:, :C1], wargs[:, C1:]
+    w_ref = O.logistic_normal(m, lv, eps)
+    klw, dm_kl, dlv_kl = O.kl_w_prior(m, lv, prior)
+    wrec, dw_rec = O.cce_keras(w_ref, y, C1)
+    wd = T(wargs, dev)
+    w = torch.empty(B, Cn, device=dev); rl = torch.empty(B, 3, device=dev)
+    ops.label_fwd(B, Cn, wd, wd[:, C1:], 2 * C1, T(eps, dev), T(y, dev), prior, w, rl)
+    np.testing.assert_allclose(N(w), w_ref, atol=2e-6)
+    np.testing.assert_allclose(N(rl)[:, 0], klw, rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(N(rl)[:, 1], wrec, rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(N(rl)[:, 2], (w_ref.argmax(1) == y.argmax(1)).astype(float))
+    dw = rng.standard_normal((B, Cn))
+    cw, wkl, inv = 0.7, 0.9, 1.0 / B
+    ds, dlv_s = O.logistic_normal_bwd(w_ref, dw + cw * inv * dw_rec, lv, eps)
+    dout = torch.empty(B, 2 * C1, device=dev)
+    ops.label_bwd(B, Cn, wd, wd[:, C1:], 2 * C1, T(eps, dev), T(y, dev), w, T(dw, dev), prior, cw, wkl, inv,
+                  dout, dout[:, C1:], 2 * C1)
+    np.testing.assert_allclose(N(dout)[:, :C1], ds + wkl * inv * dm_kl, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(N(dout)[:, C1:], dlv_s + wkl * inv * dlv_kl, rtol=1e-4, atol=2e-6)
+
+    R = 101
+    za = rng.standard_normal((R, 2 * L)); ez = rng.standard_normal((R, L))
+    z = torch.zeros(R, L + 2, device=dev); kl = torch.empty(R, device=dev)
+    ops.gauss_fwd(R, L, T(za, dev), T(ez, dev), z[:, 2:], L + 2, kl)
+    kl_ref, dzm, dzlv = O.kl_gauss(za[:, :L], za[:, L:])
+    np.testing.assert_allclose(N(z)[:, 2:], za[:, :L] + np.exp(za[:, L:] / 2) * ez, atol=3e-6)
+    np.testing.assert_allclose(N(kl), kl_ref, rtol=2e-5, atol=1e-5)
+    dz = rng.standard_normal((R, L)); dza = torch.empty(R, 2 * L, device=dev)
+    ops.gauss_bwd(R, L, T(za, dev), T(ez, dev), T(dz, dev), L, 0.25, dza)
+    np.testing.assert_allclose(N(dza)[:, :L], dz + 0.25 * dzm, atol=3e-6)
+    np.testing.assert_allclose(N(dza)[:, L:], dz * ez * 0.5 * np.exp(za[:, L:] / 2) + 0.25 * dzlv, atol=5e-6)
+
+    a = rng.standard_normal((R, D)) * 6
+    a[0, :5] = [20.0, -20.0, 16.2, -16.2, 0.0]              # beyond Keras' epsilon clip
+    yy = (rng.random((R, D)) < 0.2).astype(np.float64)
+    loss_ref, g_ref = O.bce_from_logits_keras(a.astype(np.float32).astype(np.float64), yy)
+    nll = torch.empty(R, device=dev); dl = torch.empty(R, D, device=dev)
+    ops.bernoulli_nll(R, D, T(a, dev), T(yy, dev), D, 0.5, nll, dl)
+    np.testing.assert_allclose(N(nll), loss_ref, rtol=3e-6, atol=1e-4)
+    np.testing.assert_allclose(N(dl), 0.5 * g_ref, atol=2e-6)
+
+
+@pytest.mark.parametrize("weightnorm", [True, False])
+def test_adam_wn_three_steps(dev, weightnorm):
+    from clvae_amd.engine import FlatParams
+    rng = np.random.default_rng(7)
+    shapes = [('a/kernel', (200, 88)), ('a/bias', (88,)), ('b/kernel', (88, 3)), ('b/bias', (3,)),
+              ('c/kernel', (10, 352)), ('c/recurrent_kernel', (88, 352)), ('c/bias', (352,))]
+    P = FlatParams(shapes, dev)
+    p = {n: rng.standard_normal(s) * 0.3 for n, s in shapes}
+    P.set_weights(p)
+    st = O.adam_wn_init(p, weightnorm=weightnorm)
+    for step in range(3):
+        g = {n: rng.standard_normal(s) * (0.1 + step) for n, s in shapes}
+        for n, _ in shapes:
+            P.g(n).copy_(T(g[n], dev))
+        P.adam_step(weightnorm=weightnorm)
+        O.adam_wn_step(p, {k: v.astype(np.float32).astype(np.float64) for k, v in g.items()}, st)
+        got = P.get_weights()
+        for n, _ in shapes:
+            np.testing.assert_allclose(got[n], p[n], rtol=3e-5, atol=3e-6, err_msg="%s step %d" % (n, step))
+    assert int(P.iterations.item()) == 3
+    if weightnorm:
+        np.testing.assert_allclose(N(P.s)[P.col_offsets['a/kernel']:][:88], st['s']['a/kernel'], rtol=3e-5)
+
+
+def test_philox_matches_oracle(dev):
+    from clvae_amd import ops
+    for first in (0, 5, 1027):
+        n = 4099
+        out = torch.empty(n, device=dev)
+        ops.philox_uniform(out, n, seed=0x123456789ABC, step=3, stream_id=2, first_index=first)
+        np.testing.assert_array_equal(N(out).astype(np.float32),
+                                      OP.uniform(n, 0x123456789ABC, 3, 2, first))
+        ops.philox_normal(out, n, seed=99, step=1, stream_id=0, first_index=first)
+        np.testing.assert_allclose(N(out), OP.normal(n, 99, 1, 0, first), atol=2e-5)
+    # step read from a device counter == step passed by value
+    ctr = torch.tensor([7], dtype=torch.int32, device=dev)
+    a = torch.empty(1000, device=dev); b = torch.empty(1000, device=dev)
+    ops.philox_normal(a, 1000, seed=5, step=2, step_dev=ctr)
+    ops.philox_normal(b, 1000, seed=5, step=9)
+    assert torch.equal(a, b)
+    big = torch.empty(1 << 20, device=dev)
+    ops.philox_normal(big, 1 << 20, seed=1234)
+    assert abs(big.mean().item()) < 5e-3 and abs(big.std().item() - 1) < 5e-3
+    u = torch.rand(1000, device=dev); pp = torch.rand(1000, device=dev); x = torch.empty(1000, device=dev)
+    ops.bernoulli_sample(1000, pp, u, x)
+    assert torch.equal(x, (u <= pp).float())
+
+
+def test_graph_capture_replay(dev):
+    from clvae_amd import ops
+    A = torch.randn(64, 32, device=dev); Bm = torch.randn(32, 48, device=dev); Cc = torch.zeros(64, 48, device=dev)
+    ws = ops.Workspace(dev)
+    ops.gemm(A, Bm, Cc, 64, 48, 32, ws=ws)
+    torch.cuda.synchronize()
+    with ops.Graph() as gr:
+        ops.gemm(A, Bm, Cc, 64, 48, 32, beta=1.0, ws=ws)
+    ref = Cc.clone()
+    for _ in range(3):
+        gr.launch()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(Cc), 4 * N(ref), rtol=1e-5, atol=1e-5)
