@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- piano-roll timesteps/sec (train) of the cl_vrnn hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by
+torch.distributed.run, one rank per GPU over RCCL).  A "step" is one full optimisation step
+(Philox noise draw, forward, 4 losses, BPTT, gradient all-reduce when N>1, Adam-with-weight-norm)
+over one batch of synthetic 88-dim piano-roll windows already resident in HBM.  Rank 0 prints ONE
+JSON line.  Workloads (BASELINE.json configs):
+  cfg3 (default)  cl_vrnn, 256 windows/GPU x seq_len 128, latent 2, 10 classes   (configs[2]; at N GPUs = configs[3])
+  cfg5            cl_vrnn, 1024 windows/GPU x seq_len 256, latent 32, 10 classes  (configs[4])
+  cfg2            cl_vae --use_x_prev, batch 512/GPU, latent 4, 2 classes (fp32 path)
+Weak scaling: per-GPU work is fixed, the global batch grows with N.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    'cfg3': dict(model='cl_vrnn', B=256, T=128, L=2, C=10),
+    'cfg5': dict(model='cl_vrnn', B=1024, T=256, L=32, C=10),
+    'cfg2': dict(model='cl_vae', B=512, T=1, L=4, C=2),
+}
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+NOTE_DENSITY = 0.0443        # measured JSB note density
+
+
+def flop_per_timestep(w):
+    """Algorithmic GEMM flops per training timestep (2 flop/MAC, train = 3x forward), SURVEY.md 8(d)."""
+    L, C, T = w['L'], w['C'], w['T']
+    if w['model'] == 'cl_vae':
+        macs = 88 * 88 + 2 * 88 * (C - 1) + (88 + C) * 88 + 2 * 88 * L + (C + 88 + L) * 88 + 88 * 88
+    else:
+        macs = (88 + C + 88) * 352 + 2 * 88 * L + (88 + L + C + 88) * 352 + 88 * 88 + 88 * 88 + 88 * 2 * (C - 1) / T
+    return 6.0 * macs
+
+
+def lstm_seq_flops(w, B):
+    """Algorithmic flops of ONE persistent LSTM sequence launch (recurrent product only): 2*B*T*88*352."""
+    return 2.0 * B * w['T'] * 88 * 352
+
+
+def make_engine(w, dev):
+    from clvae_amd.engine import VaeEngine, VrnnEngine
+    from clvae_amd.initializers import init_weights
+    if w['model'] == 'cl_vrnn':
+        cfg = dict(D=88, H=88, L=w['L'], T=w['T'], C=w['C'], use_x_prev=True, class_weight=1.0, kl_weight=1.0,
+                   w_kl_weight=1.0, w_log_var_prior=0.0, gate_act='hard_sigmoid')
+        eng = VrnnEngine(cfg, w['B'], dev)
+    else:
+        cfg = dict(D=88, H=88, L=w['L'], Hc=88, C=w['C'], use_x_prev=True, class_weight=1.0, kl_weight=1.0,
+                   w_kl_weight=1.0, w_log_var_prior=0.0)
+        eng = VaeEngine(cfg, w['B'], dev)
+    eng.P.set_weights(init_weights(eng.P.shapes, cfg, seed=0))
+    return eng, cfg
+
+
+def synthetic_windows(w, n, seed, dev):
+    """uint8 Bernoulli(0.0443) piano-roll windows + labels, resident on the device as fp32."""
+    import torch
+    rng = np.random.default_rng(seed)
+    T = w['T']
+    win = (rng.random((n, T + 1, 88)) < NOTE_DENSITY)
+    keys = rng.integers(0, w['C'], n)
+    onehot = np.eye(w['C'], dtype=np.float32)[keys]
+    wt = torch.as_tensor(win.astype(np.float32), device=dev)
+    if w['model'] == 'cl_vae':
+        return wt[:, 1].contiguous(), wt[:, 0].contiguous(), torch.as_tensor(onehot, device=dev)
+    return wt[:, 1:].contiguous(), wt[:, :-1].contiguous(), torch.as_tensor(onehot, device=dev)
+
+
+def cpu_baseline(w, seconds=15.0):
+    """The numpy oracle (CPU restatement of the Keras math, fp32, per-timestep LSTM loop like K.rnn)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import clvae_oracle as O
+    rng = np.random.default_rng(0)
+    T, L, C = w['T'], w['L'], w['C']
+    B = min(w['B'], 64)
+    if w['model'] == 'cl_vrnn':
+        cfg = O.vrnn_config(latent_dim=L, seq_length=T, n_classes=C, use_x_prev=True)
+        p = O.vrnn_init_params(cfg, seed=0, dtype=np.float32)
+        win = (rng.random((B, T + 1, 88)) < NOTE_DENSITY).astype(np.float32)
+        X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+        eZ = rng.standard_normal((B, T, L)).astype(np.float32)
+        fn = O.vrnn_loss_and_grads
+    else:
+        cfg = O.vae_config(latent_dim=L, n_classes=C, use_x_prev=True)
+        p = O.vae_init_params(cfg, seed=0, dtype=np.float32)
+        X = (rng.random((B, 88)) < NOTE_DENSITY).astype(np.float32)
+        Xp = (rng.random((B, 88)) < NOTE_DENSITY).astype(np.float32)
+        eZ = rng.standard_normal((B, L)).astype(np.float32)
+        fn = O.vae_loss_and_grads
+    wt = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
+    eW = rng.standard_normal((B, C - 1)).astype(np.float32)
+    st = O.adam_wn_init(p)
+    for _ in range(2):
+        r = fn(p, cfg, X, Xp, wt, eW, eZ); O.adam_wn_step(p, r['grads'], st)
+    t0 = time.time(); n = 0
+    while time.time() - t0 < seconds and n < 200:
+        r = fn(p, cfg, X, Xp, wt, eW, eZ); O.adam_wn_step(p, r['grads'], st); n += 1
+    dt = time.time() - t0
+    try:
+        import threadpoolctl
+        threads = max([i['num_threads'] for i in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return dict(value=B * T * n / dt, unit="timesteps/s", cores=int(threads), kind="port",
+                sample="%d steps of batch %d x seq_len %d (numpy fp32 oracle, %d host cores visible)"
+                       % (n, B, T, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--kernel-times', action='store_true', help='print per-kernel event times to stderr')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import clvae_amd  # noqa: F401
+    from clvae_amd import _lib, ops
+    from clvae_amd.parallel import init_from_env
+    from clvae_amd.trainer import TrainStep
+
+    rank, local, world = init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    w = WORKLOADS[args.workload]
+    B, T = w['B'], w['T']
+
+    eng, cfg = make_engine(w, dev)
+    if world > 1:      # replicas start from rank 0's weights
+        dist.broadcast(eng.P.params, src=0)
+    X_all, Xp_all, w_all = synthetic_windows(w, 4 * B, 1234 + rank, dev)
+    ts = TrainStep(eng, seed=1234, rank=rank, world=world, use_graph=not args.no_graph)
+    nb = X_all.shape[0] // B
+
+    def run(k):
+        for i in range(k):
+            j = i % nb
+            ts.stage_batch(X_all[j * B:(j + 1) * B], Xp_all[j * B:(j + 1) * B], w_all[j * B:(j + 1) * B])
+            ts.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(max(args.warmup, 3))            # >= 3: eager warm-up, graph capture, first replay
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = eng.losses()
+    value = world * B * T * args.steps / dt
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # per-kernel HIP-event timing (eager launches on the same stream, same shapes)
+        ts_e = TrainStep(eng, seed=1234, rank=rank, world=1, use_graph=False)
+        ts_e.stage_batch(X_all[:B], Xp_all[:B], w_all[:B])
+        ts_e.step(); torch.cuda.synchronize()
+        ops.prof_enable(True)
+        reps = 10
+        for _ in range(reps):
+            ts_e.step()
+        recs = ops.prof_collect()
+        ops.prof_enable(False)
+        if args.kernel_times:
+            tot = sum(r[2] for r in recs)
+            for name, n, ms in sorted(recs, key=lambda r: -r[2]):
+                print("  %-22s launches/step %5.1f  ms/step %8.4f  %5.1f%%" % (name, n / reps, ms / reps, 100 * ms / tot),
+                      file=sys.stderr)
+        by = {r[0]: r for r in recs}
+        if w['model'] == 'cl_vrnn':
+            # dominant kernel: the persistent LSTM sequence kernels (fwd+bwd, 2 LSTMs each)
+            n = by['lstm_seq_fwd'][1] + by['lstm_seq_bwd'][1]
+            ms = by['lstm_seq_fwd'][2] + by['lstm_seq_bwd'][2]
+            avg_s = ms / n * 1e-3
+            achieved = lstm_seq_flops(w, B) / avg_s / 1e12
+            kname = 'lstm_seq_fwd+lstm_seq_bwd'
+        else:
+            n, ms = by['gemm_f32'][1], by['gemm_f32'][2]
+            avg_s = ms / n * 1e-3
+            achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
+            kname = 'gemm_f32'
+        roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None, kernel=kname,
+                        avg_launch_us=round(avg_s * 1e6, 2),
+                        whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w)
+
+    if rank == 0:
+        out = {
+            "metric": "piano-roll timesteps/sec (train)", "value": round(value, 1), "unit": "timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s batch %d/GPU x seq_len %d, latent %d, %d classes, 88-dim piano-roll, "
+                                   "Adam-WN, hipGraph=%s" % (args.workload, w['model'], B, T, w['L'], w['C'],
+                                                             not args.no_graph),
+                       "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
+            "final_loss": round(float(loss['total']), 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -389,7 +389,18 @@ class VrnnEngine(_EngineBase):
             dU.zero_()
         ops.colsum(dzsum, B, G4, P.g(name + '/bias'), ws)
 
-    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True):
+    def grads_tail(self, X):
+        """hW kernel gradient: the last and largest (T*D*D floats) product of the backward pass."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, T = cfg['D'], cfg['T']
+        ops.gemm(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=self.ws)
+
+    def tail_range(self):
+        """(offset, numel) of the tail bucket inside the flat gradient buffer."""
+        D, T = self.cfg['D'], self.cfg['T']
+        return self.P.offsets['hW/kernel'], T * D * D
+
+    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True):
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
@@ -439,5 +450,6 @@ class VrnnEngine(_EngineBase):
         g(self.hW, self.dwargs, P.g('Wargs/kernel'), D, 2 * C1, B, ta=True, ws=ws)
         ops.colsum(self.dwargs, B, 2 * C1, P.g('Wargs/bias'), ws)
         g(self.dwargs, P.p('Wargs/kernel'), self.dhW, B, D, 2 * C1, tb=True, act=ACT_MASKPOS, aux=self.hW, ws=ws)
-        g(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)
         ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
+        if do_tail:
+            self.grads_tail(X)

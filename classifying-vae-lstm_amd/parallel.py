@@ -1,0 +1,101 @@
+"""Data parallelism for the training step: one process per GPU, torch.distributed (RCCL on
+ROCm, gloo in the CPU tests), no collective on the data path except ONE gradient all-reduce
+per step over the flat fp32 gradient buffer, issued in two buckets on a side HIP stream so the
+first bucket overlaps the hW weight-gradient GEMM.
+
+The reference has no distributed code; this layer is new.  Sharding contract:
+  * global batch = world * local batch; rank r owns global rows [r*B, (r+1)*B) of every batch;
+  * noise is drawn from the counter-based Philox stream at GLOBAL sample indices, so the
+    same global batch sees the same eps at any world size;
+  * gradients are averaged (sum / world) => equal to the global-batch mean the reference's
+    single-process fit() would compute;
+  * parameters and optimizer state are replicated (weight-norm needs whole columns).
+"""
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* if world > 1."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_rows(global_batch, rank, world):
+    """[start, stop) of this rank's rows inside a global batch (must divide evenly, like
+    PianoData.adjust_for_batch_size guarantees for batch_size in the reference)."""
+    if global_batch % world:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_batch, world))
+    b = global_batch // world
+    return rank * b, (rank + 1) * b
+
+
+def eps_first_index(global_row0, per_row):
+    """First Philox element index of this rank's slice when every global row owns `per_row` draws."""
+    return int(global_row0) * int(per_row)
+
+
+class GradAllReduce:
+    """Bucketed average of a flat gradient tensor: bucket 'main' = everything except the tail
+    range, bucket 'tail' = [tail_off, tail_off + tail_n).  On CUDA tensors the collectives run on
+    a side stream; `wait()` joins it back into the current stream."""
+
+    def __init__(self, flat_grads, tail_off=0, tail_n=0, group=None):
+        self.flat = flat_grads
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = flat_grads.numel()
+        self.tail = flat_grads[tail_off:tail_off + tail_n] if tail_n else None
+        self.main = []
+        if tail_n:
+            if tail_off > 0:
+                self.main.append(flat_grads[:tail_off])
+            if tail_off + tail_n < n:
+                self.main.append(flat_grads[tail_off + tail_n:])
+        else:
+            self.main.append(flat_grads)
+        self.cuda = flat_grads.is_cuda
+        self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
+
+    def _reduce(self, t):
+        if self.world == 1:
+            return
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.div_(self.world)
+
+    def _on_side(self, tensors):
+        if self.world == 1:
+            return
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                for t in tensors:
+                    self._reduce(t)
+        else:
+            for t in tensors:
+                self._reduce(t)
+
+    def reduce_main(self):
+        self._on_side(self.main)
+
+    def reduce_tail(self):
+        if self.tail is not None:
+            self._on_side([self.tail])
+
+    def wait(self):
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.side)

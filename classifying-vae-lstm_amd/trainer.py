@@ -1,0 +1,115 @@
+"""One optimisation step of cl_vrnn / cl_vae on the HIP path, graph-captured.
+
+Replaces the per-batch body of Keras Model.fit() at cl_vae/train.py:66-71 and
+cl_vrnn/train.py:66-71: noise draw -> forward -> 4 losses -> backward ->
+(data-parallel gradient average) -> Adam-with-weight-norm update.
+
+Everything step-dependent lives on the device (Adam `iterations` counter, which also keys
+the Philox noise stream), so the captured hipGraph is replayed unchanged every step; the
+batch is staged into fixed buffers (`stage_batch`).
+"""
+import torch
+
+from . import ops
+from .parallel import GradAllReduce, eps_first_index
+
+
+class TrainStep:
+    def __init__(self, engine, seed=1234, rank=0, world=1, group=None, optimizer='adam-wn',
+                 lr=1e-3, use_graph=True):
+        self.eng = engine
+        self.seed, self.rank, self.world = int(seed), int(rank), int(world)
+        self.weightnorm = optimizer == 'adam-wn'
+        if optimizer not in ('adam-wn', 'adam'):
+            raise ValueError("optimizer %r is not supported on the HIP path (adam-wn, adam)" % optimizer)
+        self.lr = lr
+        self.use_graph = use_graph
+        cfg, B, d = engine.cfg, engine.B, engine.device
+        self.is_vrnn = 'T' in cfg
+        T = cfg['T'] if self.is_vrnn else 1
+        D, L, C1 = cfg['D'], cfg['L'], cfg['C'] - 1
+        f = dict(dtype=torch.float32, device=d)
+        shp = (B, T, D) if self.is_vrnn else (B, D)
+        self.X = torch.zeros(*shp, **f)
+        self.Xp = torch.zeros(*shp, **f)
+        self.w_true = torch.zeros(B, cfg['C'], **f)
+        self.eps_w = torch.zeros(B, C1, **f)
+        self.eps_z = torch.zeros(B * T, L, **f)
+        tail = engine.tail_range() if self.is_vrnn else (0, 0)
+        self.ar = GradAllReduce(engine.P.grads, tail[0], tail[1], group) if world > 1 else None
+        self._graphs = None
+        self._warm = False
+
+    # -- pieces -----------------------------------------------------------
+    def draw_noise(self):
+        eng, B = self.eng, self.eng.B
+        C1, L = eng.cfg['C'] - 1, eng.cfg['L']
+        T = eng.cfg['T'] if self.is_vrnn else 1
+        row0 = self.rank * B                         # global row of this rank's first sample
+        it = eng.P.iterations
+        ops.philox_normal(self.eps_w, B * C1, self.seed, 0, 0, eps_first_index(row0, C1), step_dev=it)
+        ops.philox_normal(self.eps_z, B * T * L, self.seed, 0, 1, eps_first_index(row0, T * L), step_dev=it)
+
+    def _main(self):
+        self.draw_noise()
+        if self.is_vrnn:
+            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, do_tail=False)
+        else:
+            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z)
+
+    def _tail(self):
+        if self.is_vrnn:
+            self.eng.grads_tail(self.X)
+
+    def _update(self):
+        self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm)
+
+    # -- public -----------------------------------------------------------
+    def stage_batch(self, X, Xp, w_true):
+        """Copy one batch (device tensors) into the fixed staging buffers."""
+        self.X.copy_(X.view_as(self.X))
+        if Xp is not None:
+            self.Xp.copy_(Xp.view_as(self.Xp))
+        self.w_true.copy_(w_true)
+
+    def _eager(self):
+        self._main()
+        if self.ar is not None:
+            self.ar.reduce_main()
+        self._tail()
+        if self.ar is not None:
+            self.ar.reduce_tail()
+            self.ar.wait()
+        self._update()
+
+    def step(self):
+        if not self.use_graph:
+            self._eager()
+            return
+        if not self._warm:               # first call sizes every workspace; graphs come next
+            self._eager()
+            self._warm = True
+            return
+        if self._graphs is None:
+            if self.ar is None:
+                with ops.Graph() as g:
+                    self._main(); self._tail(); self._update()
+                self._graphs = (g,)
+            else:
+                with ops.Graph() as g1:
+                    self._main()
+                with ops.Graph() as g2:
+                    self._tail()
+                with ops.Graph() as g3:
+                    self._update()
+                self._graphs = (g1, g2, g3)
+        if self.ar is None:
+            self._graphs[0].launch()
+        else:
+            g1, g2, g3 = self._graphs
+            g1.launch()
+            self.ar.reduce_main()
+            g2.launch()
+            self.ar.reduce_tail()
+            self.ar.wait()
+            g3.launch()
