@@ -192,7 +192,10 @@ def main():
             for name, n, ms in sorted(recs, key=lambda r: -r[2]):
                 print("  %-22s launches/step %5.1f  ms/step %8.4f  %5.1f%%" % (name, n / reps, ms / reps, 100 * ms / tot),
                       file=sys.stderr)
-        by = {r[0]: r for r in recs}
+        by = {}
+        for r in recs:
+            k = "gemm_f32" if r[0].startswith("gemm ") else r[0]
+            by[k] = (k, by.get(k, (k, 0, 0.0))[1] + r[1], by.get(k, (k, 0, 0.0))[2] + r[2])
         if w['model'] == 'cl_vrnn':
             # dominant kernel: the persistent LSTM sequence kernels (fwd+bwd, 2 LSTMs each)
             n = by['lstm_seq_fwd'][1] + by['lstm_seq_bwd'][1]

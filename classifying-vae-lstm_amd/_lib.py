@@ -35,6 +35,7 @@ SIGNATURES = {
     "clv_version": (_i, []),
     "clv_device_count": (_i, []),
     "clv_error_string": (C.c_char_p, [_i]),
+    "clv_gemm_auto_split": (_i, [_i, _i, _i]),
     "clv_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p]),
     "clv_colsum_workspace_bytes": (_sz, [_i, _i]),

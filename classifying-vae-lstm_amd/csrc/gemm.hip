@@ -8,6 +8,8 @@
 // Tile: BM = 16*WM*WAVES_M, BN = 16*WN*WAVES_N, BK = 16, 256 threads (4 waves).
 // LDS holds both operands k-major ([k][m] / [k][n]) with a row stride == 16
 // (mod 32) floats so the two k-rows a half-wave reads land on disjoint banks.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace clv {
@@ -202,11 +204,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// sum of `splits` partial slabs + epilogue.  64 outputs x 4 slab-lanes per block, 8 loads in flight
+// per thread (a serial loop over the slabs is latency-bound: ~0.5 us per dependent HBM load).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int splits) {
+  __shared__ float red[4][64];
   const size_t mn = (size_t)g.M * g.N;
-  for (size_t idx = blockIdx.x * 256 + threadIdx.x; idx < mn; idx += (size_t)gridDim.x * 256) {
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += g.partial[z * mn + idx];
+  const int ex = threadIdx.x & 63, zy = threadIdx.x >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + ex;
+  float v = 0.f;
+  if (idx < mn) {
+    const float* p = g.partial + idx;
+    int z = zy;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    for (; z + 28 < splits; z += 32) {
+      a0 += p[(size_t)(z + 0) * mn]; a1 += p[(size_t)(z + 4) * mn]; a2 += p[(size_t)(z + 8) * mn];
+      a3 += p[(size_t)(z + 12) * mn]; a4 += p[(size_t)(z + 16) * mn]; a5 += p[(size_t)(z + 20) * mn];
+      a6 += p[(size_t)(z + 24) * mn]; a7 += p[(size_t)(z + 28) * mn];
+    }
+    for (; z < splits; z += 4) a0 += p[(size_t)z * mn];
+    v = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  }
+  red[zy][ex] = v;
+  __syncthreads();
+  if (zy == 0 && idx < mn) {
+    v = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
     const int row = (int)(idx / g.N), col = (int)(idx % g.N);
     v *= g.alpha;
     if (g.bias) v += g.bias[col];
@@ -227,27 +248,53 @@ static void launch_cfg(const GemmArgs& g, int ta, int tb, int splits, hipStream_
   else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, true, true>), grid, dim3(256), 0, s, g);
 }
 
-// tile choice by output shape (all shapes of the path: N in {2..352}, M in {10..262144})
+// tile choice by output shape (all shapes of the path: N in {1..352}, M in {2..262144})
+enum TileCfg { T128x16, T64x32, T64x64, T96x96, T64x96, T64x176 };
+static TileCfg pick_tile(int M, int N) {
+  if (N <= 16) return T128x16;
+  if (N <= 32) return T64x32;
+  if (N <= 64) return T64x64;
+  if (N <= 96) return M <= 96 ? T96x96 : T64x96;
+  if (N % 176 == 0 || N > 256) return M <= 96 ? T96x96 : T64x176;
+  return T64x64;
+}
+static void tile_dims(TileCfg c, int& bm, int& bn) {
+  switch (c) {
+    case T128x16: bm = 128; bn = 16; break;
+    case T64x32: bm = 64; bn = 32; break;
+    case T64x64: bm = 64; bn = 64; break;
+    case T96x96: bm = 96; bn = 96; break;
+    case T64x96: bm = 64; bn = 96; break;
+    default: bm = 64; bn = 176; break;
+  }
+}
+// split K until ~4 workgroups per CU are in flight (each k-tile is a dependent HBM round trip, so a
+// few long workgroups are latency-bound); chunks stay >= 32 deep.
+static int auto_split(int M, int N, int K) {
+  int bm, bn;
+  tile_dims(pick_tile(M, N), bm, bn);
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  if (tiles >= 512 || K < 64) return 1;
+  long s = (1024 + tiles - 1) / tiles;
+  if (s > K / 32) s = K / 32;
+  if (s > 512) s = 512;
+  return s < 1 ? 1 : (int)s;
+}
+
 static void launch_gemm(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
-  const int M = g.M, N = g.N;
-  if (N <= 16) {
-    launch_cfg<2, 1, 4, 1>(g, ta, tb, splits, s);            // 128 x 16
-  } else if (N <= 32) {
-    launch_cfg<1, 2, 4, 1>(g, ta, tb, splits, s);            // 64 x 32
-  } else if (N <= 64) {
-    launch_cfg<2, 2, 2, 2>(g, ta, tb, splits, s);            // 64 x 64
-  } else if (N <= 96) {
-    if (M <= 96) launch_cfg<3, 3, 2, 2>(g, ta, tb, splits, s);   // 96 x 96
-    else launch_cfg<1, 6, 4, 1>(g, ta, tb, splits, s);           // 64 x 96
-  } else if (N % 176 == 0 || N > 256) {
-    if (M <= 96) launch_cfg<3, 3, 2, 2>(g, ta, tb, splits, s);   // 96 x 96 (weight grads, split-K)
-    else launch_cfg<1, 11, 4, 1>(g, ta, tb, splits, s);          // 64 x 176
-  } else {
-    launch_cfg<2, 2, 2, 2>(g, ta, tb, splits, s);
+  switch (pick_tile(g.M, g.N)) {
+    case T128x16: launch_cfg<2, 1, 4, 1>(g, ta, tb, splits, s); break;
+    case T64x32: launch_cfg<1, 2, 4, 1>(g, ta, tb, splits, s); break;
+    case T64x64: launch_cfg<2, 2, 2, 2>(g, ta, tb, splits, s); break;
+    case T96x96: launch_cfg<3, 3, 2, 2>(g, ta, tb, splits, s); break;
+    case T64x96: launch_cfg<1, 6, 4, 1>(g, ta, tb, splits, s); break;
+    default: launch_cfg<1, 11, 4, 1>(g, ta, tb, splits, s); break;
   }
 }
 
 }  // namespace clv
+
+extern "C" int clv_gemm_auto_split(int M, int N, int K) { return clv::auto_split(M, N, K); }
 
 extern "C" size_t clv_gemm_workspace_bytes(int M, int N, int split_k) {
   if (split_k <= 1) return 0;
@@ -270,7 +317,7 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
   g.bias = bias; g.act = act; g.aux = aux;
   g.vecA = (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
   g.vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
-  int splits = split_k < 1 ? 1 : split_k;
+  int splits = split_k < 1 ? auto_split(M, N, K) : split_k;
   int kc = (K + splits - 1) / splits;
   kc = (kc + 15) / 16 * 16;
   if (kc == 0) kc = 16;
@@ -284,7 +331,10 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
     g.partial = (float*)ws;
   }
   {
-    ProfScope p("gemm_f32", s);
+    char label[48] = "gemm_f32";
+    if (prof_on() && getenv("CLV_PROF_SHAPES"))
+      snprintf(label, sizeof(label), "gemm %dx%dx%d %c%c s%d", M, N, K, transa ? 'T' : 'N', transb ? 'T' : 'N', splits);
+    ProfScope p(label, s);
     launch_gemm(g, transa != 0, transb != 0, splits, s);
   }
   int st = launch_status();
@@ -292,9 +342,7 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
   if (splits > 1) {
     ProfScope p("gemm_splitk_reduce", s);
     size_t mn = (size_t)M * N;
-    int blocks = (int)((mn + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, g, splits);
     st = launch_status();
   }
   return st;

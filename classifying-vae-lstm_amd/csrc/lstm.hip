@@ -59,7 +59,7 @@ struct LstmFwdArgs {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <int R, int GATE>
+template <int R, int GATE, bool SAVE>
 __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   constexpr int NC = 8 / R;            // lane copies per (row, unit)
   constexpr int NX = (4 * R + 7) / 8;  // xproj loads per lane per step
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   for (int i = 0; i < NX; ++i) {
     const int e = s + 8 * i;
     xok[i] = e < 4 * R;
-    const int rr = xok[i] ? (e >> 2) : 0, gg = e & 3;
+    const int rr = xok[i] ? (e >> 2) : 0, gg = e & 3;   // surplus lanes re-read a valid element
     xoff[i] = (size_t)(row0 + rr) * T * LG + gg * LH + u;
     rb[i] = (xok[i] && a.rowbias) ? a.rowbias[(size_t)(row0 + rr) * LG + gg * LH + u] : 0.f;
   }
@@ -99,8 +99,27 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
   float xn[NX];
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xn[i] = (xok[i] && T > 0) ? a.xproj[xoff[i]] : 0.f;
+  for (int i = 0; i < NX; ++i) xn[i] = T > 0 ? a.xproj[xoff[i]] : 0.f;
   __syncthreads();
+
+  // output slots of this lane (loop-invariant): slot 0 h, 1 c, 2..5 gates (z_i, z_f, g, z_o)
+  constexpr int NS = (6 + NC - 1) / NC;
+  float* optr[NS];
+  int ostr[NS], oslot[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    int slot = copy + j * NC;
+    slot = slot < 6 ? slot : slot - 6;                    // surplus copies repeat slot 0/1 (same value, same address)
+    oslot[j] = slot;
+    const size_t bt0 = (size_t)(row0 + myrow) * T;
+    if (SAVE) {
+      optr[j] = slot == 0 ? a.hs + bt0 * LH + u : slot == 1 ? a.cs + bt0 * LH + u : a.gates + bt0 * LG + (slot - 2) * LH + u;
+      ostr[j] = slot < 2 ? LH : LG;
+    } else {
+      optr[j] = a.hs + bt0 * LH + u;
+      ostr[j] = LH;
+    }
+  }
 
   float hlast = 0.f;
   for (int t = 0; t < T; ++t) {
@@ -109,7 +128,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       xv[i] = xn[i] + rb[i];
-      if (t + 1 < T && xok[i]) xn[i] = a.xproj[xoff[i] + (size_t)(t + 1) * LG];   // prefetch
+      xn[i] = a.xproj[xoff[i] + (size_t)min(t + 1, T - 1) * LG];   // prefetch, unconditional (clamped)
     }
     // acc[r][g] starts from the lane's xproj share, then 11 FMAs per gate
     float acc[R][4];
@@ -117,9 +136,8 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        constexpr int dummy = 0; (void)dummy;
         const int e = r * 4 + g;              // compile-time
-        acc[r][g] = (s == (e & 7)) ? xv[e >> 3] : 0.f;
+        acc[r][g] = (s == (e & 7) && xok[e >> 3]) ? xv[e >> 3] : 0.f;
       }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -148,19 +166,20 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     c = fg * c + ig * gg;
     const float h = og * fast_tanh(c);
     hlast = h;
-    if (copy == 0) hbuf[cur ^ 1][myrow][12 * (u / 11) + (u % 11)] = h;
-    // outputs: 6 arrays shared among the NC copies
-    const size_t bt = (size_t)(row0 + myrow) * T + t;
-    if (copy == 0 % NC) a.hs[bt * LH + u] = h;
-    if (copy == 1 % NC) a.cs[bt * LH + u] = c;
-    if (a.gates) {
-      float* gp = a.gates + bt * LG + u;
-      if (copy == 2 % NC) gp[0] = z[0];
-      if (copy == 3 % NC) gp[LH] = z[1];
-      if (copy == 4 % NC) gp[2 * LH] = gg;
-      if (copy == 5 % NC) gp[3 * LH] = z[3];
+    hbuf[cur ^ 1][myrow][12 * (u / 11) + (u % 11)] = h;     // all copies write the same value
+    // outputs: 6 values per (row, unit) shared among the NC lane copies.  Every lane issues the same
+    // number of stores, unconditionally, so the next step's wait on the prefetched xproj is a counted
+    // vmcnt(#stores) instead of a drain of these stores (vmcnt retires in issue order).
+    const float ov[6] = {h, c, z[0], z[1], gg, z[3]};
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      float val = ov[0];
+#pragma unroll
+      for (int q = 1; q < 6; ++q) val = (oslot[j] == q) ? ov[q] : val;
+      *optr[j] = SAVE ? val : h;
+      optr[j] += ostr[j];
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if (copy == 0) {
     if (a.hT) a.hT[(size_t)(row0 + myrow) * LH + u] = T > 0 ? hlast : (a.h0 ? a.h0[(size_t)(row0 + myrow) * LH + u] : 0.f);
@@ -206,22 +225,63 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
   const size_t rowbt = (size_t)(row0 + myrow) * T;
   float dc = 0.f;
   float zs[4] = {0.f, 0.f, 0.f, 0.f};   // running sum_t dz (this lane's row/unit)
-  // prefetch registers for step t
-  float p_zi = 0.f, p_zf = 0.f, p_g = 0.f, p_zo = 0.f, p_c = 0.f, p_cp = 0.f, p_dh = 0.f;
-  auto prefetch = [&](int t) {
-    const size_t bt = rowbt + t;
-    const float* gp = a.gates + bt * LG + u;
-    p_zi = gp[0]; p_zf = gp[LH]; p_g = gp[2 * LH]; p_zo = gp[3 * LH];
-    p_c = a.cs[bt * LH + u];
-    p_cp = t > 0 ? a.cs[(bt - 1) * LH + u] : (a.c0 ? a.c0[(size_t)(row0 + myrow) * LH + u] : 0.f);
-    p_dh = a.dhs[bt * LH + u];
+
+  // Two-stage software pipeline.  Everything that does not depend on the recurrence (gate
+  // activations, tanh(c_t), gate derivatives) is folded into 7 coefficients per step, computed one
+  // iteration ahead from values loaded two iterations ahead, so a load has a full step to land and
+  // the per-step critical path is: reduce -> 8 multiply/adds -> LDS write -> barrier.
+  struct Raw { float zi, zf, g, zo, c, cp, dh; };
+  struct Coef { float ko, kc, ki, kf, kg, kcarry, dhh; };
+  // Loads are unconditional and branch-free (the step index is clamped instead), so the compiler can
+  // count them: a wait for the previous load set is vmcnt(#younger ops) and never drains the dz store.
+  const float* g_base = a.gates + rowbt * LG + u;
+  const float* c_base = a.cs + rowbt * LH + u;
+  const float* d_base = a.dhs + rowbt * LH + u;
+  const float c0v = a.c0 ? a.c0[(size_t)(row0 + myrow) * LH + u] : 0.f;
+  auto load_raw = [&](int t) {                     // t >= 0 (clamped by the caller)
+    Raw r;
+    const float* gp = g_base + (size_t)t * LG;
+    r.zi = gp[0]; r.zf = gp[LH]; r.g = gp[2 * LH]; r.zo = gp[3 * LH];
+    r.c = c_base[(size_t)t * LH];
+    const float cprev = c_base[(size_t)max(t - 1, 0) * LH];
+    r.cp = t > 0 ? cprev : c0v;
+    r.dh = d_base[(size_t)t * LH];
+    return r;
   };
-  if (T > 0) prefetch(T - 1);
+  auto make_coef = [&](const Raw& r) {
+    Coef k;
+    const float ig = gate_fn<GATE>(r.zi), fg = gate_fn<GATE>(r.zf), og = gate_fn<GATE>(r.zo);
+    const float tc = fast_tanh(r.c);
+    k.ko = tc * gate_grad<GATE>(r.zo, og);          // dz_o = dh * ko
+    k.kc = og * (1.f - tc * tc);                    // dc  += dh * kc
+    k.ki = r.g * gate_grad<GATE>(r.zi, ig);         // dz_i = dc * ki
+    k.kf = r.cp * gate_grad<GATE>(r.zf, fg);        // dz_f = dc * kf
+    k.kg = ig * (1.f - r.g * r.g);                  // dz_g = dc * kg
+    k.kcarry = fg;                                  // dc_{t-1} = dc * f
+    k.dhh = r.dh;
+    return k;
+  };
+  Raw raw_next = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  Coef coef_next = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (T > 0) {
+    coef_next = make_coef(load_raw(T - 1));
+    raw_next = load_raw(max(T - 2, 0));
+  }
+  // One store after the prologue's loads, exactly like every loop iteration issues one after its
+  // loads: the waitcnt pass merges the loop-entry and back-edge states, and with matching queues
+  // the wait for `raw_next` stays vmcnt(#younger ops) instead of draining the previous dz store.
+  a.dzsum[(size_t)(row0 + myrow) * LG + (copy & 3) * LH + u] = 0.f;
+  constexpr int NSB = (4 + NC - 1) / NC;
+  float* gptr[NSB];
+#pragma unroll
+  for (int j = 0; j < NSB; ++j) gptr[j] = a.gates + (rowbt + (T > 0 ? T - 1 : 0)) * LG + ((copy + j * NC) & 3) * LH + u;
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
     const int cur = (T - 1 - t) & 1;
-    const float zi = p_zi, zf = p_zf, g = p_g, zo = p_zo, ct = p_c, cp = p_cp, dhh = p_dh;
+    const Coef k = coef_next;
+    const Raw rcur = raw_next;                     // values of step t-1 (loaded one iteration ago)
+    raw_next = load_raw(max(t - 2, 0));            // lands during this whole iteration (redundant for t < 2)
     // dh_rec[u] = sum_c dz_{t+1}[c] * U[u][c]
     float part[R];
 #pragma unroll
@@ -238,48 +298,49 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
       }
       part[r] = acc0 + acc1;
     }
-    if (t > 0) prefetch(t - 1);   // loads for the next iteration; gates[t-1] is not written this step
+    coef_next = make_coef(rcur);                   // off the critical path (unused after t == 0)
 #pragma unroll
     for (int r = 0; r < R; ++r) part[r] = reduce8(part[r]);
     float dhrec = part[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) dhrec = (myrow == r) ? part[r] : dhrec;
 
-    const float ig = gate_fn<GATE>(zi), fg = gate_fn<GATE>(zf), og = gate_fn<GATE>(zo);
-    const float tc = fast_tanh(ct);
-    const float dh = dhh + dhrec;
-    const float d_o = dh * tc;
-    dc = dc + dh * og * (1.f - tc * tc);
+    const float dh = k.dhh + dhrec;
+    dc = fmaf(dh, k.kc, dc);
     float dz[4];
-    dz[0] = dc * g * gate_grad<GATE>(zi, ig);
-    dz[1] = dc * cp * gate_grad<GATE>(zf, fg);
-    dz[2] = dc * ig * (1.f - g * g);
-    dz[3] = d_o * gate_grad<GATE>(zo, og);
-    dc = dc * fg;
-    float* gp = a.gates + (rowbt + t) * LG + u;
+    dz[0] = dc * k.ki;
+    dz[1] = dc * k.kf;
+    dz[2] = dc * k.kg;
+    dz[3] = dh * k.ko;
+    dc = dc * k.kcarry;
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      zs[gi] += dz[gi];
-      if (copy == gi % NC) {
-        dzbuf[cur ^ 1][myrow][gi * LH + u] = dz[gi];
-        gp[gi * LH] = dz[gi];
-      }
+    for (int gi = 0; gi < 4; ++gi) zs[gi] += dz[gi];
+    // 4 values per (row, unit) shared among NC copies; copies beyond the 4th repeat (unconditional stores)
+#pragma unroll
+    for (int j = 0; j < NSB; ++j) {
+      const int slot = (copy + j * NC) & 3;
+      float val = dz[0];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) val = (slot == q) ? dz[q] : val;
+      dzbuf[cur ^ 1][myrow][slot * LH + u] = val;
+      *gptr[j] = val;
+      gptr[j] -= LG;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  if (a.dzsum) {
+  {
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi)
-      if (copy == gi % NC) a.dzsum[(size_t)(row0 + myrow) * LG + gi * LH + u] = zs[gi];
+      if (copy == gi % NC || NC > 4 && copy == gi) a.dzsum[(size_t)(row0 + myrow) * LG + gi * LH + u] = zs[gi];
   }
 }
 
-template <int GATE>
+template <int GATE, bool SAVE>
 static int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
   const int B = a.B;
-  if (B % 4 == 0 && B >= 2048) hipLaunchKernelGGL((lstm_fwd_kernel<4, GATE>), dim3(B / 4), dim3(LTHREADS), 0, s, a);
-  else if (B % 2 == 0 && B >= 1024) hipLaunchKernelGGL((lstm_fwd_kernel<2, GATE>), dim3(B / 2), dim3(LTHREADS), 0, s, a);
-  else hipLaunchKernelGGL((lstm_fwd_kernel<1, GATE>), dim3(B), dim3(LTHREADS), 0, s, a);
+  if (B % 4 == 0 && B >= 2048) hipLaunchKernelGGL((lstm_fwd_kernel<4, GATE, SAVE>), dim3(B / 4), dim3(LTHREADS), 0, s, a);
+  else if (B % 2 == 0 && B >= 1024) hipLaunchKernelGGL((lstm_fwd_kernel<2, GATE, SAVE>), dim3(B / 2), dim3(LTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((lstm_fwd_kernel<1, GATE, SAVE>), dim3(B), dim3(LTHREADS), 0, s, a);
   return launch_status();
 }
 template <int GATE>
@@ -299,20 +360,22 @@ extern "C" int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
                                 float* hs, float* cs, float* gates, float* hT, float* cT,
                                 void* stream) {
   using namespace clv;
-  if (H != LH || B <= 0 || T < 0 || !xproj || !U || !hs || !cs) return CLV_EINVAL;
+  if (H != LH || B <= 0 || T < 0 || !xproj || !U || !hs || (gates && !cs)) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
   LstmFwdArgs a{B, T, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_seq_fwd", s);
-  return gate_act == CLV_GATE_HARD_SIGMOID ? launch_fwd<CLV_GATE_HARD_SIGMOID>(a, s)
-                                           : launch_fwd<CLV_GATE_SIGMOID>(a, s);
+  const bool save = gates != nullptr;
+  if (gate_act == CLV_GATE_HARD_SIGMOID)
+    return save ? launch_fwd<CLV_GATE_HARD_SIGMOID, true>(a, s) : launch_fwd<CLV_GATE_HARD_SIGMOID, false>(a, s);
+  return save ? launch_fwd<CLV_GATE_SIGMOID, true>(a, s) : launch_fwd<CLV_GATE_SIGMOID, false>(a, s);
 }
 
 extern "C" int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
                                 const float* U, const float* dhs, const float* cs, const float* c0,
                                 float* gates_inout_dz, float* dzsum, void* stream) {
   using namespace clv;
-  if (H != LH || B <= 0 || T < 0 || !U || !dhs || !cs || !gates_inout_dz) return CLV_EINVAL;
+  if (H != LH || B <= 0 || T < 0 || !U || !dhs || !cs || !gates_inout_dz || !dzsum) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
   LstmBwdArgs a{B, T, U, dhs, cs, c0, gates_inout_dz, dzsum};
   hipStream_t s = (hipStream_t)stream;

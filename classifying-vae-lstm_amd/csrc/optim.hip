@@ -5,15 +5,18 @@
 // Work is cut into units of <= 64 rows of one tensor (all its columns).  The two
 // per-column reductions (||V||^2 and sum g.V before the update, ||V'||^2 after)
 // go through deterministic partial slabs, not atomics:
-//   K1 stats   : partial (sum V^2, sum g.V) per unit and column
-//   K2 columns : per column: ||V||, grad_g, Adam on g  -> column scalars
-//   K3 update  : grad_V, Adam on V, W <- V', partial sum V'^2 ; biases: plain Adam
-//   K4 rescale : s' = g'/||V'||, W <- s'.V', s <- s' ; advances `iterations`
+//   K1 stats    : partial (sum V^2, sum g.V) per unit and column
+//   K2 columns  : per column: ||V||, grad_g, Adam on g  -> column scalars
+//   K3 update   : grad_V, Adam on V, W <- V', partial sum V'^2 ; biases: plain Adam
+//   K4 columns2 : per column: s' = g'/||V'|| -> s ; advances `iterations`
+//   K5 rescale  : W <- s'.V'
+// The column kernels sum a tensor's per-unit partials with 64 columns x 4 unit-lanes per block and
+// several loads in flight (a serial loop over hW's 352 units would be latency-bound).
 #include "common.h"
 
 namespace clv {
 
-constexpr int UNIT_ROWS = 64;
+constexpr int UNIT_ROWS = 32;
 
 struct AdamUnit {
   int64_t offset;       // element offset of the tensor
@@ -70,17 +73,39 @@ __global__ __launch_bounds__(256) void wn_stats_kernel(const AdamUnit* units, co
   }
 }
 
-// colscal[4*j + {0,1,2,3}] = {1/s, grad_g/||V||, s, new_g}
-__global__ void wn_cols_kernel(int n_cols, const AdamCol* cols, const float* partA, const float* partB,
-                               const float* s, float* mg, float* vg, float* colscal, AdamHyper h) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_cols) return;
-  const AdamCol c = cols[j];
-  float a = 0.f, b = 0.f;
-  for (int k = 0; k < c.nunits; ++k) {
-    a += partA[c.part_base + k * c.cols + c.col_local];
-    b += partB[c.part_base + k * c.cols + c.col_local];
+// block = 64 consecutive global matrix columns x 4 unit-lanes; returns the column's sum of two slabs
+__device__ __forceinline__ void col_partial_sums(const AdamCol& c, const float* pa, const float* pb, int zy,
+                                                 float& a, float& b) {
+  const float* qa = pa + c.part_base + c.col_local;
+  const float* qb = pb ? pb + c.part_base + c.col_local : nullptr;
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  int k = zy;
+  for (; k + 4 < c.nunits; k += 8) {
+    a0 += qa[(size_t)k * c.cols]; a1 += qa[(size_t)(k + 4) * c.cols];
+    if (qb) { b0 += qb[(size_t)k * c.cols]; b1 += qb[(size_t)(k + 4) * c.cols]; }
   }
+  for (; k < c.nunits; k += 4) {
+    a0 += qa[(size_t)k * c.cols];
+    if (qb) b0 += qb[(size_t)k * c.cols];
+  }
+  a = a0 + a1; b = b0 + b1;
+}
+
+// colscal[4*j + {0,1,2,3}] = {1/s, grad_g/||V||, s, new_g}
+__global__ __launch_bounds__(256) void wn_cols_kernel(int n_cols, const AdamCol* cols, const float* partA,
+                                                      const float* partB, const float* s, float* mg, float* vg,
+                                                      float* colscal, AdamHyper h) {
+  __shared__ float ra[4][64], rbb[4][64];
+  const int cx = threadIdx.x & 63, zy = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cx;
+  float a = 0.f, b = 0.f;
+  AdamCol c;
+  if (j < n_cols) { c = cols[j]; col_partial_sums(c, partA, partB, zy, a, b); }
+  ra[zy][cx] = a; rbb[zy][cx] = b;
+  __syncthreads();
+  if (zy != 0 || j >= n_cols) return;
+  a = (ra[0][cx] + ra[1][cx]) + (ra[2][cx] + ra[3][cx]);
+  b = (rbb[0][cx] + rbb[1][cx]) + (rbb[2][cx] + rbb[3][cx]);
   const float lr_t = adam_lr_t(h);
   const float sc = s[c.col_global];
   const float Vn = sqrtf(a);
@@ -94,6 +119,25 @@ __global__ void wn_cols_kernel(int n_cols, const AdamCol* cols, const float* par
   colscal[4 * j + 1] = grad_g / Vn;
   colscal[4 * j + 2] = sc;
   colscal[4 * j + 3] = gparam - lr_t * mgn / (sqrtf(vgn) + h.eps);
+}
+
+// s' = g'/||V'|| per column -> colscal[4j+0] (reused) and the persistent s; advances `iterations`
+__global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol* cols, const float* partC, float* s,
+                                                       float* colscal, int32_t* iterations) {
+  __shared__ float ra[4][64];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && iterations) *iterations += 1;
+  const int cx = threadIdx.x & 63, zy = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cx;
+  float a = 0.f, b = 0.f;
+  AdamCol c;
+  if (j < n_cols) { c = cols[j]; col_partial_sums(c, partC, nullptr, zy, a, b); }
+  ra[zy][cx] = a;
+  __syncthreads();
+  if (zy != 0 || j >= n_cols) return;
+  a = (ra[0][cx] + ra[1][cx]) + (ra[2][cx] + ra[3][cx]);
+  const float snew = colscal[4 * j + 3] / sqrtf(a);
+  colscal[4 * j + 0] = snew;
+  s[c.col_global] = snew;
 }
 
 __global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, float* params, const float* grads,
@@ -141,28 +185,24 @@ __global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, f
   }
 }
 
-__global__ __launch_bounds__(256) void wn_rescale_kernel(const AdamUnit* units, const AdamCol* cols, float* params,
-                                                         float* s, const float* colscal, const int32_t* colidx0,
-                                                         const float* partC, int weightnorm, int32_t* iterations) {
-  if (blockIdx.x == 0 && threadIdx.x == 0 && iterations) *iterations += 1;
+__global__ __launch_bounds__(256) void wn_rescale_kernel(const AdamUnit* units, float* params, const float* colscal,
+                                                         const int32_t* colidx0) {
   const AdamUnit un = units[blockIdx.x];
-  if (!un.is_matrix || !weightnorm) return;
+  if (!un.is_matrix) return;
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int cbase = colidx0[blockIdx.x];
   for (int c0 = 0; c0 < un.cols; c0 += 64) {
     const int col = c0 + cx;
     if (col >= un.cols) continue;
-    const AdamCol c = cols[cbase + col];
-    float a = 0.f;
-    for (int k = 0; k < c.nunits; ++k) a += partC[c.part_base + k * c.cols + c.col_local];
-    const float snew = colscal[4 * (cbase + col) + 3] / sqrtf(a);
+    const float snew = colscal[4 * (cbase + col) + 0];
     for (int r = ry; r < un.nrows; r += 4) {
       const size_t o = un.offset + (size_t)(un.row0 + r) * un.cols + col;
       params[o] *= snew;
     }
-    if (un.row0 == 0 && ry == 0) s[un.col_offset + col] = snew;
   }
 }
+
+__global__ void adam_bump_kernel(int32_t* iterations) { *iterations += 1; }
 
 struct PlanCounts { int n_units, n_cols, n_part; };
 
@@ -255,14 +295,20 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   float* colscal = partC + c.n_part;
   AdamHyper h{lr, beta1, beta2, eps, weightnorm, step_t, iterations_dev};
   ProfScope pr("adam_wn_step", st);
-  if (weightnorm && c.n_cols > 0) {
+  const bool wn = weightnorm && c.n_cols > 0;
+  if (wn) {
     hipLaunchKernelGGL(wn_stats_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, s, partA, partB);
-    hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + 127) / 128), dim3(128), 0, st, c.n_cols, cols, partA, partB, s,
+    hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + 63) / 64), dim3(256), 0, st, c.n_cols, cols, partA, partB, s,
                        mg, vg, colscal, h);
   }
   hipLaunchKernelGGL(wn_update_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, m, v, colscal, colidx0,
                      partC, h);
-  hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, cols, params, s, colscal, colidx0,
-                     partC, weightnorm, iterations_dev);
+  if (wn) {
+    hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + 63) / 64), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
+                       iterations_dev);
+    hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, colscal, colidx0);
+  } else if (iterations_dev) {
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, iterations_dev);
+  }
   return launch_status();
 }

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(1024) void sum_strided_kernel(int n, const float* x
 }
 
 // column sums, stage 1: block (64 cols x 4 row-lanes) handles a chunk of rows
-constexpr int CS_ROWS = 512;
+constexpr int CS_ROWS = 64;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const float* X, int ldx, float* partial) {
   __shared__ float red[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -177,12 +177,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const
   __syncthreads();
   if (ry == 0 && col < N) partial[(size_t)blockIdx.y * N + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
 }
-__global__ void colsum_final_kernel(int N, int chunks, const float* partial, float beta, float* out) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+// stage 2: 64 columns x 4 chunk-lanes per block, 4 loads in flight per thread
+__global__ __launch_bounds__(256) void colsum_final_kernel(int N, int chunks, const float* partial, float beta, float* out) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, zy = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
   float acc = 0.f;
-  for (int c = 0; c < chunks; ++c) acc += partial[(size_t)c * N + col];
-  out[col] = (beta != 0.f ? beta * out[col] : 0.f) + acc;
+  if (col < N) {
+    const float* p = partial + col;
+    int c = zy;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (; c + 12 < chunks; c += 16) {
+      a0 += p[(size_t)(c + 0) * N]; a1 += p[(size_t)(c + 4) * N];
+      a2 += p[(size_t)(c + 8) * N]; a3 += p[(size_t)(c + 12) * N];
+    }
+    for (; c < chunks; c += 4) a0 += p[(size_t)c * N];
+    acc = (a0 + a1) + (a2 + a3);
+  }
+  red[zy][cx] = acc;
+  __syncthreads();
+  if (zy == 0 && col < N)
+    out[col] = (beta != 0.f ? beta * out[col] : 0.f) + ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
 __global__ void bernoulli_sample_kernel(int64_t n, const float* p, const float* u, float* x) {
@@ -268,7 +283,7 @@ extern "C" int clv_colsum_f32(int M, int N, const float* X, int ldx, float beta,
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("colsum", s);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, s, M, N, X, ldx, (float*)ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(64), 0, s, N, chunks, (const float*)ws, beta, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, N, chunks, (const float*)ws, beta, out);
   return launch_status();
 }
 

@@ -15,7 +15,7 @@ struct ProfState {
   struct Pending { std::string name; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<std::pair<std::string, std::pair<int, float>>> totals;   // insertion-ordered
-  const char* cur_name = nullptr;
+  std::string cur_name;
   hipEvent_t cur_a = nullptr;
 };
 static ProfState g_prof;

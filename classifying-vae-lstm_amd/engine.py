@@ -384,7 +384,7 @@ class VrnnEngine(_EngineBase):
             g(hs, dz.view(-1)[G4:], dU, H, G4, BT - 1, ta=True, ws=ws)
             if B > 1:
                 g(hs.view(-1)[(T - 1) * H:], dz.view(-1)[T * G4:], dU, H, G4, B - 1, ta=True, lda=T * H, ldb=T * G4,
-                  alpha=-1.0, beta=1.0, split_k=1, ws=ws)
+                  alpha=-1.0, beta=1.0, ws=ws)
         else:
             dU.zero_()
         ops.colsum(dzsum, B, G4, P.g(name + '/bias'), ws)

@@ -33,15 +33,6 @@ class Workspace:
         return self.buf
 
 
-def pick_split_k(M, N, K, cus=256):
-    """Split K so that small-output GEMMs (weight gradients, hW) still fill the chip."""
-    tiles = ((M + 63) // 64) * ((N + 95) // 96)
-    if tiles >= cus or K < 512:
-        return 1
-    s = max(1, min((2 * cus) // max(tiles, 1), K // 128))
-    return int(s)
-
-
 def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None, alpha=1.0, beta=0.0,
          bias=None, act=ACT_NONE, aux=None, split_k=None, ws=None):
     """C[M,N] = act(alpha*op(A).op(B) + bias + beta*C); A/B/C are tensors (possibly offset views)."""
@@ -50,7 +41,7 @@ def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None,
     ldb = ldb if ldb is not None else (K if tb else N)
     ldc = ldc if ldc is not None else N
     if split_k is None:
-        split_k = pick_split_k(M, N, K)
+        split_k = L.clv_gemm_auto_split(M, N, K)
     wsp, wsb = None, 0
     if split_k > 1:
         need = L.clv_gemm_workspace_bytes(M, N, split_k)

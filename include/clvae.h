@@ -56,7 +56,10 @@ const char* clv_error_string(int code);
  * ws >= clv_gemm_workspace_bytes(M,N,split_k).
  * Replaces every keras.layers.Dense / TimeDistributed(Dense) / LSTM input
  * projection matmul and their gradients: cl_vae/model.py:141-143,160-167,
- * 184-186; cl_vrnn/model.py:174-175,196-209,225-234. */
+ * 184-186; cl_vrnn/model.py:174-175,196-209,225-234.
+ * split_k <= 0 lets the library choose (clv_gemm_auto_split); the workspace must then hold
+ * clv_gemm_workspace_bytes(M, N, clv_gemm_auto_split(M, N, K)). */
+int clv_gemm_auto_split(int M, int N, int K);
 size_t clv_gemm_workspace_bytes(int M, int N, int split_k);
 int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
                  const float* A, int lda, const float* B, int ldb,
