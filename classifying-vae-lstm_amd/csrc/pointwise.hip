@@ -200,6 +200,26 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int N, int chunks, co
     out[col] = (beta != 0.f ? beta * out[col] : 0.f) + ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
+__global__ void axpy_kernel(int64_t n, float alpha, const float* x, float* y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += alpha * x[i];
+}
+
+// out[r, :] = src[idx[r], :]  (row gather: mini-batch assembly from the HBM-resident data set)
+__global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = row_elems / 4;
+  if (i >= rows * n4) return;
+  const int64_t r = i / n4, c = i % n4;
+  reinterpret_cast<float4*>(out + r * row_elems)[c] = reinterpret_cast<const float4*>(src + idx[r] * row_elems)[c];
+}
+__global__ void gather_rows_scalar_kernel(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * row_elems) return;
+  const int64_t r = i / row_elems, c = i % row_elems;
+  out[i] = src[idx[r] * row_elems + c];
+}
+
 __global__ void bernoulli_sample_kernel(int64_t n, const float* p, const float* u, float* x) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = (u[i] <= p[i]) ? 1.f : 0.f;
@@ -292,5 +312,29 @@ extern "C" int clv_bernoulli_sample(int64_t n, const float* p, const float* u, f
   hipStream_t s = (hipStream_t)stream;
   ProfScope pr("bernoulli_sample", s);
   hipLaunchKernelGGL(bernoulli_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, p, u, x);
+  return launch_status();
+}
+
+extern "C" int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream) {
+  if (n <= 0 || !x || !y) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope pr("axpy", s);
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, alpha, x, y);
+  return launch_status();
+}
+
+extern "C" int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out,
+                               void* stream) {
+  if (rows <= 0 || row_elems <= 0 || !src || !idx || !out) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope pr("gather_rows", s);
+  const bool vec = row_elems % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (vec) {
+    const int64_t n = rows * (row_elems / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems, src, idx, out);
+  } else {
+    const int64_t n = rows * row_elems;
+    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems, src, idx, out);
+  }
   return launch_status();
 }

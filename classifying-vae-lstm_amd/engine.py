@@ -232,6 +232,13 @@ class VaeEngine(_EngineBase):
         g(self.h_dec, P.p('x_decoded_mean/kernel'), self.logits, B, D, H, bias=P.p('x_decoded_mean/bias'), act=act,
           ws=self.ws)
 
+    def x_hat(self):
+        """sigmoid(logits) of the last forward -> self.dlogits (the Keras output `x_decoded_mean`)."""
+        cfg, P, B = self.cfg, self.P, self.B
+        ops.gemm(self.h_dec, P.p('x_decoded_mean/kernel'), self.dlogits, B, cfg['D'], cfg['H'],
+                 bias=P.p('x_decoded_mean/bias'), act=ACT_SIGMOID, ws=self.ws)
+        return self.dlogits
+
     def forward(self, x, xp, eps_w, eps_z, w_true=None):
         cfg, B = self.cfg, self.B
         L, Cn = cfg['L'], cfg['C']
@@ -369,6 +376,59 @@ class VrnnEngine(_EngineBase):
                          self.cs_dec, self.gates_dec, gate_act=self.gate_act)
         # output head (:229-234)
         g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
+
+    def x_hat(self):
+        """sigmoid(logits) of the last forward -> self.dlogits (the Keras output `X_decoded_mean`)."""
+        cfg, P = self.cfg, self.P
+        ops.gemm(self.hs_dec, P.p('X_decoded_mean/kernel'), self.dlogits, self.B * cfg['T'], cfg['D'], cfg['H'],
+                 bias=P.p('X_decoded_mean/bias'), act=ACT_SIGMOID, ws=self.ws)
+        return self.dlogits
+
+    # -- stateful single-step inference (the reference's stateful batch-1 sub-models,
+    #    cl_vrnn/model.py:116-162; here for any batch of independent sequences) -------------
+    def new_state(self, B):
+        d, H = self.device, self.cfg['H']
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=d)
+        return dict(B=B, h_enc=z(B, H), c_enc=z(B, H), h_dec=z(B, H), c_dec=z(B, H), gates=z(B, 4 * H),
+                    hs=z(B, H), zargs=z(B, 2 * self.cfg['L']), xhat=z(B, self.cfg['D']))
+
+    def encode_w(self, X, B):
+        """hW -> Wargs for B windows [B, T*D] (:174-181) -> self.wargs[:B]"""
+        cfg, P = self.cfg, self.P
+        D, T, C1 = cfg['D'], cfg['T'], cfg['C'] - 1
+        ops.gemm(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=self.ws)
+        ops.gemm(self.hW, P.p('Wargs/kernel'), self.wargs, B, 2 * C1, D, bias=P.p('Wargs/bias'), ws=self.ws)
+
+    def _lstm_step(self, name, st, hkey, ckey):
+        ops.lstm_seq_fwd(st['B'], 1, st['gates'], None, self.P.p(name + '/recurrent_kernel'), st['hs'], None, None,
+                         h0=st[hkey], c0=st[ckey], hT=st[hkey], cT=st[ckey], gate_act=self.gate_act)
+
+    def enc_step(self, x, w, st, rec_name='encoder_h'):
+        """one encoder-LSTM step on [x_t, w] + the Z heads -> st['zargs'] = [z_mean | z_log_var]"""
+        cfg, P, B = self.cfg, self.P, st['B']
+        D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
+        g, ws = ops.gemm, self.ws
+        g(x, P.p(rec_name + '/kernel'), st['gates'], B, 4 * H, D, ws=ws)
+        g(w, P.rows(P.params, rec_name + '/kernel', D), st['gates'], B, 4 * H, Cn, beta=1.0, bias=P.p(rec_name + '/bias'),
+          ws=ws)
+        self._lstm_step(rec_name, st, 'h_enc', 'c_enc')
+        g(st['hs'], P.p('Z_mean/kernel'), st['zargs'], B, L, H, ldc=2 * L, bias=P.p('Z_mean/bias'), ws=ws)
+        g(st['hs'], P.p('Z_log_var/kernel'), st['zargs'][:, L:], B, L, H, ldc=2 * L, bias=P.p('Z_log_var/bias'), ws=ws)
+
+    def dec_step(self, z, xp, w, st):
+        """one decoder-LSTM step on [x_{t-1}, z_t, w] + sigmoid head -> st['xhat']"""
+        cfg, P, B = self.cfg, self.P, st['B']
+        D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
+        g, ws, off = ops.gemm, self.ws, self.off
+        if cfg['use_x_prev']:
+            g(xp, P.p('decoder_h/kernel'), st['gates'], B, 4 * H, D, ws=ws)
+        g(z, P.rows(P.params, 'decoder_h/kernel', off), st['gates'], B, 4 * H, L,
+          beta=1.0 if cfg['use_x_prev'] else 0.0, ws=ws)
+        g(w, P.rows(P.params, 'decoder_h/kernel', off + L), st['gates'], B, 4 * H, Cn, beta=1.0,
+          bias=P.p('decoder_h/bias'), ws=ws)
+        self._lstm_step('decoder_h', st, 'h_dec', 'c_dec')
+        g(st['hs'], P.p('X_decoded_mean/kernel'), st['xhat'], B, D, H, bias=P.p('X_decoded_mean/bias'),
+          act=ACT_SIGMOID, ws=ws)
 
     def _lstm_wgrads(self, name, X_in, hs, dz, dzsum, in_rows):
         """dkernel[0:in_rows], drecurrent, dbias of one LSTM from dz [B*T,4H]."""

@@ -1,0 +1,285 @@
+"""The slice of the Keras 2.0.0 `Model` surface that the reference's scripts use, on the HIP engines.
+
+The reference calls: fit(x, y, shuffle, epochs, batch_size, callbacks,
+validation_data) -> history with .history[str] -> list (cl_vae/train.py:66-73,
+cl_vrnn/train.py:66-73); predict(x | [x...]) (cl_vae/model.py:25,29,38; cl_vrnn/model.py:40,50,57);
+save_weights / load_weights (utils/model_utils.py:138; cl_vae/model.py:238); to_yaml
+(utils/model_utils.py:164); get_layer(name).get_weights()/.set_weights() (cl_vrnn/model.py:130-133,
+160-161); reset_states() (cl_vrnn/model.py:22-24); .layers, .inputs, .stop_training (callbacks).
+Semantics of fit() follow SURVEY.md Appendix A.4 (Keras 2.0.0, recalled).
+
+Nothing here computes on the host: every batch is a replay of the captured training step
+(trainer.TrainStep) on HBM-resident data; the host only shuffles indices and keeps the books.
+"""
+import json
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .trainer import TrainStep
+from .utils import h5io
+
+
+class Variable:
+    """keras.backend.variable for the annealed loss weights (cl_vae/train.py:42,48)."""
+
+    def __init__(self, value, name=None):
+        self.value = float(value)
+        self.name = name
+
+
+def get_value(v):
+    return v.value if isinstance(v, Variable) else float(v)
+
+
+def set_value(v, x):
+    v.value = float(x)
+
+
+class Callback:
+    """keras.callbacks.Callback protocol used by utils/model_utils.py."""
+
+    def __init__(self):
+        self.model = None
+        self.params = {}
+
+    def set_model(self, model):
+        self.model = model
+
+    def set_params(self, params):
+        self.params = params
+
+    def on_train_begin(self, logs=None):
+        pass
+
+    def on_train_end(self, logs=None):
+        pass
+
+    def on_epoch_begin(self, epoch, logs=None):
+        pass
+
+    def on_epoch_end(self, epoch, logs=None):
+        pass
+
+
+class History(Callback):
+    def on_train_begin(self, logs=None):
+        self.epoch = []
+        self.history = {}
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.history.setdefault(k, []).append(v)
+
+
+class Layer:
+    """A named layer owning a list of weights of the model's flat parameter buffer (Keras order)."""
+
+    def __init__(self, name, model, weight_names=(), class_name='Dense'):
+        self.name = name
+        self._model = model
+        self.weight_names = list(weight_names)      # e.g. ['kernel', 'bias']
+        self.class_name = class_name
+        self.built = True
+
+    def get_weights(self):
+        P = self._model.engine.P
+        return [P.p('%s/%s' % (self.name, w)).detach().cpu().numpy().copy() for w in self.weight_names]
+
+    def set_weights(self, weights):
+        P = self._model.engine.P
+        if len(weights) != len(self.weight_names):
+            raise ValueError("layer %s expects %d weight arrays, got %d" % (self.name, len(self.weight_names), len(weights)))
+        for w, arr in zip(self.weight_names, weights):
+            dst = P.p('%s/%s' % (self.name, w))
+            arr = np.asarray(arr, dtype=np.float32)
+            if tuple(arr.shape) != tuple(dst.shape):
+                raise ValueError("layer %s weight %s: shape %s != %s" % (self.name, w, arr.shape, tuple(dst.shape)))
+            dst.copy_(torch.as_tensor(arr))
+
+
+class OptimizerSpec:
+    """What utils/weightnorm.AdamWithWeightnorm / the strings 'adam' resolve to on the HIP path."""
+
+    def __init__(self, name='adam-wn', lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=0.0):
+        if decay != 0.0:
+            raise ValueError("learning-rate decay is not used by the reference and not supported")
+        self.name, self.lr, self.beta_1, self.beta_2, self.epsilon = name, lr, beta_1, beta_2, epsilon
+
+    @staticmethod
+    def resolve(opt):
+        if isinstance(opt, OptimizerSpec):
+            return opt
+        if opt in ('adam', 'adam-wn'):
+            return OptimizerSpec(opt)
+        raise ValueError("optimizer %r is not supported on the HIP path (use 'adam-wn' or 'adam')" % (opt,))
+
+
+def _to_dev(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32), device=dev)
+
+
+class Model:
+    """Training model; subclasses set `engine`, `layers`, `output_names`, `_split_inputs`."""
+
+    output_names = ()
+    acc_name = 'w_acc'
+
+    def __init__(self, engine, optimizer, kl_weight, w_kl_weight, class_weight, seed=None):
+        self.engine = engine
+        self.optimizer = OptimizerSpec.resolve(optimizer)
+        self._kl, self._wkl, self._cw = kl_weight, w_kl_weight, class_weight
+        self.stop_training = False
+        self.seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)
+        self._step = None
+        self._step_weights = None
+        self.layers = []
+        self.inputs = []
+        self.history = None
+        dev = engine.device
+        self._acc = torch.zeros(8, dtype=torch.float32, device=dev)
+
+    # -- structure ----------------------------------------------------------
+    def get_layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError("No such layer: " + name)
+
+    def to_yaml(self):
+        """Architecture description (written next to the weights, never read back: utils/model_utils.py:160-165)."""
+        import yaml
+        return yaml.safe_dump({'class_name': 'Model', 'backend': 'clvae-mi355x-hip', 'keras_version': '2.0.0',
+                               'config': {'name': type(self).__name__, 'engine_config': self.engine.cfg,
+                                          'batch_size': self.engine.B,
+                                          'layers': [{'name': l.name, 'class_name': l.class_name,
+                                                      'weights': l.weight_names} for l in self.layers]}})
+
+    def reset_states(self):
+        pass
+
+    # -- weights ------------------------------------------------------------
+    def get_weights(self):
+        out = []
+        for l in self.layers:
+            out.extend(l.get_weights())
+        return out
+
+    def save_weights(self, filepath, overwrite=True):
+        h5io.save_keras_weights(filepath, [(l.name, l.weight_names, l.get_weights()) for l in self.layers])
+
+    def load_weights(self, filepath):
+        """Keras (non by_name) semantics: layers with weights are matched BY ORDER, weights by order."""
+        saved = [(n, ws) for n, ws in h5io.load_keras_weights(filepath) if len(ws) > 0]
+        mine = [l for l in self.layers if l.weight_names]
+        if len(saved) != len(mine):
+            raise ValueError("weight file has %d layers with weights, model has %d" % (len(saved), len(mine)))
+        for l, (_, ws) in zip(mine, saved):
+            l.set_weights(ws)
+
+    # -- training -------------------------------------------------------------
+    def _sync_loss_weights(self):
+        e = self.engine
+        e.kl_weight, e.w_kl_weight, e.class_weight = get_value(self._kl), get_value(self._wkl), get_value(self._cw)
+        return (e.kl_weight, e.w_kl_weight, e.class_weight)
+
+    def _train_step(self):
+        """(Re)build the captured step when the annealed loss weights changed (they are baked into the graph)."""
+        w = self._sync_loss_weights()
+        if self._step is None or self._step_weights != w:
+            self._step = TrainStep(self.engine, seed=self.seed, optimizer=self.optimizer.name, lr=self.optimizer.lr)
+            self._step_weights = w
+        return self._step
+
+    def _logs_from(self, acc, n, prefix=''):
+        s = (acc.detach().cpu().numpy().astype(np.float64)) / max(n, 1)
+        kl, wkl, cw = self._step_weights if self._step_weights else self._sync_loss_weights()
+        names = self.output_names       # (recon, w(kl_w), w2(w_rec), z_args(kl_z))
+        logs = {prefix + 'loss': s[0] + wkl * s[2] + cw * s[3] + kl * s[1],
+                prefix + names[0] + '_loss': s[0], prefix + names[1] + '_loss': s[2],
+                prefix + names[2] + '_loss': s[3], prefix + names[3] + '_loss': s[1],
+                prefix + self.acc_name: s[4]}
+        return logs
+
+    def fit(self, x, y, shuffle=True, epochs=1, batch_size=None, callbacks=None, validation_data=None, verbose=1,
+            initial_epoch=0):
+        eng = self.engine
+        B = eng.B if batch_size is None else int(batch_size)
+        if B != eng.B:
+            raise ValueError("model was built with batch_size %d (fixed batch_shape), got %d" % (eng.B, B))
+        cur, hist, w_true = self._split_inputs(x, y)
+        n = cur.shape[0]
+        if n % B:
+            raise ValueError("number of samples %d is not a multiple of batch_size %d" % (n, B))
+        dev = eng.device
+        d_cur, d_hist, d_w = _to_dev(cur, dev), (None if hist is None else _to_dev(hist, dev)), _to_dev(w_true, dev)
+        val = None
+        if validation_data is not None:
+            vc, vh, vw = self._split_inputs(validation_data[0], validation_data[1])
+            if vc.shape[0] % B:
+                raise ValueError("validation samples %d not a multiple of batch_size %d" % (vc.shape[0], B))
+            val = (_to_dev(vc, dev), None if vh is None else _to_dev(vh, dev), _to_dev(vw, dev))
+        self.history = History()
+        cbs = list(callbacks or []) + [self.history]
+        for c in cbs:
+            c.set_model(self)
+            c.set_params({'epochs': epochs, 'batch_size': B, 'samples': n})
+        self.stop_training = False
+        for c in cbs:
+            c.on_train_begin({})
+        row = int(np.prod(cur.shape[1:]))
+        idx_dev = torch.zeros(n, dtype=torch.int64, device=dev)
+        for epoch in range(initial_epoch, epochs):
+            for c in cbs:
+                c.on_epoch_begin(epoch, {})
+            ts = self._train_step()
+            index = np.arange(n)
+            if shuffle:
+                np.random.shuffle(index)                        # global np.random state, like Keras (A.4)
+            idx_dev.copy_(torch.from_numpy(index))
+            self._acc.zero_()
+            for b0 in range(0, n, B):
+                ib = idx_dev[b0:b0 + B]
+                ops.gather_rows(B, row, d_cur, ib, ts.X)
+                if d_hist is not None:
+                    ops.gather_rows(B, row, d_hist, ib, ts.Xp)
+                ops.gather_rows(B, d_w.shape[1], d_w, ib, ts.w_true)
+                ts.step()
+                ops.axpy(5, 1.0, eng.scal, self._acc)
+            logs = self._logs_from(self._acc, n // B)
+            if val is not None:
+                logs.update(self.evaluate_device(*val, prefix='val_'))
+            if verbose:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+            for c in cbs:
+                c.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for c in cbs:
+            c.on_train_end({})
+        return self.history
+
+    def evaluate_device(self, d_cur, d_hist, d_w, prefix=''):
+        """Validation pass: forward + losses with the sampling noise ON (Lambda layers have no test switch,
+        SURVEY.md 5.9 B10), batch-size chunks, no parameter update."""
+        eng = self.engine
+        B = eng.B
+        ts = self._train_step()
+        acc = torch.zeros(8, dtype=torch.float32, device=eng.device)
+        n = d_cur.shape[0]
+        for b0 in range(0, n, B):
+            ts.X.copy_(d_cur[b0:b0 + B].view_as(ts.X))
+            if d_hist is not None:
+                ts.Xp.copy_(d_hist[b0:b0 + B].view_as(ts.Xp))
+            ts.w_true.copy_(d_w[b0:b0 + B])
+            ts.draw_noise(stream_offset=2 + b0 // B)
+            eng.loss_and_grads(ts.X, ts.Xp, ts.w_true, ts.eps_w, ts.eps_z, need_grads=False)
+            ops.axpy(5, 1.0, eng.scal, acc)
+        return self._logs_from(acc, n // B, prefix)
+
+
+def save_args_json(args_dict, path):
+    with open(path, 'w') as f:
+        json.dump(args_dict, f)

@@ -100,6 +100,14 @@ def sum_strided(n, x, stride, scale, out):
     check(_lib.lib().clv_sum_strided(n, _ptr(x), stride, float(scale), _ptr(out), _stream()), "clv_sum_strided")
 
 
+def axpy(n, alpha, x, y):
+    check(_lib.lib().clv_axpy(n, float(alpha), _ptr(x), _ptr(y), _stream()), "clv_axpy")
+
+
+def gather_rows(rows, row_elems, src, idx, out):
+    check(_lib.lib().clv_gather_rows(rows, row_elems, _ptr(src), _ptr(idx), _ptr(out), _stream()), "clv_gather_rows")
+
+
 def philox_normal(out, n, seed, step=0, stream_id=0, first_index=0, step_dev=None):
     check(_lib.lib().clv_philox_normal(_ptr(out), n, seed, step, _ptr(step_dev), stream_id, first_index, _stream()),
           "clv_philox_normal")

@@ -41,14 +41,15 @@ class TrainStep:
         self._warm = False
 
     # -- pieces -----------------------------------------------------------
-    def draw_noise(self):
+    def draw_noise(self, stream_offset=0):
+        """eps_w / eps_z from the Philox streams (2*stream_offset, 2*stream_offset+1) at this rank's global rows."""
         eng, B = self.eng, self.eng.B
         C1, L = eng.cfg['C'] - 1, eng.cfg['L']
         T = eng.cfg['T'] if self.is_vrnn else 1
         row0 = self.rank * B                         # global row of this rank's first sample
         it = eng.P.iterations
-        ops.philox_normal(self.eps_w, B * C1, self.seed, 0, 0, eps_first_index(row0, C1), step_dev=it)
-        ops.philox_normal(self.eps_z, B * T * L, self.seed, 0, 1, eps_first_index(row0, T * L), step_dev=it)
+        ops.philox_normal(self.eps_w, B * C1, self.seed, 0, 2 * stream_offset, eps_first_index(row0, C1), step_dev=it)
+        ops.philox_normal(self.eps_z, B * T * L, self.seed, 0, 2 * stream_offset + 1, eps_first_index(row0, T * L), step_dev=it)
 
     def _main(self):
         self.draw_noise()

@@ -125,6 +125,13 @@ int clv_gauss_bwd(int R, int L, const float* zargs, const float* eps, const floa
 int clv_bernoulli_nll(int R, int D, const float* logits, const float* y, int ldy, float scale,
                       float* rownll, float* dlogits, void* stream);
 
+/* y[i] += alpha * x[i]  (epoch running sums of the loss scalars stay on the device) */
+int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
+
+/* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
+ * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71). */
+int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out, void* stream);
+
 /* deterministic sum of n floats with stride: out[0] = scale * sum_i x[i*stride] */
 int clv_sum_strided(int n, const float* x, int stride, float scale, float* out, void* stream);
 

@@ -1,0 +1,69 @@
+"""The data-parallel layer on CPU: world_size-2 gloo processes, bucketed gradient averaging,
+row sharding and Philox index sharding (the HIP step itself needs a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import clvae_amd  # noqa: F401
+from clvae_amd.parallel import GradAllReduce, eps_first_index, shard_rows
+from oracle import philox as OP
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, tail_off, tail_n = 1000, 0, 600           # tail bucket first in the flat buffer, like hW/kernel
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        ar = GradAllReduce(g, tail_off, tail_n)
+        assert ar.world == world and ar.tail.numel() == tail_n and sum(t.numel() for t in ar.main) == n - tail_n
+        ar.reduce_main()
+        # only the main bucket is averaged so far
+        assert torch.allclose(g[tail_n:], torch.arange(tail_n, n, dtype=torch.float32) * 1.5)
+        assert torch.allclose(g[:tail_n], torch.arange(tail_n, dtype=torch.float32) * (rank + 1))
+        ar.reduce_tail(); ar.wait()
+        assert torch.allclose(g, torch.arange(n, dtype=torch.float32) * 1.5)
+        # sharding: the union of the ranks' noise equals the single-process draw for the global batch
+        B_global, per_row = 8, 9
+        r0, r1 = shard_rows(B_global, rank, world)
+        mine = OP.normal((r1 - r0) * per_row, 1234, step=3, stream_id=0, first_index=eps_first_index(r0, per_row))
+        full = OP.normal(B_global * per_row, 1234, step=3, stream_id=0, first_index=0)
+        assert np.array_equal(mine, full[r0 * per_row:r1 * per_row])
+        out.put((rank, float(g.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo_gradient_average_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got[0][1] == got[1][1]
+
+
+def test_shard_rows_contract():
+    assert shard_rows(2048, 3, 8) == (768, 1024)
+    with pytest.raises(ValueError):
+        shard_rows(10, 0, 4)
+    assert eps_first_index(256, 128 * 2) == 65536

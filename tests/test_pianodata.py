@@ -1,0 +1,75 @@
+"""G1: the product's PianoData vs tensors produced by the reference's own utils/pianoroll.py."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import clvae_amd  # noqa: F401
+from clvae_amd.utils import pianoroll as PR
+from helpers import REF_DATA, golden, make_synthetic_pickle
+
+G1 = golden("g1_pianodata.npz")
+CASES = [('Cs', 100, 1, dict(return_y_next=True, squeeze_x=True, squeeze_y=True)),
+         ('Cs', 512, 1, dict(return_y_next=True, squeeze_x=True, squeeze_y=True)),
+         ('all', 200, 16, dict(return_y_next=True, return_y_hist=True, squeeze_x=False, squeeze_y=False)),
+         ('all', 256, 32, dict(return_y_next=True, return_y_hist=True, squeeze_x=False, squeeze_y=False)),
+         ('all', 256, 64, dict(return_y_next=True, return_y_hist=True, squeeze_x=False, squeeze_y=False)),
+         ('all', 256, 128, dict(return_y_next=True, return_y_hist=True, squeeze_x=False, squeeze_y=False)),
+         ('Cs', 1, 32, dict(return_y_next=False, squeeze_x=False, squeeze_y=False)),
+         ('all', None, 1, dict())]
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()[:8], dtype=np.uint64)[0]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the JSB pickles live in the reference checkout (build container only)")
+@pytest.mark.parametrize("name,bs,T,kw", CASES)
+def test_pianodata_matches_reference_golden(name, bs, T, kw):
+    P = PR.PianoData(os.path.join(REF_DATA, 'JSB Chorales_%s.pickle' % name), batch_size=bs, seq_length=T,
+                     step_length=1, **kw)
+    tag = '%s_b%s_t%d' % (name, bs, T)
+    for split in ('train', 'valid', 'test'):
+        for xy in ('x', 'y'):
+            a = getattr(P, '%s_%s' % (xy, split))
+            assert a.dtype == np.float64
+            assert tuple(G1['%s/%s_%s/shape' % (tag, xy, split)]) == a.shape
+            assert float(G1['%s/%s_%s/sum' % (tag, xy, split)]) == a.sum()
+            assert int(G1['%s/%s_%s/sha' % (tag, xy, split)]) == int(sha(a.astype(np.uint8)))
+            if a.shape[0]:
+                np.testing.assert_array_equal(G1['%s/%s_%s/head' % (tag, xy, split)], a[:4])
+                np.testing.assert_array_equal(G1['%s/%s_%s/tail' % (tag, xy, split)], a[-4:])
+        np.testing.assert_array_equal(G1['%s/%s_song_keys' % (tag, split)], getattr(P, '%s_song_keys' % split))
+        np.testing.assert_array_equal(G1['%s/%s_song_inds' % (tag, split)], getattr(P, '%s_song_inds' % split))
+        np.testing.assert_array_equal(G1['%s/%s_song_modes' % (tag, split)].astype(bool),
+                                      getattr(P, '%s_song_modes' % split))
+    keys = sorted(P.key_map, key=lambda k: P.key_map[k])
+    assert [str(k) for k in G1['%s/key_map' % tag]] == keys
+
+
+def test_helpers_match_reference_golden():
+    np.testing.assert_array_equal(G1['helpers/song_to_pianoroll_low'], PR.song_to_pianoroll([(20, 30), (50,)]))
+    np.testing.assert_array_equal(G1['helpers/song_to_pianoroll_high'], PR.song_to_pianoroll([(50, 109), (60,)]))
+    np.testing.assert_array_equal(G1['helpers/sliding_window'],
+                                  PR.sliding_window(np.arange(7 * 88).reshape(7, 88) % 5, 3, 2))
+    assert PR.sliding_window(np.zeros((3, 88)), 3).size == 0           # n <= seq: no window (last one is dropped)
+    assert PR.relative_major('a') == 'C' and PR.relative_major('E-') == 'E-'
+    assert PR.pianoroll_to_song(PR.song_to_pianoroll([(60, 64), (62,)])) == [[60, 64], [62]]
+
+
+def test_synthetic_schema_and_song_index_bug(tmp_path):
+    f = make_synthetic_pickle(str(tmp_path / "syn.pickle"), min_len=10, max_len=40, seed=3)
+    T = 20
+    P = PR.PianoData(f, batch_size=4, seq_length=T, return_y_next=True, return_y_hist=True, squeeze_x=False,
+                     squeeze_y=False)
+    assert P.x_train.shape[1:] == (T, 88) and P.x_train.shape[0] % 4 == 0
+    np.testing.assert_array_equal(P.x_train[:, 1:], P.y_train[:, :-1])     # y is x shifted by one frame
+    # songs shorter than T+1 are dropped before indices are assigned (B2): the fix flag changes the lookups
+    Pf = PR.PianoData(f, batch_size=4, seq_length=T, return_y_next=True, return_y_hist=True, squeeze_x=False,
+                      squeeze_y=False, fix_song_index=True)
+    np.testing.assert_array_equal(P.x_train, Pf.x_train)
+    assert Pf.train_song_inds.max() >= P.train_song_inds.max()
+    assert set(P.key_map) == {'C', 'G', 'F'}                               # a -> C, e -> G (relative major)
+    P32 = PR.PianoData(f, batch_size=4, seq_length=T, dtype=np.float32)
+    assert P32.x_train.dtype == np.float32
