@@ -1,0 +1,251 @@
+"""-m gpu: the reference-shaped Python surface (get_model / fit / predict / sub-models / CLIs / .h5) on the HIP path."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from helpers import golden, make_synthetic_pickle
+from oracle import clvae_oracle as O
+from oracle import philox as OP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import clvae_amd  # noqa: F401
+    from clvae_amd import _lib
+    _lib.require_gpu()
+    return torch.device("cuda:0")
+
+
+def f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+# ------------------------------------------------------------------ golden G4 on the device
+def test_golden_g4_cl_vae(dev):
+    from clvae_amd.engine import VaeEngine
+    G = golden("g4_oracle_steps.npz")
+    cfg = O.vae_config(latent_dim=4, n_classes=2, use_x_prev=True)
+    p = {k[len('vae/p/'):]: G[k] for k in G.files if k.startswith('vae/p/')}
+    eng = VaeEngine(cfg, 16, dev)
+    eng.P.set_weights(p)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+    args = (t(G['vae/x']), t(G['vae/xp']), t(G['vae/wt']), t(G['vae/ew']), t(G['vae/ez']))
+    eng.loss_and_grads(*args)
+    got = eng.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total', 'elbo'):
+        assert abs(got[k] - float(G['vae/loss/' + k])) <= 1e-3, k
+    assert abs(got['acc'] - float(G['vae/loss/acc'])) < 1e-6
+    assert np.abs(eng.logits.cpu().numpy() - G['vae/c/logits']).max() < 2e-4
+    gr = eng.P.get_weights(eng.P.grads)
+    for k in gr:
+        ref = G['vae/g/' + k]
+        assert np.abs(gr[k] - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-8), k
+    for _ in range(3):
+        eng.loss_and_grads(*args)
+        eng.P.adam_step()
+    w = eng.P.get_weights()
+    for k in w:
+        np.testing.assert_allclose(w[k], G['vae/p3/' + k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_golden_g4_cl_vrnn(dev):
+    from clvae_amd.engine import VrnnEngine
+    G = golden("g4_oracle_steps.npz")
+    cfg = O.vrnn_config(latent_dim=2, seq_length=16, n_classes=10, use_x_prev=True)
+    p = {k[len('vrnn/p/'):]: G[k] for k in G.files if k.startswith('vrnn/p/')}
+    eng = VrnnEngine(cfg, 8, dev)
+    eng.P.set_weights(p)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+    eng.loss_and_grads(t(G['vrnn/X']), t(G['vrnn/Xp']), t(G['vrnn/wt']), t(G['vrnn/eW']), t(G['vrnn/eZ']))
+    got = eng.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total', 'elbo'):
+        assert abs(got[k] - float(G['vrnn/loss/' + k])) <= 1e-3, k
+    assert np.abs(eng.logits.cpu().numpy().reshape(8, 16, 88) - G['vrnn/c/logits']).max() < 2e-4
+    gr = eng.P.get_weights(eng.P.grads)
+    for k in gr:
+        ref = G['vrnn/g/' + k].astype(np.float64)
+        assert np.abs(gr[k] - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-8), k
+
+
+# ------------------------------------------------------------------ fit() == oracle loop with the same noise
+def test_fit_tracks_an_oracle_training_loop(dev):
+    """Two epochs of Model.fit (shuffle off) vs the oracle driven with the SAME Philox noise:
+    eps of step i is philox(seed, step=i, stream 0/1, first_index=0) -- reproduced with oracle/philox.py."""
+    from clvae_amd.cl_vrnn.model import get_model
+    B, T, L, C, n = 4, 6, 2, 3, 12
+    rng = np.random.default_rng(0)
+    win = (rng.random((n, T + 1, 88)) < 0.05).astype(np.float64)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(C)[rng.integers(0, C, n)]
+    model, _ = get_model(B, 88, 88, L, T, C, True, 'adam-wn', seed=77)
+    p = {k: f32(v) for k, v in model.engine.P.get_weights().items()}
+    cfg = O.vrnn_config(latent_dim=L, seq_length=T, n_classes=C, use_x_prev=True)
+    hist = model.fit([X, Xp], [X, wt, wt, X], shuffle=False, epochs=2, batch_size=B, verbose=0,
+                     validation_data=([X[:B], Xp[:B]], [X[:B], wt[:B], wt[:B], X[:B]]))
+    st = O.adam_wn_init(p)
+    it = 0
+    ref_epoch = []
+    for ep in range(2):
+        tot = 0.0
+        for b0 in range(0, n, B):
+            eW = OP.normal(B * (C - 1), 77, step=it, stream_id=0).reshape(B, C - 1).astype(np.float64)
+            eZ = OP.normal(B * T * L, 77, step=it, stream_id=1).reshape(B, T, L).astype(np.float64)
+            r = O.vrnn_loss_and_grads(p, cfg, X[b0:b0 + B], Xp[b0:b0 + B], wt[b0:b0 + B], eW, eZ)
+            O.adam_wn_step(p, r['grads'], st)
+            tot += r['total']
+            it += 1
+        ref_epoch.append(tot / (n // B))
+    np.testing.assert_allclose(hist.history['loss'], ref_epoch, rtol=2e-4)
+    w = model.engine.P.get_weights()
+    for k in p:
+        np.testing.assert_allclose(w[k], p[k], rtol=2e-2, atol=3e-4, err_msg=k)
+    assert set(hist.history) == {'loss', 'X_decoded_mean_loss', 'W_loss', 'W2_loss', 'Z_args_loss', 'W_acc',
+                                 'val_loss', 'val_X_decoded_mean_loss', 'val_W_loss', 'val_W2_loss',
+                                 'val_Z_args_loss', 'val_W_acc'}
+    assert int(model.engine.P.iterations.item()) == 6
+
+
+# ------------------------------------------------------------------ sub-models
+def test_cl_vae_submodels_match_oracle(dev):
+    from clvae_amd.cl_vae.model import get_model, make_decoder, make_w_encoder, make_z_encoder
+    model, _ = get_model(1, 88, (88, 4), (88, 2), 'adam', use_x_prev=True, seed=3)
+    p = {k: f32(v) for k, v in model.engine.P.get_weights().items()}
+    cfg = O.vae_config(latent_dim=4, n_classes=2, use_x_prev=True)
+    rng = np.random.default_rng(1)
+    x = (rng.random((1, 88)) < 0.1).astype(float); xp = (rng.random((1, 88)) < 0.1).astype(float)
+    w = np.array([[0.3, 0.7]]); z = rng.standard_normal((1, 4))
+    wm, wlv = make_w_encoder(model, 88).predict(x)
+    hw = np.maximum(x @ p['h_w/kernel'] + p['h_w/bias'], 0)
+    np.testing.assert_allclose(wm, hw @ p['w_mean/kernel'] + p['w_mean/bias'], atol=2e-5)
+    np.testing.assert_allclose(wlv, hw @ p['w_log_var/kernel'] + p['w_log_var/bias'], atol=2e-5)
+    zm, zlv = make_z_encoder(model, 88, 2, (88, 4)).predict([x, w])
+    h = np.maximum(np.concatenate([x, w], 1) @ p['h/kernel'] + p['h/bias'], 0)
+    np.testing.assert_allclose(zm, h @ p['z_mean/kernel'] + p['z_mean/bias'], atol=2e-5)
+    np.testing.assert_allclose(zlv, h @ p['z_log_var/kernel'] + p['z_log_var/bias'], atol=2e-5)
+    xh = make_decoder(model, (88, 4), 2, use_x_prev=True).predict([w, z, xp])
+    hd = np.maximum(np.concatenate([w, xp, z], 1) @ p['decoder_h/kernel'] + p['decoder_h/bias'], 0)
+    np.testing.assert_allclose(xh, O.sigmoid(hd @ p['x_decoded_mean/kernel'] + p['x_decoded_mean/bias']), atol=2e-5)
+    assert xh.shape == (1, 88)
+
+
+def test_cl_vrnn_stateful_submodels_match_full_sequence_oracle(dev):
+    from clvae_amd.cl_vrnn.model import get_model, make_decoder, make_w_encoder, make_z_encoder
+    T, L, C = 8, 2, 10
+    model, _ = get_model(2, 88, 88, L, T, C, True, 'adam', seed=5)
+    p = {k: f32(v) for k, v in model.engine.P.get_weights().items()}
+    rng = np.random.default_rng(2)
+    X = (rng.random((1, T, 88)) < 0.08).astype(float)
+    w = np.eye(C)[[4]]
+    Z = rng.standard_normal((1, T, L))
+    wenc, zenc, dec = make_w_encoder(model, 88, C, T), make_z_encoder(model, 88, C, (88, L)), \
+        make_decoder(model, 88, 88, L, C, True)
+    wm, wlv = wenc.predict(X)
+    hW = np.maximum(X.reshape(1, -1) @ p['hW/kernel'] + p['hW/bias'], 0)
+    wa = hW @ p['Wargs/kernel'] + p['Wargs/bias']
+    np.testing.assert_allclose(np.concatenate([wm, wlv], 1), wa, atol=3e-5)
+    # oracle over the whole sequence, step models frame by frame (state carried on the device)
+    Wrep = np.repeat(w[:, None, :], T, 1)
+    enc_h, _ = O.lstm_forward(np.concatenate([X, Wrep], -1), p['encoder_h/kernel'], p['encoder_h/recurrent_kernel'],
+                              p['encoder_h/bias'])
+    dec_h, _ = O.lstm_forward(np.concatenate([X, Z, Wrep], -1), p['decoder_h/kernel'], p['decoder_h/recurrent_kernel'],
+                              p['decoder_h/bias'])
+    for rep in range(2):                       # second pass checks reset_states()
+        zenc.reset_states(); dec.reset_states()
+        for t in range(T):
+            zm, zlv = zenc.predict([X[:, t:t + 1], w])
+            assert zm.shape == (1, 1, L)
+            np.testing.assert_allclose(zm[0, 0], enc_h[0, t] @ p['Z_mean/kernel'] + p['Z_mean/bias'], atol=3e-5)
+            np.testing.assert_allclose(zlv[0, 0], enc_h[0, t] @ p['Z_log_var/kernel'] + p['Z_log_var/bias'], atol=3e-5)
+            xh = dec.predict([Z[:, t:t + 1], X[:, t:t + 1], w])
+            assert xh.shape == (1, 1, 88)
+            np.testing.assert_allclose(xh[0, 0], O.sigmoid(dec_h[0, t] @ p['X_decoded_mean/kernel']
+                                                           + p['X_decoded_mean/bias']), atol=3e-5)
+    fresh = make_z_encoder(model, 88, C, (88, L), emulate_fresh_encoder=True)
+    zf, _ = fresh.predict([X[:, :1], w])
+    zt, _ = (zenc.reset_states(), zenc.predict([X[:, :1], w]))[1]
+    assert not np.allclose(zf, zt)              # reference bug B3 emulation really uses an untrained LSTM
+    np.testing.assert_array_equal(model.get_layer('encoder_h').get_weights()[0], p['encoder_h/kernel'].astype(np.float32))
+
+
+# ------------------------------------------------------------------ weights I/O
+def test_save_load_weights_roundtrip(dev, tmp_path):
+    from clvae_amd.cl_vrnn.model import get_model, load_model
+    m1, _ = get_model(2, 88, 88, 2, 4, 3, True, 'adam-wn', seed=1)
+    path = str(tmp_path / "run.h5")
+    m1.save_weights(path)
+    json.dump(dict(batch_size=2, original_dim=88, intermediate_dim=88, latent_dim=2, seq_length=4, n_classes=3,
+                   use_x_prev=True, optimizer='adam-wn', class_weight=1.0), open(str(tmp_path / "run.json"), 'w'))
+    m2, _, margs = load_model(path)
+    a, b = m1.engine.P.get_weights(), m2.engine.P.get_weights()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert margs['seq_length'] == 4
+    assert [l.name for l in m1.layers if l.weight_names] == ['hW', 'Wargs', 'encoder_h', 'Z_mean', 'Z_log_var',
+                                                              'decoder_h', 'X_decoded_mean']
+    y = m1.to_yaml()
+    assert 'encoder_h' in y and 'keras_version' in y
+    outs = m1.predict([np.zeros((2, 4, 88)), np.zeros((2, 4, 88))])
+    assert [o.shape for o in outs] == [(2, 4, 88), (2, 3), (2, 3), (2, 4, 4)]
+    assert np.all((outs[0] > 0) & (outs[0] < 1)) and np.allclose(outs[1].sum(1), 1, atol=1e-5)
+
+
+# ------------------------------------------------------------------ CLIs end to end
+def _ns(parser, argv):
+    return parser.parse_args(argv)
+
+
+def test_cl_vae_cli_train_then_sample(dev, tmp_path):
+    from clvae_amd.cl_vae import sample as S, train as TR
+    data = make_synthetic_pickle(str(tmp_path / "syn.pickle"), n_songs=(10, 4, 4), seed=1)
+    mdir, sdir = str(tmp_path / "models"), str(tmp_path / "samples")
+    os.makedirs(mdir); os.makedirs(sdir)
+    args = _ns(TR.build_parser(), ['run1', '--use_x_prev', '--latent_dim', '4', '--batch_size', '50', '--num_epochs', '4',
+                                   '--kl_anneal', '2', '--train_file', data, '--model_dir', mdir])
+    np.random.seed(0)
+    model, best = TR.train(args)
+    assert os.path.exists(os.path.join(mdir, 'run1.h5')) and os.path.exists(os.path.join(mdir, 'run1.yaml'))
+    margs = json.load(open(os.path.join(mdir, 'run1.json')))
+    assert margs['n_classes'] == 3 and margs['original_dim'] == 88 and margs['optimizer'] == 'adam-wn'
+    h = model.history.history
+    assert len(h['loss']) == 4 and h['loss'][-1] < h['loss'][0]
+    assert set(best) == set(h) and 'val_w_acc' in best and 'x_decoded_mean_loss' in best
+    sargs = _ns(S.build_parser(), ['out', '-n', '2', '-t', '8', '-i', os.path.join(mdir, 'run1.h5'), '--train_file', data,
+                                   '--sample_dir', sdir])
+    samples = S.sample(sargs)
+    assert len(samples) == 2 and samples[0].shape == (8, 88) and set(np.unique(samples[0])) <= {0.0, 1.0}
+    for i in range(2):
+        b = open(os.path.join(sdir, 'out_%d.mid' % i), 'rb').read()
+        assert b[:4] == b'MThd'
+    sargs = _ns(S.build_parser(), ['inf', '--infer_w', '--use_z_prior', '-t', '4', '-i', os.path.join(mdir, 'run1.h5'),
+                                   '--train_file', data, '--sample_dir', sdir])
+    assert S.sample(sargs)[0].shape == (4, 88)
+
+
+def test_cl_vrnn_cli_train_then_sample(dev, tmp_path):
+    from clvae_amd.cl_vrnn import sample as S, train as TR
+    data = make_synthetic_pickle(str(tmp_path / "jsb_syn.pickle"), n_songs=(10, 4, 4), seed=2)
+    mdir, sdir = str(tmp_path / "models"), str(tmp_path / "samples")
+    os.makedirs(mdir); os.makedirs(sdir)
+    args = _ns(TR.build_parser(), ['r2', '--use_x_prev', '--seq_length', '8', '--batch_size', '20', '--num_epochs', '3',
+                                   '--train_file', data, '--model_dir', mdir, '--patience', '0'])
+    np.random.seed(1)
+    model, best = TR.train(args)
+    h = model.history.history
+    assert len(h['loss']) == 3 and h['loss'][-1] < h['loss'][0] and 'W_acc' in h
+    assert os.path.exists(os.path.join(mdir, 'r2.h5'))
+    sargs = _ns(S.build_parser(), ['g', '-n', '2', '-t', '8', '-i', os.path.join(mdir, 'r2.h5'), '--train_file', data,
+                                   '--sample_dir', sdir])
+    np.random.seed(2)
+    out = S.sample(sargs)
+    assert len(out) == 2 and out[0].shape == (8, 88)
+    assert os.path.exists(os.path.join(sdir, 'g_0.mid')) and any(f.startswith('g0_seed_') for f in os.listdir(sdir))
+    sargs = _ns(S.build_parser(), ['h', '--infer_w', '--discrete_w', '-t', '8', '-i', os.path.join(mdir, 'r2.h5'),
+                                   '--train_file', data, '--sample_dir', sdir])
+    assert S.sample(sargs)[0].shape == (8, 88)
