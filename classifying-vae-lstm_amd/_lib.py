@@ -26,6 +26,11 @@ class ParamDesc(C.Structure):
                 ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
 
 
+class GemmProb(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("M", C.c_int32), ("C", C.c_void_p), ("ldc", C.c_int32),
+                ("a_shift", C.c_int32), ("a_zero_period", C.c_int32), ("ones", C.c_int32)]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
 
@@ -38,6 +43,9 @@ SIGNATURES = {
     "clv_gemm_auto_split": (_i, [_i, _i, _i]),
     "clv_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p]),
+    "clv_gemm_grouped_auto_split": (_i, [_p, _i, _i, _i]),
+    "clv_gemm_grouped_workspace_bytes": (_sz, [_p, _i, _i, _i]),
+    "clv_gemm_grouped_tn": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p]),
     "clv_colsum_workspace_bytes": (_sz, [_i, _i]),
     "clv_colsum_f32": (_i, [_i, _i, _p, _i, _f, _p, _p, _sz, _p]),
     "clv_lstm_seq_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -47,6 +55,7 @@ SIGNATURES = {
     "clv_gauss_fwd": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
     "clv_gauss_bwd": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p]),
     "clv_bernoulli_nll": (_i, [_i, _i, _p, _p, _i, _f, _p, _p, _p]),
+    "clv_loss_sums": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p]),
     "clv_sum_strided": (_i, [_i, _p, _i, _f, _p, _p]),
     "clv_axpy": (_i, [_i64, _f, _p, _p, _p]),
     "clv_gather_rows": (_i, [_i64, _i64, _p, _p, _p, _p]),

@@ -16,7 +16,21 @@ namespace clv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int MAX_PROB = 4;
+// one problem of a grouped launch: C_p[M_p,N] = op(A_p)[M_p,K] . B[K,N]; all problems share B, N, K.
+struct GemmProb {
+  const float* A; int lda; int M;
+  float* C; int ldc;
+  int a_shift;        // TN only: row k of op(A)^T is taken from row k - a_shift of A ...
+  int a_zero_period;  // ... and is zero when k % a_zero_period == 0 (h_{t-1} of the first step of a sequence)
+  int ones;           // A is an implicit row of ones (M == 1): column sums of B
+  int tile0;          // first blockIdx.x of this problem
+  int row0;           // first row of this problem in the split-K partial slabs
+};
+
 struct GemmArgs {
+  int nprob;          // 0: single problem described by the fields below
+  GemmProb prob[MAX_PROB];
   int M, N, K;
   float alpha, beta;
   const float* A; int lda;
@@ -46,7 +60,8 @@ struct TileLoader {
   static constexpr int LD = LdsStride<BMN>::value;
 
   __device__ static void load(float4 (&r)[PER], const float* __restrict__ p, int ld, int dim_mn,
-                              int k_end, int mn0, int k0, int vec, int tid) {
+                              int k_end, int mn0, int k0, int vec, int tid, int shift = 0, int zperiod = 0,
+                              int ones = 0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int idx = tid + i * 256;
@@ -70,8 +85,10 @@ struct TileLoader {
           constexpr int RV = BMN / 4;
           int k = idx / RV, c4 = (idx % RV) * 4;
           int gk = k0 + k, gm = mn0 + c4;
-          if (gk < k_end) {
-            const float* src = p + (size_t)gk * ld + gm;
+          if (ones) {
+            if (gk < k_end && gm == 0) v.x = 1.f;
+          } else if (gk < k_end && !(zperiod > 0 && gk % zperiod == 0)) {
+            const float* src = p + (size_t)(gk - shift) * ld + gm;
             if (vec && gm + 3 < dim_mn) {
               v = *reinterpret_cast<const float4*>(src);
             } else {
@@ -129,7 +146,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // grouped launch: blockIdx.x enumerates the m-tiles of every problem
+  const float* __restrict__ Aptr = g.A;
+  float* Cptr = g.C;
+  int lda = g.lda, ldc = g.ldc, Mp = g.M, mtile = blockIdx.x, prow0 = 0, a_shift = 0, a_zper = 0, a_ones = 0;
+  if (g.nprob > 0) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_PROB; ++i)
+      if (i < g.nprob && (int)blockIdx.x >= g.prob[i].tile0) pi = i;
+    const GemmProb& pr = g.prob[pi];
+    Aptr = pr.A; Cptr = pr.C; lda = pr.lda; ldc = pr.ldc; Mp = pr.M; mtile = blockIdx.x - pr.tile0;
+    prow0 = pr.row0; a_shift = pr.a_shift; a_zper = pr.a_zero_period; a_ones = pr.ones;
+  }
+  const int m0 = mtile * BM, n0 = blockIdx.y * BN;
   const int kbeg = blockIdx.z * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -142,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   float4 ra[LA::PER], rb[LB::PER];
   if (nk > 0) {
-    LA::load(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
+    LA::load(ra, Aptr, lda, Mp, kend, m0, kbeg, g.vecA, tid, a_shift, a_zper, a_ones);
     LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
     LA::store(ra, As, tid);
     LB::store(rb, Bs, tid);
@@ -152,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      LA::load(ra, g.A, g.lda, g.M, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid);
+      LA::load(ra, Aptr, lda, Mp, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid, a_shift, a_zper, a_ones);
       LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
     }
     const float* as = As + cur * BK * LDA + wm * WM * 16 + r;
@@ -187,17 +217,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = m0 + (wm * WM + i) * 16 + q * 4 + reg;
-        if (row >= g.M) continue;
+        if (row >= Mp) continue;
         float v = acc[i][j][reg];
         if (g.partial) {
-          g.partial[((size_t)blockIdx.z * g.M + row) * g.N + col] = v;
+          g.partial[((size_t)blockIdx.z * g.M + prow0 + row) * g.N + col] = v;
         } else {
           v *= g.alpha;
           if (g.bias) v += g.bias[col];
-          const size_t o = (size_t)row * g.ldc + col;
-          if (g.beta != 0.f) v += g.beta * g.C[o];
+          const size_t o = (size_t)row * ldc + col;
+          if (g.beta != 0.f) v += g.beta * Cptr[o];
           v = apply_act(v, g.act, g.act == CLV_ACT_MASKPOS ? g.aux[o] : 0.f);
-          g.C[o] = v;
+          Cptr[o] = v;
         }
       }
     }
@@ -228,20 +258,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
   __syncthreads();
   if (zy == 0 && idx < mn) {
     v = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
-    const int row = (int)(idx / g.N), col = (int)(idx % g.N);
+    int row = (int)(idx / g.N);
+    const int col = (int)(idx % g.N);
+    float* Cptr = g.C;
+    int ldc = g.ldc;
+    if (g.nprob > 0) {
+      int pi = 0;
+#pragma unroll
+      for (int i = 1; i < MAX_PROB; ++i)
+        if (i < g.nprob && row >= g.prob[i].row0) pi = i;
+      Cptr = g.prob[pi].C; ldc = g.prob[pi].ldc; row -= g.prob[pi].row0;
+    }
     v *= g.alpha;
     if (g.bias) v += g.bias[col];
-    const size_t o = (size_t)row * g.ldc + col;
-    if (g.beta != 0.f) v += g.beta * g.C[o];
+    const size_t o = (size_t)row * ldc + col;
+    if (g.beta != 0.f) v += g.beta * Cptr[o];
     v = apply_act(v, g.act, g.act == CLV_ACT_MASKPOS ? g.aux[o] : 0.f);
-    g.C[o] = v;
+    Cptr[o] = v;
   }
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N>
 static void launch_cfg(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
   constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
-  dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, splits);
+  dim3 grid(g.nprob > 0 ? g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BM - 1) / BM : (g.M + BM - 1) / BM,
+            (g.N + BN - 1) / BN, splits);
   if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, false, false>), grid, dim3(256), 0, s, g);
   else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, false, true>), grid, dim3(256), 0, s, g);
   else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, true, false>), grid, dim3(256), 0, s, g);
@@ -312,6 +353,7 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
   if (act == CLV_ACT_MASKPOS && !aux) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g;
+  g.nprob = 0;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.bias = bias; g.act = act; g.aux = aux;
@@ -342,6 +384,80 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
   if (splits > 1) {
     ProfScope p("gemm_splitk_reduce", s);
     size_t mn = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, g, splits);
+    st = launch_status();
+  }
+  return st;
+}
+
+// Grouped weight-gradient GEMM: C_p[M_p,N] = A_p^T . B for up to 4 problems that share B [K,N] (one pass over
+// dz for all of an LSTM's kernel / recurrent-kernel gradients, or dW and db of a Dense layer).
+static int grouped_tiles(const clv_gemm_prob* probs, int nprob, int bm) {
+  int t = 0;
+  for (int i = 0; i < nprob; ++i) t += (probs[i].M + bm - 1) / bm;
+  return t;
+}
+
+extern "C" int clv_gemm_grouped_auto_split(const clv_gemm_prob* probs, int nprob, int N, int K) {
+  if (!probs || nprob < 1 || nprob > clv::MAX_PROB) return 1;
+  const long tiles = (long)grouped_tiles(probs, nprob, 96) * ((N + 95) / 96);
+  if (tiles >= 512 || K < 64) return 1;
+  long s = (1024 + tiles - 1) / tiles;
+  if (s > K / 32) s = K / 32;
+  if (s > 512) s = 512;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" size_t clv_gemm_grouped_workspace_bytes(const clv_gemm_prob* probs, int nprob, int N, int split_k) {
+  if (!probs || split_k <= 1) return 0;
+  size_t m = 0;
+  for (int i = 0; i < nprob; ++i) m += probs[i].M;
+  return (size_t)split_k * m * N * sizeof(float);
+}
+
+extern "C" int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N, int K,
+                                   const float* B, int ldb, float beta,
+                                   int split_k, void* ws, size_t ws_bytes, void* stream) {
+  using namespace clv;
+  if (!probs || nprob < 1 || nprob > MAX_PROB || N <= 0 || K <= 0 || !B) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.nprob = nprob;
+  int tile = 0, row = 0, vec = 1;
+  for (int i = 0; i < nprob; ++i) {
+    const clv_gemm_prob& p = probs[i];
+    if (p.M <= 0 || !p.C || (!p.ones && !p.A) || (p.ones && p.M != 1)) return CLV_EINVAL;
+    if (p.a_shift < 0 || (p.a_shift > 0 && p.a_zero_period <= 0)) return CLV_EINVAL;
+    g.prob[i] = GemmProb{p.A, p.lda, p.M, p.C, p.ldc, p.a_shift, p.a_zero_period, p.ones, tile, row};
+    tile += (p.M + 95) / 96;
+    row += p.M;
+    if (!p.ones) vec = vec && (p.lda % 4 == 0) && (((uintptr_t)p.A) % 16 == 0);
+  }
+  g.M = row; g.N = N; g.K = K; g.alpha = 1.f; g.beta = beta;
+  g.B = B; g.ldb = ldb; g.bias = nullptr; g.act = CLV_ACT_NONE; g.aux = nullptr;
+  g.vecA = vec;
+  g.vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
+  int splits = split_k < 1 ? clv_gemm_grouped_auto_split(probs, nprob, N, K) : split_k;
+  int kc = (K + splits - 1) / splits;
+  kc = (kc + 15) / 16 * 16;
+  splits = (K + kc - 1) / kc;
+  g.k_chunk = kc;
+  g.partial = nullptr;
+  if (splits > 1) {
+    size_t need = (size_t)splits * row * N * sizeof(float);
+    if (!ws || ws_bytes < need) return CLV_EWORKSPACE;
+    g.partial = (float*)ws;
+  }
+  {
+    ProfScope p("gemm_grouped_tn", s);
+    launch_cfg<3, 3, 2, 2>(g, 1, 0, splits, s);       // 96 x 96 tiles
+  }
+  int st = launch_status();
+  if (st) return st;
+  if (splits > 1) {
+    ProfScope p("gemm_splitk_reduce", s);
+    size_t mn = (size_t)row * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, g, splits);
     st = launch_status();
   }

@@ -73,39 +73,48 @@ __global__ __launch_bounds__(256) void wn_stats_kernel(const AdamUnit* units, co
   }
 }
 
-// block = 64 consecutive global matrix columns x 4 unit-lanes; returns the column's sum of two slabs
+// block = 16 consecutive global matrix columns x 16 unit-lanes; returns this lane's share of the column sums
+constexpr int CL = 16;     // unit-lanes per column
 __device__ __forceinline__ void col_partial_sums(const AdamCol& c, const float* pa, const float* pb, int zy,
                                                  float& a, float& b) {
   const float* qa = pa + c.part_base + c.col_local;
   const float* qb = pb ? pb + c.part_base + c.col_local : nullptr;
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
   int k = zy;
-  for (; k + 4 < c.nunits; k += 8) {
-    a0 += qa[(size_t)k * c.cols]; a1 += qa[(size_t)(k + 4) * c.cols];
-    if (qb) { b0 += qb[(size_t)k * c.cols]; b1 += qb[(size_t)(k + 4) * c.cols]; }
+  for (; k + CL < c.nunits; k += 2 * CL) {
+    a0 += qa[(size_t)k * c.cols]; a1 += qa[(size_t)(k + CL) * c.cols];
+    if (qb) { b0 += qb[(size_t)k * c.cols]; b1 += qb[(size_t)(k + CL) * c.cols]; }
   }
-  for (; k < c.nunits; k += 4) {
+  for (; k < c.nunits; k += CL) {
     a0 += qa[(size_t)k * c.cols];
     if (qb) b0 += qb[(size_t)k * c.cols];
   }
   a = a0 + a1; b = b0 + b1;
+}
+__device__ __forceinline__ float lanes16_sum(float (*red)[16], int zy, int cx, float v) {
+  red[zy][cx] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (zy == 0)
+#pragma unroll
+    for (int i = 0; i < CL; ++i) t += red[i][cx];
+  __syncthreads();
+  return t;
 }
 
 // colscal[4*j + {0,1,2,3}] = {1/s, grad_g/||V||, s, new_g}
 __global__ __launch_bounds__(256) void wn_cols_kernel(int n_cols, const AdamCol* cols, const float* partA,
                                                       const float* partB, const float* s, float* mg, float* vg,
                                                       float* colscal, AdamHyper h) {
-  __shared__ float ra[4][64], rbb[4][64];
-  const int cx = threadIdx.x & 63, zy = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cx;
+  __shared__ float red[CL][16];
+  const int cx = threadIdx.x & 15, zy = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + cx;
   float a = 0.f, b = 0.f;
   AdamCol c;
   if (j < n_cols) { c = cols[j]; col_partial_sums(c, partA, partB, zy, a, b); }
-  ra[zy][cx] = a; rbb[zy][cx] = b;
-  __syncthreads();
+  a = lanes16_sum(red, zy, cx, a);
+  b = lanes16_sum(red, zy, cx, b);
   if (zy != 0 || j >= n_cols) return;
-  a = (ra[0][cx] + ra[1][cx]) + (ra[2][cx] + ra[3][cx]);
-  b = (rbb[0][cx] + rbb[1][cx]) + (rbb[2][cx] + rbb[3][cx]);
   const float lr_t = adam_lr_t(h);
   const float sc = s[c.col_global];
   const float Vn = sqrtf(a);
@@ -124,17 +133,15 @@ __global__ __launch_bounds__(256) void wn_cols_kernel(int n_cols, const AdamCol*
 // s' = g'/||V'|| per column -> colscal[4j+0] (reused) and the persistent s; advances `iterations`
 __global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol* cols, const float* partC, float* s,
                                                        float* colscal, int32_t* iterations) {
-  __shared__ float ra[4][64];
+  __shared__ float red[CL][16];
   if (blockIdx.x == 0 && threadIdx.x == 0 && iterations) *iterations += 1;
-  const int cx = threadIdx.x & 63, zy = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cx;
+  const int cx = threadIdx.x & 15, zy = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + cx;
   float a = 0.f, b = 0.f;
   AdamCol c;
   if (j < n_cols) { c = cols[j]; col_partial_sums(c, partC, nullptr, zy, a, b); }
-  ra[zy][cx] = a;
-  __syncthreads();
+  a = lanes16_sum(red, zy, cx, a);
   if (zy != 0 || j >= n_cols) return;
-  a = (ra[0][cx] + ra[1][cx]) + (ra[2][cx] + ra[3][cx]);
   const float snew = colscal[4 * j + 3] / sqrtf(a);
   colscal[4 * j + 0] = snew;
   s[c.col_global] = snew;
@@ -298,13 +305,13 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   const bool wn = weightnorm && c.n_cols > 0;
   if (wn) {
     hipLaunchKernelGGL(wn_stats_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, s, partA, partB);
-    hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + 63) / 64), dim3(256), 0, st, c.n_cols, cols, partA, partB, s,
+    hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + 15) / 16), dim3(256), 0, st, c.n_cols, cols, partA, partB, s,
                        mg, vg, colscal, h);
   }
   hipLaunchKernelGGL(wn_update_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, m, v, colscal, colidx0,
                      partC, h);
   if (wn) {
-    hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + 63) / 64), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
+    hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + 15) / 16), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
                        iterations_dev);
     hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, colscal, colidx0);
   } else if (iterations_dev) {

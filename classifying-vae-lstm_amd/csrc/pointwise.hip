@@ -163,6 +163,30 @@ __global__ __launch_bounds__(1024) void sum_strided_kernel(int n, const float* x
   }
 }
 
+struct SumArgs { const float* x[5]; int n[5]; int stride[5]; };
+// out[k] = mean of x[k] (n[k] strided elements); one block per term
+__global__ __launch_bounds__(1024) void loss_sums_kernel(SumArgs a, float* out) {
+  __shared__ float part[16];
+  const int k = blockIdx.x;
+  const float* x = a.x[k];
+  const int n = a.n[k], st = a.stride[k];
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int i = threadIdx.x;
+  for (; i + 3072 < n; i += 4096) {
+    acc0 += x[(size_t)i * st]; acc1 += x[(size_t)(i + 1024) * st];
+    acc2 += x[(size_t)(i + 2048) * st]; acc3 += x[(size_t)(i + 3072) * st];
+  }
+  for (; i < n; i += 1024) acc0 += x[(size_t)i * st];
+  float acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int j = 0; j < 16; ++j) t += part[j];
+    out[k] = t / (float)n;
+  }
+}
+
 // column sums, stage 1: block (64 cols x 4 row-lanes) handles a chunk of rows
 constexpr int CS_ROWS = 64;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int N, const float* X, int ldx, float* partial) {
@@ -336,5 +360,16 @@ extern "C" int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src
     const int64_t n = rows * row_elems;
     hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems, src, idx, out);
   }
+  return launch_status();
+}
+
+extern "C" int clv_loss_sums(const float* x0, int n0, int s0, const float* x1, int n1, int s1, const float* x2, int n2,
+                             int s2, const float* x3, int n3, int s3, const float* x4, int n4, int s4, float* out,
+                             void* stream) {
+  if (!x0 || !x1 || !x2 || !x3 || !x4 || !out || n0 <= 0 || n1 <= 0 || n2 <= 0 || n3 <= 0 || n4 <= 0) return CLV_EINVAL;
+  SumArgs a{{x0, x1, x2, x3, x4}, {n0, n1, n2, n3, n4}, {s0, s1, s2, s3, s4}};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("loss_sums", s);
+  hipLaunchKernelGGL(loss_sums_kernel, dim3(5), dim3(1024), 0, s, a, out);
   return launch_status();
 }

@@ -11,6 +11,7 @@ layer/weight order), each starting on a 16-byte boundary of one flat fp32
 buffer; gradients, Adam m/v use the same layout; the weight-norm column state
 (s, m_g, v_g) is a second flat layout over the last axis of every matrix.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -142,6 +143,8 @@ class _EngineBase:
         self.device = torch.device(device)
         self.P = FlatParams(shapes, self.device)
         self.ws = ops.Workspace(self.device, 8 << 20)
+        self.ws2 = ops.Workspace(self.device, 8 << 20)        # scratch of the side stream
+        self.side = torch.cuda.Stream(device=self.device) if cfg.get('two_streams', False) else None
         self.scal = torch.zeros(8, dtype=torch.float32, device=self.device)   # vae, kl_z, kl_w, w_rec, acc
         # loss weights may be annealed per epoch (utils/model_utils.py:19-50)
         self.kl_weight = float(cfg.get('kl_weight', 1.0))
@@ -159,6 +162,22 @@ class _EngineBase:
 
     def _mean_into(self, n, x, stride, slot):
         ops.sum_strided(n, x, stride, 1.0 / n, self.scal[slot:])
+
+    # -- two-stream DAG: MFMA GEMMs on the side stream overlap the VALU-bound LSTM kernels ---------
+    def _side(self):
+        """Context: enqueue on the side stream, ordered after everything enqueued so far on the main one."""
+        if self.side is None:
+            return contextlib.nullcontext()
+        self.side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.side)
+
+    def _side_more(self):
+        """Context: continue on the side stream without a new dependency on the main stream."""
+        return contextlib.nullcontext() if self.side is None else torch.cuda.stream(self.side)
+
+    def _join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
 
 # --------------------------------------------------------------------------- #
@@ -258,11 +277,8 @@ class VaeEngine(_EngineBase):
         inv = 1.0 / B
         self.forward(x, xp, eps_w, eps_z, w_true)
         ops.bernoulli_nll(B, D, self.logits, x, D, inv, self.rownll, self.dlogits if need_grads else None)
-        self._mean_into(B, self.rownll, 1, 0)
-        self._mean_into(B, self.rowkl, 1, 1)
-        self._mean_into(B, self.rowloss, 3, 2)
-        self._mean_into(B, self.rowloss[:, 1:], 3, 3)
-        self._mean_into(B, self.rowloss[:, 2:], 3, 4)
+        ops.loss_sums([(self.rownll, B, 1), (self.rowkl, B, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
+                       (self.rowloss[:, 2:], B, 3)], self.scal)
         if not need_grads:
             return
         g, ws, xo = ops.gemm, self.ws, self.xoff
@@ -349,14 +365,23 @@ class VrnnEngine(_EngineBase):
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         g, ws = ops.gemm, self.ws
+        # the two big input projections only need X / Xp: side stream, under the label path and encoder LSTM
+        with self._side():
+            g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
         # label path (:174-191)
         g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
         g(self.hW, P.p('Wargs/kernel'), self.wargs, B, 2 * C1, D, bias=P.p('Wargs/bias'), ws=ws)
         ops.label_fwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, cfg['w_log_var_prior'],
                       self.W, self.rowloss)
         # encoder LSTM on [X, repeat(W)] (:193-199): per-row bias carries W.K_w + b
+        off = self.off
         g(self.W, P.rows(P.params, 'encoder_h/kernel', D), self.wk_enc, B, G4, Cn, bias=P.p('encoder_h/bias'), ws=ws)
-        g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
+        g(self.W, P.rows(P.params, 'decoder_h/kernel', off + L), self.wk_dec, B, G4, Cn, bias=P.p('decoder_h/bias'),
+          ws=ws)
+        self._join()
+        if cfg['use_x_prev']:
+            with self._side():
+                g(Xp, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, D, ws=self.ws2)
         ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
                          self.cs_enc, self.gates_enc, gate_act=self.gate_act)
         # latent heads + sample (:200-216)
@@ -365,11 +390,7 @@ class VrnnEngine(_EngineBase):
           ws=ws)
         ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, L, self.rowkl)
         # decoder LSTM on [Xp, Z, repeat(W)] (:218-228)
-        off = self.off
-        g(self.W, P.rows(P.params, 'decoder_h/kernel', off + L), self.wk_dec, B, G4, Cn, bias=P.p('decoder_h/bias'),
-          ws=ws)
-        if cfg['use_x_prev']:
-            g(Xp, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, D, ws=ws)
+        self._join()
         g(self.Z, P.rows(P.params, 'decoder_h/kernel', off), self.gates_dec, BT, G4, L,
           beta=1.0 if cfg['use_x_prev'] else 0.0, ws=ws)
         ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
@@ -430,24 +451,21 @@ class VrnnEngine(_EngineBase):
         g(st['hs'], P.p('X_decoded_mean/kernel'), st['xhat'], B, D, H, bias=P.p('X_decoded_mean/bias'),
           act=ACT_SIGMOID, ws=ws)
 
-    def _lstm_wgrads(self, name, X_in, hs, dz, dzsum, in_rows):
-        """dkernel[0:in_rows], drecurrent, dbias of one LSTM from dz [B*T,4H]."""
+    def _lstm_wgrads(self, name, X_in, hs, dz, dzsum, Z_in, z_row, w_row, ws):
+        """Every weight gradient of one LSTM in two grouped launches.
+        Over dz [B*T,4H] (K = B*T): kernel rows of x_t, recurrent kernel (h_{t-1}: shift 1, zero at t == 0),
+        kernel rows of z_t.  Over dzsum [B,4H] (K = B): kernel rows of the repeated label W, and the bias."""
         cfg, P, B = self.cfg, self.P, self.B
-        H, T = cfg['H'], cfg['T']
+        D, H, T, L, Cn = cfg['D'], cfg['H'], cfg['T'], cfg['L'], cfg['C']
         BT, G4 = B * T, 4 * H
-        g, ws = ops.gemm, self.ws
+        probs = [dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)]
         if X_in is not None:
-            g(X_in, dz, P.g(name + '/kernel'), in_rows, G4, BT, ta=True, ws=ws)
-        # recurrent: sum_{b,t>=1} h[b,t-1]^T dz[b,t] = shifted product minus the rows that cross a batch boundary
-        dU = P.g(name + '/recurrent_kernel')
-        if BT > 1:
-            g(hs, dz.view(-1)[G4:], dU, H, G4, BT - 1, ta=True, ws=ws)
-            if B > 1:
-                g(hs.view(-1)[(T - 1) * H:], dz.view(-1)[T * G4:], dU, H, G4, B - 1, ta=True, lda=T * H, ldb=T * G4,
-                  alpha=-1.0, beta=1.0, ws=ws)
-        else:
-            dU.zero_()
-        ops.colsum(dzsum, B, G4, P.g(name + '/bias'), ws)
+            probs.insert(0, dict(A=X_in, lda=D, M=D, C=P.g(name + '/kernel')))
+        if Z_in is not None:
+            probs.append(dict(A=Z_in, lda=L, M=L, C=P.rows(P.grads, name + '/kernel', z_row)))
+        ops.gemm_grouped_tn(probs, G4, BT, dz, ws)
+        ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
+                             dict(A=None, M=1, C=P.g(name + '/bias'), ones=True)], G4, B, dzsum, ws)
 
     def grads_tail(self, X):
         """hW kernel gradient: the last and largest (T*D*D floats) product of the backward pass."""
@@ -468,40 +486,42 @@ class VrnnEngine(_EngineBase):
         g, ws, off = ops.gemm, self.ws, self.off
         self.forward(X, Xp, eps_W, eps_Z, w_true)
         ops.bernoulli_nll(BT, D, self.logits, X, D, inv_bt, self.rownll, self.dlogits if need_grads else None)
-        self._mean_into(BT, self.rownll, 1, 0)
-        self._mean_into(BT, self.rowkl, 1, 1)
-        self._mean_into(B, self.rowloss, 3, 2)
-        self._mean_into(B, self.rowloss[:, 1:], 3, 3)
-        self._mean_into(B, self.rowloss[:, 2:], 3, 4)
+        ops.loss_sums([(self.rownll, BT, 1), (self.rowkl, BT, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
+                       (self.rowloss[:, 2:], B, 3)], self.scal)
         if not need_grads:
+            self._join()
             return
-        # output head
-        g(self.hs_dec, self.dlogits, P.g('X_decoded_mean/kernel'), H, D, BT, ta=True, ws=ws)
-        ops.colsum(self.dlogits, BT, D, P.g('X_decoded_mean/bias'), ws)
+        ws2 = self.ws2 if self.side is not None else self.ws
+        # output head: its weight gradient runs on the side stream under the decoder BPTT
+        with self._side():
+            g(self.hs_dec, self.dlogits, P.g('X_decoded_mean/kernel'), H, D, BT, ta=True, ws=ws2)
+            ops.colsum(self.dlogits, BT, D, P.g('X_decoded_mean/bias'), ws2)
         g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
-        # decoder BPTT
+        # decoder BPTT (VALU) ...
         ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
                          self.dzsum_dec, gate_act=self.gate_act)
         dz = self.gates_dec
-        self._lstm_wgrads('decoder_h', Xp if cfg['use_x_prev'] else None, self.hs_dec, dz, self.dzsum_dec, D)
-        g(self.Z, dz, P.rows(P.grads, 'decoder_h/kernel', off), L, G4, BT, ta=True, ws=ws)
-        g(self.W, self.dzsum_dec, P.rows(P.grads, 'decoder_h/kernel', off + L), Cn, G4, B, ta=True, ws=ws)
+        # ... then its weight gradients (MFMA) go to the side stream and overlap the encoder BPTT
+        with self._side():
+            self._lstm_wgrads('decoder_h', Xp if cfg['use_x_prev'] else None, self.hs_dec, dz, self.dzsum_dec,
+                              self.Z, off, off + L, ws2)
         g(dz, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
         g(self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off + L), self.dW, B, Cn, G4, tb=True, ws=ws)
         # latent heads
         ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
-        g(self.hs_enc, self.dzargs, P.g('Z_mean/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws)
-        g(self.hs_enc, self.dzargs[:, L:], P.g('Z_log_var/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws)
-        ops.colsum(self.dzargs, BT, L, P.g('Z_mean/bias'), ws, ldx=2 * L)
-        ops.colsum(self.dzargs[:, L:], BT, L, P.g('Z_log_var/bias'), ws, ldx=2 * L)
         g(self.dzargs, P.p('Z_mean/kernel'), self.dhs, BT, H, L, tb=True, lda=2 * L, ws=ws)
         g(self.dzargs[:, L:], P.p('Z_log_var/kernel'), self.dhs, BT, H, L, tb=True, lda=2 * L, beta=1.0, ws=ws)
+        with self._side():
+            g(self.hs_enc, self.dzargs, P.g('Z_mean/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws2)
+            g(self.hs_enc, self.dzargs[:, L:], P.g('Z_log_var/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws2)
+            ops.colsum(self.dzargs, BT, L, P.g('Z_mean/bias'), ws2, ldx=2 * L)
+            ops.colsum(self.dzargs[:, L:], BT, L, P.g('Z_log_var/bias'), ws2, ldx=2 * L)
         # encoder BPTT
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                          self.dzsum_enc, gate_act=self.gate_act)
         dz = self.gates_enc
-        self._lstm_wgrads('encoder_h', X, self.hs_enc, dz, self.dzsum_enc, D)
-        g(self.W, self.dzsum_enc, P.rows(P.grads, 'encoder_h/kernel', D), Cn, G4, B, ta=True, ws=ws)
+        with self._side():
+            self._lstm_wgrads('encoder_h', X, self.hs_enc, dz, self.dzsum_enc, None, 0, D, ws2)
         g(self.dzsum_enc, P.rows(P.params, 'encoder_h/kernel', D), self.dW, B, Cn, G4, tb=True, beta=1.0, ws=ws)
         # label head
         ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, self.W, self.dW,
@@ -511,5 +531,6 @@ class VrnnEngine(_EngineBase):
         ops.colsum(self.dwargs, B, 2 * C1, P.g('Wargs/bias'), ws)
         g(self.dwargs, P.p('Wargs/kernel'), self.dhW, B, D, 2 * C1, tb=True, act=ACT_MASKPOS, aux=self.hW, ws=ws)
         ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
+        self._join()
         if do_tail:
             self.grads_tail(X)

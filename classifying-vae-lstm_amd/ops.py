@@ -51,6 +51,35 @@ def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None,
                          _ptr(C_out), ldc, _ptr(bias), act, _ptr(aux), split_k, wsp, wsb, _stream()), "clv_gemm_f32")
 
 
+def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None):
+    """probs: list of dict(A=tensor|None, lda, M, C=tensor, ldc, shift=0, zero_period=0, ones=False);
+    C_p[M_p,N] = A_p^T . B for every problem in one launch (all share B [K,N])."""
+    L = _lib.lib()
+    arr = (_lib.GemmProb * len(probs))()
+    for i, p in enumerate(probs):
+        A = p.get('A')
+        arr[i] = _lib.GemmProb(A.data_ptr() if A is not None else None, p.get('lda', p['M']), p['M'],
+                               p['C'].data_ptr(), p.get('ldc', N), p.get('shift', 0), p.get('zero_period', 0),
+                               int(bool(p.get('ones', False))))
+    n = len(probs)
+    if split_k is None:
+        split_k = L.clv_gemm_grouped_auto_split(arr, n, N, K)
+    wsp, wsb = None, 0
+    if split_k > 1:
+        buf = ws.ensure(L.clv_gemm_grouped_workspace_bytes(arr, n, N, split_k))
+        wsp, wsb = _ptr(buf), buf.numel()
+    check(L.clv_gemm_grouped_tn(arr, n, N, K, _ptr(B), ldb if ldb is not None else N, float(beta), split_k, wsp, wsb,
+                                _stream()), "clv_gemm_grouped_tn")
+
+
+def loss_sums(terms, out):
+    """terms: five (tensor, n, stride); out[k] = mean of term k."""
+    a = []
+    for t, n, st in terms:
+        a += [_ptr(t), n, st]
+    check(_lib.lib().clv_loss_sums(*a, _ptr(out), _stream()), "clv_loss_sums")
+
+
 def colsum(X, M, N, out, ws, ldx=None, beta=0.0):
     L = _lib.lib()
     buf = ws.ensure(L.clv_colsum_workspace_bytes(M, N))

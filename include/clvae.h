@@ -67,6 +67,24 @@ int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
                  const float* bias, int act, const float* aux,
                  int split_k, void* ws, size_t ws_bytes, void* stream);
 
+/* Grouped weight-gradient GEMM: C_p[M_p,N] = (beta ? beta*C_p : 0) + op(A_p)^T . B for up to 4 problems
+ * that share B [K,N] -- one pass over dz yields every kernel gradient of an LSTM
+ * (x^T.dz, h_{t-1}^T.dz, z^T.dz) or dW and db of a Dense layer.  A_p is [K, M_p] row-major (lda).
+ * a_shift/a_zero_period: row k of A_p is taken from row k - a_shift and is zero when
+ * k % a_zero_period == 0 (h_{t-1}: shift 1, period T, zero initial state).  ones != 0: A_p is an
+ * implicit row of ones, M_p must be 1 (column sums of B = bias gradient).
+ * Replaces the weight-gradient half of K.gradients() for cl_vrnn/model.py:196-199,225-228. */
+typedef struct clv_gemm_prob {
+  const float* A; int32_t lda; int32_t M;
+  float* C; int32_t ldc;
+  int32_t a_shift; int32_t a_zero_period; int32_t ones;
+} clv_gemm_prob;
+int clv_gemm_grouped_auto_split(const clv_gemm_prob* host_probs, int nprob, int N, int K);
+size_t clv_gemm_grouped_workspace_bytes(const clv_gemm_prob* host_probs, int nprob, int N, int split_k);
+int clv_gemm_grouped_tn(const clv_gemm_prob* host_probs, int nprob, int N, int K,
+                        const float* B, int ldb, float beta,
+                        int split_k, void* ws, size_t ws_bytes, void* stream);
+
 /* column sums: out[N] = (beta ? out : 0) + sum_m X[m, n]   (bias gradients) */
 size_t clv_colsum_workspace_bytes(int M, int N);
 int clv_colsum_f32(int M, int N, const float* X, int ldx, float beta, float* out,
@@ -131,6 +149,11 @@ int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
  * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71). */
 int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out, void* stream);
+
+/* the five loss scalars of a step in one launch: out[k] = scale[k] * sum_{i<n[k]} x[k][i*stride[k]], k < 5
+ * (vae, kl_z, kl_w, w_rec, acc means; fixed summation order => deterministic). */
+int clv_loss_sums(const float* x0, int n0, int s0, const float* x1, int n1, int s1, const float* x2, int n2, int s2,
+                  const float* x3, int n3, int s3, const float* x4, int n4, int s4, float* out, void* stream);
 
 /* deterministic sum of n floats with stride: out[0] = scale * sum_i x[i*stride] */
 int clv_sum_strided(int n, const float* x, int stride, float scale, float* out, void* stream);

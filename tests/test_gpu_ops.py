@@ -263,3 +263,40 @@ def test_graph_capture_replay(dev):
         gr.launch()
     torch.cuda.synchronize()
     np.testing.assert_allclose(N(Cc), 4 * N(ref), rtol=1e-5, atol=1e-5)
+
+
+def test_gemm_grouped_tn(dev):
+    """one launch: x^T.dz, h_{t-1}^T.dz (shift 1, zero at t == 0), z^T.dz, and the column sums (ones row)."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(5)
+    B, Tn, H, Nn = 6, 7, 88, 352
+    K = B * Tn
+    X = rng.standard_normal((K, 88)); hs = rng.standard_normal((K, H)); Z = rng.standard_normal((K, 3))
+    dz = rng.standard_normal((K, Nn))
+    hprev = hs.reshape(B, Tn, H).copy()
+    hprev[:, 1:] = hprev[:, :-1]; hprev[:, 0] = 0
+    hprev = hprev.reshape(K, H)
+    ws = ops.Workspace(dev)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    for split in (1, 3, None):
+        dK = torch.zeros(88 + 3, Nn, device=dev); dU = torch.zeros(H, Nn, device=dev); db = torch.ones(Nn, device=dev)
+        ops.gemm_grouped_tn([dict(A=T(X, dev), lda=88, M=88, C=dK),
+                             dict(A=T(hs, dev), lda=H, M=H, C=dU, shift=1, zero_period=Tn),
+                             dict(A=T(Z, dev), lda=3, M=3, C=dK[88:]),
+                             dict(A=None, M=1, C=db, ones=True)], Nn, K, T(dz, dev), ws, split_k=split)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(N(dK)[:88], f(X).T @ f(dz), atol=2e-4)
+        np.testing.assert_allclose(N(dK)[88:], f(Z).T @ f(dz), atol=2e-4)
+        np.testing.assert_allclose(N(dU), f(hprev).T @ f(dz), atol=2e-4)
+        np.testing.assert_allclose(N(db), f(dz).sum(0), atol=2e-4)
+
+
+def test_loss_sums(dev):
+    from clvae_amd import ops
+    rng = np.random.default_rng(6)
+    a, b, c = rng.standard_normal(5000), rng.standard_normal(37), rng.standard_normal((29, 3))
+    out = torch.zeros(8, device=dev)
+    cd = T(c, dev)
+    ops.loss_sums([(T(a, dev), 5000, 1), (T(b, dev), 37, 1), (cd, 29, 3), (cd[:, 1:], 29, 3), (cd[:, 2:], 29, 3)], out)
+    ref = [a.astype(np.float32).mean(), b.astype(np.float32).mean()] + [c[:, j].astype(np.float32).mean() for j in range(3)]
+    np.testing.assert_allclose(N(out)[:5], ref, atol=1e-5)
