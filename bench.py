@@ -58,7 +58,7 @@ def make_engine(w, dev):
         cfg = dict(D=88, H=88, L=w['L'], Hc=88, C=w['C'], use_x_prev=True, class_weight=1.0, kl_weight=1.0,
                    w_kl_weight=1.0, w_log_var_prior=0.0)
         eng = VaeEngine(cfg, w['B'], dev)
-    eng.P.set_weights(init_weights(eng.P.shapes, cfg, seed=0))
+    eng.P.set_weights(init_weights(eng.P.logical, cfg, seed=0))
     return eng, cfg
 
 

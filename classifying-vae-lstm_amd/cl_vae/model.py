@@ -232,7 +232,7 @@ def get_model(batch_size, original_dim, latent_dims, class_dims, optimizer, clas
                use_x_prev=bool(use_x_prev), class_weight=get_value(class_weight), kl_weight=get_value(kl_weight),
                w_kl_weight=get_value(w_kl_weight), w_log_var_prior=float(w_log_var_prior))
     eng = VaeEngine(cfg, batch_size, device)
-    eng.P.set_weights(init_weights(eng.P.shapes, cfg, seed=seed))
+    eng.P.set_weights(init_weights(eng.P.logical, cfg, seed=seed))
     model = ClVaeModel(eng, optimizer, kl_weight, w_kl_weight, class_weight, bool(use_x_prev), seed=seed)
     return model, EncModel(model)
 

@@ -315,9 +315,9 @@ static int auto_split(int M, int N, int K) {
   int bm, bn;
   tile_dims(pick_tile(M, N), bm, bn);
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-  if (tiles >= 512 || K < 64) return 1;
+  if (tiles >= 256 || K < 512) return 1;       // a reduce launch costs ~6 us: only worth it for long K
   long s = (1024 + tiles - 1) / tiles;
-  if (s > K / 32) s = K / 32;
+  if (s > K / 64) s = K / 64;
   if (s > 512) s = 512;
   return s < 1 ? 1 : (int)s;
 }
@@ -401,9 +401,9 @@ static int grouped_tiles(const clv_gemm_prob* probs, int nprob, int bm) {
 extern "C" int clv_gemm_grouped_auto_split(const clv_gemm_prob* probs, int nprob, int N, int K) {
   if (!probs || nprob < 1 || nprob > clv::MAX_PROB) return 1;
   const long tiles = (long)grouped_tiles(probs, nprob, 96) * ((N + 95) / 96);
-  if (tiles >= 512 || K < 64) return 1;
+  if (tiles >= 256 || K < 512) return 1;
   long s = (1024 + tiles - 1) / tiles;
-  if (s > K / 32) s = K / 32;
+  if (s > K / 64) s = K / 64;
   if (s > 512) s = 512;
   return s < 1 ? 1 : (int)s;
 }

@@ -56,11 +56,20 @@ __global__ __launch_bounds__(256) void wn_stats_kernel(const AdamUnit* units, co
     float a = 0.f, b = 0.f;
     if (col < un.cols) {
       const float inv_s = 1.f / s[un.col_offset + col];
-      for (int r = ry; r < un.nrows; r += 4) {
-        const size_t o = un.offset + (size_t)(un.row0 + r) * un.cols + col;
-        const float V = params[o] * inv_s;
-        a += V * V;
-        b += grads[o] * V;
+      float pv[UNIT_ROWS / 4], gv[UNIT_ROWS / 4];
+#pragma unroll
+      for (int i = 0; i < UNIT_ROWS / 4; ++i) {
+        const int r = ry + 4 * i;
+        const size_t o = un.offset + (size_t)(un.row0 + min(r, un.nrows - 1)) * un.cols + col;
+        pv[i] = params[o]; gv[i] = grads[o];
+      }
+#pragma unroll
+      for (int i = 0; i < UNIT_ROWS / 4; ++i) {
+        if (ry + 4 * i < un.nrows) {
+          const float V = pv[i] * inv_s;
+          a += V * V;
+          b += gv[i] * V;
+        }
       }
     }
     ra[ry][cx] = a; rbb[ry][cx] = b;
@@ -173,16 +182,27 @@ __global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, f
     if (col < un.cols) {
       const float inv_s = colscal[4 * (cbase + col) + 0], gov = colscal[4 * (cbase + col) + 1];
       const float sc = colscal[4 * (cbase + col) + 2];
-      for (int r = ry; r < un.nrows; r += 4) {
-        const size_t o = un.offset + (size_t)(un.row0 + r) * un.cols + col;
-        const float V = params[o] * inv_s;
-        const float gV = sc * (grads[o] - gov * V);
-        const float mn = h.b1 * m[o] + (1.f - h.b1) * gV;
-        const float vn = h.b2 * v[o] + (1.f - h.b2) * gV * gV;
-        m[o] = mn; v[o] = vn;
-        const float Vp = V - lr_t * mn / (sqrtf(vn) + h.eps);
-        params[o] = Vp;
-        acc += Vp * Vp;
+      float pv[UNIT_ROWS / 4], gv[UNIT_ROWS / 4], mv[UNIT_ROWS / 4], vv[UNIT_ROWS / 4];
+#pragma unroll
+      for (int i = 0; i < UNIT_ROWS / 4; ++i) {
+        const int r = ry + 4 * i;
+        const size_t o = un.offset + (size_t)(un.row0 + min(r, un.nrows - 1)) * un.cols + col;
+        pv[i] = params[o]; gv[i] = grads[o]; mv[i] = m[o]; vv[i] = v[o];
+      }
+#pragma unroll
+      for (int i = 0; i < UNIT_ROWS / 4; ++i) {
+        const int r = ry + 4 * i;
+        if (r < un.nrows) {
+          const size_t o = un.offset + (size_t)(un.row0 + r) * un.cols + col;
+          const float V = pv[i] * inv_s;
+          const float gV = sc * (gv[i] - gov * V);
+          const float mn = h.b1 * mv[i] + (1.f - h.b1) * gV;
+          const float vn = h.b2 * vv[i] + (1.f - h.b2) * gV * gV;
+          m[o] = mn; v[o] = vn;
+          const float Vp = V - lr_t * mn / (sqrtf(vn) + h.eps);
+          params[o] = Vp;
+          acc += Vp * Vp;
+        }
       }
     }
     rc[ry][cx] = acc;

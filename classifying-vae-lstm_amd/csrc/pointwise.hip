@@ -135,11 +135,14 @@ __global__ __launch_bounds__(256) void bernoulli_nll_kernel(int R, int D, const 
     const float a = logits[(size_t)row * D + j];
     const float t = y[(size_t)row * ldy + j];
     const float l = fminf(fmaxf(a, -LOGIT_CLIP), LOGIT_CLIP);
-    const float sp = fmaxf(l, 0.f) + log1pf(__expf(-fabsf(l)));
+    // softplus(l) = max(l,0) + log(1 + e^-|l|); e = e^-|l| in (1e-7, 1] so 1+e is exact enough for v_log_f32
+    const float e = __expf(-fabsf(l));
+    const float sp = fmaxf(l, 0.f) + __logf(1.f + e);
     acc += sp - l * t;
     if (dlogits) {
       const bool inside = (a >= -LOGIT_CLIP) && (a <= LOGIT_CLIP);
-      const float sg = 1.f / (1.f + expf(-l));
+      const float r1 = fast_rcp(1.f + e);
+      const float sg = l >= 0.f ? r1 : e * r1;          // sigmoid(l) from the same exponential
       dlogits[(size_t)row * D + j] = inside ? scale * (sg - t) : 0.f;
     }
   }
@@ -229,19 +232,22 @@ __global__ void axpy_kernel(int64_t n, float alpha, const float* x, float* y) {
   if (i < n) y[i] += alpha * x[i];
 }
 
-// out[r, :] = src[idx[r], :]  (row gather: mini-batch assembly from the HBM-resident data set)
-__global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out) {
+// out[r, :] = src[idx[r], :]  (row gather: mini-batch assembly from the HBM-resident data set).  A source row
+// is a sequence of `chunk`-float pieces (frames); piece j of row r lands at out + (r*pieces + j)*out_ld, so
+// the history frames can be written straight into the [Xp | Z] decoder-input buffer (out_ld > chunk).
+template <bool VEC>
+__global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out,
+                                   int64_t chunk, int64_t out_ld) {
+  constexpr int W = VEC ? 4 : 1;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n4 = row_elems / 4;
-  if (i >= rows * n4) return;
-  const int64_t r = i / n4, c = i % n4;
-  reinterpret_cast<float4*>(out + r * row_elems)[c] = reinterpret_cast<const float4*>(src + idx[r] * row_elems)[c];
-}
-__global__ void gather_rows_scalar_kernel(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * row_elems) return;
-  const int64_t r = i / row_elems, c = i % row_elems;
-  out[i] = src[idx[r] * row_elems + c];
+  const int64_t nw = row_elems / W;
+  if (i >= rows * nw) return;
+  const int64_t r = i / nw, c = (i % nw) * W;
+  const int64_t piece = c / chunk, within = c % chunk;
+  const float* sp = src + idx[r] * row_elems + c;
+  float* dp = out + (r * (row_elems / chunk) + piece) * out_ld + within;
+  if (VEC) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
+  else *dp = *sp;
 }
 
 __global__ void bernoulli_sample_kernel(int64_t n, const float* p, const float* u, float* x) {
@@ -348,18 +354,20 @@ extern "C" int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* 
 }
 
 extern "C" int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out,
-                               void* stream) {
+                               int64_t chunk, int64_t out_ld, void* stream) {
   if (rows <= 0 || row_elems <= 0 || !src || !idx || !out) return CLV_EINVAL;
+  if (chunk <= 0) { chunk = row_elems; out_ld = row_elems; }
+  if (row_elems % chunk != 0 || out_ld < chunk) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ProfScope pr("gather_rows", s);
-  const bool vec = row_elems % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
-  if (vec) {
-    const int64_t n = rows * (row_elems / 4);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems, src, idx, out);
-  } else {
-    const int64_t n = rows * row_elems;
-    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems, src, idx, out);
-  }
+  const bool vec = chunk % 4 == 0 && out_ld % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const int64_t n = rows * (vec ? row_elems / 4 : row_elems);
+  if (vec)
+    hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems, src,
+                       idx, out, chunk, out_ld);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems,
+                       src, idx, out, chunk, out_ld);
   return launch_status();
 }
 

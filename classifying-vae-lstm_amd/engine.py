@@ -52,11 +52,41 @@ def vrnn_param_shapes(cfg):
             ('X_decoded_mean/kernel', (H, D)), ('X_decoded_mean/bias', (D,))]
 
 
-class FlatParams:
-    """Flat fp32 parameter / gradient / optimizer-state buffers plus the Adam-WN plan."""
+def fuse_heads(shapes, pairs):
+    """Physical layout where each (a, b, fused) pair of same-input Dense heads is ONE [in, na+nb] kernel and
+    one [na+nb] bias: a single GEMM serves both heads (forward, dX and dW).  Columns are independent under
+    weight normalisation and Adam, so the update is identical to two separate tensors.
+    Returns (physical shapes, aliases: logical name -> (physical name, col0, ncols))."""
+    d = dict(shapes)
+    phys, aliases, done = [], {}, set()
+    for name, shp in shapes:
+        layer, w = name.split('/')
+        hit = [pr for pr in pairs if layer in pr[:2]]
+        if not hit:
+            phys.append((name, shp))
+            continue
+        a, b, fused = hit[0]
+        na, nb = d[a + '/kernel'][1], d[b + '/kernel'][1]
+        for wn in ('kernel', 'bias'):
+            aliases[a + '/' + wn] = (fused + '/' + wn, 0, na)
+            aliases[b + '/' + wn] = (fused + '/' + wn, na, nb)
+        if fused not in done:
+            done.add(fused)
+            phys.append((fused + '/kernel', (d[a + '/kernel'][0], na + nb)))
+            phys.append((fused + '/bias', (na + nb,)))
+    return phys, aliases
 
-    def __init__(self, shapes, device):
-        self.shapes = list(shapes)
+
+class FlatParams:
+    """Flat fp32 parameter / gradient / optimizer-state buffers plus the Adam-WN plan.
+
+    `shapes` are the logical (Keras) tensors; `aliases` maps some of them onto column slices of fused
+    physical tensors (see fuse_heads)."""
+
+    def __init__(self, shapes, device, phys=None, aliases=None):
+        self.logical = list(shapes)
+        self.aliases = dict(aliases or {})
+        self.shapes = list(phys) if phys is not None else list(shapes)
         self.device = device
         self.offsets, self.col_offsets = {}, {}
         off = col = 0
@@ -91,6 +121,9 @@ class FlatParams:
 
     # views ---------------------------------------------------------------
     def view(self, buf, name):
+        if name in self.aliases:
+            phys, c0, nc = self.aliases[name]
+            return self.view(buf, phys)[..., c0:c0 + nc]
         shp = dict(self.shapes)[name]
         o = self.offsets[name]
         return buf[o:o + int(np.prod(shp))].view(*shp)
@@ -109,12 +142,12 @@ class FlatParams:
 
     # host <-> device -------------------------------------------------------
     def set_weights(self, weights):
-        for name, _ in self.shapes:
+        for name, _ in self.logical:
             self.p(name).copy_(torch.as_tensor(np.asarray(weights[name], dtype=np.float32)))
 
     def get_weights(self, buf=None):
         buf = self.params if buf is None else buf
-        return {name: self.view(buf, name).detach().cpu().numpy().copy() for name, _ in self.shapes}
+        return {name: self.view(buf, name).detach().cpu().numpy().copy() for name, _ in self.logical}
 
     def reset_optimizer(self):
         for t in (self.m, self.v, self.mg, self.vg):
@@ -136,12 +169,13 @@ def _f(device, *shape):
 
 
 class _EngineBase:
-    def __init__(self, cfg, batch_size, shapes, device):
+    def __init__(self, cfg, batch_size, shapes, device, head_pairs=()):
         _lib.require_gpu()
         self.cfg = dict(cfg)
         self.B = int(batch_size)
         self.device = torch.device(device)
-        self.P = FlatParams(shapes, self.device)
+        phys, aliases = fuse_heads(shapes, head_pairs)
+        self.P = FlatParams(shapes, self.device, phys, aliases)
         self.ws = ops.Workspace(self.device, 8 << 20)
         self.ws2 = ops.Workspace(self.device, 8 << 20)        # scratch of the side stream
         self.side = torch.cuda.Stream(device=self.device) if cfg.get('two_streams', False) else None
@@ -188,7 +222,8 @@ class VaeEngine(_EngineBase):
     the sum of GEMMs over row blocks of its kernel (beta = 1 accumulation)."""
 
     def __init__(self, cfg, batch_size, device='cuda:0'):
-        super().__init__(cfg, batch_size, vae_param_shapes(cfg), device)
+        super().__init__(cfg, batch_size, vae_param_shapes(cfg), device,
+                         head_pairs=[('w_mean', 'w_log_var', 'wargs'), ('z_mean', 'z_log_var', 'zargs')])
         B, D, H, L, Hc, Cn = self.B, cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
         d = self.device
         self.xoff = D if cfg['use_x_prev'] else 0      # decoder_h kernel rows: [w | xp | z]
@@ -220,9 +255,7 @@ class VaeEngine(_EngineBase):
         D, Hc, C1 = cfg['D'], cfg['Hc'], cfg['C'] - 1
         g = ops.gemm
         g(x, P.p('h_w/kernel'), self.h_w, B, Hc, D, bias=P.p('h_w/bias'), act=ACT_RELU, ws=self.ws)
-        g(self.h_w, P.p('w_mean/kernel'), self.wargs, B, C1, Hc, ldc=2 * C1, bias=P.p('w_mean/bias'), ws=self.ws)
-        g(self.h_w, P.p('w_log_var/kernel'), self.wargs[:, C1:], B, C1, Hc, ldc=2 * C1, bias=P.p('w_log_var/bias'),
-          ws=self.ws)
+        g(self.h_w, P.p('wargs/kernel'), self.wargs, B, 2 * C1, Hc, bias=P.p('wargs/bias'), ws=self.ws)
 
     def encode_z(self, x, w, B=None):
         """h = relu([x,w].K + b); z_mean, z_log_var (:160-164) -> self.zargs"""
@@ -233,9 +266,7 @@ class VaeEngine(_EngineBase):
         g(x, P.p('h/kernel'), self.h, B, H, D, ws=self.ws)
         g(w, P.rows(P.params, 'h/kernel', D), self.h, B, H, Cn, beta=1.0, bias=P.p('h/bias'), act=ACT_RELU,
           ws=self.ws)
-        g(self.h, P.p('z_mean/kernel'), self.zargs, B, L, H, ldc=2 * L, bias=P.p('z_mean/bias'), ws=self.ws)
-        g(self.h, P.p('z_log_var/kernel'), self.zargs[:, L:], B, L, H, ldc=2 * L, bias=P.p('z_log_var/bias'),
-          ws=self.ws)
+        g(self.h, P.p('zargs/kernel'), self.zargs, B, 2 * L, H, bias=P.p('zargs/bias'), ws=self.ws)
 
     def decode(self, w, z, xp, B=None, act=ACT_NONE):
         """logits (or x_hat with act=sigmoid) = Dense(relu([w,xp,z].K + b)) (:177-188) -> self.logits"""
@@ -296,13 +327,9 @@ class VaeEngine(_EngineBase):
         g(self.d_hdec, P.rows(P.params, 'decoder_h/kernel', Cn + xo), self.dz, B, L, H, tb=True, ws=ws)
         # latent heads
         ops.gauss_bwd(B, L, self.zargs, eps_z, self.dz, L, self.kl_weight * inv, self.dzargs)
-        g(self.h, self.dzargs, P.g('z_mean/kernel'), H, L, B, ta=True, ldb=2 * L, ws=ws)
-        g(self.h, self.dzargs[:, L:], P.g('z_log_var/kernel'), H, L, B, ta=True, ldb=2 * L, ws=ws)
-        ops.colsum(self.dzargs, B, L, P.g('z_mean/bias'), ws, ldx=2 * L)
-        ops.colsum(self.dzargs[:, L:], B, L, P.g('z_log_var/bias'), ws, ldx=2 * L)
-        g(self.dzargs, P.p('z_mean/kernel'), self.d_h, B, H, L, tb=True, lda=2 * L, ws=ws)
-        g(self.dzargs[:, L:], P.p('z_log_var/kernel'), self.d_h, B, H, L, tb=True, lda=2 * L, beta=1.0,
-          act=ACT_MASKPOS, aux=self.h, ws=ws)
+        g(self.h, self.dzargs, P.g('zargs/kernel'), H, 2 * L, B, ta=True, ws=ws)
+        ops.colsum(self.dzargs, B, 2 * L, P.g('zargs/bias'), ws)
+        g(self.dzargs, P.p('zargs/kernel'), self.d_h, B, H, 2 * L, tb=True, act=ACT_MASKPOS, aux=self.h, ws=ws)
         g(x, self.d_h, P.g('h/kernel'), D, H, B, ta=True, ws=ws)
         g(self.w, self.d_h, P.rows(P.grads, 'h/kernel', D), Cn, H, B, ta=True, ws=ws)
         ops.colsum(self.d_h, B, H, P.g('h/bias'), ws)
@@ -311,13 +338,9 @@ class VaeEngine(_EngineBase):
         ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_w, w_true, self.w, self.dw,
                       cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv,
                       self.dwargs, self.dwargs[:, C1:], 2 * C1)
-        g(self.h_w, self.dwargs, P.g('w_mean/kernel'), Hc, C1, B, ta=True, ldb=2 * C1, ws=ws)
-        g(self.h_w, self.dwargs[:, C1:], P.g('w_log_var/kernel'), Hc, C1, B, ta=True, ldb=2 * C1, ws=ws)
-        ops.colsum(self.dwargs, B, C1, P.g('w_mean/bias'), ws, ldx=2 * C1)
-        ops.colsum(self.dwargs[:, C1:], B, C1, P.g('w_log_var/bias'), ws, ldx=2 * C1)
-        g(self.dwargs, P.p('w_mean/kernel'), self.d_hw, B, Hc, C1, tb=True, lda=2 * C1, ws=ws)
-        g(self.dwargs[:, C1:], P.p('w_log_var/kernel'), self.d_hw, B, Hc, C1, tb=True, lda=2 * C1, beta=1.0,
-          act=ACT_MASKPOS, aux=self.h_w, ws=ws)
+        g(self.h_w, self.dwargs, P.g('wargs/kernel'), Hc, 2 * C1, B, ta=True, ws=ws)
+        ops.colsum(self.dwargs, B, 2 * C1, P.g('wargs/bias'), ws)
+        g(self.dwargs, P.p('wargs/kernel'), self.d_hw, B, Hc, 2 * C1, tb=True, act=ACT_MASKPOS, aux=self.h_w, ws=ws)
         g(x, self.d_hw, P.g('h_w/kernel'), D, Hc, B, ta=True, ws=ws)
         ops.colsum(self.d_hw, B, Hc, P.g('h_w/bias'), ws)
 
@@ -327,7 +350,8 @@ class VrnnEngine(_EngineBase):
     """cl_vrnn: classifying VAE + two LSTMs (cl_vrnn/model.py:164-267)."""
 
     def __init__(self, cfg, batch_size, device='cuda:0'):
-        super().__init__(cfg, batch_size, vrnn_param_shapes(cfg), device)
+        super().__init__(cfg, batch_size, vrnn_param_shapes(cfg), device,
+                         head_pairs=[('Z_mean', 'Z_log_var', 'Zargs')])
         B, D, H, L, T, Cn = self.B, cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         if H != 88:
             raise ValueError("the LSTM sequence kernels are built for intermediate_dim == 88")
@@ -347,7 +371,12 @@ class VrnnEngine(_EngineBase):
         self.hs_enc, self.cs_enc = _f(d, BT, H), _f(d, BT, H)
         self.hs_dec, self.cs_dec = _f(d, BT, H), _f(d, BT, H)
         self.zargs = _f(d, BT, 2 * L)
-        self.Z = _f(d, BT, L)
+        # decoder input [Xp | Z] as ONE matrix (row stride padded to a multiple of 4 floats): the history
+        # frames are staged into its first D columns, gauss_fwd writes Z next to them, so the decoder's
+        # input projection and its kernel gradient are single GEMMs over K = D + L
+        self.xz_ld = (self.off + L + 3) // 4 * 4
+        self.XZ = torch.zeros(BT, self.xz_ld, dtype=torch.float32, device=d)
+        self.Z = self.XZ[:, self.off:self.off + L]
         self.rowkl = _f(d, BT)
         self.logits = _f(d, BT, D)
         self.dlogits = _f(d, BT, D)
@@ -365,7 +394,9 @@ class VrnnEngine(_EngineBase):
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         g, ws = ops.gemm, self.ws
-        # the two big input projections only need X / Xp: side stream, under the label path and encoder LSTM
+        if cfg['use_x_prev'] and Xp.data_ptr() != self.XZ.data_ptr():
+            self.XZ.view(B, T, self.xz_ld)[:, :, :D].copy_(Xp.view(B, T, D))     # staging copy only
+        # the encoder's input projection only needs X: optionally on the side stream under the label path
         with self._side():
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
         # label path (:174-191)
@@ -379,24 +410,22 @@ class VrnnEngine(_EngineBase):
         g(self.W, P.rows(P.params, 'decoder_h/kernel', off + L), self.wk_dec, B, G4, Cn, bias=P.p('decoder_h/bias'),
           ws=ws)
         self._join()
-        if cfg['use_x_prev']:
-            with self._side():
-                g(Xp, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, D, ws=self.ws2)
         ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
                          self.cs_enc, self.gates_enc, gate_act=self.gate_act)
         # latent heads + sample (:200-216)
-        g(self.hs_enc, P.p('Z_mean/kernel'), self.zargs, BT, L, H, ldc=2 * L, bias=P.p('Z_mean/bias'), ws=ws)
-        g(self.hs_enc, P.p('Z_log_var/kernel'), self.zargs[:, L:], BT, L, H, ldc=2 * L, bias=P.p('Z_log_var/bias'),
-          ws=ws)
-        ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, L, self.rowkl)
-        # decoder LSTM on [Xp, Z, repeat(W)] (:218-228)
+        g(self.hs_enc, P.p('Zargs/kernel'), self.zargs, BT, 2 * L, H, bias=P.p('Zargs/bias'), ws=ws)
+        ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
+        # decoder LSTM on [Xp, Z, repeat(W)] (:218-228): one projection of the [Xp | Z] rows
         self._join()
-        g(self.Z, P.rows(P.params, 'decoder_h/kernel', off), self.gates_dec, BT, G4, L,
-          beta=1.0 if cfg['use_x_prev'] else 0.0, ws=ws)
+        g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
         ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
                          self.cs_dec, self.gates_dec, gate_act=self.gate_act)
         # output head (:229-234)
         g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
+
+    def xp_view(self):
+        """[B,T,D] strided view of the history columns of the [Xp | Z] buffer (stage batches straight into it)."""
+        return self.XZ.view(self.B, self.cfg['T'], self.xz_ld)[:, :, :self.cfg['D']]
 
     def x_hat(self):
         """sigmoid(logits) of the last forward -> self.dlogits (the Keras output `X_decoded_mean`)."""
@@ -433,8 +462,7 @@ class VrnnEngine(_EngineBase):
         g(w, P.rows(P.params, rec_name + '/kernel', D), st['gates'], B, 4 * H, Cn, beta=1.0, bias=P.p(rec_name + '/bias'),
           ws=ws)
         self._lstm_step(rec_name, st, 'h_enc', 'c_enc')
-        g(st['hs'], P.p('Z_mean/kernel'), st['zargs'], B, L, H, ldc=2 * L, bias=P.p('Z_mean/bias'), ws=ws)
-        g(st['hs'], P.p('Z_log_var/kernel'), st['zargs'][:, L:], B, L, H, ldc=2 * L, bias=P.p('Z_log_var/bias'), ws=ws)
+        g(st['hs'], P.p('Zargs/kernel'), st['zargs'], B, 2 * L, H, bias=P.p('Zargs/bias'), ws=ws)
 
     def dec_step(self, z, xp, w, st):
         """one decoder-LSTM step on [x_{t-1}, z_t, w] + sigmoid head -> st['xhat']"""
@@ -446,24 +474,22 @@ class VrnnEngine(_EngineBase):
         g(z, P.rows(P.params, 'decoder_h/kernel', off), st['gates'], B, 4 * H, L,
           beta=1.0 if cfg['use_x_prev'] else 0.0, ws=ws)
         g(w, P.rows(P.params, 'decoder_h/kernel', off + L), st['gates'], B, 4 * H, Cn, beta=1.0,
-          bias=P.p('decoder_h/bias'), ws=ws)
+          bias=P.p('decoder_h/bias'), ws=ws)     # three tiny GEMMs: batch-1 sampling is launch-bound, not flop-bound
         self._lstm_step('decoder_h', st, 'h_dec', 'c_dec')
         g(st['hs'], P.p('X_decoded_mean/kernel'), st['xhat'], B, D, H, bias=P.p('X_decoded_mean/bias'),
           act=ACT_SIGMOID, ws=ws)
 
-    def _lstm_wgrads(self, name, X_in, hs, dz, dzsum, Z_in, z_row, w_row, ws):
+    def _lstm_wgrads(self, name, X_in, x_ld, x_rows, hs, dz, dzsum, w_row, ws):
         """Every weight gradient of one LSTM in two grouped launches.
-        Over dz [B*T,4H] (K = B*T): kernel rows of x_t, recurrent kernel (h_{t-1}: shift 1, zero at t == 0),
-        kernel rows of z_t.  Over dzsum [B,4H] (K = B): kernel rows of the repeated label W, and the bias."""
+        Over dz [B*T,4H] (K = B*T): kernel rows of the per-step inputs (x_t, or [x_{t-1} | z_t] for the
+        decoder) and the recurrent kernel (h_{t-1}: shift 1, zero at t == 0).
+        Over dzsum [B,4H] (K = B): kernel rows of the repeated label W, and the bias."""
         cfg, P, B = self.cfg, self.P, self.B
-        D, H, T, L, Cn = cfg['D'], cfg['H'], cfg['T'], cfg['L'], cfg['C']
+        H, T, Cn = cfg['H'], cfg['T'], cfg['C']
         BT, G4 = B * T, 4 * H
-        probs = [dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)]
-        if X_in is not None:
-            probs.insert(0, dict(A=X_in, lda=D, M=D, C=P.g(name + '/kernel')))
-        if Z_in is not None:
-            probs.append(dict(A=Z_in, lda=L, M=L, C=P.rows(P.grads, name + '/kernel', z_row)))
-        ops.gemm_grouped_tn(probs, G4, BT, dz, ws)
+        ops.gemm_grouped_tn([dict(A=X_in, lda=x_ld, M=x_rows, C=P.g(name + '/kernel')),
+                             dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)],
+                            G4, BT, dz, ws)
         ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
                              dict(A=None, M=1, C=P.g(name + '/bias'), ones=True)], G4, B, dzsum, ws)
 
@@ -503,25 +529,21 @@ class VrnnEngine(_EngineBase):
         dz = self.gates_dec
         # ... then its weight gradients (MFMA) go to the side stream and overlap the encoder BPTT
         with self._side():
-            self._lstm_wgrads('decoder_h', Xp if cfg['use_x_prev'] else None, self.hs_dec, dz, self.dzsum_dec,
-                              self.Z, off, off + L, ws2)
+            self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, dz, self.dzsum_dec, off + L, ws2)
         g(dz, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
         g(self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off + L), self.dW, B, Cn, G4, tb=True, ws=ws)
         # latent heads
         ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
-        g(self.dzargs, P.p('Z_mean/kernel'), self.dhs, BT, H, L, tb=True, lda=2 * L, ws=ws)
-        g(self.dzargs[:, L:], P.p('Z_log_var/kernel'), self.dhs, BT, H, L, tb=True, lda=2 * L, beta=1.0, ws=ws)
+        g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
         with self._side():
-            g(self.hs_enc, self.dzargs, P.g('Z_mean/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws2)
-            g(self.hs_enc, self.dzargs[:, L:], P.g('Z_log_var/kernel'), H, L, BT, ta=True, ldb=2 * L, ws=ws2)
-            ops.colsum(self.dzargs, BT, L, P.g('Z_mean/bias'), ws2, ldx=2 * L)
-            ops.colsum(self.dzargs[:, L:], BT, L, P.g('Z_log_var/bias'), ws2, ldx=2 * L)
+            g(self.hs_enc, self.dzargs, P.g('Zargs/kernel'), H, 2 * L, BT, ta=True, ws=ws2)
+            ops.colsum(self.dzargs, BT, 2 * L, P.g('Zargs/bias'), ws2)
         # encoder BPTT
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                          self.dzsum_enc, gate_act=self.gate_act)
         dz = self.gates_enc
         with self._side():
-            self._lstm_wgrads('encoder_h', X, self.hs_enc, dz, self.dzsum_enc, None, 0, D, ws2)
+            self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, dz, self.dzsum_enc, D, ws2)
         g(self.dzsum_enc, P.rows(P.params, 'encoder_h/kernel', D), self.dW, B, Cn, G4, tb=True, beta=1.0, ws=ws)
         # label head
         ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, self.W, self.dW,

@@ -241,11 +241,7 @@ class Model:
             idx_dev.copy_(torch.from_numpy(index))
             self._acc.zero_()
             for b0 in range(0, n, B):
-                ib = idx_dev[b0:b0 + B]
-                ops.gather_rows(B, row, d_cur, ib, ts.X)
-                if d_hist is not None:
-                    ops.gather_rows(B, row, d_hist, ib, ts.Xp)
-                ops.gather_rows(B, d_w.shape[1], d_w, ib, ts.w_true)
+                ts.gather_batch(d_cur, d_hist, d_w, idx_dev[b0:b0 + B])
                 ts.step()
                 ops.axpy(5, 1.0, eng.scal, self._acc)
             logs = self._logs_from(self._acc, n // B)
@@ -272,7 +268,7 @@ class Model:
         for b0 in range(0, n, B):
             ts.X.copy_(d_cur[b0:b0 + B].view_as(ts.X))
             if d_hist is not None:
-                ts.Xp.copy_(d_hist[b0:b0 + B].view_as(ts.Xp))
+                ts.Xp.copy_(d_hist[b0:b0 + B].view(ts.Xp.shape))
             ts.w_true.copy_(d_w[b0:b0 + B])
             ts.draw_noise(stream_offset=2 + b0 // B)
             eng.loss_and_grads(ts.X, ts.Xp, ts.w_true, ts.eps_w, ts.eps_z, need_grads=False)

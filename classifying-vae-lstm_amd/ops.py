@@ -133,8 +133,9 @@ def axpy(n, alpha, x, y):
     check(_lib.lib().clv_axpy(n, float(alpha), _ptr(x), _ptr(y), _stream()), "clv_axpy")
 
 
-def gather_rows(rows, row_elems, src, idx, out):
-    check(_lib.lib().clv_gather_rows(rows, row_elems, _ptr(src), _ptr(idx), _ptr(out), _stream()), "clv_gather_rows")
+def gather_rows(rows, row_elems, src, idx, out, chunk=0, out_ld=0):
+    check(_lib.lib().clv_gather_rows(rows, row_elems, _ptr(src), _ptr(idx), _ptr(out), chunk, out_ld, _stream()),
+          "clv_gather_rows")
 
 
 def philox_normal(out, n, seed, step=0, stream_id=0, first_index=0, step_dev=None):

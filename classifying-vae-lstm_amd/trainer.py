@@ -31,7 +31,13 @@ class TrainStep:
         f = dict(dtype=torch.float32, device=d)
         shp = (B, T, D) if self.is_vrnn else (B, D)
         self.X = torch.zeros(*shp, **f)
-        self.Xp = torch.zeros(*shp, **f)
+        # cl_vrnn with history: stage x_{t-1} straight into the engine's [Xp | Z] decoder-input buffer
+        self.xp_ld = 0
+        if self.is_vrnn and cfg['use_x_prev']:
+            self.Xp = engine.xp_view()
+            self.xp_ld = engine.xz_ld
+        else:
+            self.Xp = torch.zeros(*shp, **f)
         self.w_true = torch.zeros(B, cfg['C'], **f)
         self.eps_w = torch.zeros(B, C1, **f)
         self.eps_z = torch.zeros(B * T, L, **f)
@@ -70,8 +76,20 @@ class TrainStep:
         """Copy one batch (device tensors) into the fixed staging buffers."""
         self.X.copy_(X.view_as(self.X))
         if Xp is not None:
-            self.Xp.copy_(Xp.view_as(self.Xp))
+            self.Xp.copy_(Xp.view(self.Xp.shape))
         self.w_true.copy_(w_true)
+
+    def gather_batch(self, d_cur, d_hist, d_w, ib):
+        """Assemble the batch rows `ib` (device int64 indices) from the HBM-resident data set."""
+        B = self.eng.B
+        row = int(d_cur[0].numel())
+        ops.gather_rows(B, row, d_cur, ib, self.X)
+        if d_hist is not None:
+            if self.xp_ld:
+                ops.gather_rows(B, row, d_hist, ib, self.Xp, chunk=self.eng.cfg['D'], out_ld=self.xp_ld)
+            else:
+                ops.gather_rows(B, row, d_hist, ib, self.Xp)
+        ops.gather_rows(B, d_w.shape[1], d_w, ib, self.w_true)
 
     def _eager(self):
         self._main()

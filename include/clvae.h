@@ -147,8 +147,11 @@ int clv_bernoulli_nll(int R, int D, const float* logits, const float* y, int ldy
 int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
 
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
- * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71). */
-int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out, void* stream);
+ * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71).
+ * A row is row_elems/chunk pieces of `chunk` floats (frames); piece j of row r is written at
+ * out + (r*pieces + j)*out_ld.  chunk <= 0 means one contiguous piece (out_ld = row_elems). */
+int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out,
+                    int64_t chunk, int64_t out_ld, void* stream);
 
 /* the five loss scalars of a step in one launch: out[k] = scale[k] * sum_{i<n[k]} x[k][i*stride[k]], k < 5
  * (vae, kl_z, kl_w, w_rec, acc means; fixed summation order => deterministic). */
