@@ -315,7 +315,7 @@ static int auto_split(int M, int N, int K) {
   int bm, bn;
   tile_dims(pick_tile(M, N), bm, bn);
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-  if (tiles >= 256 || K < 512) return 1;       // a reduce launch costs ~6 us: only worth it for long K
+  if (tiles >= 256 || K < 128) return 1;       // each k-tile is a dependent ~1 us round trip; a reduce launch ~6 us
   long s = (1024 + tiles - 1) / tiles;
   if (s > K / 64) s = K / 64;
   if (s > 512) s = 512;
@@ -401,7 +401,7 @@ static int grouped_tiles(const clv_gemm_prob* probs, int nprob, int bm) {
 extern "C" int clv_gemm_grouped_auto_split(const clv_gemm_prob* probs, int nprob, int N, int K) {
   if (!probs || nprob < 1 || nprob > clv::MAX_PROB) return 1;
   const long tiles = (long)grouped_tiles(probs, nprob, 96) * ((N + 95) / 96);
-  if (tiles >= 256 || K < 512) return 1;
+  if (tiles >= 256 || K < 128) return 1;
   long s = (1024 + tiles - 1) / tiles;
   if (s > K / 64) s = K / 64;
   if (s > 512) s = 512;
