@@ -4,32 +4,42 @@
 // grid-level sync exists.  At the reference's batch sizes (256 rows per GPU) the
 // chip has one CU per row: the recurrent product h.U is a matrix-vector product
 // per CU, which the MFMA (16-row tiles) cannot fill, so it runs on the VALU with
-// the whole recurrent kernel U [88,352] (124 KB) resident in REGISTERS:
-//   704 threads = 11 waves; lane = (unit_local = lane>>3, kslice = lane&7);
-//   unit u = 8*wave + unit_local; thread (u, s) keeps U[11s..11s+10][{i,f,c,o} of u]
-//   (forward) or U[u][44s..44s+43] (backward) = 44 floats.
-// Per step a thread does 44 FMAs per row, the 8 k-slices are summed with three
-// DPP adds (quad_perm, quad_perm, row_half_mirror), and the unit's gate math and
-// cell state stay in that thread group's registers; only h_t (forward) / dz_t
-// (backward) cross lanes through LDS, one barrier per step.
+// the whole recurrent kernel U [88,352] (124 KB) resident in REGISTERS.
+//
+// Thread layout (template KS = number of k-slices, 8 or 4):
+//   lane = (unit_local = lane / KS, kslice = lane % KS); unit u = (64/KS)*wave + unit_local;
+//   KS = 8: 11 waves, 44 U-floats per thread;  KS = 4: 6 waves, 88 U-floats per thread.
+//   forward : thread (u,s) keeps U[KK*s .. KK*s+KK-1][{i,f,c,o} of u]   (KK = 88/KS)
+//   backward: thread (u,s) keeps U[u][CS*s .. CS*s+CS-1]                 (CS = 352/KS)
+// Per step a thread does 4*KK FMAs per row, the k-slices are summed with log2(KS) DPP
+// adds, and the unit's gate math and cell state stay in that lane group's registers; only
+// h_t (forward) / dz_t (backward) cross lanes through LDS, one barrier per step.
+// Fewer slices = fewer redundant copies of the per-unit gate math and of every
+// per-step overhead instruction (the kernels are VALU-issue-bound, not FMA-bound).
+//
+// Memory pipeline: all per-step loads and stores are unconditional and branch-free so that
+// the compiler's s_waitcnt is a counted vmcnt(#younger ops); vmcnt retires in issue order, so
+// a conditional or drained wait would expose the latency of the previous step's stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace clv {
 
 constexpr int LH = 88;          // hidden units
 constexpr int LG = 4 * LH;      // gate columns
-constexpr int LTHREADS = 704;   // 11 waves
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
   return v + __builtin_bit_cast(float, t);
 }
-// sum over the 8 consecutive lanes of a k-slice group; every lane gets the total
-__device__ __forceinline__ float reduce8(float v) {
-  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);   // row_half_mirror
+// sum over the KS consecutive lanes of a k-slice group; every lane gets the total
+template <int KS>
+__device__ __forceinline__ float reduce_slices(float v) {
+  v = dpp_add<0xB1>(v);                  // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                  // quad_perm [2,3,0,1]
+  if (KS == 8) v = dpp_add<0x141>(v);    // row_half_mirror
   return v;
 }
 
@@ -41,6 +51,16 @@ template <int GATE>
 __device__ __forceinline__ float gate_grad(float z, float y) {
   return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid_grad(z) : y * (1.f - y);
 }
+
+template <int KS>
+struct Geo {
+  static constexpr int UL = 64 / KS;                   // units per wave
+  static constexpr int NW = (LH + UL - 1) / UL;        // waves
+  static constexpr int NT = NW * 64;                   // threads
+  static constexpr int KK = LH / KS;                   // k values per slice (forward)
+  static constexpr int KP = (KK + 3) / 4 * 4;          // padded slice length in LDS
+  static constexpr int CS = LG / KS;                   // gate columns per slice (backward)
+};
 
 struct LstmFwdArgs {
   int B, T;
@@ -59,32 +79,36 @@ struct LstmFwdArgs {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <int R, int GATE, bool SAVE>
-__global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
-  constexpr int NC = 8 / R;            // lane copies per (row, unit)
-  constexpr int NX = (4 * R + 7) / 8;  // xproj loads per lane per step
-  __shared__ __attribute__((aligned(16))) float hbuf[2][R][96];   // slice s at 12*s (11 used)
+// ABL != 0 builds exist only in tools/lstm_ablate.hip (phase-removal timing, results are wrong by design)
+template <int KS, int R, int GATE, bool SAVE, int ABL = 0>
+__global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
+  using G = Geo<KS>;
+  constexpr int KK = G::KK, KP = G::KP;
+  constexpr int NC = KS / R;                 // lane copies per (row, unit)
+  constexpr int NX = (4 * R + KS - 1) / KS;  // xproj loads per lane per step
+  __shared__ __attribute__((aligned(16))) float hbuf[2][R][KS * KP];   // slice s at KP*s (KK used)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s = lane & 7, u = wave * 8 + (lane >> 3);
+  const int s = lane % KS;
+  const int u = min(wave * G::UL + lane / KS, LH - 1);   // surplus lane groups duplicate unit 87 (same values, same addresses)
   const int row0 = blockIdx.x * R;
   const int myrow = s % R, copy = s / R;     // which row this lane finishes, which outputs it stores
   const int T = a.T;
 
   // recurrent kernel slice -> registers
-  float Ur[11][4];
+  float Ur[KK][4];
 #pragma unroll
-  for (int kk = 0; kk < 11; ++kk)
+  for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Ur[kk][g] = a.U[(size_t)(11 * s + kk) * LG + g * LH + u];
+    for (int g = 0; g < 4; ++g) Ur[kk][g] = a.U[(size_t)(KK * s + kk) * LG + g * LH + u];
 
-  // per-lane share of xproj / rowbias: element e = s + 8*i -> (row e>>2, gate e&3)
+  // per-lane share of xproj / rowbias: element e = s + KS*i -> (row e>>2, gate e&3)
   float rb[NX];
   size_t xoff[NX];
   bool xok[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const int e = s + 8 * i;
+    const int e = s + KS * i;
     xok[i] = e < 4 * R;
     const int rr = xok[i] ? (e >> 2) : 0, gg = e & 3;   // surplus lanes re-read a valid element
     xoff[i] = (size_t)(row0 + rr) * T * LG + gg * LH + u;
@@ -92,11 +116,9 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 
   // initial state
+  const int hslot = KP * (u / KK) + (u % KK);
   float c = a.c0 ? a.c0[(size_t)(row0 + myrow) * LH + u] : 0.f;
-  if (copy == 0) {
-    float h = a.h0 ? a.h0[(size_t)(row0 + myrow) * LH + u] : 0.f;
-    hbuf[0][myrow][12 * (u / 11) + (u % 11)] = h;
-  }
+  if (copy == 0) hbuf[0][myrow][hslot] = a.h0 ? a.h0[(size_t)(row0 + myrow) * LH + u] : 0.f;
   float xn[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) xn[i] = T > 0 ? a.xproj[xoff[i]] : 0.f;
@@ -128,31 +150,40 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       xv[i] = xn[i] + rb[i];
-      xn[i] = a.xproj[xoff[i] + (size_t)min(t + 1, T - 1) * LG];   // prefetch, unconditional (clamped)
+      if (ABL != 5) xn[i] = a.xproj[xoff[i] + (size_t)min(t + 1, T - 1) * LG];   // prefetch, unconditional (clamped)
     }
-    // acc[r][g] starts from the lane's xproj share, then 11 FMAs per gate
+    // acc[r][g] starts from the lane's xproj share, then KK FMAs per gate
     float acc[R][4];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int e = r * 4 + g;              // compile-time
-        acc[r][g] = (s == (e & 7) && xok[e >> 3]) ? xv[e >> 3] : 0.f;
+        acc[r][g] = (s == (e % KS) && xok[e / KS]) ? xv[e / KS] : 0.f;
       }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][r][12 * s]);
-      float4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
-      const float hv[11] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z};
+      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][r][KP * s]);
+      float hv[KP];
 #pragma unroll
-      for (int kk = 0; kk < 11; ++kk)
+      for (int q = 0; q < KP / 4; ++q) {
+        const float4 v = hp[q];
+        hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+      }
+      if (ABL == 3) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[r][g] = fmaf(hv[kk], Ur[kk][g], acc[r][g]);
+        for (int g = 0; g < 4; ++g) acc[r][g] += hv[g] * Ur[g][g];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[r][g] = fmaf(hv[kk], Ur[kk][g], acc[r][g]);
+      }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[r][g] = reduce8(acc[r][g]);
+      for (int g = 0; g < 4; ++g) acc[r][g] = ABL == 6 ? acc[r][g] : reduce_slices<KS>(acc[r][g]);
     // this lane finishes row `myrow`
     float z[4];
 #pragma unroll
@@ -161,26 +192,34 @@ __global__ __launch_bounds__(LTHREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
       for (int r = 1; r < R; ++r) z[g] = (myrow == r) ? acc[r][g] : z[g];
     }
-    const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);
-    const float gg = fast_tanh(z[2]);
-    c = fg * c + ig * gg;
-    const float h = og * fast_tanh(c);
+    float ig, fg, og, gg, h;
+    if (ABL == 2) {
+      ig = z[0]; fg = z[1]; og = z[3]; gg = z[2];
+      c = 0.5f * c + 0.01f * ig * gg;
+      h = 0.1f * og + 0.1f * c + 0.01f * fg;
+    } else {
+      ig = gate_fn<GATE>(z[0]); fg = gate_fn<GATE>(z[1]); og = gate_fn<GATE>(z[3]);
+      gg = fast_tanh(z[2]);
+      c = fg * c + ig * gg;
+      h = og * fast_tanh(c);
+    }
     hlast = h;
-    hbuf[cur ^ 1][myrow][12 * (u / 11) + (u % 11)] = h;     // all copies write the same value
-    // outputs: 6 values per (row, unit) shared among the NC lane copies.  Every lane issues the same
-    // number of stores, unconditionally, so the next step's wait on the prefetched xproj is a counted
-    // vmcnt(#stores) instead of a drain of these stores (vmcnt retires in issue order).
+    hbuf[cur ^ 1][myrow][hslot] = h;     // all copies write the same value
+    // outputs: 6 values per (row, unit) shared among the NC lane copies; every lane issues the same
+    // number of stores, unconditionally (see the header note on counted vmcnt)
     const float ov[6] = {h, c, z[0], z[1], gg, z[3]};
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       float val = ov[0];
 #pragma unroll
       for (int q = 1; q < 6; ++q) val = (oslot[j] == q) ? ov[q] : val;
-      *optr[j] = SAVE ? val : h;
+      if (ABL != 1) *optr[j] = SAVE ? val : h;
       optr[j] += ostr[j];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ABL == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  if (ABL == 1) a.hs[(size_t)(row0 + myrow) * T * LH + u] = hlast + c;
   if (copy == 0) {
     if (a.hT) a.hT[(size_t)(row0 + myrow) * LH + u] = T > 0 ? hlast : (a.h0 ? a.h0[(size_t)(row0 + myrow) * LH + u] : 0.f);
     if (a.cT) a.cT[(size_t)(row0 + myrow) * LH + u] = c;
@@ -197,30 +236,33 @@ struct LstmBwdArgs {
   const float* cs;      // [B,T,88]
   const float* c0;      // [B,88] or null
   float* gates;         // in: (z_i,z_f,g,z_o)  out: dz
-  float* dzsum;         // [B,352] or null
+  float* dzsum;         // [B,352]
 };
 
-template <int R, int GATE>
-__global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
-  constexpr int NC = 8 / R;
+template <int KS, int R, int GATE>
+__global__ __launch_bounds__(Geo<KS>::NT) void lstm_bwd_kernel(LstmBwdArgs a) {
+  using G = Geo<KS>;
+  constexpr int CS = G::CS;
+  constexpr int NC = KS / R;
   __shared__ __attribute__((aligned(16))) float dzbuf[2][R][LG];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s = lane & 7, u = wave * 8 + (lane >> 3);
+  const int s = lane % KS;
+  const int u = min(wave * G::UL + lane / KS, LH - 1);
   const int row0 = blockIdx.x * R;
   const int myrow = s % R, copy = s / R;
   const int T = a.T;
 
-  float Ur[44];   // U[u][44s .. 44s+43]
+  float Ur[CS];   // U[u][CS*s .. CS*s+CS-1]
   {
-    const float4* up = reinterpret_cast<const float4*>(a.U + (size_t)u * LG + 44 * s);
+    const float4* up = reinterpret_cast<const float4*>(a.U + (size_t)u * LG + CS * s);
 #pragma unroll
-    for (int j = 0; j < 11; ++j) {
+    for (int j = 0; j < CS / 4; ++j) {
       float4 v = up[j];
       Ur[4 * j] = v.x; Ur[4 * j + 1] = v.y; Ur[4 * j + 2] = v.z; Ur[4 * j + 3] = v.w;
     }
   }
-  for (int i = tid; i < 2 * R * LG; i += LTHREADS) (&dzbuf[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * R * LG; i += G::NT) (&dzbuf[0][0][0])[i] = 0.f;
 
   const size_t rowbt = (size_t)(row0 + myrow) * T;
   float dc = 0.f;
@@ -232,8 +274,6 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
   // the per-step critical path is: reduce -> 8 multiply/adds -> LDS write -> barrier.
   struct Raw { float zi, zf, g, zo, c, cp, dh; };
   struct Coef { float ko, kc, ki, kf, kg, kcarry, dhh; };
-  // Loads are unconditional and branch-free (the step index is clamped instead), so the compiler can
-  // count them: a wait for the previous load set is vmcnt(#younger ops) and never drains the dz store.
   const float* g_base = a.gates + rowbt * LG + u;
   const float* c_base = a.cs + rowbt * LH + u;
   const float* d_base = a.dhs + rowbt * LH + u;
@@ -267,9 +307,9 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
     coef_next = make_coef(load_raw(T - 1));
     raw_next = load_raw(max(T - 2, 0));
   }
-  // One store after the prologue's loads, exactly like every loop iteration issues one after its
-  // loads: the waitcnt pass merges the loop-entry and back-edge states, and with matching queues
-  // the wait for `raw_next` stays vmcnt(#younger ops) instead of draining the previous dz store.
+  // One store after the prologue's loads, exactly like every loop iteration issues after its loads: the
+  // waitcnt pass merges the loop-entry and back-edge states, and with matching queues the wait for
+  // `raw_next` stays vmcnt(#younger ops) instead of draining the previous dz store.
   a.dzsum[(size_t)(row0 + myrow) * LG + (copy & 3) * LH + u] = 0.f;
   constexpr int NSB = (4 + NC - 1) / NC;
   float* gptr[NSB];
@@ -286,10 +326,10 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
     float part[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][44 * s]);
+      const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][CS * s]);
       float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 11; ++j) {
+      for (int j = 0; j < CS / 4; ++j) {
         float4 v = dp[j];
         acc0 = fmaf(v.x, Ur[4 * j], acc0);
         acc1 = fmaf(v.y, Ur[4 * j + 1], acc1);
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
     }
     coef_next = make_coef(rcur);                   // off the critical path (unused after t == 0)
 #pragma unroll
-    for (int r = 0; r < R; ++r) part[r] = reduce8(part[r]);
+    for (int r = 0; r < R; ++r) part[r] = reduce_slices<KS>(part[r]);
     float dhrec = part[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) dhrec = (myrow == r) ? part[r] : dhrec;
@@ -328,27 +368,47 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  {
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
-      if (copy == gi % NC || NC > 4 && copy == gi) a.dzsum[(size_t)(row0 + myrow) * LG + gi * LH + u] = zs[gi];
+  for (int j = 0; j < NSB; ++j) {
+    const int slot = (copy + j * NC) & 3;
+    float val = zs[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) val = (slot == q) ? zs[q] : val;
+    a.dzsum[(size_t)(row0 + myrow) * LG + slot * LH + u] = val;
   }
 }
 
-template <int GATE, bool SAVE>
+// rows per workgroup: one while every CU can get its own row, more as the batch outgrows the chip
+static int rows_per_wg(int B) {
+  if (B % 4 == 0 && B >= 2048) return 4;
+  if (B % 2 == 0 && B >= 1024) return 2;
+  return 1;
+}
+static int lstm_ks() {
+  static int ks = 0;
+  if (!ks) {
+    const char* e = getenv("CLV_LSTM_KS");
+    ks = (e && atoi(e) == 8) ? 8 : 4;
+  }
+  return ks;
+}
+
+template <int KS, int GATE, bool SAVE>
 static int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
-  const int B = a.B;
-  if (B % 4 == 0 && B >= 2048) hipLaunchKernelGGL((lstm_fwd_kernel<4, GATE, SAVE>), dim3(B / 4), dim3(LTHREADS), 0, s, a);
-  else if (B % 2 == 0 && B >= 1024) hipLaunchKernelGGL((lstm_fwd_kernel<2, GATE, SAVE>), dim3(B / 2), dim3(LTHREADS), 0, s, a);
-  else hipLaunchKernelGGL((lstm_fwd_kernel<1, GATE, SAVE>), dim3(B), dim3(LTHREADS), 0, s, a);
+  const int B = a.B, R = rows_per_wg(B);
+  constexpr int NT = Geo<KS>::NT;
+  if (R == 4) hipLaunchKernelGGL((lstm_fwd_kernel<KS, 4, GATE, SAVE>), dim3(B / 4), dim3(NT), 0, s, a);
+  else if (R == 2) hipLaunchKernelGGL((lstm_fwd_kernel<KS, 2, GATE, SAVE>), dim3(B / 2), dim3(NT), 0, s, a);
+  else hipLaunchKernelGGL((lstm_fwd_kernel<KS, 1, GATE, SAVE>), dim3(B), dim3(NT), 0, s, a);
   return launch_status();
 }
-template <int GATE>
+template <int KS, int GATE>
 static int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
-  const int B = a.B;
-  if (B % 4 == 0 && B >= 2048) hipLaunchKernelGGL((lstm_bwd_kernel<4, GATE>), dim3(B / 4), dim3(LTHREADS), 0, s, a);
-  else if (B % 2 == 0 && B >= 1024) hipLaunchKernelGGL((lstm_bwd_kernel<2, GATE>), dim3(B / 2), dim3(LTHREADS), 0, s, a);
-  else hipLaunchKernelGGL((lstm_bwd_kernel<1, GATE>), dim3(B), dim3(LTHREADS), 0, s, a);
+  const int B = a.B, R = rows_per_wg(B);
+  constexpr int NT = Geo<KS>::NT;
+  if (R == 4) hipLaunchKernelGGL((lstm_bwd_kernel<KS, 4, GATE>), dim3(B / 4), dim3(NT), 0, s, a);
+  else if (R == 2) hipLaunchKernelGGL((lstm_bwd_kernel<KS, 2, GATE>), dim3(B / 2), dim3(NT), 0, s, a);
+  else hipLaunchKernelGGL((lstm_bwd_kernel<KS, 1, GATE>), dim3(B), dim3(NT), 0, s, a);
   return launch_status();
 }
 
@@ -366,9 +426,13 @@ extern "C" int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_seq_fwd", s);
   const bool save = gates != nullptr;
-  if (gate_act == CLV_GATE_HARD_SIGMOID)
-    return save ? launch_fwd<CLV_GATE_HARD_SIGMOID, true>(a, s) : launch_fwd<CLV_GATE_HARD_SIGMOID, false>(a, s);
-  return save ? launch_fwd<CLV_GATE_SIGMOID, true>(a, s) : launch_fwd<CLV_GATE_SIGMOID, false>(a, s);
+  const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
+  if (lstm_ks() == 8) {
+    if (hard) return save ? launch_fwd<8, CLV_GATE_HARD_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_HARD_SIGMOID, false>(a, s);
+    return save ? launch_fwd<8, CLV_GATE_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_SIGMOID, false>(a, s);
+  }
+  if (hard) return save ? launch_fwd<4, CLV_GATE_HARD_SIGMOID, true>(a, s) : launch_fwd<4, CLV_GATE_HARD_SIGMOID, false>(a, s);
+  return save ? launch_fwd<4, CLV_GATE_SIGMOID, true>(a, s) : launch_fwd<4, CLV_GATE_SIGMOID, false>(a, s);
 }
 
 extern "C" int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
@@ -380,6 +444,7 @@ extern "C" int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
   LstmBwdArgs a{B, T, U, dhs, cs, c0, gates_inout_dz, dzsum};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_seq_bwd", s);
-  return gate_act == CLV_GATE_HARD_SIGMOID ? launch_bwd<CLV_GATE_HARD_SIGMOID>(a, s)
-                                           : launch_bwd<CLV_GATE_SIGMOID>(a, s);
+  const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
+  if (lstm_ks() == 8) return hard ? launch_bwd<8, CLV_GATE_HARD_SIGMOID>(a, s) : launch_bwd<8, CLV_GATE_SIGMOID>(a, s);
+  return hard ? launch_bwd<4, CLV_GATE_HARD_SIGMOID>(a, s) : launch_bwd<4, CLV_GATE_SIGMOID>(a, s);
 }
