@@ -208,8 +208,14 @@ def main():
             avg_s = ms / n * 1e-3
             achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
             kname = 'gemm_f32'
+        traffic = None       # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_%s.json' % args.workload)))
+            traffic = round(pm['lstm_seq_bytes_per_launch']) if w['model'] == 'cl_vrnn' else None
+        except Exception:
+            pass
         roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None, kernel=kname,
+                        frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=kname,
                         avg_launch_us=round(avg_s * 1e6, 2),
                         whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4))
 
