@@ -96,31 +96,37 @@ __global__ void label_bwd_kernel(int B, int C, const float* mean, const float* l
 }
 
 // ------------------------------------------------------------------ gauss --
-__global__ void gauss_fwd_kernel(int R, int L, const float* zargs, const float* eps, float* z, int ldz,
-                                 float* rowkl) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  float kl = 0.f;
-  for (int j = 0; j < L; ++j) {
-    const float m = zargs[(size_t)r * 2 * L + j], lv = zargs[(size_t)r * 2 * L + L + j];
+// one thread per (row, latent) element, LP = next power of two >= L lanes per row (coalesced for any L <= 64);
+// the row's KL term is a shuffle reduction over those LP lanes.
+template <int LP>
+__global__ __launch_bounds__(256) void gauss_fwd_kernel(int R, int L, const float* zargs, const float* eps, float* z,
+                                                        int ldz, float* rowkl) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = gid / LP;
+  const int j = (int)(gid % LP);
+  float term = 0.f;
+  if (r < R && j < L) {
+    const float m = zargs[r * 2 * L + j], lv = zargs[r * 2 * L + L + j];
     const float sd = expf(0.5f * lv);
-    z[(size_t)r * ldz + j] = m + sd * eps[(size_t)r * L + j];
-    kl += 1.f + lv - m * m - sd * sd;
+    z[r * ldz + j] = m + sd * eps[r * L + j];
+    term = 1.f + lv - m * m - sd * sd;
   }
-  if (rowkl) rowkl[r] = -0.5f * kl;
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
+  if (rowkl && r < R && j == 0) rowkl[r] = -0.5f * term;
 }
 
-__global__ void gauss_bwd_kernel(int R, int L, const float* zargs, const float* eps, const float* dz, int lddz,
-                                 float kl_scale, float* dzargs) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  for (int j = 0; j < L; ++j) {
-    const float m = zargs[(size_t)r * 2 * L + j], lv = zargs[(size_t)r * 2 * L + L + j];
-    const float sd = expf(0.5f * lv);
-    const float d = dz[(size_t)r * lddz + j];
-    dzargs[(size_t)r * 2 * L + j] = d + kl_scale * m;
-    dzargs[(size_t)r * 2 * L + L + j] = d * eps[(size_t)r * L + j] * 0.5f * sd - 0.5f * kl_scale * (1.f - sd * sd);
-  }
+__global__ __launch_bounds__(256) void gauss_bwd_kernel(int R, int L, const float* zargs, const float* eps,
+                                                        const float* dz, int lddz, float kl_scale, float* dzargs) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)R * L) return;
+  const int64_t r = gid / L;
+  const int j = (int)(gid % L);
+  const float m = zargs[r * 2 * L + j], lv = zargs[r * 2 * L + L + j];
+  const float sd = expf(0.5f * lv);
+  const float d = dz[r * lddz + j];
+  dzargs[r * 2 * L + j] = d + kl_scale * m;
+  dzargs[r * 2 * L + L + j] = d * eps[r * L + j] * 0.5f * sd - 0.5f * kl_scale * (1.f - sd * sd);
 }
 
 // ------------------------------------------------------- Bernoulli NLL (BCE) --
@@ -285,10 +291,15 @@ extern "C" int clv_label_bwd(int B, int C, const float* mean, const float* logva
 
 extern "C" int clv_gauss_fwd(int R, int L, const float* zargs, const float* eps, float* z, int ldz,
                              float* rowkl, void* stream) {
-  if (R <= 0 || L <= 0 || !zargs || !eps || !z) return CLV_EINVAL;
+  if (R <= 0 || L <= 0 || L > 64 || !zargs || !eps || !z) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("gauss_fwd", s);
-  hipLaunchKernelGGL(gauss_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, L, zargs, eps, z, ldz, rowkl);
+  int lp = 1;
+  while (lp < L) lp <<= 1;
+  const unsigned blocks = (unsigned)(((int64_t)R * lp + 255) / 256);
+#define GAUSS_CASE(LPV) case LPV: hipLaunchKernelGGL(gauss_fwd_kernel<LPV>, dim3(blocks), dim3(256), 0, s, R, L, zargs, eps, z, ldz, rowkl); break;
+  switch (lp) { GAUSS_CASE(1) GAUSS_CASE(2) GAUSS_CASE(4) GAUSS_CASE(8) GAUSS_CASE(16) GAUSS_CASE(32) GAUSS_CASE(64) }
+#undef GAUSS_CASE
   return launch_status();
 }
 
@@ -297,8 +308,8 @@ extern "C" int clv_gauss_bwd(int R, int L, const float* zargs, const float* eps,
   if (R <= 0 || L <= 0 || !zargs || !eps || !dz || !dzargs) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("gauss_bwd", s);
-  hipLaunchKernelGGL(gauss_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, L, zargs, eps, dz, lddz, kl_scale,
-                     dzargs);
+  hipLaunchKernelGGL(gauss_bwd_kernel, dim3((unsigned)(((int64_t)R * L + 255) / 256)), dim3(256), 0, s, R, L, zargs, eps,
+                     dz, lddz, kl_scale, dzargs);
   return launch_status();
 }
 
