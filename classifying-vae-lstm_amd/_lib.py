@@ -52,6 +52,8 @@ SIGNATURES = {
     "clv_lstm_seq_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "clv_label_fwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "clv_label_bwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _i, _p]),
+    "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_vrnn_label_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "clv_gauss_fwd": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
     "clv_gauss_bwd": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p]),
     "clv_bernoulli_nll": (_i, [_i, _i, _p, _p, _i, _f, _p, _p, _p]),

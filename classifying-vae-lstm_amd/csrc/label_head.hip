@@ -1,0 +1,207 @@
+// label_head.hip -- the cl_vrnn label path of one batch row per workgroup.
+//
+// Forward (cl_vrnn/model.py:175-193 + the W rows of both LSTM kernels):
+//   Wargs = hW.K_a + b_a ; W = softmax([mean + exp(lv/2)*eps, 0]) ; kl_w, w_rec, hit ;
+//   rowbias_enc = W.K_enc[D:D+C] + b_enc ; rowbias_dec = W.K_dec[off:off+C] + b_dec
+// Backward: dW = dzsum_dec.K_dec_w^T + dzsum_enc.K_enc_w^T ; label backward ; dWargs ;
+//   dhW = (dWargs.K_a^T) * (hW > 0)
+// Each of these is a handful of 88..352-long dot products per row: far too small for a GEMM launch
+// each (a launch costs ~5 us), so one workgroup does the whole chain for its row out of LDS.
+#include "common.h"
+
+namespace clv {
+
+constexpr int LH_T = 384;     // threads (6 waves) >= 4H = 352
+constexpr int LH_MAXC = 32;
+constexpr float LEPS_K = 1e-7f, LW2 = 1e-10f;
+
+struct LabelFwdArgs {
+  int B, D, C, G4;
+  const float* hW;          // [B,D]
+  const float* Ka;          // Wargs kernel [D, 2(C-1)]
+  const float* ba;          // [2(C-1)]
+  const float* eps;         // [B,C-1]
+  const float* onehot;      // [B,C] or null
+  float prior;
+  const float* Kenc_w;      // [C,G4] rows of the encoder kernel that multiply W
+  const float* benc;        // [G4]
+  const float* Kdec_w;      // [C,G4]
+  const float* bdec;
+  float* wargs;             // [B,2(C-1)]
+  float* W;                 // [B,C]
+  float* rowloss;           // [B,3]
+  float* rb_enc;            // [B,G4]
+  float* rb_dec;            // [B,G4]
+};
+
+__global__ __launch_bounds__(LH_T) void vrnn_label_fwd_kernel(LabelFwdArgs a) {
+  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int C1 = a.C - 1, NA = 2 * C1;
+  if (tid < a.D) s_h[tid] = a.hW[(size_t)b * a.D + tid];
+  __syncthreads();
+  if (tid < NA) {
+    float acc = a.ba[tid];
+    for (int k = 0; k < a.D; ++k) acc = fmaf(s_h[k], a.Ka[(size_t)k * NA + tid], acc);
+    s_wargs[tid] = acc;
+    a.wargs[(size_t)b * NA + tid] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float e[LH_MAXC];
+    float S = 1.f, klw = 0.f;
+    const float ep = __expf(a.prior);
+    for (int j = 0; j < C1; ++j) {
+      const float m = s_wargs[j], lv = s_wargs[C1 + j];
+      const float sd = expf(0.5f * lv);
+      e[j] = expf(m + sd * a.eps[(size_t)b * C1 + j]);
+      S += e[j];
+      klw += 1.f - a.prior + lv - sd * sd / ep - m * m / ep;
+    }
+    e[C1] = 1.f;
+    const float invS = 1.f / S;
+    float qs = 0.f, wbest = -1.f, tbest = -1.f;
+    int amax = 0, tmax = 0;
+    for (int j = 0; j < a.C; ++j) {
+      const float w = e[j] * invS;
+      s_w[j] = w;
+      a.W[(size_t)b * a.C + j] = w;
+      qs += w + LW2;
+      if (w > wbest) { wbest = w; amax = j; }
+      const float tj = a.onehot ? a.onehot[(size_t)b * a.C + j] : 0.f;
+      if (tj > tbest) { tbest = tj; tmax = j; }
+    }
+    float wrec = 0.f;
+    if (a.onehot)
+      for (int j = 0; j < a.C; ++j) {
+        const float n = (s_w[j] + LW2) / qs;
+        wrec -= a.onehot[(size_t)b * a.C + j] * logf(fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K));
+      }
+    a.rowloss[(size_t)b * 3 + 0] = -0.5f * klw;
+    a.rowloss[(size_t)b * 3 + 1] = (float)C1 * wrec;
+    a.rowloss[(size_t)b * 3 + 2] = (a.onehot && amax == tmax) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < a.G4; c += LH_T) {
+    float e = a.benc[c], d = a.bdec[c];
+    for (int j = 0; j < a.C; ++j) {
+      e = fmaf(s_w[j], a.Kenc_w[(size_t)j * a.G4 + c], e);
+      d = fmaf(s_w[j], a.Kdec_w[(size_t)j * a.G4 + c], d);
+    }
+    a.rb_enc[(size_t)b * a.G4 + c] = e;
+    a.rb_dec[(size_t)b * a.G4 + c] = d;
+  }
+}
+
+struct LabelBwdArgs {
+  int B, D, C, G4;
+  const float* dzsum_enc;   // [B,G4]
+  const float* dzsum_dec;
+  const float* Kenc_w;      // [C,G4]
+  const float* Kdec_w;
+  const float* wargs;       // [B,2(C-1)]
+  const float* eps;
+  const float* onehot;
+  const float* W;           // [B,C]
+  const float* hW;          // [B,D]
+  const float* Ka;          // [D,2(C-1)]
+  float prior, class_weight, w_kl_weight, inv_b;
+  float* dwargs;            // [B,2(C-1)]
+  float* dhW;               // [B,D]
+};
+
+__global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
+  __shared__ float s_part[LH_T / 64][LH_MAXC], s_dw[LH_MAXC], s_dwa[2 * LH_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C1 = a.C - 1, NA = 2 * C1;
+  // dW[j] = sum_c dzsum_dec[c] K_dec_w[j,c] + dzsum_enc[c] K_enc_w[j,c]
+  float part[LH_MAXC];
+#pragma unroll
+  for (int j = 0; j < LH_MAXC; ++j) part[j] = 0.f;
+  for (int c = tid; c < a.G4; c += LH_T) {
+    const float de = a.dzsum_enc[(size_t)b * a.G4 + c], dd = a.dzsum_dec[(size_t)b * a.G4 + c];
+#pragma unroll
+    for (int j = 0; j < LH_MAXC; ++j)
+      if (j < a.C) part[j] = fmaf(dd, a.Kdec_w[(size_t)j * a.G4 + c], fmaf(de, a.Kenc_w[(size_t)j * a.G4 + c], part[j]));
+  }
+#pragma unroll
+  for (int j = 0; j < LH_MAXC; ++j)
+    if (j < a.C) {
+      const float v = wave_sum(part[j]);
+      if (lane == 0) s_part[wave][j] = v;
+    }
+  __syncthreads();
+  if (tid < a.C) {
+    float v = 0.f;
+    for (int w = 0; w < LH_T / 64; ++w) v += s_part[w][tid];
+    s_dw[tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float ep = __expf(a.prior);
+    float wv[LH_MAXC], dn[LH_MAXC], d[LH_MAXC];
+    float qs = 0.f, dot = 0.f, dsum = 0.f;
+    for (int j = 0; j < a.C; ++j) { wv[j] = a.W[(size_t)b * a.C + j]; qs += wv[j] + LW2; }
+    for (int j = 0; j < a.C; ++j) {
+      const float n = (wv[j] + LW2) / qs;
+      const bool inside = (n >= LEPS_K) && (n <= 1.f - LEPS_K);
+      const float nc = fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K);
+      dn[j] = inside ? -(float)C1 * a.onehot[(size_t)b * a.C + j] / nc : 0.f;
+      dot += dn[j] * n;
+    }
+    for (int j = 0; j < a.C; ++j) {
+      d[j] = s_dw[j] + a.class_weight * a.inv_b * ((dn[j] - dot) / qs);
+      dsum += d[j] * wv[j];
+    }
+    for (int j = 0; j < C1; ++j) {
+      const float ds = wv[j] * (d[j] - dsum);
+      const float m = a.wargs[(size_t)b * NA + j], lv = a.wargs[(size_t)b * NA + C1 + j];
+      const float sd = expf(0.5f * lv);
+      const float dm = ds + a.w_kl_weight * a.inv_b * (m / ep);
+      const float dl = ds * a.eps[(size_t)b * C1 + j] * 0.5f * sd + a.w_kl_weight * a.inv_b * (-0.5f * (1.f - sd * sd / ep));
+      s_dwa[j] = dm; s_dwa[C1 + j] = dl;
+      a.dwargs[(size_t)b * NA + j] = dm;
+      a.dwargs[(size_t)b * NA + C1 + j] = dl;
+    }
+  }
+  __syncthreads();
+  if (tid < a.D) {
+    float acc = 0.f;
+    for (int j = 0; j < NA; ++j) acc = fmaf(s_dwa[j], a.Ka[(size_t)tid * NA + j], acc);
+    a.dhW[(size_t)b * a.D + tid] = a.hW[(size_t)b * a.D + tid] > 0.f ? acc : 0.f;
+  }
+}
+
+}  // namespace clv
+
+using namespace clv;
+
+extern "C" int clv_vrnn_label_fwd(int B, int D, int C, int G4, const float* hW, const float* Ka, const float* ba,
+                                  const float* eps, const float* onehot, float prior_logvar,
+                                  const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                                  float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec, void* stream) {
+  if (B <= 0 || D <= 0 || D > 128 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
+  if (!hW || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss || !rb_enc || !rb_dec)
+    return CLV_EINVAL;
+  LabelFwdArgs a{B, D, C, G4, hW, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("vrnn_label_fwd", s);
+  hipLaunchKernelGGL(vrnn_label_fwd_kernel, dim3(B), dim3(LH_T), 0, s, a);
+  return launch_status();
+}
+
+extern "C" int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
+                                  const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
+                                  const float* onehot, const float* W, const float* hW, const float* Ka,
+                                  float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
+                                  float* dwargs, float* dhW, void* stream) {
+  if (B <= 0 || D <= 0 || D > 128 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
+  if (!dzsum_enc || !dzsum_dec || !Kenc_w || !Kdec_w || !wargs || !eps || !onehot || !W || !hW || !Ka || !dwargs || !dhW)
+    return CLV_EINVAL;
+  LabelBwdArgs a{B, D, C, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka,
+                 prior_logvar, class_weight, w_kl_weight, inv_b, dwargs, dhW};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("vrnn_label_bwd", s);
+  hipLaunchKernelGGL(vrnn_label_bwd_kernel, dim3(B), dim3(LH_T), 0, s, a);
+  return launch_status();
+}

@@ -401,14 +401,12 @@ class VrnnEngine(_EngineBase):
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
         # label path (:174-191)
         g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
-        g(self.hW, P.p('Wargs/kernel'), self.wargs, B, 2 * C1, D, bias=P.p('Wargs/bias'), ws=ws)
-        ops.label_fwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, cfg['w_log_var_prior'],
-                      self.W, self.rowloss)
-        # encoder LSTM on [X, repeat(W)] (:193-199): per-row bias carries W.K_w + b
+        # Wargs head, logistic-normal sample, label losses and both per-row LSTM biases (W.K_w + b): one launch
         off = self.off
-        g(self.W, P.rows(P.params, 'encoder_h/kernel', D), self.wk_enc, B, G4, Cn, bias=P.p('encoder_h/bias'), ws=ws)
-        g(self.W, P.rows(P.params, 'decoder_h/kernel', off + L), self.wk_dec, B, G4, Cn, bias=P.p('decoder_h/bias'),
-          ws=ws)
+        ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true,
+                           cfg['w_log_var_prior'], P.rows(P.params, 'encoder_h/kernel', D), P.p('encoder_h/bias'),
+                           P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
+                           self.wargs, self.W, self.rowloss, self.wk_enc, self.wk_dec)
         self._join()
         ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
                          self.cs_enc, self.gates_enc, gate_act=self.gate_act)
@@ -531,7 +529,6 @@ class VrnnEngine(_EngineBase):
         with self._side():
             self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, dz, self.dzsum_dec, off + L, ws2)
         g(dz, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
-        g(self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off + L), self.dW, B, Cn, G4, tb=True, ws=ws)
         # latent heads
         ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
         g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
@@ -544,14 +541,14 @@ class VrnnEngine(_EngineBase):
         dz = self.gates_enc
         with self._side():
             self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, dz, self.dzsum_enc, D, ws2)
-        g(self.dzsum_enc, P.rows(P.params, 'encoder_h/kernel', D), self.dW, B, Cn, G4, tb=True, beta=1.0, ws=ws)
-        # label head
-        ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, self.W, self.dW,
-                      cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
-                      self.dwargs, self.dwargs[:, C1:], 2 * C1)
-        g(self.hW, self.dwargs, P.g('Wargs/kernel'), D, 2 * C1, B, ta=True, ws=ws)
-        ops.colsum(self.dwargs, B, 2 * C1, P.g('Wargs/bias'), ws)
-        g(self.dwargs, P.p('Wargs/kernel'), self.dhW, B, D, 2 * C1, tb=True, act=ACT_MASKPOS, aux=self.hW, ws=ws)
+        # label head: dW from both LSTMs, label backward, dWargs and dhW in one launch; then the two Dense
+        # layers' (dW, db) pairs as grouped GEMMs
+        ops.vrnn_label_bwd(B, D, Cn, G4, self.dzsum_enc, self.dzsum_dec, P.rows(P.params, 'encoder_h/kernel', D),
+                           P.rows(P.params, 'decoder_h/kernel', off + L), self.wargs, eps_W, w_true, self.W, self.hW,
+                           P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
+                           self.dwargs, self.dhW)
+        ops.gemm_grouped_tn([dict(A=self.hW, lda=D, M=D, C=P.g('Wargs/kernel')),
+                             dict(A=None, M=1, C=P.g('Wargs/bias'), ones=True)], 2 * C1, B, self.dwargs, ws)
         ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
         self._join()
         if do_tail:

@@ -110,6 +110,22 @@ def label_bwd(B, Cn, mean, logvar, ld_in, eps, onehot, w, dw, prior, class_weigh
                                    _ptr(dmean), _ptr(dlogvar), ld_out, _stream()), "clv_label_bwd")
 
 
+def vrnn_label_fwd(B, D, Cn, G4, hW, Ka, ba, eps, onehot, prior, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc,
+                   rb_dec):
+    check(_lib.lib().clv_vrnn_label_fwd(B, D, Cn, G4, _ptr(hW), _ptr(Ka), _ptr(ba), _ptr(eps), _ptr(onehot),
+                                        float(prior), _ptr(Kenc_w), _ptr(benc), _ptr(Kdec_w), _ptr(bdec), _ptr(wargs),
+                                        _ptr(W), _ptr(rowloss), _ptr(rb_enc), _ptr(rb_dec), _stream()),
+          "clv_vrnn_label_fwd")
+
+
+def vrnn_label_bwd(B, D, Cn, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior,
+                   class_weight, w_kl_weight, inv_b, dwargs, dhW):
+    check(_lib.lib().clv_vrnn_label_bwd(B, D, Cn, G4, _ptr(dzsum_enc), _ptr(dzsum_dec), _ptr(Kenc_w), _ptr(Kdec_w),
+                                        _ptr(wargs), _ptr(eps), _ptr(onehot), _ptr(W), _ptr(hW), _ptr(Ka),
+                                        float(prior), float(class_weight), float(w_kl_weight), float(inv_b),
+                                        _ptr(dwargs), _ptr(dhW), _stream()), "clv_vrnn_label_bwd")
+
+
 def gauss_fwd(R, Ld, zargs, eps, z, ldz, rowkl):
     check(_lib.lib().clv_gauss_fwd(R, Ld, _ptr(zargs), _ptr(eps), _ptr(z), ldz, _ptr(rowkl), _stream()),
           "clv_gauss_fwd")

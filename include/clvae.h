@@ -127,6 +127,23 @@ int clv_label_bwd(int B, int C, const float* mean, const float* logvar, int ld_i
                   float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
                   float* dmean, float* dlogvar, int ld_out, void* stream);
 
+/* The whole cl_vrnn label path of a batch row in one launch (one workgroup per row):
+ * fwd: Wargs = hW.K_a + b_a; W = logistic-normal sample; (kl_w, w_rec, hit) -> rowloss[B,3];
+ *      rb_enc = W.K_enc_w + b_enc, rb_dec = W.K_dec_w + b_dec  -- the per-row LSTM biases that carry
+ *      the RepeatVector(W) columns of the LSTM inputs (K_*_w = the C kernel rows that multiply W).
+ * bwd: dW = dzsum_dec.K_dec_w^T + dzsum_enc.K_enc_w^T (RepeatVector sums), label backward with the
+ *      weighted w_rec / kl_w terms, dwargs[B,2(C-1)], dhW = (dwargs.K_a^T)*(hW > 0).
+ * D <= 128, C <= 32.  cl_vrnn/model.py:175-193,218-222,244-252. */
+int clv_vrnn_label_fwd(int B, int D, int C, int G4, const float* hW, const float* Ka, const float* ba,
+                       const float* eps, const float* onehot, float prior_logvar,
+                       const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                       float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec, void* stream);
+int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
+                       const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
+                       const float* onehot, const float* W, const float* hW, const float* Ka,
+                       float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
+                       float* dwargs, float* dhW, void* stream);
+
 /* gaussian reparameterisation rows: zargs[R, 2L] = [mean | log_var];
  * z[R, ldz] (written at column offset 0..L-1) = mean + exp(lv/2)*eps; rowkl[R] = KL(N(mean,exp(lv))||N(0,1)).
  * cl_vae/model.py:170-174,193-196; cl_vrnn/model.py:212-216,236-239. */
