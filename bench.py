@@ -27,6 +27,9 @@ WORKLOADS = {
     'cfg3': dict(model='cl_vrnn', B=256, T=128, L=2, C=10),
     'cfg5': dict(model='cl_vrnn', B=1024, T=256, L=32, C=10),
     'cfg2': dict(model='cl_vae', B=512, T=1, L=4, C=2),
+    # BASELINE config 5, second half: autoregressive generation under hipGraph (frames/s, N seeds at once)
+    'gen1024': dict(model='cl_vrnn', B=1024, T=256, L=32, C=10, generate=True),
+    'gen1': dict(model='cl_vrnn', B=1, T=256, L=32, C=10, generate=True),
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 NOTE_DENSITY = 0.0443        # measured JSB note density
@@ -116,6 +119,38 @@ def cpu_baseline(w, seconds=15.0):
                        % (n, B, T, os.cpu_count()))
 
 
+def bench_generate(args, w, dev, rank, world):
+    """Replicas-only sampling benchmark: N seeds per GPU, 16 teacher-forced frames, then free-running frames;
+    a "step" is one generated frame for all N sequences (one hipGraph replay)."""
+    import torch
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.initializers import init_weights
+    N, L, C = w['B'], w['L'], w['C']
+    cfg = dict(D=88, H=88, L=L, T=16, C=C, use_x_prev=True, class_weight=1.0, kl_weight=1.0, w_kl_weight=1.0,
+               w_log_var_prior=0.0, gate_act='hard_sigmoid')
+    eng = VrnnEngine(cfg, 1, dev)
+    eng.P.set_weights(init_weights(eng.P.logical, cfg, seed=0))
+    rng = np.random.default_rng(1234 + rank)
+    seeds = torch.as_tensor((rng.random((N, 16, 88)) < NOTE_DENSITY).astype(np.float32), device=dev)
+    wv = torch.as_tensor(np.eye(C, dtype=np.float32)[rng.integers(0, C, N)], device=dev)
+    eng.generate(seeds, wv, max(args.warmup, 2), seed=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = eng.generate(seeds, wv, args.steps, seed=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = world * N * (args.steps + 16)
+    if rank == 0:
+        print(json.dumps({"metric": "generated piano-roll frames/sec (sample)", "value": round(frames / dt, 1),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * dt / (args.steps + 16), 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "%s: cl_vrnn generation, %d seeds/GPU, latent %d, 16 seed frames, "
+                                                 "hipGraph replay per frame" % (args.workload, N, L),
+                                     "parallelism": "replicas%d" % world},
+                          "note_density_out": round(float(out.mean().item()), 4)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -144,6 +179,8 @@ def main():
     w = WORKLOADS[args.workload]
     B, T = w['B'], w['T']
 
+    if w.get('generate'):
+        return bench_generate(args, w, dev, rank, world)
     eng, cfg = make_engine(w, dev)
     if world > 1:      # replicas start from rank 0's weights
         dist.broadcast(eng.P.params, src=0)

@@ -246,6 +246,17 @@ class Encoder:
         return [Zargs[..., :L], Zargs[..., L:], W]
 
 
+def generate_samples_device(model, x_seeds, nsteps, w_vals, seed=0, z_prior=False):
+    """Batched, device-resident counterpart of generate_sample: N seeds at once, the whole frame loop as
+    replays of one captured hipGraph, Philox noise instead of np.random (so the draws differ from the numpy
+    path, the distribution does not).  x_seeds [N,S,88] (S >= 0 teacher-forced frames), w_vals [N,C].
+    Returns the free-running part [N,nsteps,88] as a numpy array, like generate_sample does per seed."""
+    e = model.engine
+    xs = torch.as_tensor(np.ascontiguousarray(np.asarray(x_seeds), dtype=np.float32), device=e.device)
+    w = torch.as_tensor(np.ascontiguousarray(np.asarray(w_vals), dtype=np.float32), device=e.device)
+    return e.generate(xs, w, int(nsteps), seed=int(seed), z_prior=z_prior).cpu().numpy().astype(np.float64)
+
+
 def make_w_encoder(model, original_dim, n_classes, seq_length=1, batch_size=1):
     return WEncoder(model, seq_length, batch_size)
 

@@ -130,6 +130,14 @@ extern "C" int clv_philox_uniform(float* out, int64_t n, uint64_t seed, uint32_t
   return launch_philox<false>(out, n, seed, step, step_dev, stream_id, first_index, (hipStream_t)stream);
 }
 
+__global__ void i32_add_kernel(int32_t* p, int32_t v) { *p += v; }
+
+extern "C" int clv_i32_add(int32_t* counter, int32_t v, void* stream) {
+  if (!counter) return CLV_EINVAL;
+  hipLaunchKernelGGL(i32_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, v);
+  return clv::launch_status();
+}
+
 // ------------------------------------------------------------------ graphs --
 extern "C" int clv_graph_begin_capture(void* stream) {
   CLV_HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));

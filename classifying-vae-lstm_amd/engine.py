@@ -477,6 +477,52 @@ class VrnnEngine(_EngineBase):
         g(st['hs'], P.p('X_decoded_mean/kernel'), st['xhat'], B, D, H, bias=P.p('X_decoded_mean/bias'),
           act=ACT_SIGMOID, ws=ws)
 
+    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False):
+        """Batched autoregressive generation on the device (the hot loop of cl_vrnn/model.py:47-59 for N
+        independent sequences at once, noise from Philox instead of np.random).
+        x_seed [N,S,D] device tensor (teacher-forced frames, S may be 0), w [N,C]; returns Xs [N,nsteps,D].
+        One frame = encoder step -> z ~ N(mean, exp(lv)) -> decoder step -> x ~ Bernoulli(x_hat); the chain
+        is captured once and replayed per frame with no host synchronisation."""
+        cfg, d = self.cfg, self.device
+        N, S = int(x_seed.shape[0]), int(x_seed.shape[1])
+        D, L = cfg['D'], cfg['L']
+        f = dict(dtype=torch.float32, device=d)
+        st = self.new_state(N)
+        x_prev, x_next = torch.zeros(N, D, **f), torch.zeros(N, D, **f)
+        eps, u, z = torch.zeros(N, L, **f), torch.zeros(N, D, **f), torch.zeros(N, L, **f)
+        counter = torch.zeros(1, dtype=torch.int32, device=d)
+        Xs = torch.zeros(N, nsteps, D, **f)
+        w = w.contiguous()
+
+        def frame():
+            self.enc_step(x_prev, w, st)
+            ops.philox_normal(eps, N * L, seed, 0, 0, 0, step_dev=counter)
+            if z_prior:
+                st['zargs'].zero_()
+            ops.gauss_fwd(N, L, st['zargs'], eps, z, L, None)
+            self.dec_step(z, x_prev if cfg['use_x_prev'] else None, w, st)
+            ops.philox_uniform(u, N * D, seed, 0, 1, 0, step_dev=counter)
+            ops.bernoulli_sample(N * D, st['xhat'], u, x_next)
+            ops.i32_add(counter, 1)
+            x_prev.copy_(x_next)
+
+        if S == 0:
+            x_prev.zero_()
+        graph = None
+        for t in range(S + nsteps):
+            if t < S:
+                x_prev.copy_(x_seed[:, t])
+            if use_graph and t == 1:
+                with ops.Graph() as graph:       # step 0 ran eagerly and sized every workspace
+                    frame()
+            if graph is not None:
+                graph.launch()
+            else:
+                frame()
+            if t >= S:
+                Xs[:, t - S].copy_(x_next)
+        return Xs
+
     def _lstm_wgrads(self, name, X_in, x_ld, x_rows, hs, dz, dzsum, w_row, ws):
         """Every weight gradient of one LSTM in two grouped launches.
         Over dz [B*T,4H] (K = B*T): kernel rows of the per-step inputs (x_t, or [x_{t-1} | z_t] for the

@@ -164,6 +164,10 @@ def philox_uniform(out, n, seed, step=0, stream_id=0, first_index=0, step_dev=No
           "clv_philox_uniform")
 
 
+def i32_add(counter, v=1):
+    check(_lib.lib().clv_i32_add(_ptr(counter), int(v), _stream()), "clv_i32_add")
+
+
 def bernoulli_sample(n, p, u, x):
     check(_lib.lib().clv_bernoulli_sample(n, _ptr(p), _ptr(u), _ptr(x), _stream()), "clv_bernoulli_sample")
 

@@ -222,6 +222,8 @@ int clv_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, const
                       uint32_t stream_id, uint64_t first_index, void* stream);
 int clv_philox_uniform(float* out, int64_t n, uint64_t seed, uint32_t step, const int32_t* step_dev,
                        uint32_t stream_id, uint64_t first_index, void* stream);
+/* *counter += v on the device (advances the Philox step between replays of a captured sampling step) */
+int clv_i32_add(int32_t* counter, int32_t v, void* stream);
 /* x[i] = (u[i] <= p[i]) ? 1 : 0   -- sample_x */
 int clv_bernoulli_sample(int64_t n, const float* p, const float* u, float* x, void* stream);
 

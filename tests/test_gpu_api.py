@@ -249,3 +249,48 @@ def test_cl_vrnn_cli_train_then_sample(dev, tmp_path):
     sargs = _ns(S.build_parser(), ['h', '--infer_w', '--discrete_w', '-t', '8', '-i', os.path.join(mdir, 'r2.h5'),
                                    '--train_file', data, '--sample_dir', sdir])
     assert S.sample(sargs)[0].shape == (8, 88)
+
+
+def test_device_generation_matches_stepwise_oracle(dev):
+    """generate_samples_device: the frame loop on the device (hipGraph replays, Philox noise) vs an oracle
+    loop that redraws the same Philox numbers on the host."""
+    from clvae_amd.cl_vrnn.model import generate_samples_device, get_model
+    T, L, C, N, S, nsteps = 8, 2, 10, 5, 3, 6
+    model, _ = get_model(4, 88, 88, L, T, C, True, 'adam', seed=9)
+    p = {k: f32(v) for k, v in model.engine.P.get_weights().items()}
+    rng = np.random.default_rng(4)
+    seeds = (rng.random((N, S, 88)) < 0.06).astype(np.float64)
+    w = np.eye(C)[rng.integers(0, C, N)]
+    out = generate_samples_device(model, seeds, nsteps, w, seed=31)
+    assert out.shape == (N, nsteps, 88) and set(np.unique(out)) <= {0.0, 1.0}
+    # oracle: same recurrences, noise re-drawn from the numpy Philox (step = frame index)
+    H = 88
+    he = np.zeros((N, H)); ce = np.zeros((N, H)); hd = np.zeros((N, H)); cd = np.zeros((N, H))
+
+    def cell(x, h, c, k, r, b):
+        zz = x @ k + b + h @ r
+        i, f_, g, o = O.hard_sigmoid(zz[:, :H]), O.hard_sigmoid(zz[:, H:2 * H]), np.tanh(zz[:, 2 * H:3 * H]), O.hard_sigmoid(zz[:, 3 * H:])
+        c = f_ * c + i * g
+        return o * np.tanh(c), c
+    x_prev = None
+    flips = 0
+    for t in range(S + nsteps):
+        if t < S:
+            x_prev = seeds[:, t]
+        he, ce = cell(np.concatenate([x_prev, w], 1), he, ce, p['encoder_h/kernel'], p['encoder_h/recurrent_kernel'], p['encoder_h/bias'])
+        zm = he @ p['Z_mean/kernel'] + p['Z_mean/bias']; zlv = he @ p['Z_log_var/kernel'] + p['Z_log_var/bias']
+        eps = OP.normal(N * L, 31, step=t, stream_id=0).reshape(N, L).astype(np.float64)
+        z = zm + np.exp(zlv / 2) * eps
+        hd, cd = cell(np.concatenate([x_prev, z, w], 1), hd, cd, p['decoder_h/kernel'], p['decoder_h/recurrent_kernel'], p['decoder_h/bias'])
+        xhat = O.sigmoid(hd @ p['X_decoded_mean/kernel'] + p['X_decoded_mean/bias'])
+        uu = OP.uniform(N * 88, 31, step=t, stream_id=1).reshape(N, 88).astype(np.float64)
+        x_t = (uu <= xhat).astype(np.float64)
+        if t >= S:
+            got = out[:, t - S]
+            # a draw within fp32 noise of its probability may flip; follow the device's path from there on
+            close = np.abs(uu - xhat) < 1e-5
+            assert np.all((got == x_t) | close), (t, np.argwhere((got != x_t) & ~close)[:3])
+            flips += int((got != x_t).sum())
+            x_t = got
+        x_prev = x_t
+    assert flips <= 2
