@@ -360,6 +360,7 @@ class VrnnEngine(_EngineBase):
         self.gate_act = _lib.GATE_HARD_SIGMOID if cfg.get('gate_act', 'hard_sigmoid') == 'hard_sigmoid' \
             else _lib.GATE_SIGMOID
         self.off = D if cfg['use_x_prev'] else 0     # decoder kernel rows: [Xp | Z | W]
+        self.fuse_xproj = bool(cfg.get('fuse_xproj', False))   # break-even vs the projection GEMM at config 3
         self.hW = _f(d, B, D)
         self.wargs = _f(d, B, 2 * (Cn - 1))
         self.W = _f(d, B, Cn)
@@ -396,9 +397,11 @@ class VrnnEngine(_EngineBase):
         g, ws = ops.gemm, self.ws
         if cfg['use_x_prev'] and Xp.data_ptr() != self.XZ.data_ptr():
             self.XZ.view(B, T, self.xz_ld)[:, :, :D].copy_(Xp.view(B, T, D))     # staging copy only
-        # the encoder's input projection only needs X: optionally on the side stream under the label path
-        with self._side():
-            g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
+        fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
+        fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)
+        if not fuse_enc:      # dense input projection as a GEMM (inputs too wide for the LDS-resident form)
+            with self._side():
+                g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
         # label path (:174-191)
         g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
         # Wargs head, logistic-normal sample, label losses and both per-row LSTM biases (W.K_w + b): one launch
@@ -408,16 +411,25 @@ class VrnnEngine(_EngineBase):
                            P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
                            self.wargs, self.W, self.rowloss, self.wk_enc, self.wk_dec)
         self._join()
-        ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
-                         self.cs_enc, self.gates_enc, gate_act=self.gate_act)
+        if fuse_enc:          # x_t.K gathered from the LDS-resident kernel inside the sequence kernel
+            ops.lstm_seq_fwd_x(B, T, X, D, D, P.p('encoder_h/kernel'), self.wk_enc, P.p('encoder_h/recurrent_kernel'),
+                               self.hs_enc, self.cs_enc, self.gates_enc, gate_act=self.gate_act)
+        else:
+            ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
+                             self.cs_enc, self.gates_enc, gate_act=self.gate_act)
         # latent heads + sample (:200-216)
         g(self.hs_enc, P.p('Zargs/kernel'), self.zargs, BT, 2 * L, H, bias=P.p('Zargs/bias'), ws=ws)
         ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
         # decoder LSTM on [Xp, Z, repeat(W)] (:218-228): one projection of the [Xp | Z] rows
         self._join()
-        g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
-        ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
-                         self.cs_dec, self.gates_dec, gate_act=self.gate_act)
+        if fuse_dec:
+            ops.lstm_seq_fwd_x(B, T, self.XZ, self.xz_ld, off + L, P.p('decoder_h/kernel'), self.wk_dec,
+                               P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.cs_dec, self.gates_dec,
+                               gate_act=self.gate_act)
+        else:
+            g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
+            ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
+                             self.cs_dec, self.gates_dec, gate_act=self.gate_act)
         # output head (:229-234)
         g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
 

@@ -93,6 +93,17 @@ def lstm_seq_fwd(B, T, xproj, rowbias, U, hs, cs, gates, h0=None, c0=None, hT=No
           "clv_lstm_seq_fwd")
 
 
+def lstm_fused_input_fits(B, nx):
+    return nx <= 128 and _lib.lib().clv_lstm_seq_fwd_x_lds_bytes(B, nx) <= 156 * 1024
+
+
+def lstm_seq_fwd_x(B, T, xin, ldx, nx, Kin, rowbias, U, hs, cs, gates, h0=None, c0=None, hT=None, cT=None, gate_act=0,
+                   H=88):
+    check(_lib.lib().clv_lstm_seq_fwd_x(B, T, H, gate_act, _ptr(xin), ldx, nx, _ptr(Kin), _ptr(rowbias), _ptr(U),
+                                        _ptr(h0), _ptr(c0), _ptr(hs), _ptr(cs), _ptr(gates), _ptr(hT), _ptr(cT),
+                                        _stream()), "clv_lstm_seq_fwd_x")
+
+
 def lstm_seq_bwd(B, T, U, dhs, cs, gates_inout, dzsum, c0=None, gate_act=0, H=88):
     check(_lib.lib().clv_lstm_seq_bwd(B, T, H, gate_act, _ptr(U), _ptr(dhs), _ptr(cs), _ptr(c0), _ptr(gates_inout),
                                       _ptr(dzsum), _stream()), "clv_lstm_seq_bwd")

@@ -106,6 +106,16 @@ int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
                      const float* h0, const float* c0,
                      float* hs, float* cs, float* gates, float* hT, float* cT,
                      void* stream);
+/* Same recurrence with the input projection fused in: z_t = sum_k xin[b,t,k] * Kin[k,:] + rowbias[b,:] + h.U.
+ * Kin [nx,4H] (the kernel rows of the per-step inputs) stays in LDS for the whole sequence and only the
+ * NONZERO inputs of a frame are visited (a piano-roll frame has ~4 of 88 notes on; any float input is
+ * handled exactly, cost grows with its nonzeros), so no [B,T,4H] projection is ever written to HBM.
+ * nx <= 128 and clv_lstm_seq_fwd_x_lds_bytes(B, nx) <= 156 KB (else CLV_EINVAL: use the xproj form). */
+size_t clv_lstm_seq_fwd_x_lds_bytes(int B, int nx);
+int clv_lstm_seq_fwd_x(int B, int T, int H, int gate_act,
+                       const float* xin, int ldx, int nx, const float* Kin,
+                       const float* rowbias, const float* U, const float* h0, const float* c0,
+                       float* hs, float* cs, float* gates, float* hT, float* cT, void* stream);
 int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
                      const float* U, const float* dhs, const float* cs, const float* c0,
                      float* gates_inout_dz, float* dzsum, void* stream);

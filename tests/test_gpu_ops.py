@@ -300,3 +300,31 @@ def test_loss_sums(dev):
     ops.loss_sums([(T(a, dev), 5000, 1), (T(b, dev), 37, 1), (cd, 29, 3), (cd[:, 1:], 29, 3), (cd[:, 2:], 29, 3)], out)
     ref = [a.astype(np.float32).mean(), b.astype(np.float32).mean()] + [c[:, j].astype(np.float32).mean() for j in range(3)]
     np.testing.assert_allclose(N(out)[:5], ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Tn,nx,ldx,dense", [(3, 9, 88, 88, False), (4, 6, 90, 92, False), (2, 5, 98, 100, True),
+                                                (1024, 3, 88, 88, False)])
+def test_lstm_fused_input_projection(dev, B, Tn, nx, ldx, dense):
+    """clv_lstm_seq_fwd_x (K resident in LDS, nonzero gather) == GEMM projection + clv_lstm_seq_fwd."""
+    from clvae_amd import ops
+    H = 88
+    rng = np.random.default_rng(B * 7 + nx)
+    U = O.orthogonal(rng, (H, 4 * H), np.float64)
+    K = rng.standard_normal((nx, 4 * H)) * 0.4
+    X = rng.standard_normal((B, Tn, ldx)) if dense else (rng.random((B, Tn, ldx)) < 0.06).astype(np.float64)
+    if not dense:
+        X[:, :, nx - 2:nx] = rng.standard_normal((B, Tn, 2))         # latent columns are dense floats
+    X[:, 0, :] = 0 if not dense else X[:, 0, :]                       # an all-zero frame (empty nonzero list)
+    rb = rng.standard_normal((B, 4 * H)) * 0.3
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    hs_ref, cache = O.lstm_forward(f(X[:, :, :nx]), f(K), f(U), np.zeros(4 * H), gate_act='hard_sigmoid')
+    hs_ref, cache = O.lstm_forward(f(X[:, :, :nx]) @ f(K) + f(rb)[:, None, :], np.eye(4 * H), f(U), np.zeros(4 * H))
+    assert ops.lstm_fused_input_fits(B, nx)
+    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
+    gates = torch.empty(B, Tn, 4 * H, device=dev)
+    ops.lstm_seq_fwd_x(B, Tn, T(X, dev), ldx, nx, T(K, dev), T(rb, dev), T(U, dev), hs, cs, gates)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(hs), hs_ref, atol=1e-5)
+    np.testing.assert_allclose(N(cs), cache['C'], atol=2e-5)
+    np.testing.assert_allclose(N(gates).reshape(B, Tn, 4, H)[:, :, 0], cache['Z'].reshape(B, Tn, 4, H)[:, :, 0], atol=3e-5)
+    assert not ops.lstm_fused_input_fits(B, 120)                      # 120 x 352 floats do not fit the LDS
