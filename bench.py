@@ -241,10 +241,11 @@ def main():
             achieved = lstm_seq_flops(w, B) / avg_s / 1e12
             kname = 'lstm_seq_fwd+lstm_seq_bwd'
         else:
-            n, ms = by['gemm_f32'][1], by['gemm_f32'][2]
+            # cl_vae: the whole step is one fused launch (all 8 Dense layers, forward + backward)
+            kname = 'vae_fused_step' if 'vae_fused_step' in by else 'gemm_f32'
+            n, ms = by[kname][1], by[kname][2]
             avg_s = ms / n * 1e-3
             achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
-            kname = 'gemm_f32'
         traffic = None       # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_%s.json' % args.workload)))

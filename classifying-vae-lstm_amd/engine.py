@@ -227,6 +227,12 @@ class VaeEngine(_EngineBase):
         B, D, H, L, Hc, Cn = self.B, cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
         d = self.device
         self.xoff = D if cfg['use_x_prev'] else 0      # decoder_h kernel rows: [w | xp | z]
+        L_ = _lib.lib()
+        self.fused = bool(cfg.get('fused_step', True)) and bool(L_.clv_vae_fused_supported(D, H, Hc, Cn, L))
+        names = ['h_w', 'wargs', 'h', 'zargs', 'decoder_h', 'x_decoded_mean']
+        self._offs = (C.c_int64 * 12)(*[self.P.offsets['%s/%s' % (n, w)] for n in names for w in ('kernel', 'bias')])
+        self._fused_ws = torch.empty(max(L_.clv_vae_fused_workspace_bytes(B, self.P.n), 16), dtype=torch.uint8,
+                                     device=self.device) if self.fused else None
         self.h_w = _f(d, B, Hc)
         self.wargs = _f(d, B, 2 * (Cn - 1))          # [w_mean | w_log_var]
         self.w = _f(d, B, Cn)
@@ -300,12 +306,27 @@ class VaeEngine(_EngineBase):
         ops.gauss_fwd(B, L, self.zargs, eps_z, self.z, L, self.rowkl)
         self.decode(self.w, self.z, xp)
 
+    def _fused_step(self, x, xp, w_true, eps_w, eps_z, need_grads):
+        """The whole step as ONE kernel (csrc/vae_fused.hip) + the slab sum + the loss means."""
+        cfg, P, B = self.cfg, self.P, self.B
+        p_ = ops._ptr
+        _lib.check(_lib.lib().clv_vae_fused_step(
+            B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), p_(x), p_(xp), p_(w_true),
+            p_(eps_w), p_(eps_z), p_(P.params), self._offs, P.n, float(cfg['w_log_var_prior']), self.class_weight,
+            self.kl_weight, self.w_kl_weight, int(need_grads), p_(P.grads), p_(self._fused_ws), self._fused_ws.numel(),
+            p_(self.logits), p_(self.w), p_(self.wargs), p_(self.zargs), p_(self.rownll), p_(self.rowkl),
+            p_(self.rowloss), ops._stream()), "clv_vae_fused_step")
+        ops.loss_sums([(self.rownll, B, 1), (self.rowkl, B, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
+                       (self.rowloss[:, 2:], B, 3)], self.scal)
+
     def loss_and_grads(self, x, xp, w_true, eps_w, eps_z, need_grads=True):
         """One forward + 4 losses (+ gradients of the weighted total into P.grads)."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, Hc, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
         C1 = Cn - 1
         inv = 1.0 / B
+        if self.fused and w_true is not None:
+            return self._fused_step(x, xp, w_true, eps_w, eps_z, need_grads)
         self.forward(x, xp, eps_w, eps_z, w_true)
         ops.bernoulli_nll(B, D, self.logits, x, D, inv, self.rownll, self.dlogits if need_grads else None)
         ops.loss_sums([(self.rownll, B, 1), (self.rowkl, B, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),

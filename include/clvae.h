@@ -137,6 +137,26 @@ int clv_label_bwd(int B, int C, const float* mean, const float* logvar, int ld_i
                   float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
                   float* dmean, float* dlogvar, int ld_out, void* stream);
 
+/* One whole cl_vae step in one launch (+ one slab-sum launch for the weight gradients): forward of
+ * cl_vae/model.py:141-188 with injected eps, the four losses (:190-206) as per-row arrays
+ * (rownll[B], rowkl[B], rowloss[B,3] = kl_w, w_rec, hit), and -- when need_grads -- the gradient of
+ * (sum_rows vae + kl_weight*kl_z + w_kl_weight*kl_w + class_weight*w_rec) / B into `grads` (flat layout).
+ * `params` is the flat parameter buffer with the two head pairs stored fused ([in, 2n] kernels:
+ * w_mean|w_log_var and z_mean|z_log_var); host_offsets12 = element offsets of
+ * {h_w, wargs, h, zargs, decoder_h, x_decoded_mean} x {kernel, bias}.  Activations live in LDS, weights
+ * stream from L2 into MFMA operands.  Limits: D, H, Hc <= 96; C, L <= 16 (clv_vae_fused_supported).
+ * ws >= clv_vae_fused_workspace_bytes(B, n_params).  logits may be NULL. */
+int clv_vae_fused_supported(int D, int H, int Hc, int C, int L);
+size_t clv_vae_fused_workspace_bytes(int B, long n_params);
+int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
+                       const float* x, const float* xp, const float* onehot,
+                       const float* eps_w, const float* eps_z,
+                       const float* params, const int64_t* host_offsets12, long n_params,
+                       float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
+                       int need_grads, float* grads, void* ws, size_t ws_bytes,
+                       float* logits, float* w_out, float* wargs_out, float* zargs_out,
+                       float* rownll, float* rowkl, float* rowloss, void* stream);
+
 /* The whole cl_vrnn label path of a batch row in one launch (one workgroup per row):
  * fwd: Wargs = hW.K_a + b_a; W = logistic-normal sample; (kl_w, w_rec, hit) -> rowloss[B,3];
  *      rb_enc = W.K_enc_w + b_enc, rb_dec = W.K_dec_w + b_dec  -- the per-row LSTM biases that carry

@@ -48,16 +48,20 @@ def frames(rng, *shape):
     return (rng.random(shape) < 0.0443).astype(np.float64)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("B,L,Cn,use_x_prev,weights", [
     (100, 4, 2, True, (1.0, 1.0, 1.0, 0.0)),       # BASELINE config 1 shape
     (512, 4, 2, True, (1.0, 1.0, 1.0, 0.0)),       # config 2 shape (fp32 path)
     (48, 2, 10, False, (0.7, 0.3, 0.9, 0.4)),
+    (37, 16, 16, True, (0.5, 0.8, 1.1, -0.2)),     # ragged last row tile, widest fused heads
 ])
-def test_cl_vae_step_matches_oracle(dev, B, L, Cn, use_x_prev, weights):
+def test_cl_vae_step_matches_oracle(dev, B, L, Cn, use_x_prev, weights, fused):
+    """fused=True: the single-launch whole-step kernel (csrc/vae_fused.hip); False: the layer-by-layer chain."""
     from clvae_amd.engine import VaeEngine
     cw, klw, wklw, prior = weights
     cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=use_x_prev, class_weight=cw, kl_weight=klw,
                        w_kl_weight=wklw, w_log_var_prior=prior)
+    cfg['fused_step'] = fused
     rng = np.random.default_rng(11)
     p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=1).items()}
     for k in p:
@@ -69,6 +73,7 @@ def test_cl_vae_step_matches_oracle(dev, B, L, Cn, use_x_prev, weights):
     ref = O.vae_loss_and_grads(p, cfg, x, xp, wt, ew, ez)
 
     eng = VaeEngine(cfg, B, dev)
+    assert eng.fused == fused
     eng.P.set_weights(p)
     args = (T(x, dev), T(xp, dev), T(wt, dev), T(ew, dev), T(ez, dev))
     eng.loss_and_grads(*args)
