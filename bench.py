@@ -235,11 +235,13 @@ def main():
             by[k] = (k, by.get(k, (k, 0, 0.0))[1] + r[1], by.get(k, (k, 0, 0.0))[2] + r[2])
         if w['model'] == 'cl_vrnn':
             # dominant kernel: the persistent LSTM sequence kernels (fwd+bwd, 2 LSTMs each)
-            n = by['lstm_seq_fwd'][1] + by['lstm_seq_bwd'][1]
-            ms = by['lstm_seq_fwd'][2] + by['lstm_seq_bwd'][2]
+            # (one launch = one LSTM pass, or both LSTMs of a pass when the pair kernels run): 4 LSTM passes per step
+            names = sorted(k for k in by if k.startswith('lstm_'))
+            n = sum(by[k][1] for k in names)
+            ms = sum(by[k][2] for k in names)
             avg_s = ms / n * 1e-3
-            achieved = lstm_seq_flops(w, B) / avg_s / 1e12
-            kname = 'lstm_seq_fwd+lstm_seq_bwd'
+            achieved = 4 * reps * lstm_seq_flops(w, B) / (ms * 1e-3) / 1e12
+            kname = '+'.join(names)
         else:
             # cl_vae: the whole step is one fused launch (all 8 Dense layers, forward + backward)
             kname = 'vae_fused_step' if 'vae_fused_step' in by else 'gemm_f32'

@@ -31,6 +31,11 @@ class GemmProb(C.Structure):
                 ("a_shift", C.c_int32), ("a_zero_period", C.c_int32), ("ones", C.c_int32)]
 
 
+class ReduceJob(C.Structure):
+    """clv_reduce_job: an opaque pending split-K reduction (include/clvae.h)."""
+    _fields_ = [("opaque", C.c_ubyte * 160)]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
 
@@ -43,6 +48,9 @@ SIGNATURES = {
     "clv_gemm_auto_split": (_i, [_i, _i, _i]),
     "clv_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p]),
+    "clv_gemm_f32_deferred": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p, _p]),
+    "clv_gemm_grouped_tn_deferred": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p, _p]),
+    "clv_splitk_reduce_multi": (_i, [_p, _i, _p]),
     "clv_gemm_grouped_auto_split": (_i, [_p, _i, _i, _i]),
     "clv_gemm_grouped_workspace_bytes": (_sz, [_p, _i, _i, _i]),
     "clv_gemm_grouped_tn": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p]),
@@ -52,6 +60,9 @@ SIGNATURES = {
     "clv_lstm_seq_fwd_x_lds_bytes": (_sz, [_i, _i]),
     "clv_lstm_seq_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_seq_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_lstm_pair_supported": (_i, [_i, _i]),
+    "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i,
+                               _p, _p]),
     "clv_label_fwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "clv_label_bwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _i, _p]),
     "clv_vae_fused_supported": (_i, [_i, _i, _i, _i, _i]),

@@ -234,13 +234,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// One pending split-K reduction: everything the epilogue needs, small enough that a table of them
+// travels as kernel arguments (clv_reduce_job in the C ABI is this struct, opaque).
+struct ReduceProb { float* C; int ldc; int row0; };
+struct ReduceJob {
+  const float* partial;    // [splits][M][N] raw partial sums
+  int M, N, splits, nprob;
+  float alpha, beta;
+  const float* bias;
+  const float* aux;
+  int act;
+  int pad_;
+  ReduceProb prob[MAX_PROB];   // nprob == 0: prob[0] is the single output
+};
+static_assert(sizeof(ReduceJob) <= sizeof(clv_reduce_job), "clv_reduce_job too small");
+
+static ReduceJob make_job(const GemmArgs& g, int splits) {
+  ReduceJob j;
+  memset(&j, 0, sizeof(j));
+  j.partial = g.partial; j.M = g.M; j.N = g.N; j.splits = splits; j.nprob = g.nprob;
+  j.alpha = g.alpha; j.beta = g.beta; j.bias = g.bias; j.aux = g.aux; j.act = g.act;
+  if (g.nprob == 0) j.prob[0] = ReduceProb{g.C, g.ldc, 0};
+  for (int i = 0; i < g.nprob; ++i) j.prob[i] = ReduceProb{g.prob[i].C, g.prob[i].ldc, g.prob[i].row0};
+  return j;
+}
+
 // sum of `splits` partial slabs + epilogue.  64 outputs x 4 slab-lanes per block, 8 loads in flight
 // per thread (a serial loop over the slabs is latency-bound: ~0.5 us per dependent HBM load).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int splits) {
-  __shared__ float red[4][64];
+__device__ __forceinline__ void reduce_block(const ReduceJob& g, unsigned blk, float (*red)[64]) {
+  const int splits = g.splits;
   const size_t mn = (size_t)g.M * g.N;
   const int ex = threadIdx.x & 63, zy = threadIdx.x >> 6;
-  const size_t idx = (size_t)blockIdx.x * 64 + ex;
+  const size_t idx = (size_t)blk * 64 + ex;
   float v = 0.f;
   if (idx < mn) {
     const float* p = g.partial + idx;
@@ -260,15 +285,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
     v = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
     int row = (int)(idx / g.N);
     const int col = (int)(idx % g.N);
-    float* Cptr = g.C;
-    int ldc = g.ldc;
-    if (g.nprob > 0) {
-      int pi = 0;
+    int pi = 0;
 #pragma unroll
-      for (int i = 1; i < MAX_PROB; ++i)
-        if (i < g.nprob && row >= g.prob[i].row0) pi = i;
-      Cptr = g.prob[pi].C; ldc = g.prob[pi].ldc; row -= g.prob[pi].row0;
-    }
+    for (int i = 1; i < MAX_PROB; ++i)
+      if (i < g.nprob && row >= g.prob[i].row0) pi = i;
+    float* Cptr = g.prob[pi].C;
+    const int ldc = g.prob[pi].ldc;
+    row -= g.prob[pi].row0;
     v *= g.alpha;
     if (g.bias) v += g.bias[col];
     const size_t o = (size_t)row * ldc + col;
@@ -276,6 +299,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
     v = apply_act(v, g.act, g.act == CLV_ACT_MASKPOS ? g.aux[o] : 0.f);
     Cptr[o] = v;
   }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceJob j) {
+  __shared__ float red[4][64];
+  reduce_block(j, blockIdx.x, red);
+}
+// several pending reductions in one launch (the weight gradients of a whole backward pass)
+constexpr int MAX_JOBS = 16;
+struct ReduceTable { int njobs; unsigned blk0[MAX_JOBS + 1]; ReduceJob job[MAX_JOBS]; };
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t) {
+  __shared__ float red[4][64];
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_JOBS; ++i)
+    if (i < t.njobs && blockIdx.x >= t.blk0[i]) ji = i;
+  reduce_block(t.job[ji], blockIdx.x - t.blk0[ji], red);
+}
+static int launch_reduce(const ReduceJob& j, hipStream_t s) {
+  ProfScope p("gemm_splitk_reduce", s);
+  const size_t mn = (size_t)j.M * j.N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, j);
+  return launch_status();
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N>
@@ -311,12 +355,17 @@ static void tile_dims(TileCfg c, int& bm, int& bn) {
 }
 // split K until ~4 workgroups per CU are in flight (each k-tile is a dependent HBM round trip, so a
 // few long workgroups are latency-bound); chunks stay >= 32 deep.
+static long split_target() {
+  static long t = 0;
+  if (!t) { const char* e = getenv("CLV_GEMM_WGS"); t = e ? atol(e) : 1024; if (t < 1) t = 1024; }
+  return t;
+}
 static int auto_split(int M, int N, int K) {
   int bm, bn;
   tile_dims(pick_tile(M, N), bm, bn);
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   if (tiles >= 256 || K < 128) return 1;       // each k-tile is a dependent ~1 us round trip; a reduce launch ~6 us
-  long s = (1024 + tiles - 1) / tiles;
+  long s = (split_target() + tiles - 1) / tiles;
   if (s > K / 64) s = K / 64;
   if (s > 512) s = 512;
   return s < 1 ? 1 : (int)s;
@@ -342,12 +391,13 @@ extern "C" size_t clv_gemm_workspace_bytes(int M, int N, int split_k) {
   return (size_t)split_k * M * N * sizeof(float);
 }
 
-extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
-                            const float* A, int lda, const float* B, int ldb,
-                            float beta, float* C, int ldc,
-                            const float* bias, int act, const float* aux,
-                            int split_k, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int clv_gemm_f32_deferred(int transa, int transb, int M, int N, int K, float alpha,
+                                     const float* A, int lda, const float* B, int ldb,
+                                     float beta, float* C, int ldc,
+                                     const float* bias, int act, const float* aux,
+                                     int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream) {
   using namespace clv;
+  if (job) memset(job, 0, sizeof(*job));
   if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return CLV_EINVAL;
   if (act < CLV_ACT_NONE || act > CLV_ACT_MASKPOS) return CLV_EINVAL;
   if (act == CLV_ACT_MASKPOS && !aux) return CLV_EINVAL;
@@ -382,12 +432,43 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
   int st = launch_status();
   if (st) return st;
   if (splits > 1) {
-    ProfScope p("gemm_splitk_reduce", s);
-    size_t mn = (size_t)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, g, splits);
-    st = launch_status();
+    const ReduceJob j = make_job(g, splits);
+    if (job) memcpy(job, &j, sizeof(j));       // the caller reduces later (clv_splitk_reduce_multi)
+    else st = launch_reduce(j, s);
   }
   return st;
+}
+
+extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
+                            const float* A, int lda, const float* B, int ldb,
+                            float beta, float* C, int ldc,
+                            const float* bias, int act, const float* aux,
+                            int split_k, void* ws, size_t ws_bytes, void* stream) {
+  return clv_gemm_f32_deferred(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, act, aux, split_k, ws,
+                               ws_bytes, nullptr, stream);
+}
+
+extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream) {
+  using namespace clv;
+  if (!jobs || njobs < 0) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ReduceTable t;
+  t.njobs = 0;
+  unsigned blk = 0;
+  for (int i = 0; i < njobs; ++i) {
+    ReduceJob j;
+    memcpy(&j, &jobs[i], sizeof(j));
+    if (j.splits <= 1 || !j.partial) continue;          // finished inside its GEMM
+    if (t.njobs == MAX_JOBS) return CLV_EINVAL;
+    t.blk0[t.njobs] = blk;
+    t.job[t.njobs++] = j;
+    blk += (unsigned)(((size_t)j.M * j.N + 63) / 64);
+  }
+  if (t.njobs == 0) return CLV_OK;
+  t.blk0[t.njobs] = blk;
+  ProfScope p("gemm_splitk_reduce", s);
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blk), dim3(256), 0, s, t);
+  return launch_status();
 }
 
 // Grouped weight-gradient GEMM: C_p[M_p,N] = A_p^T . B for up to 4 problems that share B [K,N] (one pass over
@@ -398,11 +479,20 @@ static int grouped_tiles(const clv_gemm_prob* probs, int nprob, int bm) {
   return t;
 }
 
+// tile of a grouped launch: narrow outputs (a latent head's 2L columns) get a narrow tile
+static void grouped_tile(int N, int& bm, int& bn) {
+  if (N <= 16) { bm = 128; bn = 16; }
+  else if (N <= 32) { bm = 64; bn = 32; }
+  else { bm = 96; bn = 96; }
+}
+
 extern "C" int clv_gemm_grouped_auto_split(const clv_gemm_prob* probs, int nprob, int N, int K) {
   if (!probs || nprob < 1 || nprob > clv::MAX_PROB) return 1;
-  const long tiles = (long)grouped_tiles(probs, nprob, 96) * ((N + 95) / 96);
+  int bm, bn;
+  grouped_tile(N, bm, bn);
+  const long tiles = (long)grouped_tiles(probs, nprob, bm) * ((N + bn - 1) / bn);
   if (tiles >= 256 || K < 128) return 1;
-  long s = (1024 + tiles - 1) / tiles;
+  long s = (clv::split_target() + tiles - 1) / tiles;
   if (s > K / 64) s = K / 64;
   if (s > 512) s = 512;
   return s < 1 ? 1 : (int)s;
@@ -415,22 +505,25 @@ extern "C" size_t clv_gemm_grouped_workspace_bytes(const clv_gemm_prob* probs, i
   return (size_t)split_k * m * N * sizeof(float);
 }
 
-extern "C" int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N, int K,
-                                   const float* B, int ldb, float beta,
-                                   int split_k, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int nprob, int N, int K,
+                                            const float* B, int ldb, float beta,
+                                            int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream) {
   using namespace clv;
+  if (job) memset(job, 0, sizeof(*job));
   if (!probs || nprob < 1 || nprob > MAX_PROB || N <= 0 || K <= 0 || !B) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.nprob = nprob;
   int tile = 0, row = 0, vec = 1;
+  int bm, bn;
+  grouped_tile(N, bm, bn);
   for (int i = 0; i < nprob; ++i) {
     const clv_gemm_prob& p = probs[i];
     if (p.M <= 0 || !p.C || (!p.ones && !p.A) || (p.ones && p.M != 1)) return CLV_EINVAL;
     if (p.a_shift < 0 || (p.a_shift > 0 && p.a_zero_period <= 0)) return CLV_EINVAL;
     g.prob[i] = GemmProb{p.A, p.lda, p.M, p.C, p.ldc, p.a_shift, p.a_zero_period, p.ones, tile, row};
-    tile += (p.M + 95) / 96;
+    tile += (p.M + bm - 1) / bm;
     row += p.M;
     if (!p.ones) vec = vec && (p.lda % 4 == 0) && (((uintptr_t)p.A) % 16 == 0);
   }
@@ -451,15 +544,22 @@ extern "C" int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N,
   }
   {
     ProfScope p("gemm_grouped_tn", s);
-    launch_cfg<3, 3, 2, 2>(g, 1, 0, splits, s);       // 96 x 96 tiles
+    if (bn == 16) launch_cfg<2, 1, 4, 1>(g, 1, 0, splits, s);          // 128 x 16
+    else if (bn == 32) launch_cfg<1, 2, 4, 1>(g, 1, 0, splits, s);     // 64 x 32
+    else launch_cfg<3, 3, 2, 2>(g, 1, 0, splits, s);                   // 96 x 96
   }
   int st = launch_status();
   if (st) return st;
   if (splits > 1) {
-    ProfScope p("gemm_splitk_reduce", s);
-    size_t mn = (size_t)row * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, g, splits);
-    st = launch_status();
+    const ReduceJob j = make_job(g, splits);
+    if (job) memcpy(job, &j, sizeof(j));
+    else st = launch_reduce(j, s);
   }
   return st;
+}
+
+extern "C" int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N, int K,
+                                   const float* B, int ldb, float beta,
+                                   int split_k, void* ws, size_t ws_bytes, void* stream) {
+  return clv_gemm_grouped_tn_deferred(probs, nprob, N, K, B, ldb, beta, split_k, ws, ws_bytes, nullptr, stream);
 }

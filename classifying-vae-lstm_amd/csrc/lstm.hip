@@ -10,7 +10,7 @@
 //   lane = (unit_local = lane / KS, kslice = lane % KS); unit u = (64/KS)*wave + unit_local;
 //   KS = 8: 11 waves, 44 U-floats per thread;  KS = 4: 6 waves, 88 U-floats per thread.
 //   forward : thread (u,s) keeps U[KK*s .. KK*s+KK-1][{i,f,c,o} of u]   (KK = 88/KS)
-//   backward: thread (u,s) keeps U[u][CS*s .. CS*s+CS-1]                 (CS = 352/KS)
+//   backward: its own layout (4 units x 22 gate columns per thread), see lstm_bwd_kernel
 // Per step a thread does 4*KK FMAs per row, the k-slices are summed with log2(KS) DPP
 // adds, and the unit's gate math and cell state stay in that lane group's registers; only
 // h_t (forward) / dz_t (backward) cross lanes through LDS, one barrier per step.
@@ -22,35 +22,9 @@
 // a conditional or drained wait would expose the latency of the previous step's stores.
 #include <stdlib.h>
 
-#include "common.h"
+#include "lstm_common.h"
 
 namespace clv {
-
-constexpr int LH = 88;          // hidden units
-constexpr int LG = 4 * LH;      // gate columns
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
-  return v + __builtin_bit_cast(float, t);
-}
-// sum over the KS consecutive lanes of a k-slice group; every lane gets the total
-template <int KS>
-__device__ __forceinline__ float reduce_slices(float v) {
-  v = dpp_add<0xB1>(v);                  // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);                  // quad_perm [2,3,0,1]
-  if (KS == 8) v = dpp_add<0x141>(v);    // row_half_mirror
-  return v;
-}
-
-template <int GATE>
-__device__ __forceinline__ float gate_fn(float z) {
-  return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid(z) : sigmoidf_(z);
-}
-template <int GATE>
-__device__ __forceinline__ float gate_grad(float z, float y) {
-  return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid_grad(z) : y * (1.f - y);
-}
 
 template <int KS>
 struct Geo {
@@ -59,7 +33,6 @@ struct Geo {
   static constexpr int NT = NW * 64;                   // threads
   static constexpr int KK = LH / KS;                   // k values per slice (forward)
   static constexpr int KP = (KK + 3) / 4 * 4;          // padded slice length in LDS
-  static constexpr int CS = LG / KS;                   // gate columns per slice (backward)
 };
 
 struct LstmFwdArgs {
@@ -110,11 +83,11 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int T = a.T;
 
   // recurrent kernel slice -> registers
-  float Ur[KK][4];
+  f2 Ur[KK][2];               // gate pairs (i,f) and (c,o)
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Ur[kk][g] = a.U[(size_t)(KK * s + kk) * LG + g * LH + u];
+    for (int g = 0; g < 4; ++g) Ur[kk][g >> 1][g & 1] = a.U[(size_t)(KK * s + kk) * LG + g * LH + u];
 
   // per-lane share of xproj / rowbias: element e = s + KS*i -> (row e>>2, gate e&3)
   float rb[NX];
@@ -265,13 +238,13 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
       xcontrib(cur ^ 1);             // for step t+1, overlaps this step's recurrence
     }
     // acc[r][g] starts from the lane's xproj share, then KK FMAs per gate
-    float acc[R][4];
+    f2 acc2[R][2];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int e = r * 4 + g;              // compile-time
-        acc[r][g] = ((s == (e % KS) && xok[e / KS]) ? xv[e / KS] : 0.f) + (XIN ? xc[r][g] : 0.f);
+        acc2[r][g >> 1][g & 1] = ((s == (e % KS) && xok[e / KS]) ? xv[e / KS] : 0.f) + (XIN ? xc[r][g] : 0.f);
       }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -284,14 +257,21 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
       if (ABL == 3) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[r][g] += hv[g] * Ur[g][g];
+        for (int g = 0; g < 4; ++g) acc2[r][g >> 1][g & 1] += hv[g] * Ur[g][g >> 1][g & 1];
       } else {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[r][g] = fmaf(hv[kk], Ur[kk][g], acc[r][g]);
+        for (int kk = 0; kk < KK; ++kk) {
+          const f2 hh = {hv[kk], hv[kk]};
+          acc2[r][0] = __builtin_elementwise_fma(hh, Ur[kk][0], acc2[r][0]);
+          acc2[r][1] = __builtin_elementwise_fma(hh, Ur[kk][1], acc2[r][1]);
+        }
       }
     }
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[r][g] = acc2[r][g >> 1][g & 1];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -351,30 +331,44 @@ struct LstmBwdArgs {
   float* dzsum;         // [B,352]
 };
 
-template <int KS, int R, int GATE>
-__global__ __launch_bounds__(Geo<KS>::NT) void lstm_bwd_kernel(LstmBwdArgs a) {
-  using G = Geo<KS>;
-  constexpr int CS = G::CS;
-  constexpr int NC = KS / R;
-  __shared__ __attribute__((aligned(16))) float dzbuf[2][R][LG];
+// Thread layout of the backward kernel: lane = (unit group ug = lane / 16, column slice cs = lane % 16);
+// a thread keeps U[4*ug + j][22*cs .. 22*cs+21] for its 4 units j, so one dz value read from LDS feeds
+// 4 FMAs (two v_pk_fma_f32).  (One unit x 88 columns per thread -- the transpose of the forward layout --
+// needs one LDS float per FMA and is bound by the LDS return path: 22 ds_read_b128 per wave per step.)
+// The 16 slice partials of a unit are summed by a reduce-scatter: xor-1 and xor-2 exchanges that halve
+// the number of units a lane carries, then two row rotations over the 4 quads.  Afterwards lane
+// (ug, cs) owns unit 4*ug + (cs & 3), replicated over the 4 quads q = cs >> 2; as in the forward
+// kernel the replicas split the rows (R) and the output slots between them.
+constexpr int BW_NW = 6, BW_NT = BW_NW * 64;    // 24 unit groups (22 used)
+constexpr int BW_CW = 22, BW_CP = 24;           // columns per slice, padded slice stride in LDS (16-byte aligned)
+constexpr int BW_LDS = 16 * BW_CP;
+
+template <int R, int GATE>
+__global__ __launch_bounds__(BW_NT) void lstm_bwd_kernel(LstmBwdArgs a) {
+  constexpr int NC = 4 / R;
+  __shared__ __attribute__((aligned(16))) float dzbuf[2][R][BW_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s = lane % KS;
-  const int u = min(wave * G::UL + lane / KS, LH - 1);
+  const int cs = lane & 15, ug = wave * 4 + (lane >> 4);
+  const int q = cs >> 2;
+  const bool b0 = cs & 1, b1 = cs & 2;
+  const int u = min(4 * ug + (cs & 3), LH - 1);       // surplus unit groups duplicate unit 87 (same values, same addresses)
   const int row0 = blockIdx.x * R;
-  const int myrow = s % R, copy = s / R;
+  const int myrow = q % R, copy = q / R;
   const int T = a.T;
 
-  float Ur[CS];   // U[u][CS*s .. CS*s+CS-1]
-  {
-    const float4* up = reinterpret_cast<const float4*>(a.U + (size_t)u * LG + CS * s);
+  f2 Ur[BW_CW][2];    // [column][unit pair]
 #pragma unroll
-    for (int j = 0; j < CS / 4; ++j) {
-      float4 v = up[j];
-      Ur[4 * j] = v.x; Ur[4 * j + 1] = v.y; Ur[4 * j + 2] = v.z; Ur[4 * j + 3] = v.w;
+  for (int j = 0; j < 4; ++j) {
+    const float2* up = reinterpret_cast<const float2*>(a.U + (size_t)min(4 * ug + j, LH - 1) * LG + BW_CW * cs);
+#pragma unroll
+    for (int c = 0; c < BW_CW / 2; ++c) {
+      const float2 v = up[c];
+      Ur[2 * c][j >> 1][j & 1] = v.x;
+      Ur[2 * c + 1][j >> 1][j & 1] = v.y;
     }
   }
-  for (int i = tid; i < 2 * R * LG; i += G::NT) (&dzbuf[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * R * BW_LDS; i += BW_NT) (&dzbuf[0][0][0])[i] = 0.f;
 
   const size_t rowbt = (size_t)(row0 + myrow) * T;
   float dc = 0.f;
@@ -425,8 +419,13 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_bwd_kernel(LstmBwdArgs a) {
   a.dzsum[(size_t)(row0 + myrow) * LG + (copy & 3) * LH + u] = 0.f;
   constexpr int NSB = (4 + NC - 1) / NC;
   float* gptr[NSB];
+  int lpos[NSB];      // LDS position of gate column slot*88 + u in the sliced layout
 #pragma unroll
-  for (int j = 0; j < NSB; ++j) gptr[j] = a.gates + (rowbt + (T > 0 ? T - 1 : 0)) * LG + ((copy + j * NC) & 3) * LH + u;
+  for (int j = 0; j < NSB; ++j) {
+    const int col = ((copy + j * NC) & 3) * LH + u;
+    gptr[j] = a.gates + (rowbt + (T > 0 ? T - 1 : 0)) * LG + col;
+    lpos[j] = BW_CP * (col / BW_CW) + col % BW_CW;
+  }
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
@@ -434,25 +433,36 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_bwd_kernel(LstmBwdArgs a) {
     const Coef k = coef_next;
     const Raw rcur = raw_next;                     // values of step t-1 (loaded one iteration ago)
     raw_next = load_raw(max(t - 2, 0));            // lands during this whole iteration (redundant for t < 2)
-    // dh_rec[u] = sum_c dz_{t+1}[c] * U[u][c]
+    // partial dh_rec of this lane's 4 units over its 22 columns: sum_c dz_{t+1}[c] * U[u_j][c]
     float part[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][CS * s]);
-      float acc0 = 0.f, acc1 = 0.f;
+      const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][BW_CP * cs]);
+      float dv[BW_CP];
 #pragma unroll
-      for (int j = 0; j < CS / 4; ++j) {
-        float4 v = dp[j];
-        acc0 = fmaf(v.x, Ur[4 * j], acc0);
-        acc1 = fmaf(v.y, Ur[4 * j + 1], acc1);
-        acc0 = fmaf(v.z, Ur[4 * j + 2], acc0);
-        acc1 = fmaf(v.w, Ur[4 * j + 3], acc1);
+      for (int j = 0; j < BW_CP / 4; ++j) {
+        const float4 v = dp[j];
+        dv[4 * j] = v.x; dv[4 * j + 1] = v.y; dv[4 * j + 2] = v.z; dv[4 * j + 3] = v.w;
       }
-      part[r] = acc0 + acc1;
+      f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < BW_CW; ++c) {
+        const f2 dd = {dv[c], dv[c]};
+        acc01 = __builtin_elementwise_fma(dd, Ur[c][0], acc01);
+        acc23 = __builtin_elementwise_fma(dd, Ur[c][1], acc23);
+      }
+      // reduce-scatter over the 16 column slices
+      const float keep_a = b0 ? acc01[1] : acc01[0], send_a = b0 ? acc01[0] : acc01[1];
+      const float keep_b = b0 ? acc23[1] : acc23[0], send_b = b0 ? acc23[0] : acc23[1];
+      const float wa = keep_a + dpp_mov<0xB1>(send_a);          // units {0,1}[b0] over a lane pair
+      const float wb = keep_b + dpp_mov<0xB1>(send_b);          // units {2,3}[b0]
+      const float keep = b1 ? wb : wa, send = b1 ? wa : wb;
+      float x = keep + dpp_mov<0x4E>(send);                     // unit (cs & 3) over the quad
+      x = dpp_add<0x124>(x);                                    // row_ror:4  -> two quads
+      x = dpp_add<0x128>(x);                                    // row_ror:8  -> all four quads
+      part[r] = x;
     }
     coef_next = make_coef(rcur);                   // off the critical path (unused after t == 0)
-#pragma unroll
-    for (int r = 0; r < R; ++r) part[r] = reduce_slices<KS>(part[r]);
     float dhrec = part[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) dhrec = (myrow == r) ? part[r] : dhrec;
@@ -467,14 +477,14 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_bwd_kernel(LstmBwdArgs a) {
     dc = dc * k.kcarry;
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) zs[gi] += dz[gi];
-    // 4 values per (row, unit) shared among NC copies; copies beyond the 4th repeat (unconditional stores)
+    // 4 values per (row, unit) shared among NC copies (unconditional stores)
 #pragma unroll
     for (int j = 0; j < NSB; ++j) {
       const int slot = (copy + j * NC) & 3;
       float val = dz[0];
 #pragma unroll
-      for (int q = 1; q < 4; ++q) val = (slot == q) ? dz[q] : val;
-      dzbuf[cur ^ 1][myrow][slot * LH + u] = val;
+      for (int qq = 1; qq < 4; ++qq) val = (slot == qq) ? dz[qq] : val;
+      dzbuf[cur ^ 1][myrow][lpos[j]] = val;
       *gptr[j] = val;
       gptr[j] -= LG;
     }
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_bwd_kernel(LstmBwdArgs a) {
     const int slot = (copy + j * NC) & 3;
     float val = zs[0];
 #pragma unroll
-    for (int q = 1; q < 4; ++q) val = (slot == q) ? zs[q] : val;
+    for (int qq = 1; qq < 4; ++qq) val = (slot == qq) ? zs[qq] : val;
     a.dzsum[(size_t)(row0 + myrow) * LG + slot * LH + u] = val;
   }
 }
@@ -530,13 +540,12 @@ static int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
   if (R == 2) return launch_fwd_r<KS, 2, GATE, SAVE>(a, s);
   return launch_fwd_r<KS, 1, GATE, SAVE>(a, s);
 }
-template <int KS, int GATE>
+template <int GATE>
 static int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
   const int B = a.B, R = rows_per_wg(B);
-  constexpr int NT = Geo<KS>::NT;
-  if (R == 4) hipLaunchKernelGGL((lstm_bwd_kernel<KS, 4, GATE>), dim3(B / 4), dim3(NT), 0, s, a);
-  else if (R == 2) hipLaunchKernelGGL((lstm_bwd_kernel<KS, 2, GATE>), dim3(B / 2), dim3(NT), 0, s, a);
-  else hipLaunchKernelGGL((lstm_bwd_kernel<KS, 1, GATE>), dim3(B), dim3(NT), 0, s, a);
+  if (R == 4) hipLaunchKernelGGL((lstm_bwd_kernel<4, GATE>), dim3(B / 4), dim3(BW_NT), 0, s, a);
+  else if (R == 2) hipLaunchKernelGGL((lstm_bwd_kernel<2, GATE>), dim3(B / 2), dim3(BW_NT), 0, s, a);
+  else hipLaunchKernelGGL((lstm_bwd_kernel<1, GATE>), dim3(B), dim3(BW_NT), 0, s, a);
   return launch_status();
 }
 
@@ -594,6 +603,5 @@ extern "C" int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_seq_bwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
-  if (lstm_ks() == 8) return hard ? launch_bwd<8, CLV_GATE_HARD_SIGMOID>(a, s) : launch_bwd<8, CLV_GATE_SIGMOID>(a, s);
-  return hard ? launch_bwd<4, CLV_GATE_HARD_SIGMOID>(a, s) : launch_bwd<4, CLV_GATE_SIGMOID>(a, s);
+  return hard ? launch_bwd<CLV_GATE_HARD_SIGMOID>(a, s) : launch_bwd<CLV_GATE_SIGMOID>(a, s);
 }

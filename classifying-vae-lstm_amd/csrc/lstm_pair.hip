@@ -1,0 +1,337 @@
+// lstm_pair.hip -- the encoder and the decoder LSTM of cl_vrnn as ONE persistent kernel per pass (gfx950).
+//
+// At the reference's batch sizes a sequence kernel (lstm.hip) is one serial latency chain per step
+// (LDS read -> 22 dependent FMAs -> lane reduce -> gate math -> LDS write -> barrier): neither the VALU
+// nor the LDS is busy, so two chains that run on the SAME CU in different waves cost little more than
+// one.  The decoder step t needs only z_t, i.e. the encoder's h_t, so the two recurrences are skewed
+// by two steps and run side by side: a workgroup owns one batch row, waves 0-5 carry the encoder
+// chain and waves 6-11 the decoder chain (3 waves per SIMD, <= 168 VGPRs each), one s_barrier per
+// step for both.
+//
+// The latent head between them (cl_vrnn/model.py:200-216: Z_mean/Z_log_var Dense, z = mean +
+// exp(log_var/2) eps, KL term) rides in the encoder's last wave: its 8 surplus lane groups (units
+// 88..95 do not exist) hold columns of the fused head kernel instead of recurrent-kernel columns, so
+// zargs_{t-1} = h_{t-1}.Wz falls out of the same FMA sequence that computes the gates of step t.
+// Group j carries (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1): latent_dim <= 16.
+// The decoder adds z_t . K_z (the z rows of its input kernel) to its input projection itself, so
+// the projection GEMM only covers the history frames x_{t-1}.
+#include "lstm_common.h"
+
+namespace clv {
+
+constexpr int PK = 4;                   // k-slices per unit
+constexpr int PKK = LH / PK;            // 22 k values per slice
+constexpr int PKP = 24;                 // padded slice stride in LDS (16-byte aligned)
+constexpr int PNW = 6;                  // waves per chain (16 units each)
+constexpr int PNT = 2 * PNW * 64;       // 768 threads
+constexpr int PLMAX = 16;               // latent dims the surplus groups can carry
+constexpr int PLQ = PLMAX / PK;         // latents per decoder lane (z_t . K_z is split over the k-slice lanes)
+
+__device__ float g_pair_dump[128];      // target of the stores of lanes that own no output (keeps every store unconditional)
+
+struct PairFwdArgs {
+  int B, T, L, ldz;
+  const float* xproj_e;   // [B,T,352] x_t.K_x      (same buffer as gates_e)
+  const float* rb_e;      // [B,352]   W.K_w + bias
+  const float* U_e;       // [88,352]
+  const float* xproj_d;   // [B,T,352] x_{t-1}.K_x  (same buffer as gates_d) or unused
+  const float* rb_d;
+  const float* U_d;
+  const float* Kz;        // [L,352]   z rows of the decoder input kernel
+  const float* Wz;        // [88,2L]   [Z_mean | Z_log_var] kernel
+  const float* bz;        // [2L]
+  const float* eps;       // [B,T,L]
+  float *hs_e, *cs_e, *gates_e, *hs_d, *cs_d, *gates_d;
+  float* zargs;           // [B*T,2L]
+  float* Z;               // [B*T] rows of stride ldz
+  float* klterm;          // [B*T,L]  L * KL_l: the mean over all entries is the per-frame KL
+};
+
+__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// h (LDS, sliced layout) . U slice -> the 4 gate sums of this lane's unit, reduced over the k-slices
+__device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)[PKK][2], f2 (&acc2)[2]) {
+  const float4* hp = reinterpret_cast<const float4*>(hslice);
+  float hv[PKP];
+#pragma unroll
+  for (int q = 0; q < PKP / 4; ++q) {
+    const float4 v = hp[q];
+    hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+  }
+#ifdef CLV_PAIR_PK
+#pragma unroll
+  for (int kk = 0; kk < PKK; ++kk) {
+    const f2 hh = {hv[kk], hv[kk]};
+    acc2[0] = __builtin_elementwise_fma(hh, Ur[kk][0], acc2[0]);
+    acc2[1] = __builtin_elementwise_fma(hh, Ur[kk][1], acc2[1]);
+  }
+#else
+  float a0 = acc2[0][0], a1 = acc2[0][1], a2 = acc2[1][0], a3 = acc2[1][1];
+#pragma unroll
+  for (int kk = 0; kk < PKK; ++kk) {
+    a0 = fmaf(hv[kk], Ur[kk][0][0], a0);
+    a1 = fmaf(hv[kk], Ur[kk][0][1], a1);
+    a2 = fmaf(hv[kk], Ur[kk][1][0], a2);
+    a3 = fmaf(hv[kk], Ur[kk][1][1], a3);
+  }
+  acc2[0][0] = a0; acc2[0][1] = a1; acc2[1][0] = a2; acc2[1][1] = a3;
+#endif
+}
+
+template <int GATE>
+__device__ __forceinline__ void lstm_cell(const float (&z)[4], float& c, float& h, float& gg) {
+  const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);
+  gg = fast_tanh(z[2]);
+  c = fg * c + ig * gg;
+  h = og * fast_tanh(c);
+}
+
+// output slots of a regular lane: 6 values per unit (h, c, z_i, z_f, g, z_o) over the 4 slice lanes, 2 stores each
+__device__ __forceinline__ void regular_slots(int s, int u, size_t bt0, float* hs, float* cs, float* gates,
+                                              float* (&optr)[2], int (&ostr)[2], int (&oslot)[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int slot = s + 4 * j;
+    slot = slot < 6 ? slot : slot - 6;                   // lanes 2,3 repeat h and c (same value, same address)
+    oslot[j] = slot;
+    optr[j] = slot == 0 ? hs + bt0 * LH + u : slot == 1 ? cs + bt0 * LH + u : gates + bt0 * LG + (slot - 2) * LH + u;
+    ostr[j] = slot < 2 ? LH : LG;
+  }
+}
+__device__ __forceinline__ float pick_slot(int slot, float h, float c, const float (&z)[4], float gg) {
+  float v = h;
+  v = slot == 1 ? c : v;
+  v = slot == 2 ? z[0] : v;
+  v = slot == 3 ? z[1] : v;
+  v = slot == 4 ? gg : v;
+  v = slot == 5 ? z[3] : v;
+  return v;
+}
+
+__device__ __forceinline__ float pick4(int i, const float (&v)[4]) {
+  float r = v[0];
+  r = i == 1 ? v[1] : r;
+  r = i == 2 ? v[2] : r;
+  r = i == 3 ? v[3] : r;
+  return r;
+}
+
+template <int GATE>
+__device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP],
+                                                 float (*zbuf)[PLMAX]) {
+  const int s = lane & 3, b = blockIdx.x, T = a.T, L = a.L;
+  const int u_raw = wave * 16 + (lane >> 2);
+  const int u = min(u_raw, LH - 1);          // surplus groups that carry no latent duplicate unit 87
+  const int zj = u_raw - LH;
+  const bool is_z = zj >= 0 && 2 * zj < L;
+  const int lat = 2 * zj + (s & 1);          // the latent this lane finishes
+  const bool lat_ok = is_z && lat < L;
+  const int zpos = (lat % PK) * PLQ + lat / PK;      // decoder lane s reads the latents s, s+4, .. as one 16-byte LDS word
+  // head column held in accumulator g of a latent group: (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)
+  auto zcol = [&](int g) { const int l = 2 * zj + (g & 1); return l < L ? (g >> 1) * L + l : -1; };
+
+  f2 Ur[PKK][2];
+#pragma unroll
+  for (int kk = 0; kk < PKK; ++kk)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // one unconditional load per element (a divergent branch here would serialise 88 L2 round trips)
+      const int cix = zcol(g);
+      const float* src = is_z ? a.Wz + (size_t)(PKK * s + kk) * 2 * L + max(cix, 0)
+                              : a.U_e + (size_t)(PKK * s + kk) * LG + g * LH + u;
+      const float v = *src;
+      Ur[kk][g >> 1][g & 1] = (is_z && cix < 0) ? 0.f : v;
+    }
+  const size_t bt0 = (size_t)b * T;
+  const float* xp = a.xproj_e + bt0 * LG + s * LH + u;
+  float rb, xmask;
+  {
+    const float* src = is_z ? a.bz + max(zcol(s), 0) : a.rb_e + (size_t)b * LG + s * LH + u;
+    rb = *src;
+    rb = (is_z && !lat_ok) ? 0.f : rb;
+    xmask = is_z ? 0.f : 1.f;
+  }
+  const float* ep = a.eps + bt0 * L + (lat_ok ? lat : 0);
+
+  float* optr[2];
+  int ostr[2], oslot[2];
+  regular_slots(s, u, bt0, a.hs_e, a.cs_e, a.gates_e, optr, ostr, oslot);
+  if (is_z) {     // store 0: head pre-activation column; store 1: z (lanes 0,1) or the KL term (lanes 2,3)
+    optr[0] = lat_ok ? a.zargs + bt0 * 2 * L + zcol(s) : g_pair_dump + lane;
+    ostr[0] = lat_ok ? 2 * L : 0;
+    optr[1] = !lat_ok ? g_pair_dump + lane : (s < 2 ? a.Z + bt0 * a.ldz + lat : a.klterm + bt0 * L + lat);
+    ostr[1] = !lat_ok ? 0 : (s < 2 ? a.ldz : L);
+  }
+  const int hslot = PKP * (u / PKK) + (u % PKK);
+  const float klscale = -0.5f * (float)L;
+
+  float c = 0.f;
+  float xn = xp[0];
+  float en = 0.f;
+  // two stores after the prologue's loads, like every iteration issues after its loads: the loop-entry and
+  // back-edge memory queues then match and the wait for `xn` stays a counted vmcnt (see lstm.hip)
+  g_pair_dump[lane] = 0.f;
+  g_pair_dump[lane + 64] = 0.f;
+  auto latent = [&](const float (&acc)[4], float e, float& zv, float& klv) {
+    const float m = (s & 1) ? acc[1] : acc[0], lv = (s & 1) ? acc[3] : acc[2];
+    const float sd = __expf(0.5f * lv);
+    zv = fmaf(sd, e, m);
+    klv = klscale * (1.f + lv - m * m - sd * sd);
+  };
+
+  for (int i = 0; i < T; ++i) {
+    const int cur = i & 1;
+    const float xv = fmaf(xn, xmask, rb);
+    xn = xp[(size_t)min(i + 1, T - 1) * LG];            // prefetch, unconditional (clamped)
+    const float ecur = en;                              // eps of step i-1
+    en = ep[(size_t)i * L];
+    f2 acc2[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? xv : 0.f;
+    slice_matvec(&hb[cur][PKP * s], Ur, acc2);
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
+    float h, gg;
+    lstm_cell<GATE>(z, c, h, gg);
+    float v0 = pick_slot(oslot[0], h, c, z, gg), v1 = pick_slot(oslot[1], h, c, z, gg);
+    if (wave == PNW - 1) {          // wave-uniform: the latent head of step i-1 (garbage at i == 0, rewritten at i == 1)
+      float zv, klv;
+      latent(z, ecur, zv, klv);
+      v0 = is_z ? pick4(s, z) : v0;
+      v1 = is_z ? (s < 2 ? zv : klv) : v1;
+      if (lat_ok && s < 2) zbuf[(i + 1) & 1][zpos] = zv;
+    }
+    if (!is_z) hb[cur ^ 1][hslot] = h;
+    *optr[0] = v0;
+    *optr[1] = v1;
+    const bool hold = is_z && i == 0;                   // the head lags one step: its row pointer starts moving at i == 1
+    optr[0] += hold ? 0 : ostr[0];
+    optr[1] += hold ? 0 : ostr[1];
+    step_barrier();
+  }
+  // iteration T: only the latent head of step T-1 is left
+  if (wave == PNW - 1) {
+    f2 acc2[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? rb : 0.f;
+    slice_matvec(&hb[T & 1][PKP * s], Ur, acc2);
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
+    float zv, klv;
+    latent(z, en, zv, klv);
+    if (lat_ok) {
+      *optr[0] = pick4(s, z);
+      *optr[1] = s < 2 ? zv : klv;
+      if (s < 2) zbuf[(T + 1) & 1][zpos] = zv;
+    }
+  }
+  step_barrier();
+  step_barrier();
+}
+
+template <int GATE, bool HASXP>
+__device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP],
+                                                 float (*zbuf)[PLMAX]) {
+  const int s = lane & 3, b = blockIdx.x, T = a.T, L = a.L;
+  const int u = min(wave * 16 + (lane >> 2), LH - 1);
+  f2 Ur[PKK][2];
+#pragma unroll
+  for (int kk = 0; kk < PKK; ++kk)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Ur[kk][g >> 1][g & 1] = a.U_d[(size_t)(PKK * s + kk) * LG + g * LH + u];
+  f2 Kzr[PLQ][2];        // lane s takes the latents s, s+4, ...
+#pragma unroll
+  for (int q = 0; q < PLQ; ++q)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int l = s + PK * q;
+      const float v = a.Kz[(size_t)min(l, L - 1) * LG + g * LH + u];
+      Kzr[q][g >> 1][g & 1] = l < L ? v : 0.f;
+    }
+  const size_t bt0 = (size_t)b * T;
+  const float* xp = a.xproj_d + bt0 * LG + s * LH + u;
+  const float rb = a.rb_d[(size_t)b * LG + s * LH + u];
+  float* optr[2];
+  int ostr[2], oslot[2];
+  regular_slots(s, u, bt0, a.hs_d, a.cs_d, a.gates_d, optr, ostr, oslot);
+  const int hslot = PKP * (u / PKK) + (u % PKK);
+  float c = 0.f;
+  float xn = HASXP ? xp[0] : 0.f;
+  g_pair_dump[lane] = 0.f;     // see the encoder
+  g_pair_dump[lane + 64] = 0.f;
+  step_barrier();          // the encoder is two steps ahead
+  step_barrier();
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    const float xv = xn + rb;
+    if (HASXP) xn = xp[(size_t)min(t + 1, T - 1) * LG];
+    f2 acc2[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? xv : 0.f;
+    {   // z_t . K_z: branch-free (rows of K_z beyond latent_dim are zero registers); does not depend on h
+      const float4 zq = *reinterpret_cast<const float4*>(&zbuf[cur][PLQ * s]);
+      const float zl[PLQ] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+      for (int q = 0; q < PLQ; ++q) {
+        const f2 zz = {zl[q], zl[q]};
+        acc2[0] = __builtin_elementwise_fma(zz, Kzr[q][0], acc2[0]);
+        acc2[1] = __builtin_elementwise_fma(zz, Kzr[q][1], acc2[1]);
+      }
+    }
+    slice_matvec(&hb[cur][PKP * s], Ur, acc2);
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
+    float h, gg;
+    lstm_cell<GATE>(z, c, h, gg);
+    hb[cur ^ 1][hslot] = h;
+    *optr[0] = pick_slot(oslot[0], h, c, z, gg);
+    *optr[1] = pick_slot(oslot[1], h, c, z, gg);
+    optr[0] += ostr[0];
+    optr[1] += ostr[1];
+    step_barrier();
+  }
+}
+
+template <int GATE, bool HASXP>
+__global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][2][PK * PKP];      // [chain][parity][sliced h]
+  __shared__ __attribute__((aligned(16))) float zbuf[2][PLMAX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 2 * 2 * PK * PKP; i += PNT) (&hbuf[0][0][0])[i] = 0.f;
+  if (tid < 2 * PLMAX) (&zbuf[0][0])[tid] = 0.f;
+  __syncthreads();
+  if (wave < PNW) pair_fwd_encoder<GATE>(a, wave, lane, hbuf[0], zbuf);
+  else pair_fwd_decoder<GATE, HASXP>(a, wave - PNW, lane, hbuf[1], zbuf);
+}
+
+}  // namespace clv
+
+extern "C" int clv_lstm_pair_supported(int H, int L) { return H == clv::LH && L >= 1 && L <= clv::PLMAX; }
+
+extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
+                                 float* gates_enc, const float* rowbias_enc, const float* U_enc,
+                                 float* gates_dec, int dec_has_xproj, const float* rowbias_dec, const float* U_dec,
+                                 const float* Kz, const float* Wz, const float* bz, const float* eps,
+                                 float* hs_enc, float* cs_enc, float* hs_dec, float* cs_dec,
+                                 float* zargs, float* Z, int ldz, float* klterm, void* stream) {
+  using namespace clv;
+  if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0 || ldz < L) return CLV_EINVAL;
+  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  if (!gates_enc || !rowbias_enc || !U_enc || !gates_dec || !rowbias_dec || !U_dec || !Kz || !Wz || !bz || !eps ||
+      !hs_enc || !cs_enc || !hs_dec || !cs_dec || !zargs || !Z || !klterm)
+    return CLV_EINVAL;
+  PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, U_enc, gates_dec, rowbias_dec, U_dec, Kz, Wz, bz, eps,
+                hs_enc, cs_enc, gates_enc, hs_dec, cs_dec, gates_dec, zargs, Z, klterm};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("lstm_pair_fwd", s);
+  const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
+#define PAIR_FWD(G, X) hipLaunchKernelGGL((lstm_pair_fwd_kernel<G, X>), dim3(B), dim3(PNT), 0, s, a)
+  if (hard) { if (dec_has_xproj) PAIR_FWD(CLV_GATE_HARD_SIGMOID, true); else PAIR_FWD(CLV_GATE_HARD_SIGMOID, false); }
+  else { if (dec_has_xproj) PAIR_FWD(CLV_GATE_SIGMOID, true); else PAIR_FWD(CLV_GATE_SIGMOID, false); }
+#undef PAIR_FWD
+  return launch_status();
+}

@@ -233,6 +233,27 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int N, int chunks, co
     out[col] = (beta != 0.f ? beta * out[col] : 0.f) + ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
+// few rows (a batch of row vectors): one launch, 64 columns x 16 row-lanes per block
+__global__ __launch_bounds__(1024) void colsum_small_kernel(int M, int N, const float* X, int ldx, float beta, float* out) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < N) {
+    int r = ry;
+    for (; r + 16 < M; r += 32) { a0 += X[(size_t)r * ldx + col]; a1 += X[(size_t)(r + 16) * ldx + col]; }
+    if (r < M) a0 += X[(size_t)r * ldx + col];
+  }
+  red[ry][cx] = a0 + a1;
+  __syncthreads();
+  if (ry == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cx];
+    out[col] = (beta != 0.f ? beta * out[col] : 0.f) + t;
+  }
+}
+
 __global__ void axpy_kernel(int64_t n, float alpha, const float* x, float* y) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] += alpha * x[i];
@@ -343,6 +364,10 @@ extern "C" int clv_colsum_f32(int M, int N, const float* X, int ldx, float beta,
   if (!ws || ws_bytes < (size_t)chunks * N * sizeof(float)) return CLV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("colsum", s);
+  if (M <= 1024) {
+    hipLaunchKernelGGL(colsum_small_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, M, N, X, ldx, beta, out);
+    return launch_status();
+  }
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, s, M, N, X, ldx, (float*)ws);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, N, chunks, (const float*)ws, beta, out);
   return launch_status();

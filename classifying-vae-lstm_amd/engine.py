@@ -178,6 +178,7 @@ class _EngineBase:
         self.P = FlatParams(shapes, self.device, phys, aliases)
         self.ws = ops.Workspace(self.device, 8 << 20)
         self.ws2 = ops.Workspace(self.device, 8 << 20)        # scratch of the side stream
+        self.rq = ops.ReduceQueue(self.device)                # split-K reductions of the weight gradients, one launch per pass
         self.side = torch.cuda.Stream(device=self.device) if cfg.get('two_streams', False) else None
         self.scal = torch.zeros(8, dtype=torch.float32, device=self.device)   # vae, kl_z, kl_w, w_rec, acc
         # loss weights may be annealed per epoch (utils/model_utils.py:19-50)
@@ -382,6 +383,8 @@ class VrnnEngine(_EngineBase):
             else _lib.GATE_SIGMOID
         self.off = D if cfg['use_x_prev'] else 0     # decoder kernel rows: [Xp | Z | W]
         self.fuse_xproj = bool(cfg.get('fuse_xproj', False))   # break-even vs the projection GEMM at config 3
+        # encoder + latent head + decoder as one launch (csrc/lstm_pair.hip); latent_dim <= 16
+        self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj
         self.hW = _f(d, B, D)
         self.wargs = _f(d, B, 2 * (Cn - 1))
         self.W = _f(d, B, Cn)
@@ -400,6 +403,7 @@ class VrnnEngine(_EngineBase):
         self.XZ = torch.zeros(BT, self.xz_ld, dtype=torch.float32, device=d)
         self.Z = self.XZ[:, self.off:self.off + L]
         self.rowkl = _f(d, BT)
+        self.klterm = _f(d, BT, L)                  # fused pair kernel: L * KL_l per latent (mean over all = per-frame KL)
         self.logits = _f(d, BT, D)
         self.dlogits = _f(d, BT, D)
         self.rownll = _f(d, BT)
@@ -418,6 +422,8 @@ class VrnnEngine(_EngineBase):
         g, ws = ops.gemm, self.ws
         if cfg['use_x_prev'] and Xp.data_ptr() != self.XZ.data_ptr():
             self.XZ.view(B, T, self.xz_ld)[:, :, :D].copy_(Xp.view(B, T, D))     # staging copy only
+        if self.fuse_pair:
+            return self._forward_pair(X, eps_W, eps_Z, w_true)
         fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
         fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)
         if not fuse_enc:      # dense input projection as a GEMM (inputs too wide for the LDS-resident form)
@@ -452,6 +458,27 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
                              self.cs_dec, self.gates_dec, gate_act=self.gate_act)
         # output head (:229-234)
+        g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
+
+    def _forward_pair(self, X, eps_W, eps_Z, w_true):
+        """Forward with both LSTMs, the latent head and the z projection in one persistent kernel."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
+        BT, G4, off = B * T, 4 * H, self.off
+        g, ws = ops.gemm, self.ws
+        g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
+        if off:        # history frames only: z_t . K_z is added inside the sequence kernel
+            g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
+        g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
+        ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true,
+                           cfg['w_log_var_prior'], P.rows(P.params, 'encoder_h/kernel', D), P.p('encoder_h/bias'),
+                           P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
+                           self.wargs, self.W, self.rowloss, self.wk_enc, self.wk_dec)
+        ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'),
+                          self.gates_dec, off > 0, self.wk_dec, P.p('decoder_h/recurrent_kernel'),
+                          P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z,
+                          self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z, self.xz_ld,
+                          self.klterm, gate_act=self.gate_act)
         g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
 
     def xp_view(self):
@@ -564,17 +591,25 @@ class VrnnEngine(_EngineBase):
         cfg, P, B = self.cfg, self.P, self.B
         H, T, Cn = cfg['H'], cfg['T'], cfg['C']
         BT, G4 = B * T, 4 * H
+        rq = self._rq()
         ops.gemm_grouped_tn([dict(A=X_in, lda=x_ld, M=x_rows, C=P.g(name + '/kernel')),
                              dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)],
-                            G4, BT, dz, ws)
+                            G4, BT, dz, ws, defer=rq)
         ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
-                             dict(A=None, M=1, C=P.g(name + '/bias'), ones=True)], G4, B, dzsum, ws)
+                             dict(A=None, M=1, C=P.g(name + '/bias'), ones=True)], G4, B, dzsum, ws, defer=rq)
 
     def grads_tail(self, X):
         """hW kernel gradient: the last and largest (T*D*D floats) product of the backward pass."""
         cfg, P, B = self.cfg, self.P, self.B
         D, T = cfg['D'], cfg['T']
-        ops.gemm(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=self.ws)
+        rq = self._rq()
+        ops.gemm(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=self.ws, defer=rq)
+        if rq is not None:
+            rq.flush()
+
+    def _rq(self):
+        """The deferred-reduction queue (single-stream schedule only: a pending job pins its scratch buffer)."""
+        return self.rq if self.side is None else None
 
     def tail_range(self):
         """(offset, numel) of the tail bucket inside the flat gradient buffer."""
@@ -589,16 +624,19 @@ class VrnnEngine(_EngineBase):
         g, ws, off = ops.gemm, self.ws, self.off
         self.forward(X, Xp, eps_W, eps_Z, w_true)
         ops.bernoulli_nll(BT, D, self.logits, X, D, inv_bt, self.rownll, self.dlogits if need_grads else None)
-        ops.loss_sums([(self.rownll, BT, 1), (self.rowkl, BT, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
+        kl = (self.klterm, BT * L, 1) if self.fuse_pair else (self.rowkl, BT, 1)
+        ops.loss_sums([(self.rownll, BT, 1), kl, (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
                        (self.rowloss[:, 2:], B, 3)], self.scal)
         if not need_grads:
             self._join()
             return
         ws2 = self.ws2 if self.side is not None else self.ws
         # output head: its weight gradient runs on the side stream under the decoder BPTT
-        with self._side():
-            g(self.hs_dec, self.dlogits, P.g('X_decoded_mean/kernel'), H, D, BT, ta=True, ws=ws2)
-            ops.colsum(self.dlogits, BT, D, P.g('X_decoded_mean/bias'), ws2)
+        rq = self._rq()
+        with self._side():        # kernel and bias gradient in one pass over dlogits (bias = an implicit row of ones)
+            ops.gemm_grouped_tn([dict(A=self.hs_dec, lda=H, M=H, C=P.g('X_decoded_mean/kernel')),
+                                 dict(A=None, M=1, C=P.g('X_decoded_mean/bias'), ones=True)], D, BT, self.dlogits, ws2,
+                                defer=rq)
         g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
         # decoder BPTT (VALU) ...
         ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
@@ -612,8 +650,8 @@ class VrnnEngine(_EngineBase):
         ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
         g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
         with self._side():
-            g(self.hs_enc, self.dzargs, P.g('Zargs/kernel'), H, 2 * L, BT, ta=True, ws=ws2)
-            ops.colsum(self.dzargs, BT, 2 * L, P.g('Zargs/bias'), ws2)
+            ops.gemm_grouped_tn([dict(A=self.hs_enc, lda=H, M=H, C=P.g('Zargs/kernel')),
+                                 dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws2, defer=rq)
         # encoder BPTT
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                          self.dzsum_enc, gate_act=self.gate_act)
@@ -627,8 +665,10 @@ class VrnnEngine(_EngineBase):
                            P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
                            self.dwargs, self.dhW)
         ops.gemm_grouped_tn([dict(A=self.hW, lda=D, M=D, C=P.g('Wargs/kernel')),
-                             dict(A=None, M=1, C=P.g('Wargs/bias'), ones=True)], 2 * C1, B, self.dwargs, ws)
+                             dict(A=None, M=1, C=P.g('Wargs/bias'), ones=True)], 2 * C1, B, self.dwargs, ws, defer=rq)
         ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
         self._join()
+        if rq is not None:
+            rq.flush()
         if do_tail:
             self.grads_tail(X)

@@ -33,25 +33,60 @@ class Workspace:
         return self.buf
 
 
+class ReduceQueue:
+    """Pending split-K reductions of one backward pass (clv_*_deferred + clv_splitk_reduce_multi).
+    Every queued product keeps its partial slabs in its own scratch buffer until flush(); the buffers are
+    kept per queue slot, so a step that queues the same products in the same order reuses the same memory
+    (and a captured hipGraph sees fixed pointers)."""
+    MAX_JOBS = 16
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = (_lib.ReduceJob * self.MAX_JOBS)()
+        self.slots = [None] * self.MAX_JOBS
+        self.n = 0
+
+    def scratch(self, nbytes):
+        if self.n >= self.MAX_JOBS:
+            raise _lib.ClvError("ReduceQueue: more than %d pending reductions" % self.MAX_JOBS)
+        buf = self.slots[self.n]
+        if buf is None or buf.numel() < nbytes:
+            buf = self.slots[self.n] = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def next_job(self):
+        j = C.byref(self.jobs, self.n * C.sizeof(_lib.ReduceJob))
+        self.n += 1
+        return j
+
+    def flush(self):
+        if self.n:
+            check(_lib.lib().clv_splitk_reduce_multi(self.jobs, self.n, _stream()), "clv_splitk_reduce_multi")
+        self.n = 0
+
+
 def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None, alpha=1.0, beta=0.0,
-         bias=None, act=ACT_NONE, aux=None, split_k=None, ws=None):
-    """C[M,N] = act(alpha*op(A).op(B) + bias + beta*C); A/B/C are tensors (possibly offset views)."""
+         bias=None, act=ACT_NONE, aux=None, split_k=None, ws=None, defer=None):
+    """C[M,N] = act(alpha*op(A).op(B) + bias + beta*C); A/B/C are tensors (possibly offset views).
+    defer: a ReduceQueue -- a split product leaves its reduction (and epilogue) pending until defer.flush()."""
     L = _lib.lib()
     lda = lda if lda is not None else (M if ta else K)
     ldb = ldb if ldb is not None else (K if tb else N)
     ldc = ldc if ldc is not None else N
     if split_k is None:
         split_k = L.clv_gemm_auto_split(M, N, K)
-    wsp, wsb = None, 0
+    wsp, wsb, job = None, 0, None
     if split_k > 1:
         need = L.clv_gemm_workspace_bytes(M, N, split_k)
-        buf = ws.ensure(need)
+        buf = defer.scratch(need) if defer is not None else ws.ensure(need)
         wsp, wsb = _ptr(buf), buf.numel()
-    check(L.clv_gemm_f32(int(ta), int(tb), M, N, K, float(alpha), _ptr(A), lda, _ptr(B), ldb, float(beta),
-                         _ptr(C_out), ldc, _ptr(bias), act, _ptr(aux), split_k, wsp, wsb, _stream()), "clv_gemm_f32")
+        job = defer.next_job() if defer is not None else None
+    check(L.clv_gemm_f32_deferred(int(ta), int(tb), M, N, K, float(alpha), _ptr(A), lda, _ptr(B), ldb, float(beta),
+                                  _ptr(C_out), ldc, _ptr(bias), act, _ptr(aux), split_k, wsp, wsb, job, _stream()),
+          "clv_gemm_f32")
 
 
-def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None):
+def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=None):
     """probs: list of dict(A=tensor|None, lda, M, C=tensor, ldc, shift=0, zero_period=0, ones=False);
     C_p[M_p,N] = A_p^T . B for every problem in one launch (all share B [K,N])."""
     L = _lib.lib()
@@ -64,12 +99,14 @@ def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None):
     n = len(probs)
     if split_k is None:
         split_k = L.clv_gemm_grouped_auto_split(arr, n, N, K)
-    wsp, wsb = None, 0
+    wsp, wsb, job = None, 0, None
     if split_k > 1:
-        buf = ws.ensure(L.clv_gemm_grouped_workspace_bytes(arr, n, N, split_k))
+        need = L.clv_gemm_grouped_workspace_bytes(arr, n, N, split_k)
+        buf = defer.scratch(need) if defer is not None else ws.ensure(need)
         wsp, wsb = _ptr(buf), buf.numel()
-    check(L.clv_gemm_grouped_tn(arr, n, N, K, _ptr(B), ldb if ldb is not None else N, float(beta), split_k, wsp, wsb,
-                                _stream()), "clv_gemm_grouped_tn")
+        job = defer.next_job() if defer is not None else None
+    check(L.clv_gemm_grouped_tn_deferred(arr, n, N, K, _ptr(B), ldb if ldb is not None else N, float(beta), split_k,
+                                         wsp, wsb, job, _stream()), "clv_gemm_grouped_tn")
 
 
 def loss_sums(terms, out):
@@ -107,6 +144,18 @@ def lstm_seq_fwd_x(B, T, xin, ldx, nx, Kin, rowbias, U, hs, cs, gates, h0=None, 
 def lstm_seq_bwd(B, T, U, dhs, cs, gates_inout, dzsum, c0=None, gate_act=0, H=88):
     check(_lib.lib().clv_lstm_seq_bwd(B, T, H, gate_act, _ptr(U), _ptr(dhs), _ptr(cs), _ptr(c0), _ptr(gates_inout),
                                       _ptr(dzsum), _stream()), "clv_lstm_seq_bwd")
+
+
+def lstm_pair_supported(L, H=88):
+    return bool(_lib.lib().clv_lstm_pair_supported(H, L))
+
+
+def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, U_enc, gates_dec, dec_has_xproj, rb_dec, U_dec, Kz, Wz, bz, eps,
+                  hs_enc, cs_enc, hs_dec, cs_dec, zargs, Z, ldz, klterm, gate_act=0, H=88):
+    check(_lib.lib().clv_lstm_pair_fwd(B, T, H, L, gate_act, _ptr(gates_enc), _ptr(rb_enc), _ptr(U_enc), _ptr(gates_dec),
+                                       int(bool(dec_has_xproj)), _ptr(rb_dec), _ptr(U_dec), _ptr(Kz), _ptr(Wz), _ptr(bz),
+                                       _ptr(eps), _ptr(hs_enc), _ptr(cs_enc), _ptr(hs_dec), _ptr(cs_dec), _ptr(zargs),
+                                       _ptr(Z), ldz, _ptr(klterm), _stream()), "clv_lstm_pair_fwd")
 
 
 def label_fwd(B, Cn, mean, logvar, ld_in, eps, onehot, prior, w, rowloss):

@@ -85,6 +85,24 @@ int clv_gemm_grouped_tn(const clv_gemm_prob* host_probs, int nprob, int N, int K
                         const float* B, int ldb, float beta,
                         int split_k, void* ws, size_t ws_bytes, void* stream);
 
+/* Deferred split-K reduction.  The *_deferred forms behave like the plain ones, but when `job` is not
+ * NULL and the product was split, they leave the partial slabs in `ws` and describe the pending
+ * reduction (+ epilogue) in *job instead of launching it; `ws` must then stay untouched until
+ * clv_splitk_reduce_multi has run.  A backward pass queues all of its weight-gradient products this
+ * way and finishes them with ONE reduce launch (up to 16 pending jobs; jobs that needed no split are
+ * skipped).  Summation order per output is fixed, so results are bit-identical to the plain forms. */
+typedef struct { unsigned char opaque[160]; } clv_reduce_job;
+int clv_gemm_f32_deferred(int transa, int transb, int M, int N, int K, float alpha,
+                          const float* A, int lda, const float* B, int ldb,
+                          float beta, float* C, int ldc,
+                          const float* bias, int act, const float* aux,
+                          int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
+int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int nprob, int N, int K,
+                                 const float* B, int ldb, float beta,
+                                 int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
+int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream);
+
+
 /* column sums: out[N] = (beta ? out : 0) + sum_m X[m, n]   (bias gradients) */
 size_t clv_colsum_workspace_bytes(int M, int N);
 int clv_colsum_f32(int M, int N, const float* X, int ldx, float beta, float* out,
@@ -119,6 +137,27 @@ int clv_lstm_seq_fwd_x(int B, int T, int H, int gate_act,
 int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
                      const float* U, const float* dhs, const float* cs, const float* c0,
                      float* gates_inout_dz, float* dzsum, void* stream);
+
+/* ------------------------------------------ cl_vrnn: both LSTMs in one launch --
+ * cl_vrnn/model.py:193-228 as ONE persistent kernel: encoder LSTM, the fused latent head
+ * [Z_mean | Z_log_var] (Wz [H,2L], bz [2L]), z = mean + exp(log_var/2)*eps, its KL term, and the
+ * decoder LSTM, whose input projection gets z_t . Kz (Kz [L,4H] = the z rows of decoder_h/kernel) added
+ * inside the kernel.  A workgroup owns one batch row; the encoder chain and the decoder chain (two steps
+ * behind) run in different waves of the same CU, so the pair costs about one sequence kernel.
+ *   gates_enc : in  x_t.K_x [B,T,4H]          out (z_i, z_f, tanh(z_c), z_o) like clv_lstm_seq_fwd
+ *   gates_dec : in  x_{t-1}.K_x (dec_has_xproj != 0; else ignored)   out likewise
+ *   rowbias_* : [B,4H] per-row bias (W.K_w + b)
+ *   zargs [B*T,2L], Z: B*T rows of stride ldz, klterm [B*T,L] = L * KL_l (the mean over ALL entries is
+ *   the per-frame KL, which is what clv_loss_sums computes).
+ * Initial states are zero (training windows: cl_vrnn/model.py builds stateless LSTMs for training).
+ * clv_lstm_pair_supported: H == 88 and 1 <= L <= 16; otherwise use the separate kernels. */
+int clv_lstm_pair_supported(int H, int L);
+int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
+                      float* gates_enc, const float* rowbias_enc, const float* U_enc,
+                      float* gates_dec, int dec_has_xproj, const float* rowbias_dec, const float* U_dec,
+                      const float* Kz, const float* Wz, const float* bz, const float* eps,
+                      float* hs_enc, float* cs_enc, float* hs_dec, float* cs_dec,
+                      float* zargs, float* Z, int ldz, float* klterm, void* stream);
 
 /* ------------------------------------------------------------ pointwise --
  * logistic-normal label sample + its two losses, one thread per row:

@@ -101,14 +101,18 @@ def test_cl_vae_step_matches_oracle(dev, B, L, Cn, use_x_prev, weights, fused):
         np.testing.assert_allclose(w[k], p[k], rtol=2e-3, atol=2e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("pair", [True, False])
 @pytest.mark.parametrize("B,Tn,L,Cn,use_x_prev,gate", [
     (6, 5, 2, 10, True, 'hard_sigmoid'),
+    (3, 1, 2, 10, True, 'hard_sigmoid'),        # one-step windows
+    (3, 6, 16, 5, True, 'sigmoid'),             # widest latent the fused pair kernel carries
     (5, 7, 3, 4, False, 'hard_sigmoid'),
     (4, 9, 2, 10, True, 'sigmoid'),
     (4, 128, 2, 10, True, 'hard_sigmoid'),      # BASELINE config 3/4 shape at reduced batch
     (4, 32, 32, 10, True, 'hard_sigmoid'),      # config 5 latent size
 ])
-def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate):
+def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate, pair):
+    """pair=True: both LSTMs + latent head in one persistent launch (csrc/lstm_pair.hip) where supported."""
     from clvae_amd.engine import VrnnEngine
     cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=use_x_prev, class_weight=0.8,
                         kl_weight=0.6, w_kl_weight=0.9, w_log_var_prior=0.2, gate_act=gate)
@@ -120,7 +124,9 @@ def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate):
     eW, eZ = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, Tn, L)))
     ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
 
+    cfg['fuse_pair'] = pair
     eng = VrnnEngine(cfg, B, dev)
+    assert eng.fuse_pair == (pair and L <= 16)
     eng.P.set_weights(p)
     args = (T(X, dev), T(Xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev))
     eng.loss_and_grads(*args)
