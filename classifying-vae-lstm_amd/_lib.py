@@ -63,6 +63,7 @@ SIGNATURES = {
     "clv_lstm_pair_supported": (_i, [_i, _i]),
     "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i,
                                _p, _p]),
+    "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 15),
     "clv_label_fwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "clv_label_bwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _i, _p]),
     "clv_vae_fused_supported": (_i, [_i, _i, _i, _i, _i]),

@@ -27,6 +27,9 @@ constexpr int PNT = 2 * PNW * 64;       // 768 threads
 constexpr int PLMAX = 16;               // latent dims the surplus groups can carry
 constexpr int PLQ = PLMAX / PK;         // latents per decoder lane (z_t . K_z is split over the k-slice lanes)
 
+constexpr int BW_CW = 22, BW_CP = 24;   // backward layout (lstm.hip): gate columns per slice, padded LDS slice stride
+constexpr int BW_LDS = 16 * BW_CP;
+
 __device__ float g_pair_dump[128];      // target of the stores of lanes that own no output (keeps every store unconditional)
 
 struct PairFwdArgs {
@@ -58,24 +61,12 @@ __device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)
     const float4 v = hp[q];
     hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
   }
-#ifdef CLV_PAIR_PK
 #pragma unroll
   for (int kk = 0; kk < PKK; ++kk) {
     const f2 hh = {hv[kk], hv[kk]};
     acc2[0] = __builtin_elementwise_fma(hh, Ur[kk][0], acc2[0]);
     acc2[1] = __builtin_elementwise_fma(hh, Ur[kk][1], acc2[1]);
   }
-#else
-  float a0 = acc2[0][0], a1 = acc2[0][1], a2 = acc2[1][0], a3 = acc2[1][1];
-#pragma unroll
-  for (int kk = 0; kk < PKK; ++kk) {
-    a0 = fmaf(hv[kk], Ur[kk][0][0], a0);
-    a1 = fmaf(hv[kk], Ur[kk][0][1], a1);
-    a2 = fmaf(hv[kk], Ur[kk][1][0], a2);
-    a3 = fmaf(hv[kk], Ur[kk][1][1], a3);
-  }
-  acc2[0][0] = a0; acc2[0][1] = a1; acc2[1][0] = a2; acc2[1][1] = a3;
-#endif
 }
 
 template <int GATE>
@@ -308,9 +299,255 @@ __global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
   else pair_fwd_decoder<GATE, HASXP>(a, wave - PNW, lane, hbuf[1], zbuf);
 }
 
+// ---------------------------------------------------------------------------
+// backward: decoder BPTT, the latent head's backward and encoder BPTT in one launch
+// ---------------------------------------------------------------------------
+// Waves 0-5 run the decoder chain (layout of lstm_bwd_kernel: lane = (unit group, column slice), 4 units x
+// 22 gate columns of U per thread), waves 6-11 the encoder chain two steps behind.  Between them:
+//   dZ_t[l]   = sum_c dz_dec_t[c] * Kz[l][c]              -- rows of Kz ride in the decoder's surplus unit
+//                                                            groups (units 88..95: latent_dim <= 8), so dZ_{t+1}
+//                                                            falls out of the FMA sequence of step t
+//   dzargs_t  = (dZ + kl*mean, dZ*eps*sd/2 - kl*(1-sd^2)/2)  -- same lanes; to HBM (head weight gradient) and LDS
+//   dh_enc_t  = dzargs_t . Wz^T                            -- 2L FMAs per encoder lane (its row of Wz in registers)
+// so neither dZ nor the encoder's upstream gradient ever exists in HBM.
+constexpr int QL = 8;                   // latent dims the surplus unit groups of the decoder chain carry
+constexpr int QZ = 2 * QL;              // head columns
+
+struct PairBwdArgs {
+  int B, T, L;
+  float kl_scale;                 // kl_weight / (B*T)
+  const float* U_d;
+  const float* U_e;
+  const float* Kz;                // [L,352]
+  const float* Wz;                // [88,2L]
+  const float* dhs_d;             // [B,T,88] dL/dh of the decoder (output head)
+  const float* cs_d;
+  const float* cs_e;
+  float* gates_d;                 // in: (z_i,z_f,g,z_o) of the forward pass   out: dz
+  float* gates_e;
+  float* dzsum_d;                 // [B,352] sum_t dz
+  float* dzsum_e;
+  const float* zargs;             // [B*T,2L]
+  const float* eps;               // [B*T,L]
+  float* dzargs;                  // [B*T,2L]
+};
+
+template <int GATE, bool DEC, int ZP>
+__device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, int lane, float (*dzb)[BW_LDS],
+                                               float (*dza)[QZ]) {
+  const int cs = lane & 15, ug = wave * 4 + (lane >> 4), q = cs >> 2;
+  const bool b0 = cs & 1, b1 = cs & 2;
+  const int b = blockIdx.x, T = a.T, L = a.L;
+  const int u = min(4 * ug + (cs & 3), LH - 1);      // surplus groups without a latent duplicate unit 87
+  const int zg0 = 4 * (ug - 22);                     // first latent of a surplus group
+  const bool zgroup = DEC && ug >= 22 && zg0 < L;
+  const int lat = zg0 + (cs & 3);                    // latent this lane finishes after the reduce-scatter
+  const bool zlane = zgroup && lat < L;
+  const float* U = DEC ? a.U_d : a.U_e;
+  float* gates = DEC ? a.gates_d : a.gates_e;
+  const float* csp = DEC ? a.cs_d : a.cs_e;
+  float* dzsum = DEC ? a.dzsum_d : a.dzsum_e;
+
+  f2 Ur[BW_CW][2];    // [column][unit pair]; a latent group holds rows of Kz instead
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int lj = zg0 + j;
+    const float* row = zgroup ? a.Kz + (size_t)min(lj, L - 1) * LG : U + (size_t)min(4 * ug + j, LH - 1) * LG;
+    const float2* up = reinterpret_cast<const float2*>(row + BW_CW * cs);
+    const bool dead = zgroup && lj >= L;
+#pragma unroll
+    for (int c = 0; c < BW_CW / 2; ++c) {
+      const float2 v = up[c];
+      Ur[2 * c][j >> 1][j & 1] = dead ? 0.f : v.x;
+      Ur[2 * c + 1][j >> 1][j & 1] = dead ? 0.f : v.y;
+    }
+  }
+  // encoder: this unit's row of the head kernel (dh_enc = dzargs . Wz^T), zero beyond 2L
+  float Wzr[ZP];
+  if (!DEC) {
+#pragma unroll
+    for (int j = 0; j < ZP; ++j) {
+      const float v = a.Wz[(size_t)u * 2 * L + min(j, 2 * L - 1)];
+      Wzr[j] = j < 2 * L ? v : 0.f;
+    }
+  }
+
+  const size_t rowbt = (size_t)b * T;
+  float dc = 0.f;
+  float zs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  struct Raw { float zi, zf, g, zo, c, cp, dh; };
+  struct Coef { float ko, kc, ki, kf, kg, kcarry, dhh; };
+  const float* g_base = gates + rowbt * LG + u;
+  // per-lane streams behind the (c_t, c_{t-1}, dh_t) load slots: a latent lane reads (mean, log_var, eps) of its
+  // latent there instead (one step later in time, see below), so every lane issues the same loads
+  const float* pc = zlane ? a.zargs + rowbt * 2 * L + lat : csp + rowbt * LH + u;
+  const float* pd = zlane ? a.eps + rowbt * L + lat : (DEC ? a.dhs_d + rowbt * LH + u : pc);
+  const int stc = zlane ? 2 * L : LH, std_ = zlane ? L : (DEC ? LH : 0);
+  const int ppo = zlane ? L : 0;                       // offset of the second stream (log_var column / same array)
+  const float hk = 0.5f * a.kl_scale;
+  auto load_raw = [&](int tr) {       // regular lanes: step max(tr, 0); latent lanes: step tr + 1 (clamped to the window)
+    Raw r;
+    const int t = max(tr, 0);
+    const float* gp = g_base + (size_t)t * LG;
+    r.zi = gp[0]; r.zf = gp[LH]; r.g = gp[2 * LH]; r.zo = gp[3 * LH];
+    const int tz = zlane ? min(max(tr + 1, 0), T - 1) : t;
+    r.c = pc[(size_t)tz * stc];
+    const float cprev = pc[(size_t)(zlane ? tz : max(tz - 1, 0)) * stc + ppo];
+    r.cp = (t > 0 || zlane) ? cprev : 0.f;
+    r.dh = DEC ? pd[(size_t)tz * std_] : 0.f;
+    return r;
+  };
+  auto make_coef = [&](const Raw& r) {
+    Coef k;
+    const float ig = gate_fn<GATE>(r.zi), fg = gate_fn<GATE>(r.zf), og = gate_fn<GATE>(r.zo);
+    const float tc = fast_tanh(r.c);
+    k.ko = tc * gate_grad<GATE>(r.zo, og);
+    k.kc = og * (1.f - tc * tc);
+    k.ki = r.g * gate_grad<GATE>(r.zi, ig);
+    k.kf = r.cp * gate_grad<GATE>(r.zf, fg);
+    k.kg = ig * (1.f - r.g * r.g);
+    k.kcarry = fg;
+    k.dhh = r.dh;
+    if (DEC && wave == PNW - 1) {
+      // latent lanes: (c, cp, dh) = (mean, log_var, eps); dzargs = dZ * ki + kf with
+      //   mean column (replica 0): ki = 1, kf = kl*mean;  log_var column: ki = eps*sd/2, kf = -kl*(1 - sd^2)/2
+      const float sd = __expf(0.5f * r.cp);
+      const float zi_ = q == 0 ? 1.f : 0.5f * r.dh * sd;
+      const float zf_ = q == 0 ? a.kl_scale * r.c : -hk * (1.f - sd * sd);
+      k.ki = zgroup ? zi_ : k.ki;
+      k.kf = zgroup ? zf_ : k.kf;
+    }
+    return k;
+  };
+  // With the +1 offset above the coefficients a latent lane holds during iteration (step t) are those of step
+  // t+1, whose dZ its matvec has just produced from dz_dec_{t+1}.
+  Coef coef_next = make_coef(load_raw(T - 1));
+  Raw raw_next = load_raw(T - 2);
+  g_pair_dump[lane] = 0.f;           // one store after the prologue's loads (see lstm_bwd_kernel)
+
+  // output slot: regular lanes: dz of gate q (4 replicas share the 4 gates); latent lanes: replica 0 the
+  // mean column of dzargs, replica 1 the log_var column
+  const int col = q * LH + u;
+  float* gptr = gates + (rowbt + T - 1) * LG + col;
+  int gstr = -LG;
+  int lpos = BW_CP * (col / BW_CW) + col % BW_CW;
+  if (zgroup) {
+    const bool live = zlane && q < 2;
+    gptr = live ? a.dzargs + (rowbt + T - 1) * 2 * L + q * L + lat : g_pair_dump + lane;
+    gstr = live ? -2 * L : 0;
+    lpos = q * L + lat;              // position in the dzargs LDS vector
+  }
+
+  auto matvec = [&](int cur) {        // reduce-scattered: this lane's unit (or latent) total
+    const float4* dp = reinterpret_cast<const float4*>(&dzb[cur][BW_CP * cs]);
+    float dv[BW_CP];
+#pragma unroll
+    for (int j = 0; j < BW_CP / 4; ++j) {
+      const float4 v = dp[j];
+      dv[4 * j] = v.x; dv[4 * j + 1] = v.y; dv[4 * j + 2] = v.z; dv[4 * j + 3] = v.w;
+    }
+    f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < BW_CW; ++c) {
+      const f2 dd = {dv[c], dv[c]};
+      acc01 = __builtin_elementwise_fma(dd, Ur[c][0], acc01);
+      acc23 = __builtin_elementwise_fma(dd, Ur[c][1], acc23);
+    }
+    const float keep_a = b0 ? acc01[1] : acc01[0], send_a = b0 ? acc01[0] : acc01[1];
+    const float keep_b = b0 ? acc23[1] : acc23[0], send_b = b0 ? acc23[0] : acc23[1];
+    const float wa = keep_a + dpp_mov<0xB1>(send_a);
+    const float wb = keep_b + dpp_mov<0xB1>(send_b);
+    const float keep = b1 ? wb : wa, send = b1 ? wa : wb;
+    float x = keep + dpp_mov<0x4E>(send);
+    x = dpp_add<0x124>(x);
+    x = dpp_add<0x128>(x);
+    return x;
+  };
+
+  if (!DEC) {                        // the encoder chain runs two iterations behind: dzargs_t leaves the decoder
+    step_barrier();                  // chain at the end of the iteration after dz_dec_t
+    step_barrier();
+  }
+
+  for (int i = 0; i < T; ++i) {
+    const int t = T - 1 - i;
+    const int cur = i & 1;
+    const Coef k = coef_next;
+    const Raw rcur = raw_next;
+    raw_next = load_raw(t - 2);
+    float dhup;
+    if (DEC) {
+      dhup = k.dhh;
+    } else {                          // dh_enc_t = dzargs_t . Wz[u,:]  (dzargs_t was written one iteration ago)
+      const int par = (i + 1) & 1;    // written by decoder iteration i + 1
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int j4 = 0; j4 < ZP; j4 += 4) {           // columns beyond 2L: zero weights, zero LDS
+        const float4 v = *reinterpret_cast<const float4*>(&dza[par][j4]);
+        s0 = fmaf(v.x, Wzr[j4], s0); s1 = fmaf(v.y, Wzr[j4 + 1], s1);
+        s0 = fmaf(v.z, Wzr[j4 + 2], s0); s1 = fmaf(v.w, Wzr[j4 + 3], s1);
+      }
+      dhup = s0 + s1;
+    }
+    const float dhrec = matvec(cur);
+    coef_next = make_coef(rcur);
+    const float dh = dhup + dhrec;
+    dc = fmaf(dh, k.kc, dc);
+    float dz[4];
+    dz[0] = dc * k.ki;
+    dz[1] = dc * k.kf;
+    dz[2] = dc * k.kg;
+    dz[3] = dh * k.ko;
+    dc = dc * k.kcarry;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) zs[gi] += dz[gi];
+    float val = pick4(q, dz);
+    if (DEC && wave == PNW - 1) {     // wave-uniform: latent lanes turn dZ_{t+1} into dzargs_{t+1}
+      const float zv = fmaf(dhrec, k.ki, k.kf);
+      val = zgroup ? zv : val;
+      if (zlane && q < 2) dza[i & 1][lpos] = zv;
+    }
+    if (!zgroup) dzb[cur ^ 1][lpos] = val;
+    *gptr = val;
+    gptr += (zgroup && i == 0) ? 0 : gstr;            // the head lags one step
+    step_barrier();
+  }
+  if (DEC) {
+    // iteration T: dZ_0 -> dzargs_0
+    if (wave == PNW - 1) {
+      const float dZ = matvec(T & 1);
+      const float zv = fmaf(dZ, coef_next.ki, coef_next.kf);
+      if (zlane && q < 2) {
+        *gptr = zv;
+        dza[T & 1][lpos] = zv;
+      }
+    }
+    step_barrier();
+    step_barrier();
+  }
+  if (!zgroup) {
+    const float val = pick4(q, zs);
+    dzsum[(size_t)b * LG + col] = val;
+  }
+}
+
+template <int GATE, int ZP>
+__global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float dzbuf[2][2][BW_LDS];       // [chain][parity][sliced dz]
+  __shared__ __attribute__((aligned(16))) float dza[2][QZ];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 2 * 2 * BW_LDS; i += PNT) (&dzbuf[0][0][0])[i] = 0.f;
+  if (tid < 2 * QZ) (&dza[0][0])[tid] = 0.f;
+  __syncthreads();
+  if (wave < PNW) pair_bwd_chain<GATE, true, ZP>(a, wave, lane, dzbuf[0], dza);
+  else pair_bwd_chain<GATE, false, ZP>(a, wave - PNW, lane, dzbuf[1], dza);
+}
+
 }  // namespace clv
 
-extern "C" int clv_lstm_pair_supported(int H, int L) { return H == clv::LH && L >= 1 && L <= clv::PLMAX; }
+extern "C" int clv_lstm_pair_supported(int H, int L) { return H == clv::LH && L >= 1 && L <= clv::QL; }
 
 extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                                  float* gates_enc, const float* rowbias_enc, const float* U_enc,
@@ -333,5 +570,32 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
   if (hard) { if (dec_has_xproj) PAIR_FWD(CLV_GATE_HARD_SIGMOID, true); else PAIR_FWD(CLV_GATE_HARD_SIGMOID, false); }
   else { if (dec_has_xproj) PAIR_FWD(CLV_GATE_SIGMOID, true); else PAIR_FWD(CLV_GATE_SIGMOID, false); }
 #undef PAIR_FWD
+  return launch_status();
+}
+
+extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
+                                 const float* U_dec, const float* U_enc, const float* Kz, const float* Wz,
+                                 const float* dhs_dec, const float* cs_dec, const float* cs_enc,
+                                 float* gates_dec_inout_dz, float* gates_enc_inout_dz,
+                                 float* dzsum_dec, float* dzsum_enc,
+                                 const float* zargs, const float* eps, float* dzargs, void* stream) {
+  using namespace clv;
+  if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0) return CLV_EINVAL;
+  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  if (!U_dec || !U_enc || !Kz || !Wz || !dhs_dec || !cs_dec || !cs_enc || !gates_dec_inout_dz || !gates_enc_inout_dz ||
+      !dzsum_dec || !dzsum_enc || !zargs || !eps || !dzargs)
+    return CLV_EINVAL;
+  PairBwdArgs a{B, T, L, kl_scale, U_dec, U_enc, Kz, Wz, dhs_dec, cs_dec, cs_enc, gates_dec_inout_dz,
+                gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("lstm_pair_bwd", s);
+  const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
+#define PAIR_BWD(G, Z) hipLaunchKernelGGL((lstm_pair_bwd_kernel<G, Z>), dim3(B), dim3(PNT), 0, s, a)
+#define PAIR_BWD_Z(Z) do { if (hard) PAIR_BWD(CLV_GATE_HARD_SIGMOID, Z); else PAIR_BWD(CLV_GATE_SIGMOID, Z); } while (0)
+  if (2 * L <= 4) PAIR_BWD_Z(4);
+  else if (2 * L <= 8) PAIR_BWD_Z(8);
+  else PAIR_BWD_Z(16);
+#undef PAIR_BWD_Z
+#undef PAIR_BWD
   return launch_status();
 }

@@ -616,6 +616,34 @@ class VrnnEngine(_EngineBase):
         D, T = self.cfg['D'], self.cfg['T']
         return self.P.offsets['hW/kernel'], T * D * D
 
+    def _bptt_separate(self, X, eps_Z, rq, ws, ws2):
+        """Backward through both LSTMs and the latent head as separate launches (any latent_dim)."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, T = cfg['D'], cfg['H'], cfg['L'], cfg['T']
+        BT, G4, off = B * T, 4 * H, self.off
+        inv_bt = 1.0 / BT
+        g = ops.gemm
+        # decoder BPTT (VALU) ...
+        ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
+                         self.dzsum_dec, gate_act=self.gate_act)
+        dz = self.gates_dec
+        # ... then its weight gradients (MFMA) go to the side stream and overlap the encoder BPTT
+        with self._side():
+            self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, dz, self.dzsum_dec, off + L, ws2)
+        g(dz, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
+        # latent heads
+        ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
+        g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
+        with self._side():
+            ops.gemm_grouped_tn([dict(A=self.hs_enc, lda=H, M=H, C=P.g('Zargs/kernel')),
+                                 dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws2, defer=rq)
+        # encoder BPTT
+        ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
+                         self.dzsum_enc, gate_act=self.gate_act)
+        dz = self.gates_enc
+        with self._side():
+            self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, dz, self.dzsum_enc, D, ws2)
+
     def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True):
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
@@ -638,26 +666,19 @@ class VrnnEngine(_EngineBase):
                                  dict(A=None, M=1, C=P.g('X_decoded_mean/bias'), ones=True)], D, BT, self.dlogits, ws2,
                                 defer=rq)
         g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
-        # decoder BPTT (VALU) ...
-        ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
-                         self.dzsum_dec, gate_act=self.gate_act)
-        dz = self.gates_dec
-        # ... then its weight gradients (MFMA) go to the side stream and overlap the encoder BPTT
-        with self._side():
-            self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, dz, self.dzsum_dec, off + L, ws2)
-        g(dz, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
-        # latent heads
-        ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
-        g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
-        with self._side():
+        if self.fuse_pair:
+            # decoder BPTT, dZ, the latent head's backward, dh_enc and encoder BPTT: one persistent launch
+            ops.lstm_pair_bwd(B, T, L, self.kl_weight * inv_bt, P.p('decoder_h/recurrent_kernel'),
+                              P.p('encoder_h/recurrent_kernel'), P.rows(P.params, 'decoder_h/kernel', off),
+                              P.p('Zargs/kernel'), self.dhs, self.cs_dec, self.cs_enc, self.gates_dec, self.gates_enc,
+                              self.dzsum_dec, self.dzsum_enc, self.zargs, eps_Z, self.dzargs, gate_act=self.gate_act)
+            self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec, self.dzsum_dec,
+                              off + L, ws)
             ops.gemm_grouped_tn([dict(A=self.hs_enc, lda=H, M=H, C=P.g('Zargs/kernel')),
-                                 dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws2, defer=rq)
-        # encoder BPTT
-        ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
-                         self.dzsum_enc, gate_act=self.gate_act)
-        dz = self.gates_enc
-        with self._side():
-            self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, dz, self.dzsum_enc, D, ws2)
+                                 dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws, defer=rq)
+            self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
+        else:
+            self._bptt_separate(X, eps_Z, rq, ws, ws2)
         # label head: dW from both LSTMs, label backward, dWargs and dhW in one launch; then the two Dense
         # layers' (dW, db) pairs as grouped GEMMs
         ops.vrnn_label_bwd(B, D, Cn, G4, self.dzsum_enc, self.dzsum_dec, P.rows(P.params, 'encoder_h/kernel', D),

@@ -158,6 +158,14 @@ def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, U_enc, gates_dec, dec_has_xproj, r
                                        _ptr(Z), ldz, _ptr(klterm), _stream()), "clv_lstm_pair_fwd")
 
 
+def lstm_pair_bwd(B, T, L, kl_scale, U_dec, U_enc, Kz, Wz, dhs_dec, cs_dec, cs_enc, gates_dec, gates_enc, dzsum_dec,
+                  dzsum_enc, zargs, eps, dzargs, gate_act=0, H=88):
+    check(_lib.lib().clv_lstm_pair_bwd(B, T, H, L, gate_act, float(kl_scale), _ptr(U_dec), _ptr(U_enc), _ptr(Kz), _ptr(Wz),
+                                       _ptr(dhs_dec), _ptr(cs_dec), _ptr(cs_enc), _ptr(gates_dec), _ptr(gates_enc),
+                                       _ptr(dzsum_dec), _ptr(dzsum_enc), _ptr(zargs), _ptr(eps), _ptr(dzargs), _stream()),
+          "clv_lstm_pair_bwd")
+
+
 def label_fwd(B, Cn, mean, logvar, ld_in, eps, onehot, prior, w, rowloss):
     check(_lib.lib().clv_label_fwd(B, Cn, _ptr(mean), _ptr(logvar), ld_in, _ptr(eps), _ptr(onehot), float(prior),
                                    _ptr(w), _ptr(rowloss), _stream()), "clv_label_fwd")

@@ -150,7 +150,14 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  *   zargs [B*T,2L], Z: B*T rows of stride ldz, klterm [B*T,L] = L * KL_l (the mean over ALL entries is
  *   the per-frame KL, which is what clv_loss_sums computes).
  * Initial states are zero (training windows: cl_vrnn/model.py builds stateless LSTMs for training).
- * clv_lstm_pair_supported: H == 88 and 1 <= L <= 16; otherwise use the separate kernels. */
+ * clv_lstm_pair_supported: H == 88 and 1 <= L <= 8 (the forward kernel alone carries L <= 16); otherwise
+ * use the separate kernels.
+ *
+ * clv_lstm_pair_bwd is the matching backward pass: decoder BPTT, dZ_t = dz_dec_t . Kz^T, the latent
+ * head's backward (dzargs = [dZ + kl*mean | dZ*eps*sd/2 - kl*(1 - sd^2)/2], kl = kl_scale, written to
+ * dzargs [B*T,2L] for the head's weight gradient), dh_enc_t = dzargs_t . Wz^T and encoder BPTT, one
+ * launch; gates_* are overwritten in place with dz and dzsum_* [B,4H] = sum_t dz like clv_lstm_seq_bwd.
+ * dhs_dec [B,T,H] is the decoder's upstream gradient (from the output head). */
 int clv_lstm_pair_supported(int H, int L);
 int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                       float* gates_enc, const float* rowbias_enc, const float* U_enc,
@@ -158,6 +165,12 @@ int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                       const float* Kz, const float* Wz, const float* bz, const float* eps,
                       float* hs_enc, float* cs_enc, float* hs_dec, float* cs_dec,
                       float* zargs, float* Z, int ldz, float* klterm, void* stream);
+int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
+                      const float* U_dec, const float* U_enc, const float* Kz, const float* Wz,
+                      const float* dhs_dec, const float* cs_dec, const float* cs_enc,
+                      float* gates_dec_inout_dz, float* gates_enc_inout_dz,
+                      float* dzsum_dec, float* dzsum_enc,
+                      const float* zargs, const float* eps, float* dzargs, void* stream);
 
 /* ------------------------------------------------------------ pointwise --
  * logistic-normal label sample + its two losses, one thread per row:
