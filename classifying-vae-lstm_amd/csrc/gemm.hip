@@ -42,6 +42,7 @@ struct GemmArgs {
   int k_chunk;       // K handled per blockIdx.z slice (multiple of 16)
   float* partial;    // != nullptr: raw partial sums [z][M][N]
   int vecA, vecB;    // 16-byte vector loads legal for A / B
+  int xcd_remap;     // split-K launches: workgroups that share a K chunk run on the same XCD (see gemm_f32_kernel)
 };
 
 template <int BMN>
@@ -59,9 +60,45 @@ struct TileLoader {
   static constexpr int PER = (NV + 255) / 256;         // float4 per thread
   static constexpr int LD = LdsStride<BMN>::value;
 
-  __device__ static void load(float4 (&r)[PER], const float* __restrict__ p, int ld, int dim_mn,
+  // Fast path (vec: 16-byte aligned base, ld % 4 == 0): every thread issues its float4 loads unconditionally
+  // from clamped, always-valid addresses and masks afterwards.  Loads under per-lane branches (the general path
+  // below) make the compiler wait for each of them where it was issued, which serialises the prefetch of the
+  // next k-tile with the MFMAs of the current one.
+  // mk[i]: validity bits of r[i]'s 4 components; the masking itself happens in store(), i.e. AFTER the MFMAs of
+  // the current tile: touching a loaded value right here would make the wave wait for the load before computing.
+  __device__ static void load(float4 (&r)[PER], int (&mk)[PER], const float* __restrict__ p, int ld, int dim_mn,
                               int k_end, int mn0, int k0, int vec, int tid, int shift = 0, int zperiod = 0,
                               int ones = 0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mk[i] = 15;
+    if (vec && !ones) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = min(tid + i * 256, NV - 1);         // surplus threads repeat the last vector (never stored)
+        float4 v;
+        bool ok0, ok1, ok2, ok3;
+        if (KC) {
+          const int mn = idx >> 2, k4 = (idx & 3) * 4;
+          const int gm = mn0 + mn, gk = k0 + k4;
+          const float* src = p + (size_t)min(gm, dim_mn - 1) * ld + min(gk, ld - 4);
+          v = *reinterpret_cast<const float4*>(src);
+          const bool row = gm < dim_mn;
+          ok0 = row && gk + 0 < k_end; ok1 = row && gk + 1 < k_end; ok2 = row && gk + 2 < k_end; ok3 = row && gk + 3 < k_end;
+        } else {
+          constexpr int RV = BMN / 4;
+          const int k = idx / RV, c4 = (idx % RV) * 4;
+          const int gk = k0 + k, gm = mn0 + c4;
+          const bool row = gk < k_end && !(zperiod > 0 && gk % zperiod == 0);
+          const int rk = max(min(gk, k_end - 1) - shift, 0);
+          const float* src = p + (size_t)rk * ld + min(gm, ld - 4);
+          v = *reinterpret_cast<const float4*>(src);
+          ok0 = row && gm + 0 < dim_mn; ok1 = row && gm + 1 < dim_mn; ok2 = row && gm + 2 < dim_mn; ok3 = row && gm + 3 < dim_mn;
+        }
+        r[i] = v;
+        mk[i] = (ok0 ? 1 : 0) | (ok1 ? 2 : 0) | (ok2 ? 4 : 0) | (ok3 ? 8 : 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int idx = tid + i * 256;
@@ -104,21 +141,25 @@ struct TileLoader {
     }
   }
 
-  __device__ static void store(const float4 (&r)[PER], float* lds, int tid) {
+  __device__ static void store(const float4 (&rr)[PER], const int (&mk)[PER], float* lds, int tid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int idx = tid + i * 256;
+      // arithmetic masks (operands are finite: a clamped address always points at real data); with selects the
+      // compiler turns the masked load back into a load under a branch
+      float4 r_i = make_float4(rr[i].x * ((mk[i] & 1) ? 1.f : 0.f), rr[i].y * ((mk[i] & 2) ? 1.f : 0.f),
+                               rr[i].z * ((mk[i] & 4) ? 1.f : 0.f), rr[i].w * ((mk[i] & 8) ? 1.f : 0.f));
       if (idx < NV) {
         if (KC) {
           int mn = idx >> 2, k4 = (idx & 3) * 4;
-          lds[(k4 + 0) * LD + mn] = r[i].x;
-          lds[(k4 + 1) * LD + mn] = r[i].y;
-          lds[(k4 + 2) * LD + mn] = r[i].z;
-          lds[(k4 + 3) * LD + mn] = r[i].w;
+          lds[(k4 + 0) * LD + mn] = r_i.x;
+          lds[(k4 + 1) * LD + mn] = r_i.y;
+          lds[(k4 + 2) * LD + mn] = r_i.z;
+          lds[(k4 + 3) * LD + mn] = r_i.w;
         } else {
           constexpr int RV = BMN / 4;
           int k = idx / RV, c4 = (idx % RV) * 4;
-          *reinterpret_cast<float4*>(&lds[k * LD + c4]) = r[i];
+          *reinterpret_cast<float4*>(&lds[k * LD + c4]) = r_i;
         }
       }
     }
@@ -146,21 +187,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-  // grouped launch: blockIdx.x enumerates the m-tiles of every problem
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  In a split-K
+  // launch the tiles of one K chunk read the same rows of A and B, so the linear id is re-decoded as
+  // (xcd = chunk % 8, tile, chunk / 8): the chunk's rows are fetched from HBM into ONE L2 and reused there by
+  // every tile, instead of once per XCD.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_remap) {
+    const int ntx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+    const int lin = bx + ntx * (by + (int)gridDim.y * bz);
+    const int xcd = lin & 7, rest = lin >> 3;
+    const int tile = rest % ntiles;
+    bz = (rest / ntiles) * 8 + xcd;
+    bx = tile % ntx;
+    by = tile / ntx;
+  }
+  // grouped launch: bx enumerates the m-tiles of every problem
   const float* __restrict__ Aptr = g.A;
   float* Cptr = g.C;
-  int lda = g.lda, ldc = g.ldc, Mp = g.M, mtile = blockIdx.x, prow0 = 0, a_shift = 0, a_zper = 0, a_ones = 0;
+  int lda = g.lda, ldc = g.ldc, Mp = g.M, mtile = bx, prow0 = 0, a_shift = 0, a_zper = 0, a_ones = 0;
   if (g.nprob > 0) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAX_PROB; ++i)
-      if (i < g.nprob && (int)blockIdx.x >= g.prob[i].tile0) pi = i;
+      if (i < g.nprob && bx >= g.prob[i].tile0) pi = i;
     const GemmProb& pr = g.prob[pi];
-    Aptr = pr.A; Cptr = pr.C; lda = pr.lda; ldc = pr.ldc; Mp = pr.M; mtile = blockIdx.x - pr.tile0;
+    Aptr = pr.A; Cptr = pr.C; lda = pr.lda; ldc = pr.ldc; Mp = pr.M; mtile = bx - pr.tile0;
     prow0 = pr.row0; a_shift = pr.a_shift; a_zper = pr.a_zero_period; a_ones = pr.ones;
   }
-  const int m0 = mtile * BM, n0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * g.k_chunk;
+  const int m0 = mtile * BM, n0 = by * BN;
+  const int kbeg = bz * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -171,19 +226,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float4 ra[LA::PER], rb[LB::PER];
+  int ma[LA::PER], mb[LB::PER];
   if (nk > 0) {
-    LA::load(ra, Aptr, lda, Mp, kend, m0, kbeg, g.vecA, tid, a_shift, a_zper, a_ones);
-    LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
-    LA::store(ra, As, tid);
-    LB::store(rb, Bs, tid);
+    LA::load(ra, ma, Aptr, lda, Mp, kend, m0, kbeg, g.vecA, tid, a_shift, a_zper, a_ones);
+    LB::load(rb, mb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
+    LA::store(ra, ma, As, tid);
+    LB::store(rb, mb, Bs, tid);
   }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      LA::load(ra, Aptr, lda, Mp, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid, a_shift, a_zper, a_ones);
-      LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
+      LA::load(ra, ma, Aptr, lda, Mp, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid, a_shift, a_zper, a_ones);
+      LB::load(rb, mb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
     }
     const float* as = As + cur * BK * LDA + wm * WM * 16 + r;
     const float* bs = Bs + cur * BK * LDB + wn * WN * 16 + r;
@@ -201,8 +257,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      LA::store(ra, As + (cur ^ 1) * BK * LDA, tid);
-      LB::store(rb, Bs + (cur ^ 1) * BK * LDB, tid);
+      LA::store(ra, ma, As + (cur ^ 1) * BK * LDA, tid);
+      LB::store(rb, mb, Bs + (cur ^ 1) * BK * LDB, tid);
     }
     __syncthreads();
   }
@@ -220,7 +276,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (row >= Mp) continue;
         float v = acc[i][j][reg];
         if (g.partial) {
-          g.partial[((size_t)blockIdx.z * g.M + prow0 + row) * g.N + col] = v;
+          g.partial[((size_t)bz * g.M + prow0 + row) * g.N + col] = v;
         } else {
           v *= g.alpha;
           if (g.bias) v += g.bias[col];
@@ -322,9 +378,111 @@ static int launch_reduce(const ReduceJob& j, hipStream_t s) {
   return launch_status();
 }
 
+// Grouped TN product with a handful of output rows in total and a short K (the label rows and the bias of an
+// LSTM kernel gradient: [C+1, 4H] over K = batch rows): the 96x96 MFMA tile would be >85 % padding and
+// its split-K chain is a string of dependent round trips, so this runs on the VALU: a block owns 64 output
+// columns, 16 k-lanes stride through K with every row's accumulator in registers, LDS-reduce at the end.
+constexpr int SK_ROWS = 16, SK_KC = 256;
+__global__ __launch_bounds__(1024) void tn_skinny_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float At[SK_KC][SK_ROWS];     // A^T chunk, [k][row] (broadcast reads: no padding needed)
+  __shared__ float red[8][16][64];
+  const int tid = threadIdx.x, cx = tid & 63;
+  const int kl = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = blockIdx.x * 64 + cx;
+  const bool live = col < g.N;
+  const int R = g.M;
+  float acc[SK_ROWS];
+#pragma unroll
+  for (int r = 0; r < SK_ROWS; ++r) acc[r] = 0.f;
+  for (int kc = 0; kc < g.K; kc += SK_KC) {
+    // all of this thread's B values of the chunk in flight at once (a serial k loop would pay an HBM round
+    // trip per iteration)
+    float breg[SK_KC / 16];
+#pragma unroll
+    for (int j = 0; j < SK_KC / 16; ++j) {
+      const int k = kc + kl + 16 * j;
+      const float v = g.B[(size_t)min(k, g.K - 1) * g.ldb + min(col, g.N - 1)];     // unconditional (clamped) load
+      breg[j] = v * ((live && k < g.K) ? 1.f : 0.f);     // arithmetic mask: a select would let the compiler sink the
+                                                         // load into a branch and wait for each one separately
+    }
+    // A^T chunk -> LDS (rows of every problem side by side); the 4 loads of a thread are issued together
+    float av[SK_KC * SK_ROWS / 1024];
+#pragma unroll
+    for (int it = 0; it < SK_KC * SK_ROWS / 1024; ++it) {
+      const int e = tid + it * 1024;
+      const int kk = e / SK_ROWS, r = e % SK_ROWS, k = kc + kk;
+      // select the row's problem with static indices (a runtime index into the argument struct would send it
+      // through scratch memory)
+      const float* Ap = g.prob[0].A;
+      int lda = g.prob[0].lda, row0 = 0, shift = g.prob[0].a_shift, zper = g.prob[0].a_zero_period, ones = g.prob[0].ones;
+#pragma unroll
+      for (int i = 1; i < MAX_PROB; ++i)
+        if (i < g.nprob && r >= g.prob[i].row0) {
+          Ap = g.prob[i].A; lda = g.prob[i].lda; row0 = g.prob[i].row0; shift = g.prob[i].a_shift;
+          zper = g.prob[i].a_zero_period; ones = g.prob[i].ones;
+        }
+      const bool ok = r < R && k < g.K;
+      const bool ld = ok && !ones && !(zper > 0 && k % zper == 0);
+      const float* src = ld ? Ap + (size_t)(k - shift) * lda + (r - row0) : g.B;       // unconditional load
+      const float v = *src;
+      av[it] = fmaf(v, ld ? 1.f : 0.f, (ok && ones) ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < SK_KC * SK_ROWS / 1024; ++it) {
+      const int e = tid + it * 1024;
+      At[e / SK_ROWS][e % SK_ROWS] = av[it];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SK_KC / 16; ++j) {
+      // wave-uniform address: 4 broadcast ds_read_b128 per k (the LDS pipe is shared by all 16 waves, so the
+      // number of LDS instructions, not bytes, is what counts here)
+      const float4* arow = reinterpret_cast<const float4*>(At[kl + 16 * j]);
+#pragma unroll
+      for (int r4 = 0; r4 < SK_ROWS / 4; ++r4) {
+        const float4 a = arow[r4];
+        acc[4 * r4] = fmaf(a.x, breg[j], acc[4 * r4]);
+        acc[4 * r4 + 1] = fmaf(a.y, breg[j], acc[4 * r4 + 1]);
+        acc[4 * r4 + 2] = fmaf(a.z, breg[j], acc[4 * r4 + 2]);
+        acc[4 * r4 + 3] = fmaf(a.w, breg[j], acc[4 * r4 + 3]);
+      }
+    }
+    __syncthreads();
+  }
+  // reduce the 16 k-lanes: 8 output rows per round through LDS, wave w sums row w of the round
+#pragma unroll
+  for (int r0 = 0; r0 < SK_ROWS; r0 += 8) {
+    if (r0 < R) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) red[r][kl][cx] = acc[r0 + r];
+      __syncthreads();
+      const int r = r0 + kl;
+      if (kl < 8 && r < R && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[kl][i][cx];
+        float* Cp = g.prob[0].C;
+        int ldc = g.prob[0].ldc, row0 = 0;
+#pragma unroll
+        for (int i = 1; i < MAX_PROB; ++i)
+          if (i < g.nprob && r >= g.prob[i].row0) { Cp = g.prob[i].C; ldc = g.prob[i].ldc; row0 = g.prob[i].row0; }
+        float* cp = Cp + (size_t)(r - row0) * ldc + col;
+        *cp = (g.beta != 0.f ? g.beta * *cp : 0.f) + t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N>
-static void launch_cfg(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
+static void launch_cfg(const GemmArgs& g_in, int ta, int tb, int splits, hipStream_t s) {
   constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
+  GemmArgs g = g_in;
+  {
+    static int remap = -1;
+    if (remap < 0) { const char* e = getenv("CLV_GEMM_XCD_REMAP"); remap = e ? atoi(e) : 1; }
+    g.xcd_remap = remap && splits > 1 && splits % 8 == 0;
+  }
   dim3 grid(g.nprob > 0 ? g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BM - 1) / BM : (g.M + BM - 1) / BM,
             (g.N + BN - 1) / BN, splits);
   if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, false, false>), grid, dim3(256), 0, s, g);
@@ -334,11 +492,14 @@ static void launch_cfg(const GemmArgs& g, int ta, int tb, int splits, hipStream_
 }
 
 // tile choice by output shape (all shapes of the path: N in {1..352}, M in {2..262144})
-enum TileCfg { T128x16, T64x32, T64x64, T96x96, T64x96, T64x176 };
-static TileCfg pick_tile(int M, int N) {
+enum TileCfg { T128x16, T64x32, T64x64, T96x96, T64x96, T64x176, T32x96 };
+static TileCfg pick_tile(int M, int N, int K) {
   if (N <= 16) return T128x16;
   if (N <= 32) return T64x32;
   if (N <= 64) return T64x64;
+  // tall output, short K (a Dense layer's weight gradient over one batch): enough 32-row tiles to fill the
+  // chip without splitting K, so no partial slabs and no reduce pass
+  if (N <= 96 && K <= 512 && M >= 32 * 256 && M < 64 * 256) return T32x96;
   if (N <= 96) return M <= 96 ? T96x96 : T64x96;
   if (N % 176 == 0 || N > 256) return M <= 96 ? T96x96 : T64x176;
   return T64x64;
@@ -350,6 +511,7 @@ static void tile_dims(TileCfg c, int& bm, int& bn) {
     case T64x64: bm = 64; bn = 64; break;
     case T96x96: bm = 96; bn = 96; break;
     case T64x96: bm = 64; bn = 96; break;
+    case T32x96: bm = 32; bn = 96; break;
     default: bm = 64; bn = 176; break;
   }
 }
@@ -362,7 +524,7 @@ static long split_target() {
 }
 static int auto_split(int M, int N, int K) {
   int bm, bn;
-  tile_dims(pick_tile(M, N), bm, bn);
+  tile_dims(pick_tile(M, N, K), bm, bn);
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   if (tiles >= 256 || K < 128) return 1;       // each k-tile is a dependent ~1 us round trip; a reduce launch ~6 us
   long s = (split_target() + tiles - 1) / tiles;
@@ -372,12 +534,13 @@ static int auto_split(int M, int N, int K) {
 }
 
 static void launch_gemm(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
-  switch (pick_tile(g.M, g.N)) {
+  switch (pick_tile(g.M, g.N, g.K)) {
     case T128x16: launch_cfg<2, 1, 4, 1>(g, ta, tb, splits, s); break;
     case T64x32: launch_cfg<1, 2, 4, 1>(g, ta, tb, splits, s); break;
     case T64x64: launch_cfg<2, 2, 2, 2>(g, ta, tb, splits, s); break;
     case T96x96: launch_cfg<3, 3, 2, 2>(g, ta, tb, splits, s); break;
     case T64x96: launch_cfg<1, 6, 4, 1>(g, ta, tb, splits, s); break;
+    case T32x96: launch_cfg<1, 3, 2, 2>(g, ta, tb, splits, s); break;
     default: launch_cfg<1, 11, 4, 1>(g, ta, tb, splits, s); break;
   }
 }
@@ -488,6 +651,9 @@ static void grouped_tile(int N, int& bm, int& bn) {
 
 extern "C" int clv_gemm_grouped_auto_split(const clv_gemm_prob* probs, int nprob, int N, int K) {
   if (!probs || nprob < 1 || nprob > clv::MAX_PROB) return 1;
+  int rows = 0;
+  for (int i = 0; i < nprob; ++i) rows += probs[i].M;
+  if (rows <= clv::SK_ROWS && K <= 4096) return 1;      // skinny VALU kernel, never split
   int bm, bn;
   grouped_tile(N, bm, bn);
   const long tiles = (long)grouped_tiles(probs, nprob, bm) * ((N + bn - 1) / bn);
@@ -531,6 +697,13 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   g.B = B; g.ldb = ldb; g.bias = nullptr; g.act = CLV_ACT_NONE; g.aux = nullptr;
   g.vecA = vec;
   g.vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
+  char glabel[48] = "gemm_grouped_tn";
+  if (prof_on() && getenv("CLV_PROF_SHAPES")) snprintf(glabel, sizeof(glabel), "ggemm %dx%dx%d", row, N, K);
+  if (row <= SK_ROWS && K <= 4096 && split_k <= 1) {     // a few rows over a short K: VALU kernel, no split, no reduce
+    ProfScope p(glabel, s);
+    hipLaunchKernelGGL(tn_skinny_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, g);
+    return launch_status();
+  }
   int splits = split_k < 1 ? clv_gemm_grouped_auto_split(probs, nprob, N, K) : split_k;
   int kc = (K + splits - 1) / splits;
   kc = (kc + 15) / 16 * 16;
@@ -543,7 +716,7 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
     g.partial = (float*)ws;
   }
   {
-    ProfScope p("gemm_grouped_tn", s);
+    ProfScope p(glabel, s);
     if (bn == 16) launch_cfg<2, 1, 4, 1>(g, 1, 0, splits, s);          // 128 x 16
     else if (bn == 32) launch_cfg<1, 2, 4, 1>(g, 1, 0, splits, s);     // 64 x 32
     else launch_cfg<3, 3, 2, 2>(g, 1, 0, splits, s);                   // 96 x 96
