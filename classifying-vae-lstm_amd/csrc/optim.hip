@@ -16,7 +16,7 @@
 
 namespace clv {
 
-constexpr int UNIT_ROWS = 32;
+constexpr int UNIT_ROWS = 16;
 
 struct AdamUnit {
   int64_t offset;       // element offset of the tensor
@@ -88,16 +88,21 @@ __device__ __forceinline__ void col_partial_sums(const AdamCol& c, const float* 
                                                  float& a, float& b) {
   const float* qa = pa + c.part_base + c.col_local;
   const float* qb = pb ? pb + c.part_base + c.col_local : nullptr;
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
   int k = zy;
-  for (; k + CL < c.nunits; k += 2 * CL) {
+  for (; k + 3 * CL < c.nunits; k += 4 * CL) {      // 4 (8 with qb) independent loads in flight
     a0 += qa[(size_t)k * c.cols]; a1 += qa[(size_t)(k + CL) * c.cols];
-    if (qb) { b0 += qb[(size_t)k * c.cols]; b1 += qb[(size_t)(k + CL) * c.cols]; }
+    a2 += qa[(size_t)(k + 2 * CL) * c.cols]; a3 += qa[(size_t)(k + 3 * CL) * c.cols];
+    if (qb) {
+      b0 += qb[(size_t)k * c.cols]; b1 += qb[(size_t)(k + CL) * c.cols];
+      b2 += qb[(size_t)(k + 2 * CL) * c.cols]; b3 += qb[(size_t)(k + 3 * CL) * c.cols];
+    }
   }
   for (; k < c.nunits; k += CL) {
     a0 += qa[(size_t)k * c.cols];
     if (qb) b0 += qb[(size_t)k * c.cols];
   }
+  a0 += a2; a1 += a3; b0 += b2; b1 += b3;
   a = a0 + a1; b = b0 + b1;
 }
 __device__ __forceinline__ float lanes16_sum(float (*red)[16], int zy, int cx, float v) {
