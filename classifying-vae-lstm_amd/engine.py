@@ -385,6 +385,8 @@ class VrnnEngine(_EngineBase):
         self.fuse_xproj = bool(cfg.get('fuse_xproj', False))   # break-even vs the projection GEMM at config 3
         # encoder + latent head + decoder as one launch (csrc/lstm_pair.hip); latent_dim <= 16
         self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj
+        # input projections by sparse row gathering (exact for any input; pays off for piano-roll frames)
+        self.sparse_inputs = bool(cfg.get('sparse_inputs', True)) and ops.sparse_proj_supported(D, 4 * H)
         self.hW = _f(d, B, D)
         self.wargs = _f(d, B, 2 * (Cn - 1))
         self.W = _f(d, B, Cn)
@@ -466,9 +468,14 @@ class VrnnEngine(_EngineBase):
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         BT, G4, off = B * T, 4 * H, self.off
         g, ws = ops.gemm, self.ws
-        g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
-        if off:        # history frames only: z_t . K_z is added inside the sequence kernel
-            g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
+        if self.sparse_inputs:     # piano-roll frames are ~4 % nonzero: add the kernel rows of the notes that are on
+            ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
+            if off:
+                ops.sparse_proj(BT, off, G4, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec)
+        else:
+            g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
+            if off:        # history frames only: z_t . K_z is added inside the sequence kernel
+                g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
         g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
         ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true,
                            cfg['w_log_var_prior'], P.rows(P.params, 'encoder_h/kernel', D), P.p('encoder_h/bias'),

@@ -146,6 +146,16 @@ def lstm_seq_bwd(B, T, U, dhs, cs, gates_inout, dzsum, c0=None, gate_act=0, H=88
                                       _ptr(dzsum), _stream()), "clv_lstm_seq_bwd")
 
 
+def sparse_proj_supported(nx, N):
+    return bool(_lib.lib().clv_sparse_proj_supported(nx, N))
+
+
+def sparse_proj(R, nx, N, X, ldx, K, out, ldo=None):
+    """out[r,:N] = sum_k X[r,k] K[k,:] visiting only the nonzero inputs of a frame (K resident in LDS)."""
+    check(_lib.lib().clv_sparse_proj(R, nx, N, _ptr(X), ldx, _ptr(K), _ptr(out), ldo if ldo is not None else N,
+                                     _stream()), "clv_sparse_proj")
+
+
 def lstm_pair_supported(L, H=88):
     return bool(_lib.lib().clv_lstm_pair_supported(H, L))
 

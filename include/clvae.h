@@ -245,6 +245,15 @@ int clv_bernoulli_nll(int R, int D, const float* logits, const float* y, int ldy
 /* y[i] += alpha * x[i]  (epoch running sums of the loss scalars stay on the device) */
 int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
 
+/* Input projection of sparse frames: out[r, 0:N] = sum_k X[r,k] * K[k,:] for r < R, X [R,ldx] (nx used
+ * columns), K [nx,N] (16-byte aligned), out rows of stride ldo.  The LSTM input projections of cl_vrnn
+ * (cl_vrnn/model.py:193-196, 218-226) multiply piano-roll frames that are ~4 % nonzero; this keeps K in LDS
+ * and adds only the kernel rows of a frame's nonzero inputs.  Exact for any float input (cost grows with
+ * the number of nonzeros); clv_sparse_proj_supported: nx <= 128, N <= 384, nx*N*4 <= 150 KB. */
+int clv_sparse_proj_supported(int nx, int N);
+size_t clv_sparse_proj_lds_bytes(int nx, int N);
+int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, const float* K, float* out, int ldo, void* stream);
+
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
  * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71).
  * A row is row_elems/chunk pieces of `chunk` floats (frames); piece j of row r is written at

@@ -328,3 +328,27 @@ def test_lstm_fused_input_projection(dev, B, Tn, nx, ldx, dense):
     np.testing.assert_allclose(N(cs), cache['C'], atol=2e-5)
     np.testing.assert_allclose(N(gates).reshape(B, Tn, 4, H)[:, :, 0], cache['Z'].reshape(B, Tn, 4, H)[:, :, 0], atol=3e-5)
     assert not ops.lstm_fused_input_fits(B, 120)                      # 120 x 352 floats do not fit the LDS
+
+
+@pytest.mark.parametrize("R,nx,Nn,ldx,dense", [(1, 88, 352, 88, False), (7, 88, 352, 92, False), (1000, 88, 352, 88, False),
+                                               (33, 90, 352, 92, True), (515, 16, 64, 16, True)])
+def test_sparse_proj_matches_dense(dev, R, nx, Nn, ldx, dense):
+    """out = X . K with only the nonzero inputs visited; exact for binary frames and for dense float frames."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(R + nx)
+    X = np.zeros((R, ldx), np.float32)
+    if dense:
+        X[:, :nx] = rng.standard_normal((R, nx)).astype(np.float32)
+    else:
+        X[:, :nx] = (rng.random((R, nx)) < 0.05).astype(np.float32)
+    X[:, nx:] = 7.0                              # padding columns must be ignored
+    K = rng.standard_normal((nx, Nn)).astype(np.float32)
+    ldo = Nn + 4
+    out = torch.full((R, ldo), -1.0, dtype=torch.float32, device=dev)
+    assert ops.sparse_proj_supported(nx, Nn)
+    ops.sparse_proj(R, nx, Nn, T(X, dev), ldx, T(K, dev), out, ldo)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    ref = X[:, :nx].astype(np.float64) @ K.astype(np.float64)
+    np.testing.assert_allclose(got[:, :Nn], ref, rtol=1e-5, atol=1e-5)
+    assert np.all(got[:, Nn:] == -1.0)
