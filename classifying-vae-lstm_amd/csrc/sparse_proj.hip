@@ -88,6 +88,146 @@ __global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Dense layer over a whole sparse window: out[r,:] = act(sum_j X[r,j] K[j,:] + bias), nx ~ 10^4 (the label
+// path's hW layer reads the flattened window, cl_vrnn/model.py:174-176).  K stays in HBM/L2; a workgroup owns
+// one row, its 16 waves scan 64-input chunks, ballot the nonzeros and add the listed kernel rows (one float2 per
+// lane, N <= 128 and even), 4 row loads in flight; the 16 partial sums meet in LDS.
+// ---------------------------------------------------------------------------
+struct SparseDenseArgs {
+  int R, nx, N, ldx, ldo, act;
+  const float* X;
+  const float* K;      // [nx, N]
+  const float* bias;   // [N] or null
+  float* out;
+};
+
+__global__ __launch_bounds__(1024) void sparse_dense_kernel(SparseDenseArgs a) {
+  __shared__ float2 part[16][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = blockIdx.x;
+  const int n2 = a.N / 2;
+  const int lc = min(lane, n2 - 1);
+  const float2* K2 = reinterpret_cast<const float2*>(a.K);
+  const float* xr = a.X + (size_t)r * a.ldx;
+  float2 acc = make_float2(0.f, 0.f);
+  const int nchunk = (a.nx + 63) / 64;
+  float xn = 0.f;
+  if (wave < nchunk) xn = xr[min(wave * 64 + lane, a.nx - 1)];
+  for (int ch = wave; ch < nchunk; ch += 16) {
+    const float x = xn;
+    const int j0 = ch * 64;
+    if (ch + 16 < nchunk) xn = xr[min((ch + 16) * 64 + lane, a.nx - 1)];
+    unsigned long long m = __ballot(j0 + lane < a.nx && x != 0.f);
+    while (m) {                                   // up to 4 kernel rows in flight
+      int kk[4];
+      float vv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool on = m != 0;
+        const int bit = on ? __builtin_ctzll(m) : 0;
+        m = on ? (m & (m - 1)) : 0;
+        kk[q] = j0 + bit;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), bit));
+        vv[q] = on ? v : 0.f;
+      }
+      float2 kr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kr[q] = K2[(size_t)min(kk[q], a.nx - 1) * n2 + lc];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < n2) {
+    float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { t.x += part[w][lane].x; t.y += part[w][lane].y; }
+    if (a.bias) { t.x += a.bias[2 * lane]; t.y += a.bias[2 * lane + 1]; }
+    if (a.act == CLV_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); }
+    float* op = a.out + (size_t)r * a.ldo + 2 * lane;
+    op[0] = t.x; op[1] = t.y;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Its weight gradient: dK[j,:] = sum_b X[b,j] G[b,:]  (X [Bn,nx] sparse, G [Bn,N] dense, N <= 128 even).
+// A workgroup owns 64 consecutive inputs j; per block of 128 batch rows it stages X[b, j0:j0+64] (transposed
+// access through a padded LDS tile) and G[b,:] in LDS, and each wave walks the nonzero b of its 4 inputs.
+// Every output row is written once: no split-K slabs, no reduce pass.
+// ---------------------------------------------------------------------------
+constexpr int SO_BB = 128;         // batch rows per staged block
+constexpr int SO_JT = 64;          // inputs per workgroup
+constexpr int SO_XS = SO_JT + 1;   // padded tile stride: a column read hits 64 different banks
+struct SparseOuterArgs {
+  int Bn, nx, N, ldx, ldg, ldo;
+  const float* X;
+  const float* G;
+  float* out;          // [nx, ldo]
+};
+
+__global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float so_lds[];
+  float* Xt = so_lds;                               // [SO_BB][SO_XS]
+  float2* Gl = reinterpret_cast<float2*>(so_lds + SO_BB * SO_XS);          // [SO_BB][N/2]   (SO_BB * SO_XS is even)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j0 = blockIdx.x * SO_JT;
+  const int n2 = a.N / 2;
+  const int lc = min(lane, n2 - 1);
+  float2 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float2(0.f, 0.f);
+  for (int b0 = 0; b0 < a.Bn; b0 += SO_BB) {
+    const int nb = min(SO_BB, a.Bn - b0);
+    // stage X[b0:b0+nb, j0:j0+64] and G[b0:b0+nb, :]
+    for (int e = tid; e < SO_BB * SO_JT; e += 1024) {
+      const int bb = e / SO_JT, jj = e % SO_JT;
+      const bool ok = bb < nb && j0 + jj < a.nx;
+      const float v = a.X[(size_t)(b0 + min(bb, nb - 1)) * a.ldx + min(j0 + jj, a.nx - 1)];
+      Xt[bb * SO_XS + jj] = v * (ok ? 1.f : 0.f);
+    }
+    for (int e = tid; e < SO_BB * n2; e += 1024) {
+      const int bb = e / n2, c = e % n2;
+      const float2 v = *reinterpret_cast<const float2*>(a.G + (size_t)(b0 + min(bb, nb - 1)) * a.ldg + 2 * c);
+      const float mk = bb < nb ? 1.f : 0.f;
+      Gl[bb * n2 + c] = make_float2(v.x * mk, v.y * mk);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int jj = wave + 16 * i;                 // this wave's i-th input of the tile
+      const float x0 = Xt[lane * SO_XS + jj], x1 = Xt[(lane + 64) * SO_XS + jj];
+      unsigned long long m0 = __ballot(x0 != 0.f), m1 = __ballot(x1 != 0.f);
+      while (m0) {
+        const int bit = __builtin_ctzll(m0);
+        m0 &= m0 - 1;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), bit));
+        const float2 g2 = Gl[bit * n2 + lc];
+        acc[i].x = fmaf(v, g2.x, acc[i].x); acc[i].y = fmaf(v, g2.y, acc[i].y);
+      }
+      while (m1) {
+        const int bit = __builtin_ctzll(m1);
+        m1 &= m1 - 1;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), bit));
+        const float2 g2 = Gl[(bit + 64) * n2 + lc];
+        acc[i].x = fmaf(v, g2.x, acc[i].x); acc[i].y = fmaf(v, g2.y, acc[i].y);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = j0 + wave + 16 * i;
+    if (j < a.nx && lane < n2) {
+      float* op = a.out + (size_t)j * a.ldo + 2 * lane;
+      op[0] = acc[i].x; op[1] = acc[i].y;
+    }
+  }
+}
+
 }  // namespace clv
 
 extern "C" size_t clv_sparse_proj_lds_bytes(int nx, int N) { return (size_t)nx * N * sizeof(float); }
@@ -114,5 +254,41 @@ extern "C" int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, co
   const int wgs = R < 256 * SP_NW ? (R + SP_NW - 1) / SP_NW : 256;     // one persistent workgroup per CU
   ProfScope p("sparse_proj", s);
   hipLaunchKernelGGL(sparse_proj_kernel, dim3(wgs), dim3(SP_NT), clv_sparse_proj_lds_bytes(nx, N), s, a);
+  return launch_status();
+}
+
+extern "C" int clv_sparse_dense_supported(int N) { return N >= 2 && N <= 128 && N % 2 == 0; }
+
+extern "C" int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, const float* K, const float* bias, int act,
+                                float* out, int ldo, void* stream) {
+  using namespace clv;
+  if (R <= 0 || nx <= 0 || !X || !K || !out || ldx < nx || ldo < N || !clv_sparse_dense_supported(N)) return CLV_EINVAL;
+  if (act != CLV_ACT_NONE && act != CLV_ACT_RELU) return CLV_EINVAL;
+  if (((uintptr_t)K) % 8 != 0) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  SparseDenseArgs a{R, nx, N, ldx, ldo, act, X, K, bias, out};
+  ProfScope p("sparse_dense", s);
+  hipLaunchKernelGGL(sparse_dense_kernel, dim3(R), dim3(1024), 0, s, a);
+  return launch_status();
+}
+
+extern "C" int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+                                void* stream) {
+  using namespace clv;
+  if (Bn <= 0 || nx <= 0 || !X || !G || !out || ldx < nx || ldg < N || ldo < N || !clv_sparse_dense_supported(N))
+    return CLV_EINVAL;
+  if (((uintptr_t)G) % 8 != 0 || ldg % 2 != 0) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)(SO_BB * SO_XS + SO_BB * N) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_outer_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  SparseOuterArgs a{Bn, nx, N, ldx, ldg, ldo, X, G, out};
+  ProfScope p("sparse_outer", s);
+  hipLaunchKernelGGL(sparse_outer_kernel, dim3((nx + SO_JT - 1) / SO_JT), dim3(1024), lds, s, a);
   return launch_status();
 }

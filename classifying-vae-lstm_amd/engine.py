@@ -476,7 +476,10 @@ class VrnnEngine(_EngineBase):
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel
                 g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
-        g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
+        if self.sparse_inputs and ops.sparse_dense_supported(D):
+            ops.sparse_dense(B, T * D, D, X, T * D, P.p('hW/kernel'), P.p('hW/bias'), ACT_RELU, self.hW)
+        else:
+            g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
         ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true,
                            cfg['w_log_var_prior'], P.rows(P.params, 'encoder_h/kernel', D), P.p('encoder_h/bias'),
                            P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
@@ -609,6 +612,9 @@ class VrnnEngine(_EngineBase):
         """hW kernel gradient: the last and largest (T*D*D floats) product of the backward pass."""
         cfg, P, B = self.cfg, self.P, self.B
         D, T = cfg['D'], cfg['T']
+        if self.sparse_inputs and ops.sparse_dense_supported(D):
+            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'))
+            return
         rq = self._rq()
         ops.gemm(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=self.ws, defer=rq)
         if rq is not None:

@@ -156,6 +156,22 @@ def sparse_proj(R, nx, N, X, ldx, K, out, ldo=None):
                                      _stream()), "clv_sparse_proj")
 
 
+def sparse_dense_supported(N):
+    return bool(_lib.lib().clv_sparse_dense_supported(N))
+
+
+def sparse_dense(R, nx, N, X, ldx, K, bias, act, out, ldo=None):
+    """out[r,:N] = act(sum_j X[r,j] K[j,:] + bias) over the nonzero inputs of each row (K read from HBM/L2)."""
+    check(_lib.lib().clv_sparse_dense(R, nx, N, _ptr(X), ldx, _ptr(K), _ptr(bias), act, _ptr(out),
+                                      ldo if ldo is not None else N, _stream()), "clv_sparse_dense")
+
+
+def sparse_outer(Bn, nx, N, X, ldx, G, ldg, out, ldo=None):
+    """out[j,:N] = sum_b X[b,j] G[b,:] (kernel gradient of a Dense layer with sparse inputs)."""
+    check(_lib.lib().clv_sparse_outer(Bn, nx, N, _ptr(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
+                                      _stream()), "clv_sparse_outer")
+
+
 def lstm_pair_supported(L, H=88):
     return bool(_lib.lib().clv_lstm_pair_supported(H, L))
 

@@ -254,6 +254,16 @@ int clv_sparse_proj_supported(int nx, int N);
 size_t clv_sparse_proj_lds_bytes(int nx, int N);
 int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, const float* K, float* out, int ldo, void* stream);
 
+/* The same idea for a Dense layer over a whole flattened window (cl_vrnn's hW layer, model.py:174-176;
+ * nx = seq_length*88 inputs, ~4 % nonzero): out[r,:N] = act(sum_j X[r,j] K[j,:] + bias), act in {none, relu};
+ * and for its kernel gradient dK[j,:N] = sum_b X[b,j] G[b,:] (every output row written once: no split-K
+ * slabs).  N even and <= 128 (clv_sparse_dense_supported). */
+int clv_sparse_dense_supported(int N);
+int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, const float* K, const float* bias, int act,
+                     float* out, int ldo, void* stream);
+int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+                     void* stream);
+
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
  * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71).
  * A row is row_elems/chunk pieces of `chunk` floats (frames); piece j of row r is written at

@@ -352,3 +352,34 @@ def test_sparse_proj_matches_dense(dev, R, nx, Nn, ldx, dense):
     ref = X[:, :nx].astype(np.float64) @ K.astype(np.float64)
     np.testing.assert_allclose(got[:, :Nn], ref, rtol=1e-5, atol=1e-5)
     assert np.all(got[:, Nn:] == -1.0)
+
+
+@pytest.mark.parametrize("R,nx,Nn,dense,relu", [(5, 11264, 88, False, True), (256, 11264, 88, False, True),
+                                                (3, 200, 18, True, False), (2, 64, 128, True, True)])
+def test_sparse_dense_matches_dense(dev, R, nx, Nn, dense, relu):
+    from clvae_amd import ops, _lib
+    rng = np.random.default_rng(R * 7 + Nn)
+    X = rng.standard_normal((R, nx)).astype(np.float32) if dense else (rng.random((R, nx)) < 0.0443).astype(np.float32)
+    K = (rng.standard_normal((nx, Nn)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(Nn).astype(np.float32)
+    out = torch.zeros(R, Nn, dtype=torch.float32, device=dev)
+    ops.sparse_dense(R, nx, Nn, T(X, dev), nx, T(K, dev), T(bias, dev), _lib.ACT_RELU if relu else _lib.ACT_NONE, out)
+    torch.cuda.synchronize()
+    ref = X.astype(np.float64) @ K.astype(np.float64) + bias
+    if relu:
+        ref = np.maximum(ref, 0.0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("Bn,nx,Nn,dense", [(256, 11264, 88, False), (100, 130, 88, False), (300, 70, 18, True),
+                                            (1, 64, 2, True)])
+def test_sparse_outer_matches_dense(dev, Bn, nx, Nn, dense):
+    from clvae_amd import ops
+    rng = np.random.default_rng(Bn + nx)
+    X = rng.standard_normal((Bn, nx)).astype(np.float32) if dense else (rng.random((Bn, nx)) < 0.0443).astype(np.float32)
+    G = rng.standard_normal((Bn, Nn)).astype(np.float32)
+    out = torch.full((nx, Nn), -3.0, dtype=torch.float32, device=dev)
+    ops.sparse_outer(Bn, nx, Nn, T(X, dev), nx, T(G, dev), Nn, out)
+    torch.cuda.synchronize()
+    ref = X.astype(np.float64).T @ G.astype(np.float64)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
