@@ -43,6 +43,8 @@ struct GemmArgs {
   float* partial;    // != nullptr: raw partial sums [z][M][N]
   int vecA, vecB;    // 16-byte vector loads legal for A / B
   int xcd_remap;     // split-K launches: workgroups that share a K chunk run on the same XCD (see gemm_f32_kernel)
+  // fused Bernoulli-NLL epilogue (output head): C = logits (may be null), plus d(loss)/d(logits) and the row NLL
+  const float* bce_y; int bce_ldy; float bce_scale; float* bce_dl; float* bce_rownll;
 };
 
 template <int BMN>
@@ -264,6 +266,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 
   // epilogue: C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+  if (g.bce_y) {
+    // logits -> Bernoulli NLL with Keras' epsilon clip (same arithmetic as bernoulli_nll_kernel).  One n-tile and
+    // WAVES_N == 1 (host-checked): a row's columns sit in this wave, 16 lanes x WN tiles, so the row sum is
+    // WN register adds and a 16-lane butterfly.
+    constexpr float CLIP = 16.11809555f;     // log((1-1e-7)/1e-7)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + (wm * WM + i) * 16 + q * 4 + reg;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int col = n0 + (wn * WN + j) * 16 + r;
+          if (row < Mp && col < g.N) {
+            float a = acc[i][j][reg] * g.alpha;
+            if (g.bias) a += g.bias[col];
+            const float t = g.bce_y[(size_t)row * g.bce_ldy + col];
+            const float l = fminf(fmaxf(a, -CLIP), CLIP);
+            const float e = __expf(-fabsf(l));
+            s += fmaxf(l, 0.f) + __logf(1.f + e) - l * t;
+            const float r1 = fast_rcp(1.f + e);
+            const float sg = l >= 0.f ? r1 : e * r1;
+            const bool inside = (a >= -CLIP) && (a <= CLIP);
+            const size_t o = (size_t)row * ldc + col;
+            if (Cptr) Cptr[o] = a;
+            if (g.bce_dl) g.bce_dl[o] = inside ? g.bce_scale * (sg - t) : 0.f;
+          }
+        }
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (r == 0 && row < Mp && g.bce_rownll) g.bce_rownll[row] = s;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -566,6 +606,7 @@ extern "C" int clv_gemm_f32_deferred(int transa, int transb, int M, int N, int K
   if (act == CLV_ACT_MASKPOS && !aux) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g;
+  memset(&g, 0, sizeof(g));
   g.nprob = 0;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
@@ -735,4 +776,30 @@ extern "C" int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N,
                                    const float* B, int ldb, float beta,
                                    int split_k, void* ws, size_t ws_bytes, void* stream) {
   return clv_gemm_grouped_tn_deferred(probs, nprob, N, K, B, ldb, beta, split_k, ws, ws_bytes, nullptr, stream);
+}
+
+// Output head with the loss fused into the epilogue: logits = A.B + bias (C, optional), row NLL and
+// d(NLL)/d(logits) * scale, see clvae.h.
+extern "C" int clv_gemm_bce_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
+                                const float* Y, int ldy, float scale, float* logits, float* dlogits, int ldc,
+                                float* rownll, void* stream) {
+  using namespace clv;
+  if (M <= 0 || N <= 0 || N > 176 || K <= 0 || !A || !B || !Y || (!dlogits && !rownll && !logits)) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.beta = 0.f;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = logits; g.ldc = ldc;
+  g.bias = bias; g.act = CLV_ACT_NONE;
+  g.vecA = (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
+  g.vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
+  g.k_chunk = (K + 15) / 16 * 16;
+  g.bce_y = Y; g.bce_ldy = ldy; g.bce_scale = scale; g.bce_dl = dlogits; g.bce_rownll = rownll;
+  ProfScope p("gemm_bce", s);
+  // tiles with one wave column (WAVES_N == 1) that cover N in one n-tile
+  if (N <= 16) launch_cfg<2, 1, 4, 1>(g, 0, 0, 1, s);
+  else if (N <= 32) launch_cfg<1, 2, 4, 1>(g, 0, 0, 1, s);
+  else if (N <= 96) launch_cfg<1, 6, 4, 1>(g, 0, 0, 1, s);
+  else launch_cfg<1, 11, 4, 1>(g, 0, 0, 1, s);
+  return launch_status();
 }

@@ -417,15 +417,17 @@ class VrnnEngine(_EngineBase):
         self.dwargs = _f(d, B, 2 * (Cn - 1))
         self.dhW = _f(d, B, D)
 
-    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True):
+    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None):
+        """nll = (scale, need_grads): fuse the Bernoulli NLL of the output head into its GEMM (targets = X)."""
         cfg, P, B = self.cfg, self.P, self.B
+        self._nll_done = False
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         g, ws = ops.gemm, self.ws
         if cfg['use_x_prev'] and Xp.data_ptr() != self.XZ.data_ptr():
             self.XZ.view(B, T, self.xz_ld)[:, :, :D].copy_(Xp.view(B, T, D))     # staging copy only
         if self.fuse_pair:
-            return self._forward_pair(X, eps_W, eps_Z, w_true)
+            return self._forward_pair(X, eps_W, eps_Z, w_true, nll)
         fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
         fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)
         if not fuse_enc:      # dense input projection as a GEMM (inputs too wide for the LDS-resident form)
@@ -462,7 +464,7 @@ class VrnnEngine(_EngineBase):
         # output head (:229-234)
         g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
 
-    def _forward_pair(self, X, eps_W, eps_Z, w_true):
+    def _forward_pair(self, X, eps_W, eps_Z, w_true, nll=None):
         """Forward with both LSTMs, the latent head and the z projection in one persistent kernel."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
@@ -489,7 +491,13 @@ class VrnnEngine(_EngineBase):
                           P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z,
                           self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z, self.xz_ld,
                           self.klterm, gate_act=self.gate_act)
-        g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
+        if nll is not None:     # output head, NLL and dlogits in one launch
+            scale, need_grads = nll
+            ops.gemm_bce(self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale, self.logits,
+                         self.dlogits if need_grads else None, self.rownll, BT, D, H)
+            self._nll_done = True
+        else:
+            g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
 
     def xp_view(self):
         """[B,T,D] strided view of the history columns of the [Xp | Z] buffer (stage batches straight into it)."""
@@ -663,8 +671,9 @@ class VrnnEngine(_EngineBase):
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         inv_bt, inv_b = 1.0 / BT, 1.0 / B
         g, ws, off = ops.gemm, self.ws, self.off
-        self.forward(X, Xp, eps_W, eps_Z, w_true)
-        ops.bernoulli_nll(BT, D, self.logits, X, D, inv_bt, self.rownll, self.dlogits if need_grads else None)
+        self.forward(X, Xp, eps_W, eps_Z, w_true, nll=(inv_bt, need_grads))
+        if not self._nll_done:
+            ops.bernoulli_nll(BT, D, self.logits, X, D, inv_bt, self.rownll, self.dlogits if need_grads else None)
         kl = (self.klterm, BT * L, 1) if self.fuse_pair else (self.rowkl, BT, 1)
         ops.loss_sums([(self.rownll, BT, 1), kl, (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
                        (self.rowloss[:, 2:], B, 3)], self.scal)

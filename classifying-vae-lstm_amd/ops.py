@@ -109,6 +109,14 @@ def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=
                                          wsp, wsb, job, _stream()), "clv_gemm_grouped_tn")
 
 
+def gemm_bce(A, B, bias, Y, scale, logits, dlogits, rownll, M, N, K, lda=None, ldb=None, ldy=None, ldc=None):
+    """Output head + Bernoulli NLL in one launch: logits = A.B + bias, rownll, dlogits = scale*(sigmoid - Y)."""
+    check(_lib.lib().clv_gemm_bce_f32(M, N, K, _ptr(A), lda if lda is not None else K, _ptr(B),
+                                      ldb if ldb is not None else N, _ptr(bias), _ptr(Y), ldy if ldy is not None else N,
+                                      float(scale), _ptr(logits), _ptr(dlogits), ldc if ldc is not None else N,
+                                      _ptr(rownll), _stream()), "clv_gemm_bce_f32")
+
+
 def loss_sums(terms, out):
     """terms: five (tensor, n, stride); out[k] = mean of term k."""
     a = []

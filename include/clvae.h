@@ -241,6 +241,12 @@ int clv_gauss_bwd(int R, int L, const float* zargs, const float* eps, const floa
  * or be NULL for loss only).  cl_vae/model.py:190-191; cl_vrnn/model.py:241-242. */
 int clv_bernoulli_nll(int R, int D, const float* logits, const float* y, int ldy, float scale,
                       float* rownll, float* dlogits, void* stream);
+/* The output head with that loss fused into the GEMM epilogue (cl_vrnn/model.py:229-242 in one launch):
+ *   a = A[M,K].B[K,N] + bias;  logits[M,N] = a (optional, row stride ldc);  rownll[M] and dlogits[M,N] (row stride
+ *   ldc) as clv_bernoulli_nll computes them from a and the targets Y (row stride ldy).  N <= 176. */
+int clv_gemm_bce_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
+                     const float* Y, int ldy, float scale, float* logits, float* dlogits, int ldc,
+                     float* rownll, void* stream);
 
 /* y[i] += alpha * x[i]  (epoch running sums of the loss scalars stay on the device) */
 int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);

@@ -383,3 +383,25 @@ def test_sparse_outer_matches_dense(dev, Bn, nx, Nn, dense):
     torch.cuda.synchronize()
     ref = X.astype(np.float64).T @ G.astype(np.float64)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,Nn,K", [(100, 88, 88), (37, 18, 40), (70, 130, 24)])
+def test_gemm_bce_matches_separate_kernels(dev, M, Nn, K):
+    """Output head with the NLL fused into the GEMM epilogue == GEMM followed by clv_bernoulli_nll."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(M + Nn)
+    A = (rng.standard_normal((M, K)) * 3).astype(np.float32)       # large logits: exercises the epsilon clip
+    Bm = rng.standard_normal((K, Nn)).astype(np.float32)
+    bias = rng.standard_normal(Nn).astype(np.float32)
+    Y = (rng.random((M, Nn)) < 0.2).astype(np.float32)
+    dA, dB, db, dY = T(A, dev), T(Bm, dev), T(bias, dev), T(Y, dev)
+    z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
+    lg1, dl1, rn1, lg2, dl2, rn2 = z(M, Nn), z(M, Nn), z(M), z(M, Nn), z(M, Nn), z(M)
+    ws = ops.Workspace(dev)
+    ops.gemm(dA, dB, lg1, M, Nn, K, bias=db, ws=ws)
+    ops.bernoulli_nll(M, Nn, lg1, dY, Nn, 0.37, rn1, dl1)
+    ops.gemm_bce(dA, dB, db, dY, 0.37, lg2, dl2, rn2, M, Nn, K)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(lg2), N(lg1), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(N(dl2), N(dl1), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(N(rn2), N(rn1), rtol=1e-5, atol=1e-5)
