@@ -2,6 +2,8 @@
 // deterministic reductions.  All HBM-bound row kernels: one thread per row for the
 // tiny label/latent heads (C <= 32, L <= 64), one wave per row for the 88-note
 // Bernoulli NLL (wave64 reduction), partial-slab column sums for bias gradients.
+#include <string.h>
+
 #include "common.h"
 
 namespace clv {
@@ -277,6 +279,36 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
   else *dp = *sp;
 }
 
+// up to 3 gathers that share the row index list (current frames, history frames, labels of a mini-batch) in one
+// launch; idx == nullptr: rows row0 .. row0+rows-1 (staging a contiguous batch)
+struct GatherSeg { const float* src; float* out; int64_t row_elems, chunk, out_ld, nwork0; int vec; };
+struct GatherArgs { GatherSeg seg[3]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; };
+__global__ void gather_multi_kernel(GatherArgs a) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < 3; ++k)
+    if (k < a.nseg && i >= a.seg[k].nwork0) si = k;
+  const float* src = a.seg[0].src; float* out = a.seg[0].out;
+  int64_t row_elems = a.seg[0].row_elems, chunk = a.seg[0].chunk, out_ld = a.seg[0].out_ld, w0 = 0;
+  int vec = a.seg[0].vec;
+#pragma unroll
+  for (int k = 1; k < 3; ++k)
+    if (si == k) { src = a.seg[k].src; out = a.seg[k].out; row_elems = a.seg[k].row_elems; chunk = a.seg[k].chunk;
+                   out_ld = a.seg[k].out_ld; w0 = a.seg[k].nwork0; vec = a.seg[k].vec; }
+  i -= w0;
+  const int W = vec ? 4 : 1;                       // work item = one float4 (aligned segments) or one float
+  const int64_t nw = row_elems / W;
+  if (i >= a.rows * nw) return;
+  const int64_t r = i / nw, c = (i % nw) * W;
+  const int64_t piece = c / chunk, within = c % chunk;
+  const int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
+  const float* sp = src + sr * row_elems + c;
+  float* dp = out + (r * (row_elems / chunk) + piece) * out_ld + within;
+  if (vec) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
+  else *dp = *sp;
+}
+
 __global__ void bernoulli_sample_kernel(int64_t n, const float* p, const float* u, float* x) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = (u[i] <= p[i]) ? 1.f : 0.f;
@@ -404,6 +436,30 @@ extern "C" int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src
   else
     hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, row_elems,
                        src, idx, out, chunk, out_ld);
+  return launch_status();
+}
+
+extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
+                                     const float* const* src, float* const* out, const int64_t* row_elems,
+                                     const int64_t* chunk, const int64_t* out_ld, void* stream) {
+  if (rows <= 0 || nseg < 1 || nseg > 3 || !src || !out || !row_elems || !chunk || !out_ld) return CLV_EINVAL;
+  GatherArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nseg = nseg; a.rows = rows; a.idx = idx; a.row0 = row0;
+  int64_t work = 0;
+  for (int k = 0; k < nseg; ++k) {
+    if (!src[k] || !out[k] || row_elems[k] <= 0) return CLV_EINVAL;
+    const int64_t ch = chunk[k] > 0 ? chunk[k] : row_elems[k];
+    if (row_elems[k] % ch != 0) return CLV_EINVAL;
+    const int64_t ld = chunk[k] > 0 ? out_ld[k] : row_elems[k];
+    const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % 16 == 0 &&
+                    ((uintptr_t)out[k]) % 16 == 0;
+    a.seg[k] = GatherSeg{src[k], out[k], row_elems[k], ch, ld, work, vec};
+    work += ((rows * (row_elems[k] / (vec ? 4 : 1)) + 255) / 256) * 256;        // segments start on block boundaries
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("gather_rows", s);
+  hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)(work / 256)), dim3(256), 0, s, a);
   return launch_status();
 }
 

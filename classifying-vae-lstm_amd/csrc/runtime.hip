@@ -82,6 +82,28 @@ __global__ void philox_kernel(float* out, int64_t n, uint32_t k0, uint32_t k1, u
   }
 }
 
+// two independent draws (the label noise and the latent noise of a training step) in one launch: blocks
+// [0, nb0) serve the first, the rest the second
+struct PhiloxSeg { float* out; int64_t n; uint32_t stream_id; uint64_t first; };
+__global__ void philox_normal2_kernel(PhiloxSeg a, PhiloxSeg b, unsigned nb0, uint32_t k0, uint32_t k1, uint32_t step,
+                                      const int32_t* step_dev) {
+  const bool second = blockIdx.x >= nb0;
+  const PhiloxSeg sg = second ? b : a;
+  const int64_t q = (int64_t)(blockIdx.x - (second ? nb0 : 0u)) * blockDim.x + threadIdx.x;
+  const uint64_t ctr = (sg.first >> 2) + (uint64_t)q;
+  const uint32_t st = step + (step_dev ? (uint32_t)*step_dev : 0u);
+  uint32_t r[4];
+  philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), sg.stream_id, st, k0, k1, r);
+  const float r0 = sqrtf(-2.f * logf(u01(r[0]))), t0 = 6.283185307179586f * u01(r[1]);
+  const float r1 = sqrtf(-2.f * logf(u01(r[2]))), t1 = 6.283185307179586f * u01(r[3]);
+  const float v[4] = {r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1), r1 * sinf(t1)};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t gi = ctr * 4 + j;
+    if (gi >= sg.first && gi < sg.first + (uint64_t)sg.n) sg.out[gi - sg.first] = v[j];
+  }
+}
+
 template <bool NORMAL>
 static int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t step, const int32_t* step_dev,
                          uint32_t stream_id, uint64_t first, hipStream_t s) {
@@ -124,6 +146,22 @@ extern "C" const char* clv_error_string(int code) {
 extern "C" int clv_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, const int32_t* step_dev,
                                  uint32_t stream_id, uint64_t first_index, void* stream) {
   return launch_philox<true>(out, n, seed, step, step_dev, stream_id, first_index, (hipStream_t)stream);
+}
+extern "C" int clv_philox_normal2(float* out0, int64_t n0, uint32_t stream_id0, uint64_t first_index0,
+                                  float* out1, int64_t n1, uint32_t stream_id1, uint64_t first_index1,
+                                  uint64_t seed, uint32_t step, const int32_t* step_dev, void* stream) {
+  if (!out0 || !out1 || n0 <= 0 || n1 <= 0) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  auto nblocks = [](uint64_t first, int64_t n) {
+    const uint64_t quads = ((first + (uint64_t)n + 3) >> 2) - (first >> 2);
+    return (unsigned)((quads + 255) / 256);
+  };
+  const unsigned nb0 = nblocks(first_index0, n0), nb1 = nblocks(first_index1, n1);
+  PhiloxSeg a{out0, n0, stream_id0, first_index0}, b{out1, n1, stream_id1, first_index1};
+  ProfScope p("philox_normal", s);
+  hipLaunchKernelGGL(philox_normal2_kernel, dim3(nb0 + nb1), dim3(256), 0, s, a, b, nb0, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), step, step_dev);
+  return launch_status();
 }
 extern "C" int clv_philox_uniform(float* out, int64_t n, uint64_t seed, uint32_t step, const int32_t* step_dev,
                                   uint32_t stream_id, uint64_t first_index, void* stream) {

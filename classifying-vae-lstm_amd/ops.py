@@ -256,6 +256,24 @@ def gather_rows(rows, row_elems, src, idx, out, chunk=0, out_ld=0):
           "clv_gather_rows")
 
 
+def gather_rows_multi(rows, idx, segs, row0=0):
+    """segs: up to 3 (src, out, row_elems, chunk, out_ld); one launch; idx None = rows row0..row0+rows-1."""
+    n = len(segs)
+    P, I = C.c_void_p * n, C.c_int64 * n
+    src = P(*[s_[0].data_ptr() for s_ in segs])
+    out = P(*[s_[1].data_ptr() for s_ in segs])
+    re = I(*[int(s_[2]) for s_ in segs])
+    ch = I(*[int(s_[3]) for s_ in segs])
+    ld = I(*[int(s_[4]) for s_ in segs])
+    check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, out, re, ch, ld, _stream()),
+          "clv_gather_rows_multi")
+
+
+def philox_normal2(out0, n0, stream0, first0, out1, n1, stream1, first1, seed, step=0, step_dev=None):
+    check(_lib.lib().clv_philox_normal2(_ptr(out0), n0, stream0, first0, _ptr(out1), n1, stream1, first1, seed, step,
+                                        _ptr(step_dev), _stream()), "clv_philox_normal2")
+
+
 def philox_normal(out, n, seed, step=0, stream_id=0, first_index=0, step_dev=None):
     check(_lib.lib().clv_philox_normal(_ptr(out), n, seed, step, _ptr(step_dev), stream_id, first_index, _stream()),
           "clv_philox_normal")

@@ -54,8 +54,9 @@ class TrainStep:
         T = eng.cfg['T'] if self.is_vrnn else 1
         row0 = self.rank * B                         # global row of this rank's first sample
         it = eng.P.iterations
-        ops.philox_normal(self.eps_w, B * C1, self.seed, 0, 2 * stream_offset, eps_first_index(row0, C1), step_dev=it)
-        ops.philox_normal(self.eps_z, B * T * L, self.seed, 0, 2 * stream_offset + 1, eps_first_index(row0, T * L), step_dev=it)
+        ops.philox_normal2(self.eps_w, B * C1, 2 * stream_offset, eps_first_index(row0, C1),
+                           self.eps_z, B * T * L, 2 * stream_offset + 1, eps_first_index(row0, T * L),
+                           self.seed, 0, step_dev=it)
 
     def _main(self):
         self.draw_noise()
@@ -72,24 +73,25 @@ class TrainStep:
         self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm)
 
     # -- public -----------------------------------------------------------
+    def _segments(self, cur, hist, w):
+        """(src, out, row_elems, chunk, out_ld) of the current frames, history frames and labels of a batch."""
+        row = int(self.X[0].numel())
+        segs = [(cur, self.X, row, 0, 0)]
+        if hist is not None:
+            if self.xp_ld:      # history frames go straight into the [Xp | Z] decoder-input buffer
+                segs.append((hist, self.Xp, row, self.eng.cfg['D'], self.xp_ld))
+            else:
+                segs.append((hist, self.Xp, row, 0, 0))
+        segs.append((w, self.w_true, int(self.w_true.shape[1]), 0, 0))
+        return segs
+
     def stage_batch(self, X, Xp, w_true):
-        """Copy one batch (device tensors) into the fixed staging buffers."""
-        self.X.copy_(X.view_as(self.X))
-        if Xp is not None:
-            self.Xp.copy_(Xp.view(self.Xp.shape))
-        self.w_true.copy_(w_true)
+        """Copy one batch (contiguous device tensors) into the fixed staging buffers: one launch."""
+        ops.gather_rows_multi(self.eng.B, None, self._segments(X, Xp, w_true))
 
     def gather_batch(self, d_cur, d_hist, d_w, ib):
-        """Assemble the batch rows `ib` (device int64 indices) from the HBM-resident data set."""
-        B = self.eng.B
-        row = int(d_cur[0].numel())
-        ops.gather_rows(B, row, d_cur, ib, self.X)
-        if d_hist is not None:
-            if self.xp_ld:
-                ops.gather_rows(B, row, d_hist, ib, self.Xp, chunk=self.eng.cfg['D'], out_ld=self.xp_ld)
-            else:
-                ops.gather_rows(B, row, d_hist, ib, self.Xp)
-        ops.gather_rows(B, d_w.shape[1], d_w, ib, self.w_true)
+        """Assemble the batch rows `ib` (device int64 indices) from the HBM-resident data set: one launch."""
+        ops.gather_rows_multi(self.eng.B, ib, self._segments(d_cur, d_hist, d_w))
 
     def _eager(self):
         self._main()

@@ -276,6 +276,12 @@ int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float
  * out + (r*pieces + j)*out_ld.  chunk <= 0 means one contiguous piece (out_ld = row_elems). */
 int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out,
                     int64_t chunk, int64_t out_ld, void* stream);
+/* Up to 3 such gathers that share one row list in a single launch (current frames, history frames and labels
+ * of a mini-batch).  idx == NULL takes the consecutive rows row0 .. row0+rows-1 (staging a contiguous batch).
+ * Per segment k: src[k] rows of row_elems[k] floats, written like clv_gather_rows with chunk[k] / out_ld[k]. */
+int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
+                          const float* const* src, float* const* out, const int64_t* row_elems,
+                          const int64_t* chunk, const int64_t* out_ld, void* stream);
 
 /* the five loss scalars of a step in one launch: out[k] = scale[k] * sum_{i<n[k]} x[k][i*stride[k]], k < 5
  * (vae, kl_z, kl_w, w_rec, acc means; fixed summation order => deterministic). */
@@ -329,6 +335,11 @@ int clv_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, const
                       uint32_t stream_id, uint64_t first_index, void* stream);
 int clv_philox_uniform(float* out, int64_t n, uint64_t seed, uint32_t step, const int32_t* step_dev,
                        uint32_t stream_id, uint64_t first_index, void* stream);
+/* Two normal draws (same seed/step, their own stream ids and first indices) in one launch: the label noise and
+ * the latent noise of a training step.  Values are identical to two clv_philox_normal calls. */
+int clv_philox_normal2(float* out0, int64_t n0, uint32_t stream_id0, uint64_t first_index0,
+                       float* out1, int64_t n1, uint32_t stream_id1, uint64_t first_index1,
+                       uint64_t seed, uint32_t step, const int32_t* step_dev, void* stream);
 /* *counter += v on the device (advances the Philox step between replays of a captured sampling step) */
 int clv_i32_add(int32_t* counter, int32_t v, void* stream);
 /* x[i] = (u[i] <= p[i]) ? 1 : 0   -- sample_x */
