@@ -251,7 +251,7 @@ def main():
         traffic = None       # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_%s.json' % args.workload)))
-            traffic = round(pm['lstm_seq_bytes_per_launch']) if w['model'] == 'cl_vrnn' else None
+            traffic = round(pm.get('dominant_bytes_per_launch', pm.get('lstm_seq_bytes_per_launch'))) if w['model'] == 'cl_vrnn' else None
         except Exception:
             pass
         roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
