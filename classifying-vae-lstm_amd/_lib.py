@@ -119,6 +119,9 @@ def lib():
             raise ClvError(
                 "libclvae_hip.so is not built (%s). Run `python __graft_entry__.py` or "
                 "`make -C classifying-vae-lstm_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # torch ships its own ROCm runtime: it has to be the first HIP runtime mapped into the process, otherwise
+        # torch.cuda later reports "No HIP GPUs are available"
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)      # AttributeError if the ABI drifted

@@ -8,6 +8,8 @@ Everything step-dependent lives on the device (Adam `iterations` counter, which 
 the Philox noise stream), so the captured hipGraph is replayed unchanged every step; the
 batch is staged into fixed buffers (`stage_batch`).
 """
+import os
+
 import torch
 
 from . import ops
@@ -42,7 +44,10 @@ class TrainStep:
         self.eps_w = torch.zeros(B, C1, **f)
         self.eps_z = torch.zeros(B * T, L, **f)
         tail = engine.tail_range() if self.is_vrnn else (0, 0)
-        self.ar = GradAllReduce(engine.P.grads, tail[0], tail[1], group) if world > 1 else None
+        # CLV_FORCE_DP_GRAPHS=1: take the multi-GPU schedule (main graph, tail graph, update graph around the two
+        # gradient buckets) on a single GPU too, with the collectives as no-ops -- lets one box test that path
+        force = os.environ.get('CLV_FORCE_DP_GRAPHS') == '1'
+        self.ar = GradAllReduce(engine.P.grads, tail[0], tail[1], group) if (world > 1 or force) else None
         self._graphs = None
         self._warm = False
 

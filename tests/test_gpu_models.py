@@ -188,3 +188,30 @@ def test_cl_vrnn_step_is_graph_replayable(dev):
     for k in w_graph:
         np.testing.assert_array_equal(w_graph[k], w_eager[k])
     assert int(eng.P.iterations.item()) == 3
+
+
+def test_cl_vrnn_dp_graph_schedule_matches_single_graph(dev, monkeypatch):
+    """The multi-GPU schedule (three graphs around the two gradient buckets) gives the same weights as the
+    single-graph step when the collectives are no-ops (one GPU)."""
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    cfg = O.vrnn_config(latent_dim=2, seq_length=12, n_classes=10, use_x_prev=True)
+    B, Tn = 8, 12
+    rng = np.random.default_rng(9)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=4).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    X, Xp, wt = T(win[:, 1:], dev), T(win[:, :-1], dev), T(np.eye(10)[rng.integers(0, 10, B)], dev)
+    out = []
+    for force in ('0', '1'):
+        monkeypatch.setenv('CLV_FORCE_DP_GRAPHS', force)
+        eng = VrnnEngine(cfg, B, dev)
+        eng.P.set_weights(p)
+        ts = TrainStep(eng, seed=77)
+        assert (ts.ar is not None) == (force == '1')
+        for _ in range(4):
+            ts.stage_batch(X, Xp, wt)
+            ts.step()
+        torch.cuda.synchronize()
+        out.append(eng.P.get_weights())
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k])
