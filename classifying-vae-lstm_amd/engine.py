@@ -616,54 +616,30 @@ class VrnnEngine(_EngineBase):
         ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
                              dict(A=None, M=1, C=P.g(name + '/bias'), ones=True)], G4, B, dzsum, ws, defer=rq)
 
-    def grads_tail(self, X):
-        """hW kernel gradient: the last and largest (T*D*D floats) product of the backward pass."""
-        cfg, P, B = self.cfg, self.P, self.B
-        D, T = cfg['D'], cfg['T']
-        if self.sparse_inputs and ops.sparse_dense_supported(D):
-            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'))
-            return
-        rq = self._rq()
-        ops.gemm(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=self.ws, defer=rq)
-        if rq is not None:
-            rq.flush()
-
     def _rq(self):
         """The deferred-reduction queue (single-stream schedule only: a pending job pins its scratch buffer)."""
         return self.rq if self.side is None else None
 
     def tail_range(self):
-        """(offset, numel) of the tail bucket inside the flat gradient buffer."""
+        """(offset, numel) of the hW-kernel bucket inside the flat gradient buffer: complete after
+        loss_and_grads(do_tail=False), i.e. before grads_tail() has produced the rest."""
         D, T = self.cfg['D'], self.cfg['T']
         return self.P.offsets['hW/kernel'], T * D * D
 
-    def _bptt_separate(self, X, eps_Z, rq, ws, ws2):
-        """Backward through both LSTMs and the latent head as separate launches (any latent_dim)."""
+    def _bptt_separate(self, eps_Z, ws):
+        """Backward through both LSTMs and the latent head as separate launches (any latent_dim); leaves dz in
+        gates_*, dzsum_*, dzargs."""
         cfg, P, B = self.cfg, self.P, self.B
-        D, H, L, T = cfg['D'], cfg['H'], cfg['L'], cfg['T']
+        H, L, T = cfg['H'], cfg['L'], cfg['T']
         BT, G4, off = B * T, 4 * H, self.off
-        inv_bt = 1.0 / BT
         g = ops.gemm
-        # decoder BPTT (VALU) ...
         ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
                          self.dzsum_dec, gate_act=self.gate_act)
-        dz = self.gates_dec
-        # ... then its weight gradients (MFMA) go to the side stream and overlap the encoder BPTT
-        with self._side():
-            self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, dz, self.dzsum_dec, off + L, ws2)
-        g(dz, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
-        # latent heads
-        ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight * inv_bt, self.dzargs)
+        g(self.gates_dec, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
+        ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight / BT, self.dzargs)
         g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
-        with self._side():
-            ops.gemm_grouped_tn([dict(A=self.hs_enc, lda=H, M=H, C=P.g('Zargs/kernel')),
-                                 dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws2, defer=rq)
-        # encoder BPTT
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                          self.dzsum_enc, gate_act=self.gate_act)
-        dz = self.gates_enc
-        with self._side():
-            self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, dz, self.dzsum_enc, D, ws2)
 
     def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True):
         cfg, P, B = self.cfg, self.P, self.B
@@ -680,13 +656,9 @@ class VrnnEngine(_EngineBase):
         if not need_grads:
             self._join()
             return
-        ws2 = self.ws2 if self.side is not None else self.ws
-        # output head: its weight gradient runs on the side stream under the decoder BPTT
-        rq = self._rq()
-        with self._side():        # kernel and bias gradient in one pass over dlogits (bias = an implicit row of ones)
-            ops.gemm_grouped_tn([dict(A=self.hs_dec, lda=H, M=H, C=P.g('X_decoded_mean/kernel')),
-                                 dict(A=None, M=1, C=P.g('X_decoded_mean/bias'), ones=True)], D, BT, self.dlogits, ws2,
-                                defer=rq)
+        # Backward, early part: everything on the critical chain dlogits -> BPTT -> label path -> hW kernel gradient.
+        # The hW kernel (T*D*D floats) is 87 % of the gradient bytes: with N > 1 GPUs its all-reduce bucket starts
+        # here and runs under the weight-gradient products of grads_tail().
         g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
         if self.fuse_pair:
             # decoder BPTT, dZ, the latent head's backward, dh_enc and encoder BPTT: one persistent launch
@@ -694,24 +666,37 @@ class VrnnEngine(_EngineBase):
                               P.p('encoder_h/recurrent_kernel'), P.rows(P.params, 'decoder_h/kernel', off),
                               P.p('Zargs/kernel'), self.dhs, self.cs_dec, self.cs_enc, self.gates_dec, self.gates_enc,
                               self.dzsum_dec, self.dzsum_enc, self.zargs, eps_Z, self.dzargs, gate_act=self.gate_act)
-            self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec, self.dzsum_dec,
-                              off + L, ws)
-            ops.gemm_grouped_tn([dict(A=self.hs_enc, lda=H, M=H, C=P.g('Zargs/kernel')),
-                                 dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws, defer=rq)
-            self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
         else:
-            self._bptt_separate(X, eps_Z, rq, ws, ws2)
-        # label head: dW from both LSTMs, label backward, dWargs and dhW in one launch; then the two Dense
-        # layers' (dW, db) pairs as grouped GEMMs
+            self._bptt_separate(eps_Z, ws)
+        # label head: dW from both LSTMs, label backward, dWargs and dhW in one launch
         ops.vrnn_label_bwd(B, D, Cn, G4, self.dzsum_enc, self.dzsum_dec, P.rows(P.params, 'encoder_h/kernel', D),
                            P.rows(P.params, 'decoder_h/kernel', off + L), self.wargs, eps_W, w_true, self.W, self.hW,
                            P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
                            self.dwargs, self.dhW)
+        if self.sparse_inputs and ops.sparse_dense_supported(D):
+            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'))
+        else:
+            g(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)
+        if do_tail:
+            self.grads_tail(X)
+
+    def grads_tail(self, X):
+        """Backward, late part: every other weight gradient (products over dz / dlogits / dzargs / dwargs that
+        nothing downstream waits for), their split-K reductions in one launch."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
+        C1, BT, off = Cn - 1, B * T, self.off
+        ws, rq = self.ws, self._rq()
+        # output head: kernel and bias gradient in one pass over dlogits (bias = an implicit row of ones)
+        ops.gemm_grouped_tn([dict(A=self.hs_dec, lda=H, M=H, C=P.g('X_decoded_mean/kernel')),
+                             dict(A=None, M=1, C=P.g('X_decoded_mean/bias'), ones=True)], D, BT, self.dlogits, ws, defer=rq)
+        self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec, self.dzsum_dec,
+                          off + L, ws)
+        ops.gemm_grouped_tn([dict(A=self.hs_enc, lda=H, M=H, C=P.g('Zargs/kernel')),
+                             dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws, defer=rq)
+        self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
         ops.gemm_grouped_tn([dict(A=self.hW, lda=D, M=D, C=P.g('Wargs/kernel')),
                              dict(A=None, M=1, C=P.g('Wargs/bias'), ones=True)], 2 * C1, B, self.dwargs, ws, defer=rq)
         ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
-        self._join()
         if rq is not None:
             rq.flush()
-        if do_tail:
-            self.grads_tail(X)

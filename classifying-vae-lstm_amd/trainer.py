@@ -101,10 +101,10 @@ class TrainStep:
     def _eager(self):
         self._main()
         if self.ar is not None:
-            self.ar.reduce_main()
+            self.ar.reduce_tail()       # the hW-kernel bucket (most of the bytes) is complete: reduce it under _tail()
         self._tail()
         if self.ar is not None:
-            self.ar.reduce_tail()
+            self.ar.reduce_main()
             self.ar.wait()
         self._update()
 
@@ -134,8 +134,8 @@ class TrainStep:
         else:
             g1, g2, g3 = self._graphs
             g1.launch()
-            self.ar.reduce_main()
+            self.ar.reduce_tail()       # hW-kernel bucket, overlaps the weight-gradient products of g2
             g2.launch()
-            self.ar.reduce_tail()
+            self.ar.reduce_main()
             self.ar.wait()
             g3.launch()
