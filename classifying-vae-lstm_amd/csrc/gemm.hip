@@ -677,17 +677,23 @@ extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, vo
 
 // Grouped weight-gradient GEMM: C_p[M_p,N] = A_p^T . B for up to 4 problems that share B [K,N] (one pass over
 // dz for all of an LSTM's kernel / recurrent-kernel gradients, or dW and db of a Dense layer).
-static int grouped_tiles(const clv_gemm_prob* probs, int nprob, int bm) {
+static int grouped_tiles(const clv_gemm_prob* probs, int nprob, int bm) {   // total m-tiles of a grouped launch
   int t = 0;
   for (int i = 0; i < nprob; ++i) t += (probs[i].M + bm - 1) / bm;
   return t;
 }
 
 // tile of a grouped launch: narrow outputs (a latent head's 2L columns) get a narrow tile
-static void grouped_tile(int N, int& bm, int& bn) {
+static int grouped_tiles(const clv_gemm_prob* probs, int nprob, int bm);
+static void grouped_tile(const clv_gemm_prob* probs, int nprob, int N, int& bm, int& bn) {
   if (N <= 16) { bm = 128; bn = 16; }
   else if (N <= 32) { bm = 64; bn = 32; }
-  else { bm = 96; bn = 96; }
+  else {
+    // 96- or 128-row tiles, whichever pads the problems' row counts less (e.g. [120 | 88] rows: 3 tiles of 96 = 288
+    // padded rows, 2 tiles of 128 = 256)
+    bn = 96;
+    bm = grouped_tiles(probs, nprob, 128) * 128 < grouped_tiles(probs, nprob, 96) * 96 ? 128 : 96;
+  }
 }
 
 extern "C" int clv_gemm_grouped_auto_split(const clv_gemm_prob* probs, int nprob, int N, int K) {
@@ -696,7 +702,7 @@ extern "C" int clv_gemm_grouped_auto_split(const clv_gemm_prob* probs, int nprob
   for (int i = 0; i < nprob; ++i) rows += probs[i].M;
   if (rows <= clv::SK_ROWS && K <= 4096) return 1;      // skinny VALU kernel, never split
   int bm, bn;
-  grouped_tile(N, bm, bn);
+  grouped_tile(probs, nprob, N, bm, bn);
   const long tiles = (long)grouped_tiles(probs, nprob, bm) * ((N + bn - 1) / bn);
   if (tiles >= 256 || K < 128) return 1;
   long s = (clv::split_target() + tiles - 1) / tiles;
@@ -724,7 +730,7 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   g.nprob = nprob;
   int tile = 0, row = 0, vec = 1;
   int bm, bn;
-  grouped_tile(N, bm, bn);
+  grouped_tile(probs, nprob, N, bm, bn);
   for (int i = 0; i < nprob; ++i) {
     const clv_gemm_prob& p = probs[i];
     if (p.M <= 0 || !p.C || (!p.ones && !p.A) || (p.ones && p.M != 1)) return CLV_EINVAL;
@@ -760,6 +766,7 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
     ProfScope p(glabel, s);
     if (bn == 16) launch_cfg<2, 1, 4, 1>(g, 1, 0, splits, s);          // 128 x 16
     else if (bn == 32) launch_cfg<1, 2, 4, 1>(g, 1, 0, splits, s);     // 64 x 32
+    else if (bm == 128) launch_cfg<4, 3, 2, 2>(g, 1, 0, splits, s);    // 128 x 96
     else launch_cfg<3, 3, 2, 2>(g, 1, 0, splits, s);                   // 96 x 96
   }
   int st = launch_status();

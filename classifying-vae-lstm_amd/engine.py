@@ -430,11 +430,17 @@ class VrnnEngine(_EngineBase):
             return self._forward_pair(X, eps_W, eps_Z, w_true, nll)
         fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
         fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)
-        if not fuse_enc:      # dense input projection as a GEMM (inputs too wide for the LDS-resident form)
-            with self._side():
-                g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
+        if not fuse_enc:
+            if self.sparse_inputs:     # add the kernel rows of the notes that are on (csrc/sparse_proj.hip)
+                ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
+            else:
+                with self._side():
+                    g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
         # label path (:174-191)
-        g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
+        if self.sparse_inputs and ops.sparse_dense_supported(D):
+            ops.sparse_dense(B, T * D, D, X, T * D, P.p('hW/kernel'), P.p('hW/bias'), ACT_RELU, self.hW)
+        else:
+            g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
         # Wargs head, logistic-normal sample, label losses and both per-row LSTM biases (W.K_w + b): one launch
         off = self.off
         ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true,
@@ -461,8 +467,20 @@ class VrnnEngine(_EngineBase):
             g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
             ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
                              self.cs_dec, self.gates_dec, gate_act=self.gate_act)
-        # output head (:229-234)
-        g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
+        # output head (:229-234), with the NLL fused into its epilogue when the caller wants the loss
+        self._output_head(X, nll)
+
+    def _output_head(self, X, nll):
+        cfg, P = self.cfg, self.P
+        D, H, BT = cfg['D'], cfg['H'], self.B * cfg['T']
+        if nll is not None:
+            scale, need_grads = nll
+            ops.gemm_bce(self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale, self.logits,
+                         self.dlogits if need_grads else None, self.rownll, BT, D, H)
+            self._nll_done = True
+        else:
+            ops.gemm(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'),
+                     ws=self.ws)
 
     def _forward_pair(self, X, eps_W, eps_Z, w_true, nll=None):
         """Forward with both LSTMs, the latent head and the z projection in one persistent kernel."""
@@ -491,13 +509,7 @@ class VrnnEngine(_EngineBase):
                           P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z,
                           self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z, self.xz_ld,
                           self.klterm, gate_act=self.gate_act)
-        if nll is not None:     # output head, NLL and dlogits in one launch
-            scale, need_grads = nll
-            ops.gemm_bce(self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale, self.logits,
-                         self.dlogits if need_grads else None, self.rownll, BT, D, H)
-            self._nll_done = True
-        else:
-            g(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'), ws=ws)
+        self._output_head(X, nll)
 
     def xp_view(self):
         """[B,T,D] strided view of the history columns of the [Xp | Z] buffer (stage batches straight into it)."""
