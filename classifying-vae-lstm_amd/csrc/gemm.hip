@@ -55,9 +55,9 @@ struct LdsStride {  // == 16 (mod 32), multiple of 4
 // ---- global -> register staging -------------------------------------------
 // MC: the tile dimension (m or n) is contiguous in memory: elem(mn,k) = p[k*ld + mn]
 // KC: k is contiguous:                                  elem(mn,k) = p[mn*ld + k]
-template <int BMN, bool KC>
+template <int BMN, bool KC, int BKT = 16>
 struct TileLoader {
-  static constexpr int BK = 16;
+  static constexpr int BK = BKT;
   static constexpr int NV = BMN * BK / 4;              // float4 per tile
   static constexpr int PER = (NV + 255) / 256;         // float4 per thread
   static constexpr int LD = LdsStride<BMN>::value;
@@ -80,7 +80,7 @@ struct TileLoader {
         float4 v;
         bool ok0, ok1, ok2, ok3;
         if (KC) {
-          const int mn = idx >> 2, k4 = (idx & 3) * 4;
+          const int mn = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
           const int gm = mn0 + mn, gk = k0 + k4;
           const float* src = p + (size_t)min(gm, dim_mn - 1) * ld + min(gk, ld - 4);
           v = *reinterpret_cast<const float4*>(src);
@@ -107,7 +107,7 @@ struct TileLoader {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < NV) {
         if (KC) {
-          int mn = idx >> 2, k4 = (idx & 3) * 4;
+          int mn = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
           int gm = mn0 + mn, gk = k0 + k4;
           if (gm < dim_mn) {
             const float* src = p + (size_t)gm * ld + gk;
@@ -153,7 +153,7 @@ struct TileLoader {
                                rr[i].z * ((mk[i] & 4) ? 1.f : 0.f), rr[i].w * ((mk[i] & 8) ? 1.f : 0.f));
       if (idx < NV) {
         if (KC) {
-          int mn = idx >> 2, k4 = (idx & 3) * 4;
+          int mn = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
           lds[(k4 + 0) * LD + mn] = r_i.x;
           lds[(k4 + 1) * LD + mn] = r_i.y;
           lds[(k4 + 2) * LD + mn] = r_i.z;
@@ -175,12 +175,12 @@ __device__ __forceinline__ float apply_act(float v, int act, float aux) {
   return v;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB, int BK = 16>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N, BK = 16;
-  using LA = TileLoader<BM, !TA>;   // A row-major [M,K] => k contiguous
-  using LB = TileLoader<BN, TB>;    // B row-major [K,N] => n contiguous
+  constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
+  using LA = TileLoader<BM, !TA, BK>;   // A row-major [M,K] => k contiguous
+  using LB = TileLoader<BN, TB, BK>;    // B row-major [K,N] => n contiguous
   constexpr int LDA = LA::LD, LDB = LB::LD;
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
   float* As = smem;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const float* as = As + cur * BK * LDA + wm * WM * 16 + r;
     const float* bs = Bs + cur * BK * LDB + wn * WN * 16 + r;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < BK / 4; ++ks) {
       float a[WM], b[WN];
 #pragma unroll
       for (int i = 0; i < WM; ++i) a[i] = as[(ks * 4 + q) * LDA + i * 16];
@@ -525,6 +525,14 @@ static void launch_cfg(const GemmArgs& g_in, int ta, int tb, int splits, hipStre
   }
   dim3 grid(g.nprob > 0 ? g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BM - 1) / BM : (g.M + BM - 1) / BM,
             (g.N + BN - 1) / BN, splits);
+  if (ta && !tb && g.nprob > 0 && BM >= 96 && BN == 96) {      // grouped weight gradients: optional deeper k-tile
+    static int bk32 = -1;
+    if (bk32 < 0) { const char* e = getenv("CLV_GEMM_BK32"); bk32 = e ? atoi(e) : 0; }
+    if (bk32) {
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, true, false, 32>), grid, dim3(256), 0, s, g);
+      return;
+    }
+  }
   if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, false, false>), grid, dim3(256), 0, s, g);
   else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, false, true>), grid, dim3(256), 0, s, g);
   else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, true, false>), grid, dim3(256), 0, s, g);

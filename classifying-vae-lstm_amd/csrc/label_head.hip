@@ -41,8 +41,15 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_fwd_kernel(LabelFwdArgs a) {
   if (tid < a.D) s_h[tid] = a.hW[(size_t)b * a.D + tid];
   __syncthreads();
   if (tid < NA) {
+    // 8 kernel rows in flight (a one-load-per-iteration loop pays an L2 round trip per row: 88 of them)
     float acc = a.ba[tid];
-    for (int k = 0; k < a.D; ++k) acc = fmaf(s_h[k], a.Ka[(size_t)k * NA + tid], acc);
+    for (int k0 = 0; k0 < a.D; k0 += 8) {
+      float kv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kv[q] = a.Ka[(size_t)min(k0 + q, a.D - 1) * NA + tid];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc = fmaf(k0 + q < a.D ? s_h[k0 + q] : 0.f, kv[q], acc);
+    }
     s_wargs[tid] = acc;
     a.wargs[(size_t)b * NA + tid] = acc;
   }
@@ -84,9 +91,20 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_fwd_kernel(LabelFwdArgs a) {
   __syncthreads();
   for (int c = tid; c < a.G4; c += LH_T) {
     float e = a.benc[c], d = a.bdec[c];
-    for (int j = 0; j < a.C; ++j) {
-      e = fmaf(s_w[j], a.Kenc_w[(size_t)j * a.G4 + c], e);
-      d = fmaf(s_w[j], a.Kdec_w[(size_t)j * a.G4 + c], d);
+    for (int j0 = 0; j0 < a.C; j0 += 8) {          // 16 loads in flight
+      float ke[8], kd[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = min(j0 + q, a.C - 1);
+        ke[q] = a.Kenc_w[(size_t)j * a.G4 + c];
+        kd[q] = a.Kdec_w[(size_t)j * a.G4 + c];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float w = j0 + q < a.C ? s_w[j0 + q] : 0.f;
+        e = fmaf(w, ke[q], e);
+        d = fmaf(w, kd[q], d);
+      }
     }
     a.rb_enc[(size_t)b * a.G4 + c] = e;
     a.rb_dec[(size_t)b * a.G4 + c] = d;
@@ -120,9 +138,25 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
   for (int j = 0; j < LH_MAXC; ++j) part[j] = 0.f;
   for (int c = tid; c < a.G4; c += LH_T) {
     const float de = a.dzsum_enc[(size_t)b * a.G4 + c], dd = a.dzsum_dec[(size_t)b * a.G4 + c];
+    // kernel rows in batches of 8 classes, loads unconditional (clamped) so that 16 are in flight; a load under
+    // `if (j < C)` is waited for where it is issued: one L2 round trip per class
 #pragma unroll
-    for (int j = 0; j < LH_MAXC; ++j)
-      if (j < a.C) part[j] = fmaf(dd, a.Kdec_w[(size_t)j * a.G4 + c], fmaf(de, a.Kenc_w[(size_t)j * a.G4 + c], part[j]));
+    for (int j0 = 0; j0 < LH_MAXC; j0 += 8) {
+      if (j0 < a.C) {                    // uniform
+        float ke[8], kd[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int j = min(j0 + q, a.C - 1);
+          ke[q] = a.Kenc_w[(size_t)j * a.G4 + c];
+          kd[q] = a.Kdec_w[(size_t)j * a.G4 + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float m = j0 + q < a.C ? 1.f : 0.f;
+          part[j0 + q] = fmaf(dd * m, kd[q], fmaf(de * m, ke[q], part[j0 + q]));
+        }
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < LH_MAXC; ++j)
@@ -167,8 +201,15 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
   __syncthreads();
   if (tid < a.D) {
     float acc = 0.f;
-    for (int j = 0; j < NA; ++j) acc = fmaf(s_dwa[j], a.Ka[(size_t)tid * NA + j], acc);
-    a.dhW[(size_t)b * a.D + tid] = a.hW[(size_t)b * a.D + tid] > 0.f ? acc : 0.f;
+    const float hv = a.hW[(size_t)b * a.D + tid];
+    for (int j0 = 0; j0 < NA; j0 += 8) {            // 8 loads in flight
+      float kv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kv[q] = a.Ka[(size_t)tid * NA + min(j0 + q, NA - 1)];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc = fmaf(j0 + q < NA ? s_dwa[j0 + q] : 0.f, kv[q], acc);
+    }
+    a.dhW[(size_t)b * a.D + tid] = hv > 0.f ? acc : 0.f;
   }
 }
 
