@@ -36,4 +36,44 @@ __device__ __forceinline__ float gate_grad(float z, float y) {
   return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid_grad(z) : y * (1.f - y);
 }
 
+// ---- pieces shared by the kernels that keep a unit's 4 gate columns in 4 k-slice lanes (lstm_pair.hip, generate.hip)
+constexpr int PK = 4;                   // k-slices per unit
+constexpr int PKK = LH / PK;            // 22 k values per slice
+constexpr int PKP = 24;                 // padded slice stride in LDS (16-byte aligned)
+
+__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// h (LDS, sliced layout) . U slice -> the 4 gate sums of this lane's unit, reduced over the k-slices
+__device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)[PKK][2], f2 (&acc2)[2]) {
+  const float4* hp = reinterpret_cast<const float4*>(hslice);
+  float hv[PKP];
+#pragma unroll
+  for (int q = 0; q < PKP / 4; ++q) {
+    const float4 v = hp[q];
+    hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int kk = 0; kk < PKK; ++kk) {
+    const f2 hh = {hv[kk], hv[kk]};
+    acc2[0] = __builtin_elementwise_fma(hh, Ur[kk][0], acc2[0]);
+    acc2[1] = __builtin_elementwise_fma(hh, Ur[kk][1], acc2[1]);
+  }
+}
+
+template <int GATE>
+__device__ __forceinline__ void lstm_cell(const float (&z)[4], float& c, float& h, float& gg) {
+  const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);
+  gg = fast_tanh(z[2]);
+  c = fg * c + ig * gg;
+  h = og * fast_tanh(c);
+}
+
+__device__ __forceinline__ float pick4(int i, const float (&v)[4]) {
+  float r = v[0];
+  r = i == 1 ? v[1] : r;
+  r = i == 2 ? v[2] : r;
+  r = i == 3 ? v[3] : r;
+  return r;
+}
+
 }  // namespace clv

@@ -19,9 +19,6 @@
 
 namespace clv {
 
-constexpr int PK = 4;                   // k-slices per unit
-constexpr int PKK = LH / PK;            // 22 k values per slice
-constexpr int PKP = 24;                 // padded slice stride in LDS (16-byte aligned)
 constexpr int PNW = 6;                  // waves per chain (16 units each)
 constexpr int PNT = 2 * PNW * 64;       // 768 threads
 constexpr int PLMAX = 16;               // latent dims the surplus groups can carry
@@ -50,33 +47,6 @@ struct PairFwdArgs {
   float* klterm;          // [B*T,L]  L * KL_l: the mean over all entries is the per-frame KL
 };
 
-__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// h (LDS, sliced layout) . U slice -> the 4 gate sums of this lane's unit, reduced over the k-slices
-__device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)[PKK][2], f2 (&acc2)[2]) {
-  const float4* hp = reinterpret_cast<const float4*>(hslice);
-  float hv[PKP];
-#pragma unroll
-  for (int q = 0; q < PKP / 4; ++q) {
-    const float4 v = hp[q];
-    hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
-  }
-#pragma unroll
-  for (int kk = 0; kk < PKK; ++kk) {
-    const f2 hh = {hv[kk], hv[kk]};
-    acc2[0] = __builtin_elementwise_fma(hh, Ur[kk][0], acc2[0]);
-    acc2[1] = __builtin_elementwise_fma(hh, Ur[kk][1], acc2[1]);
-  }
-}
-
-template <int GATE>
-__device__ __forceinline__ void lstm_cell(const float (&z)[4], float& c, float& h, float& gg) {
-  const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);
-  gg = fast_tanh(z[2]);
-  c = fg * c + ig * gg;
-  h = og * fast_tanh(c);
-}
-
 // output slots of a regular lane: 6 values per unit (h, c, z_i, z_f, g, z_o) over the 4 slice lanes, 2 stores each
 __device__ __forceinline__ void regular_slots(int s, int u, size_t bt0, float* hs, float* cs, float* gates,
                                               float* (&optr)[2], int (&ostr)[2], int (&oslot)[2]) {
@@ -97,14 +67,6 @@ __device__ __forceinline__ float pick_slot(int slot, float h, float c, const flo
   v = slot == 4 ? gg : v;
   v = slot == 5 ? z[3] : v;
   return v;
-}
-
-__device__ __forceinline__ float pick4(int i, const float (&v)[4]) {
-  float r = v[0];
-  r = i == 1 ? v[1] : r;
-  r = i == 2 ? v[2] : r;
-  r = i == 3 ? v[3] : r;
-  return r;
 }
 
 template <int GATE>

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.h"
+#include "philox.h"
 
 namespace clv {
 
@@ -41,20 +42,7 @@ void prof_end(hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ Philox --
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// (philox4x32_10, u01, philox_normal_at, philox_uniform_at: philox.h)
 
 // element i uses counter (i>>2) and word/branch (i&3): a pure function of (seed, step, stream, index)
 template <bool NORMAL>

@@ -567,7 +567,31 @@ class VrnnEngine(_EngineBase):
         g(st['hs'], P.p('X_decoded_mean/kernel'), st['xhat'], B, D, H, bias=P.p('X_decoded_mean/bias'),
           act=ACT_SIGMOID, ws=ws)
 
-    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False):
+    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False, persistent=True, xhat_out=None):
+        """Autoregressive generation of N independent sequences on the device.  persistent=True (default where the
+        shapes allow): the whole frame loop is ONE kernel, a workgroup per sequence (csrc/generate.hip); otherwise the
+        per-frame chain below, captured once and replayed per frame.  Same Philox noise either way.
+        xhat_out [N,S+nsteps,D] (persistent path only) receives every frame's note probabilities."""
+        cfg = self.cfg
+        if persistent and ops.vrnn_generate_supported(cfg['D'], cfg['H'], cfg['L'], cfg['C']):
+            return self._generate_persistent(x_seed, w, nsteps, seed, z_prior, xhat_out)
+        return self._generate_frames(x_seed, w, nsteps, seed, use_graph, z_prior)
+
+    def _generate_persistent(self, x_seed, w, nsteps, seed, z_prior, xhat_out):
+        cfg, P, d = self.cfg, self.P, self.device
+        D, H, L, Cn, off = cfg['D'], cfg['H'], cfg['L'], cfg['C'], self.off
+        N, S = int(x_seed.shape[0]), int(x_seed.shape[1])
+        Xs = torch.zeros(N, nsteps, D, dtype=torch.float32, device=d)
+        rows = lambda name, r: P.rows(P.params, name, r)
+        ops.vrnn_generate(N, S, nsteps, D, H, L, Cn, self.gate_act, z_prior, seed, x_seed.contiguous() if S else None,
+                          w.contiguous(), P.p('encoder_h/kernel'), rows('encoder_h/kernel', D), P.p('encoder_h/bias'),
+                          P.p('encoder_h/recurrent_kernel'), P.p('Zargs/kernel'), P.p('Zargs/bias'),
+                          P.p('decoder_h/kernel') if cfg['use_x_prev'] else None, rows('decoder_h/kernel', off),
+                          rows('decoder_h/kernel', off + L), P.p('decoder_h/bias'), P.p('decoder_h/recurrent_kernel'),
+                          P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), Xs, xhat_out)
+        return Xs
+
+    def _generate_frames(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False):
         """Batched autoregressive generation on the device (the hot loop of cl_vrnn/model.py:47-59 for N
         independent sequences at once, noise from Philox instead of np.random).
         x_seed [N,S,D] device tensor (teacher-forced frames, S may be 0), w [N,C]; returns Xs [N,nsteps,D].

@@ -180,6 +180,18 @@ def sparse_outer(Bn, nx, N, X, ldx, G, ldg, out, ldo=None):
                                       _stream()), "clv_sparse_outer")
 
 
+def vrnn_generate_supported(D, H, L, Cn):
+    return bool(_lib.lib().clv_vrnn_generate_supported(D, H, L, Cn))
+
+
+def vrnn_generate(N, S, nsteps, D, H, L, Cn, gate_act, z_prior, seed, x_seed, w, Kx_enc, Kw_enc, b_enc, U_enc, Wz, bz,
+                  Kx_dec, Kz, Kw_dec, b_dec, U_dec, Wo, bo, Xs, xhat=None):
+    check(_lib.lib().clv_vrnn_generate(N, S, nsteps, D, H, L, Cn, gate_act, int(bool(z_prior)), int(seed), _ptr(x_seed),
+                                       _ptr(w), _ptr(Kx_enc), _ptr(Kw_enc), _ptr(b_enc), _ptr(U_enc), _ptr(Wz), _ptr(bz),
+                                       _ptr(Kx_dec), _ptr(Kz), _ptr(Kw_dec), _ptr(b_dec), _ptr(U_dec), _ptr(Wo), _ptr(bo),
+                                       _ptr(Xs), _ptr(xhat), _stream()), "clv_vrnn_generate")
+
+
 def lstm_pair_supported(L, H=88):
     return bool(_lib.lib().clv_lstm_pair_supported(H, L))
 

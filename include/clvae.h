@@ -172,6 +172,26 @@ int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
                       float* dzsum_dec, float* dzsum_enc,
                       const float* zargs, const float* eps, float* dzargs, void* stream);
 
+/* ------------------------------------------------ cl_vrnn generation, persistent --
+ * cl_vrnn/model.py:9-60 (generate_sample's frame loop) for N independent sequences, one workgroup per
+ * sequence for its whole length, one launch: per frame encoder LSTM step on [x_{t-1}, w], latent head,
+ * z = mean + exp(log_var/2)*eps (z_prior != 0: z = eps), decoder LSTM step on [x_{t-1}, z, w],
+ * x_hat = sigmoid(head), x_t = [u <= x_hat].  Frames t < S are teacher-forced from x_seed [N,S,D];
+ * the nsteps sampled frames go to Xs [N,nsteps,D]; xhat [N,S+nsteps,D] (optional) receives every frame's
+ * probabilities.  eps = the clv_philox_normal value for (seed, step t, stream 0, index n*L+l), u = the
+ * clv_philox_uniform value for (seed, step t, stream 1, index n*D+j).  Kernel pieces are the row blocks of the
+ * Keras tensors: encoder_h/kernel = [Kx_enc (D rows) ; Kw_enc (C rows)], decoder_h/kernel = [Kx_dec (D rows,
+ * NULL without use_x_prev) ; Kz (L rows) ; Kw_dec (C rows)], Wz = [Z_mean | Z_log_var] kernel [H,2L].
+ * clv_vrnn_generate_supported: D == H == 88, L <= 16, C <= 32. */
+int clv_vrnn_generate_supported(int D, int H, int L, int C);
+int clv_vrnn_generate(int N, int S, int nsteps, int D, int H, int L, int C, int gate_act, int z_prior,
+                      uint64_t seed, const float* x_seed, const float* w,
+                      const float* Kx_enc, const float* Kw_enc, const float* b_enc, const float* U_enc,
+                      const float* Wz, const float* bz,
+                      const float* Kx_dec, const float* Kz, const float* Kw_dec, const float* b_dec,
+                      const float* U_dec, const float* Wo, const float* bo,
+                      float* Xs, float* xhat, void* stream);
+
 /* ------------------------------------------------------------ pointwise --
  * logistic-normal label sample + its two losses, one thread per row:
  *   w = softmax([mean + exp(lv/2)*eps, 0]); kl_w, w_rec = (C-1)*CCE(onehot, w+1e-10), hit

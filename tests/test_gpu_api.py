@@ -294,3 +294,60 @@ def test_device_generation_matches_stepwise_oracle(dev):
             x_t = got
         x_prev = x_t
     assert flips <= 2
+
+
+@pytest.mark.parametrize("N,L,use_x_prev,gate,z_prior", [(3, 2, True, 'hard_sigmoid', False), (2, 5, False, 'sigmoid', False),
+                                                         (1, 16, True, 'hard_sigmoid', True), (2, 32, True, 'hard_sigmoid', False),
+                                                         (2, 19, False, 'sigmoid', False)])
+def test_persistent_generation_matches_frame_steps(dev, N, L, use_x_prev, gate, z_prior):
+    """csrc/generate.hip (the whole generate_sample frame loop in one kernel) against the engine's single-step API
+    driven from the host with the same Philox noise: probabilities of every frame, and sample = [u <= x_hat]."""
+    from clvae_amd import ops
+    from clvae_amd.engine import VrnnEngine
+    from oracle import clvae_oracle as O
+    Cn, S, nsteps, seed = 10, 5, 9, 4242
+    cfg = O.vrnn_config(latent_dim=L, seq_length=8, n_classes=Cn, use_x_prev=use_x_prev, gate_act=gate)
+    rng = np.random.default_rng(L)
+    p = {k: np.asarray(v, np.float32) for k, v in O.vrnn_init_params(cfg, seed=5).items()}
+    for k in p:                                    # livelier weights than the initialisers give
+        if not k.startswith('hW'):
+            p[k] = (p[k] + 0.15 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    eng = VrnnEngine(cfg, 4, dev)
+    eng.P.set_weights(p)
+    f = dict(dtype=torch.float32, device=dev)
+    x_seed = torch.as_tensor((rng.random((N, S, 88)) < 0.06).astype(np.float32), device=dev)
+    w = torch.as_tensor(np.eye(Cn, dtype=np.float32)[rng.integers(0, Cn, N)], device=dev)
+    xhat = torch.zeros(N, S + nsteps, 88, **f)
+    Xs = eng.generate(x_seed, w, nsteps, seed=seed, z_prior=z_prior, xhat_out=xhat)
+    torch.cuda.synchronize()
+    assert Xs.shape == (N, nsteps, 88)
+    # 1. every sampled frame is [u <= x_hat] with the documented Philox stream
+    for t in range(S, S + nsteps):
+        u = torch.zeros(N, 88, **f)
+        ops.philox_uniform(u, N * 88, seed, t, 1, 0)
+        np.testing.assert_array_equal(Xs[:, t - S].cpu().numpy(), (u <= xhat[:, t]).float().cpu().numpy())
+    assert 0.0 < float(Xs.mean()) < 1.0
+    # 2. teacher-forcing the generated frames reproduces the same probabilities bit for bit
+    #    (the input of step S is the sample drawn at step S-1, which is not part of the returned frames)
+    u = torch.zeros(N, 88, **f)
+    ops.philox_uniform(u, N * 88, seed, S - 1, 1, 0)
+    x_bridge = (u <= xhat[:, S - 1]).float().unsqueeze(1)
+    forced = torch.cat([x_seed, x_bridge, Xs[:, :-1]], dim=1).contiguous()
+    assert forced.shape[1] == S + nsteps
+    xhat2 = torch.zeros(N, S + nsteps, 88, **f)
+    eng.generate(forced, w, 0, seed=seed, z_prior=z_prior, xhat_out=xhat2)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(xhat2.cpu().numpy(), xhat.cpu().numpy())
+    # 3. the host-driven single-step path (dense GEMMs, separate kernels) gives the same probabilities
+    st = eng.new_state(N)
+    eps, z = torch.zeros(N, L, **f), torch.zeros(N, L, **f)
+    for t in range(S + nsteps):
+        x = forced[:, t].contiguous()
+        eng.enc_step(x, w, st)
+        ops.philox_normal(eps, N * L, seed, t, 0, 0)
+        if z_prior:
+            st['zargs'].zero_()
+        ops.gauss_fwd(N, L, st['zargs'], eps, z, L, None)
+        eng.dec_step(z, x if use_x_prev else None, w, st)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(xhat[:, t].cpu().numpy(), st['xhat'].cpu().numpy(), rtol=0, atol=2e-5)
