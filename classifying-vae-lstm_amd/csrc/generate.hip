@@ -185,11 +185,17 @@ __global__ __launch_bounds__(GN_NT) void vrnn_generate_kernel(GenArgs a) {
   float c = 0.f;                       // cell state of this lane's unit (its role's LSTM)
   const bool writer = s == 0 && u_raw < LH;        // one lane per unit publishes
 
+  // The noise of a frame does not depend on the data: it is drawn one phase (uniform) / one frame (normal) ahead, in
+  // slots where its lanes would otherwise wait at a barrier.
+  const bool zdraw = ZW ? (tid < L) : (lat_ok && s < 2);            // lanes that own a latent's eps
+  const uint64_t zidx = (uint64_t)n * L + (ZW ? tid : lat);
+  float e_cur = zdraw ? philox_normal_at(zidx, a.k0, a.k1, 0u, 0u) : 0.f;
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     float x0, x1;
     unsigned long long m0, m1;
     frame_masks(xbuf, lane, x0, x1, m0, m1);       // xbuf = input frame of step t (seed frame or last sample)
+    float u_cur = 0.f;
     float seed_next = 0.f;                         // teacher forcing: next seed frame, requested a whole frame early
     if (enc && writer && t + 1 < a.S) seed_next = a.x_seed[((size_t)n * a.S + t + 1) * LH + u];
     // ---- phase 1: encoder cell (enc waves) | decoder input-kernel rows from L2 (dec waves) ------------------------
@@ -257,8 +263,7 @@ __global__ __launch_bounds__(GN_NT) void vrnn_generate_kernel(GenArgs a) {
         if (lat_ok && s < 2) {
           const float m = a.z_prior ? 0.f : ((s & 1) ? z[1] : z[0]);
           const float lv = a.z_prior ? 0.f : ((s & 1) ? z[3] : z[2]);
-          const float e = philox_normal_at((uint64_t)n * L + lat, a.k0, a.k1, 0u, (uint32_t)t);
-          zbuf[zpos] = fmaf(expf(0.5f * lv), e, m);
+          zbuf[zpos] = fmaf(expf(0.5f * lv), e_cur, m);
         }
       }
       step_barrier();
@@ -280,8 +285,7 @@ __global__ __launch_bounds__(GN_NT) void vrnn_generate_kernel(GenArgs a) {
       step_barrier();
       if (tid < L) {
         const float m = a.z_prior ? 0.f : zargs_l[tid], lv = a.z_prior ? 0.f : zargs_l[L + tid];
-        const float e = philox_normal_at((uint64_t)n * L + tid, a.k0, a.k1, 0u, (uint32_t)t);
-        zbuf[(tid % PK) * GN_LQ + tid / PK] = fmaf(expf(0.5f * lv), e, m);
+        zbuf[(tid % PK) * GN_LQ + tid / PK] = fmaf(expf(0.5f * lv), e_cur, m);
       }
       step_barrier();
     }
@@ -313,6 +317,10 @@ __global__ __launch_bounds__(GN_NT) void vrnn_generate_kernel(GenArgs a) {
       float h, gg;
       lstm_cell<GATE>(z, c, h, gg);
       hb[1][cur ^ 1][hslot] = h;
+    } else {
+      // encoder waves are idle here: draw this frame's Bernoulli uniforms and the next frame's latent noise
+      if (writer) u_cur = philox_uniform_at((uint64_t)n * LH + u, a.k0, a.k1, 1u, (uint32_t)t);
+      if (zdraw) e_cur = philox_normal_at(zidx, a.k0, a.k1, 0u, (uint32_t)(t + 1));
     }
     step_barrier();
     // ---- phase 4: output head, Bernoulli sample, next input frame (enc waves) ------------------------------------
@@ -333,8 +341,7 @@ __global__ __launch_bounds__(GN_NT) void vrnn_generate_kernel(GenArgs a) {
       acc = reduce_slices<PK>(acc);
       if (writer) {
         const float p = sigmoidf_(acc + bor);
-        const float r = philox_uniform_at((uint64_t)n * LH + u, a.k0, a.k1, 1u, (uint32_t)t);
-        const float xs = r <= p ? 1.f : 0.f;
+        const float xs = u_cur <= p ? 1.f : 0.f;
         if (a.xhat) a.xhat[((size_t)n * T + t) * LH + u] = p;
         if (t >= a.S) a.Xs[((size_t)n * a.nsteps + (t - a.S)) * LH + u] = xs;
         // teacher forcing: the next input is the next seed frame while there is one
