@@ -143,6 +143,68 @@ struct TileLoader {
     }
   }
 
+  // ---- interior k-tiles: loop-invariant addressing ------------------------------------------------------------------
+  // The index arithmetic above (divisions, clamps, 64-bit address products, validity bits: ~40 VALU instructions per
+  // vector, 35 more for the zero-period modulo) used to run for every k-tile and made the kernel VALU-issue-bound
+  // (ablation: the tile loop without MFMAs took 46 us of 64).  For a k-tile that lies fully inside [0, K) the address
+  // of a thread's vector just advances by a constant, and nothing has to be masked along m/n at all: an out-of-range
+  // row or column of a tile only ever feeds output rows/columns that the epilogue does not store.  Only the k
+  // direction needs zeros (K tail, zero-period rows); the tail tile takes the general path.
+  struct Iter {
+    const float* p[PER];     // this thread's vector in the current k-tile (clamped to valid memory along m/n)
+    int lofs[PER];           // LDS offset of the vector
+    int zr[PER];             // (global k of the vector's row) % zperiod
+  };
+  __device__ static void iter_init(Iter& it, const float* __restrict__ base, int ld, int dim_mn, int mn0, int k0, int tid,
+                                   int shift, int zperiod) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = min(tid + i * 256, NV - 1);
+      if (KC) {
+        const int mn = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+        it.p[i] = base + (size_t)min(mn0 + mn, dim_mn - 1) * ld + (k0 + k4);
+        it.lofs[i] = k4 * LD + mn;
+        it.zr[i] = 1;
+      } else {
+        constexpr int RV = BMN / 4;
+        const int k = idx / RV, c4 = (idx % RV) * 4;
+        it.p[i] = base + (size_t)(k0 + k - shift) * ld + min(mn0 + c4, ld - 4);
+        it.lofs[i] = k * LD + c4;
+        it.zr[i] = zperiod > 0 ? (k0 + k) % zperiod : 1;
+      }
+    }
+  }
+  __device__ static void iter_load(Iter& it, float4 (&r)[PER], int ld, int zperiod) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      r[i] = *reinterpret_cast<const float4*>(it.p[i]);
+      it.p[i] += KC ? BK : (size_t)BK * ld;
+    }
+  }
+  // store the vectors loaded by iter_load (the row of tile t), then advance the zero-period phase to tile t+1
+  __device__ static void iter_store(Iter& it, const float4 (&r)[PER], float* lds, int tid, int zperiod) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      float4 v = r[i];
+      if (!KC && zperiod > 0) {                      // uniform
+        const float f = it.zr[i] == 0 ? 0.f : 1.f;
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        int z = it.zr[i] + BK;
+        it.zr[i] = z >= zperiod ? z - zperiod : z;
+      }
+      if (tid + i * 256 < NV) {
+        if (KC) {
+          lds[it.lofs[i]] = v.x;
+          lds[it.lofs[i] + LD] = v.y;
+          lds[it.lofs[i] + 2 * LD] = v.z;
+          lds[it.lofs[i] + 3 * LD] = v.w;
+        } else {
+          *reinterpret_cast<float4*>(&lds[it.lofs[i]]) = v;
+        }
+      }
+    }
+  }
+
   __device__ static void store(const float4 (&rr)[PER], const int (&mk)[PER], float* lds, int tid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -175,18 +237,26 @@ __device__ __forceinline__ float apply_act(float v, int act, float aux) {
   return v;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB, int BK = 16>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+// KG > 1: in-workgroup split-K.  The workgroup is KG groups of 4 waves; group kg runs the ordinary tile loop over its
+// own K sub-chunk with its own LDS tiles, and the KG accumulators are summed through LDS (the lane -> (row, col) map
+// is the same in every group) before group 0 writes ONE partial slab.  Same waves per CU as KG workgroups, 1/KG of
+// the slab traffic.  Needs dynamic LDS (KG * tile bytes).
+extern __shared__ __attribute__((aligned(16))) float gemm_dyn_smem[];
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB, int BK = 16, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
   using LA = TileLoader<BM, !TA, BK>;   // A row-major [M,K] => k contiguous
   using LB = TileLoader<BN, TB, BK>;    // B row-major [K,N] => n contiguous
   constexpr int LDA = LA::LD, LDB = LB::LD;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  constexpr int TILE_FLOATS = 2 * BK * (LDA + LDB);
+  __shared__ __attribute__((aligned(16))) float smem_static[KG == 1 ? TILE_FLOATS : 4];
+  const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+  float* smem = KG == 1 ? smem_static : gemm_dyn_smem + kg * TILE_FLOATS;
   float* As = smem;
   float* Bs = smem + 2 * BK * LDA;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
   // Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  In a split-K
@@ -194,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   // (xcd = chunk % 8, tile, chunk / 8): the chunk's rows are fetched from HBM into ONE L2 and reused there by
   // every tile, instead of once per XCD.
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (g.xcd_remap) {
+  if (g.xcd_remap & 1) {
     const int ntx = gridDim.x, ntiles = gridDim.x * gridDim.y;
     const int lin = bx + ntx * (by + (int)gridDim.y * bz);
     const int xcd = lin & 7, rest = lin >> 3;
@@ -217,9 +287,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     prow0 = pr.row0; a_shift = pr.a_shift; a_zper = pr.a_zero_period; a_ones = pr.ones;
   }
   const int m0 = mtile * BM, n0 = by * BN;
-  const int kbeg = bz * g.k_chunk;
+  const int kbeg = min((bz * KG + kg) * g.k_chunk, g.K);
   const int kend = min(g.K, kbeg + g.k_chunk);
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  // KG > 1: every group runs the same number of k-tiles (barriers are workgroup-wide); tiles past kend load zeros
+  const int nk = KG == 1 ? (kend - kbeg + BK - 1) / BK : (g.k_chunk + BK - 1) / BK;
 
   f32x4 acc[WM][WN];
 #pragma unroll
@@ -236,12 +307,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     LB::store(rb, mb, Bs, tid);
   }
   __syncthreads();
+  // interior k-tiles (1 .. nfast): whole tile inside [kbeg, kend) -> incremental addressing, no masks along m/n
+  const bool fastA = g.vecA && !a_ones && (a_zper == 0 || a_zper >= BK) && !(!TA && false);
+  const bool fastB = g.vecB != 0;
+  const int nfull = (kend - kbeg) / BK;              // k-tiles that are completely inside the chunk
+  typename LA::Iter ia;
+  typename LB::Iter ib;
+  if (fastA) LA::iter_init(ia, Aptr, lda, Mp, m0, kbeg + BK, tid, a_shift, a_zper);
+  if (fastB) LB::iter_init(ib, g.B, g.ldb, g.N, n0, kbeg + BK, tid, 0, 0);
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      LA::load(ra, ma, Aptr, lda, Mp, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid, a_shift, a_zper, a_ones);
-      LB::load(rb, mb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
+    const bool nxt = kt + 1 < nk;
+    const bool inner = kt + 1 < nfull;              // next tile is a full interior tile (uniform)
+    if (nxt) {
+      if (fastA && inner) LA::iter_load(ia, ra, lda, a_zper);
+      else LA::load(ra, ma, Aptr, lda, Mp, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid, a_shift, a_zper, a_ones);
+      if (fastB && inner) LB::iter_load(ib, rb, g.ldb, 0);
+      else LB::load(rb, mb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
     }
     const float* as = As + cur * BK * LDA + wm * WM * 16 + r;
     const float* bs = Bs + cur * BK * LDB + wn * WN * 16 + r;
@@ -259,12 +342,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      LA::store(ra, ma, As + (cur ^ 1) * BK * LDA, tid);
-      LB::store(rb, mb, Bs + (cur ^ 1) * BK * LDB, tid);
+      if (fastA && inner) LA::iter_store(ia, ra, As + (cur ^ 1) * BK * LDA, tid, a_zper);
+      else LA::store(ra, ma, As + (cur ^ 1) * BK * LDA, tid);
+      if (fastB && inner) LB::iter_store(ib, rb, Bs + (cur ^ 1) * BK * LDB, tid, 0);
+      else LB::store(rb, mb, Bs + (cur ^ 1) * BK * LDB, tid);
     }
     __syncthreads();
   }
 
+  if (KG > 1) {
+    // sum the groups' accumulators: groups 1.. park theirs in LDS (tile memory is free after the last barrier)
+    static_assert(KG == 1 || (KG - 1) * WM * WN * 256 * 4 <= KG * TILE_FLOATS, "accumulators must fit the tile memory");
+    f32x4* park = reinterpret_cast<f32x4*>(gemm_dyn_smem);
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) park[((kg - 1) * WM * WN + i * WN + j) * 256 + tid] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int gq = 0; gq < KG - 1; ++gq)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const f32x4 v = park[(gq * WM * WN + i * WN + j) * 256 + tid];
+          acc[i][j][0] += v[0]; acc[i][j][1] += v[1]; acc[i][j][2] += v[2]; acc[i][j][3] += v[3];
+        }
+  }
   // epilogue: C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
   if (g.bce_y) {
     // logits -> Bernoulli NLL with Keras' epsilon clip (same arithmetic as bernoulli_nll_kernel).  One n-tile and
@@ -522,6 +629,7 @@ static void launch_cfg(const GemmArgs& g_in, int ta, int tb, int splits, hipStre
     static int remap = -1;
     if (remap < 0) { const char* e = getenv("CLV_GEMM_XCD_REMAP"); remap = e ? atoi(e) : 1; }
     g.xcd_remap = remap && splits > 1 && splits % 8 == 0;
+    if (const char* e = getenv("CLV_GEMM_NOITER")) g.xcd_remap |= atoi(e);      // dev: 2 = no A iterator, 4 = no B iterator
   }
   dim3 grid(g.nprob > 0 ? g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BM - 1) / BM : (g.M + BM - 1) / BM,
             (g.N + BN - 1) / BN, splits);
@@ -764,6 +872,11 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   kc = (kc + 15) / 16 * 16;
   splits = (K + kc - 1) / kc;
   g.k_chunk = kc;
+  // in-workgroup split-K: 4 K sub-chunks per workgroup, one slab per workgroup (96 x 96 tiles, enough splits)
+  static int kg_on = -1;
+  if (kg_on < 0) { const char* e = getenv("CLV_GEMM_KG"); kg_on = e ? atoi(e) : 1; }
+  const bool kg4 = kg_on && bn == 96 && bm == 96 && splits >= 16 && splits % 4 == 0;
+  if (kg4) splits /= 4;                  // = number of slabs / workgroups along K
   g.partial = nullptr;
   if (splits > 1) {
     size_t need = (size_t)splits * row * N * sizeof(float);
@@ -772,7 +885,23 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   }
   {
     ProfScope p(glabel, s);
-    if (bn == 16) launch_cfg<2, 1, 4, 1>(g, 1, 0, splits, s);          // 128 x 16
+    if (kg4) {
+      constexpr int BMq = 96, BNq = 96;
+      auto kern = gemm_f32_kernel<3, 3, 2, 2, true, false, 16, 4>;
+      const size_t lds = 4 * (2 * 16 * (LdsStride<BMq>::value + LdsStride<BNq>::value)) * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+      }
+      static int remap = -1;
+      if (remap < 0) { const char* e = getenv("CLV_GEMM_XCD_REMAP"); remap = e ? atoi(e) : 1; }
+      g.xcd_remap = remap && splits > 1 && splits % 8 == 0;
+      dim3 grid(g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BMq - 1) / BMq, (g.N + BNq - 1) / BNq, splits);
+      hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, g);
+    }
+    else if (bn == 16) launch_cfg<2, 1, 4, 1>(g, 1, 0, splits, s);     // 128 x 16
     else if (bn == 32) launch_cfg<1, 2, 4, 1>(g, 1, 0, splits, s);     // 64 x 32
     else if (bm == 128) launch_cfg<4, 3, 2, 2>(g, 1, 0, splits, s);    // 128 x 96
     else launch_cfg<3, 3, 2, 2>(g, 1, 0, splits, s);                   // 96 x 96
