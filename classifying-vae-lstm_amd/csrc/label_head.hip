@@ -18,6 +18,7 @@ constexpr float LEPS_K = 1e-7f, LW2 = 1e-10f;
 struct LabelFwdArgs {
   int B, D, C, G4;
   const float* hW;          // [B,D]
+  __device__ float* hW_out() const { return const_cast<float*>(hW); }
   const float* Ka;          // Wargs kernel [D, 2(C-1)]
   const float* ba;          // [2(C-1)]
   const float* eps;         // [B,C-1]
@@ -34,12 +35,10 @@ struct LabelFwdArgs {
   float* rb_dec;            // [B,G4]
 };
 
-__global__ __launch_bounds__(LH_T) void vrnn_label_fwd_kernel(LabelFwdArgs a) {
-  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// label path of row b from its hW activations in s_h (LDS); NT threads take part
+template <int NT>
+__device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int tid, const float* s_h, float* s_wargs, float* s_w) {
   const int C1 = a.C - 1, NA = 2 * C1;
-  if (tid < a.D) s_h[tid] = a.hW[(size_t)b * a.D + tid];
-  __syncthreads();
   if (tid < NA) {
     // 8 kernel rows in flight (a one-load-per-iteration loop pays an L2 round trip per row: 88 of them)
     float acc = a.ba[tid];
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_fwd_kernel(LabelFwdArgs a) {
     a.rowloss[(size_t)b * 3 + 2] = (a.onehot && amax == tmax) ? 1.f : 0.f;
   }
   __syncthreads();
-  for (int c = tid; c < a.G4; c += LH_T) {
+  for (int c = tid; c < a.G4; c += NT) {
     float e = a.benc[c], d = a.bdec[c];
     for (int j0 = 0; j0 < a.C; j0 += 8) {          // 16 loads in flight
       float ke[8], kd[8];
@@ -109,6 +108,79 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_fwd_kernel(LabelFwdArgs a) {
     a.rb_enc[(size_t)b * a.G4 + c] = e;
     a.rb_dec[(size_t)b * a.G4 + c] = d;
   }
+}
+
+__global__ __launch_bounds__(LH_T) void vrnn_label_fwd_kernel(LabelFwdArgs a) {
+  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < a.D) s_h[tid] = a.hW[(size_t)b * a.D + tid];
+  __syncthreads();
+  label_fwd_row<LH_T>(a, b, tid, s_h, s_wargs, s_w);
+}
+
+// The same with the hW Dense layer in front (cl_vrnn/model.py:174-176): hW = relu(flat(X_b) . K_h + b_h) over the
+// row's nonzero inputs (the window is ~4 % notes), as in sparse_dense_kernel -- 16 waves scan 64-input chunks, ballot,
+// and add the listed kernel rows (float2 per lane, 4 loads in flight) -- then the label path without leaving the
+// workgroup.  hW is also written out (the backward pass needs it).
+struct LabelFwdXArgs {
+  LabelFwdArgs l;          // l.hW is the OUTPUT here
+  const float* X;          // [B, ldx]
+  const float* Kh;         // [nx, D]
+  const float* bh;         // [D]
+  int nx, ldx;
+};
+__global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax) {
+  __shared__ float2 part[16][64];
+  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
+  const LabelFwdArgs& a = ax.l;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int n2 = a.D / 2;
+  const int lc = min(lane, n2 - 1);
+  const float2* K2 = reinterpret_cast<const float2*>(ax.Kh);
+  const float* xr = ax.X + (size_t)b * ax.ldx;
+  float2 acc = make_float2(0.f, 0.f);
+  const int nchunk = (ax.nx + 63) / 64;
+  float xn = 0.f;
+  if (wave < nchunk) xn = xr[min(wave * 64 + lane, ax.nx - 1)];
+  for (int ch = wave; ch < nchunk; ch += 16) {
+    const float x = xn;
+    const int j0 = ch * 64;
+    if (ch + 16 < nchunk) xn = xr[min((ch + 16) * 64 + lane, ax.nx - 1)];
+    unsigned long long m = __ballot(j0 + lane < ax.nx && x != 0.f);
+    while (m) {
+      int kk[4];
+      float vv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool on = m != 0;
+        const int bit = on ? __builtin_ctzll(m) : 0;
+        m = on ? (m & (m - 1)) : 0;
+        kk[q] = j0 + bit;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), bit));
+        vv[q] = on ? v : 0.f;
+      }
+      float2 kr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kr[q] = K2[(size_t)min(kk[q], ax.nx - 1) * n2 + lc];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < n2) {
+    float2 t = make_float2(ax.bh[2 * lane], ax.bh[2 * lane + 1]);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { t.x += part[w][lane].x; t.y += part[w][lane].y; }
+    t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f);
+    s_h[2 * lane] = t.x; s_h[2 * lane + 1] = t.y;
+    float* op = a.hW_out() + (size_t)b * a.D + 2 * lane;
+    op[0] = t.x; op[1] = t.y;
+  }
+  __syncthreads();
+  label_fwd_row<1024>(a, b, tid, s_h, s_wargs, s_w);
 }
 
 struct LabelBwdArgs {
@@ -244,5 +316,23 @@ extern "C" int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsu
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("vrnn_label_bwd", s);
   hipLaunchKernelGGL(vrnn_label_bwd_kernel, dim3(B), dim3(LH_T), 0, s, a);
+  return launch_status();
+}
+
+extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
+                                    const float* bh, float* hW_out, const float* Ka, const float* ba,
+                                    const float* eps, const float* onehot, float prior_logvar,
+                                    const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                                    float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec, void* stream) {
+  if (B <= 0 || D <= 0 || D > 128 || D % 2 != 0 || C < 2 || C > LH_MAXC || G4 <= 0 || nx <= 0 || ldx < nx) return CLV_EINVAL;
+  if (!X || !Kh || !bh || !hW_out || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss ||
+      !rb_enc || !rb_dec)
+    return CLV_EINVAL;
+  if (((uintptr_t)Kh) % 8 != 0) return CLV_EINVAL;
+  LabelFwdXArgs a{{B, D, C, G4, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc,
+                   rb_dec}, X, Kh, bh, nx, ldx};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("vrnn_label_fwd", s);
+  hipLaunchKernelGGL(vrnn_label_fwd_x_kernel, dim3(B), dim3(1024), 0, s, a);
   return launch_status();
 }

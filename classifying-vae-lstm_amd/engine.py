@@ -437,16 +437,8 @@ class VrnnEngine(_EngineBase):
                 with self._side():
                     g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
         # label path (:174-191)
-        if self.sparse_inputs and ops.sparse_dense_supported(D):
-            ops.sparse_dense(B, T * D, D, X, T * D, P.p('hW/kernel'), P.p('hW/bias'), ACT_RELU, self.hW)
-        else:
-            g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
-        # Wargs head, logistic-normal sample, label losses and both per-row LSTM biases (W.K_w + b): one launch
         off = self.off
-        ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true,
-                           cfg['w_log_var_prior'], P.rows(P.params, 'encoder_h/kernel', D), P.p('encoder_h/bias'),
-                           P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
-                           self.wargs, self.W, self.rowloss, self.wk_enc, self.wk_dec)
+        self._label_forward(X, eps_W, w_true)
         self._join()
         if fuse_enc:          # x_t.K gathered from the LDS-resident kernel inside the sequence kernel
             ops.lstm_seq_fwd_x(B, T, X, D, D, P.p('encoder_h/kernel'), self.wk_enc, P.p('encoder_h/recurrent_kernel'),
@@ -469,6 +461,22 @@ class VrnnEngine(_EngineBase):
                              self.cs_dec, self.gates_dec, gate_act=self.gate_act)
         # output head (:229-234), with the NLL fused into its epilogue when the caller wants the loss
         self._output_head(X, nll)
+
+    def _label_forward(self, X, eps_W, w_true):
+        """Label path (:174-191): hW Dense layer over the flattened window, Wargs head, logistic-normal sample, label
+        losses and both per-row LSTM biases (W.K_w + b).  One launch when the window is handled sparsely."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, T, Cn, off = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C'], self.off
+        G4 = 4 * H
+        tail = (P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true, cfg['w_log_var_prior'],
+                P.rows(P.params, 'encoder_h/kernel', D), P.p('encoder_h/bias'),
+                P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
+                self.wargs, self.W, self.rowloss, self.wk_enc, self.wk_dec)
+        if self.sparse_inputs and D % 2 == 0:
+            ops.vrnn_label_fwd_x(B, D, Cn, G4, X, T * D, T * D, P.p('hW/kernel'), P.p('hW/bias'), self.hW, *tail)
+        else:
+            ops.gemm(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=self.ws)
+            ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, *tail)
 
     def _output_head(self, X, nll):
         cfg, P = self.cfg, self.P
@@ -496,14 +504,7 @@ class VrnnEngine(_EngineBase):
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel
                 g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
-        if self.sparse_inputs and ops.sparse_dense_supported(D):
-            ops.sparse_dense(B, T * D, D, X, T * D, P.p('hW/kernel'), P.p('hW/bias'), ACT_RELU, self.hW)
-        else:
-            g(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=ws)
-        ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, P.p('Wargs/kernel'), P.p('Wargs/bias'), eps_W, w_true,
-                           cfg['w_log_var_prior'], P.rows(P.params, 'encoder_h/kernel', D), P.p('encoder_h/bias'),
-                           P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
-                           self.wargs, self.W, self.rowloss, self.wk_enc, self.wk_dec)
+        self._label_forward(X, eps_W, w_true)
         ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'),
                           self.gates_dec, off > 0, self.wk_dec, P.p('decoder_h/recurrent_kernel'),
                           P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z,

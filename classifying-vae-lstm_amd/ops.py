@@ -232,6 +232,15 @@ def vrnn_label_fwd(B, D, Cn, G4, hW, Ka, ba, eps, onehot, prior, Kenc_w, benc, K
           "clv_vrnn_label_fwd")
 
 
+def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, onehot, prior, Kenc_w, benc, Kdec_w, bdec, wargs,
+                     W, rowloss, rb_enc, rb_dec):
+    """hW = relu(X . Kh + bh) over the nonzero inputs of each row, then vrnn_label_fwd, one workgroup per row."""
+    check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), _ptr(bh), _ptr(hW_out), _ptr(Ka),
+                                          _ptr(ba), _ptr(eps), _ptr(onehot), float(prior), _ptr(Kenc_w), _ptr(benc),
+                                          _ptr(Kdec_w), _ptr(bdec), _ptr(wargs), _ptr(W), _ptr(rowloss), _ptr(rb_enc),
+                                          _ptr(rb_dec), _stream()), "clv_vrnn_label_fwd_x")
+
+
 def vrnn_label_bwd(B, D, Cn, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior,
                    class_weight, w_kl_weight, inv_b, dwargs, dhW):
     check(_lib.lib().clv_vrnn_label_bwd(B, D, Cn, G4, _ptr(dzsum_enc), _ptr(dzsum_dec), _ptr(Kenc_w), _ptr(Kdec_w),

@@ -240,6 +240,14 @@ int clv_vrnn_label_fwd(int B, int D, int C, int G4, const float* hW, const float
                        const float* eps, const float* onehot, float prior_logvar,
                        const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                        float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec, void* stream);
+/* clv_vrnn_label_fwd with the hW Dense layer in front of it, same workgroup: hW[b,:] = relu(X[b,:nx] . Kh + bh) over
+ * the nonzero inputs of the row (cl_vrnn/model.py:174-176; X = the flattened window, ~4 % notes), written to hW_out
+ * [B,D] for the backward pass, then the label path as above.  D even. */
+int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
+                         const float* bh, float* hW_out, const float* Ka, const float* ba,
+                         const float* eps, const float* onehot, float prior_logvar,
+                         const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                         float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec, void* stream);
 int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
                        const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
                        const float* onehot, const float* W, const float* hW, const float* Ka,
