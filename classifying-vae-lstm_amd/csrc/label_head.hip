@@ -39,6 +39,14 @@ struct LabelFwdArgs {
 template <int NT>
 __device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int tid, const float* s_h, float* s_wargs, float* s_w) {
   const int C1 = a.C - 1, NA = 2 * C1;
+  // the row's small vectors go to LDS in one round trip: the serial part below (thread 0) would otherwise pay an L2
+  // round trip per element
+  __shared__ float s_eps[LH_MAXC], s_oh[LH_MAXC];
+  if (tid >= NT - 64 && tid - (NT - 64) < a.C) {
+    const int j = tid - (NT - 64);
+    s_eps[j] = j < C1 ? a.eps[(size_t)b * C1 + j] : 0.f;
+    s_oh[j] = a.onehot ? a.onehot[(size_t)b * a.C + j] : 0.f;
+  }
   if (tid < NA) {
     // 8 kernel rows in flight (a one-load-per-iteration loop pays an L2 round trip per row: 88 of them)
     float acc = a.ba[tid];
@@ -60,7 +68,7 @@ __device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int 
     for (int j = 0; j < C1; ++j) {
       const float m = s_wargs[j], lv = s_wargs[C1 + j];
       const float sd = expf(0.5f * lv);
-      e[j] = expf(m + sd * a.eps[(size_t)b * C1 + j]);
+      e[j] = expf(m + sd * s_eps[j]);
       S += e[j];
       klw += 1.f - a.prior + lv - sd * sd / ep - m * m / ep;
     }
@@ -74,14 +82,14 @@ __device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int 
       a.W[(size_t)b * a.C + j] = w;
       qs += w + LW2;
       if (w > wbest) { wbest = w; amax = j; }
-      const float tj = a.onehot ? a.onehot[(size_t)b * a.C + j] : 0.f;
+      const float tj = s_oh[j];
       if (tj > tbest) { tbest = tj; tmax = j; }
     }
     float wrec = 0.f;
     if (a.onehot)
       for (int j = 0; j < a.C; ++j) {
         const float n = (s_w[j] + LW2) / qs;
-        wrec -= a.onehot[(size_t)b * a.C + j] * logf(fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K));
+        wrec -= s_oh[j] * logf(fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K));
       }
     a.rowloss[(size_t)b * 3 + 0] = -0.5f * klw;
     a.rowloss[(size_t)b * 3 + 1] = (float)C1 * wrec;
@@ -202,8 +210,13 @@ struct LabelBwdArgs {
 
 __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
   __shared__ float s_part[LH_T / 64][LH_MAXC], s_dw[LH_MAXC], s_dwa[2 * LH_MAXC];
+  __shared__ float s_wv[LH_MAXC], s_oh[LH_MAXC], s_wa[2 * LH_MAXC], s_eps[LH_MAXC];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int C1 = a.C - 1, NA = 2 * C1;
+  // the row's small vectors -> LDS in one round trip (the serial label backward below reads them element by element)
+  if (tid < a.C) { s_wv[tid] = a.W[(size_t)b * a.C + tid]; s_oh[tid] = a.onehot[(size_t)b * a.C + tid]; }
+  if (tid >= 64 && tid - 64 < NA) s_wa[tid - 64] = a.wargs[(size_t)b * NA + tid - 64];
+  if (tid >= 128 && tid - 128 < C1) s_eps[tid - 128] = a.eps[(size_t)b * C1 + tid - 128];
   // dW[j] = sum_c dzsum_dec[c] K_dec_w[j,c] + dzsum_enc[c] K_enc_w[j,c]
   float part[LH_MAXC];
 #pragma unroll
@@ -247,12 +260,12 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
     const float ep = __expf(a.prior);
     float wv[LH_MAXC], dn[LH_MAXC], d[LH_MAXC];
     float qs = 0.f, dot = 0.f, dsum = 0.f;
-    for (int j = 0; j < a.C; ++j) { wv[j] = a.W[(size_t)b * a.C + j]; qs += wv[j] + LW2; }
+    for (int j = 0; j < a.C; ++j) { wv[j] = s_wv[j]; qs += wv[j] + LW2; }
     for (int j = 0; j < a.C; ++j) {
       const float n = (wv[j] + LW2) / qs;
       const bool inside = (n >= LEPS_K) && (n <= 1.f - LEPS_K);
       const float nc = fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K);
-      dn[j] = inside ? -(float)C1 * a.onehot[(size_t)b * a.C + j] / nc : 0.f;
+      dn[j] = inside ? -(float)C1 * s_oh[j] / nc : 0.f;
       dot += dn[j] * n;
     }
     for (int j = 0; j < a.C; ++j) {
@@ -261,10 +274,10 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
     }
     for (int j = 0; j < C1; ++j) {
       const float ds = wv[j] * (d[j] - dsum);
-      const float m = a.wargs[(size_t)b * NA + j], lv = a.wargs[(size_t)b * NA + C1 + j];
+      const float m = s_wa[j], lv = s_wa[C1 + j];
       const float sd = expf(0.5f * lv);
       const float dm = ds + a.w_kl_weight * a.inv_b * (m / ep);
-      const float dl = ds * a.eps[(size_t)b * C1 + j] * 0.5f * sd + a.w_kl_weight * a.inv_b * (-0.5f * (1.f - sd * sd / ep));
+      const float dl = ds * s_eps[j] * 0.5f * sd + a.w_kl_weight * a.inv_b * (-0.5f * (1.f - sd * sd / ep));
       s_dwa[j] = dm; s_dwa[C1 + j] = dl;
       a.dwargs[(size_t)b * NA + j] = dm;
       a.dwargs[(size_t)b * NA + C1 + j] = dl;
