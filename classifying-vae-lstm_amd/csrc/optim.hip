@@ -17,6 +17,8 @@
 namespace clv {
 
 constexpr int UNIT_ROWS = 16;
+constexpr int SM_RL = 16, SM_RMAX = 8;        // fused small-tensor kernel: 16 row lanes x 8 rows = matrices of <= 128 rows
+constexpr int SM_ROWS = SM_RL * SM_RMAX;
 
 struct AdamUnit {
   int64_t offset;       // element offset of the tensor
@@ -24,7 +26,7 @@ struct AdamUnit {
   int32_t row0, nrows, cols;
   int32_t is_matrix;
   int32_t part_off;     // this unit's offset into the partial slabs
-  int32_t pad_;
+  int32_t small;        // tensor handled by wn_small_kernel when weight norm is on (the chain kernels skip it)
 };
 struct AdamCol {
   int64_t col_global;   // index into s/mg/vg
@@ -48,7 +50,7 @@ __device__ __forceinline__ float adam_lr_t(const AdamHyper& h) {
 __global__ __launch_bounds__(256) void wn_stats_kernel(const AdamUnit* units, const float* params, const float* grads,
                                                        const float* s, float* partA, float* partB) {
   const AdamUnit un = units[blockIdx.x];
-  if (!un.is_matrix) return;
+  if (!un.is_matrix || un.small) return;
   __shared__ float ra[4][64], rbb[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   for (int c0 = 0; c0 < un.cols; c0 += 64) {
@@ -125,10 +127,11 @@ __global__ __launch_bounds__(256) void wn_cols_kernel(int n_cols, const AdamCol*
   const int j = blockIdx.x * 16 + cx;
   float a = 0.f, b = 0.f;
   AdamCol c;
-  if (j < n_cols) { c = cols[j]; col_partial_sums(c, partA, partB, zy, a, b); }
+  bool skip = true;
+  if (j < n_cols) { c = cols[j]; skip = c.nunits < 0; if (!skip) col_partial_sums(c, partA, partB, zy, a, b); }
   a = lanes16_sum(red, zy, cx, a);
   b = lanes16_sum(red, zy, cx, b);
-  if (zy != 0 || j >= n_cols) return;
+  if (zy != 0 || j >= n_cols || skip) return;
   const float lr_t = adam_lr_t(h);
   const float sc = s[c.col_global];
   const float Vn = sqrtf(a);
@@ -153,9 +156,10 @@ __global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol
   const int j = blockIdx.x * 16 + cx;
   float a = 0.f, b = 0.f;
   AdamCol c;
-  if (j < n_cols) { c = cols[j]; col_partial_sums(c, partC, nullptr, zy, a, b); }
+  bool skip = true;
+  if (j < n_cols) { c = cols[j]; skip = c.nunits < 0; if (!skip) col_partial_sums(c, partC, nullptr, zy, a, b); }
   a = lanes16_sum(red, zy, cx, a);
-  if (zy != 0 || j >= n_cols) return;
+  if (zy != 0 || j >= n_cols || skip) return;
   const float snew = colscal[4 * j + 3] / sqrtf(a);
   colscal[4 * j + 0] = snew;
   s[c.col_global] = snew;
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, f
                                                         float* m, float* v, const float* colscal,
                                                         const int32_t* colidx0, float* partC, AdamHyper h) {
   const AdamUnit un = units[blockIdx.x];
+  if (un.small && h.weightnorm) return;   // done by wn_small_kernel
   const float lr_t = adam_lr_t(h);
   if (!un.is_matrix || !h.weightnorm) {   // plain Adam (biases; everything when weightnorm is off)
     const int n = un.nrows * un.cols;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, f
 __global__ __launch_bounds__(256) void wn_rescale_kernel(const AdamUnit* units, float* params, const float* colscal,
                                                          const int32_t* colidx0) {
   const AdamUnit un = units[blockIdx.x];
-  if (!un.is_matrix) return;
+  if (!un.is_matrix || un.small) return;
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int cbase = colidx0[blockIdx.x];
   for (int c0 = 0; c0 < un.cols; c0 += 64) {
@@ -234,16 +239,115 @@ __global__ __launch_bounds__(256) void wn_rescale_kernel(const AdamUnit* units, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Matrices of <= 128 rows (every tensor of cl_vae; everything but hW/kernel in cl_vrnn) and the biases: the whole
+// Adam-WN update of 16 columns in ONE workgroup -- both column reductions stay in LDS, parameters and gradients are
+// read once -- instead of five launches with partial slabs in between.
+// ---------------------------------------------------------------------------
+struct SmallItem {
+  int64_t offset;       // tensor's element offset
+  int64_t col_offset;   // tensor's offset into s/mg/vg
+  int32_t rows, cols, col0, is_matrix;
+};
+__global__ __launch_bounds__(256) void wn_small_kernel(const SmallItem* items, float* params, const float* grads, float* m,
+                                                       float* v, float* mg, float* vg, float* s, AdamHyper h) {
+  const SmallItem it = items[blockIdx.x];
+  const float lr_t = adam_lr_t(h);
+  if (!it.is_matrix) {                                  // bias: plain Adam over its elements
+    const int n = it.rows * it.cols;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const size_t o = it.offset + i;
+      const float g = grads[o];
+      const float mn = h.b1 * m[o] + (1.f - h.b1) * g;
+      const float vn = h.b2 * v[o] + (1.f - h.b2) * g * g;
+      m[o] = mn; v[o] = vn;
+      params[o] -= lr_t * mn / (sqrtf(vn) + h.eps);
+    }
+    return;
+  }
+  __shared__ float red[SM_RL][16], tot[2][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = it.col0 + cx;
+  const bool live = col < it.cols;
+  const int cc = min(col, it.cols - 1);
+  const float sc = s[it.col_offset + cc];
+  const float inv_s = 1.f / sc;
+  float pv[SM_RMAX], gv[SM_RMAX], mv[SM_RMAX], vv[SM_RMAX];
+#pragma unroll
+  for (int i = 0; i < SM_RMAX; ++i) {                   // unconditional (clamped) loads, all in flight
+    const size_t o = it.offset + (size_t)min(ry + SM_RL * i, it.rows - 1) * it.cols + cc;
+    pv[i] = params[o]; gv[i] = grads[o]; mv[i] = m[o]; vv[i] = v[o];
+  }
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_RMAX; ++i)
+    if (ry + SM_RL * i < it.rows) {
+      const float V = pv[i] * inv_s;
+      pv[i] = V;
+      a += V * V;
+      b += gv[i] * V;
+    }
+  auto colsum = [&](float x, int slot) {               // sum over the 16 row lanes, result to every lane of the column
+    red[ry][cx] = x;
+    __syncthreads();
+    if (ry == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < SM_RL; ++i) t += red[i][cx];
+      tot[slot][cx] = t;
+    }
+    __syncthreads();
+    return tot[slot][cx];
+  };
+  a = colsum(a, 0);
+  b = colsum(b, 1);
+  const float Vn = sqrtf(a);
+  const float gparam = sc * Vn;
+  const float grad_g = b / Vn;
+  const size_t cg = it.col_offset + cc;
+  const float mgn = h.b1 * mg[cg] + (1.f - h.b1) * grad_g;
+  const float vgn = h.b2 * vg[cg] + (1.f - h.b2) * grad_g * grad_g;
+  const float gnew = gparam - lr_t * mgn / (sqrtf(vgn) + h.eps);
+  const float gov = grad_g / Vn;
+  float c2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_RMAX; ++i)
+    if (ry + SM_RL * i < it.rows) {
+      const float gV = sc * (gv[i] - gov * pv[i]);
+      const float mn = h.b1 * mv[i] + (1.f - h.b1) * gV;
+      const float vn = h.b2 * vv[i] + (1.f - h.b2) * gV * gV;
+      mv[i] = mn; vv[i] = vn;
+      const float Vp = pv[i] - lr_t * mn / (sqrtf(vn) + h.eps);
+      pv[i] = Vp;
+      c2 += Vp * Vp;
+    }
+  c2 = colsum(c2, 0);
+  const float snew = gnew / sqrtf(c2);
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < SM_RMAX; ++i)
+      if (ry + SM_RL * i < it.rows) {
+        const size_t o = it.offset + (size_t)(ry + SM_RL * i) * it.cols + col;
+        m[o] = mv[i]; v[o] = vv[i];
+        params[o] = snew * pv[i];
+      }
+    if (ry == 0) { mg[cg] = mgn; vg[cg] = vgn; s[cg] = snew; }
+  }
+}
+
 __global__ void adam_bump_kernel(int32_t* iterations) { *iterations += 1; }
 
-struct PlanCounts { int n_units, n_cols, n_part; };
+struct PlanCounts { int n_units, n_cols, n_part, n_small, n_big; };
 
+static bool is_small(const clv_param_desc& t) { return !t.is_matrix || t.rows <= SM_ROWS; }
 static PlanCounts plan_counts(const clv_param_desc* t, int n) {
-  PlanCounts c{0, 0, 0};
+  PlanCounts c{0, 0, 0, 0, 0};
   for (int i = 0; i < n; ++i) {
     const int units = (t[i].rows + UNIT_ROWS - 1) / UNIT_ROWS;
     c.n_units += units;
     if (t[i].is_matrix) { c.n_cols += t[i].cols; c.n_part += units * t[i].cols; }
+    if (is_small(t[i])) c.n_small += t[i].is_matrix ? (t[i].cols + 15) / 16 : 1;
+    else c.n_big += 1;
   }
   return c;
 }
@@ -252,12 +356,12 @@ static PlanCounts plan_counts(const clv_param_desc* t, int n) {
 
 using namespace clv;
 
-// device blob: AdamUnit[n_units] | AdamCol[n_cols] | int32 colidx0[n_units]
+// device blob: AdamUnit[n_units] | AdamCol[n_cols] | int32 colidx0[n_units] | SmallItem[n_small]
 extern "C" size_t clv_adam_wn_plan_bytes(const clv_param_desc* host_table, int n_tensors) {
   if (!host_table || n_tensors <= 0) return 0;
   PlanCounts c = plan_counts(host_table, n_tensors);
   return align_up(sizeof(AdamUnit) * c.n_units, 16) + align_up(sizeof(AdamCol) * (c.n_cols > 0 ? c.n_cols : 1), 16) +
-         align_up(sizeof(int32_t) * c.n_units, 16);
+         align_up(sizeof(int32_t) * c.n_units, 16) + align_up(sizeof(SmallItem) * (c.n_small > 0 ? c.n_small : 1), 16);
 }
 
 extern "C" int clv_adam_wn_plan_build(const clv_param_desc* host_table, int n_tensors, void* host_blob) {
@@ -269,10 +373,17 @@ extern "C" int clv_adam_wn_plan_build(const clv_param_desc* host_table, int n_te
   AdamCol* cols = (AdamCol*)p;
   p += align_up(sizeof(AdamCol) * (c.n_cols > 0 ? c.n_cols : 1), 16);
   int32_t* colidx0 = (int32_t*)p;
-  int ui = 0, ci = 0, part = 0;
+  p += align_up(sizeof(int32_t) * c.n_units, 16);
+  SmallItem* small = (SmallItem*)p;
+  int ui = 0, ci = 0, part = 0, si = 0;
   for (int i = 0; i < n_tensors; ++i) {
     const clv_param_desc& t = host_table[i];
     if (t.rows <= 0 || t.cols <= 0) return CLV_EINVAL;
+    if (is_small(t)) {
+      if (t.is_matrix)
+        for (int c0 = 0; c0 < t.cols; c0 += 16) small[si++] = SmallItem{t.offset, t.col_offset, t.rows, t.cols, c0, 1};
+      else small[si++] = SmallItem{t.offset, 0, t.rows, t.cols, 0, 0};
+    }
     const int nun = (t.rows + UNIT_ROWS - 1) / UNIT_ROWS;
     const int part_base = part;
     for (int k = 0; k < nun; ++k) {
@@ -282,7 +393,7 @@ extern "C" int clv_adam_wn_plan_build(const clv_param_desc* host_table, int n_te
       u.nrows = (t.rows - u.row0) < UNIT_ROWS ? (t.rows - u.row0) : UNIT_ROWS;
       u.cols = t.cols; u.is_matrix = t.is_matrix;
       u.part_off = t.is_matrix ? part : 0;
-      u.pad_ = 0;
+      u.small = is_small(t) ? 1 : 0;
       colidx0[ui] = t.is_matrix ? ci : 0;
       if (t.is_matrix) part += t.cols;
       ++ui;
@@ -291,7 +402,7 @@ extern "C" int clv_adam_wn_plan_build(const clv_param_desc* host_table, int n_te
       for (int cidx = 0; cidx < t.cols; ++cidx) {
         AdamCol& c2 = cols[ci + cidx];
         c2.col_global = t.col_offset + cidx;
-        c2.part_base = part_base; c2.nunits = nun; c2.cols = t.cols; c2.col_local = cidx;
+        c2.part_base = part_base; c2.nunits = is_small(t) ? -1 : nun; c2.cols = t.cols; c2.col_local = cidx;
       }
       ci += t.cols;
     }
@@ -321,6 +432,8 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   const AdamCol* cols = (const AdamCol*)p;
   p += align_up(sizeof(AdamCol) * (c.n_cols > 0 ? c.n_cols : 1), 16);
   const int32_t* colidx0 = (const int32_t*)p;
+  p += align_up(sizeof(int32_t) * c.n_units, 16);
+  const SmallItem* small = (const SmallItem*)p;
   float* partA = (float*)ws;
   float* partB = partA + c.n_part;
   float* partC = partB + c.n_part;
@@ -328,14 +441,18 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   AdamHyper h{lr, beta1, beta2, eps, weightnorm, step_t, iterations_dev};
   ProfScope pr("adam_wn_step", st);
   const bool wn = weightnorm && c.n_cols > 0;
-  if (wn) {
+  if (wn && c.n_small > 0)        // small matrices and biases: whole update in one launch (reads `iterations` before the bump)
+    hipLaunchKernelGGL(wn_small_kernel, dim3(c.n_small), dim3(256), 0, st, small, params, grads, m, v, mg, vg, s, h);
+  const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything
+  if (wn && chain) {
     hipLaunchKernelGGL(wn_stats_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, s, partA, partB);
     hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + 15) / 16), dim3(256), 0, st, c.n_cols, cols, partA, partB, s,
                        mg, vg, colscal, h);
   }
-  hipLaunchKernelGGL(wn_update_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, m, v, colscal, colidx0,
-                     partC, h);
-  if (wn) {
+  if (chain)
+    hipLaunchKernelGGL(wn_update_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, m, v, colscal, colidx0,
+                       partC, h);
+  if (wn && chain) {
     hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + 15) / 16), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
                        iterations_dev);
     hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, colscal, colidx0);
