@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256) void wn_stats_kernel(const AdamUnit* units, co
   }
 }
 
-// block = 16 consecutive global matrix columns x 16 unit-lanes; returns this lane's share of the column sums
-constexpr int CL = 16;     // unit-lanes per column
+// block = 4 consecutive global matrix columns x 64 unit-lanes (only tall tensors reach these kernels: hW/kernel has
+// 704 partial rows per column); returns this lane's share of the column sums
+constexpr int CL = 64;     // unit-lanes per column
+constexpr int CPB = 4;     // columns per block
 __device__ __forceinline__ void col_partial_sums(const AdamCol& c, const float* pa, const float* pb, int zy,
                                                  float& a, float& b) {
   const float* qa = pa + c.part_base + c.col_local;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void col_partial_sums(const AdamCol& c, const float* 
   a0 += a2; a1 += a3; b0 += b2; b1 += b3;
   a = a0 + a1; b = b0 + b1;
 }
-__device__ __forceinline__ float lanes16_sum(float (*red)[16], int zy, int cx, float v) {
+__device__ __forceinline__ float lanes16_sum(float (*red)[CPB], int zy, int cx, float v) {
   red[zy][cx] = v;
   __syncthreads();
   float t = 0.f;
@@ -122,9 +124,9 @@ __device__ __forceinline__ float lanes16_sum(float (*red)[16], int zy, int cx, f
 __global__ __launch_bounds__(256) void wn_cols_kernel(int n_cols, const AdamCol* cols, const float* partA,
                                                       const float* partB, const float* s, float* mg, float* vg,
                                                       float* colscal, AdamHyper h) {
-  __shared__ float red[CL][16];
-  const int cx = threadIdx.x & 15, zy = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + cx;
+  __shared__ float red[CL][CPB];
+  const int cx = threadIdx.x & (CPB - 1), zy = threadIdx.x / CPB;
+  const int j = blockIdx.x * CPB + cx;
   float a = 0.f, b = 0.f;
   AdamCol c;
   bool skip = true;
@@ -150,10 +152,10 @@ __global__ __launch_bounds__(256) void wn_cols_kernel(int n_cols, const AdamCol*
 // s' = g'/||V'|| per column -> colscal[4j+0] (reused) and the persistent s; advances `iterations`
 __global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol* cols, const float* partC, float* s,
                                                        float* colscal, int32_t* iterations) {
-  __shared__ float red[CL][16];
+  __shared__ float red[CL][CPB];
   if (blockIdx.x == 0 && threadIdx.x == 0 && iterations) *iterations += 1;
-  const int cx = threadIdx.x & 15, zy = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + cx;
+  const int cx = threadIdx.x & (CPB - 1), zy = threadIdx.x / CPB;
+  const int j = blockIdx.x * CPB + cx;
   float a = 0.f, b = 0.f;
   AdamCol c;
   bool skip = true;
@@ -446,14 +448,14 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything
   if (wn && chain) {
     hipLaunchKernelGGL(wn_stats_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, s, partA, partB);
-    hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + 15) / 16), dim3(256), 0, st, c.n_cols, cols, partA, partB, s,
+    hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + CPB - 1) / CPB), dim3(256), 0, st, c.n_cols, cols, partA, partB, s,
                        mg, vg, colscal, h);
   }
   if (chain)
     hipLaunchKernelGGL(wn_update_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, m, v, colscal, colidx0,
                        partC, h);
   if (wn && chain) {
-    hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + 15) / 16), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
+    hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + CPB - 1) / CPB), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
                        iterations_dev);
     hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, colscal, colidx0);
   } else if (iterations_dev) {
