@@ -59,6 +59,17 @@ __device__ __forceinline__ void regular_slots(int s, int u, size_t bt0, float* h
     ostr[j] = slot < 2 ? LH : LG;
   }
 }
+// the two values lane s stores (slots s and s+4: see regular_slots): 3 selects each instead of a 6-way pick
+__device__ __forceinline__ void pick_pair(int s, float h, float c, const float (&z)[4], float gg, float& v0, float& v1) {
+  v0 = h;                       // flat selects (a nested ?: chain becomes branches around the stores)
+  v0 = s == 1 ? c : v0;
+  v0 = s == 2 ? z[0] : v0;
+  v0 = s == 3 ? z[1] : v0;
+  v1 = gg;
+  v1 = s == 1 ? z[3] : v1;
+  v1 = s == 2 ? h : v1;
+  v1 = s == 3 ? c : v1;
+}
 __device__ __forceinline__ float pick_slot(int slot, float h, float c, const float (&z)[4], float gg) {
   float v = h;
   v = slot == 1 ? c : v;
@@ -147,7 +158,8 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
     float h, gg;
     lstm_cell<GATE>(z, c, h, gg);
-    float v0 = pick_slot(oslot[0], h, c, z, gg), v1 = pick_slot(oslot[1], h, c, z, gg);
+    float v0, v1;
+    pick_pair(s, h, c, z, gg, v0, v1);
     if (wave == PNW - 1) {          // wave-uniform: the latent head of step i-1 (garbage at i == 0, rewritten at i == 1)
       float zv, klv;
       latent(z, ecur, zv, klv);
@@ -219,6 +231,9 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     const float xv = xn + rb;
+    // NOTE (ISA): the register allocator pairs this load's destination with an h value inside a v_pk_fma operand, so
+    // the decoder waves wait for the prefetch in the middle of the FMA block (s_waitcnt vmcnt(0)); with 3 waves per
+    // SIMD the other waves cover most of it (~7 % of the kernel when measured against the variant without the load).
     if (HASXP) xn = xp[(size_t)min(t + 1, T - 1) * LG];
     f2 acc2[2];
 #pragma unroll
@@ -240,8 +255,10 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     float h, gg;
     lstm_cell<GATE>(z, c, h, gg);
     hb[cur ^ 1][hslot] = h;
-    *optr[0] = pick_slot(oslot[0], h, c, z, gg);
-    *optr[1] = pick_slot(oslot[1], h, c, z, gg);
+    float v0, v1;
+    pick_pair(s, h, c, z, gg, v0, v1);
+    *optr[0] = v0;
+    *optr[1] = v1;
     optr[0] += ostr[0];
     optr[1] += ostr[1];
     step_barrier();
