@@ -73,7 +73,7 @@ struct TileLoader {
                               int ones = 0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) mk[i] = 15;
-    if (vec && !ones) {
+    if (vec && ones != 1) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int idx = min(tid + i * 256, NV - 1);         // surplus threads repeat the last vector (never stored)
@@ -94,7 +94,15 @@ struct TileLoader {
           const int rk = max(min(gk, k_end - 1) - shift, 0);
           const float* src = p + (size_t)rk * ld + min(gm, ld - 4);
           v = *reinterpret_cast<const float4*>(src);
-          ok0 = row && gm + 0 < dim_mn; ok1 = row && gm + 1 < dim_mn; ok2 = row && gm + 2 < dim_mn; ok3 = row && gm + 3 < dim_mn;
+          const int nreal = ones == 2 ? dim_mn - 1 : dim_mn;     // ones == 2: the last row of op(A)^T is implicit ones
+          ok0 = row && gm + 0 < nreal; ok1 = row && gm + 1 < nreal; ok2 = row && gm + 2 < nreal; ok3 = row && gm + 3 < nreal;
+          mk[i] = (ok0 ? 1 : 0) | (ok1 ? 2 : 0) | (ok2 ? 4 : 0) | (ok3 ? 8 : 0);
+          if (ones == 2 && gk < k_end) {                          // bits 4..7: component is the ones row
+            const int oc = dim_mn - 1 - gm;
+            if (oc >= 0 && oc < 4) mk[i] |= 16 << oc;
+          }
+          r[i] = v;
+          continue;
         }
         r[i] = v;
         mk[i] = (ok0 ? 1 : 0) | (ok1 ? 2 : 0) | (ok2 ? 4 : 0) | (ok3 ? 8 : 0);
@@ -154,9 +162,10 @@ struct TileLoader {
     const float* p[PER];     // this thread's vector in the current k-tile (clamped to valid memory along m/n)
     int lofs[PER];           // LDS offset of the vector
     int zr[PER];             // (global k of the vector's row) % zperiod
+    int oc[PER];             // component (0..3) of the vector that is the implicit ones row, or -1
   };
   __device__ static void iter_init(Iter& it, const float* __restrict__ base, int ld, int dim_mn, int mn0, int k0, int tid,
-                                   int shift, int zperiod) {
+                                   int shift, int zperiod, int ones = 0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int idx = min(tid + i * 256, NV - 1);
@@ -165,12 +174,15 @@ struct TileLoader {
         it.p[i] = base + (size_t)min(mn0 + mn, dim_mn - 1) * ld + (k0 + k4);
         it.lofs[i] = k4 * LD + mn;
         it.zr[i] = 1;
+        it.oc[i] = -1;
       } else {
         constexpr int RV = BMN / 4;
         const int k = idx / RV, c4 = (idx % RV) * 4;
         it.p[i] = base + (size_t)(k0 + k - shift) * ld + min(mn0 + c4, ld - 4);
         it.lofs[i] = k * LD + c4;
         it.zr[i] = zperiod > 0 ? (k0 + k) % zperiod : 1;
+        const int oc = dim_mn - 1 - (mn0 + c4);
+        it.oc[i] = (ones == 2 && oc >= 0 && oc < 4) ? oc : -1;
       }
     }
   }
@@ -182,10 +194,14 @@ struct TileLoader {
     }
   }
   // store the vectors loaded by iter_load (the row of tile t), then advance the zero-period phase to tile t+1
-  __device__ static void iter_store(Iter& it, const float4 (&r)[PER], float* lds, int tid, int zperiod) {
+  __device__ static void iter_store(Iter& it, const float4 (&r)[PER], float* lds, int tid, int zperiod, int ones = 0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       float4 v = r[i];
+      if (!KC && ones == 2) {                        // uniform: implicit ones row of this problem
+        v.x = it.oc[i] == 0 ? 1.f : v.x; v.y = it.oc[i] == 1 ? 1.f : v.y;
+        v.z = it.oc[i] == 2 ? 1.f : v.z; v.w = it.oc[i] == 3 ? 1.f : v.w;
+      }
       if (!KC && zperiod > 0) {                      // uniform
         const float f = it.zr[i] == 0 ? 0.f : 1.f;
         v.x *= f; v.y *= f; v.z *= f; v.w *= f;
@@ -213,6 +229,12 @@ struct TileLoader {
       // compiler turns the masked load back into a load under a branch
       float4 r_i = make_float4(rr[i].x * ((mk[i] & 1) ? 1.f : 0.f), rr[i].y * ((mk[i] & 2) ? 1.f : 0.f),
                                rr[i].z * ((mk[i] & 4) ? 1.f : 0.f), rr[i].w * ((mk[i] & 8) ? 1.f : 0.f));
+      if (mk[i] & 0xF0) {          // implicit ones row (GemmProb.ones == 2)
+        if (mk[i] & 16) r_i.x = 1.f;
+        if (mk[i] & 32) r_i.y = 1.f;
+        if (mk[i] & 64) r_i.z = 1.f;
+        if (mk[i] & 128) r_i.w = 1.f;
+      }
       if (idx < NV) {
         if (KC) {
           int mn = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
@@ -308,12 +330,13 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
   }
   __syncthreads();
   // interior k-tiles (1 .. nfast): whole tile inside [kbeg, kend) -> incremental addressing, no masks along m/n
-  const bool fastA = g.vecA && !a_ones && (a_zper == 0 || a_zper >= BK) && !(!TA && false);
-  const bool fastB = g.vecB != 0;
+  const bool fastA = g.vecA && a_ones != 1 && !(a_ones == 2 && a_zper > 0) && (a_zper == 0 || a_zper >= BK) &&
+                     !(g.xcd_remap & 2);
+  const bool fastB = g.vecB != 0 && !(g.xcd_remap & 4);
   const int nfull = (kend - kbeg) / BK;              // k-tiles that are completely inside the chunk
   typename LA::Iter ia;
   typename LB::Iter ib;
-  if (fastA) LA::iter_init(ia, Aptr, lda, Mp, m0, kbeg + BK, tid, a_shift, a_zper);
+  if (fastA) LA::iter_init(ia, Aptr, lda, Mp, m0, kbeg + BK, tid, a_shift, a_zper, a_ones);
   if (fastB) LB::iter_init(ib, g.B, g.ldb, g.N, n0, kbeg + BK, tid, 0, 0);
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      if (fastA && inner) LA::iter_store(ia, ra, As + (cur ^ 1) * BK * LDA, tid, a_zper);
+      if (fastA && inner) LA::iter_store(ia, ra, As + (cur ^ 1) * BK * LDA, tid, a_zper, a_ones);
       else LA::store(ra, ma, As + (cur ^ 1) * BK * LDA, tid);
       if (fastB && inner) LB::iter_store(ib, rb, Bs + (cur ^ 1) * BK * LDB, tid, 0);
       else LB::store(rb, mb, Bs + (cur ^ 1) * BK * LDB, tid);
@@ -845,16 +868,20 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   memset(&g, 0, sizeof(g));
   g.nprob = nprob;
   int tile = 0, row = 0, vec = 1;
+  bool has_ones2 = false;
   int bm, bn;
   grouped_tile(probs, nprob, N, bm, bn);
   for (int i = 0; i < nprob; ++i) {
     const clv_gemm_prob& p = probs[i];
-    if (p.M <= 0 || !p.C || (!p.ones && !p.A) || (p.ones && p.M != 1)) return CLV_EINVAL;
+    if (p.M <= 0 || !p.C || (p.ones != 1 && !p.A) || (p.ones == 1 && p.M != 1) || (p.ones == 2 && p.M < 2) ||
+        p.ones < 0 || p.ones > 2)
+      return CLV_EINVAL;
     if (p.a_shift < 0 || (p.a_shift > 0 && p.a_zero_period <= 0)) return CLV_EINVAL;
     g.prob[i] = GemmProb{p.A, p.lda, p.M, p.C, p.ldc, p.a_shift, p.a_zero_period, p.ones, tile, row};
     tile += (p.M + bm - 1) / bm;
     row += p.M;
-    if (!p.ones) vec = vec && (p.lda % 4 == 0) && (((uintptr_t)p.A) % 16 == 0);
+    if (p.ones != 1) vec = vec && (p.lda % 4 == 0) && (((uintptr_t)p.A) % 16 == 0);
+    if (p.ones == 2) { has_ones2 = true; if (p.a_zero_period > 0 || p.a_shift > 0) return CLV_EINVAL; }
   }
   g.M = row; g.N = N; g.K = K; g.alpha = 1.f; g.beta = beta;
   g.B = B; g.ldb = ldb; g.bias = nullptr; g.act = CLV_ACT_NONE; g.aux = nullptr;
@@ -862,7 +889,8 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   g.vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
   char glabel[48] = "gemm_grouped_tn";
   if (prof_on() && getenv("CLV_PROF_SHAPES")) snprintf(glabel, sizeof(glabel), "ggemm %dx%dx%d", row, N, K);
-  if (row <= SK_ROWS && K <= 4096 && split_k <= 1) {     // a few rows over a short K: VALU kernel, no split, no reduce
+  if (has_ones2 && !vec) return CLV_EINVAL;       // the appended ones row is only implemented on the vector-load path
+  if (row <= SK_ROWS && K <= 4096 && split_k <= 1 && !has_ones2) {     // a few rows over a short K: VALU kernel, no split, no reduce
     ProfScope p(glabel, s);
     hipLaunchKernelGGL(tn_skinny_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, g);
     return launch_status();
@@ -875,7 +903,8 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   // in-workgroup split-K: 4 K sub-chunks per workgroup, one slab per workgroup (96 x 96 tiles, enough splits)
   static int kg_on = -1;
   if (kg_on < 0) { const char* e = getenv("CLV_GEMM_KG"); kg_on = e ? atoi(e) : 1; }
-  const bool kg4 = kg_on && bn == 96 && bm == 96 && splits >= 16 && splits % 4 == 0;
+  const long wg_after = (long)tile * ((N + bn - 1) / bn) * (splits / 4);      // workgroups left if 4 chunks share one
+  const bool kg4 = kg_on && bn == 96 && bm == 96 && splits >= 16 && splits % 4 == 0 && wg_after >= 256;
   if (kg4) splits /= 4;                  // = number of slabs / workgroups along K
   g.partial = nullptr;
   if (splits > 1) {

@@ -653,6 +653,17 @@ class VrnnEngine(_EngineBase):
         ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
                              dict(A=None, M=1, C=P.g(name + '/bias'), ones=True)], G4, B, dzsum, ws, defer=rq)
 
+    def _dense_wgrad(self, name, A, lda, rows, N, K, Bm, ws, rq):
+        """Kernel and bias gradient of a Dense layer in one pass over Bm = dL/d(output) [K,N].  When the bias follows the
+        kernel in the flat gradient buffer the pair is ONE problem of rows+1 output rows (last row = implicit ones)."""
+        P = self.P
+        gk, gb = P.g(name + '/kernel'), P.g(name + '/bias')
+        if gb.data_ptr() == gk.data_ptr() + 4 * rows * N and lda % 4 == 0 and A.data_ptr() % 16 == 0:
+            probs = [dict(A=A, lda=lda, M=rows + 1, C=gk, ldc=N, ones=2)]
+        else:
+            probs = [dict(A=A, lda=lda, M=rows, C=gk), dict(A=None, M=1, C=gb, ones=1)]
+        ops.gemm_grouped_tn(probs, N, K, Bm, ws, defer=rq)
+
     def _rq(self):
         """The deferred-reduction queue (single-stream schedule only: a pending job pins its scratch buffer)."""
         return self.rq if self.side is None else None
@@ -725,15 +736,12 @@ class VrnnEngine(_EngineBase):
         C1, BT, off = Cn - 1, B * T, self.off
         ws, rq = self.ws, self._rq()
         # output head: kernel and bias gradient in one pass over dlogits (bias = an implicit row of ones)
-        ops.gemm_grouped_tn([dict(A=self.hs_dec, lda=H, M=H, C=P.g('X_decoded_mean/kernel')),
-                             dict(A=None, M=1, C=P.g('X_decoded_mean/bias'), ones=True)], D, BT, self.dlogits, ws, defer=rq)
+        self._dense_wgrad('X_decoded_mean', self.hs_dec, H, H, D, BT, self.dlogits, ws, rq)
         self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec, self.dzsum_dec,
                           off + L, ws)
-        ops.gemm_grouped_tn([dict(A=self.hs_enc, lda=H, M=H, C=P.g('Zargs/kernel')),
-                             dict(A=None, M=1, C=P.g('Zargs/bias'), ones=True)], 2 * L, BT, self.dzargs, ws, defer=rq)
+        self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)
         self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
-        ops.gemm_grouped_tn([dict(A=self.hW, lda=D, M=D, C=P.g('Wargs/kernel')),
-                             dict(A=None, M=1, C=P.g('Wargs/bias'), ones=True)], 2 * C1, B, self.dwargs, ws, defer=rq)
+        self._dense_wgrad('Wargs', self.hW, D, D, 2 * C1, B, self.dwargs, ws, rq)
         ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
         if rq is not None:
             rq.flush()

@@ -87,7 +87,8 @@ def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None,
 
 
 def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=None):
-    """probs: list of dict(A=tensor|None, lda, M, C=tensor, ldc, shift=0, zero_period=0, ones=False);
+    """probs: list of dict(A=tensor|None, lda, M, C=tensor, ldc, shift=0, zero_period=0, ones=0|1|2);
+    ones=1: implicit row of ones (M == 1); ones=2: row M-1 is an implicit row of ones appended to A's M-1 columns;
     C_p[M_p,N] = A_p^T . B for every problem in one launch (all share B [K,N])."""
     L = _lib.lib()
     arr = (_lib.GemmProb * len(probs))()
@@ -95,7 +96,7 @@ def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=
         A = p.get('A')
         arr[i] = _lib.GemmProb(A.data_ptr() if A is not None else None, p.get('lda', p['M']), p['M'],
                                p['C'].data_ptr(), p.get('ldc', N), p.get('shift', 0), p.get('zero_period', 0),
-                               int(bool(p.get('ones', False))))
+                               int(p.get('ones', 0)))
     n = len(probs)
     if split_k is None:
         split_k = L.clv_gemm_grouped_auto_split(arr, n, N, K)

@@ -71,8 +71,10 @@ int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
  * that share B [K,N] -- one pass over dz yields every kernel gradient of an LSTM
  * (x^T.dz, h_{t-1}^T.dz, z^T.dz) or dW and db of a Dense layer.  A_p is [K, M_p] row-major (lda).
  * a_shift/a_zero_period: row k of A_p is taken from row k - a_shift and is zero when
- * k % a_zero_period == 0 (h_{t-1}: shift 1, period T, zero initial state).  ones != 0: A_p is an
- * implicit row of ones, M_p must be 1 (column sums of B = bias gradient).
+ * k % a_zero_period == 0 (h_{t-1}: shift 1, period T, zero initial state).  ones == 1: A_p is an
+ * implicit row of ones, M_p must be 1 (column sums of B = bias gradient).  ones == 2: A_p has M_p - 1 real
+ * columns and row M_p - 1 of C_p is that column sum -- a Dense layer's kernel and bias gradient as ONE problem
+ * when the bias follows the kernel in the flat gradient buffer (A 16-byte aligned, lda % 4 == 0, no shift).
  * Replaces the weight-gradient half of K.gradients() for cl_vrnn/model.py:196-199,225-228. */
 typedef struct clv_gemm_prob {
   const float* A; int32_t lda; int32_t M;
