@@ -553,7 +553,13 @@ static int launch_reduce(const ReduceJob& j, hipStream_t s) {
 // its split-K chain is a string of dependent round trips, so this runs on the VALU: a block owns 64 output
 // columns, 16 k-lanes stride through K with every row's accumulator in registers, LDS-reduce at the end.
 constexpr int SK_ROWS = 16, SK_KC = 256;
-__global__ __launch_bounds__(1024) void tn_skinny_kernel(GemmArgs g) {
+__device__ __forceinline__ void tn_skinny_body(const GemmArgs& g);
+__global__ __launch_bounds__(1024) void tn_skinny_kernel(GemmArgs g) { tn_skinny_body(g); }
+// two independent products of this kind (the two LSTMs of cl_vrnn) in one launch: blockIdx.y picks the set
+__global__ __launch_bounds__(1024) void tn_skinny2_kernel(GemmArgs g0, GemmArgs g1) {
+  if (blockIdx.y == 0) tn_skinny_body(g0); else tn_skinny_body(g1);
+}
+__device__ __forceinline__ void tn_skinny_body(const GemmArgs& g) {
   __shared__ __attribute__((aligned(16))) float At[SK_KC][SK_ROWS];     // A^T chunk, [k][row] (broadcast reads: no padding needed)
   __shared__ float red[8][16][64];
   const int tid = threadIdx.x, cx = tid & 63;
@@ -974,5 +980,35 @@ extern "C" int clv_gemm_bce_f32(int M, int N, int K, const float* A, int lda, co
   else if (N <= 32) launch_cfg<1, 2, 4, 1>(g, 0, 0, 1, s);
   else if (N <= 96) launch_cfg<1, 6, 4, 1>(g, 0, 0, 1, s);
   else launch_cfg<1, 11, 4, 1>(g, 0, 0, 1, s);
+  return launch_status();
+}
+
+// Two few-row grouped products C_p = A_p^T . B (rows in total <= 16 each, K <= 4096) with different B operands in ONE
+// launch -- the label rows and the bias of both LSTM input-kernel gradients of cl_vrnn (B = sum_t dz of each LSTM).
+extern "C" int clv_gemm_grouped_tn_small2(const clv_gemm_prob* probs0, int nprob0, const float* B0,
+                                          const clv_gemm_prob* probs1, int nprob1, const float* B1,
+                                          int N, int K, int ldb, void* stream) {
+  using namespace clv;
+  if (!probs0 || !probs1 || !B0 || !B1 || N <= 0 || K <= 0 || K > 4096) return CLV_EINVAL;
+  GemmArgs g[2];
+  const clv_gemm_prob* pp[2] = {probs0, probs1};
+  const int np[2] = {nprob0, nprob1};
+  const float* Bs[2] = {B0, B1};
+  for (int q = 0; q < 2; ++q) {
+    if (np[q] < 1 || np[q] > MAX_PROB) return CLV_EINVAL;
+    memset(&g[q], 0, sizeof(GemmArgs));
+    int row = 0;
+    for (int i = 0; i < np[q]; ++i) {
+      const clv_gemm_prob& p = pp[q][i];
+      if (p.M <= 0 || !p.C || (p.ones != 1 && !p.A) || (p.ones == 1 && p.M != 1) || p.ones < 0 || p.ones > 1) return CLV_EINVAL;
+      g[q].prob[i] = GemmProb{p.A, p.lda, p.M, p.C, p.ldc, p.a_shift, p.a_zero_period, p.ones, 0, row};
+      row += p.M;
+    }
+    if (row > SK_ROWS) return CLV_EINVAL;
+    g[q].nprob = np[q]; g[q].M = row; g[q].N = N; g[q].K = K; g[q].alpha = 1.f; g[q].B = Bs[q]; g[q].ldb = ldb;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("gemm_grouped_tn", s);
+  hipLaunchKernelGGL(tn_skinny2_kernel, dim3((N + 63) / 64, 2), dim3(1024), 0, s, g[0], g[1]);
   return launch_status();
 }

@@ -650,8 +650,9 @@ class VrnnEngine(_EngineBase):
         ops.gemm_grouped_tn([dict(A=X_in, lda=x_ld, M=x_rows, C=P.g(name + '/kernel')),
                              dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)],
                             G4, BT, dz, ws, defer=rq)
-        ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
-                             dict(A=None, M=1, C=P.g(name + '/bias'), ones=True)], G4, B, dzsum, ws, defer=rq)
+        if not (Cn + 1 <= 16 and B <= 4096):      # else: both LSTMs' label rows + biases in one launch (grads_tail)
+            ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
+                                 dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)], G4, B, dzsum, ws, defer=rq)
 
     def _dense_wgrad(self, name, A, lda, rows, N, K, Bm, ws, rq):
         """Kernel and bias gradient of a Dense layer in one pass over Bm = dL/d(output) [K,N].  When the bias follows the
@@ -741,6 +742,11 @@ class VrnnEngine(_EngineBase):
                           off + L, ws)
         self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)
         self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
+        if Cn + 1 <= 16 and B <= 4096:
+            wprobs = lambda name, w_row: [dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
+                                          dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)]
+            ops.gemm_grouped_tn_small2(wprobs('encoder_h', D), self.dzsum_enc, wprobs('decoder_h', off + L), self.dzsum_dec,
+                                       4 * H, B)
         self._dense_wgrad('Wargs', self.hW, D, D, 2 * C1, B, self.dwargs, ws, rq)
         ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
         if rq is not None:

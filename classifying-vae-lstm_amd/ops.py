@@ -118,6 +118,23 @@ def gemm_bce(A, B, bias, Y, scale, logits, dlogits, rownll, M, N, K, lda=None, l
                                       _ptr(rownll), _stream()), "clv_gemm_bce_f32")
 
 
+def _prob_array(probs, N):
+    arr = (_lib.GemmProb * len(probs))()
+    for i, p in enumerate(probs):
+        A = p.get('A')
+        arr[i] = _lib.GemmProb(A.data_ptr() if A is not None else None, p.get('lda', p['M']), p['M'],
+                               p['C'].data_ptr(), p.get('ldc', N), p.get('shift', 0), p.get('zero_period', 0),
+                               int(p.get('ones', 0)))
+    return arr
+
+
+def gemm_grouped_tn_small2(probs0, B0, probs1, B1, N, K, ldb=None):
+    """Two few-row grouped products (different B operands) in one launch; see clv_gemm_grouped_tn_small2."""
+    a0, a1 = _prob_array(probs0, N), _prob_array(probs1, N)
+    check(_lib.lib().clv_gemm_grouped_tn_small2(a0, len(probs0), _ptr(B0), a1, len(probs1), _ptr(B1), N, K,
+                                                ldb if ldb is not None else N, _stream()), "clv_gemm_grouped_tn_small2")
+
+
 def loss_sums(terms, out):
     """terms: five (tensor, n, stride); out[k] = mean of term k."""
     a = []

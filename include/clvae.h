@@ -86,6 +86,12 @@ size_t clv_gemm_grouped_workspace_bytes(const clv_gemm_prob* host_probs, int npr
 int clv_gemm_grouped_tn(const clv_gemm_prob* host_probs, int nprob, int N, int K,
                         const float* B, int ldb, float beta,
                         int split_k, void* ws, size_t ws_bytes, void* stream);
+/* Two such grouped products with few output rows (<= 16 in total each) over a short K (<= 4096) and DIFFERENT B
+ * operands in one launch: the label rows and the bias of both LSTM input-kernel gradients of cl_vrnn
+ * (B = sum_t dz [batch,4H] of the encoder / of the decoder, K = batch).  ones in {0, 1}; beta = 0. */
+int clv_gemm_grouped_tn_small2(const clv_gemm_prob* probs0, int nprob0, const float* B0,
+                               const clv_gemm_prob* probs1, int nprob1, const float* B1,
+                               int N, int K, int ldb, void* stream);
 
 /* Deferred split-K reduction.  The *_deferred forms behave like the plain ones, but when `job` is not
  * NULL and the product was split, they leave the partial slabs in `ws` and describe the pending
