@@ -70,7 +70,7 @@ SIGNATURES = {
     "clv_sparse_proj": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p]),
     "clv_sparse_dense_supported": (_i, [_i]),
     "clv_sparse_dense": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
-    "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p]),
+    "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p]),
     "clv_gemm_bce_f32": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _i, _p, _p]),
     "clv_vrnn_generate_supported": (_i, [_i, _i, _i, _i]),
     "clv_vrnn_generate": (_i, [_i] * 9 + [_u64] + [_p] * 18),

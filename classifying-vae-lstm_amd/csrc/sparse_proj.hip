@@ -166,6 +166,7 @@ struct SparseOuterArgs {
   const float* X;
   const float* G;
   float* out;          // [nx, ldo]
+  float* colsum;       // [N] = sum_b G[b,:] (the layer's bias gradient) or null; written by workgroup 0
 };
 
 __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
   float2 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float2(0.f, 0.f);
+  float2 csum = make_float2(0.f, 0.f);
   for (int b0 = 0; b0 < a.Bn; b0 += SO_BB) {
     const int nb = min(SO_BB, a.Bn - b0);
     // stage X[b0:b0+nb, j0:j0+64] and G[b0:b0+nb, :]
@@ -196,6 +198,15 @@ __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
       Gl[bb * n2 + c] = make_float2(v.x * mk, v.y * mk);
     }
     __syncthreads();
+    if (a.colsum && blockIdx.x == 0 && wave == 15 && lane < n2) {      // bias gradient: column sums of the staged G block
+      float2 t = make_float2(0.f, 0.f);
+      for (int bb = 0; bb < SO_BB; bb += 4) {
+        const float2 g0 = Gl[bb * n2 + lane], g1 = Gl[(bb + 1) * n2 + lane], g2 = Gl[(bb + 2) * n2 + lane], g3 = Gl[(bb + 3) * n2 + lane];
+        t.x += (g0.x + g1.x) + (g2.x + g3.x);
+        t.y += (g0.y + g1.y) + (g2.y + g3.y);
+      }
+      csum.x += t.x; csum.y += t.y;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int jj = wave + 16 * i;                 // this wave's i-th input of the tile
@@ -217,6 +228,10 @@ __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
       }
     }
     __syncthreads();
+  }
+  if (a.colsum && blockIdx.x == 0 && wave == 15 && lane < n2) {
+    a.colsum[2 * lane] = csum.x;
+    a.colsum[2 * lane + 1] = csum.y;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -273,7 +288,7 @@ extern "C" int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, c
 }
 
 extern "C" int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
-                                void* stream) {
+                                float* colsum, void* stream) {
   using namespace clv;
   if (Bn <= 0 || nx <= 0 || !X || !G || !out || ldx < nx || ldg < N || ldo < N || !clv_sparse_dense_supported(N))
     return CLV_EINVAL;
@@ -287,7 +302,7 @@ extern "C" int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  SparseOuterArgs a{Bn, nx, N, ldx, ldg, ldo, X, G, out};
+  SparseOuterArgs a{Bn, nx, N, ldx, ldg, ldo, X, G, out, colsum};
   ProfScope p("sparse_outer", s);
   hipLaunchKernelGGL(sparse_outer_kernel, dim3((nx + SO_JT - 1) / SO_JT), dim3(1024), lds, s, a);
   return launch_status();

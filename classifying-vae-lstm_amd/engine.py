@@ -722,10 +722,11 @@ class VrnnEngine(_EngineBase):
                            P.rows(P.params, 'decoder_h/kernel', off + L), self.wargs, eps_W, w_true, self.W, self.hW,
                            P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
                            self.dwargs, self.dhW)
-        if self.sparse_inputs and ops.sparse_dense_supported(D):
-            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'))
+        if self.sparse_inputs and ops.sparse_dense_supported(D):      # kernel gradient and bias gradient (column sums of dhW)
+            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'))
         else:
             g(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)
+            ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
         if do_tail:
             self.grads_tail(X)
 
@@ -748,6 +749,5 @@ class VrnnEngine(_EngineBase):
             ops.gemm_grouped_tn_small2(wprobs('encoder_h', D), self.dzsum_enc, wprobs('decoder_h', off + L), self.dzsum_dec,
                                        4 * H, B)
         self._dense_wgrad('Wargs', self.hW, D, D, 2 * C1, B, self.dwargs, ws, rq)
-        ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
         if rq is not None:
             rq.flush()

@@ -192,10 +192,10 @@ def sparse_dense(R, nx, N, X, ldx, K, bias, act, out, ldo=None):
                                       ldo if ldo is not None else N, _stream()), "clv_sparse_dense")
 
 
-def sparse_outer(Bn, nx, N, X, ldx, G, ldg, out, ldo=None):
-    """out[j,:N] = sum_b X[b,j] G[b,:] (kernel gradient of a Dense layer with sparse inputs)."""
+def sparse_outer(Bn, nx, N, X, ldx, G, ldg, out, ldo=None, colsum=None):
+    """out[j,:N] = sum_b X[b,j] G[b,:] (kernel gradient of a Dense layer with sparse inputs); colsum[N] = sum_b G[b,:]."""
     check(_lib.lib().clv_sparse_outer(Bn, nx, N, _ptr(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
-                                      _stream()), "clv_sparse_outer")
+                                      _ptr(colsum), _stream()), "clv_sparse_outer")
 
 
 def vrnn_generate_supported(D, H, L, Cn):

@@ -304,7 +304,7 @@ int clv_sparse_dense_supported(int N);
 int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, const float* K, const float* bias, int act,
                      float* out, int ldo, void* stream);
 int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
-                     void* stream);
+                     float* colsum /* [N] = sum_b G[b,:], the layer's bias gradient; may be NULL */, void* stream);
 
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
  * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71).

@@ -379,10 +379,12 @@ def test_sparse_outer_matches_dense(dev, Bn, nx, Nn, dense):
     X = rng.standard_normal((Bn, nx)).astype(np.float32) if dense else (rng.random((Bn, nx)) < 0.0443).astype(np.float32)
     G = rng.standard_normal((Bn, Nn)).astype(np.float32)
     out = torch.full((nx, Nn), -3.0, dtype=torch.float32, device=dev)
-    ops.sparse_outer(Bn, nx, Nn, T(X, dev), nx, T(G, dev), Nn, out)
+    cs = torch.full((Nn,), -3.0, dtype=torch.float32, device=dev)
+    ops.sparse_outer(Bn, nx, Nn, T(X, dev), nx, T(G, dev), Nn, out, colsum=cs)
     torch.cuda.synchronize()
     ref = X.astype(np.float64).T @ G.astype(np.float64)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), G.astype(np.float64).sum(0), rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize("M,Nn,K", [(100, 88, 88), (37, 18, 40), (70, 130, 24)])
