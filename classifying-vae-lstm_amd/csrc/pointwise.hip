@@ -183,6 +183,18 @@ __global__ __launch_bounds__(1024) void loss_sums_kernel(SumArgs a, float* out) 
   const int n = a.n[k], st = a.stride[k];
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
   int i = threadIdx.x;
+  if (st == 1 && ((uintptr_t)x) % 16 == 0) {        // contiguous term: float4 loads, 4 in flight per thread
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const int n4 = n / 4;
+    int j = threadIdx.x;
+    for (; j + 3072 < n4; j += 4096) {
+      const float4 a = x4[j], b = x4[j + 1024], c = x4[j + 2048], d = x4[j + 3072];
+      acc0 += (a.x + a.y) + (a.z + a.w); acc1 += (b.x + b.y) + (b.z + b.w);
+      acc2 += (c.x + c.y) + (c.z + c.w); acc3 += (d.x + d.y) + (d.z + d.w);
+    }
+    for (; j < n4; j += 1024) { const float4 a = x4[j]; acc0 += (a.x + a.y) + (a.z + a.w); }
+    i = 4 * n4 + threadIdx.x;                        // tail elements
+  }
   for (; i + 3072 < n; i += 4096) {
     acc0 += x[(size_t)i * st]; acc1 += x[(size_t)(i + 1024) * st];
     acc2 += x[(size_t)(i + 2048) * st]; acc3 += x[(size_t)(i + 3072) * st];
