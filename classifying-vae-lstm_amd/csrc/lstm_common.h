@@ -60,6 +60,26 @@ __device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)
   }
 }
 
+// the same product with scalar FMAs: no register pairs, so no v_pk operand can alias the destination of a load in flight
+__device__ __forceinline__ void slice_matvec_scalar(const float* hslice, const f2 (&Ur)[PKK][2], f2 (&acc2)[2]) {
+  const float4* hp = reinterpret_cast<const float4*>(hslice);
+  float hv[PKP];
+#pragma unroll
+  for (int q = 0; q < PKP / 4; ++q) {
+    const float4 v = hp[q];
+    hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+  }
+  float a0 = acc2[0][0], a1 = acc2[0][1], a2 = acc2[1][0], a3 = acc2[1][1];
+#pragma unroll
+  for (int kk = 0; kk < PKK; ++kk) {
+    a0 = fmaf(hv[kk], Ur[kk][0][0], a0);
+    a1 = fmaf(hv[kk], Ur[kk][0][1], a1);
+    a2 = fmaf(hv[kk], Ur[kk][1][0], a2);
+    a3 = fmaf(hv[kk], Ur[kk][1][1], a3);
+  }
+  acc2[0][0] = a0; acc2[0][1] = a1; acc2[1][0] = a2; acc2[1][1] = a3;
+}
+
 template <int GATE>
 __device__ __forceinline__ void lstm_cell(const float (&z)[4], float& c, float& h, float& gg) {
   const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);

@@ -15,6 +15,8 @@
 // Group j carries (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1): latent_dim <= 16.
 // The decoder adds z_t . K_z (the z rows of its input kernel) to its input projection itself, so
 // the projection GEMM only covers the history frames x_{t-1}.
+#include <stdlib.h>
+
 #include "lstm_common.h"
 
 namespace clv {
@@ -231,9 +233,6 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     const float xv = xn + rb;
-    // NOTE (ISA): the register allocator pairs this load's destination with an h value inside a v_pk_fma operand, so
-    // the decoder waves wait for the prefetch in the middle of the FMA block (s_waitcnt vmcnt(0)); with 3 waves per
-    // SIMD the other waves cover most of it (~7 % of the kernel when measured against the variant without the load).
     if (HASXP) xn = xp[(size_t)min(t + 1, T - 1) * LG];
     f2 acc2[2];
 #pragma unroll
@@ -248,7 +247,11 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
         acc2[1] = __builtin_elementwise_fma(zz, Kzr[q][1], acc2[1]);
       }
     }
-    slice_matvec(&hb[cur][PKP * s], Ur, acc2);
+    // scalar FMAs while a prefetch is in flight: with v_pk_fma the allocator pairs the load's destination register
+    // with an h value inside a packed operand, and the wave waits for the load in the middle of the FMA block
+    // (measured: +4 % step throughput for the scalar form; the encoder loop's allocation does not have the problem)
+    if (HASXP) slice_matvec_scalar(&hb[cur][PKP * s], Ur, acc2);
+    else slice_matvec(&hb[cur][PKP * s], Ur, acc2);
     float z[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
