@@ -164,8 +164,8 @@ def bench_generate(args, w, dev, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-persistent', action='store_true', help='generation: per-frame hipGraph replay instead of the persistent kernel')
