@@ -684,7 +684,7 @@ static TileCfg pick_tile(int M, int N, int K) {
   if (N <= 64) return T64x64;
   // tall output, short K (a Dense layer's weight gradient over one batch): enough 32-row tiles to fill the
   // chip without splitting K, so no partial slabs and no reduce pass
-  if (N <= 96 && K <= 512 && M >= 32 * 256 && M < 64 * 256) return T32x96;
+  if (N <= 96 && K <= 512 && M >= 32 * 256) return T32x96;
   if (N <= 96) return M <= 96 ? T96x96 : T64x96;
   if (N % 176 == 0 || N > 256) return M <= 96 ? T96x96 : T64x176;
   return T64x64;
