@@ -14,6 +14,7 @@ if __package__ in (None, ''):          # run as a script: make the package impor
 import clvae_amd  # noqa: E402,F401
 from clvae_amd.cl_vae.model import get_model  # noqa: E402
 from clvae_amd.keras_like import Variable  # noqa: E402
+from clvae_amd.parallel import init_from_env  # noqa: E402
 from clvae_amd.utils.model_utils import (AnnealLossWeight, get_callbacks, init_adam_wn,  # noqa: E402
                                           save_model_in_pieces, to_categorical)
 from clvae_amd.utils.pianoroll import PianoData  # noqa: E402
@@ -21,6 +22,12 @@ from clvae_amd.utils.weightnorm import data_based_init  # noqa: E402
 
 
 def train(args):
+    # one process per GPU under torch.distributed.run: --batch_size stays the GLOBAL batch, each rank holds 1/world
+    # of it (keras_like.Model.fit); a plain `python train.py` is world 1
+    rank, local, world = init_from_env()
+    if args.batch_size % world:
+        raise SystemExit("--batch_size %d is not divisible by the %d processes" % (args.batch_size, world))
+    local_batch, device = args.batch_size // world, 'cuda:%d' % local
     P = PianoData(args.train_file, batch_size=args.batch_size, seq_length=args.seq_length, step_length=1,
                   return_y_next=args.predict_next or args.use_x_prev, squeeze_x=True, squeeze_y=True)
     if args.seq_length > 1:
@@ -55,9 +62,10 @@ def train(args):
     model, enc_model = get_model(args.batch_size, args.original_dim, (args.intermediate_dim, args.latent_dim),
                                  (args.intermediate_class_dim, args.n_classes), args.optimizer, args.class_weight,
                                  kl_weight, use_x_prev=args.use_x_prev, w_kl_weight=w_kl_weight,
-                                 w_log_var_prior=args.w_log_var_prior, seed=getattr(args, 'seed', None))
+                                 w_log_var_prior=args.w_log_var_prior, seed=getattr(args, 'seed', None), device=device)
     args.optimizer = 'adam-wn' if was_adam_wn else args.optimizer
-    save_model_in_pieces(model, args)
+    if rank == 0:
+        save_model_in_pieces(model, args)
 
     if args.use_x_prev:
         xtr = [P.y_train, P.x_train]

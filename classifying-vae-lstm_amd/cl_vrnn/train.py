@@ -19,6 +19,7 @@ if __package__ in (None, ''):
 import clvae_amd  # noqa: E402,F401
 from clvae_amd.cl_vrnn.model import get_model  # noqa: E402
 from clvae_amd.keras_like import Variable  # noqa: E402
+from clvae_amd.parallel import init_from_env  # noqa: E402
 from clvae_amd.utils.model_utils import (AnnealLossWeight, get_callbacks, init_adam_wn,  # noqa: E402
                                           save_model_in_pieces, to_categorical)
 from clvae_amd.utils.pianoroll import PianoData  # noqa: E402
@@ -26,6 +27,12 @@ from clvae_amd.utils.weightnorm import data_based_init  # noqa: E402
 
 
 def train(args):
+    # one process per GPU under torch.distributed.run: --batch_size stays the GLOBAL batch, each rank holds 1/world
+    # of it (keras_like.Model.fit); a plain `python train.py` is world 1
+    rank, local, world = init_from_env()
+    if args.batch_size % world:
+        raise SystemExit("--batch_size %d is not divisible by the %d processes" % (args.batch_size, world))
+    local_batch, device = args.batch_size // world, 'cuda:%d' % local
     P = PianoData(args.train_file, batch_size=args.batch_size, seq_length=args.seq_length, step_length=1,
                   return_y_next=args.predict_next or args.use_x_prev, return_y_hist=True, squeeze_x=False,
                   squeeze_y=False)
@@ -58,12 +65,13 @@ def train(args):
         w_kl_weight = 1.0
 
     args.optimizer, was_adam_wn = init_adam_wn(args.optimizer)
-    model, _ = get_model(args.batch_size, args.original_dim, args.intermediate_dim, args.latent_dim, args.seq_length,
+    model, _ = get_model(local_batch, args.original_dim, args.intermediate_dim, args.latent_dim, args.seq_length,
                          args.n_classes, args.use_x_prev, args.optimizer, args.class_weight, kl_weight,
                          w_kl_weight=w_kl_weight, w_log_var_prior=args.w_log_var_prior,
-                         seed=getattr(args, 'seed', None))
+                         seed=getattr(args, 'seed', None), device=device)
     args.optimizer = 'adam-wn' if was_adam_wn else args.optimizer
-    save_model_in_pieces(model, args)
+    if rank == 0:
+        save_model_in_pieces(model, args)
 
     print((P.x_train.shape, P.y_train.shape))
     if args.use_x_prev:

@@ -15,6 +15,7 @@ import json
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import _lib, ops
 from .trainer import TrainStep
@@ -39,6 +40,7 @@ def set_value(v, x):
 
 class Callback:
     """keras.callbacks.Callback protocol used by utils/model_utils.py."""
+    rank0_only = False       # True for callbacks that write files: data-parallel runs keep them on rank 0
 
     def __init__(self):
         self.model = None
@@ -189,7 +191,9 @@ class Model:
         """(Re)build the captured step when the annealed loss weights changed (they are baked into the graph)."""
         w = self._sync_loss_weights()
         if self._step is None or self._step_weights != w:
-            self._step = TrainStep(self.engine, seed=self.seed, optimizer=self.optimizer.name, lr=self.optimizer.lr)
+            rank, world = _dp()
+            self._step = TrainStep(self.engine, seed=self.seed, rank=rank, world=world, optimizer=self.optimizer.name,
+                                   lr=self.optimizer.lr)
             self._step_weights = w
         return self._step
 
@@ -205,14 +209,22 @@ class Model:
 
     def fit(self, x, y, shuffle=True, epochs=1, batch_size=None, callbacks=None, validation_data=None, verbose=1,
             initial_epoch=0):
+        """Keras' fit() loop on device-resident data.  Under torch.distributed (one process per GPU) the
+        model holds this rank's slice of every global batch: `batch_size` is the GLOBAL batch (world x the model's
+        batch), rank 0 draws the epoch permutation and broadcasts it, rank r takes rows [r*B, (r+1)*B) of each
+        global batch, gradients are averaged inside the step, the epoch's loss sums and the validation sums are
+        all-reduced once per epoch, and callbacks that write files run on rank 0 only (Callback.rank0_only)."""
         eng = self.engine
-        B = eng.B if batch_size is None else int(batch_size)
-        if B != eng.B:
-            raise ValueError("model was built with batch_size %d (fixed batch_shape), got %d" % (eng.B, B))
+        rank, world = _dp()
+        B = eng.B
+        GB = B * world
+        if batch_size is not None and int(batch_size) != GB:
+            raise ValueError("model was built with batch_size %d per process x %d processes, got batch_size %d"
+                             % (B, world, int(batch_size)))
         cur, hist, w_true = self._split_inputs(x, y)
         n = cur.shape[0]
-        if n % B:
-            raise ValueError("number of samples %d is not a multiple of batch_size %d" % (n, B))
+        if n % GB:
+            raise ValueError("number of samples %d is not a multiple of the global batch %d" % (n, GB))
         dev = eng.device
         d_cur, d_hist, d_w = _to_dev(cur, dev), (None if hist is None else _to_dev(hist, dev)), _to_dev(w_true, dev)
         val = None
@@ -221,15 +233,21 @@ class Model:
             if vc.shape[0] % B:
                 raise ValueError("validation samples %d not a multiple of batch_size %d" % (vc.shape[0], B))
             val = (_to_dev(vc, dev), None if vh is None else _to_dev(vh, dev), _to_dev(vw, dev))
+        if world > 1:           # replicas start from rank 0's weights, optimizer state and noise key
+            for t in (eng.P.params, eng.P.m, eng.P.v):
+                dist.broadcast(t, src=0)
+            seed_t = torch.tensor([self.seed], dtype=torch.int64, device=dev)
+            dist.broadcast(seed_t, src=0)
+            if int(seed_t.item()) != self.seed:
+                self.seed, self._step = int(seed_t.item()), None
         self.history = History()
-        cbs = list(callbacks or []) + [self.history]
+        cbs = [c for c in list(callbacks or []) if rank == 0 or not getattr(c, 'rank0_only', False)] + [self.history]
         for c in cbs:
             c.set_model(self)
-            c.set_params({'epochs': epochs, 'batch_size': B, 'samples': n})
+            c.set_params({'epochs': epochs, 'batch_size': GB, 'samples': n})
         self.stop_training = False
         for c in cbs:
             c.on_train_begin({})
-        row = int(np.prod(cur.shape[1:]))
         idx_dev = torch.zeros(n, dtype=torch.int64, device=dev)
         for epoch in range(initial_epoch, epochs):
             for c in cbs:
@@ -239,15 +257,19 @@ class Model:
             if shuffle:
                 np.random.shuffle(index)                        # global np.random state, like Keras (A.4)
             idx_dev.copy_(torch.from_numpy(index))
+            if world > 1:
+                dist.broadcast(idx_dev, src=0)                  # every rank walks rank 0's permutation
             self._acc.zero_()
-            for b0 in range(0, n, B):
-                ts.gather_batch(d_cur, d_hist, d_w, idx_dev[b0:b0 + B])
+            for b0 in range(0, n, GB):
+                ts.gather_batch(d_cur, d_hist, d_w, idx_dev[b0 + rank * B:b0 + (rank + 1) * B])
                 ts.step()
                 ops.axpy(5, 1.0, eng.scal, self._acc)
-            logs = self._logs_from(self._acc, n // B)
+            if world > 1:
+                dist.all_reduce(self._acc)                      # once per epoch (sum over ranks of per-batch means)
+            logs = self._logs_from(self._acc, (n // GB) * world)
             if val is not None:
                 logs.update(self.evaluate_device(*val, prefix='val_'))
-            if verbose:
+            if verbose and rank == 0:
                 print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
             for c in cbs:
                 c.on_epoch_end(epoch, logs)
@@ -259,21 +281,34 @@ class Model:
 
     def evaluate_device(self, d_cur, d_hist, d_w, prefix=''):
         """Validation pass: forward + losses with the sampling noise ON (Lambda layers have no test switch,
-        SURVEY.md 5.9 B10), batch-size chunks, no parameter update."""
+        SURVEY.md 5.9 B10), batch-size chunks, no parameter update.  Under torch.distributed the chunks are dealt
+        round-robin to the ranks and the sums are all-reduced."""
         eng = self.engine
+        rank, world = _dp()
         B = eng.B
         ts = self._train_step()
         acc = torch.zeros(8, dtype=torch.float32, device=eng.device)
         n = d_cur.shape[0]
-        for b0 in range(0, n, B):
+        for j, b0 in enumerate(range(0, n, B)):
+            if j % world != rank:
+                continue
             ts.X.copy_(d_cur[b0:b0 + B].view_as(ts.X))
             if d_hist is not None:
                 ts.Xp.copy_(d_hist[b0:b0 + B].view(ts.Xp.shape))
             ts.w_true.copy_(d_w[b0:b0 + B])
-            ts.draw_noise(stream_offset=2 + b0 // B)
+            ts.draw_noise(stream_offset=2 + b0 // B, row0=0)     # a validation chunk is a whole batch of its own
             eng.loss_and_grads(ts.X, ts.Xp, ts.w_true, ts.eps_w, ts.eps_z, need_grads=False)
             ops.axpy(5, 1.0, eng.scal, acc)
+        if world > 1:
+            dist.all_reduce(acc)
         return self._logs_from(acc, n // B, prefix)
+
+
+def _dp():
+    """(rank, world) of the default process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
 
 
 def save_args_json(args_dict, path):

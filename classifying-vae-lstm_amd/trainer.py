@@ -52,12 +52,13 @@ class TrainStep:
         self._warm = False
 
     # -- pieces -----------------------------------------------------------
-    def draw_noise(self, stream_offset=0):
-        """eps_w / eps_z from the Philox streams (2*stream_offset, 2*stream_offset+1) at this rank's global rows."""
+    def draw_noise(self, stream_offset=0, row0=None):
+        """eps_w / eps_z from the Philox streams (2*stream_offset, 2*stream_offset+1) at this rank's global rows
+        (row0 = first global row of the batch held here; default rank * B)."""
         eng, B = self.eng, self.eng.B
         C1, L = eng.cfg['C'] - 1, eng.cfg['L']
         T = eng.cfg['T'] if self.is_vrnn else 1
-        row0 = self.rank * B                         # global row of this rank's first sample
+        row0 = self.rank * B if row0 is None else int(row0)      # global row of this rank's first sample
         it = eng.P.iterations
         ops.philox_normal2(self.eps_w, B * C1, 2 * stream_offset, eps_first_index(row0, C1),
                            self.eps_z, B * T * L, 2 * stream_offset + 1, eps_first_index(row0, T * L),

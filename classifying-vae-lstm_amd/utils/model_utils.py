@@ -108,6 +108,7 @@ class EarlyStoppingAfterEpoch(Callback):
 
 
 class ModelCheckpointAfterEpoch(Callback):
+    rank0_only = True
     def __init__(self, filepath, monitor, min_epoch=0, save_weights_only=True, save_best_only=True, mode='auto',
                  verbose=False):
         super().__init__()
@@ -131,6 +132,7 @@ class ModelCheckpointAfterEpoch(Callback):
 
 
 class EpochLogger(Callback):
+    rank0_only = True
     """--do_log: per-epoch scalars as JSON lines under <log_dir>/<run>/ (stands in for the TensorBoard callback)."""
 
     def __init__(self, log_dir):

@@ -112,6 +112,39 @@ def test_fit_tracks_an_oracle_training_loop(dev):
     assert int(model.engine.P.iterations.item()) == 6
 
 
+def test_fit_under_a_process_group_matches_plain_fit(dev):
+    """fit() with torch.distributed initialised (one rank, RCCL): the data-parallel code path -- broadcast of weights,
+    noise key and permutation, per-rank batch slices, all-reduced epoch sums, sharded validation -- gives exactly the
+    numbers of the plain path.  (Two ranks on two GPUs is what the driver's multi-GPU bench exercises.)"""
+    import torch.distributed as dist
+    from clvae_amd.cl_vrnn.model import get_model
+    B, T, L, C, n = 4, 6, 2, 3, 16
+    rng = np.random.default_rng(3)
+    win = (rng.random((n, T + 1, 88)) < 0.05).astype(np.float64)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(C)[rng.integers(0, C, n)]
+    data = ([X, Xp], [X, wt, wt, X])
+    val = ([X[:2 * B], Xp[:2 * B]], [X[:2 * B], wt[:2 * B], wt[:2 * B], X[:2 * B]])
+
+    def run():
+        np.random.seed(5)
+        model, _ = get_model(B, 88, 88, L, T, C, True, 'adam-wn', seed=21)
+        h = model.fit(*data, shuffle=True, epochs=2, batch_size=B, verbose=0, validation_data=val)
+        return h.history, model.engine.P.get_weights()
+
+    h0, w0 = run()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29617', rank=0, world_size=1)
+    try:
+        h1, w1 = run()
+    finally:
+        dist.destroy_process_group()
+    assert set(h0) == set(h1)
+    for k in h0:
+        np.testing.assert_array_equal(h0[k], h1[k], err_msg=k)
+    for k in w0:
+        np.testing.assert_array_equal(w0[k], w1[k], err_msg=k)
+
+
 # ------------------------------------------------------------------ sub-models
 def test_cl_vae_submodels_match_oracle(dev):
     from clvae_amd.cl_vae.model import get_model, make_decoder, make_w_encoder, make_z_encoder
