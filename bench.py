@@ -66,14 +66,15 @@ def make_engine(w, dev):
 
 
 def synthetic_windows(w, n, seed, dev):
-    """uint8 Bernoulli(0.0443) piano-roll windows + labels, resident on the device as fp32."""
+    """Bernoulli(0.0443) piano-roll windows + labels, resident on the device the way Model.fit keeps a data set:
+    frames as uint8 (the batch gather converts to float), labels as float32."""
     import torch
     rng = np.random.default_rng(seed)
     T = w['T']
     win = (rng.random((n, T + 1, 88)) < NOTE_DENSITY)
     keys = rng.integers(0, w['C'], n)
     onehot = np.eye(w['C'], dtype=np.float32)[keys]
-    wt = torch.as_tensor(win.astype(np.float32), device=dev)
+    wt = torch.as_tensor(win.astype(np.uint8), device=dev)
     if w['model'] == 'cl_vae':
         return wt[:, 1].contiguous(), wt[:, 0].contiguous(), torch.as_tensor(onehot, device=dev)
     return wt[:, 1:].contiguous(), wt[:, :-1].contiguous(), torch.as_tensor(onehot, device=dev)

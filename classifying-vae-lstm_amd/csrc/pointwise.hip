@@ -293,7 +293,7 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
 
 // up to 3 gathers that share the row index list (current frames, history frames, labels of a mini-batch) in one
 // launch; idx == nullptr: rows row0 .. row0+rows-1 (staging a contiguous batch)
-struct GatherSeg { const float* src; float* out; int64_t row_elems, chunk, out_ld, nwork0; int vec; };
+struct GatherSeg { const float* src; float* out; int64_t row_elems, chunk, out_ld, nwork0; int vec; int u8; };
 struct GatherArgs { GatherSeg seg[3]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; };
 __global__ void gather_multi_kernel(GatherArgs a) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -303,20 +303,31 @@ __global__ void gather_multi_kernel(GatherArgs a) {
     if (k < a.nseg && i >= a.seg[k].nwork0) si = k;
   const float* src = a.seg[0].src; float* out = a.seg[0].out;
   int64_t row_elems = a.seg[0].row_elems, chunk = a.seg[0].chunk, out_ld = a.seg[0].out_ld, w0 = 0;
-  int vec = a.seg[0].vec;
+  int vec = a.seg[0].vec, u8 = a.seg[0].u8;
 #pragma unroll
   for (int k = 1; k < 3; ++k)
     if (si == k) { src = a.seg[k].src; out = a.seg[k].out; row_elems = a.seg[k].row_elems; chunk = a.seg[k].chunk;
-                   out_ld = a.seg[k].out_ld; w0 = a.seg[k].nwork0; vec = a.seg[k].vec; }
+                   out_ld = a.seg[k].out_ld; w0 = a.seg[k].nwork0; vec = a.seg[k].vec; u8 = a.seg[k].u8; }
   i -= w0;
-  const int W = vec ? 4 : 1;                       // work item = one float4 (aligned segments) or one float
+  const int W = vec ? 4 : 1;                       // work item = 4 elements (aligned segments) or one
   const int64_t nw = row_elems / W;
   if (i >= a.rows * nw) return;
   const int64_t r = i / nw, c = (i % nw) * W;
   const int64_t piece = c / chunk, within = c % chunk;
   const int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
-  const float* sp = src + sr * row_elems + c;
   float* dp = out + (r * (row_elems / chunk) + piece) * out_ld + within;
+  if (u8) {                                        // uint8 store (binary piano-roll frames): 4 bytes in, one float4 out
+    const unsigned char* sp = reinterpret_cast<const unsigned char*>(src) + sr * row_elems + c;
+    if (vec) {
+      const unsigned int v = *reinterpret_cast<const unsigned int*>(sp);
+      *reinterpret_cast<float4*>(dp) = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                   (float)(v >> 24));
+    } else {
+      *dp = (float)*sp;
+    }
+    return;
+  }
+  const float* sp = src + sr * row_elems + c;
   if (vec) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
   else *dp = *sp;
 }
@@ -452,8 +463,8 @@ extern "C" int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src
 }
 
 extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
-                                     const float* const* src, float* const* out, const int64_t* row_elems,
-                                     const int64_t* chunk, const int64_t* out_ld, void* stream) {
+                                     const void* const* src, const int32_t* src_u8, float* const* out,
+                                     const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld, void* stream) {
   if (rows <= 0 || nseg < 1 || nseg > 3 || !src || !out || !row_elems || !chunk || !out_ld) return CLV_EINVAL;
   GatherArgs a;
   memset(&a, 0, sizeof(a));
@@ -464,9 +475,10 @@ extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t r
     const int64_t ch = chunk[k] > 0 ? chunk[k] : row_elems[k];
     if (row_elems[k] % ch != 0) return CLV_EINVAL;
     const int64_t ld = chunk[k] > 0 ? out_ld[k] : row_elems[k];
-    const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % 16 == 0 &&
+    const int u8 = src_u8 && src_u8[k];
+    const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % (u8 ? 4 : 16) == 0 &&
                     ((uintptr_t)out[k]) % 16 == 0;
-    a.seg[k] = GatherSeg{src[k], out[k], row_elems[k], ch, ld, work, vec};
+    a.seg[k] = GatherSeg{(const float*)src[k], out[k], row_elems[k], ch, ld, work, vec, u8};
     work += ((rows * (row_elems[k] / (vec ? 4 : 1)) + 255) / 256) * 256;        // segments start on block boundaries
   }
   hipStream_t s = (hipStream_t)stream;

@@ -123,6 +123,15 @@ def _to_dev(a, dev):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32), device=dev)
 
 
+def _frames_to_dev(a, dev):
+    """Piano-roll frames for the device-resident data set: uint8 when every value is 0 or 1 (the gather converts to
+    float while it assembles a batch: a quarter of the HBM footprint and of the read traffic), float32 otherwise."""
+    a = np.asarray(a)
+    if a.size and a.min() >= 0 and a.max() <= 1 and np.array_equal(a, a.astype(np.uint8)):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.uint8), device=dev)
+    return _to_dev(a, dev)
+
+
 class Model:
     """Training model; subclasses set `engine`, `layers`, `output_names`, `_split_inputs`."""
 
@@ -226,13 +235,14 @@ class Model:
         if n % GB:
             raise ValueError("number of samples %d is not a multiple of the global batch %d" % (n, GB))
         dev = eng.device
-        d_cur, d_hist, d_w = _to_dev(cur, dev), (None if hist is None else _to_dev(hist, dev)), _to_dev(w_true, dev)
+        d_cur, d_hist = _frames_to_dev(cur, dev), (None if hist is None else _frames_to_dev(hist, dev))
+        d_w = _to_dev(w_true, dev)
         val = None
         if validation_data is not None:
             vc, vh, vw = self._split_inputs(validation_data[0], validation_data[1])
             if vc.shape[0] % B:
                 raise ValueError("validation samples %d not a multiple of batch_size %d" % (vc.shape[0], B))
-            val = (_to_dev(vc, dev), None if vh is None else _to_dev(vh, dev), _to_dev(vw, dev))
+            val = (_frames_to_dev(vc, dev), None if vh is None else _frames_to_dev(vh, dev), _to_dev(vw, dev))
         if world > 1:           # replicas start from rank 0's weights, optimizer state and noise key
             for t in (eng.P.params, eng.P.m, eng.P.v):
                 dist.broadcast(t, src=0)
@@ -292,10 +302,7 @@ class Model:
         for j, b0 in enumerate(range(0, n, B)):
             if j % world != rank:
                 continue
-            ts.X.copy_(d_cur[b0:b0 + B].view_as(ts.X))
-            if d_hist is not None:
-                ts.Xp.copy_(d_hist[b0:b0 + B].view(ts.Xp.shape))
-            ts.w_true.copy_(d_w[b0:b0 + B])
+            ts.gather_batch(d_cur, d_hist, d_w, None, row0=b0)
             ts.draw_noise(stream_offset=2 + b0 // B, row0=0)     # a validation chunk is a whole batch of its own
             eng.loss_and_grads(ts.X, ts.Xp, ts.w_true, ts.eps_w, ts.eps_z, need_grads=False)
             ops.axpy(5, 1.0, eng.scal, acc)

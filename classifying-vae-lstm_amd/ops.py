@@ -296,15 +296,17 @@ def gather_rows(rows, row_elems, src, idx, out, chunk=0, out_ld=0):
 
 
 def gather_rows_multi(rows, idx, segs, row0=0):
-    """segs: up to 3 (src, out, row_elems, chunk, out_ld); one launch; idx None = rows row0..row0+rows-1."""
+    """segs: up to 3 (src, out, row_elems, chunk, out_ld); one launch; idx None = rows row0..row0+rows-1.
+    A uint8 src (binary frames kept as bytes) is converted to float on the way."""
     n = len(segs)
-    P, I = C.c_void_p * n, C.c_int64 * n
+    P, I, U = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     src = P(*[s_[0].data_ptr() for s_ in segs])
+    u8 = U(*[1 if s_[0].dtype == torch.uint8 else 0 for s_ in segs])
     out = P(*[s_[1].data_ptr() for s_ in segs])
     re = I(*[int(s_[2]) for s_ in segs])
     ch = I(*[int(s_[3]) for s_ in segs])
     ld = I(*[int(s_[4]) for s_ in segs])
-    check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, out, re, ch, ld, _stream()),
+    check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, _stream()),
           "clv_gather_rows_multi")
 
 

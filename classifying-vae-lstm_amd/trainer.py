@@ -95,9 +95,10 @@ class TrainStep:
         """Copy one batch (contiguous device tensors) into the fixed staging buffers: one launch."""
         ops.gather_rows_multi(self.eng.B, None, self._segments(X, Xp, w_true))
 
-    def gather_batch(self, d_cur, d_hist, d_w, ib):
-        """Assemble the batch rows `ib` (device int64 indices) from the HBM-resident data set: one launch."""
-        ops.gather_rows_multi(self.eng.B, ib, self._segments(d_cur, d_hist, d_w))
+    def gather_batch(self, d_cur, d_hist, d_w, ib, row0=0):
+        """Assemble the batch rows `ib` (device int64 indices; None = rows row0..row0+B-1) from the HBM-resident
+        data set (frames float32 or uint8): one launch."""
+        ops.gather_rows_multi(self.eng.B, ib, self._segments(d_cur, d_hist, d_w), row0=row0)
 
     def _eager(self):
         self._main()

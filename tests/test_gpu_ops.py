@@ -407,3 +407,32 @@ def test_gemm_bce_matches_separate_kernels(dev, M, Nn, K):
     np.testing.assert_allclose(N(lg2), N(lg1), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(N(dl2), N(dl1), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(N(rn2), N(rn1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,n,row,chunk,ld,use_idx", [(40, 300, 88 * 4, 88, 96, True), (33, 90, 88, 0, 0, True),
+                                                         (16, 64, 87, 0, 0, True), (25, 100, 88 * 3, 0, 0, False)])
+def test_gather_rows_multi_uint8_store(dev, rows, n, row, chunk, ld, use_idx):
+    """Frames kept as uint8 in HBM gather to exactly the floats the float32 store gives (bit-exact), in one launch
+    together with a float32 segment; aligned (4 bytes -> float4) and unaligned row lengths, chunked output rows."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(rows)
+    F = (rng.random((n, row)) < 0.1).astype(np.uint8)
+    Wl = rng.standard_normal((n, 4)).astype(np.float32)
+    idx = torch.as_tensor(rng.permutation(n)[:rows].astype(np.int64), device=dev) if use_idx else None
+    row0 = 0 if use_idx else 7
+    d_u8, d_f, d_w = torch.as_tensor(F, device=dev), T(F, dev), T(Wl, dev)
+    pieces = row // chunk if chunk else 1
+    width = ld if chunk else row
+    outs = [torch.full((rows * pieces, width), -2.0, dtype=torch.float32, device=dev) for _ in range(2)]
+    wout = [torch.zeros(rows, 4, dtype=torch.float32, device=dev) for _ in range(2)]
+    ops.gather_rows_multi(rows, idx, [(d_u8, outs[0], row, chunk, ld), (d_w, wout[0], 4, 0, 0)], row0=row0)
+    ops.gather_rows_multi(rows, idx, [(d_f, outs[1], row, chunk, ld), (d_w, wout[1], 4, 0, 0)], row0=row0)
+    torch.cuda.synchronize()
+    sel = idx.cpu().numpy() if use_idx else np.arange(row0, row0 + rows)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(wout[0], wout[1])
+    got = outs[0].cpu().numpy()
+    if chunk:
+        got = got[:, :chunk].reshape(rows, row)
+        assert (outs[0].cpu().numpy()[:, chunk:] == -2.0).all()          # padding columns untouched
+    np.testing.assert_array_equal(got, F[sel].astype(np.float32))
+    np.testing.assert_array_equal(wout[0].cpu().numpy(), Wl[sel])
