@@ -72,6 +72,9 @@ SIGNATURES = {
     "clv_sparse_dense": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p]),
     "clv_gemm_bce_f32": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _i, _p, _p]),
+    "clv_out_head_train_supported": (_i, [_i, _i]),
+    "clv_out_head_train_workspace_bytes": (_sz, [_i]),
+    "clv_out_head_train": (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "clv_vrnn_generate_supported": (_i, [_i, _i, _i, _i]),
     "clv_vrnn_generate": (_i, [_i] * 9 + [_u64] + [_p] * 18),
     "clv_label_fwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),

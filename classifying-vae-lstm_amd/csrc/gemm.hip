@@ -11,12 +11,12 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "reduce_job.h"
 
 namespace clv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MAX_PROB = 4;
 // one problem of a grouped launch: C_p[M_p,N] = op(A_p)[M_p,K] . B[K,N]; all problems share B, N, K.
 struct GemmProb {
   const float* A; int lda; int M;
@@ -460,21 +460,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-// One pending split-K reduction: everything the epilogue needs, small enough that a table of them
-// travels as kernel arguments (clv_reduce_job in the C ABI is this struct, opaque).
-struct ReduceProb { float* C; int ldc; int row0; };
-struct ReduceJob {
-  const float* partial;    // [splits][M][N] raw partial sums
-  int M, N, splits, nprob;
-  float alpha, beta;
-  const float* bias;
-  const float* aux;
-  int act;
-  int pad_;
-  ReduceProb prob[MAX_PROB];   // nprob == 0: prob[0] is the single output
-};
-static_assert(sizeof(ReduceJob) <= sizeof(clv_reduce_job), "clv_reduce_job too small");
-
 static ReduceJob make_job(const GemmArgs& g, int splits) {
   ReduceJob j;
   memset(&j, 0, sizeof(j));
@@ -541,7 +526,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t)
     if (i < t.njobs && blockIdx.x >= t.blk0[i]) ji = i;
   reduce_block(t.job[ji], blockIdx.x - t.blk0[ji], red);
 }
-static int launch_reduce(const ReduceJob& j, hipStream_t s) {
+int launch_reduce(const ReduceJob& j, hipStream_t s) {
   ProfScope p("gemm_splitk_reduce", s);
   const size_t mn = (size_t)j.M * j.N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, j);

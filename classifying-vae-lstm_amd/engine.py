@@ -13,6 +13,7 @@ buffer; gradients, Adam m/v use the same layout; the weight-norm column state
 """
 import contextlib
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -387,6 +388,10 @@ class VrnnEngine(_EngineBase):
         self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj
         # input projections by sparse row gathering (exact for any input; pays off for piano-roll frames)
         self.sparse_inputs = bool(cfg.get('sparse_inputs', True)) and ops.sparse_proj_supported(D, 4 * H)
+        # output head: forward + loss + all three backward products in one launch
+        self.fuse_head = bool(cfg.get('fuse_head', os.environ.get('CLV_FUSE_HEAD', '1') != '0')) \
+            and ops.out_head_train_supported(H, D)
+        self._head_done = False
         self.hW = _f(d, B, D)
         self.wargs = _f(d, B, 2 * (Cn - 1))
         self.W = _f(d, B, Cn)
@@ -481,10 +486,19 @@ class VrnnEngine(_EngineBase):
     def _output_head(self, X, nll):
         cfg, P = self.cfg, self.P
         D, H, BT = cfg['D'], cfg['H'], self.B * cfg['T']
+        self._head_done = False
         if nll is not None:
             scale, need_grads = nll
-            ops.gemm_bce(self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale, self.logits,
-                         self.dlogits if need_grads else None, self.rownll, BT, D, H)
+            if need_grads and self.fuse_head:
+                # forward, loss, dL/dh_dec and the layer's weight gradients in one pass over hs_dec (csrc/out_head.hip);
+                # the weight-gradient slabs are summed with the other pending reductions in grads_tail()
+                ops.out_head_train(BT, H, D, self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale,
+                                   self.rownll, self.dhs, P.g('X_decoded_mean/kernel'), P.g('X_decoded_mean/bias'),
+                                   self.ws, logits=self.logits, defer=self._rq())
+                self._head_done = True
+            else:
+                ops.gemm_bce(self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale, self.logits,
+                             self.dlogits if need_grads else None, self.rownll, BT, D, H)
             self._nll_done = True
         else:
             ops.gemm(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'),
@@ -708,7 +722,8 @@ class VrnnEngine(_EngineBase):
         # Backward, early part: everything on the critical chain dlogits -> BPTT -> label path -> hW kernel gradient.
         # The hW kernel (T*D*D floats) is 87 % of the gradient bytes: with N > 1 GPUs its all-reduce bucket starts
         # here and runs under the weight-gradient products of grads_tail().
-        g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
+        if not self._head_done:
+            g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
         if self.fuse_pair:
             # decoder BPTT, dZ, the latent head's backward, dh_enc and encoder BPTT: one persistent launch
             ops.lstm_pair_bwd(B, T, L, self.kl_weight * inv_bt, P.p('decoder_h/recurrent_kernel'),
@@ -738,7 +753,8 @@ class VrnnEngine(_EngineBase):
         C1, BT, off = Cn - 1, B * T, self.off
         ws, rq = self.ws, self._rq()
         # output head: kernel and bias gradient in one pass over dlogits (bias = an implicit row of ones)
-        self._dense_wgrad('X_decoded_mean', self.hs_dec, H, H, D, BT, self.dlogits, ws, rq)
+        if not self._head_done:
+            self._dense_wgrad('X_decoded_mean', self.hs_dec, H, H, D, BT, self.dlogits, ws, rq)
         self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec, self.dzsum_dec,
                           off + L, ws)
         self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)

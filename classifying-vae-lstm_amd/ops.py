@@ -118,6 +118,23 @@ def gemm_bce(A, B, bias, Y, scale, logits, dlogits, rownll, M, N, K, lda=None, l
                                       _ptr(rownll), _stream()), "clv_gemm_bce_f32")
 
 
+def out_head_train_supported(H, D):
+    return bool(_lib.lib().clv_out_head_train_supported(H, D))
+
+
+def out_head_train(R, H, D, hs, Wo, bo, Y, scale, rownll, dhs, dWo, dbo, ws, logits=None, dlogits=None, ldy=None,
+                   defer=None):
+    """Output head forward + Bernoulli NLL + dhs + dWo/dbo in one launch (see clv_out_head_train).
+    defer: a ReduceQueue that takes the pending reduction of the weight-gradient slabs."""
+    L = _lib.lib()
+    need = L.clv_out_head_train_workspace_bytes(R)
+    buf = defer.scratch(need) if defer is not None else ws.ensure(need)
+    job = defer.next_job() if defer is not None else None
+    check(L.clv_out_head_train(R, H, D, _ptr(hs), _ptr(Wo), _ptr(bo), _ptr(Y), ldy if ldy is not None else D,
+                               float(scale), _ptr(logits), _ptr(rownll), _ptr(dlogits), _ptr(dhs), _ptr(dWo), _ptr(dbo),
+                               _ptr(buf), buf.numel(), job, _stream()), "clv_out_head_train")
+
+
 def _prob_array(probs, N):
     arr = (_lib.GemmProb * len(probs))()
     for i, p in enumerate(probs):

@@ -284,6 +284,19 @@ int clv_gemm_bce_f32(int M, int N, int K, const float* A, int lda, const float* 
                      const float* Y, int ldy, float scale, float* logits, float* dlogits, int ldc,
                      float* rownll, void* stream);
 
+/* The output head of cl_vrnn in one training pass (H == D == 88): logits = hs.Wo + bo, the Bernoulli NLL and its
+ * gradient exactly as clv_gemm_bce_f32, then dhs = dl.Wo^T (upstream gradient of the decoder BPTT) and
+ * dWo = hs^T.dl, dbo = sum_r dl, with dl kept on chip (cl_vrnn/model.py:229-234, 241-242 and their K.gradients).
+ * hs [R,88] and Wo 16-byte aligned; logits / dlogits may be NULL (not stored).  dWo/dbo leave as one partial slab per
+ * workgroup in `ws`: with job == NULL they are reduced at once, otherwise *job receives the pending reduction for
+ * clv_splitk_reduce_multi.  Replaces clv_gemm_bce_f32 + clv_gemm_f32 (NT) + clv_gemm_grouped_tn for this layer. */
+int clv_out_head_train_supported(int H, int D);
+size_t clv_out_head_train_workspace_bytes(int R);
+int clv_out_head_train(int R, int H, int D, const float* hs, const float* Wo, const float* bo,
+                       const float* Y, int ldy, float scale, float* logits, float* rownll, float* dlogits,
+                       float* dhs, float* dWo, float* dbo, void* ws, size_t ws_bytes, clv_reduce_job* job,
+                       void* stream);
+
 /* y[i] += alpha * x[i]  (epoch running sums of the loss scalars stay on the device) */
 int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
 

@@ -154,6 +154,34 @@ def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate, pair):
         np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
 
 
+def test_cl_vrnn_fused_and_separate_output_head_agree(dev):
+    """Output head as one launch (clv_out_head_train, default) == gemm_bce + dhs GEMM + weight-gradient GEMM."""
+    from clvae_amd.engine import VrnnEngine
+    B, Tn, L, Cn = 8, 40, 2, 10
+    rng = np.random.default_rng(78)
+    base = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(base, seed=4).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    args_np = (win[:, 1:].copy(), win[:, :-1].copy(), np.eye(Cn)[rng.integers(0, Cn, B)],
+               rng.standard_normal((B, Cn - 1)), rng.standard_normal((B, Tn, L)))
+    res = []
+    for flag in (True, False):
+        cfg = dict(base)
+        cfg['fuse_head'] = flag
+        eng = VrnnEngine(cfg, B, dev)
+        assert eng.fuse_head == flag
+        eng.P.set_weights(p)
+        eng.loss_and_grads(*(T(a, dev) for a in args_np))
+        torch.cuda.synchronize()
+        res.append((eng.losses(), eng.P.get_weights(eng.P.grads), N(eng.logits)))
+    for k in res[0][0]:
+        assert abs(res[0][0][k] - res[1][0][k]) <= 1e-4 * max(1.0, abs(res[1][0][k])), k
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-5)
+    for k in res[0][1]:
+        scale = np.abs(res[1][1][k]).max() + 1e-12
+        assert np.abs(res[0][1][k] - res[1][1][k]).max() <= 2e-5 * scale, k
+
+
 def test_cl_vrnn_step_is_graph_replayable(dev):
     """The whole step enqueues kernels only: capture once, replay, same numbers."""
     from clvae_amd import ops

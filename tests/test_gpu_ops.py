@@ -436,3 +436,41 @@ def test_gather_rows_multi_uint8_store(dev, rows, n, row, chunk, ld, use_idx):
         assert (outs[0].cpu().numpy()[:, chunk:] == -2.0).all()          # padding columns untouched
     np.testing.assert_array_equal(got, F[sel].astype(np.float32))
     np.testing.assert_array_equal(wout[0].cpu().numpy(), Wl[sel])
+
+
+@pytest.mark.parametrize("R,defer,store", [(1, False, True), (37, False, True), (128, True, True), (1000, True, False),
+                                           (4096, True, True), (128 * 300 + 5, True, False)])
+def test_out_head_train_matches_numpy(dev, R, defer, store):
+    """clv_out_head_train: logits, row NLL, dhs, dWo, dbo against fp64 numpy (Keras' clipped BCE, cl_vrnn/model.py:229-242);
+    ragged row counts, one block per workgroup and the persistent multi-block case, immediate and deferred reduction."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(R)
+    H = D = 88
+    hs = np.tanh(rng.standard_normal((R, H))).astype(np.float32)
+    Wo = (rng.standard_normal((H, D)) * 0.4).astype(np.float32)
+    Wo[:, 3] *= 30.0                                     # one output column far outside the epsilon clip
+    bo = rng.standard_normal(D).astype(np.float32)
+    Y = (rng.random((R, D)) < 0.1).astype(np.float32)
+    scale = 1.0 / R
+    z = lambda *sh: torch.full(sh, -7.0, dtype=torch.float32, device=dev)
+    logits, dl = (z(R, D), z(R, D)) if store else (None, None)
+    rownll, dhs, dWo, dbo = z(R), z(R, H), z(H, D), z(D)
+    ws = ops.Workspace(dev)
+    rq = ops.ReduceQueue(dev) if defer else None
+    ops.out_head_train(R, H, D, T(hs, dev), T(Wo, dev), T(bo, dev), T(Y, dev), scale, rownll, dhs, dWo, dbo, ws,
+                       logits=logits, dlogits=dl, defer=rq)
+    if rq is not None:
+        rq.flush()
+    torch.cuda.synchronize()
+    a = hs.astype(np.float64) @ Wo.astype(np.float64) + bo
+    clip = np.log((1 - 1e-7) / 1e-7)
+    l = np.clip(a, -clip, clip)
+    nll = (np.maximum(l, 0) + np.log1p(np.exp(-np.abs(l))) - l * Y).sum(1)
+    dlr = scale * (1 / (1 + np.exp(-l)) - Y) * (np.abs(a) <= clip)
+    np.testing.assert_allclose(N(rownll), nll, rtol=2e-5, atol=2e-4)
+    if store:
+        np.testing.assert_allclose(N(logits), a, rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(N(dl), dlr, rtol=1e-4, atol=2e-7 * scale * 10)
+    np.testing.assert_allclose(N(dhs), dlr @ Wo.astype(np.float64).T, rtol=1e-4, atol=3e-5 * scale * 100)
+    np.testing.assert_allclose(N(dWo), hs.astype(np.float64).T @ dlr, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(N(dbo), dlr.sum(0), rtol=1e-4, atol=2e-5)
