@@ -28,6 +28,7 @@ constexpr int OH_NW = 8;           // waves per workgroup, one 16-row tile each
 constexpr int OH_RB = 16 * OH_NW;  // rows per block
 constexpr int OH_TILE = 16 * OH_LD;
 constexpr int OH_SLAB_ROWS = OH + 1;      // dWo rows + the dbo row
+constexpr int OH_P3 = 5;           // weight-gradient tiles per wave (36 tiles over 8 waves: 4 x 5 + 4 x 4)
 
 struct OutHeadArgs {
   int R, ldy;
@@ -52,41 +53,76 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
 
-  for (int e = tid; e < OH * (OH / 4); e += 64 * OH_NW) {              // Wo -> LDS (float4 along the output index)
-    const int h = e / (OH / 4), c4 = e - h * (OH / 4);
-    *reinterpret_cast<float4*>(WoL + h * OH_LD + 4 * c4) = *reinterpret_cast<const float4*>(a.Wo + h * OH + 4 * c4);
-  }
-  for (int e = tid; e < OH * 8; e += 64 * OH_NW) WoL[(e >> 3) * OH_LD + OH + (e & 7)] = 0.f;      // columns 88..95
   float bias[OH_T];
 #pragma unroll
   for (int j = 0; j < OH_T; ++j) bias[j] = a.bo[min(16 * j + r, OH - 1)];
-  __syncthreads();
 
-  f32x4 acc3[OH_T];        // waves 0..5: rows 16*wave .. +15 of [dWo ; dbo], all 6 column tiles
+  // weight-gradient tiles of this wave: tile t = 6*jm + jn covers rows 16*jm.. of [dWo ; dbo], columns 16*jn..
+  const int t0 = wave < 4 ? OH_P3 * wave : 4 * OH_P3 + (OH_P3 - 1) * (wave - 4);
+  const int nt = wave < 4 ? OH_P3 : OH_P3 - 1;
+  int tm[OH_P3], tn[OH_P3];
+  f32x4 acc3[OH_P3];
 #pragma unroll
-  for (int j = 0; j < OH_T; ++j) acc3[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < OH_P3; ++i) {
+    const int t = min(t0 + i, OH_T * OH_T - 1);
+    tm[i] = t / OH_T; tn[i] = t - tm[i] * OH_T;
+    acc3[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   float* myhs = hsT + wave * OH_TILE;
   float* mydl = dlT + wave * OH_TILE;
   constexpr float CLIP = 16.11809555f;     // log((1-1e-7)/1e-7)
 
+  // this wave's 16 rows of hs are one contiguous 5.6 KB piece of HBM: 6 float4 per lane
+  float4 hv[6];
+  auto load_hs = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int e = min(lane + 64 * i, 16 * (OH / 4) - 1);
+      const int rr = e / (OH / 4), c4 = e - rr * (OH / 4);
+      hv[i] = *reinterpret_cast<const float4*>(a.hs + (size_t)min(row0 + rr, a.R - 1) * OH + 4 * c4);
+    }
+  };
+  // targets of this lane's outputs (C/D layout: column 16j + r, rows 4q + reg)
+  float y[OH_T][4];
+  auto load_y = [&](int row0) {
+#pragma unroll
+    for (int j = 0; j < OH_T; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        y[j][reg] = a.Y[(size_t)min(row0 + 4 * q + reg, a.R - 1) * a.ldy + min(16 * j + r, OH - 1)];
+  };
+  load_hs(blockIdx.x * OH_RB + wave * 16);               // both in flight while Wo is staged
+  load_y(blockIdx.x * OH_RB + wave * 16);
+  {
+    constexpr int NV = OH * (OH / 4);                     // Wo -> LDS (float4 along the output index), loads issued together
+    float4 wv[(NV + 64 * OH_NW - 1) / (64 * OH_NW)];
+#pragma unroll
+    for (int i = 0; i < (NV + 64 * OH_NW - 1) / (64 * OH_NW); ++i) {
+      const int e = min(tid + 64 * OH_NW * i, NV - 1);
+      const int h = e / (OH / 4), c4 = e - h * (OH / 4);
+      wv[i] = *reinterpret_cast<const float4*>(a.Wo + h * OH + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < (NV + 64 * OH_NW - 1) / (64 * OH_NW); ++i) {
+      const int e = tid + 64 * OH_NW * i;
+      const int h = e / (OH / 4), c4 = e - h * (OH / 4);
+      if (e < NV) *reinterpret_cast<float4*>(WoL + h * OH_LD + 4 * c4) = wv[i];
+    }
+    for (int e = tid; e < OH * 8; e += 64 * OH_NW) WoL[(e >> 3) * OH_LD + OH + (e & 7)] = 0.f;      // columns 88..95
+  }
+  __syncthreads();
+
   for (int blk = blockIdx.x; blk * OH_RB < a.R; blk += gridDim.x) {
     const int row0 = blk * OH_RB + wave * 16;
-    // ---- this wave's 16 rows of hs: one contiguous 5.6 KB piece of HBM -> LDS tile
+    if (blk != (int)blockIdx.x) { load_hs(row0); load_y(row0); }
     {
-      float4 v[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int e = min(lane + 64 * i, 16 * (OH / 4) - 1);
-        const int rr = e / (OH / 4), c4 = e - rr * (OH / 4);
-        v[i] = *reinterpret_cast<const float4*>(a.hs + (size_t)min(row0 + rr, a.R - 1) * OH + 4 * c4);
-      }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int e = lane + 64 * i;
         const int rr = e / (OH / 4), c4 = e - rr * (OH / 4);
         const float mk = row0 + rr < a.R ? 1.f : 0.f;
         if (e < 16 * (OH / 4))
-          *reinterpret_cast<float4*>(myhs + rr * OH_LD + 4 * c4) = make_float4(v[i].x * mk, v[i].y * mk, v[i].z * mk, v[i].w * mk);
+          *reinterpret_cast<float4*>(myhs + rr * OH_LD + 4 * c4) = make_float4(hv[i].x * mk, hv[i].y * mk, hv[i].z * mk, hv[i].w * mk);
       }
       // columns 88..95 of the tile: the ones column (bias gradient) and zeros
       for (int e = lane; e < 16 * 8; e += 64) {
@@ -94,27 +130,35 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
         myhs[rr * OH_LD + OH + c] = (c == 0 && row0 + rr < a.R) ? 1.f : 0.f;
       }
     }
-    // targets of this lane's outputs (C/D layout: column 16j + r, rows 4q + reg), in flight during the first product
-    float y[OH_T][4];
-#pragma unroll
-    for (int j = 0; j < OH_T; ++j)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        y[j][reg] = a.Y[(size_t)min(row0 + 4 * q + reg, a.R - 1) * a.ldy + min(16 * j + r, OH - 1)];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is wave-private: no barrier
 
     // ---- logits = hs.Wo
     f32x4 acc[OH_T];
 #pragma unroll
     for (int j = 0; j < OH_T; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {   // operands of k-step s+1 are read while the MFMAs of step s issue (explicit register double buffer: left to
+        // itself the compiler reads two operands, waits, issues two MFMAs)
+      float av = myhs[r * OH_LD + q], bv[OH_T];
 #pragma unroll
-    for (int s = 0; s < OH_KS; ++s) {
-      const float av = myhs[r * OH_LD + 4 * s + q];
-      float bv[OH_T];
+      for (int j = 0; j < OH_T; ++j) bv[j] = WoL[q * OH_LD + 16 * j + r];
 #pragma unroll
-      for (int j = 0; j < OH_T; ++j) bv[j] = WoL[(4 * s + q) * OH_LD + 16 * j + r];
+      for (int s = 0; s < OH_KS; ++s) {
+        float an = 0.f, bn[OH_T];
+        if (s + 1 < OH_KS) {
+          an = myhs[r * OH_LD + 4 * (s + 1) + q];
 #pragma unroll
-      for (int j = 0; j < OH_T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[j], 0, 0, 0);
+          for (int j = 0; j < OH_T; ++j) bn[j] = WoL[(4 * (s + 1) + q) * OH_LD + 16 * j + r];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads above the MFMAs (the scheduler sinks them to their uses)
+#pragma unroll
+        for (int j = 0; j < OH_T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < OH_KS) {
+          av = an;
+#pragma unroll
+          for (int j = 0; j < OH_T; ++j) bv[j] = bn[j];
+        }
+      }
     }
     // ---- Bernoulli NLL with Keras' epsilon clip (same arithmetic as the gemm_bce epilogue); dl -> LDS tile
 #pragma unroll
@@ -157,14 +201,28 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
     int wrow[OH_T];
 #pragma unroll
     for (int j = 0; j < OH_T; ++j) wrow[j] = min(16 * j + r, OH - 1) * OH_LD + q;      // units 88..95: repeat row 87 (never stored)
+    {
+      float av = mydl[r * OH_LD + q], bv[OH_T];
 #pragma unroll
-    for (int s = 0; s < OH_KS; ++s) {
-      const float av = mydl[r * OH_LD + 4 * s + q];
-      float bv[OH_T];
+      for (int j = 0; j < OH_T; ++j) bv[j] = WoL[wrow[j]];
 #pragma unroll
-      for (int j = 0; j < OH_T; ++j) bv[j] = WoL[wrow[j] + 4 * s];
+      for (int s = 0; s < OH_KS; ++s) {
+        float an = 0.f, bn[OH_T];
+        if (s + 1 < OH_KS) {
+          an = mydl[r * OH_LD + 4 * (s + 1) + q];
 #pragma unroll
-      for (int j = 0; j < OH_T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[j], 0, 0, 0);
+          for (int j = 0; j < OH_T; ++j) bn[j] = WoL[wrow[j] + 4 * (s + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < OH_T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < OH_KS) {
+          av = an;
+#pragma unroll
+          for (int j = 0; j < OH_T; ++j) bv[j] = bn[j];
+        }
+      }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -177,31 +235,43 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
     }
     __syncthreads();         // every wave's hs and dl tiles are in LDS
 
-    // ---- [dWo ; dbo] += [hs | 1]^T . dl over the block's 128 rows: wave w < 6 owns output rows 16w..16w+15
-    if (wave < OH_T) {
-#pragma unroll 2
+    // ---- [dWo ; dbo] += [hs | 1]^T . dl over the block's 128 rows: the 6 x 6 output tiles are dealt 5,5,5,5,4,4,4,4
+    {
+      auto p3off = [&](int ks) { return (ks >> 2) * OH_TILE + ((ks & 3) * 4 + q) * OH_LD + r; };     // row 4*ks + q of the block
+      float av[OH_P3], bv[OH_P3];
+#pragma unroll
+      for (int i = 0; i < OH_P3; ++i) {
+        av[i] = hsT[p3off(0) + 16 * tm[i]];
+        bv[i] = dlT[p3off(0) + 16 * tn[i]];
+      }
+#pragma unroll 4
       for (int ks = 0; ks < OH_RB / 4; ++ks) {
-        const int off = (ks >> 2) * OH_TILE + ((ks & 3) * 4 + q) * OH_LD + r;       // row 4*ks + q of the block
-        const float av = hsT[off + 16 * wave];
-        float bv[OH_T];
+        const int off = p3off(min(ks + 1, OH_RB / 4 - 1));        // the last step re-reads its own operands (unused)
+        float an[OH_P3], bn[OH_P3];
 #pragma unroll
-        for (int j = 0; j < OH_T; ++j) bv[j] = dlT[off + 16 * j];
+        for (int i = 0; i < OH_P3; ++i) {
+          an[i] = hsT[off + 16 * tm[i]];
+          bn[i] = dlT[off + 16 * tn[i]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < OH_T; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc3[j], 0, 0, 0);
+        for (int i = 0; i < OH_P3; ++i)
+          if (i < nt) acc3[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc3[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < OH_P3; ++i) { av[i] = an[i]; bv[i] = bn[i]; }
       }
     }
     __syncthreads();         // before the next block overwrites the tiles
   }
-  if (wave < OH_T) {
-    float* slab = a.partial + (size_t)blockIdx.x * OH_SLAB_ROWS * OH;
+  float* slab = a.partial + (size_t)blockIdx.x * OH_SLAB_ROWS * OH;
 #pragma unroll
-    for (int j = 0; j < OH_T; ++j)
+  for (int i = 0; i < OH_P3; ++i)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int h = 16 * wave + 4 * q + reg, o = 16 * j + r;
-        if (h < OH_SLAB_ROWS && o < OH) slab[h * OH + o] = acc3[j][reg];
-      }
-  }
+    for (int reg = 0; reg < 4; ++reg) {
+      const int h = 16 * tm[i] + 4 * q + reg, o = 16 * tn[i] + r;
+      if (i < nt && h < OH_SLAB_ROWS && o < OH) slab[h * OH + o] = acc3[i][reg];
+    }
 }
 
 static int out_head_wgs(int R) {
