@@ -264,7 +264,10 @@ __device__ __forceinline__ float apply_act(float v, int act, float aux) {
 // is the same in every group) before group 0 writes ONE partial slab.  Same waves per CU as KG workgroups, 1/KG of
 // the slab traffic.  Needs dynamic LDS (KG * tile bytes).
 extern __shared__ __attribute__((aligned(16))) float gemm_dyn_smem[];
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB, int BK = 16, int KG = 1>
+// PF: tiles in flight between HBM and LDS.  PF = 2 keeps two register sets and issues the loads of tile t+2 at the top
+// of iteration t: at the weight-gradient shapes a load takes ~3600 cycles under load (in-kernel stamps),
+// three times the MFMA phase of an iteration, so one tile of lookahead leaves every k-group waiting for its data.
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB, int BK = 16, int KG = 1, int PF = 1>
 __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
@@ -339,16 +342,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
   if (fastA) LA::iter_init(ia, Aptr, lda, Mp, m0, kbeg + BK, tid, a_shift, a_zper, a_ones);
   if (fastB) LB::iter_init(ib, g.B, g.ldb, g.N, n0, kbeg + BK, tid, 0, 0);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool nxt = kt + 1 < nk;
-    const bool inner = kt + 1 < nfull;              // next tile is a full interior tile (uniform)
-    if (nxt) {
-      if (fastA && inner) LA::iter_load(ia, ra, lda, a_zper);
-      else LA::load(ra, ma, Aptr, lda, Mp, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid, a_shift, a_zper, a_ones);
-      if (fastB && inner) LB::iter_load(ib, rb, g.ldb, 0);
-      else LB::load(rb, mb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
-    }
+  auto mma = [&](int cur) {
     const float* as = As + cur * BK * LDA + wm * WM * 16 + r;
     const float* bs = Bs + cur * BK * LDB + wn * WN * 16 + r;
 #pragma unroll
@@ -364,13 +358,73 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < WN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      if (fastA && inner) LA::iter_store(ia, ra, As + (cur ^ 1) * BK * LDA, tid, a_zper, a_ones);
-      else LA::store(ra, ma, As + (cur ^ 1) * BK * LDA, tid);
-      if (fastB && inner) LB::iter_store(ib, rb, Bs + (cur ^ 1) * BK * LDB, tid, 0);
-      else LB::store(rb, mb, Bs + (cur ^ 1) * BK * LDB, tid);
+  };
+  // tile t >= 1 takes the incremental path while it is a full interior tile (uniform), the general path otherwise
+  auto load_tile = [&](int t, float4 (&xa)[LA::PER], int (&xma)[LA::PER], float4 (&xb)[LB::PER], int (&xmb)[LB::PER]) {
+    const bool inner = t < nfull;
+    if (fastA && inner) LA::iter_load(ia, xa, lda, a_zper);
+    else LA::load(xa, xma, Aptr, lda, Mp, kend, m0, kbeg + t * BK, g.vecA, tid, a_shift, a_zper, a_ones);
+    if (fastB && inner) LB::iter_load(ib, xb, g.ldb, 0);
+    else LB::load(xb, xmb, g.B, g.ldb, g.N, kend, n0, kbeg + t * BK, g.vecB, tid);
+  };
+  auto store_tile = [&](int t, const float4 (&xa)[LA::PER], const int (&xma)[LA::PER], const float4 (&xb)[LB::PER],
+                        const int (&xmb)[LB::PER]) {
+    const bool inner = t < nfull;
+    const int buf = t & 1;
+    if (fastA && inner) LA::iter_store(ia, xa, As + buf * BK * LDA, tid, a_zper, a_ones);
+    else LA::store(xa, xma, As + buf * BK * LDA, tid);
+    if (fastB && inner) LB::iter_store(ib, xb, Bs + buf * BK * LDB, tid, 0);
+    else LB::store(xb, xmb, Bs + buf * BK * LDB, tid);
+  };
+
+  if (PF == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) load_tile(kt + 1, ra, ma, rb, mb);
+      mma(kt & 1);
+      if (kt + 1 < nk) store_tile(kt + 1, ra, ma, rb, mb);
+      __syncthreads();
     }
+  } else {
+    // Two tiles in flight: (ra, rb) and (ra2, rb2) take turns; tile t+2 is requested at the top of iteration t, right
+    // after its register set was emptied into LDS.  Host-checked: every tile of every chunk is a full interior tile on the
+    // incremental path, so the steady-state body is straight-line code and the waits before the LDS stores stay
+    // counted (the loads issued since remain in flight) instead of draining the queue.
+    static_assert(PF == 1 || PF == 2, "1 or 2 tiles in flight");
+    float4 ra2[LA::PER], rb2[LB::PER];
+    auto ld = [&](float4 (&xa)[LA::PER], float4 (&xb)[LB::PER]) {
+      LA::iter_load(ia, xa, lda, a_zper);
+      LB::iter_load(ib, xb, g.ldb, 0);
+    };
+    auto st = [&](int buf, const float4 (&xa)[LA::PER], const float4 (&xb)[LB::PER]) {
+      LA::iter_store(ia, xa, As + buf * BK * LDA, tid, a_zper, a_ones);
+      LB::iter_store(ib, xb, Bs + buf * BK * LDB, tid, 0);
+    };
+    int kt = 0;
+    if (nk > 1) ld(ra2, rb2);                      // tile 1
+    for (; kt + 3 < nk; kt += 2) {
+      ld(ra, rb);                                  // tile kt+2
+      mma(0);
+      st(1, ra2, rb2);                             // tile kt+1
+      __syncthreads();
+      ld(ra2, rb2);                                // tile kt+3
+      mma(1);
+      st(0, ra, rb);                               // tile kt+2
+      __syncthreads();
+    }
+    // tail: tile kt is in LDS buffer 0, tile kt+1 (if any) in (ra2, rb2), tile kt+2 (if any) not requested yet
+    if (kt + 2 < nk) ld(ra, rb);
+    mma(0);
+    if (kt + 1 < nk) st(1, ra2, rb2);
     __syncthreads();
+    if (kt + 1 < nk) {
+      mma(1);
+      if (kt + 2 < nk) st(0, ra, rb);
+      __syncthreads();
+      if (kt + 2 < nk) {
+        mma(0);
+        __syncthreads();
+      }
+    }
   }
 
   if (KG > 1) {
@@ -896,6 +950,12 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   if (kg_on < 0) { const char* e = getenv("CLV_GEMM_KG"); kg_on = e ? atoi(e) : 1; }
   const long wg_after = (long)tile * ((N + bn - 1) / bn) * (splits / 4);      // workgroups left if 4 chunks share one
   const bool kg4 = kg_on && bn == 96 && bm == 96 && splits >= 16 && splits % 4 == 0 && wg_after >= 256;
+  // two tiles in flight per k-group where every tile of every chunk is a full interior tile on the incremental path
+  static int pf2_on = -1;
+  if (pf2_on < 0) { const char* e = getenv("CLV_GEMM_PF2"); pf2_on = e ? atoi(e) : 1; }
+  bool pf2 = kg4 && pf2_on && kc % 16 == 0 && K == kc * splits && vec && g.vecB;
+  for (int i = 0; i < nprob && pf2; ++i)
+    pf2 = probs[i].ones == 0 && (probs[i].a_zero_period == 0 || probs[i].a_zero_period >= 16);
   if (kg4) splits /= 4;                  // = number of slabs / workgroups along K
   g.partial = nullptr;
   if (splits > 1) {
@@ -907,11 +967,14 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
     ProfScope p(glabel, s);
     if (kg4) {
       constexpr int BMq = 96, BNq = 96;
-      auto kern = gemm_f32_kernel<3, 3, 2, 2, true, false, 16, 4>;
+      auto kern1 = gemm_f32_kernel<3, 3, 2, 2, true, false, 16, 4, 1>;
+      auto kern2 = gemm_f32_kernel<3, 3, 2, 2, true, false, 16, 4, 2>;
       const size_t lds = 4 * (2 * 16 * (LdsStride<BMq>::value + LdsStride<BNq>::value)) * sizeof(float);
       static bool attr_set = false;
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
       }
@@ -919,7 +982,8 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
       if (remap < 0) { const char* e = getenv("CLV_GEMM_XCD_REMAP"); remap = e ? atoi(e) : 1; }
       g.xcd_remap = remap && splits > 1 && splits % 8 == 0;
       dim3 grid(g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BMq - 1) / BMq, (g.N + BNq - 1) / BNq, splits);
-      hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, g);
+      if (pf2) hipLaunchKernelGGL(kern2, grid, dim3(1024), lds, s, g);
+      else hipLaunchKernelGGL(kern1, grid, dim3(1024), lds, s, g);
     }
     else if (bn == 16) launch_cfg<2, 1, 4, 1>(g, 1, 0, splits, s);     // 128 x 16
     else if (bn == 32) launch_cfg<1, 2, 4, 1>(g, 1, 0, splits, s);     // 64 x 32

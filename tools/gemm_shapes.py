@@ -1,5 +1,5 @@
 """Time the GEMM shapes of a config-3 training step one by one (200 launches each, HIP events on the launch stream).
-Usage (GPU box): python tools/gemm_shapes.py"""
+Usage (GPU box): python tools/gemm_shapes.py [path/to/libclvae_hip.so]"""
 import os
 import sys
 
@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import clvae_amd  # noqa: F401
-from clvae_amd import ops
+from clvae_amd import _lib, ops
+
+if len(sys.argv) > 1:           # another build of the library (A/B inside one run of the GPU box)
+    _lib.LIB_PATH = sys.argv[1]
 
 dev = torch.device('cuda:0')
 f = lambda *s: torch.randn(*s, device=dev)
