@@ -15,6 +15,16 @@
 
 namespace clv {
 
+// Build with -DCLV_GEMM_STAMPS (make EXTRA=-DCLV_GEMM_STAMPS) to record, for the first wave of every k-group of one
+// workgroup of the in-workgroup split-K kernel, the shader clock at five points of each of its first 16 k-tiles (loop
+// top, loads issued, MFMAs issued, tile stored, after the barrier); tools/gemm_stamps.py prints them.
+#ifdef CLV_GEMM_STAMPS
+__device__ unsigned long long g_stamps[4][16][5];
+#define CLV_STAMP(kt, i) do { if (stamp_on && (kt) < 16) g_stamps[kg][kt][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CLV_STAMP(kt, i) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one problem of a grouped launch: C_p[M_p,N] = op(A_p)[M_p,K] . B[K,N]; all problems share B, N, K.
@@ -377,12 +387,20 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
     else LB::store(xb, xmb, Bs + buf * BK * LDB, tid);
   };
 
+#ifdef CLV_GEMM_STAMPS
+  const bool stamp_on = blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 3 && lane == 0 && wave == 0 && g.nprob > 0 && KG == 4;
+#endif
   if (PF == 1) {
     for (int kt = 0; kt < nk; ++kt) {
+      CLV_STAMP(kt, 0);
       if (kt + 1 < nk) load_tile(kt + 1, ra, ma, rb, mb);
+      CLV_STAMP(kt, 1);
       mma(kt & 1);
+      CLV_STAMP(kt, 2);
       if (kt + 1 < nk) store_tile(kt + 1, ra, ma, rb, mb);
+      CLV_STAMP(kt, 3);
       __syncthreads();
+      CLV_STAMP(kt, 4);
     }
   } else {
     // Two tiles in flight: (ra, rb) and (ra2, rb2) take turns; tile t+2 is requested at the top of iteration t, right
@@ -402,14 +420,24 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
     int kt = 0;
     if (nk > 1) ld(ra2, rb2);                      // tile 1
     for (; kt + 3 < nk; kt += 2) {
+      CLV_STAMP(kt, 0);
       ld(ra, rb);                                  // tile kt+2
+      CLV_STAMP(kt, 1);
       mma(0);
+      CLV_STAMP(kt, 2);
       st(1, ra2, rb2);                             // tile kt+1
+      CLV_STAMP(kt, 3);
       __syncthreads();
+      CLV_STAMP(kt, 4);
+      CLV_STAMP(kt + 1, 0);
       ld(ra2, rb2);                                // tile kt+3
+      CLV_STAMP(kt + 1, 1);
       mma(1);
+      CLV_STAMP(kt + 1, 2);
       st(0, ra, rb);                               // tile kt+2
+      CLV_STAMP(kt + 1, 3);
       __syncthreads();
+      CLV_STAMP(kt + 1, 4);
     }
     // tail: tile kt is in LDS buffer 0, tile kt+1 (if any) in (ra2, rb2), tile kt+2 (if any) not requested yet
     if (kt + 2 < nk) ld(ra, rb);
@@ -1061,3 +1089,9 @@ extern "C" int clv_gemm_grouped_tn_small2(const clv_gemm_prob* probs0, int nprob
   hipLaunchKernelGGL(tn_skinny2_kernel, dim3((N + 63) / 64, 2), dim3(1024), 0, s, g[0], g[1]);
   return launch_status();
 }
+
+#ifdef CLV_GEMM_STAMPS
+extern "C" int clv_dbg_gemm_stamps(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(clv::g_stamps), sizeof(clv::g_stamps));
+}
+#endif

@@ -1,5 +1,7 @@
-"""Per-iteration phase stamps of the LSTM weight-gradient GEMM (needs a library built with the stamp patch, see
-DESIGN.md 8): python tools/gemm_stamps.py path/to/libclvae_hip.so"""
+"""Per-k-tile phase stamps (shader clock) of the LSTM weight-gradient GEMM, one wave per k-group of one workgroup.
+Needs a library built with the stamp code compiled in, e.g. in a scratch copy of the tree:
+    make -C classifying-vae-lstm_amd/csrc EXTRA=-DCLV_GEMM_STAMPS
+then on the GPU box: python tools/gemm_stamps.py path/to/that/libclvae_hip.so"""
 import ctypes as C
 import os
 import sys
