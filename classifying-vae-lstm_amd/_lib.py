@@ -62,9 +62,10 @@ SIGNATURES = {
     "clv_lstm_seq_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_seq_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_pair_supported": (_i, [_i, _i]),
-    "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i,
-                               _p, _p]),
-    "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 15),
+    "clv_lstm_pair_pack_floats": (_sz, []),
+    "clv_lstm_pair_pack": (_i, [_i, _i, _p, _p, _p, _p, _p, _p]),
+    "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 13),
     "clv_sparse_proj_supported": (_i, [_i, _i]),
     "clv_sparse_proj_lds_bytes": (_sz, [_i, _i]),
     "clv_sparse_proj": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p]),

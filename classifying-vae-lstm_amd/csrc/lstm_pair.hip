@@ -31,16 +31,75 @@ constexpr int BW_LDS = 16 * BW_CP;
 
 __device__ float g_pair_dump[128];      // target of the stores of lanes that own no output (keeps every store unconditional)
 
+// ---------------------------------------------------------------------------
+// Weights in lane order.  A workgroup needs every recurrent weight exactly once, one value per lane: read straight from
+// the [88,352] kernels that is 88 dword loads per lane whose 64 lanes touch four 64-byte pieces of four different rows
+// (1056 such wave loads per workgroup, every workgroup at the same time: ~13 us of each launch at config 3).  The pack
+// kernel writes each lane's values as consecutive float4 (one wave load = 1 KB contiguous), once per step, for both
+// passes: regions of [6 waves][n][64 lanes] float4.
+//   PK_FE / PK_FD: forward encoder / decoder, n = 22 k values, components = gates (i,f,c,o); the encoder's latent lanes
+//                  carry columns of the head kernel Wz instead (see pair_fwd_encoder)
+//   PK_KZ:         forward decoder, n = 4: latent s + 4q of the decoder input kernel's z rows, components = gates
+//   PK_BD / PK_BE: backward decoder / encoder, n = 22 gate columns of the lane's slice, components = the 4 units of the
+//                  lane's group; the decoder's surplus groups carry rows of Kz (see pair_bwd_chain)
+// ---------------------------------------------------------------------------
+constexpr int PK_N = PNW * PKK * 64;               // float4 per 22-deep region
+constexpr int PK_FE = 0, PK_FD = PK_N, PK_KZ = 2 * PK_N, PK_BD = PK_KZ + PNW * PLQ * 64, PK_BE = PK_BD + PK_N;
+constexpr int PK_TOTAL = PK_BE + PK_N;             // float4
+
+struct PairPackArgs { int L; const float* U_e; const float* U_d; const float* Kz; const float* Wz; float4* out; };
+
+__global__ __launch_bounds__(256) void lstm_pair_pack_kernel(PairPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PK_TOTAL) return;
+  const int L = a.L;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < PK_KZ) {                                 // forward: lane = (unit, k-slice), n = kk
+    const bool dec = i >= PK_FD;
+    const int e = i - (dec ? PK_FD : PK_FE);
+    const int wave = e / (PKK * 64), kk = (e / 64) % PKK, lane = e & 63;
+    const int s = lane & 3, u_raw = wave * 16 + (lane >> 2), u = min(u_raw, LH - 1), zj = u_raw - LH;
+    const bool is_z = !dec && zj >= 0 && 2 * zj < L;
+    const float* U = dec ? a.U_d : a.U_e;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (is_z) {                                  // head column (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)
+        const int l = 2 * zj + (g & 1);
+        v[g] = l < L ? a.Wz[(size_t)(PKK * s + kk) * 2 * L + (g >> 1) * L + l] : 0.f;
+      } else {
+        v[g] = U[(size_t)(PKK * s + kk) * LG + g * LH + u];
+      }
+    }
+  } else if (i < PK_BD) {                          // z rows of the decoder input kernel: latent s + 4q
+    const int e = i - PK_KZ;
+    const int wave = e / (PLQ * 64), q = (e / 64) % PLQ, lane = e & 63;
+    const int s = lane & 3, u = min(wave * 16 + (lane >> 2), LH - 1), l = s + PK * q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[g] = l < L ? a.Kz[(size_t)l * LG + g * LH + u] : 0.f;
+  } else {                                         // backward: lane = (unit group, column slice), n = column in the slice
+    const bool dec = i < PK_BE;
+    const int e = i - (dec ? PK_BD : PK_BE);
+    const int wave = e / (BW_CW * 64), c = (e / 64) % BW_CW, lane = e & 63;
+    const int cs = lane & 15, ug = wave * 4 + (lane >> 4), zg0 = 4 * (ug - 22);
+    const bool zgroup = dec && ug >= 22 && zg0 < L;
+    const float* U = dec ? a.U_d : a.U_e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lj = zg0 + j;
+      if (zgroup) v[j] = lj < L ? a.Kz[(size_t)lj * LG + BW_CW * cs + c] : 0.f;
+      else v[j] = U[(size_t)min(4 * ug + j, LH - 1) * LG + BW_CW * cs + c];
+    }
+  }
+  a.out[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 struct PairFwdArgs {
   int B, T, L, ldz;
   const float* xproj_e;   // [B,T,352] x_t.K_x      (same buffer as gates_e)
   const float* rb_e;      // [B,352]   W.K_w + bias
-  const float* U_e;       // [88,352]
   const float* xproj_d;   // [B,T,352] x_{t-1}.K_x  (same buffer as gates_d) or unused
   const float* rb_d;
-  const float* U_d;
-  const float* Kz;        // [L,352]   z rows of the decoder input kernel
-  const float* Wz;        // [88,2L]   [Z_mean | Z_log_var] kernel
+  const float* pack;      // weights in lane order (clv_lstm_pair_pack)
   const float* bz;        // [2L]
   const float* eps;       // [B,T,L]
   float *hs_e, *cs_e, *gates_e, *hs_d, *cs_d, *gates_d;
@@ -97,17 +156,14 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   auto zcol = [&](int g) { const int l = 2 * zj + (g & 1); return l < L ? (g >> 1) * L + l : -1; };
 
   f2 Ur[PKK][2];
+  {
+    const float4* pw = reinterpret_cast<const float4*>(a.pack) + PK_FE + wave * PKK * 64 + lane;
 #pragma unroll
-  for (int kk = 0; kk < PKK; ++kk)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      // one unconditional load per element (a divergent branch here would serialise 88 L2 round trips)
-      const int cix = zcol(g);
-      const float* src = is_z ? a.Wz + (size_t)(PKK * s + kk) * 2 * L + max(cix, 0)
-                              : a.U_e + (size_t)(PKK * s + kk) * LG + g * LH + u;
-      const float v = *src;
-      Ur[kk][g >> 1][g & 1] = (is_z && cix < 0) ? 0.f : v;
+    for (int kk = 0; kk < PKK; ++kk) {
+      const float4 v = pw[kk * 64];
+      Ur[kk][0][0] = v.x; Ur[kk][0][1] = v.y; Ur[kk][1][0] = v.z; Ur[kk][1][1] = v.w;
     }
+  }
   const size_t bt0 = (size_t)b * T;
   const float* xp = a.xproj_e + bt0 * LG + s * LH + u;
   float rb, xmask;
@@ -201,22 +257,24 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
 template <int GATE, bool HASXP>
 __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP],
                                                  float (*zbuf)[PLMAX]) {
-  const int s = lane & 3, b = blockIdx.x, T = a.T, L = a.L;
+  const int s = lane & 3, b = blockIdx.x, T = a.T;
   const int u = min(wave * 16 + (lane >> 2), LH - 1);
   f2 Ur[PKK][2];
-#pragma unroll
-  for (int kk = 0; kk < PKK; ++kk)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) Ur[kk][g >> 1][g & 1] = a.U_d[(size_t)(PKK * s + kk) * LG + g * LH + u];
   f2 Kzr[PLQ][2];        // lane s takes the latents s, s+4, ...
+  {
+    const float4* pw = reinterpret_cast<const float4*>(a.pack) + PK_FD + wave * PKK * 64 + lane;
 #pragma unroll
-  for (int q = 0; q < PLQ; ++q)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int l = s + PK * q;
-      const float v = a.Kz[(size_t)min(l, L - 1) * LG + g * LH + u];
-      Kzr[q][g >> 1][g & 1] = l < L ? v : 0.f;
+    for (int kk = 0; kk < PKK; ++kk) {
+      const float4 v = pw[kk * 64];
+      Ur[kk][0][0] = v.x; Ur[kk][0][1] = v.y; Ur[kk][1][0] = v.z; Ur[kk][1][1] = v.w;
     }
+    const float4* pz = reinterpret_cast<const float4*>(a.pack) + PK_KZ + wave * PLQ * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < PLQ; ++q) {
+      const float4 v = pz[q * 64];
+      Kzr[q][0][0] = v.x; Kzr[q][0][1] = v.y; Kzr[q][1][0] = v.z; Kzr[q][1][1] = v.w;
+    }
+  }
   const size_t bt0 = (size_t)b * T;
   const float* xp = a.xproj_d + bt0 * LG + s * LH + u;
   const float rb = a.rb_d[(size_t)b * LG + s * LH + u];
@@ -298,9 +356,7 @@ constexpr int QZ = 2 * QL;              // head columns
 struct PairBwdArgs {
   int B, T, L;
   float kl_scale;                 // kl_weight / (B*T)
-  const float* U_d;
-  const float* U_e;
-  const float* Kz;                // [L,352]
+  const float* pack;              // weights in lane order (clv_lstm_pair_pack)
   const float* Wz;                // [88,2L]
   const float* dhs_d;             // [B,T,88] dL/dh of the decoder (output head)
   const float* cs_d;
@@ -325,23 +381,17 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   const bool zgroup = DEC && ug >= 22 && zg0 < L;
   const int lat = zg0 + (cs & 3);                    // latent this lane finishes after the reduce-scatter
   const bool zlane = zgroup && lat < L;
-  const float* U = DEC ? a.U_d : a.U_e;
   float* gates = DEC ? a.gates_d : a.gates_e;
   const float* csp = DEC ? a.cs_d : a.cs_e;
   float* dzsum = DEC ? a.dzsum_d : a.dzsum_e;
 
   f2 Ur[BW_CW][2];    // [column][unit pair]; a latent group holds rows of Kz instead
+  {
+    const float4* pw = reinterpret_cast<const float4*>(a.pack) + (DEC ? PK_BD : PK_BE) + wave * BW_CW * 64 + lane;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int lj = zg0 + j;
-    const float* row = zgroup ? a.Kz + (size_t)min(lj, L - 1) * LG : U + (size_t)min(4 * ug + j, LH - 1) * LG;
-    const float2* up = reinterpret_cast<const float2*>(row + BW_CW * cs);
-    const bool dead = zgroup && lj >= L;
-#pragma unroll
-    for (int c = 0; c < BW_CW / 2; ++c) {
-      const float2 v = up[c];
-      Ur[2 * c][j >> 1][j & 1] = dead ? 0.f : v.x;
-      Ur[2 * c + 1][j >> 1][j & 1] = dead ? 0.f : v.y;
+    for (int c = 0; c < BW_CW; ++c) {
+      const float4 v = pw[c * 64];
+      Ur[c][0][0] = v.x; Ur[c][0][1] = v.y; Ur[c][1][0] = v.z; Ur[c][1][1] = v.w;
     }
   }
   // encoder: this unit's row of the head kernel (dh_enc = dzargs . Wz^T), zero beyond 2L
@@ -531,19 +581,33 @@ __global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
 
 extern "C" int clv_lstm_pair_supported(int H, int L) { return H == clv::LH && L >= 1 && L <= clv::QL; }
 
+extern "C" size_t clv_lstm_pair_pack_floats(void) { return (size_t)clv::PK_TOTAL * 4; }
+
+extern "C" int clv_lstm_pair_pack(int H, int L, const float* U_enc, const float* U_dec, const float* Kz, const float* Wz,
+                                  float* pack, void* stream) {
+  using namespace clv;
+  if (!clv_lstm_pair_supported(H, L) || !U_enc || !U_dec || !Kz || !Wz || !pack || ((uintptr_t)pack) % 16 != 0)
+    return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  PairPackArgs a{L, U_enc, U_dec, Kz, Wz, reinterpret_cast<float4*>(pack)};
+  ProfScope p("lstm_pair_pack", s);
+  hipLaunchKernelGGL(lstm_pair_pack_kernel, dim3((PK_TOTAL + 255) / 256), dim3(256), 0, s, a);
+  return launch_status();
+}
+
 extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
-                                 float* gates_enc, const float* rowbias_enc, const float* U_enc,
-                                 float* gates_dec, int dec_has_xproj, const float* rowbias_dec, const float* U_dec,
-                                 const float* Kz, const float* Wz, const float* bz, const float* eps,
+                                 float* gates_enc, const float* rowbias_enc,
+                                 float* gates_dec, int dec_has_xproj, const float* rowbias_dec,
+                                 const float* pack, const float* bz, const float* eps,
                                  float* hs_enc, float* cs_enc, float* hs_dec, float* cs_dec,
                                  float* zargs, float* Z, int ldz, float* klterm, void* stream) {
   using namespace clv;
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0 || ldz < L) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
-  if (!gates_enc || !rowbias_enc || !U_enc || !gates_dec || !rowbias_dec || !U_dec || !Kz || !Wz || !bz || !eps ||
+  if (!gates_enc || !rowbias_enc || !gates_dec || !rowbias_dec || !pack || !bz || !eps ||
       !hs_enc || !cs_enc || !hs_dec || !cs_dec || !zargs || !Z || !klterm)
     return CLV_EINVAL;
-  PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, U_enc, gates_dec, rowbias_dec, U_dec, Kz, Wz, bz, eps,
+  PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, gates_dec, rowbias_dec, pack, bz, eps,
                 hs_enc, cs_enc, gates_enc, hs_dec, cs_dec, gates_dec, zargs, Z, klterm};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_fwd", s);
@@ -556,7 +620,7 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
 }
 
 extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
-                                 const float* U_dec, const float* U_enc, const float* Kz, const float* Wz,
+                                 const float* pack, const float* Wz,
                                  const float* dhs_dec, const float* cs_dec, const float* cs_enc,
                                  float* gates_dec_inout_dz, float* gates_enc_inout_dz,
                                  float* dzsum_dec, float* dzsum_enc,
@@ -564,10 +628,10 @@ extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float
   using namespace clv;
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
-  if (!U_dec || !U_enc || !Kz || !Wz || !dhs_dec || !cs_dec || !cs_enc || !gates_dec_inout_dz || !gates_enc_inout_dz ||
+  if (!pack || !Wz || !dhs_dec || !cs_dec || !cs_enc || !gates_dec_inout_dz || !gates_enc_inout_dz ||
       !dzsum_dec || !dzsum_enc || !zargs || !eps || !dzargs)
     return CLV_EINVAL;
-  PairBwdArgs a{B, T, L, kl_scale, U_dec, U_enc, Kz, Wz, dhs_dec, cs_dec, cs_enc, gates_dec_inout_dz,
+  PairBwdArgs a{B, T, L, kl_scale, pack, Wz, dhs_dec, cs_dec, cs_enc, gates_dec_inout_dz,
                 gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_bwd", s);

@@ -386,6 +386,7 @@ class VrnnEngine(_EngineBase):
         self.fuse_xproj = bool(cfg.get('fuse_xproj', False))   # break-even vs the projection GEMM at config 3
         # encoder + latent head + decoder as one launch (csrc/lstm_pair.hip); latent_dim <= 16
         self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj
+        self.pair_pack = _f(d, ops.lstm_pair_pack_floats()) if self.fuse_pair else None
         # input projections by sparse row gathering (exact for any input; pays off for piano-roll frames)
         self.sparse_inputs = bool(cfg.get('sparse_inputs', True)) and ops.sparse_proj_supported(D, 4 * H)
         # output head: forward + loss + all three backward products in one launch
@@ -510,6 +511,9 @@ class VrnnEngine(_EngineBase):
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         BT, G4, off = B * T, 4 * H, self.off
         g, ws = ops.gemm, self.ws
+        # this step's recurrent kernels, K_z and the head kernel in the lane order of the pair kernels (both passes)
+        ops.lstm_pair_pack(L, P.p('encoder_h/recurrent_kernel'), P.p('decoder_h/recurrent_kernel'),
+                           P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), self.pair_pack)
         if self.sparse_inputs:     # piano-roll frames are ~4 % nonzero: add the kernel rows of the notes that are on
             ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
             if off:
@@ -519,11 +523,9 @@ class VrnnEngine(_EngineBase):
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel
                 g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
         self._label_forward(X, eps_W, w_true)
-        ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'),
-                          self.gates_dec, off > 0, self.wk_dec, P.p('decoder_h/recurrent_kernel'),
-                          P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z,
-                          self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z, self.xz_ld,
-                          self.klterm, gate_act=self.gate_act)
+        ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, self.gates_dec, off > 0, self.wk_dec, self.pair_pack,
+                          P.p('Zargs/bias'), eps_Z, self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z,
+                          self.xz_ld, self.klterm, gate_act=self.gate_act)
         self._output_head(X, nll)
 
     def xp_view(self):
@@ -726,10 +728,9 @@ class VrnnEngine(_EngineBase):
             g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
         if self.fuse_pair:
             # decoder BPTT, dZ, the latent head's backward, dh_enc and encoder BPTT: one persistent launch
-            ops.lstm_pair_bwd(B, T, L, self.kl_weight * inv_bt, P.p('decoder_h/recurrent_kernel'),
-                              P.p('encoder_h/recurrent_kernel'), P.rows(P.params, 'decoder_h/kernel', off),
-                              P.p('Zargs/kernel'), self.dhs, self.cs_dec, self.cs_enc, self.gates_dec, self.gates_enc,
-                              self.dzsum_dec, self.dzsum_enc, self.zargs, eps_Z, self.dzargs, gate_act=self.gate_act)
+            ops.lstm_pair_bwd(B, T, L, self.kl_weight * inv_bt, self.pair_pack, P.p('Zargs/kernel'), self.dhs,
+                              self.cs_dec, self.cs_enc, self.gates_dec, self.gates_enc, self.dzsum_dec, self.dzsum_enc,
+                              self.zargs, eps_Z, self.dzargs, gate_act=self.gate_act)
         else:
             self._bptt_separate(eps_Z, ws)
         # label head: dW from both LSTMs, label backward, dWargs and dhW in one launch

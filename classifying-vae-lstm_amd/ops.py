@@ -231,17 +231,27 @@ def lstm_pair_supported(L, H=88):
     return bool(_lib.lib().clv_lstm_pair_supported(H, L))
 
 
-def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, U_enc, gates_dec, dec_has_xproj, rb_dec, U_dec, Kz, Wz, bz, eps,
+def lstm_pair_pack_floats():
+    return int(_lib.lib().clv_lstm_pair_pack_floats())
+
+
+def lstm_pair_pack(L, U_enc, U_dec, Kz, Wz, pack, H=88):
+    """Recurrent kernels, Kz and Wz in the lane order of the pair kernels (once per weight update)."""
+    check(_lib.lib().clv_lstm_pair_pack(H, L, _ptr(U_enc), _ptr(U_dec), _ptr(Kz), _ptr(Wz), _ptr(pack), _stream()),
+          "clv_lstm_pair_pack")
+
+
+def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, gates_dec, dec_has_xproj, rb_dec, pack, bz, eps,
                   hs_enc, cs_enc, hs_dec, cs_dec, zargs, Z, ldz, klterm, gate_act=0, H=88):
-    check(_lib.lib().clv_lstm_pair_fwd(B, T, H, L, gate_act, _ptr(gates_enc), _ptr(rb_enc), _ptr(U_enc), _ptr(gates_dec),
-                                       int(bool(dec_has_xproj)), _ptr(rb_dec), _ptr(U_dec), _ptr(Kz), _ptr(Wz), _ptr(bz),
+    check(_lib.lib().clv_lstm_pair_fwd(B, T, H, L, gate_act, _ptr(gates_enc), _ptr(rb_enc), _ptr(gates_dec),
+                                       int(bool(dec_has_xproj)), _ptr(rb_dec), _ptr(pack), _ptr(bz),
                                        _ptr(eps), _ptr(hs_enc), _ptr(cs_enc), _ptr(hs_dec), _ptr(cs_dec), _ptr(zargs),
                                        _ptr(Z), ldz, _ptr(klterm), _stream()), "clv_lstm_pair_fwd")
 
 
-def lstm_pair_bwd(B, T, L, kl_scale, U_dec, U_enc, Kz, Wz, dhs_dec, cs_dec, cs_enc, gates_dec, gates_enc, dzsum_dec,
+def lstm_pair_bwd(B, T, L, kl_scale, pack, Wz, dhs_dec, cs_dec, cs_enc, gates_dec, gates_enc, dzsum_dec,
                   dzsum_enc, zargs, eps, dzargs, gate_act=0, H=88):
-    check(_lib.lib().clv_lstm_pair_bwd(B, T, H, L, gate_act, float(kl_scale), _ptr(U_dec), _ptr(U_enc), _ptr(Kz), _ptr(Wz),
+    check(_lib.lib().clv_lstm_pair_bwd(B, T, H, L, gate_act, float(kl_scale), _ptr(pack), _ptr(Wz),
                                        _ptr(dhs_dec), _ptr(cs_dec), _ptr(cs_enc), _ptr(gates_dec), _ptr(gates_enc),
                                        _ptr(dzsum_dec), _ptr(dzsum_enc), _ptr(zargs), _ptr(eps), _ptr(dzargs), _stream()),
           "clv_lstm_pair_bwd")

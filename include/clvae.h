@@ -167,14 +167,21 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  * launch; gates_* are overwritten in place with dz and dzsum_* [B,4H] = sum_t dz like clv_lstm_seq_bwd.
  * dhs_dec [B,T,H] is the decoder's upstream gradient (from the output head). */
 int clv_lstm_pair_supported(int H, int L);
+/* Both passes read the recurrent kernels U_enc / U_dec [H,4H], Kz and (forward) Wz from `pack`: every workgroup needs
+ * each weight exactly once, one value per lane, and clv_lstm_pair_pack lays them out in that order (one wave load = 1 KB
+ * contiguous instead of four 64-byte pieces of four rows).  Run it after every weight update, before the forward pass;
+ * pack holds clv_lstm_pair_pack_floats() floats, 16-byte aligned. */
+size_t clv_lstm_pair_pack_floats(void);
+int clv_lstm_pair_pack(int H, int L, const float* U_enc, const float* U_dec, const float* Kz, const float* Wz,
+                       float* pack, void* stream);
 int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
-                      float* gates_enc, const float* rowbias_enc, const float* U_enc,
-                      float* gates_dec, int dec_has_xproj, const float* rowbias_dec, const float* U_dec,
-                      const float* Kz, const float* Wz, const float* bz, const float* eps,
+                      float* gates_enc, const float* rowbias_enc,
+                      float* gates_dec, int dec_has_xproj, const float* rowbias_dec,
+                      const float* pack, const float* bz, const float* eps,
                       float* hs_enc, float* cs_enc, float* hs_dec, float* cs_dec,
                       float* zargs, float* Z, int ldz, float* klterm, void* stream);
 int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
-                      const float* U_dec, const float* U_enc, const float* Kz, const float* Wz,
+                      const float* pack, const float* Wz,
                       const float* dhs_dec, const float* cs_dec, const float* cs_enc,
                       float* gates_dec_inout_dz, float* gates_enc_inout_dz,
                       float* dzsum_dec, float* dzsum_enc,
