@@ -167,11 +167,10 @@ __global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol
   s[c.col_global] = snew;
 }
 
-__global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, float* params, const float* grads,
-                                                        float* m, float* v, const float* colscal,
-                                                        const int32_t* colidx0, float* partC, AdamHyper h) {
-  const AdamUnit un = units[blockIdx.x];
-  if (un.small && h.weightnorm) return;   // done by wn_small_kernel
+__device__ __forceinline__ void wn_update_body(const AdamUnit& un, int unit_idx, float* params, const float* grads,
+                                               float* m, float* v, const float* colscal,
+                                               const int32_t* colidx0, float* partC, const AdamHyper& h) {
+  if (un.small && h.weightnorm) return;   // done by the small-tensor blocks
   const float lr_t = adam_lr_t(h);
   if (!un.is_matrix || !h.weightnorm) {   // plain Adam (biases; everything when weightnorm is off)
     const int n = un.nrows * un.cols;
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(256) void wn_update_kernel(const AdamUnit* units, f
   }
   __shared__ float rc[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int cbase = colidx0[blockIdx.x];     // index of this tensor's column 0 in colscal
+  const int cbase = colidx0[unit_idx];     // index of this tensor's column 0 in colscal
   for (int c0 = 0; c0 < un.cols; c0 += 64) {
     const int col = c0 + cx;
     float acc = 0.f;
@@ -251,9 +250,8 @@ struct SmallItem {
   int64_t col_offset;   // tensor's offset into s/mg/vg
   int32_t rows, cols, col0, is_matrix;
 };
-__global__ __launch_bounds__(256) void wn_small_kernel(const SmallItem* items, float* params, const float* grads, float* m,
-                                                       float* v, float* mg, float* vg, float* s, AdamHyper h) {
-  const SmallItem it = items[blockIdx.x];
+__device__ __forceinline__ void wn_small_body(const SmallItem& it, float* params, const float* grads, float* m,
+                                              float* v, float* mg, float* vg, float* s, const AdamHyper& h) {
   const float lr_t = adam_lr_t(h);
   if (!it.is_matrix) {                                  // bias: plain Adam over its elements
     const int n = it.rows * it.cols;
@@ -335,6 +333,20 @@ __global__ __launch_bounds__(256) void wn_small_kernel(const SmallItem* items, f
       }
     if (ry == 0) { mg[cg] = mgn; vg[cg] = vgn; s[cg] = snew; }
   }
+}
+
+// K3 and the small tensors in one launch: blocks [0, n_units) update a unit of a tall matrix (or plain Adam), blocks
+// [n_units, n_units + n_small) do the whole Adam-WN of one small tensor.  The small-tensor blocks are a latency chain
+// of their own (~7 us); next to the update blocks they cost nothing.
+__global__ __launch_bounds__(256) void wn_update_kernel(int n_units, const AdamUnit* units, const SmallItem* items,
+                                                        float* params, const float* grads, float* m, float* v,
+                                                        float* mg, float* vg, float* s, const float* colscal,
+                                                        const int32_t* colidx0, float* partC, AdamHyper h) {
+  if ((int)blockIdx.x >= n_units) {
+    wn_small_body(items[blockIdx.x - n_units], params, grads, m, v, mg, vg, s, h);
+    return;
+  }
+  wn_update_body(units[blockIdx.x], (int)blockIdx.x, params, grads, m, v, colscal, colidx0, partC, h);
 }
 
 __global__ void adam_bump_kernel(int32_t* iterations) { *iterations += 1; }
@@ -443,17 +455,19 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   AdamHyper h{lr, beta1, beta2, eps, weightnorm, step_t, iterations_dev};
   ProfScope pr("adam_wn_step", st);
   const bool wn = weightnorm && c.n_cols > 0;
-  if (wn && c.n_small > 0)        // small matrices and biases: whole update in one launch (reads `iterations` before the bump)
-    hipLaunchKernelGGL(wn_small_kernel, dim3(c.n_small), dim3(256), 0, st, small, params, grads, m, v, mg, vg, s, h);
   const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything
+  const int n_small = wn ? c.n_small : 0;     // small matrices and biases: whole update in their own blocks of K3
   if (wn && chain) {
     hipLaunchKernelGGL(wn_stats_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, s, partA, partB);
     hipLaunchKernelGGL(wn_cols_kernel, dim3((c.n_cols + CPB - 1) / CPB), dim3(256), 0, st, c.n_cols, cols, partA, partB, s,
                        mg, vg, colscal, h);
   }
-  if (chain)
-    hipLaunchKernelGGL(wn_update_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, grads, m, v, colscal, colidx0,
-                       partC, h);
+  {
+    const int n_units = chain ? c.n_units : 0;
+    if (n_units + n_small > 0)
+      hipLaunchKernelGGL(wn_update_kernel, dim3(n_units + n_small), dim3(256), 0, st, n_units, units, small, params, grads, m,
+                         v, mg, vg, s, colscal, colidx0, partC, h);
+  }
   if (wn && chain) {
     hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + CPB - 1) / CPB), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
                        iterations_dev);
