@@ -69,6 +69,7 @@ SIGNATURES = {
     "clv_sparse_proj_supported": (_i, [_i, _i]),
     "clv_sparse_proj_lds_bytes": (_sz, [_i, _i]),
     "clv_sparse_proj": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p]),
+    "clv_sparse_proj2": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p]),
     "clv_sparse_dense_supported": (_i, [_i]),
     "clv_sparse_dense": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p]),

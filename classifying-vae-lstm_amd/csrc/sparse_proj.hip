@@ -15,20 +15,32 @@ constexpr int SP_NT = SP_NW * 64;
 constexpr int SP_XMAX = 128;       // max inputs per frame (2 per lane)
 constexpr int SP_NC = 6;           // output columns per lane (N <= 384)
 
-struct SparseProjArgs {
-  int R, nx, N, ldx, ldo;
+struct SparseProjSet {
+  int nx, ldx;
   const float* X;      // [R, ldx]
   const float* K;      // [nx, N]
   float* out;          // [R, ldo]
+};
+struct SparseProjArgs {
+  int R, N, ldo, wgs;  // wgs: workgroups per projection (a launch carries one or two projections over the same R frames)
+  SparseProjSet set[2];
 };
 
 // A wave handles a frame on its own: lane k holds inputs k and k+64, two ballots give the nonzero sets as
 // scalar masks, and a scalar bit-scan loop adds the listed kernel rows (LDS) into the lane's 6 output columns.
 // No lists, no LDS traffic besides the kernel rows, no barriers after the kernel is staged.
-__global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs a) {
+__global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs g) {
   extern __shared__ __attribute__((aligned(16))) float Kl[];            // [nx][N]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // second projection of the launch: its workgroups start as the first one's retire, so the two tails overlap
+  const bool second = (int)blockIdx.x >= g.wgs;
+  struct { int R, nx, N, ldx, ldo; const float* X; const float* K; float* out; } a;
+  a.R = g.R; a.N = g.N; a.ldo = g.ldo;
+  a.nx = second ? g.set[1].nx : g.set[0].nx; a.ldx = second ? g.set[1].ldx : g.set[0].ldx;
+  a.X = second ? g.set[1].X : g.set[0].X; a.K = second ? g.set[1].K : g.set[0].K;
+  a.out = second ? g.set[1].out : g.set[0].out;
+  const int bid = (int)blockIdx.x - (second ? g.wgs : 0);
   {
     const int nv = a.nx * a.N / 4;
     const float4* src = reinterpret_cast<const float4*>(a.K);
@@ -43,8 +55,8 @@ __global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs a) {
     }
   }
   __syncthreads();
-  const int per = (a.R + gridDim.x - 1) / gridDim.x;
-  const int first = blockIdx.x * per, last = min(a.R, first + per);
+  const int per = (a.R + g.wgs - 1) / g.wgs;
+  const int first = bid * per, last = min(a.R, first + per);
   int colo[SP_NC];
 #pragma unroll
   for (int c = 0; c < SP_NC; ++c) colo[c] = min(lane + 64 * c, a.N - 1);
@@ -252,12 +264,16 @@ extern "C" int clv_sparse_proj_supported(int nx, int N) {
          clv_sparse_proj_lds_bytes(nx, N) <= 150 * 1024;
 }
 
-extern "C" int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, const float* K, float* out, int ldo,
-                               void* stream) {
+static int sparse_proj_launch(int R, int N, int ldo, int nset, const clv::SparseProjSet* sets, hipStream_t s) {
   using namespace clv;
-  if (R <= 0 || !X || !K || !out || ldx < nx || ldo < N || !clv_sparse_proj_supported(nx, N)) return CLV_EINVAL;
-  if (((uintptr_t)K) % 16 != 0) return CLV_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
+  int nxmax = 0;
+  for (int i = 0; i < nset; ++i) {
+    const SparseProjSet& p = sets[i];
+    if (!p.X || !p.K || !p.out || p.ldx < p.nx || !clv_sparse_proj_supported(p.nx, N) || ((uintptr_t)p.K) % 16 != 0)
+      return CLV_EINVAL;
+    nxmax = p.nx > nxmax ? p.nx : nxmax;
+  }
+  if (R <= 0 || ldo < N) return CLV_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_proj_kernel),
@@ -265,11 +281,26 @@ extern "C" int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, co
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  SparseProjArgs a{R, nx, N, ldx, ldo, X, K, out};
-  const int wgs = R < 256 * SP_NW ? (R + SP_NW - 1) / SP_NW : 256;     // one persistent workgroup per CU
+  SparseProjArgs a;
+  memset(&a, 0, sizeof(a));
+  a.R = R; a.N = N; a.ldo = ldo;
+  a.wgs = R < 256 * SP_NW ? (R + SP_NW - 1) / SP_NW : 256;     // one persistent workgroup per CU and projection
+  for (int i = 0; i < nset; ++i) a.set[i] = sets[i];
   ProfScope p("sparse_proj", s);
-  hipLaunchKernelGGL(sparse_proj_kernel, dim3(wgs), dim3(SP_NT), clv_sparse_proj_lds_bytes(nx, N), s, a);
+  hipLaunchKernelGGL(sparse_proj_kernel, dim3(nset * a.wgs), dim3(SP_NT), clv_sparse_proj_lds_bytes(nxmax, N), s, a);
   return launch_status();
+}
+
+extern "C" int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, const float* K, float* out, int ldo,
+                               void* stream) {
+  const clv::SparseProjSet set{nx, ldx, X, K, out};
+  return sparse_proj_launch(R, N, ldo, 1, &set, (hipStream_t)stream);
+}
+
+extern "C" int clv_sparse_proj2(int R, int N, int ldo, int nx0, const float* X0, int ldx0, const float* K0, float* out0,
+                                int nx1, const float* X1, int ldx1, const float* K1, float* out1, void* stream) {
+  const clv::SparseProjSet sets[2] = {{nx0, ldx0, X0, K0, out0}, {nx1, ldx1, X1, K1, out1}};
+  return sparse_proj_launch(R, N, ldo, 2, sets, (hipStream_t)stream);
 }
 
 extern "C" int clv_sparse_dense_supported(int N) { return N >= 2 && N <= 128 && N % 2 == 0; }

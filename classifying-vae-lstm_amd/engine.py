@@ -515,9 +515,11 @@ class VrnnEngine(_EngineBase):
         ops.lstm_pair_pack(L, P.p('encoder_h/recurrent_kernel'), P.p('decoder_h/recurrent_kernel'),
                            P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), self.pair_pack)
         if self.sparse_inputs:     # piano-roll frames are ~4 % nonzero: add the kernel rows of the notes that are on
-            ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
-            if off:
-                ops.sparse_proj(BT, off, G4, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec)
+            if off:        # both LSTMs in one launch
+                ops.sparse_proj2(BT, G4, (D, X, D, P.p('encoder_h/kernel'), self.gates_enc),
+                                 (off, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec))
+            else:
+                ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
         else:
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel

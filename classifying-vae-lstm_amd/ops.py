@@ -193,6 +193,12 @@ def sparse_proj_supported(nx, N):
     return bool(_lib.lib().clv_sparse_proj_supported(nx, N))
 
 
+def sparse_proj2(R, N, a, b, ldo=None):
+    """Two projections over the same R frames in one launch; a, b = (nx, X, ldx, K, out)."""
+    check(_lib.lib().clv_sparse_proj2(R, N, ldo if ldo is not None else N, a[0], _ptr(a[1]), a[2], _ptr(a[3]), _ptr(a[4]),
+                                      b[0], _ptr(b[1]), b[2], _ptr(b[3]), _ptr(b[4]), _stream()), "clv_sparse_proj2")
+
+
 def sparse_proj(R, nx, N, X, ldx, K, out, ldo=None):
     """out[r,:N] = sum_k X[r,k] K[k,:] visiting only the nonzero inputs of a frame (K resident in LDS)."""
     check(_lib.lib().clv_sparse_proj(R, nx, N, _ptr(X), ldx, _ptr(K), _ptr(out), ldo if ldo is not None else N,

@@ -315,6 +315,9 @@ int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
 int clv_sparse_proj_supported(int nx, int N);
 size_t clv_sparse_proj_lds_bytes(int nx, int N);
 int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, const float* K, float* out, int ldo, void* stream);
+/* two such projections over the same R frames (the two LSTMs of cl_vrnn) in one launch */
+int clv_sparse_proj2(int R, int N, int ldo, int nx0, const float* X0, int ldx0, const float* K0, float* out0,
+                     int nx1, const float* X1, int ldx1, const float* K1, float* out1, void* stream);
 
 /* The same idea for a Dense layer over a whole flattened window (cl_vrnn's hW layer, model.py:174-176;
  * nx = seq_length*88 inputs, ~4 % nonzero): out[r,:N] = act(sum_j X[r,j] K[j,:] + bias), act in {none, relu};

@@ -474,3 +474,23 @@ def test_out_head_train_matches_numpy(dev, R, defer, store):
     np.testing.assert_allclose(N(dhs), dlr @ Wo.astype(np.float64).T, rtol=1e-4, atol=3e-5 * scale * 100)
     np.testing.assert_allclose(N(dWo), hs.astype(np.float64).T @ dlr, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(N(dbo), dlr.sum(0), rtol=1e-4, atol=2e-5)
+
+
+def test_sparse_proj2_matches_two_single_launches(dev):
+    """Both LSTM input projections in one launch == two clv_sparse_proj launches (bit-exact), different nx / ldx."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(11)
+    R, N = 5000, 352
+    Xa = (rng.random((R, 88)) < 0.05).astype(np.float32)
+    Xb = np.zeros((R, 92), dtype=np.float32)
+    Xb[:, :70] = (rng.random((R, 70)) < 0.08)
+    Xb[3, 5] = 0.37
+    Ka, Kb = rng.standard_normal((88, N)).astype(np.float32), rng.standard_normal((70, N)).astype(np.float32)
+    dXa, dXb, dKa, dKb = T(Xa, dev), T(Xb, dev), T(Ka, dev), T(Kb, dev)
+    o = [torch.full((R, N), -1.0, dtype=torch.float32, device=dev) for _ in range(4)]
+    ops.sparse_proj2(R, N, (88, dXa, 88, dKa, o[0]), (70, dXb, 92, dKb, o[1]))
+    ops.sparse_proj(R, 88, N, dXa, 88, dKa, o[2])
+    ops.sparse_proj(R, 70, N, dXb, 92, dKb, o[3])
+    torch.cuda.synchronize()
+    assert torch.equal(o[0], o[2]) and torch.equal(o[1], o[3])
+    np.testing.assert_allclose(o[1].cpu().numpy(), Xb[:, :70].astype(np.float64) @ Kb, rtol=1e-5, atol=1e-5)
