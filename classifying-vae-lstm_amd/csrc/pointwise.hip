@@ -293,43 +293,41 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
 
 // up to 3 gathers that share the row index list (current frames, history frames, labels of a mini-batch) in one
 // launch; idx == nullptr: rows row0 .. row0+rows-1 (staging a contiguous batch)
-struct GatherSeg { const float* src; float* out; int64_t row_elems, chunk, out_ld, nwork0; int vec; int u8; };
+struct GatherSeg { const float* src; float* out; int64_t row_elems, out_ld; int chunk, pieces, vec, u8; };
 struct GatherArgs { GatherSeg seg[3]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; };
-__global__ void gather_multi_kernel(GatherArgs a) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int si = 0;
-#pragma unroll
-  for (int k = 1; k < 3; ++k)
-    if (k < a.nseg && i >= a.seg[k].nwork0) si = k;
+// grid = (work items of a row / 256, rows, segments): no 64-bit divisions per element (they cost more than the copy)
+__global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
+  const int si = blockIdx.z;
   const float* src = a.seg[0].src; float* out = a.seg[0].out;
-  int64_t row_elems = a.seg[0].row_elems, chunk = a.seg[0].chunk, out_ld = a.seg[0].out_ld, w0 = 0;
-  int vec = a.seg[0].vec, u8 = a.seg[0].u8;
+  int64_t row_elems = a.seg[0].row_elems, out_ld = a.seg[0].out_ld;
+  int chunk = a.seg[0].chunk, pieces = a.seg[0].pieces, vec = a.seg[0].vec, u8 = a.seg[0].u8;
 #pragma unroll
   for (int k = 1; k < 3; ++k)
-    if (si == k) { src = a.seg[k].src; out = a.seg[k].out; row_elems = a.seg[k].row_elems; chunk = a.seg[k].chunk;
-                   out_ld = a.seg[k].out_ld; w0 = a.seg[k].nwork0; vec = a.seg[k].vec; u8 = a.seg[k].u8; }
-  i -= w0;
+    if (si == k) { src = a.seg[k].src; out = a.seg[k].out; row_elems = a.seg[k].row_elems; out_ld = a.seg[k].out_ld;
+                   chunk = a.seg[k].chunk; pieces = a.seg[k].pieces; vec = a.seg[k].vec; u8 = a.seg[k].u8; }
   const int W = vec ? 4 : 1;                       // work item = 4 elements (aligned segments) or one
-  const int64_t nw = row_elems / W;
-  if (i >= a.rows * nw) return;
-  const int64_t r = i / nw, c = (i % nw) * W;
-  const int64_t piece = c / chunk, within = c % chunk;
-  const int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
-  float* dp = out + (r * (row_elems / chunk) + piece) * out_ld + within;
-  if (u8) {                                        // uint8 store (binary piano-roll frames): 4 bytes in, one float4 out
-    const unsigned char* sp = reinterpret_cast<const unsigned char*>(src) + sr * row_elems + c;
-    if (vec) {
-      const unsigned int v = *reinterpret_cast<const unsigned int*>(sp);
-      *reinterpret_cast<float4*>(dp) = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
-                                                   (float)(v >> 24));
+  const unsigned c = (blockIdx.x * 256u + threadIdx.x) * (unsigned)W;
+  if ((int64_t)c >= row_elems) return;
+  unsigned piece = 0, within = c;
+  if (pieces > 1) { piece = c / (unsigned)chunk; within = c - piece * (unsigned)chunk; }
+  for (int64_t r = blockIdx.y; r < a.rows; r += gridDim.y) {
+    const int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
+    float* dp = out + (r * pieces + piece) * out_ld + within;
+    if (u8) {                                      // uint8 store (binary piano-roll frames): 4 bytes in, one float4 out
+      const unsigned char* sp = reinterpret_cast<const unsigned char*>(src) + sr * row_elems + c;
+      if (vec) {
+        const unsigned int v = *reinterpret_cast<const unsigned int*>(sp);
+        *reinterpret_cast<float4*>(dp) = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                     (float)(v >> 24));
+      } else {
+        *dp = (float)*sp;
+      }
     } else {
-      *dp = (float)*sp;
+      const float* sp = src + sr * row_elems + c;
+      if (vec) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
+      else *dp = *sp;
     }
-    return;
   }
-  const float* sp = src + sr * row_elems + c;
-  if (vec) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
-  else *dp = *sp;
 }
 
 __global__ void bernoulli_sample_kernel(int64_t n, const float* p, const float* u, float* x) {
@@ -469,21 +467,23 @@ extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t r
   GatherArgs a;
   memset(&a, 0, sizeof(a));
   a.nseg = nseg; a.rows = rows; a.idx = idx; a.row0 = row0;
-  int64_t work = 0;
+  int64_t maxw = 0;
   for (int k = 0; k < nseg; ++k) {
-    if (!src[k] || !out[k] || row_elems[k] <= 0) return CLV_EINVAL;
+    if (!src[k] || !out[k] || row_elems[k] <= 0 || row_elems[k] >= (1ll << 31)) return CLV_EINVAL;
     const int64_t ch = chunk[k] > 0 ? chunk[k] : row_elems[k];
     if (row_elems[k] % ch != 0) return CLV_EINVAL;
     const int64_t ld = chunk[k] > 0 ? out_ld[k] : row_elems[k];
     const int u8 = src_u8 && src_u8[k];
     const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % (u8 ? 4 : 16) == 0 &&
                     ((uintptr_t)out[k]) % 16 == 0;
-    a.seg[k] = GatherSeg{(const float*)src[k], out[k], row_elems[k], ch, ld, work, vec, u8};
-    work += ((rows * (row_elems[k] / (vec ? 4 : 1)) + 255) / 256) * 256;        // segments start on block boundaries
+    a.seg[k] = GatherSeg{(const float*)src[k], out[k], row_elems[k], ld, (int)ch, (int)(row_elems[k] / ch), vec, u8};
+    const int64_t w = row_elems[k] / (vec ? 4 : 1);
+    maxw = w > maxw ? w : maxw;
   }
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("gather_rows", s);
-  hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)(work / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)((maxw + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535), nseg),
+                     dim3(256), 0, s, a);
   return launch_status();
 }
 
