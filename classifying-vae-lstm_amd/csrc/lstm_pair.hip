@@ -188,8 +188,10 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   const float klscale = -0.5f * (float)L;
 
   float c = 0.f;
-  float xn = xp[0];
-  float en = 0.f;
+  // The per-step loads are requested two steps ahead: one step (0.75 us) is less than a load takes from HBM under
+  // load, and with one step of lookahead the launch time moved 117..130 us from run to run with the latency.
+  float xn = xp[0], xn2 = xp[(size_t)min(1, T - 1) * LG];      // projections of steps i and i+1
+  float en = 0.f, en2 = ep[0];                                 // eps of steps i-1 and i
   // two stores after the prologue's loads, like every iteration issues after its loads: the loop-entry and
   // back-edge memory queues then match and the wait for `xn` stays a counted vmcnt (see lstm.hip)
   g_pair_dump[lane] = 0.f;
@@ -204,9 +206,11 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   for (int i = 0; i < T; ++i) {
     const int cur = i & 1;
     const float xv = fmaf(xn, xmask, rb);
-    xn = xp[(size_t)min(i + 1, T - 1) * LG];            // prefetch, unconditional (clamped)
+    xn = xn2;
+    xn2 = xp[(size_t)min(i + 2, T - 1) * LG];           // prefetch two steps ahead, unconditional (clamped)
     const float ecur = en;                              // eps of step i-1
-    en = ep[(size_t)i * L];
+    en = en2;
+    en2 = ep[(size_t)min(i + 1, T - 1) * L];
     f2 acc2[2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? xv : 0.f;
@@ -283,7 +287,7 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   regular_slots(s, u, bt0, a.hs_d, a.cs_d, a.gates_d, optr, ostr, oslot);
   const int hslot = PKP * (u / PKK) + (u % PKK);
   float c = 0.f;
-  float xn = HASXP ? xp[0] : 0.f;
+  float xn = HASXP ? xp[0] : 0.f, xn2 = HASXP ? xp[(size_t)min(1, T - 1) * LG] : 0.f;
   g_pair_dump[lane] = 0.f;     // see the encoder
   g_pair_dump[lane + 64] = 0.f;
   step_barrier();          // the encoder is two steps ahead
@@ -291,7 +295,8 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     const float xv = xn + rb;
-    if (HASXP) xn = xp[(size_t)min(t + 1, T - 1) * LG];
+    xn = xn2;
+    if (HASXP) xn2 = xp[(size_t)min(t + 2, T - 1) * LG];
     f2 acc2[2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? xv : 0.f;
@@ -300,9 +305,14 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
       const float zl[PLQ] = {zq.x, zq.y, zq.z, zq.w};
 #pragma unroll
       for (int q = 0; q < PLQ; ++q) {
-        const f2 zz = {zl[q], zl[q]};
-        acc2[0] = __builtin_elementwise_fma(zz, Kzr[q][0], acc2[0]);
-        acc2[1] = __builtin_elementwise_fma(zz, Kzr[q][1], acc2[1]);
+        if (HASXP) {      // scalar, like the recurrent product below: no packed operand next to the prefetch registers
+          acc2[0][0] = fmaf(zl[q], Kzr[q][0][0], acc2[0][0]); acc2[0][1] = fmaf(zl[q], Kzr[q][0][1], acc2[0][1]);
+          acc2[1][0] = fmaf(zl[q], Kzr[q][1][0], acc2[1][0]); acc2[1][1] = fmaf(zl[q], Kzr[q][1][1], acc2[1][1]);
+        } else {
+          const f2 zz = {zl[q], zl[q]};
+          acc2[0] = __builtin_elementwise_fma(zz, Kzr[q][0], acc2[0]);
+          acc2[1] = __builtin_elementwise_fma(zz, Kzr[q][1], acc2[1]);
+        }
       }
     }
     // scalar FMAs while a prefetch is in flight: with v_pk_fma the allocator pairs the load's destination register
@@ -454,8 +464,11 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   };
   // With the +1 offset above the coefficients a latent lane holds during iteration (step t) are those of step
   // t+1, whose dZ its matvec has just produced from dz_dec_{t+1}.
-  Coef coef_next = make_coef(load_raw(T - 1));
-  Raw raw_next = load_raw(T - 2);
+  // Two steps of loads in flight: the values of step t are requested at iteration t+2 and turned into coefficients at
+  // the top of iteration t (off the recurrence: the coefficients are first used after the matvec).  One step of
+  // lookahead is less than a load takes from HBM under load.
+  Raw raw0 = load_raw(T - 1);         // step t
+  Raw raw1 = load_raw(T - 2);         // step t-1
   g_pair_dump[lane] = 0.f;           // one store after the prologue's loads (see lstm_bwd_kernel)
 
   // output slot: regular lanes: dz of gate q (4 replicas share the 4 gates); latent lanes: replica 0 the
@@ -505,9 +518,8 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   for (int i = 0; i < T; ++i) {
     const int t = T - 1 - i;
     const int cur = i & 1;
-    const Coef k = coef_next;
-    const Raw rcur = raw_next;
-    raw_next = load_raw(t - 2);
+    const Raw raw2 = load_raw(t - 2);
+    const Coef k = make_coef(raw0);
     float dhup;
     if (DEC) {
       dhup = k.dhh;
@@ -523,7 +535,6 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
       dhup = s0 + s1;
     }
     const float dhrec = matvec(cur);
-    coef_next = make_coef(rcur);
     const float dh = dhup + dhrec;
     dc = fmaf(dh, k.kc, dc);
     float dz[4];
@@ -543,13 +554,16 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     if (!zgroup) dzb[cur ^ 1][lpos] = val;
     *gptr = val;
     gptr += (zgroup && i == 0) ? 0 : gstr;            // the head lags one step
+    raw0 = raw1;
+    raw1 = raw2;
     step_barrier();
   }
   if (DEC) {
     // iteration T: dZ_0 -> dzargs_0
     if (wave == PNW - 1) {
       const float dZ = matvec(T & 1);
-      const float zv = fmaf(dZ, coef_next.ki, coef_next.kf);
+      const Coef klast = make_coef(raw0);          // raw0 = load_raw(-1): a latent lane's values of step 0
+      const float zv = fmaf(dZ, klast.ki, klast.kf);
       if (zlane && q < 2) {
         *gptr = zv;
         dza[T & 1][lpos] = zv;
