@@ -248,7 +248,7 @@ def main():
         if w['model'] == 'cl_vrnn':
             # dominant kernel: the persistent LSTM sequence kernels (fwd+bwd, 2 LSTMs each)
             # (one launch = one LSTM pass, or both LSTMs of a pass when the pair kernels run): 4 LSTM passes per step
-            names = sorted(k for k in by if k.startswith('lstm_'))
+            names = sorted(k for k in by if k.startswith('lstm_') and not k.endswith('_pack'))
             n = sum(by[k][1] for k in names)
             ms = sum(by[k][2] for k in names)
             avg_s = ms / n * 1e-3

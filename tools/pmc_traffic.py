@@ -26,7 +26,7 @@ for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) * 2 + sum(w.
     short = re.sub(r'^void ', '', k).replace('clv::', '')
     rows.append(dict(kernel=short[:120], launches=len(fk), fetch_size_kb_avg=sum(fk) / len(fk), write_size_kb_avg=sum(wk) / len(wk),
                      hbm_read_bytes_corrected=2 * 1024 * sum(fk) / len(fk), hbm_write_bytes=1024 * sum(wk) / len(wk)))
-dom = [r for r in rows if r['kernel'].startswith('lstm_')]
+dom = [r for r in rows if re.match(r'lstm_(pair_)?(fwd|bwd)_kernel', r['kernel'])]      # the kernels bench.py's roofline times
 per_launch = sum(r['hbm_read_bytes_corrected'] + r['hbm_write_bytes'] for r in dom) / max(len(dom), 1)
 json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --no-graph); FETCH_SIZE x2 "
                     "(gfx950 reports half of the bytes read), both KB -> bytes x1024 (MI355X_MICROARCH.md)",
