@@ -31,9 +31,12 @@ template <int GATE>
 __device__ __forceinline__ float gate_fn(float z) {
   return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid(z) : sigmoidf_(z);
 }
+// y = gate_fn(z).  hard_sigmoid: the clip changes the value exactly when it is out of range, so "gradient passes"
+// (inside the range, ties included, like TF's clip) == "clipped value equals the unclipped one": one compare against
+// the fma the forward expression already holds instead of two range compares.
 template <int GATE>
 __device__ __forceinline__ float gate_grad(float z, float y) {
-  return GATE == CLV_GATE_HARD_SIGMOID ? hard_sigmoid_grad(z) : y * (1.f - y);
+  return GATE == CLV_GATE_HARD_SIGMOID ? ((0.2f * z + 0.5f) == y ? 0.2f : 0.0f) : y * (1.f - y);
 }
 
 // ---- pieces shared by the kernels that keep a unit's 4 gate columns in 4 k-slice lanes (lstm_pair.hip, generate.hip)
