@@ -428,16 +428,18 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   const int stc = zlane ? 2 * L : LH, std_ = zlane ? L : (DEC ? LH : 0);
   const int ppo = zlane ? L : 0;                       // offset of the second stream (log_var column / same array)
   const float hk = 0.5f * a.kl_scale;
+  // Offsets stay 32-bit and their per-lane products go through v_mul_u32_u24 (time index < 2^24, strides <= 88): the
+  // 64-bit `(size_t)t * stride` forms compile to quarter-rate v_mul_lo_u32 / v_mad_u64_u32, ~30 issue slots of a step.
   auto load_raw = [&](int tr) {       // regular lanes: step max(tr, 0); latent lanes: step tr + 1 (clamped to the window)
     Raw r;
     const int t = max(tr, 0);
-    const float* gp = g_base + (size_t)t * LG;
+    const float* gp = g_base + (unsigned)t * (unsigned)LG;                   // uniform offset: scalar multiply
     r.zi = gp[0]; r.zf = gp[LH]; r.g = gp[2 * LH]; r.zo = gp[3 * LH];
     const int tz = zlane ? min(max(tr + 1, 0), T - 1) : t;
-    r.c = pc[(size_t)tz * stc];
-    const float cprev = pc[(size_t)(zlane ? tz : max(tz - 1, 0)) * stc + ppo];
+    r.c = pc[__umul24(tz, stc)];
+    const float cprev = pc[__umul24(zlane ? tz : max(tz - 1, 0), stc) + (unsigned)ppo];
     r.cp = (t > 0 || zlane) ? cprev : 0.f;
-    r.dh = DEC ? pd[(size_t)tz * std_] : 0.f;
+    r.dh = DEC ? pd[__umul24(tz, std_)] : 0.f;
     return r;
   };
   auto make_coef = [&](const Raw& r) {
