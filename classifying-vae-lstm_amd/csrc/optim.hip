@@ -453,6 +453,9 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   float* partC = partB + c.n_part;
   float* colscal = partC + c.n_part;
   AdamHyper h{lr, beta1, beta2, eps, weightnorm, step_t, iterations_dev};
+  // step_t == -1 with a device counter: read it, leave it alone (another call of the same step, on another subset of the
+  // tensors, advances it)
+  int32_t* bump = (iterations_dev && step_t == -1) ? nullptr : iterations_dev;
   ProfScope pr("adam_wn_step", st);
   const bool wn = weightnorm && c.n_cols > 0;
   const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything
@@ -470,10 +473,10 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   }
   if (wn && chain) {
     hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + CPB - 1) / CPB), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
-                       iterations_dev);
+                       bump);
     hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, colscal, colidx0);
-  } else if (iterations_dev) {
-    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, iterations_dev);
+  } else if (bump) {
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, bump);
   }
   return launch_status();
 }

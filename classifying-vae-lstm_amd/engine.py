@@ -103,6 +103,7 @@ class FlatParams:
                 col += (int(shp[-1]) + 3) // 4 * 4
             off += (n + 3) // 4 * 4
         self.n, self.n_cols, self.table = off, max(col, 4), table
+        self._subplans = {}
         f = dict(dtype=torch.float32, device=device)
         self.params = torch.zeros(self.n, **f)
         self.grads = torch.zeros(self.n, **f)
@@ -156,12 +157,28 @@ class FlatParams:
         self.s.fill_(1.0)
         self.iterations.zero_()
 
-    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True):
-        """utils/weightnorm.py:75-143; t comes from the device `iterations` counter."""
+    def _subplan(self, names):
+        """(table, n, device plan) of the update restricted to the tensors in `names` (same flat buffers)."""
+        key = tuple(names)
+        if key not in self._subplans:
+            idx = [i for i, (name, _) in enumerate(self.shapes) if name in names]
+            table = (_lib.ParamDesc * len(idx))(*[self.table[i] for i in idx])
+            L = _lib.lib()
+            blob = (C.c_uint8 * L.clv_adam_wn_plan_bytes(table, len(idx)))()
+            _lib.check(L.clv_adam_wn_plan_build(table, len(idx), blob), "adam plan")
+            plan = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(self.device)
+            self._subplans[key] = (table, len(idx), plan)
+        return self._subplans[key]
+
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True, only=None, advance=True):
+        """utils/weightnorm.py:75-143; t comes from the device `iterations` counter.
+        only: names of the tensors to update (default all); advance=False leaves `iterations` alone, so one optimizer step
+        can be issued in pieces (the multi-GPU schedule updates a bucket as soon as its all-reduce has landed)."""
+        table, n, plan = (self.table, len(self.shapes), self.plan) if only is None else self._subplan(only)
         _lib.check(_lib.lib().clv_adam_wn_step(
-            self.table, len(self.shapes), ops._ptr(self.plan), ops._ptr(self.params), ops._ptr(self.grads),
+            table, n, ops._ptr(plan), ops._ptr(self.params), ops._ptr(self.grads),
             ops._ptr(self.m), ops._ptr(self.v), ops._ptr(self.mg), ops._ptr(self.vg), ops._ptr(self.s),
-            ops._ptr(self.iterations), 0, lr, b1, b2, eps, int(weightnorm), ops._ptr(self.adam_ws),
+            ops._ptr(self.iterations), 0 if advance else -1, lr, b1, b2, eps, int(weightnorm), ops._ptr(self.adam_ws),
             self.adam_ws.numel(), ops._stream()), "clv_adam_wn_step")
 
 

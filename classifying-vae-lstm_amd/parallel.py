@@ -68,6 +68,7 @@ class GradAllReduce:
             self.main.append(flat_grads)
         self.cuda = flat_grads.is_cuda
         self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda else None
+        self.tail_done = None
 
     def _reduce(self, t):
         if self.world == 1:
@@ -96,6 +97,14 @@ class GradAllReduce:
     def reduce_tail(self):
         if self.tail is not None:
             self._on_side([self.tail])
+            if self.cuda and self.world > 1:
+                self.tail_done = torch.cuda.Event()
+                self.tail_done.record(self.side)
+
+    def wait_tail(self):
+        """The current stream waits for the tail bucket only (the main bucket may still be in flight on the side stream)."""
+        if self.cuda and self.world > 1 and self.tail is not None and self.tail_done is not None:
+            torch.cuda.current_stream().wait_event(self.tail_done)
 
     def wait(self):
         if self.cuda and self.world > 1:

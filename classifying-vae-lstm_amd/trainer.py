@@ -10,6 +10,8 @@ batch is staged into fixed buffers (`stage_batch`).
 """
 import os
 
+import numpy as np
+
 import torch
 
 from . import ops
@@ -48,6 +50,11 @@ class TrainStep:
         # gradient buckets) on a single GPU too, with the collectives as no-ops -- lets one box test that path
         force = os.environ.get('CLV_FORCE_DP_GRAPHS') == '1'
         self.ar = GradAllReduce(engine.P.grads, tail[0], tail[1], group) if (world > 1 or force) else None
+        # the tail bucket is exactly one tensor (the hW kernel): its update can run while the main bucket is reduced
+        self.tail_names = [n for n, _ in engine.P.shapes if tail[1] and engine.P.offsets[n] == tail[0]
+                           and int(np.prod(dict(engine.P.shapes)[n])) == tail[1]]
+        self.rest_names = [n for n, _ in engine.P.shapes if n not in self.tail_names]
+        self.split_update = self.ar is not None and len(self.tail_names) == 1
         self._graphs = None
         self._warm = False
 
@@ -78,6 +85,14 @@ class TrainStep:
     def _update(self):
         self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm)
 
+    # multi-GPU: the optimizer step in two pieces, the tail bucket's tensor first (its all-reduce has landed under
+    # _tail()), the rest once the main bucket is in; `iterations` advances with the second piece
+    def _update_tail(self):
+        self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm, only=self.tail_names, advance=False)
+
+    def _update_rest(self):
+        self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm, only=self.rest_names)
+
     # -- public -----------------------------------------------------------
     def _segments(self, cur, hist, w):
         """(src, out, row_elems, chunk, out_ld) of the current frames, history frames and labels of a batch."""
@@ -107,6 +122,12 @@ class TrainStep:
         self._tail()
         if self.ar is not None:
             self.ar.reduce_main()
+            if self.split_update:
+                self.ar.wait_tail()
+                self._update_tail()
+                self.ar.wait()
+                self._update_rest()
+                return
             self.ar.wait()
         self._update()
 
@@ -128,16 +149,29 @@ class TrainStep:
                     self._main()
                 with ops.Graph() as g2:
                     self._tail()
-                with ops.Graph() as g3:
-                    self._update()
-                self._graphs = (g1, g2, g3)
+                if self.split_update:
+                    with ops.Graph() as g3:
+                        self._update_tail()
+                    with ops.Graph() as g4:
+                        self._update_rest()
+                    self._graphs = (g1, g2, g3, g4)
+                else:
+                    with ops.Graph() as g3:
+                        self._update()
+                    self._graphs = (g1, g2, g3)
         if self.ar is None:
             self._graphs[0].launch()
         else:
-            g1, g2, g3 = self._graphs
+            g1, g2, g3 = self._graphs[:3]
             g1.launch()
             self.ar.reduce_tail()       # hW-kernel bucket, overlaps the weight-gradient products of g2
             g2.launch()
             self.ar.reduce_main()
-            self.ar.wait()
-            g3.launch()
+            if self.split_update:
+                self.ar.wait_tail()
+                g3.launch()             # Adam-WN of the hW kernel (87 % of the parameters) under the main bucket's all-reduce
+                self.ar.wait()
+                self._graphs[3].launch()
+            else:
+                self.ar.wait()
+                g3.launch()

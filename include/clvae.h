@@ -376,7 +376,9 @@ int clv_adam_wn_plan_build(const clv_param_desc* host_table, int n_tensors, void
 size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tensors);
 /* iterations_dev (device int32, may be NULL): Keras' `iterations` variable; when given,
  * t = *iterations_dev + 1 is read on the device and the counter is advanced by the call
- * (so a captured graph can be replayed); otherwise t = step_t. */
+ * (so a captured graph can be replayed); otherwise t = step_t.  iterations_dev with step_t == -1: the
+ * counter is read but NOT advanced -- a step may be split over several calls on disjoint tensor subsets (each with its
+ * own table and plan over the same flat buffers), of which only the last one advances the counter. */
 int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
                      float* params, const float* grads, float* m, float* v,
                      float* mg, float* vg, float* s,

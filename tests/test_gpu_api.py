@@ -384,3 +384,44 @@ def test_persistent_generation_matches_frame_steps(dev, N, L, use_x_prev, gate, 
         eng.dec_step(z, x if use_x_prev else None, w, st)
         torch.cuda.synchronize()
         np.testing.assert_allclose(xhat[:, t].cpu().numpy(), st['xhat'].cpu().numpy(), rtol=0, atol=2e-5)
+
+
+# ------------------------------------------------------------------ data parallel, two ranks on one GPU
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_rank_dp_step_matches_single_process(dev, tmp_path, mode):
+    """Two data-parallel ranks (4 rows each, gloo carrying the CUDA gradient buckets, both on this GPU) end every step
+    with identical weights, equal to one process training on the 8 rows: bucketed all-reduce on the side stream, the
+    tail-bucket event, the optimizer step issued in two pieces, Philox noise addressed by global row."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "w%d.npz")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), out, mode], env=env))
+    for pr in procs:
+        assert pr.wait(timeout=300) == 0
+    w0, w1 = np.load(out % 0), np.load(out % 1)
+    for k in w0.files:
+        np.testing.assert_array_equal(w0[k], w1[k], err_msg=k)
+    # the same four steps in one process on the concatenated batch
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    B, Tn, L, C = 8, 6, 2, 3
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=C, use_x_prev=True)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=11).items()}
+    rng = np.random.default_rng(0)
+    win = (rng.random((B, Tn + 1, 88)) < 0.05).astype(np.float32)
+    wt = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
+    eng = VrnnEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    ts = TrainStep(eng, seed=5, use_graph=False)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    for _ in range(4):
+        ts.stage_batch(t(win[:, 1:]), t(win[:, :-1]), t(wt))
+        ts.step()
+    torch.cuda.synchronize()
+    ref = eng.P.get_weights()
+    for k in ref:
+        np.testing.assert_allclose(w0[k], ref[k], rtol=2e-3, atol=2e-5, err_msg=k)

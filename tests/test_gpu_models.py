@@ -243,3 +243,31 @@ def test_cl_vrnn_dp_graph_schedule_matches_single_graph(dev, monkeypatch):
         out.append(eng.P.get_weights())
     for k in out[0]:
         np.testing.assert_array_equal(out[0][k], out[1][k])
+
+
+def test_adam_step_in_two_pieces_is_bitwise_the_whole_step(dev):
+    """FlatParams.adam_step(only=..., advance=False) then the rest == one call (per-tensor independence of Adam-WN,
+    `iterations` advanced once): the multi-GPU schedule updates the hW kernel while the other bucket is still reduced."""
+    from clvae_amd.engine import VrnnEngine
+    cfg = O.vrnn_config(latent_dim=2, seq_length=6, n_classes=4, use_x_prev=True)
+    rng = np.random.default_rng(3)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=5).items()}
+    res = []
+    for split in (False, True):
+        eng = VrnnEngine(cfg, 4, dev)
+        eng.P.set_weights(p)
+        g = torch.as_tensor(np.random.default_rng(9).standard_normal(eng.P.n).astype(np.float32), device=dev)
+        for it in range(3):
+            eng.P.grads.copy_(g * (it + 1))
+            if split:
+                eng.P.adam_step(only=['hW/kernel'], advance=False)
+                eng.P.adam_step(only=[n for n, _ in eng.P.shapes if n != 'hW/kernel'])
+            else:
+                eng.P.adam_step()
+        torch.cuda.synchronize()
+        assert int(eng.P.iterations.item()) == 3
+        res.append((eng.P.get_weights(), eng.P.m.cpu().numpy(), eng.P.s.cpu().numpy()))
+    for k in res[0][0]:
+        np.testing.assert_array_equal(res[0][0][k], res[1][0][k])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
