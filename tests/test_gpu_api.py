@@ -392,13 +392,17 @@ def test_two_rank_dp_step_matches_single_process(dev, tmp_path, mode):
     """Two data-parallel ranks (4 rows each, gloo carrying the CUDA gradient buckets, both on this GPU) end every step
     with identical weights, equal to one process training on the 8 rows: bucketed all-reduce on the side stream, the
     tail-bucket event, the optimizer step issued in two pieces, Philox noise addressed by global row."""
+    import socket
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     out = str(tmp_path / "w%d.npz")
+    with socket.socket() as sk:          # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), out, mode], env=env))
     for pr in procs:
         assert pr.wait(timeout=300) == 0
