@@ -101,7 +101,7 @@ SIGNATURES = {
     "clv_adam_wn_workspace_bytes": (_sz, [_p, _i]),
     "clv_adam_wn_step": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _p, _sz, _p]),
     "clv_philox_normal2": (_i, [_p, _i64, _u32, _u64, _p, _i64, _u32, _u64, _u64, _u32, _p, _p]),
-    "clv_gather_rows_multi": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_gather_rows_multi": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_philox_normal": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
     "clv_philox_uniform": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
     "clv_i32_add": (_i, [_p, C.c_int32, _p]),

@@ -18,6 +18,7 @@ import torch
 from ..engine import VrnnEngine, vrnn_param_shapes
 from ..initializers import glorot_uniform, init_weights, orthogonal
 from ..keras_like import Layer, Model, get_value
+from ..utils.pianoroll import Windows
 
 
 # --------------------------------------------------------------------------- #
@@ -134,7 +135,8 @@ class ClVrnnModel(Model):
             cur, hist = x[0], x[1]
         else:
             cur, hist = (x[0] if isinstance(x, (list, tuple)) else x), None
-        return np.asarray(cur), (None if hist is None else np.asarray(hist)), np.asarray(y[1])
+        keep = lambda a: a if isinstance(a, Windows) else np.asarray(a)       # lazy windows stay views (8f4)
+        return keep(cur), (None if hist is None else keep(hist)), np.asarray(y[1])
 
     def predict(self, x, batch_size=None, verbose=0):
         """[X_decoded_mean, W, W2, Z_args] with freshly drawn noise, in chunks of the model's batch size."""

@@ -35,7 +35,7 @@ def train(args):
     local_batch, device = args.batch_size // world, 'cuda:%d' % local
     P = PianoData(args.train_file, batch_size=args.batch_size, seq_length=args.seq_length, step_length=1,
                   return_y_next=args.predict_next or args.use_x_prev, return_y_hist=True, squeeze_x=False,
-                  squeeze_y=False)
+                  squeeze_y=False, lazy=True)     # windows stay views of one uint8 frame store per split
 
     args.n_classes = len(np.unique(P.train_song_keys))
     max_key = max(int(P.train_song_keys.max()), int(P.valid_song_keys.max()) if len(P.valid_song_keys) else 0)

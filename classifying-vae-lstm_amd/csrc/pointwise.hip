@@ -293,17 +293,22 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
 
 // up to 3 gathers that share the row index list (current frames, history frames, labels of a mini-batch) in one
 // launch; idx == nullptr: rows row0 .. row0+rows-1 (staging a contiguous batch)
-struct GatherSeg { const float* src; float* out; int64_t row_elems, out_ld; int chunk, pieces, vec, u8; };
+// a source row starts at element table[idx] * stride + offset (table optional: then idx itself; stride defaults to
+// row_elems): overlapping windows of a frame store are rows of stride one frame
+struct GatherSeg { const float* src; float* out; const int64_t* table; int64_t row_elems, out_ld, stride, offset;
+                   int chunk, pieces, vec, u8; };
 struct GatherArgs { GatherSeg seg[3]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; };
 // grid = (work items of a row / 256, rows, segments): no 64-bit divisions per element (they cost more than the copy)
 __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
   const int si = blockIdx.z;
   const float* src = a.seg[0].src; float* out = a.seg[0].out;
-  int64_t row_elems = a.seg[0].row_elems, out_ld = a.seg[0].out_ld;
+  const int64_t* table = a.seg[0].table;
+  int64_t row_elems = a.seg[0].row_elems, out_ld = a.seg[0].out_ld, stride = a.seg[0].stride, offset = a.seg[0].offset;
   int chunk = a.seg[0].chunk, pieces = a.seg[0].pieces, vec = a.seg[0].vec, u8 = a.seg[0].u8;
 #pragma unroll
   for (int k = 1; k < 3; ++k)
-    if (si == k) { src = a.seg[k].src; out = a.seg[k].out; row_elems = a.seg[k].row_elems; out_ld = a.seg[k].out_ld;
+    if (si == k) { src = a.seg[k].src; out = a.seg[k].out; table = a.seg[k].table; row_elems = a.seg[k].row_elems;
+                   out_ld = a.seg[k].out_ld; stride = a.seg[k].stride; offset = a.seg[k].offset;
                    chunk = a.seg[k].chunk; pieces = a.seg[k].pieces; vec = a.seg[k].vec; u8 = a.seg[k].u8; }
   const int W = vec ? 4 : 1;                       // work item = 4 elements (aligned segments) or one
   const unsigned c = (blockIdx.x * 256u + threadIdx.x) * (unsigned)W;
@@ -311,10 +316,12 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
   unsigned piece = 0, within = c;
   if (pieces > 1) { piece = c / (unsigned)chunk; within = c - piece * (unsigned)chunk; }
   for (int64_t r = blockIdx.y; r < a.rows; r += gridDim.y) {
-    const int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
+    int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
+    if (table) sr = table[sr];
+    const int64_t s0 = sr * stride + offset;       // first element of the source row
     float* dp = out + (r * pieces + piece) * out_ld + within;
     if (u8) {                                      // uint8 store (binary piano-roll frames): 4 bytes in, one float4 out
-      const unsigned char* sp = reinterpret_cast<const unsigned char*>(src) + sr * row_elems + c;
+      const unsigned char* sp = reinterpret_cast<const unsigned char*>(src) + s0 + c;
       if (vec) {
         const unsigned int v = *reinterpret_cast<const unsigned int*>(sp);
         *reinterpret_cast<float4*>(dp) = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
         *dp = (float)*sp;
       }
     } else {
-      const float* sp = src + sr * row_elems + c;
+      const float* sp = src + s0 + c;
       if (vec) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
       else *dp = *sp;
     }
@@ -462,7 +469,9 @@ extern "C" int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src
 
 extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                                      const void* const* src, const int32_t* src_u8, float* const* out,
-                                     const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld, void* stream) {
+                                     const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
+                                     const int64_t* src_stride, const int64_t* src_offset,
+                                     const int64_t* const* src_table, void* stream) {
   if (rows <= 0 || nseg < 1 || nseg > 3 || !src || !out || !row_elems || !chunk || !out_ld) return CLV_EINVAL;
   GatherArgs a;
   memset(&a, 0, sizeof(a));
@@ -474,9 +483,13 @@ extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t r
     if (row_elems[k] % ch != 0) return CLV_EINVAL;
     const int64_t ld = chunk[k] > 0 ? out_ld[k] : row_elems[k];
     const int u8 = src_u8 && src_u8[k];
-    const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % (u8 ? 4 : 16) == 0 &&
-                    ((uintptr_t)out[k]) % 16 == 0;
-    a.seg[k] = GatherSeg{(const float*)src[k], out[k], row_elems[k], ld, (int)ch, (int)(row_elems[k] / ch), vec, u8};
+    const int64_t stride = (src_stride && src_stride[k] > 0) ? src_stride[k] : row_elems[k];
+    const int64_t offset = src_offset ? src_offset[k] : 0;
+    const int64_t salign = u8 ? 4 : 16, ealign = u8 ? 4 : 4;       // bytes / elements a vector access needs
+    const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % salign == 0 &&
+                    stride % ealign == 0 && offset % ealign == 0 && ((uintptr_t)out[k]) % 16 == 0;
+    a.seg[k] = GatherSeg{(const float*)src[k], out[k], src_table ? src_table[k] : nullptr, row_elems[k], ld, stride, offset,
+                         (int)ch, (int)(row_elems[k] / ch), vec, u8};
     const int64_t w = row_elems[k] / (vec ? 4 : 1);
     maxw = w > maxw ? w : maxw;
   }

@@ -123,6 +123,21 @@ def _to_dev(a, dev):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32), device=dev)
 
 
+def _windows_to_dev(cur, hist, dev):
+    """utils.pianoroll.Windows -> DevWindows; views of the same frame store share one device copy."""
+    from .trainer import DevWindows
+    stores = {}
+
+    def one(w):
+        if w is None:
+            return None
+        key = id(w.store)
+        if key not in stores:
+            stores[key] = _frames_to_dev(w.store, dev)
+        return DevWindows(stores[key], torch.as_tensor(np.ascontiguousarray(w.starts, dtype=np.int64), device=dev), w.t0)
+    return one(cur), one(hist)
+
+
 def _frames_to_dev(a, dev):
     """Piano-roll frames for the device-resident data set: uint8 when every value is 0 or 1 (the gather converts to
     float while it assembles a batch: a quarter of the HBM footprint and of the read traffic), float32 otherwise."""
@@ -235,14 +250,14 @@ class Model:
         if n % GB:
             raise ValueError("number of samples %d is not a multiple of the global batch %d" % (n, GB))
         dev = eng.device
-        d_cur, d_hist = _frames_to_dev(cur, dev), (None if hist is None else _frames_to_dev(hist, dev))
+        d_cur, d_hist = self._data_to_dev(cur, hist, dev)
         d_w = _to_dev(w_true, dev)
         val = None
         if validation_data is not None:
             vc, vh, vw = self._split_inputs(validation_data[0], validation_data[1])
             if vc.shape[0] % B:
                 raise ValueError("validation samples %d not a multiple of batch_size %d" % (vc.shape[0], B))
-            val = (_frames_to_dev(vc, dev), None if vh is None else _frames_to_dev(vh, dev), _to_dev(vw, dev))
+            val = self._data_to_dev(vc, vh, dev) + (_to_dev(vw, dev),)
         if world > 1:           # replicas start from rank 0's weights, optimizer state and noise key
             for t in (eng.P.params, eng.P.m, eng.P.v):
                 dist.broadcast(t, src=0)
@@ -288,6 +303,15 @@ class Model:
         for c in cbs:
             c.on_train_end({})
         return self.history
+
+    @staticmethod
+    def _data_to_dev(cur, hist, dev):
+        """Frames of a data set on the device: whole rows (uint8 when binary) or, for Windows views, the frame store
+        plus the windows' start offsets."""
+        from .utils.pianoroll import Windows
+        if isinstance(cur, Windows) and (hist is None or isinstance(hist, Windows)):
+            return _windows_to_dev(cur, hist, dev)
+        return (_frames_to_dev(np.asarray(cur), dev), None if hist is None else _frames_to_dev(np.asarray(hist), dev))
 
     def evaluate_device(self, d_cur, d_hist, d_w, prefix=''):
         """Validation pass: forward + losses with the sampling noise ON (Lambda layers have no test switch,

@@ -329,8 +329,9 @@ def gather_rows(rows, row_elems, src, idx, out, chunk=0, out_ld=0):
 
 
 def gather_rows_multi(rows, idx, segs, row0=0):
-    """segs: up to 3 (src, out, row_elems, chunk, out_ld); one launch; idx None = rows row0..row0+rows-1.
-    A uint8 src (binary frames kept as bytes) is converted to float on the way."""
+    """segs: up to 3 (src, out, row_elems, chunk, out_ld[, stride, offset, table]); one launch; idx None = rows
+    row0..row0+rows-1.  A uint8 src (binary frames kept as bytes) is converted to float on the way.  With (stride,
+    offset, table) source row r starts at element table[idx[r]] * stride + offset: windows of a frame store."""
     n = len(segs)
     P, I, U = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     src = P(*[s_[0].data_ptr() for s_ in segs])
@@ -339,7 +340,11 @@ def gather_rows_multi(rows, idx, segs, row0=0):
     re = I(*[int(s_[2]) for s_ in segs])
     ch = I(*[int(s_[3]) for s_ in segs])
     ld = I(*[int(s_[4]) for s_ in segs])
-    check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, _stream()),
+    ext = [tuple(s_[5:8]) + (0, 0, None)[len(s_[5:8]):] for s_ in segs]
+    st = I(*[int(e[0]) for e in ext])
+    of = I(*[int(e[1]) for e in ext])
+    tb = P(*[(e[2].data_ptr() if e[2] is not None else None) for e in ext])
+    check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, _stream()),
           "clv_gather_rows_multi")
 
 

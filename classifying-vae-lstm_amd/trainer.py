@@ -18,6 +18,15 @@ from . import ops
 from .parallel import GradAllReduce, eps_first_index
 
 
+class DevWindows:
+    """Device side of utils.pianoroll.Windows: row i = store[starts[i] + t0 : ... + T] (store uint8 or float32 [F, D],
+    starts int64 [n]); the batch gather reads the overlapping windows straight from the store."""
+
+    def __init__(self, store, starts, t0):
+        self.store, self.starts, self.t0 = store, starts, int(t0)
+        self.shape = (int(starts.shape[0]),)
+
+
 class TrainStep:
     def __init__(self, engine, seed=1234, rank=0, world=1, group=None, optimizer='adam-wn',
                  lr=1e-3, use_graph=True):
@@ -95,14 +104,20 @@ class TrainStep:
 
     # -- public -----------------------------------------------------------
     def _segments(self, cur, hist, w):
-        """(src, out, row_elems, chunk, out_ld) of the current frames, history frames and labels of a batch."""
-        row = int(self.X[0].numel())
-        segs = [(cur, self.X, row, 0, 0)]
+        """(src, out, row_elems, chunk, out_ld[, stride, offset, table]) of the current frames, history frames and labels
+        of a batch.  cur / hist are device tensors of whole rows or DevWindows (windows of a frame store)."""
+        row, D = int(self.X[0].numel()), self.eng.cfg['D']
+
+        def src(x):
+            return (x.store, (D, x.t0 * D, x.starts)) if isinstance(x, DevWindows) else (x, ())
+        c, cx = src(cur)
+        segs = [(c, self.X, row, 0, 0) + cx]
         if hist is not None:
+            h, hx = src(hist)
             if self.xp_ld:      # history frames go straight into the [Xp | Z] decoder-input buffer
-                segs.append((hist, self.Xp, row, self.eng.cfg['D'], self.xp_ld))
+                segs.append((h, self.Xp, row, D, self.xp_ld) + hx)
             else:
-                segs.append((hist, self.Xp, row, 0, 0))
+                segs.append((h, self.Xp, row, 0, 0) + hx)
         segs.append((w, self.w_true, int(self.w_true.shape[1]), 0, 0))
         return segs
 

@@ -60,6 +60,39 @@ def songs_to_pianoroll(songs, seq_length, step_length, inner_fcn=song_to_pianoro
     return np.vstack(rolls), np.hstack(inds)
 
 
+class Windows:
+    """Read-only [n, length, 88] view of a uint8 frame store: row i is store[starts[i] + t0 : starts[i] + t0 + length].
+    The sliding windows of a split overlap almost entirely (step 1: 128 copies of every frame at seq_length 128), so
+    PianoData(lazy=True) hands these out instead of arrays: numpy sees an array (np.asarray materialises it), row
+    slicing stays lazy, and Model.fit uploads the store once and gathers windows by start offset on the device
+    (SURVEY.md 8f4)."""
+
+    def __init__(self, store, starts, t0, length, dtype=np.float64):
+        self.store, self.starts = store, np.asarray(starts, dtype=np.int64)
+        self.t0, self.length, self.dtype = int(t0), int(length), np.dtype(dtype)
+
+    @property
+    def shape(self):
+        return (len(self.starts), self.length, self.store.shape[1])
+
+    ndim = 3
+
+    def __len__(self):
+        return len(self.starts)
+
+    def __array__(self, dtype=None, copy=None):
+        idx = (self.starts + self.t0)[:, None] + np.arange(self.length)[None, :]
+        return self.store[idx].astype(dtype or self.dtype)
+
+    def __getitem__(self, key):
+        if isinstance(key, (slice, np.ndarray, list)):          # rows: still a view
+            return Windows(self.store, self.starts[key], self.t0, self.length, self.dtype)
+        return np.asarray(self)[key]
+
+    def squeeze(self):
+        return np.asarray(self).squeeze() if 1 in self.shape else self
+
+
 def _load_pickle(path):
     with open(path, 'rb') as f:
         try:
@@ -72,8 +105,11 @@ def _load_pickle(path):
 class PianoData:
     def __init__(self, train_file, batch_size=None, seq_length=1, step_length=1, return_y_next=True,
                  return_y_hist=False, squeeze_x=True, squeeze_y=True, use_rel_major=True,
-                 fix_song_index=False, dtype=np.float64):
+                 fix_song_index=False, dtype=np.float64, lazy=False):
+        """lazy=True: x_* / y_* are `Windows` views of one uint8 frame store per split instead of materialised arrays
+        (same values: np.asarray(view) == the eager array)."""
         D = _load_pickle(train_file)
+        self.lazy = lazy
         self.train_file = train_file
         self.batch_size = batch_size
         self.seq_length = seq_length
@@ -103,6 +139,8 @@ class PianoData:
 
     def make_xy(self, songs):
         win = self.seq_length + int(self.return_y_next)
+        if self.lazy:
+            return self._make_xy_lazy(songs, win)
         rolls, inds = [], []
         kept = 0
         for si, s in enumerate(songs):
@@ -127,6 +165,35 @@ class PianoData:
         if self.squeeze_y:
             y_rolls = y_rolls.squeeze()
         return x_rolls, y_rolls, song_inds
+
+    def _make_xy_lazy(self, songs, win):
+        """The same windows as make_xy, as views: every song is rasterised once into a shared uint8 store and a window
+        is its start frame."""
+        store, starts, inds = [], [], []
+        kept = frames = 0
+        for si, s in enumerate(songs):
+            roll = song_to_pianoroll(s, dtype=np.uint8)
+            st = sliding_inds(roll.shape[0], win, self.step_length)
+            if len(st) > 0:
+                starts.append(frames + st)
+                inds.append(np.full(len(st), si if self.fix_song_index else kept, dtype=np.float64))
+                kept += 1
+            store.append(roll)
+            frames += roll.shape[0]
+        store = np.vstack(store)
+        starts = self.adjust_for_batch_size(np.hstack(starts))
+        song_inds = self.adjust_for_batch_size(np.hstack(inds))
+        T = self.seq_length
+        if self.return_y_next:
+            x = Windows(store, starts, 0, T, self.dtype)
+            y = Windows(store, starts, 1, T, self.dtype) if self.return_y_hist else Windows(store, starts, T, 1, self.dtype)
+        else:
+            x = y = Windows(store, starts, 0, win, self.dtype)
+        if self.squeeze_x:
+            x = x.squeeze()
+        if self.squeeze_y:
+            y = y.squeeze()
+        return x, y, song_inds
 
     def song_modes(self, modes, song_inds):
         return np.array(modes)[song_inds.astype(int)]

@@ -338,11 +338,17 @@ int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int
 /* Up to 3 such gathers that share one row list in a single launch (current frames, history frames and labels
  * of a mini-batch).  idx == NULL takes the consecutive rows row0 .. row0+rows-1 (staging a contiguous batch).
  * Per segment k: src[k] rows of row_elems[k] elements, written like clv_gather_rows with chunk[k] / out_ld[k].
+ * Source row r of segment k starts at element t * src_stride[k] + src_offset[k], t = src_table[k] ? src_table[k][i] : i,
+ * i = idx ? idx[r] : row0 + r (src_stride / src_offset / src_table may be NULL: stride = row_elems[k], offset 0, no table).
+ * With stride = one frame the rows are overlapping windows of a frame store (songs are kept once, as
+ * uint8, and the sliding windows of utils/pianoroll.py:49-71 are never materialised).
  * src_u8 (may be NULL): src_u8[k] != 0 marks a uint8 source (binary piano-roll frames kept as bytes in HBM,
  * a quarter of the footprint and of the gather's read traffic); the output is float either way. */
 int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                           const void* const* src, const int32_t* src_u8, float* const* out,
-                          const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld, void* stream);
+                          const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
+                          const int64_t* src_stride, const int64_t* src_offset, const int64_t* const* src_table,
+                          void* stream);
 
 /* the five loss scalars of a step in one launch: out[k] = scale[k] * sum_{i<n[k]} x[k][i*stride[k]], k < 5
  * (vae, kl_z, kl_w, w_rec, acc means; fixed summation order => deterministic). */

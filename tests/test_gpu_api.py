@@ -429,3 +429,29 @@ def test_two_rank_dp_step_matches_single_process(dev, tmp_path, mode):
     ref = eng.P.get_weights()
     for k in ref:
         np.testing.assert_allclose(w0[k], ref[k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+# ------------------------------------------------------------------ 8f4: fit() from a frame store
+def test_fit_from_lazy_windows_equals_fit_from_arrays(dev, tmp_path):
+    """Model.fit on PianoData(lazy=True) views (one uint8 frame store on the device, windows gathered by start offset)
+    gives bitwise the weights and history of fit on the materialised window arrays, with shuffling and validation."""
+    from helpers import make_synthetic_pickle
+    from clvae_amd.cl_vrnn.model import get_model
+    from clvae_amd.utils.pianoroll import PianoData, Windows
+    f = make_synthetic_pickle(str(tmp_path / "syn.pickle"), n_songs=(10, 4, 4), min_len=30, max_len=60, seed=6)
+    B, T, L = 8, 10, 2
+    res = []
+    for lazy in (False, True):
+        P = PianoData(f, batch_size=B, seq_length=T, step_length=1, return_y_next=True, return_y_hist=True,
+                      squeeze_x=False, squeeze_y=False, lazy=lazy)
+        assert isinstance(P.x_train, Windows) == lazy
+        C = len(P.key_map)
+        w, wv = np.eye(C)[P.train_song_keys], np.eye(C)[P.valid_song_keys]
+        model, _ = get_model(B, 88, 88, L, T, C, True, 'adam-wn', seed=3)
+        np.random.seed(1)                                   # the epoch permutations
+        hist = model.fit([P.y_train, P.x_train], [P.y_train, w, w, P.y_train], shuffle=True, epochs=2, batch_size=B,
+                         verbose=0, validation_data=([P.y_valid, P.x_valid], [P.y_valid, wv, wv, P.y_valid]))
+        res.append((model.engine.P.get_weights(), hist.history))
+    for k in res[0][0]:
+        np.testing.assert_array_equal(res[0][0][k], res[1][0][k], err_msg=k)
+    assert res[0][1] == res[1][1]

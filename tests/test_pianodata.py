@@ -73,3 +73,30 @@ def test_synthetic_schema_and_song_index_bug(tmp_path):
     assert set(P.key_map) == {'C', 'G', 'F'}                               # a -> C, e -> G (relative major)
     P32 = PR.PianoData(f, batch_size=4, seq_length=T, dtype=np.float32)
     assert P32.x_train.dtype == np.float32
+
+
+@pytest.mark.parametrize("kw", [dict(return_y_next=True, return_y_hist=True, squeeze_x=False, squeeze_y=False),
+                                dict(return_y_next=True, return_y_hist=False, squeeze_x=False, squeeze_y=True),
+                                dict(return_y_next=False, squeeze_x=False, squeeze_y=False)])
+def test_lazy_windows_equal_the_materialised_arrays(tmp_path, kw):
+    """PianoData(lazy=True): x_* / y_* are views of one uint8 frame store per split with exactly the
+    values, shapes and song lookups of the eager arrays; row slices stay views."""
+    f = make_synthetic_pickle(str(tmp_path / "syn.pickle"), min_len=10, max_len=60, seed=4)
+    T = 12
+    E = PR.PianoData(f, batch_size=8, seq_length=T, **kw)
+    Lz = PR.PianoData(f, batch_size=8, seq_length=T, lazy=True, **kw)
+    for split in ('train', 'valid', 'test'):
+        for xy in ('x', 'y'):
+            e, l = getattr(E, '%s_%s' % (xy, split)), getattr(Lz, '%s_%s' % (xy, split))
+            assert tuple(e.shape) == tuple(l.shape) and len(e) == len(l)
+            np.testing.assert_array_equal(e, np.asarray(l))
+            assert np.asarray(l).dtype == np.float64
+            if isinstance(l, PR.Windows) and len(l) > 8:
+                sub = l[3:8]
+                assert isinstance(sub, PR.Windows) and sub.store is l.store
+                np.testing.assert_array_equal(e[3:8], np.asarray(sub))
+                np.testing.assert_array_equal(e[5], l[5])
+        np.testing.assert_array_equal(getattr(E, '%s_song_inds' % split), getattr(Lz, '%s_song_inds' % split))
+        np.testing.assert_array_equal(getattr(E, '%s_song_keys' % split), getattr(Lz, '%s_song_keys' % split))
+    assert isinstance(Lz.x_train, PR.Windows)
+    assert Lz.x_train.store.dtype == np.uint8 and Lz.x_train.store.nbytes * T // 2 < E.x_train.nbytes // 8
