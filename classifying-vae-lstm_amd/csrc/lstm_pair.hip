@@ -258,13 +258,15 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   step_barrier();
 }
 
-template <int GATE, bool HASXP>
+// ZQ: latents per decoder lane actually present (ceil(latent_dim / 4)): lane s multiplies the latents s, s+4, ..; the
+// slots beyond latent_dim hold zero weights, so they are not issued at all
+template <int GATE, bool HASXP, int ZQ>
 __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP],
                                                  float (*zbuf)[PLMAX]) {
   const int s = lane & 3, b = blockIdx.x, T = a.T;
   const int u = min(wave * 16 + (lane >> 2), LH - 1);
   f2 Ur[PKK][2];
-  f2 Kzr[PLQ][2];        // lane s takes the latents s, s+4, ...
+  f2 Kzr[ZQ][2];         // lane s takes the latents s, s+4, ...
   {
     const float4* pw = reinterpret_cast<const float4*>(a.pack) + PK_FD + wave * PKK * 64 + lane;
 #pragma unroll
@@ -274,7 +276,7 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     }
     const float4* pz = reinterpret_cast<const float4*>(a.pack) + PK_KZ + wave * PLQ * 64 + lane;
 #pragma unroll
-    for (int q = 0; q < PLQ; ++q) {
+    for (int q = 0; q < ZQ; ++q) {
       const float4 v = pz[q * 64];
       Kzr[q][0][0] = v.x; Kzr[q][0][1] = v.y; Kzr[q][1][0] = v.z; Kzr[q][1][1] = v.w;
     }
@@ -304,7 +306,7 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
       const float4 zq = *reinterpret_cast<const float4*>(&zbuf[cur][PLQ * s]);
       const float zl[PLQ] = {zq.x, zq.y, zq.z, zq.w};
 #pragma unroll
-      for (int q = 0; q < PLQ; ++q) {
+      for (int q = 0; q < ZQ; ++q) {
         if (HASXP) {      // scalar, like the recurrent product below: no packed operand next to the prefetch registers
           acc2[0][0] = fmaf(zl[q], Kzr[q][0][0], acc2[0][0]); acc2[0][1] = fmaf(zl[q], Kzr[q][0][1], acc2[0][1]);
           acc2[1][0] = fmaf(zl[q], Kzr[q][1][0], acc2[1][0]); acc2[1][1] = fmaf(zl[q], Kzr[q][1][1], acc2[1][1]);
@@ -336,7 +338,7 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   }
 }
 
-template <int GATE, bool HASXP>
+template <int GATE, bool HASXP, int ZQ>
 __global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float hbuf[2][2][PK * PKP];      // [chain][parity][sliced h]
   __shared__ __attribute__((aligned(16))) float zbuf[2][PLMAX];
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
   if (tid < 2 * PLMAX) (&zbuf[0][0])[tid] = 0.f;
   __syncthreads();
   if (wave < PNW) pair_fwd_encoder<GATE>(a, wave, lane, hbuf[0], zbuf);
-  else pair_fwd_decoder<GATE, HASXP>(a, wave - PNW, lane, hbuf[1], zbuf);
+  else pair_fwd_decoder<GATE, HASXP, ZQ>(a, wave - PNW, lane, hbuf[1], zbuf);
 }
 
 // ---------------------------------------------------------------------------
@@ -628,9 +630,11 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_fwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
-#define PAIR_FWD(G, X) hipLaunchKernelGGL((lstm_pair_fwd_kernel<G, X>), dim3(B), dim3(PNT), 0, s, a)
+#define PAIR_FWD_Z(G, X, Z) hipLaunchKernelGGL((lstm_pair_fwd_kernel<G, X, Z>), dim3(B), dim3(PNT), 0, s, a)
+#define PAIR_FWD(G, X) do { if (L <= 4) PAIR_FWD_Z(G, X, 1); else if (L <= 8) PAIR_FWD_Z(G, X, 2); else PAIR_FWD_Z(G, X, 4); } while (0)
   if (hard) { if (dec_has_xproj) PAIR_FWD(CLV_GATE_HARD_SIGMOID, true); else PAIR_FWD(CLV_GATE_HARD_SIGMOID, false); }
   else { if (dec_has_xproj) PAIR_FWD(CLV_GATE_SIGMOID, true); else PAIR_FWD(CLV_GATE_SIGMOID, false); }
+#undef PAIR_FWD_Z
 #undef PAIR_FWD
   return launch_status();
 }
