@@ -403,6 +403,11 @@ class VrnnEngine(_EngineBase):
         self.fuse_xproj = bool(cfg.get('fuse_xproj', False))   # break-even vs the projection GEMM at config 3
         # encoder + latent head + decoder as one launch (csrc/lstm_pair.hip); latent_dim <= 16
         self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj
+        # Twice the workgroups, half the K each, for the LSTM weight-gradient products.  They run one 1024-thread
+        # workgroup per CU with the register file full: alone on the GPU a grid of exactly 256 is best, but when the
+        # gradient all-reduce holds a few CUs a 256-workgroup grid needs a whole second round; 512 shorter ones lose
+        # only the share of the CUs that is taken.  TrainStep turns it on for world > 1.
+        self.fine_grid = bool(cfg.get('fine_grid', os.environ.get('CLV_FINE_GRID', '0') == '1'))
         self.pair_pack = _f(d, ops.lstm_pair_pack_floats()) if self.fuse_pair else None
         # input projections by sparse row gathering (exact for any input; pays off for piano-roll frames)
         self.sparse_inputs = bool(cfg.get('sparse_inputs', True)) and ops.sparse_proj_supported(D, 4 * H)
@@ -684,7 +689,7 @@ class VrnnEngine(_EngineBase):
         rq = self._rq()
         ops.gemm_grouped_tn([dict(A=X_in, lda=x_ld, M=x_rows, C=P.g(name + '/kernel')),
                              dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)],
-                            G4, BT, dz, ws, defer=rq)
+                            G4, BT, dz, ws, defer=rq, split_scale=2 if self.fine_grid else 1)
         if not (Cn + 1 <= 16 and B <= 4096):      # else: both LSTMs' label rows + biases in one launch (grads_tail)
             ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
                                  dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)], G4, B, dzsum, ws, defer=rq)

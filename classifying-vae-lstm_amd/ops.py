@@ -86,7 +86,7 @@ def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None,
           "clv_gemm_f32")
 
 
-def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=None):
+def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=None, split_scale=1):
     """probs: list of dict(A=tensor|None, lda, M, C=tensor, ldc, shift=0, zero_period=0, ones=0|1|2);
     ones=1: implicit row of ones (M == 1); ones=2: row M-1 is an implicit row of ones appended to A's M-1 columns;
     C_p[M_p,N] = A_p^T . B for every problem in one launch (all share B [K,N])."""
@@ -100,6 +100,8 @@ def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=
     n = len(probs)
     if split_k is None:
         split_k = L.clv_gemm_grouped_auto_split(arr, n, N, K)
+        if split_k > 1:
+            split_k *= int(split_scale)      # finer grid: more, shorter workgroups (see VrnnEngine.fine_grid)
     wsp, wsb, job = None, 0, None
     if split_k > 1:
         need = L.clv_gemm_grouped_workspace_bytes(arr, n, N, split_k)

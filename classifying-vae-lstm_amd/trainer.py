@@ -64,6 +64,9 @@ class TrainStep:
                            and int(np.prod(dict(engine.P.shapes)[n])) == tail[1]]
         self.rest_names = [n for n, _ in engine.P.shapes if n not in self.tail_names]
         self.split_update = self.ar is not None and len(self.tail_names) == 1
+        if world > 1 and hasattr(engine, 'fine_grid') and 'fine_grid' not in cfg:
+            # the big bucket's all-reduce runs next to the LSTM weight-gradient products: see VrnnEngine.fine_grid
+            engine.fine_grid = True
         self._graphs = None
         self._warm = False
 
