@@ -162,6 +162,49 @@ def bench_generate(args, w, dev, rank, world):
                           "note_density_out": round(float(out.mean().item()), 4)}))
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside a process group: start the N ranks (one per GPU) as fresh children under
+    torch.distributed.run and return their exit code.  Called before anything has touched the GPU in this process; the
+    parent only waits (it never execs)."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def launch_selftest(args):
+    """--selftest-launch: the launcher, the rendezvous and the rank-0 JSON line without a GPU (gloo); used by
+    tests/test_parallel_cpu.py.  No timing is reported."""
+    import torch
+    import torch.distributed as dist
+    from clvae_amd.parallel import init_from_env
+    rank, local, world = init_from_env(backend='gloo')
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    t = torch.tensor([float(rank + 1)])
+    ranks = [None] * world
+    if world > 1:
+        dist.all_reduce(t)
+        dist.all_gather_object(ranks, (rank, local))
+    else:
+        ranks = [(rank, local)]
+    if rank == 0:
+        print(json.dumps({"metric": "launch selftest", "value": float(t.item()), "unit": "sum of (rank+1)",
+                          "n_gpus": world, "ranks": ranks, "backend": "gloo"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -173,7 +216,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--kernel-times', action='store_true', help='print per-kernel event times to stderr')
+    ap.add_argument('--selftest-launch', action='store_true', help='launcher / rendezvous check on CPU (gloo), no timing')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.selftest_launch:
+        return launch_selftest(args)
 
     import torch
     import torch.distributed as dist
@@ -183,8 +232,10 @@ def main():
     from clvae_amd.trainer import TrainStep
 
     rank, local, world = init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d (launch with torch.distributed.run --nproc-per-node %d, or run "
+                         "`python bench.py --gpus %d` outside a process group and it starts the ranks itself)"
+                         % (world, args.gpus, args.gpus, args.gpus))
     _lib.require_gpu()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -194,8 +245,9 @@ def main():
     if w.get('generate'):
         return bench_generate(args, w, dev, rank, world)
     eng, cfg = make_engine(w, dev)
-    if world > 1:      # replicas start from rank 0's weights
-        dist.broadcast(eng.P.params, src=0)
+    if world > 1:      # replicas start from rank 0's weights and optimizer state
+        for t_ in eng.P.state_tensors():
+            dist.broadcast(t_, src=0)
     X_all, Xp_all, w_all = synthetic_windows(w, 4 * B, 1234 + rank, dev)
     ts = TrainStep(eng, seed=1234, rank=rank, world=world, use_graph=not args.no_graph)
     nb = X_all.shape[0] // B
@@ -226,7 +278,9 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # per-kernel HIP-event timing (eager launches on the same stream, same shapes)
+        # per-kernel HIP-event timing (eager launches on the same stream, same shapes); the steps of this pass are
+        # rank 0's alone, so parameters and optimizer state are put back afterwards
+        saved = [t_.clone() for t_ in eng.P.state_tensors()]
         ts_e = TrainStep(eng, seed=1234, rank=rank, world=1, use_graph=False)
         ts_e.stage_batch(X_all[:B], Xp_all[:B], w_all[:B])
         ts_e.step(); torch.cuda.synchronize()
@@ -236,6 +290,8 @@ def main():
             ts_e.step()
         recs = ops.prof_collect()
         ops.prof_enable(False)
+        for t_, sv in zip(eng.P.state_tensors(), saved):
+            t_.copy_(sv)
         if args.kernel_times:
             tot = sum(r[2] for r in recs)
             for name, n, ms in sorted(recs, key=lambda r: -r[2]):
@@ -275,7 +331,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w)
 
+    devices = [torch.cuda.get_device_name(local)]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, "rank %d: cuda:%d %s" % (rank, local, torch.cuda.get_device_name(local)))
     if rank == 0:
+        try:
+            rccl = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
         out = {
             "metric": "piano-roll timesteps/sec (train)", "value": round(value, 1), "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -287,6 +351,7 @@ def main():
                        "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
             "final_loss": round(float(loss['total']), 4),
             "roofline": roofline, "cpu_baseline": cpu,
+            "devices": devices, "rccl": rccl if world > 1 else None,
         }
         print(json.dumps(out))
     if world > 1:

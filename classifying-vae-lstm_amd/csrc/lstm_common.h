@@ -46,6 +46,27 @@ constexpr int PKP = 24;                 // padded slice stride in LDS (16-byte a
 
 __device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// v[i] for a per-lane i in 0..3 as three v_cndmask_b32 on lane masks kept in SGPR pairs.  Written as a chain of selects
+// on `i == const` the compiler recognises a dynamic index into a 4-element array and puts the array in LDS
+// (ds_write_b128 + ds_read_b32 and a full lgkmcnt wait on the critical path of every step); the asm form costs no VGPR.
+struct Sel4 {
+  unsigned long long m1, m2, m3;
+  __device__ __forceinline__ explicit Sel4(int i) {
+    m1 = __builtin_amdgcn_ballot_w64(i == 1);
+    m2 = __builtin_amdgcn_ballot_w64(i == 2);
+    m3 = __builtin_amdgcn_ballot_w64(i == 3);
+  }
+  __device__ __forceinline__ static float pick(unsigned long long m, float a, float b) {     // m ? a : b
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+  }
+  __device__ __forceinline__ float operator()(float v0, float v1, float v2, float v3) const {
+    return pick(m3, v3, pick(m2, v2, pick(m1, v1, v0)));
+  }
+  __device__ __forceinline__ float operator()(const float (&v)[4]) const { return (*this)(v[0], v[1], v[2], v[3]); }
+};
+
 // h (LDS, sliced layout) . U slice -> the 4 gate sums of this lane's unit, reduced over the k-slices
 __device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)[PKK][2], f2 (&acc2)[2]) {
   const float4* hp = reinterpret_cast<const float4*>(hslice);
@@ -60,6 +81,26 @@ __device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)
     const f2 hh = {hv[kk], hv[kk]};
     acc2[0] = __builtin_elementwise_fma(hh, Ur[kk][0], acc2[0]);
     acc2[1] = __builtin_elementwise_fma(hh, Ur[kk][1], acc2[1]);
+  }
+}
+
+// the same product in pieces: the slice's h values, then the k range [K0, K1) with scalar FMAs
+__device__ __forceinline__ void load_hslice(const float* hslice, float (&hv)[PKP]) {
+  const float4* hp = reinterpret_cast<const float4*>(hslice);
+#pragma unroll
+  for (int q = 0; q < PKP / 4; ++q) {
+    const float4 v = hp[q];
+    hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+  }
+}
+template <int K0, int K1>
+__device__ __forceinline__ void slice_fma_range(const float (&hv)[PKP], const f2 (&Ur)[PKK][2], float (&a)[4]) {
+#pragma unroll
+  for (int kk = K0; kk < K1; ++kk) {
+    a[0] = fmaf(hv[kk], Ur[kk][0][0], a[0]);
+    a[1] = fmaf(hv[kk], Ur[kk][0][1], a[1]);
+    a[2] = fmaf(hv[kk], Ur[kk][1][0], a[2]);
+    a[3] = fmaf(hv[kk], Ur[kk][1][1], a[3]);
   }
 }
 

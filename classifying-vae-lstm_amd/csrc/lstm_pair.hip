@@ -26,8 +26,16 @@ constexpr int PNT = 2 * PNW * 64;       // 768 threads
 constexpr int PLMAX = 16;               // latent dims the surplus groups can carry
 constexpr int PLQ = PLMAX / PK;         // latents per decoder lane (z_t . K_z is split over the k-slice lanes)
 
-constexpr int BW_CW = 22, BW_CP = 24;   // backward layout (lstm.hip): gate columns per slice, padded LDS slice stride
+// backward layout: gate columns per slice, padded LDS slice stride.  28 floats: the 16 slices of a ds_read_b128 lane
+// group start at banks 28*cs mod 64 = {0,28,56,20,48,12,40,4,32,60,24,52,16,44,8,36}, four banks each, all distinct
+// (a stride of 24 puts slices cs and cs+8 on the same banks: every read of the step was a 2-way conflict)
+constexpr int BW_CW = 22, BW_CP = 28;
 constexpr int BW_LDS = 16 * BW_CP;
+
+// Tried and dropped (round 2, gpurun_out/s1): a two-barrier step with the chains half a step apart (one chain's FMAs
+// over the other's LDS-write -> barrier -> LDS-read latency).  Every barrier makes all 12 waves wait for the slowest
+// one, and two of them per step cost more than the overlap returns: +10 % per step (0.73 + 0.93 us against
+// 0.67 + 0.83 us) for every split point of the FMA block tried (10, 12, 14 of 22).
 
 __device__ float g_pair_dump[128];      // target of the stores of lanes that own no output (keeps every store unconditional)
 
@@ -154,6 +162,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   const int zpos = (lat % PK) * PLQ + lat / PK;      // decoder lane s reads the latents s, s+4, .. as one 16-byte LDS word
   // head column held in accumulator g of a latent group: (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)
   auto zcol = [&](int g) { const int l = 2 * zj + (g & 1); return l < L ? (g >> 1) * L + l : -1; };
+  const Sel4 sel_s(s);
 
   f2 Ur[PKK][2];
   {
@@ -202,6 +211,17 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     zv = fmaf(sd, e, m);
     klv = klscale * (1.f + lv - m * m - sd * sd);
   };
+  // the 4 gate sums of this lane's unit: h (LDS) . U slice, reduced over the k-slices
+  auto gate_sums = [&](const float* hslice, float x0, float (&z)[4]) {
+    float acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (s == g) ? x0 : 0.f;
+    float hv[PKP];
+    load_hslice(hslice, hv);
+    slice_fma_range<0, PKK>(hv, Ur, acc);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g]);
+  };
 
   for (int i = 0; i < T; ++i) {
     const int cur = i & 1;
@@ -211,13 +231,8 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     const float ecur = en;                              // eps of step i-1
     en = en2;
     en2 = ep[(size_t)min(i + 1, T - 1) * L];
-    f2 acc2[2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? xv : 0.f;
-    slice_matvec(&hb[cur][PKP * s], Ur, acc2);
     float z[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
+    gate_sums(&hb[cur][PKP * s], xv, z);
     float h, gg;
     lstm_cell<GATE>(z, c, h, gg);
     float v0, v1;
@@ -225,7 +240,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     if (wave == PNW - 1) {          // wave-uniform: the latent head of step i-1 (garbage at i == 0, rewritten at i == 1)
       float zv, klv;
       latent(z, ecur, zv, klv);
-      v0 = is_z ? pick4(s, z) : v0;
+      v0 = is_z ? sel_s(z) : v0;
       v1 = is_z ? (s < 2 ? zv : klv) : v1;
       if (lat_ok && s < 2) zbuf[(i + 1) & 1][zpos] = zv;
     }
@@ -239,22 +254,24 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   }
   // iteration T: only the latent head of step T-1 is left
   if (wave == PNW - 1) {
-    f2 acc2[2];
+    float acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? rb : 0.f;
-    slice_matvec(&hb[T & 1][PKP * s], Ur, acc2);
+    for (int g = 0; g < 4; ++g) acc[g] = (s == g) ? rb : 0.f;
+    float hv[PKP];
+    load_hslice(&hb[T & 1][PKP * s], hv);
+    slice_fma_range<0, PKK>(hv, Ur, acc);
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g]);
     float zv, klv;
     latent(z, en, zv, klv);
     if (lat_ok) {
-      *optr[0] = pick4(s, z);
+      *optr[0] = sel_s(z);
       *optr[1] = s < 2 ? zv : klv;
       if (s < 2) zbuf[(T + 1) & 1][zpos] = zv;
     }
   }
-  step_barrier();
+  step_barrier();          // the decoder chain runs two steps behind
   step_barrier();
 }
 
@@ -299,32 +316,26 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     const float xv = xn + rb;
     xn = xn2;
     if (HASXP) xn2 = xp[(size_t)min(t + 2, T - 1) * LG];
-    f2 acc2[2];
+    // scalar FMAs throughout: with v_pk_fma the allocator pairs a prefetch's destination register with an h value
+    // inside a packed operand, and the wave waits for the load in the middle of the FMA block (+4 % step throughput)
+    float acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc2[g >> 1][g & 1] = (s == g) ? xv : 0.f;
+    for (int g = 0; g < 4; ++g) acc[g] = (s == g) ? xv : 0.f;
     {   // z_t . K_z: branch-free (rows of K_z beyond latent_dim are zero registers); does not depend on h
       const float4 zq = *reinterpret_cast<const float4*>(&zbuf[cur][PLQ * s]);
       const float zl[PLQ] = {zq.x, zq.y, zq.z, zq.w};
 #pragma unroll
       for (int q = 0; q < ZQ; ++q) {
-        if (HASXP) {      // scalar, like the recurrent product below: no packed operand next to the prefetch registers
-          acc2[0][0] = fmaf(zl[q], Kzr[q][0][0], acc2[0][0]); acc2[0][1] = fmaf(zl[q], Kzr[q][0][1], acc2[0][1]);
-          acc2[1][0] = fmaf(zl[q], Kzr[q][1][0], acc2[1][0]); acc2[1][1] = fmaf(zl[q], Kzr[q][1][1], acc2[1][1]);
-        } else {
-          const f2 zz = {zl[q], zl[q]};
-          acc2[0] = __builtin_elementwise_fma(zz, Kzr[q][0], acc2[0]);
-          acc2[1] = __builtin_elementwise_fma(zz, Kzr[q][1], acc2[1]);
-        }
+        acc[0] = fmaf(zl[q], Kzr[q][0][0], acc[0]); acc[1] = fmaf(zl[q], Kzr[q][0][1], acc[1]);
+        acc[2] = fmaf(zl[q], Kzr[q][1][0], acc[2]); acc[3] = fmaf(zl[q], Kzr[q][1][1], acc[3]);
       }
     }
-    // scalar FMAs while a prefetch is in flight: with v_pk_fma the allocator pairs the load's destination register
-    // with an h value inside a packed operand, and the wave waits for the load in the middle of the FMA block
-    // (measured: +4 % step throughput for the scalar form; the encoder loop's allocation does not have the problem)
-    if (HASXP) slice_matvec_scalar(&hb[cur][PKP * s], Ur, acc2);
-    else slice_matvec(&hb[cur][PKP * s], Ur, acc2);
+    float hv[PKP];
+    load_hslice(&hb[cur][PKP * s], hv);
+    slice_fma_range<0, PKK>(hv, Ur, acc);
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc2[g >> 1][g & 1]);
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g]);
     float h, gg;
     lstm_cell<GATE>(z, c, h, gg);
     hb[cur ^ 1][hslot] = h;
@@ -393,6 +404,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   const bool zgroup = DEC && ug >= 22 && zg0 < L;
   const int lat = zg0 + (cs & 3);                    // latent this lane finishes after the reduce-scatter
   const bool zlane = zgroup && lat < L;
+  const Sel4 sel_q(q);
   float* gates = DEC ? a.gates_d : a.gates_e;
   const float* csp = DEC ? a.cs_d : a.cs_e;
   float* dzsum = DEC ? a.dzsum_d : a.dzsum_e;
@@ -418,7 +430,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
 
   const size_t rowbt = (size_t)b * T;
   float dc = 0.f;
-  float zs[4] = {0.f, 0.f, 0.f, 0.f};
+  float zsum = 0.f;                  // sum_t dz of this lane's gate column (the 4 replicas of a unit share the 4 gates)
 
   struct Raw { float zi, zf, g, zo, c, cp, dh; };
   struct Coef { float ko, kc, ki, kf, kg, kcarry, dhh; };
@@ -547,9 +559,8 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     dz[2] = dc * k.kg;
     dz[3] = dh * k.ko;
     dc = dc * k.kcarry;
-#pragma unroll
-    for (int gi = 0; gi < 4; ++gi) zs[gi] += dz[gi];
-    float val = pick4(q, dz);
+    float val = sel_q(dz);
+    zsum += val;
     if (DEC && wave == PNW - 1) {     // wave-uniform: latent lanes turn dZ_{t+1} into dzargs_{t+1}
       const float zv = fmaf(dhrec, k.ki, k.kf);
       val = zgroup ? zv : val;
@@ -576,10 +587,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     step_barrier();
     step_barrier();
   }
-  if (!zgroup) {
-    const float val = pick4(q, zs);
-    dzsum[(size_t)b * LG + col] = val;
-  }
+  if (!zgroup) dzsum[(size_t)b * LG + col] = zsum;
 }
 
 template <int GATE, int ZP>

@@ -151,6 +151,11 @@ class FlatParams:
         buf = self.params if buf is None else buf
         return {name: self.view(buf, name).detach().cpu().numpy().copy() for name, _ in self.logical}
 
+    def state_tensors(self):
+        """Everything a replica must share to step identically: parameters, Adam moments, the weight-norm column state
+        and the step counter (which also keys the Philox noise stream)."""
+        return [self.params, self.m, self.v, self.mg, self.vg, self.s, self.iterations]
+
     def reset_optimizer(self):
         for t in (self.m, self.v, self.mg, self.vg):
             t.zero_()

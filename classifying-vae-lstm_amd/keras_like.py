@@ -214,10 +214,13 @@ class Model:
     def _train_step(self):
         """(Re)build the captured step when the annealed loss weights changed (they are baked into the graph)."""
         w = self._sync_loss_weights()
-        if self._step is None or self._step_weights != w:
+        if self._step is None:
             rank, world = _dp()
             self._step = TrainStep(self.engine, seed=self.seed, rank=rank, world=world, optimizer=self.optimizer.name,
                                    lr=self.optimizer.lr)
+            self._step_weights = w
+        elif self._step_weights != w:       # same step object (streams, staging buffers): only the graphs are stale
+            self._step.recapture()
             self._step_weights = w
         return self._step
 
@@ -259,7 +262,7 @@ class Model:
                 raise ValueError("validation samples %d not a multiple of batch_size %d" % (vc.shape[0], B))
             val = self._data_to_dev(vc, vh, dev) + (_to_dev(vw, dev),)
         if world > 1:           # replicas start from rank 0's weights, optimizer state and noise key
-            for t in (eng.P.params, eng.P.m, eng.P.v):
+            for t in eng.P.state_tensors():     # incl. the weight-norm column state and `iterations` (resumed fits)
                 dist.broadcast(t, src=0)
             seed_t = torch.tensor([self.seed], dtype=torch.int64, device=dev)
             dist.broadcast(seed_t, src=0)

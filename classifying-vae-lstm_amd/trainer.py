@@ -149,6 +149,11 @@ class TrainStep:
             self.ar.wait()
         self._update()
 
+    def recapture(self):
+        """Drop the captured graphs (values baked into them changed, e.g. annealed loss weights); the next step()
+        captures again.  Buffers, streams and the all-reduce buckets stay."""
+        self._graphs = None
+
     def step(self):
         if not self.use_graph:
             self._eager()

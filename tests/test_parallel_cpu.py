@@ -67,3 +67,28 @@ def test_shard_rows_contract():
     with pytest.raises(ValueError):
         shard_rows(10, 0, 4)
     assert eps_first_index(256, 128 * 2) == 65536
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`python bench.py --gpus 2` outside a process group starts the two ranks itself (fresh children under
+    torch.distributed.run) and rank 0 reports n_gpus = 2; here through the CPU self-test path (gloo, no GPU)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] == 3.0
+    assert sorted(tuple(x) for x in d["ranks"]) == [(0, 0), (1, 1)]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in (r.stderr + r.stdout)
