@@ -227,7 +227,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     const int cur = i & 1;
     const float xv = fmaf(xn, xmask, rb);
     xn = xn2;
-    xn2 = xp[(size_t)min(i + 2, T - 1) * LG];           // prefetch two steps ahead, unconditional (clamped)
+    xn2 = xp[(size_t)min(i + 2, T - 1) * LG];           // prefetch two steps ahead, unconditional (clamped); three: no gain
     const float ecur = en;                              // eps of step i-1
     en = en2;
     en2 = ep[(size_t)min(i + 1, T - 1) * L];
