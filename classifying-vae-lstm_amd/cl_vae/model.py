@@ -7,79 +7,64 @@ parameters, so `(latent_dim_0, latent_dim)` and `(class_dim_0, class_dim)` are p
 
 The graph the reference builds out of Keras layers is one fixed chain of HIP kernels here
 (engine.VaeEngine); the returned objects only expose the Keras methods the scripts call.
-The numpy samplers below are host code in the reference too and keep its RNG consumption order.
+The numpy samplers are host code in the reference too; they live in clvae_amd.sampling and consume np.random in the
+reference's order.
 """
 import json
 
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, sampling
 from ..engine import VaeEngine
 from ..initializers import init_weights
 from ..keras_like import Layer, Model, get_value
 
 
 # --------------------------------------------------------------------------- #
-# numpy sampling helpers (host code in the reference as well)
+# host-side sampling (clvae_amd.sampling holds the shared pieces; these are cl_vae's bindings)
 # --------------------------------------------------------------------------- #
-def generate_sample(dec_model, w_enc_model, z_enc_model, x_seed, nsteps, w_val=None, use_z_prior=False,
-                    do_reset=True, w_sample=False, use_x_prev=False):
-    """for t = 1:nsteps: encode x -> w (once), z; decode (w, z[, x_{t-1}]) -> x_mean; x_t ~ Bern(x_mean)."""
-    original_dim = x_seed.shape[0]
-    Xs = np.zeros([nsteps, original_dim])
-    x_prev = np.expand_dims(x_seed, axis=0)
-    x_prev_t = x_prev
-    if w_val is None:
-        w_t = sample_w(w_enc_model.predict(x_prev), add_noise=w_sample)
-    else:
-        w_t = w_val
-    for t in range(nsteps):
-        z_mean, z_log_var = z_enc_model.predict([x_prev, w_t])
-        if use_z_prior:
-            z_t = sample_z((0 * z_mean, 0 * z_log_var))
-        else:
-            z_t = sample_z((z_mean, z_log_var))
-        zc = [w_t, z_t, x_prev_t] if use_x_prev else [w_t, z_t]
-        x_t = sample_x(dec_model.predict(zc))
-        Xs[t] = x_t
-        x_prev_t = x_prev          # the decoder's history lags the encoder input by one step
-        x_prev = x_t
-    return Xs
-
-
 def sample_x(x_mean):
-    return 1.0 * (np.random.rand(len(x_mean.squeeze())) <= x_mean)
+    """x ~ Bernoulli(x_mean) as 0./1. (reference :44-45: one uniform per entry of the squeezed vector)"""
+    return sampling.draw_frame(x_mean, flat=True)
 
 
 def sample_w(args, nsamps=1, nrm_samp=False, add_noise=True):
+    """Label sample from (w_mean, w_log_var) (reference :47-66)."""
     w_mean, w_log_var = args
-    if nsamps == 1:
-        eps = np.random.randn(*((1, w_mean.flatten().shape[0])))
-    else:
-        eps = np.random.randn(*((nsamps,) + w_mean.shape))
-    if eps.T.shape == w_mean.shape:
-        eps = eps.T
-    if add_noise:
-        w_norm = w_mean + np.exp(w_log_var / 2) * eps
-    else:
-        w_norm = w_mean + 0 * np.exp(w_log_var / 2) * eps
-    if nrm_samp:
-        return w_norm
-    if nsamps == 1:
-        w_norm = np.hstack([w_norm, np.zeros((w_norm.shape[0], 1))])
-        return np.exp(w_norm) / np.sum(np.exp(w_norm), axis=-1)[:, None]
-    w_norm = np.dstack([w_norm, np.zeros(w_norm.shape[:-1] + (1,))])
-    return np.exp(w_norm) / np.sum(np.exp(w_norm), axis=-1)[:, :, None]
+    return sampling.logistic_normal(w_mean, w_log_var, nsamps, normal_only=nrm_samp, add_noise=add_noise,
+                                    transpose_eps=True, mute_through_scale=True)
 
 
 def sample_z(args, nsamps=1):
-    Z_mean, Z_log_var = args
-    if nsamps == 1:
-        eps = np.random.randn(*Z_mean.squeeze().shape)
-    else:
-        eps = np.random.randn(*((nsamps,) + Z_mean.squeeze().shape))
-    return Z_mean + np.exp(Z_log_var / 2) * eps
+    """Latent sample from (z_mean, z_log_var) (reference :68-74)."""
+    return sampling.gaussian(args[0], args[1], nsamps)
+
+
+def generate_sample(dec_model, w_enc_model, z_enc_model, x_seed, nsteps, w_val=None, use_z_prior=False,
+                    do_reset=True, w_sample=False, use_x_prev=False):
+    """`nsteps` frames after the seed frame (reference :9-42): w once (given, or inferred from the seed), then per
+    frame z from the last frame and w, x ~ Bernoulli(decoder(w, z[, history])).  The decoder's history input lags the
+    encoder's input by one frame: at step t the encoder sees x_{t-1}, the decoder x_{t-2} (x_seed for both at t = 0)."""
+    loop = sampling.HostFrameLoop(dec_model, w_enc_model, z_enc_model, sample_x, sample_w, sample_z)
+    x_in = hist = x_seed[None, :]
+    w = w_val if w_val is not None else loop.label([x_in], add_noise=w_sample)
+    frames = np.zeros((nsteps, x_seed.shape[0]))
+    for t in range(nsteps):
+        z = loop.latent(x_in, w, from_prior=use_z_prior)
+        frames[t] = x_t = loop.frame([w, z, hist] if use_x_prev else [w, z])
+        hist, x_in = x_in, x_t
+    return frames
+
+
+def generate_samples_device(model, x_seeds, nsteps, w_vals, seed=0, use_z_prior=False):
+    """N sequences at once with the frame loop on the device (VaeEngine.generate: one captured hipGraph replayed per
+    frame, Philox noise instead of np.random: same distribution, different draws).  x_seeds [N,D], w_vals [N,C];
+    returns [N,nsteps,D] float64 like generate_sample does per sequence."""
+    e = model.engine
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32), device=e.device)
+    return e.generate(t(x_seeds), t(w_vals), int(nsteps), seed=int(seed), z_prior=use_z_prior).cpu().numpy() \
+        .astype(np.float64)
 
 
 # --------------------------------------------------------------------------- #

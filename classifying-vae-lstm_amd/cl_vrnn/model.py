@@ -15,6 +15,7 @@ import json
 import numpy as np
 import torch
 
+from .. import sampling
 from ..engine import VrnnEngine, vrnn_param_shapes
 from ..initializers import glorot_uniform, init_weights, orthogonal
 from ..keras_like import Layer, Model, get_value
@@ -22,79 +23,64 @@ from ..utils.pianoroll import Windows
 
 
 # --------------------------------------------------------------------------- #
-# numpy sampling helpers (host code in the reference as well)
+# host-side sampling (clvae_amd.sampling holds the shared pieces; these are cl_vrnn's bindings)
 # --------------------------------------------------------------------------- #
-def generate_sample(dec_model, w_enc_model, z_enc_model, x_seed, nsteps, use_x_prev, w_val=None, do_reset=True,
-                    seq_length=None, w_sample=False, w_discrete=False):
-    """Teacher-force the seed frames through the stateful models, then free-run `nsteps` frames."""
-    if do_reset:
-        dec_model.reset_states()
-        w_enc_model.reset_states()
-        z_enc_model.reset_states()
-    original_dim = x_seed.shape[-1]
-    nseedsteps = x_seed.shape[0] if len(x_seed.shape) > 1 else 0
-    Xs = np.zeros([nsteps + nseedsteps, original_dim])
-    if nseedsteps == 0:
-        x_prev = x_seed[None, None, :]
-    if w_val is None:
-        ntms = x_seed.shape[1]       # sic: the feature dim (reference :35, SURVEY.md 5.9 B5); short chunks are skipped
-        w_ts = []
-        for i in np.arange(0, ntms, seq_length):
-            xcs = x_seed[i:i + seq_length]
-            if xcs.shape[0] == seq_length:
-                w_ts.append(sample_w(w_enc_model.predict(xcs[None, :]), add_noise=w_sample))
-        w_t = np.vstack(w_ts).mean(axis=0)[None, :]
-        if w_discrete:
-            w_t = sample_w_discrete(w_t[0])[None, :]
-    else:
-        w_t = w_val
-    for t in range(nsteps + nseedsteps):
-        if t < nseedsteps:
-            x_prev = x_seed[t][None, None, :]
-        z_t = sample_z(z_enc_model.predict([x_prev, w_t]))
-        z_t = [z_t, x_prev, w_t] if use_x_prev else [z_t, w_t]
-        x_t = sample_x(dec_model.predict(z_t))
-        x_prev = x_t
-        Xs[t] = x_t
-    return Xs[nseedsteps:]
-
-
 def sample_x(x_mean):
-    return 1.0 * (np.random.rand(*x_mean.squeeze().shape) <= x_mean)
+    """x ~ Bernoulli(x_mean) as 0./1. (reference :62-63: uniforms shaped like the squeezed mean)"""
+    return sampling.draw_frame(x_mean, flat=False)
 
 
 def sample_w_discrete(w):
-    wn = np.zeros(w.shape)
-    wn[np.random.choice(len(w), p=w / w.sum())] = 1.
-    return wn
+    """A one-hot label drawn from the label vector w (reference :65-68)."""
+    return sampling.one_hot_draw(w)
 
 
 def sample_w(args, nsamps=1, nrm_samp=False, add_noise=True):
+    """Label sample from (w_mean, w_log_var) (reference :70-88)."""
     w_mean, w_log_var = args
-    if nsamps == 1:
-        eps = np.random.randn(*((1, w_mean.flatten().shape[0])))
-    else:
-        eps = np.random.randn(*((nsamps,) + w_mean.shape))
-    if add_noise:
-        w_norm = w_mean + np.exp(w_log_var / 2) * eps
-    else:
-        w_norm = w_mean + 0 * eps
-    if nrm_samp:
-        return w_norm
-    if nsamps == 1:
-        w_norm = np.hstack([w_norm, np.zeros((w_norm.shape[0], 1))])
-        return np.exp(w_norm) / np.sum(np.exp(w_norm), axis=-1)[:, None]
-    w_norm = np.dstack([w_norm, np.zeros(w_norm.shape[:-1] + (1,))])
-    return np.exp(w_norm) / np.sum(np.exp(w_norm), axis=-1)[:, :, None]
+    return sampling.logistic_normal(w_mean, w_log_var, nsamps, normal_only=nrm_samp, add_noise=add_noise)
 
 
 def sample_z(args, nsamps=1):
-    Z_mean, Z_log_var = args
-    if nsamps == 1:
-        eps = np.random.randn(*Z_mean.squeeze().shape)
-    else:
-        eps = np.random.randn(*((nsamps,) + Z_mean.squeeze().shape))
-    return Z_mean + np.exp(Z_log_var / 2) * eps
+    """Latent sample from (Z_mean, Z_log_var) (reference :90-96)."""
+    return sampling.gaussian(args[0], args[1], nsamps)
+
+
+def label_windows(x_seed, seq_length):
+    """The windows the label is inferred from: consecutive chunks of seq_length frames; an incomplete chunk is
+    skipped.  The reference walks the chunk starts up to x_seed.shape[1] -- the FEATURE dimension (:35, SURVEY.md 5.9
+    B5) --, so a seed shorter than 88 frames is covered entirely and the starts beyond its end give empty chunks."""
+    starts = range(0, x_seed.shape[1], seq_length)
+    return [x_seed[i:i + seq_length][None, :] for i in starts if len(x_seed[i:i + seq_length]) == seq_length]
+
+
+def infer_label(w_enc_model, x_seed, seq_length, add_noise=False, discrete=False):
+    """w [1,C]: the mean of the per-window label samples, optionally replaced by a one-hot draw from it."""
+    wins = label_windows(x_seed, seq_length)
+    if not wins:
+        raise ValueError("need at least one window of seq_length frames to infer w from")
+    w = np.vstack([sample_w(w_enc_model.predict(win), add_noise=add_noise) for win in wins]).mean(axis=0)[None, :]
+    return sample_w_discrete(w[0])[None, :] if discrete else w
+
+
+def generate_sample(dec_model, w_enc_model, z_enc_model, x_seed, nsteps, use_x_prev, w_val=None, do_reset=True,
+                    seq_length=None, w_sample=False, w_discrete=False):
+    """Continue a seed (reference :9-60): the stateful step models are teacher-forced through the seed frames
+    [S,D] (S = 0 for a single seed frame [D], which is then the first input), then run `nsteps` frames on their own
+    output; returns the free-running frames only."""
+    loop = sampling.HostFrameLoop(dec_model, w_enc_model, z_enc_model, sample_x, sample_w, sample_z)
+    if do_reset:
+        loop.reset()
+    n_seed = len(x_seed) if x_seed.ndim > 1 else 0
+    w = w_val if w_val is not None else infer_label(w_enc_model, x_seed, seq_length, w_sample, w_discrete)
+    x_in = None if n_seed else x_seed[None, None, :]
+    frames = np.zeros((n_seed + nsteps, x_seed.shape[-1]))
+    for t in range(n_seed + nsteps):
+        if t < n_seed:
+            x_in = x_seed[t][None, None, :]
+        z = loop.latent(x_in, w)
+        frames[t] = x_in = loop.frame([z, x_in, w] if use_x_prev else [z, w])
+    return frames[n_seed:]
 
 
 # --------------------------------------------------------------------------- #

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/clvae.h"
@@ -39,6 +40,16 @@ inline int launch_status() {
 }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// measurement knobs: `static const int x = env_int("NAME", dflt);` (a function-local static is initialised once, thread-safe)
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kernel` on the CURRENT device, set once per (device, kernel): safe
+// from several host threads and for a process that drives more than one GPU.  Returns a hipError_t / CLV_OK.
+int allow_dynamic_lds(const void* kernel, int bytes);
 
 // ---- device math ------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -722,16 +722,14 @@ static void launch_cfg(const GemmArgs& g_in, int ta, int tb, int splits, hipStre
   constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
   GemmArgs g = g_in;
   {
-    static int remap = -1;
-    if (remap < 0) { const char* e = getenv("CLV_GEMM_XCD_REMAP"); remap = e ? atoi(e) : 1; }
+    static const int remap = env_int("CLV_GEMM_XCD_REMAP", 1);
     g.xcd_remap = remap && splits > 1 && splits % 8 == 0;
     if (const char* e = getenv("CLV_GEMM_NOITER")) g.xcd_remap |= atoi(e);      // dev: 2 = no A iterator, 4 = no B iterator
   }
   dim3 grid(g.nprob > 0 ? g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BM - 1) / BM : (g.M + BM - 1) / BM,
             (g.N + BN - 1) / BN, splits);
   if (ta && !tb && g.nprob > 0 && BM >= 96 && BN == 96) {      // grouped weight gradients: optional deeper k-tile
-    static int bk32 = -1;
-    if (bk32 < 0) { const char* e = getenv("CLV_GEMM_BK32"); bk32 = e ? atoi(e) : 0; }
+    static const int bk32 = env_int("CLV_GEMM_BK32", 0);
     if (bk32) {
       hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, true, false, 32>), grid, dim3(256), 0, s, g);
       return;
@@ -974,13 +972,11 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
   splits = (K + kc - 1) / kc;
   g.k_chunk = kc;
   // in-workgroup split-K: 4 K sub-chunks per workgroup, one slab per workgroup (96 x 96 tiles, enough splits)
-  static int kg_on = -1;
-  if (kg_on < 0) { const char* e = getenv("CLV_GEMM_KG"); kg_on = e ? atoi(e) : 1; }
+  static const int kg_on = env_int("CLV_GEMM_KG", 1);
   const long wg_after = (long)tile * ((N + bn - 1) / bn) * (splits / 4);      // workgroups left if 4 chunks share one
   const bool kg4 = kg_on && bn == 96 && bm == 96 && splits >= 16 && splits % 4 == 0 && wg_after >= 256;
   // two tiles in flight per k-group where every tile of every chunk is a full interior tile on the incremental path
-  static int pf2_on = -1;
-  if (pf2_on < 0) { const char* e = getenv("CLV_GEMM_PF2"); pf2_on = e ? atoi(e) : 1; }
+  static const int pf2_on = env_int("CLV_GEMM_PF2", 1);
   bool pf2 = kg4 && pf2_on && kc % 16 == 0 && K == kc * splits && vec && g.vecB;
   for (int i = 0; i < nprob && pf2; ++i)
     pf2 = probs[i].ones == 0 && (probs[i].a_zero_period == 0 || probs[i].a_zero_period >= 16);
@@ -998,16 +994,9 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
       auto kern1 = gemm_f32_kernel<3, 3, 2, 2, true, false, 16, 4, 1>;
       auto kern2 = gemm_f32_kernel<3, 3, 2, 2, true, false, 16, 4, 2>;
       const size_t lds = 4 * (2 * 16 * (LdsStride<BMq>::value + LdsStride<BNq>::value)) * sizeof(float);
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-          e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-      }
-      static int remap = -1;
-      if (remap < 0) { const char* e = getenv("CLV_GEMM_XCD_REMAP"); remap = e ? atoi(e) : 1; }
+      if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern1), (int)lds)) return e;
+      if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern2), (int)lds)) return e;
+      static const int remap = env_int("CLV_GEMM_XCD_REMAP", 1);
       g.xcd_remap = remap && splits > 1 && splits % 8 == 0;
       dim3 grid(g.prob[g.nprob - 1].tile0 + (g.prob[g.nprob - 1].M + BMq - 1) / BMq, (g.N + BNq - 1) / BNq, splits);
       if (pf2) hipLaunchKernelGGL(kern2, grid, dim3(1024), lds, s, g);

@@ -379,8 +379,7 @@ extern "C" int clv_vrnn_generate(int N, int S, int nsteps, int D, int H, int L, 
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID, wide = L > GN_LMAX;
   void (*kern)(GenArgs) = hard ? (wide ? vrnn_generate_kernel<CLV_GATE_HARD_SIGMOID, true> : vrnn_generate_kernel<CLV_GATE_HARD_SIGMOID, false>)
                                : (wide ? vrnn_generate_kernel<CLV_GATE_SIGMOID, true> : vrnn_generate_kernel<CLV_GATE_SIGMOID, false>);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-  if (e != hipSuccess) return (int)e;
+  if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), 156 * 1024)) return e;
   ProfScope p("vrnn_generate", s);
   hipLaunchKernelGGL(kern, dim3(N), dim3(GN_NT), lds, s, a);
   return launch_status();

@@ -507,11 +507,7 @@ static int rows_per_wg(int B) {
   return 1;
 }
 static int lstm_ks() {
-  static int ks = 0;
-  if (!ks) {
-    const char* e = getenv("CLV_LSTM_KS");
-    ks = (e && atoi(e) == 8) ? 8 : 4;
-  }
+  static const int ks = env_int("CLV_LSTM_KS", 4) == 8 ? 8 : 4;
   return ks;
 }
 
@@ -521,12 +517,7 @@ static int launch_fwd_r(const LstmFwdArgs& a, hipStream_t s) {
   if (a.xin) {
     const size_t dyn = (size_t)a.nx * LG * sizeof(float) + 2 * R * XMAX * sizeof(XItem);
     auto kern = lstm_fwd_kernel<KS, R, GATE, SAVE, 0, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 4096)) return e;
     hipLaunchKernelGGL(kern, dim3(a.B / R), dim3(NT), dyn, s, a);
   } else {
     hipLaunchKernelGGL((lstm_fwd_kernel<KS, R, GATE, SAVE, 0, false>), dim3(a.B / R), dim3(NT), 0, s, a);

@@ -298,13 +298,7 @@ extern "C" int clv_out_head_train(int R, int H, int D, const float* hs, const fl
   if (!ws || ws_bytes < clv_out_head_train_workspace_bytes(R)) return CLV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)(OH * OH_LD + 2 * OH_NW * OH_TILE) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(out_head_train_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(out_head_train_kernel), (int)lds)) return e;
   const int wgs = out_head_wgs(R);
   OutHeadArgs a{R, ldy, scale, hs, Wo, bo, Y, logits, rownll, dlogits, dhs, (float*)ws};
   {

@@ -297,7 +297,7 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
 // row_elems): overlapping windows of a frame store are rows of stride one frame
 struct GatherSeg { const float* src; float* out; const int64_t* table; int64_t row_elems, out_ld, stride, offset;
                    int chunk, pieces, vec, u8; };
-struct GatherArgs { GatherSeg seg[3]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; };
+struct GatherArgs { GatherSeg seg[4]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; };
 // grid = (work items of a row / 256, rows, segments): no 64-bit divisions per element (they cost more than the copy)
 __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
   const int si = blockIdx.z;
@@ -472,7 +472,7 @@ extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t r
                                      const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
                                      const int64_t* src_stride, const int64_t* src_offset,
                                      const int64_t* const* src_table, void* stream) {
-  if (rows <= 0 || nseg < 1 || nseg > 3 || !src || !out || !row_elems || !chunk || !out_ld) return CLV_EINVAL;
+  if (rows <= 0 || nseg < 1 || nseg > 4 || !src || !out || !row_elems || !chunk || !out_ld) return CLV_EINVAL;
   GatherArgs a;
   memset(&a, 0, sizeof(a));
   a.nseg = nseg; a.rows = rows; a.idx = idx; a.row0 = row0;

@@ -7,7 +7,26 @@
 #include "common.h"
 #include "philox.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace clv {
+
+int allow_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kernel})) return CLV_OK;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.insert({dev, kernel});
+  return CLV_OK;
+}
+
 
 // ---------------------------------------------------------------- profiler --
 struct ProfState {

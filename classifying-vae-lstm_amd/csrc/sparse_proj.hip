@@ -274,13 +274,7 @@ static int sparse_proj_launch(int R, int N, int ldo, int nset, const clv::Sparse
     nxmax = p.nx > nxmax ? p.nx : nxmax;
   }
   if (R <= 0 || ldo < N) return CLV_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_proj_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(sparse_proj_kernel), 150 * 1024)) return e;
   SparseProjArgs a;
   memset(&a, 0, sizeof(a));
   a.R = R; a.N = N; a.ldo = ldo;
@@ -326,13 +320,7 @@ extern "C" int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, 
   if (((uintptr_t)G) % 8 != 0 || ldg % 2 != 0) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)(SO_BB * SO_XS + SO_BB * N) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_outer_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(sparse_outer_kernel), 150 * 1024)) return e;
   SparseOuterArgs a{Bn, nx, N, ldx, ldg, ldo, X, G, out, colsum};
   ProfScope p("sparse_outer", s);
   hipLaunchKernelGGL(sparse_outer_kernel, dim3((nx + SO_JT - 1) / SO_JT), dim3(1024), lds, s, a);

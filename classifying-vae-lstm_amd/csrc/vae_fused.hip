@@ -22,6 +22,7 @@ constexpr float VEPS_K = 1e-7f, VW2 = 1e-10f, VLOGIT_CLIP = 16.11809555f;
 struct VaeArgs {
   int B, D, H, Hc, C, L, use_xp;
   const float* x; const float* xp; const float* onehot;    // [B,D] [B,D] [B,C]
+  const float* y;                                          // [B,D] reconstruction target (NULL: x itself)
   const float* eps_w; const float* eps_z;                    // [B,C-1] [B,L]
   const float* P;                                            // flat parameters
   long o_hw_k, o_hw_b, o_wa_k, o_wa_b, o_h_k, o_h_b, o_za_k, o_za_b, o_d_k, o_d_b, o_x_k, o_x_b;
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
     for (int r = wave; r < RB; r += VNW) {
       float acc = 0.f;
       for (int j = lane; j < D; j += 64) {
-        const float av = LG[r * VLW + j], t = X[r * VLW + j];
+        const float av = LG[r * VLW + j];
+        const float t = a.y ? (r < nvalid ? a.y[(size_t)(row0 + r) * D + j] : 0.f) : X[r * VLW + j];
         if (r < nvalid && a.logits) a.logits[(size_t)(row0 + r) * D + j] = av;
         const float l = fminf(fmaxf(av, -VLOGIT_CLIP), VLOGIT_CLIP);
         const float e = __expf(-fabsf(l));
@@ -388,7 +390,7 @@ extern "C" size_t clv_vae_fused_workspace_bytes(int B, long n_params) {
 }
 
 extern "C" int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
-                                  const float* x, const float* xp, const float* onehot,
+                                  const float* x, const float* xp, const float* target, const float* onehot,
                                   const float* eps_w, const float* eps_z,
                                   const float* params, const int64_t* host_offsets12, long n_params,
                                   float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
@@ -404,7 +406,7 @@ extern "C" int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int
   const int nwg = (B + rb - 1) / rb;
   if (need_grads && (!ws || ws_bytes < (size_t)nwg * n_params * sizeof(float))) return CLV_EWORKSPACE;
   const int64_t* o = host_offsets12;
-  VaeArgs a{B, D, H, Hc, C, L, use_x_prev, x, xp, onehot, eps_w, eps_z, params,
+  VaeArgs a{B, D, H, Hc, C, L, use_x_prev, x, xp, onehot, target == x ? nullptr : target, eps_w, eps_z, params,
             (long)o[0], (long)o[1], (long)o[2], (long)o[3], (long)o[4], (long)o[5], (long)o[6], (long)o[7], (long)o[8],
             (long)o[9], (long)o[10], (long)o[11], prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads,
             (float*)ws, n_params, logits, w_out, wargs_out, zargs_out, rownll, rowkl, rowloss};
@@ -413,13 +415,11 @@ extern "C" int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int
     ProfScope p("vae_fused_step", s);
     if (rb == 16) {
       auto k = vae_fused_kernel<16>;
-      static bool set16 = false;
-      if (!set16) { CLV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vae_lds_bytes<16>())); set16 = true; }
+      if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(k), (int)vae_lds_bytes<16>())) return e;
       hipLaunchKernelGGL(k, dim3(nwg), dim3(VNT), vae_lds_bytes<16>(), s, a);
     } else {
       auto k = vae_fused_kernel<32>;
-      static bool set32 = false;
-      if (!set32) { CLV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vae_lds_bytes<32>())); set32 = true; }
+      if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(k), (int)vae_lds_bytes<32>())) return e;
       hipLaunchKernelGGL(k, dim3(nwg), dim3(VNT), vae_lds_bytes<32>(), s, a);
     }
   }

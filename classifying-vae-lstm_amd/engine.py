@@ -330,12 +330,54 @@ class VaeEngine(_EngineBase):
         ops.gauss_fwd(B, L, self.zargs, eps_z, self.z, L, self.rowkl)
         self.decode(self.w, self.z, xp)
 
-    def _fused_step(self, x, xp, w_true, eps_w, eps_z, need_grads):
+    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False):
+        """N independent sequences of `nsteps` frames on the device: the frame loop of cl_vae/model.py:28-41
+        (z-encoder on the last frame, z ~ N(mean, exp(lv)) or N(0, 1), decoder on (w, z, frame before last),
+        x ~ Bernoulli) captured once as a hipGraph and replayed per frame with no host synchronisation; eps and u come
+        from the Philox streams 0 / 1 at step = frame index.  x_seed [N,D], w [N,C] device tensors, N <= batch size."""
+        cfg, d = self.cfg, self.device
+        N, D, L = int(x_seed.shape[0]), cfg['D'], cfg['L']
+        if N > self.B:
+            raise ValueError("%d sequences exceed the engine's batch size %d" % (N, self.B))
+        f = dict(dtype=torch.float32, device=d)
+        x_in, hist, x_next = x_seed.to(**f).clone(), x_seed.to(**f).clone(), torch.zeros(N, D, **f)
+        eps, u = torch.zeros(N, L, **f), torch.zeros(N, D, **f)
+        counter = torch.zeros(1, dtype=torch.int32, device=d)
+        Xs = torch.zeros(N, nsteps, D, **f)
+        w = w.to(**f).contiguous()
+
+        def frame():
+            self.encode_z(x_in, w, N)
+            ops.philox_normal(eps, N * L, seed, 0, 0, 0, step_dev=counter)
+            if z_prior:
+                self.zargs[:N].zero_()
+            ops.gauss_fwd(N, L, self.zargs, eps, self.z, L, None)
+            self.decode(w, self.z, hist if cfg['use_x_prev'] else None, N, act=ACT_SIGMOID)
+            ops.philox_uniform(u, N * D, seed, 0, 1, 0, step_dev=counter)
+            ops.bernoulli_sample(N * D, self.logits, u, x_next)
+            ops.i32_add(counter, 1)
+            hist.copy_(x_in)            # the decoder's history lags the encoder input by one frame
+            x_in.copy_(x_next)
+
+        graph = None
+        for t in range(nsteps):
+            if use_graph and t == 1:
+                with ops.Graph() as graph:       # frame 0 ran eagerly and sized every workspace
+                    frame()
+            if graph is not None:
+                graph.launch()
+            else:
+                frame()
+            Xs[:, t].copy_(x_next)
+        return Xs
+
+    def _fused_step(self, x, xp, w_true, eps_w, eps_z, need_grads, target=None):
         """The whole step as ONE kernel (csrc/vae_fused.hip) + the slab sum + the loss means."""
         cfg, P, B = self.cfg, self.P, self.B
         p_ = ops._ptr
         _lib.check(_lib.lib().clv_vae_fused_step(
-            B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), p_(x), p_(xp), p_(w_true),
+            B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), p_(x), p_(xp), p_(target),
+            p_(w_true),
             p_(eps_w), p_(eps_z), p_(P.params), self._offs, P.n, float(cfg['w_log_var_prior']), self.class_weight,
             self.kl_weight, self.w_kl_weight, int(need_grads), p_(P.grads), p_(self._fused_ws), self._fused_ws.numel(),
             p_(self.logits), p_(self.w), p_(self.wargs), p_(self.zargs), p_(self.rownll), p_(self.rowkl),
@@ -343,16 +385,18 @@ class VaeEngine(_EngineBase):
         ops.loss_sums([(self.rownll, B, 1), (self.rowkl, B, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
                        (self.rowloss[:, 2:], B, 3)], self.scal)
 
-    def loss_and_grads(self, x, xp, w_true, eps_w, eps_z, need_grads=True):
-        """One forward + 4 losses (+ gradients of the weighted total into P.grads)."""
+    def loss_and_grads(self, x, xp, w_true, eps_w, eps_z, need_grads=True, target=None):
+        """One forward + 4 losses (+ gradients of the weighted total into P.grads).  target: what the decoder output is
+        scored against (default x; the next frame under --predict_next)."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, Hc, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
         C1 = Cn - 1
         inv = 1.0 / B
         if self.fused and w_true is not None:
-            return self._fused_step(x, xp, w_true, eps_w, eps_z, need_grads)
+            return self._fused_step(x, xp, w_true, eps_w, eps_z, need_grads, target)
         self.forward(x, xp, eps_w, eps_z, w_true)
-        ops.bernoulli_nll(B, D, self.logits, x, D, inv, self.rownll, self.dlogits if need_grads else None)
+        ops.bernoulli_nll(B, D, self.logits, x if target is None else target, D, inv, self.rownll,
+                          self.dlogits if need_grads else None)
         ops.loss_sums([(self.rownll, B, 1), (self.rowkl, B, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
                        (self.rowloss[:, 2:], B, 3)], self.scal)
         if not need_grads:
@@ -450,8 +494,10 @@ class VrnnEngine(_EngineBase):
         self.dwargs = _f(d, B, 2 * (Cn - 1))
         self.dhW = _f(d, B, D)
 
-    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None):
-        """nll = (scale, need_grads): fuse the Bernoulli NLL of the output head into its GEMM (targets = X)."""
+    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None, target=None):
+        """nll = (scale, need_grads): fuse the Bernoulli NLL of the output head into its GEMM; target = the frames the
+        output is scored against (default X)."""
+        target = X if target is None else target
         cfg, P, B = self.cfg, self.P, self.B
         self._nll_done = False
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
@@ -460,7 +506,7 @@ class VrnnEngine(_EngineBase):
         if cfg['use_x_prev'] and Xp.data_ptr() != self.XZ.data_ptr():
             self.XZ.view(B, T, self.xz_ld)[:, :, :D].copy_(Xp.view(B, T, D))     # staging copy only
         if self.fuse_pair:
-            return self._forward_pair(X, eps_W, eps_Z, w_true, nll)
+            return self._forward_pair(X, eps_W, eps_Z, w_true, nll, target)
         fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
         fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)
         if not fuse_enc:
@@ -493,7 +539,7 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
                              self.cs_dec, self.gates_dec, gate_act=self.gate_act)
         # output head (:229-234), with the NLL fused into its epilogue when the caller wants the loss
-        self._output_head(X, nll)
+        self._output_head(target, nll)
 
     def _label_forward(self, X, eps_W, w_true):
         """Label path (:174-191): hW Dense layer over the flattened window, Wargs head, logistic-normal sample, label
@@ -512,6 +558,7 @@ class VrnnEngine(_EngineBase):
             ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, *tail)
 
     def _output_head(self, X, nll):
+        """X: the frames the output is scored against"""
         cfg, P = self.cfg, self.P
         D, H, BT = cfg['D'], cfg['H'], self.B * cfg['T']
         self._head_done = False
@@ -532,7 +579,7 @@ class VrnnEngine(_EngineBase):
             ops.gemm(self.hs_dec, P.p('X_decoded_mean/kernel'), self.logits, BT, D, H, bias=P.p('X_decoded_mean/bias'),
                      ws=self.ws)
 
-    def _forward_pair(self, X, eps_W, eps_Z, w_true, nll=None):
+    def _forward_pair(self, X, eps_W, eps_Z, w_true, nll=None, target=None):
         """Forward with both LSTMs, the latent head and the z projection in one persistent kernel."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
@@ -555,7 +602,7 @@ class VrnnEngine(_EngineBase):
         ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, self.gates_dec, off > 0, self.wk_dec, self.pair_pack,
                           P.p('Zargs/bias'), eps_Z, self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z,
                           self.xz_ld, self.klterm, gate_act=self.gate_act)
-        self._output_head(X, nll)
+        self._output_head(X if target is None else target, nll)
 
     def xp_view(self):
         """[B,T,D] strided view of the history columns of the [Xp | Z] buffer (stage batches straight into it)."""
@@ -735,15 +782,17 @@ class VrnnEngine(_EngineBase):
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                          self.dzsum_enc, gate_act=self.gate_act)
 
-    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True):
+    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True, target=None):
+        """target: the frames the decoder output is scored against (default X; the next frames under --predict_next)."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         inv_bt, inv_b = 1.0 / BT, 1.0 / B
         g, ws, off = ops.gemm, self.ws, self.off
-        self.forward(X, Xp, eps_W, eps_Z, w_true, nll=(inv_bt, need_grads))
+        self.forward(X, Xp, eps_W, eps_Z, w_true, nll=(inv_bt, need_grads), target=target)
         if not self._nll_done:
-            ops.bernoulli_nll(BT, D, self.logits, X, D, inv_bt, self.rownll, self.dlogits if need_grads else None)
+            ops.bernoulli_nll(BT, D, self.logits, X if target is None else target, D, inv_bt, self.rownll,
+                              self.dlogits if need_grads else None)
         kl = (self.klterm, BT * L, 1) if self.fuse_pair else (self.rowkl, BT, 1)
         ops.loss_sums([(self.rownll, BT, 1), kl, (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
                        (self.rowloss[:, 2:], B, 3)], self.scal)

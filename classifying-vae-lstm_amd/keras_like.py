@@ -249,18 +249,23 @@ class Model:
             raise ValueError("model was built with batch_size %d per process x %d processes, got batch_size %d"
                              % (B, world, int(batch_size)))
         cur, hist, w_true = self._split_inputs(x, y)
+        tgt = self._target_of(cur, y)
         n = cur.shape[0]
         if n % GB:
             raise ValueError("number of samples %d is not a multiple of the global batch %d" % (n, GB))
         dev = eng.device
         d_cur, d_hist = self._data_to_dev(cur, hist, dev)
         d_w = _to_dev(w_true, dev)
+        d_tgt = None if tgt is None else self._data_to_dev(tgt, None, dev)[0]
         val = None
         if validation_data is not None:
             vc, vh, vw = self._split_inputs(validation_data[0], validation_data[1])
             if vc.shape[0] % B:
                 raise ValueError("validation samples %d not a multiple of batch_size %d" % (vc.shape[0], B))
-            val = self._data_to_dev(vc, vh, dev) + (_to_dev(vw, dev),)
+            vt = self._target_of(vc, validation_data[1])
+            if (vt is None) != (tgt is None):
+                raise ValueError("training and validation targets must both be the inputs or both be separate frames")
+            val = self._data_to_dev(vc, vh, dev) + (_to_dev(vw, dev), None if vt is None else self._data_to_dev(vt, None, dev)[0])
         if world > 1:           # replicas start from rank 0's weights, optimizer state and noise key
             for t in eng.P.state_tensors():     # incl. the weight-norm column state and `iterations` (resumed fits)
                 dist.broadcast(t, src=0)
@@ -289,7 +294,7 @@ class Model:
                 dist.broadcast(idx_dev, src=0)                  # every rank walks rank 0's permutation
             self._acc.zero_()
             for b0 in range(0, n, GB):
-                ts.gather_batch(d_cur, d_hist, d_w, idx_dev[b0 + rank * B:b0 + (rank + 1) * B])
+                ts.gather_batch(d_cur, d_hist, d_w, idx_dev[b0 + rank * B:b0 + (rank + 1) * B], d_target=d_tgt)
                 ts.step()
                 ops.axpy(5, 1.0, eng.scal, self._acc)
             if world > 1:
@@ -316,7 +321,23 @@ class Model:
             return _windows_to_dev(cur, hist, dev)
         return (_frames_to_dev(np.asarray(cur), dev), None if hist is None else _frames_to_dev(np.asarray(hist), dev))
 
-    def evaluate_device(self, d_cur, d_hist, d_w, prefix=''):
+    @staticmethod
+    def _target_of(cur, y):
+        """The frames the decoder output is scored against when they are NOT the input frames themselves (the scripts
+        pass [recon_target, w, w, recon_target]; with --predict_next recon_target is the next frame, cl_vae/train.py:15,66
+        and cl_vrnn/train.py:15,66), else None."""
+        t = y[0] if isinstance(y, (list, tuple)) else None
+        if t is None or t is cur:
+            return None
+        from .utils.pianoroll import Windows
+        if isinstance(t, Windows) or isinstance(cur, Windows):
+            same = isinstance(t, Windows) and isinstance(cur, Windows) and t.same_frames(cur)
+        else:
+            t = np.asarray(t)
+            same = t.shape == np.asarray(cur).shape and (np.shares_memory(t, cur) or np.array_equal(t, cur))
+        return None if same else t
+
+    def evaluate_device(self, d_cur, d_hist, d_w, d_target=None, prefix=''):
         """Validation pass: forward + losses with the sampling noise ON (Lambda layers have no test switch,
         SURVEY.md 5.9 B10), batch-size chunks, no parameter update.  Under torch.distributed the chunks are dealt
         round-robin to the ranks and the sums are all-reduced."""
@@ -329,9 +350,9 @@ class Model:
         for j, b0 in enumerate(range(0, n, B)):
             if j % world != rank:
                 continue
-            ts.gather_batch(d_cur, d_hist, d_w, None, row0=b0)
+            ts.gather_batch(d_cur, d_hist, d_w, None, row0=b0, d_target=d_target)
             ts.draw_noise(stream_offset=2 + b0 // B, row0=0)     # a validation chunk is a whole batch of its own
-            eng.loss_and_grads(ts.X, ts.Xp, ts.w_true, ts.eps_w, ts.eps_z, need_grads=False)
+            eng.loss_and_grads(ts.X, ts.Xp, ts.w_true, ts.eps_w, ts.eps_z, need_grads=False, target=ts.Y)
             ops.axpy(5, 1.0, eng.scal, acc)
         if world > 1:
             dist.all_reduce(acc)

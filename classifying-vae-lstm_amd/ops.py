@@ -331,7 +331,7 @@ def gather_rows(rows, row_elems, src, idx, out, chunk=0, out_ld=0):
 
 
 def gather_rows_multi(rows, idx, segs, row0=0):
-    """segs: up to 3 (src, out, row_elems, chunk, out_ld[, stride, offset, table]); one launch; idx None = rows
+    """segs: up to 4 (src, out, row_elems, chunk, out_ld[, stride, offset, table]); one launch; idx None = rows
     row0..row0+rows-1.  A uint8 src (binary frames kept as bytes) is converted to float on the way.  With (stride,
     offset, table) source row r starts at element table[idx[r]] * stride + offset: windows of a frame store."""
     n = len(segs)

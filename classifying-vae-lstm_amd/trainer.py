@@ -51,6 +51,7 @@ class TrainStep:
             self.xp_ld = engine.xz_ld
         else:
             self.Xp = torch.zeros(*shp, **f)
+        self.Y = None        # reconstruction target when it is not the input itself (--predict_next): see set_target()
         self.w_true = torch.zeros(B, cfg['C'], **f)
         self.eps_w = torch.zeros(B, C1, **f)
         self.eps_z = torch.zeros(B * T, L, **f)
@@ -83,12 +84,19 @@ class TrainStep:
                            self.eps_z, B * T * L, 2 * stream_offset + 1, eps_first_index(row0, T * L),
                            self.seed, 0, step_dev=it)
 
+    def set_target(self, on):
+        """on: the decoder output is scored against a separate target batch (staged next to the inputs) instead of the
+        input frames.  Changes what the captured step reads, so the graphs are dropped."""
+        if bool(on) != (self.Y is not None):
+            self.Y = torch.zeros_like(self.X) if on else None
+            self.recapture()
+
     def _main(self):
         self.draw_noise()
         if self.is_vrnn:
-            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, do_tail=False)
+            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, do_tail=False, target=self.Y)
         else:
-            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z)
+            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y)
 
     def _tail(self):
         if self.is_vrnn:
@@ -106,9 +114,10 @@ class TrainStep:
         self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm, only=self.rest_names)
 
     # -- public -----------------------------------------------------------
-    def _segments(self, cur, hist, w):
-        """(src, out, row_elems, chunk, out_ld[, stride, offset, table]) of the current frames, history frames and labels
-        of a batch.  cur / hist are device tensors of whole rows or DevWindows (windows of a frame store)."""
+    def _segments(self, cur, hist, w, target=None):
+        """(src, out, row_elems, chunk, out_ld[, stride, offset, table]) of the current frames, history frames, labels and
+        (optional) target frames of a batch.  cur / hist / target are device tensors of whole rows or DevWindows (windows
+        of a frame store)."""
         row, D = int(self.X[0].numel()), self.eng.cfg['D']
 
         def src(x):
@@ -122,16 +131,21 @@ class TrainStep:
             else:
                 segs.append((h, self.Xp, row, 0, 0) + hx)
         segs.append((w, self.w_true, int(self.w_true.shape[1]), 0, 0))
+        if target is not None:
+            t, tx = src(target)
+            segs.append((t, self.Y, row, 0, 0) + tx)
         return segs
 
-    def stage_batch(self, X, Xp, w_true):
+    def stage_batch(self, X, Xp, w_true, target=None):
         """Copy one batch (contiguous device tensors) into the fixed staging buffers: one launch."""
-        ops.gather_rows_multi(self.eng.B, None, self._segments(X, Xp, w_true))
+        self.set_target(target is not None)
+        ops.gather_rows_multi(self.eng.B, None, self._segments(X, Xp, w_true, target))
 
-    def gather_batch(self, d_cur, d_hist, d_w, ib, row0=0):
+    def gather_batch(self, d_cur, d_hist, d_w, ib, row0=0, d_target=None):
         """Assemble the batch rows `ib` (device int64 indices; None = rows row0..row0+B-1) from the HBM-resident
         data set (frames float32 or uint8): one launch."""
-        ops.gather_rows_multi(self.eng.B, ib, self._segments(d_cur, d_hist, d_w), row0=row0)
+        self.set_target(d_target is not None)
+        ops.gather_rows_multi(self.eng.B, ib, self._segments(d_cur, d_hist, d_w, d_target), row0=row0)
 
     def _eager(self):
         self._main()

@@ -31,18 +31,12 @@ def write_varlen(value):
 
 
 class MidiWriter(object):
+    """Piano-roll -> SMF bytes.  Events are (delta ticks, status byte, data bytes) triples."""
+
     def __init__(self, verbose=False, default_vel=100):
         self.verbose = verbose
         self.note_range = RANGE
         self.default_velocity = default_vel
-
-    def note_off(self, val, tick):
-        self.track.append((tick, 0x80, (val, 0)))
-        return 0
-
-    def note_on(self, val, tick):
-        self.track.append((tick, 0x90, (val, self.default_velocity)))
-        return 0
 
     @staticmethod
     def _encode_track(events, end_of_track):
@@ -61,34 +55,39 @@ class MidiWriter(object):
             buf += b'\x00\xFF\x2F\x00'
         return b'MTrk' + struct.pack('>I', len(buf)) + bytes(buf)
 
+    def note_events(self, roll, time_step, offset):
+        """The note track of a [frames, notes] roll as the difference of consecutive frames: what stopped sounding is
+        released (ascending pitch), then what started is struck (ascending pitch); after the last frame everything
+        still sounding is released.  The ticks since the previous event ride on a frame's FIRST event, the others of
+        the frame follow at delta 0; a frame without changes only lets the ticks accumulate."""
+        sounding = np.asarray(roll) != 0
+        silent = np.zeros((1, sounding.shape[1]), dtype=bool)
+        before = np.vstack([silent, sounding])           # frame f-1 (nothing before the first; all released at the end)
+        after = np.vstack([sounding, silent])
+        events, pending = [], 0
+        for prev, cur in zip(before, after):
+            pending += time_step
+            released = np.flatnonzero(prev & ~cur) + offset
+            struck = np.flatnonzero(cur & ~prev) + offset
+            for status, pitches, vel in ((0x80, released, 0), (0x90, struck, self.default_velocity)):
+                for pitch in pitches.tolist():
+                    events.append((pending, status, (pitch, vel)))
+                    pending = 0
+        return events
+
     def dump_sequence_to_midi(self, seq, output_filename, time_step=120, resolution=480, metronome=24, offset=21,
                               format='final', end_of_track=False):
+        """format 'final': [frames, notes] 0/1 roll; 'icml': a list of note lists per frame; 'flat': one long vector."""
         if format == 'icml':
-            sequence = np.array([[1 if i in tm else 0 for i in range(self.note_range)] for tm in seq])
+            roll = np.zeros((len(seq), self.note_range))
+            for f, notes in enumerate(seq):
+                roll[f, [n for n in notes if 0 <= n < self.note_range]] = 1
         elif format == 'flat':
-            sequence = np.reshape(seq, [-1, self.note_range])
+            roll = np.reshape(seq, [-1, self.note_range])
         else:
-            sequence = np.asarray(seq)
-        self.track = []
-        meta_track = [(0, 0xFF, (0x58, 4, 2, metronome, 8))]
-        tick = time_step
-        self.notes_on = {n: False for n in range(self.note_range)}
-        for seq_idx in range(sequence.shape[0]):
-            notes = [n + offset for n in np.nonzero(sequence[seq_idx, :])[0].tolist()]
-            for n in self.notes_on:
-                if self.notes_on[n] and n not in notes:
-                    tick = self.note_off(n, tick)
-                    self.notes_on[n] = False
-            for note in notes:
-                if not self.notes_on[note]:
-                    tick = self.note_on(note, tick)
-                    self.notes_on[note] = True
-            tick += time_step
-        for n in self.notes_on:
-            if self.notes_on[n]:
-                self.note_off(n, tick)
-                tick = 0
-                self.notes_on[n] = False
+            roll = np.asarray(seq)
+        self.track = self.note_events(roll, time_step, offset)
+        meta_track = [(0, 0xFF, (0x58, 4, 2, metronome, 8))]          # 4/4, `metronome` clocks per click, 8 32nds
         data = (b'MThd' + struct.pack('>IHHH', 6, 1, 2, resolution) + self._encode_track(meta_track, end_of_track)
                 + self._encode_track(self.track, end_of_track))
         with open(output_filename, 'wb') as f:

@@ -92,6 +92,11 @@ class Windows:
     def squeeze(self):
         return np.asarray(self).squeeze() if 1 in self.shape else self
 
+    def same_frames(self, other):
+        """True when `other` shows exactly the same frames (same store, offsets and length)."""
+        return (self.store is other.store and self.t0 == other.t0 and self.length == other.length
+                and np.array_equal(self.starts, other.starts))
+
 
 def _load_pickle(path):
     with open(path, 'rb') as f:

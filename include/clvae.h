@@ -232,11 +232,12 @@ int clv_label_bwd(int B, int C, const float* mean, const float* logvar, int ld_i
  * w_mean|w_log_var and z_mean|z_log_var); host_offsets12 = element offsets of
  * {h_w, wargs, h, zargs, decoder_h, x_decoded_mean} x {kernel, bias}.  Activations live in LDS, weights
  * stream from L2 into MFMA operands.  Limits: D, H, Hc <= 96; C, L <= 16 (clv_vae_fused_supported).
- * ws >= clv_vae_fused_workspace_bytes(B, n_params).  logits may be NULL. */
+ * ws >= clv_vae_fused_workspace_bytes(B, n_params).  logits may be NULL.  target [B,D] is what the decoder output is
+ * scored against: NULL or x for the auto-encoder, the next frame under --predict_next (cl_vae/train.py:15,66). */
 int clv_vae_fused_supported(int D, int H, int Hc, int C, int L);
 size_t clv_vae_fused_workspace_bytes(int B, long n_params);
 int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
-                       const float* x, const float* xp, const float* onehot,
+                       const float* x, const float* xp, const float* target, const float* onehot,
                        const float* eps_w, const float* eps_z,
                        const float* params, const int64_t* host_offsets12, long n_params,
                        float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
@@ -335,8 +336,8 @@ int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float
  * out + (r*pieces + j)*out_ld.  chunk <= 0 means one contiguous piece (out_ld = row_elems). */
 int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int64_t* idx, float* out,
                     int64_t chunk, int64_t out_ld, void* stream);
-/* Up to 3 such gathers that share one row list in a single launch (current frames, history frames and labels
- * of a mini-batch).  idx == NULL takes the consecutive rows row0 .. row0+rows-1 (staging a contiguous batch).
+/* Up to 4 such gathers that share one row list in a single launch (current frames, history frames, labels and --
+ * under --predict_next -- target frames of a mini-batch).  idx == NULL takes the consecutive rows row0 .. row0+rows-1 (staging a contiguous batch).
  * Per segment k: src[k] rows of row_elems[k] elements, written like clv_gather_rows with chunk[k] / out_ld[k].
  * Source row r of segment k starts at element t * src_stride[k] + src_offset[k], t = src_table[k] ? src_table[k][i] : i,
  * i = idx ? idx[r] : row0 + r (src_stride / src_offset / src_table may be NULL: stride = row_elems[k], offset 0, no table).

@@ -201,12 +201,14 @@ def vae_forward(p, cfg, x, xp, eps_w, eps_z):
     return c
 
 
-def vae_loss_and_grads(p, cfg, x, xp, w_true, eps_w, eps_z, need_grads=True):
+def vae_loss_and_grads(p, cfg, x, xp, w_true, eps_w, eps_z, need_grads=True, target=None):
     """Forward + the four losses (:190-219) + analytic gradients of the weighted total."""
     B = x.shape[0]
     D, L, C = cfg['D'], cfg['L'], cfg['C']
     c = vae_forward(p, cfg, x, xp, eps_w, eps_z)
-    vae_b, dlogits = bce_from_logits_keras(c['logits'], x)
+    # the decoder output is scored against y[0] of fit(): x itself, or the next frame under --predict_next
+    # (cl_vae/train.py:15,66: PianoData(return_y_next=...) and [P.y_train, wtr, wtr, P.y_train])
+    vae_b, dlogits = bce_from_logits_keras(c['logits'], x if target is None else target)
     klz_b, dzm_kl, dzlv_kl = kl_gauss(c['z_mean'], c['z_log_var'])
     wrec_b, dw_rec = cce_keras(c['w'], w_true, C - 1)
     klw_b, dwm_kl, dwlv_kl = kl_w_prior(c['w_mean'], c['w_log_var'], cfg['w_log_var_prior'])
@@ -395,11 +397,12 @@ def vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z):
     return c
 
 
-def vrnn_loss_and_grads(p, cfg, X, Xp, w_true, eps_W, eps_Z, need_grads=True):
+def vrnn_loss_and_grads(p, cfg, X, Xp, w_true, eps_W, eps_Z, need_grads=True, target=None):
     B, T, D = X.shape
     C, L, H = cfg['C'], cfg['L'], cfg['H']
     c = vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z)
-    vae_bt, dlogits = bce_from_logits_keras(c['logits'], X)                # [B,T]
+    # scored against y[0] of fit() (cl_vrnn/train.py:15,59-66): X, or the next frames under --predict_next
+    vae_bt, dlogits = bce_from_logits_keras(c['logits'], X if target is None else target)                # [B,T]
     klz_bt, dzm_kl, dzlv_kl = kl_gauss(c['Z_mean'], c['Z_log_var'])
     wrec_b, dw_rec = cce_keras(c['W'], w_true, C - 1)
     klw_b, dwm_kl, dwlv_kl = kl_w_prior(c['W_mean'], c['W_log_var'], cfg['w_log_var_prior'])

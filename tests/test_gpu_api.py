@@ -431,6 +431,99 @@ def test_two_rank_dp_step_matches_single_process(dev, tmp_path, mode):
         np.testing.assert_allclose(w0[k], ref[k], rtol=2e-3, atol=2e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("which,extra", [('cl_vae', ['--use_x_prev', '--latent_dim', '4', '--batch_size', '40']),
+                                         ('cl_vrnn', ['--use_x_prev', '--seq_length', '8', '--batch_size', '20'])])
+def test_train_clis_under_two_ranks(dev, tmp_path, which, extra):
+    """Both train CLIs through Model.fit under a 2-rank process group (--batch_size stays the GLOBAL batch, the model is
+    built for half of it): the ranks end with identical weights, equal (up to summation order) to the one-process run
+    of the same command line."""
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    data = make_synthetic_pickle(str(tmp_path / "syn.pickle"), n_songs=(10, 4, 4), seed=1)
+    argv = ['r', '--num_epochs', '2', '--patience', '0', '--train_file', data] + extra
+
+    def run(world, tag):
+        mdir = str(tmp_path / ("models_" + tag))
+        os.makedirs(mdir)
+        out = str(tmp_path / (tag + "_w%d.npz"))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(here, "dp_cli_worker.py"), which, out]
+                                          + argv + ['--model_dir', mdir], env=env))
+        for pr in procs:
+            assert pr.wait(timeout=600) == 0
+        assert os.path.exists(os.path.join(mdir, 'r.h5')) and os.path.exists(os.path.join(mdir, 'r.json'))
+        return [np.load(out % r) for r in range(world)], [eval(open((out % r) + '.loss').read()) for r in range(world)]
+
+    (w0, w1), (l0, l1) = run(2, "dp")
+    for k in w0.files:
+        np.testing.assert_array_equal(w0[k], w1[k], err_msg=k)
+    assert l0 == l1 and l0[-1] < l0[0]
+    (ws,), (ls,) = run(1, "single")
+    np.testing.assert_allclose(l0, ls, rtol=1e-4)
+    for k in ws.files:
+        np.testing.assert_allclose(w0[k], ws[k], rtol=5e-3, atol=5e-5, err_msg=k)
+
+
+def test_cl_vae_device_generation_matches_stepwise_oracle(dev):
+    """cl_vae.generate_samples_device (the frame loop as hipGraph replays, Philox noise) vs an oracle loop that redraws
+    the same Philox numbers on the host: encoder input x_{t-1}, decoder history x_{t-2} (cl_vae/model.py:28-41)."""
+    from clvae_amd.cl_vae.model import generate_samples_device, get_model
+    L, C, N, nsteps = 3, 4, 6, 7
+    model, _ = get_model(8, 88, (88, L), (88, C), 'adam', use_x_prev=True, seed=2)
+    p = {k: f32(v) for k, v in model.engine.P.get_weights().items()}
+    rng = np.random.default_rng(8)
+    seeds = (rng.random((N, 88)) < 0.06).astype(np.float64)
+    w = np.eye(C)[rng.integers(0, C, N)]
+    for z_prior in (False, True):
+        out = generate_samples_device(model, seeds, nsteps, w, seed=17, use_z_prior=z_prior)
+        assert out.shape == (N, nsteps, 88) and set(np.unique(out)) <= {0.0, 1.0}
+        x_in, hist, flips = seeds, seeds, 0
+        for t in range(nsteps):
+            h = O.relu(np.concatenate([x_in, w], 1) @ p['h/kernel'] + p['h/bias'])
+            zm, zlv = h @ p['z_mean/kernel'] + p['z_mean/bias'], h @ p['z_log_var/kernel'] + p['z_log_var/bias']
+            if z_prior:
+                zm, zlv = 0 * zm, 0 * zlv
+            eps = OP.normal(N * L, 17, step=t, stream_id=0).reshape(N, L).astype(np.float64)
+            z = zm + np.exp(zlv / 2) * eps
+            hd = O.relu(np.concatenate([w, hist, z], 1) @ p['decoder_h/kernel'] + p['decoder_h/bias'])
+            xhat = O.sigmoid(hd @ p['x_decoded_mean/kernel'] + p['x_decoded_mean/bias'])
+            uu = OP.uniform(N * 88, 17, step=t, stream_id=1).reshape(N, 88).astype(np.float64)
+            x_t, got = (uu <= xhat).astype(np.float64), out[:, t]
+            close = np.abs(uu - xhat) < 1e-5         # a draw within fp32 noise of its probability may flip
+            assert np.all((got == x_t) | close), (t, np.argwhere((got != x_t) & ~close)[:3])
+            flips += int((got != x_t).sum())
+            hist, x_in = x_in, got
+        assert flips <= 2
+
+
+def test_fit_with_predict_next_targets(dev):
+    """Model.fit with targets [next frames, w, w, next frames] (what train.py passes under --predict_next) pulls the
+    decoder towards the NEXT frames, not towards its input."""
+    from clvae_amd.cl_vae.model import get_model
+    B, L, C = 20, 2, 3
+    rng = np.random.default_rng(3)
+    x = (rng.random((B, 88)) < 0.2).astype(np.float64)
+    y = (rng.random((B, 88)) < 0.2).astype(np.float64)
+    wt = np.eye(C)[rng.integers(0, C, B)]
+    model, _ = get_model(B, 88, (88, L), (88, C), 'adam-wn', seed=4)
+    np.random.seed(0)
+    h = model.fit(x, [y, wt, wt, y], shuffle=False, epochs=200, batch_size=B, verbose=0,
+                  validation_data=(x, [y, wt, wt, y]))
+    rec = h.history['x_decoded_mean_loss']
+    assert rec[-1] < 0.6 * rec[0] and h.history['val_x_decoded_mean_loss'][-1] < 0.7 * rec[0]
+    xhat = model.predict(x)[0]
+    hit_next, hit_input = np.mean((xhat > 0.5) == (y > 0.5)), np.mean((xhat > 0.5) == (x > 0.5))
+    assert hit_next > 0.9 and hit_next > hit_input + 0.1
+
+
 # ------------------------------------------------------------------ 8f4: fit() from a frame store
 def test_fit_from_lazy_windows_equals_fit_from_arrays(dev, tmp_path):
     """Model.fit on PianoData(lazy=True) views (one uint8 frame store on the device, windows gathered by start offset)

@@ -154,6 +154,76 @@ def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate, pair):
         np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("B,Tn,L", [(256, 128, 2),         # BASELINE config 3 (and 4 per GPU): what bench.py times
+                                    (1024, 256, 32)])      # config 5 per GPU
+def test_cl_vrnn_full_size_step_matches_oracle(dev, B, Tn, L):
+    """One step at the sizes the benchmark runs, against the fp64 oracle on the same weights, frames and noise: ELBO
+    and every loss term to 1e-3, per-note logits, both LSTMs' states, every gradient tensor."""
+    from clvae_amd.engine import VrnnEngine
+    Cn = 10
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(B + Tn)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=3).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    eW, eZ = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, Tn, L)))
+    ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
+    eng = VrnnEngine(cfg, B, dev)
+    assert eng.fuse_pair == (L <= 8)
+    eng.P.set_weights(p)
+    eng.loss_and_grads(T(X, dev), T(Xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev))
+    torch.cuda.synchronize()
+    got = eng.losses()
+    logit_err = np.abs(N(eng.logits).reshape(B, Tn, 88) - ref['cache']['logits']).max()
+    print("cl_vrnn FULL SIZE B=%d T=%d L=%d: ELBO gpu %.6f oracle %.6f |d|=%.2e  logits max-abs err %.2e"
+          % (B, Tn, L, got['elbo'], ref['elbo'], abs(got['elbo'] - ref['elbo']), logit_err))
+    assert abs(got['elbo'] - ref['elbo']) <= ELBO_TOL
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, k
+    assert logit_err < LOGIT_TOL
+    np.testing.assert_allclose(N(eng.hs_enc).reshape(B, Tn, 88), ref['cache']['enc_h'], atol=5e-5)
+    np.testing.assert_allclose(N(eng.hs_dec).reshape(B, Tn, 88), ref['cache']['dec_h'], atol=5e-5)
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'], tol=3e-4)
+
+
+@pytest.mark.parametrize("model", ["cl_vae_fused", "cl_vae_layers", "cl_vrnn_pair", "cl_vrnn_separate"])
+def test_predict_next_scores_the_next_frame(dev, model):
+    """--predict_next (cl_vae/train.py:15,66; cl_vrnn/train.py:15,66): the input is frame t, the reconstruction target
+    frame t+1.  Losses and gradients with a separate target vs the oracle given the same target."""
+    from clvae_amd.engine import VaeEngine, VrnnEngine
+    rng = np.random.default_rng(5)
+    if model.startswith("cl_vae"):
+        B, L, Cn = 40, 3, 4
+        cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=False)
+        cfg['fused_step'] = model.endswith("fused")
+        p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=4).items()}
+        x, y = frames(rng, B, 88), frames(rng, B, 88)
+        eZ = f32(rng.standard_normal((B, L)))
+        fn, eng, xp = O.vae_loss_and_grads, VaeEngine(cfg, B, dev), x
+    else:
+        B, Tn, L, Cn = 5, 7, 2, 4
+        cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=False)
+        cfg['fuse_pair'] = model.endswith("pair")
+        p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=4).items()}
+        win = frames(rng, B, Tn + 1, 88)
+        x, y = win[:, :-1].copy(), win[:, 1:].copy()
+        eZ = f32(rng.standard_normal((B, Tn, L)))
+        fn, eng, xp = O.vrnn_loss_and_grads, VrnnEngine(cfg, B, dev), x
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    eW = f32(rng.standard_normal((B, Cn - 1)))
+    ref = fn(p, cfg, x, xp, wt, eW, eZ, target=y)
+    plain = fn(p, cfg, x, xp, wt, eW, eZ)
+    assert abs(ref['vae'] - plain['vae']) > 1.0           # the two targets really differ
+    eng.P.set_weights(p)
+    eng.loss_and_grads(T(x, dev), T(xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev), target=T(y, dev))
+    torch.cuda.synchronize()
+    got = eng.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, k
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'], tol=2e-4)
+
+
 def test_cl_vrnn_fused_and_separate_output_head_agree(dev):
     """Output head as one launch (clv_out_head_train, default) == gemm_bce + dhs GEMM + weight-gradient GEMM."""
     from clvae_amd.engine import VrnnEngine

@@ -355,6 +355,7 @@ def test_sparse_proj_matches_dense(dev, R, nx, Nn, ldx, dense):
 
 
 @pytest.mark.parametrize("R,nx,Nn,dense,relu", [(5, 11264, 88, False, True), (256, 11264, 88, False, True),
+                                                (64, 22528, 88, False, True),       # config 5: T = 256 windows
                                                 (3, 200, 18, True, False), (2, 64, 128, True, True)])
 def test_sparse_dense_matches_dense(dev, R, nx, Nn, dense, relu):
     from clvae_amd import ops, _lib
@@ -372,6 +373,7 @@ def test_sparse_dense_matches_dense(dev, R, nx, Nn, dense, relu):
 
 
 @pytest.mark.parametrize("Bn,nx,Nn,dense", [(256, 11264, 88, False), (100, 130, 88, False), (300, 70, 18, True),
+                                            (1024, 22528, 88, False),               # config 5: T = 256 windows
                                             (1, 64, 2, True)])
 def test_sparse_outer_matches_dense(dev, Bn, nx, Nn, dense):
     from clvae_amd import ops
