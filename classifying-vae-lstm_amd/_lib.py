@@ -95,6 +95,7 @@ SIGNATURES = {
     "clv_bernoulli_nll": (_i, [_i, _i, _p, _p, _i, _f, _p, _p, _p]),
     "clv_loss_sums": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p]),
     "clv_sum_strided": (_i, [_i, _p, _i, _f, _p, _p]),
+    "clv_act_grad": (_i, [_i64, _i, _p, _p, _p, _p]),
     "clv_axpy": (_i, [_i64, _f, _p, _p, _p]),
     "clv_gather_rows": (_i, [_i64, _i64, _p, _p, _p, _i64, _i64, _p]),
     "clv_adam_wn_plan_bytes": (_sz, [_p, _i]),

@@ -46,7 +46,7 @@ class Sampler:
         if self.args.infer_w:
             ws = [M.sample_w(self.w_enc.predict(s[None, :]), add_noise=False) for s in seeds]
         rolls = M.generate_samples_device(self.model, np.stack(seeds), self.args.t, np.vstack(ws),
-                                          seed=self.args.seed, use_z_prior=self.args.use_z_prior)
+                                          seed=getattr(self.args, 'seed', 0), use_z_prior=self.args.use_z_prior)
         for roll, name in zip(rolls, names):
             write_sample(roll, self.args.sample_dir, name, True)
         return list(rolls)

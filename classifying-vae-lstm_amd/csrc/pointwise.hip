@@ -273,6 +273,14 @@ __global__ void axpy_kernel(int64_t n, float alpha, const float* x, float* y) {
   if (i < n) y[i] += alpha * x[i];
 }
 
+// dpre = dy * act'(.) written in terms of the activation's OUTPUT y: relu -> [y > 0], sigmoid -> y (1 - y)
+__global__ void act_grad_kernel(int64_t n, int act, const float* y, const float* dy, float* dpre) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = y[i], g = dy[i];
+  dpre[i] = act == CLV_ACT_RELU ? (v > 0.f ? g : 0.f) : act == CLV_ACT_SIGMOID ? g * v * (1.f - v) : g;
+}
+
 // out[r, :] = src[idx[r], :]  (row gather: mini-batch assembly from the HBM-resident data set).  A source row
 // is a sequence of `chunk`-float pieces (frames); piece j of row r lands at out + (r*pieces + j)*out_ld, so
 // the history frames can be written straight into the [Xp | Z] decoder-input buffer (out_ld > chunk).
@@ -446,6 +454,15 @@ extern "C" int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* 
   hipStream_t s = (hipStream_t)stream;
   ProfScope pr("axpy", s);
   hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, alpha, x, y);
+  return launch_status();
+}
+
+extern "C" int clv_act_grad(int64_t n, int act, const float* y, const float* dy, float* dpre, void* stream) {
+  if (n <= 0 || !y || !dy || !dpre) return CLV_EINVAL;
+  if (act != CLV_ACT_NONE && act != CLV_ACT_RELU && act != CLV_ACT_SIGMOID) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("act_grad", s);
+  hipLaunchKernelGGL(act_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, act, y, dy, dpre);
   return launch_status();
 }
 

@@ -365,6 +365,10 @@ def philox_uniform(out, n, seed, step=0, stream_id=0, first_index=0, step_dev=No
           "clv_philox_uniform")
 
 
+def act_grad(n, act, y, dy, dpre):
+    check(_lib.lib().clv_act_grad(n, act, _ptr(y), _ptr(dy), _ptr(dpre), _stream()), "clv_act_grad")
+
+
 def i32_add(counter, v=1):
     check(_lib.lib().clv_i32_add(_ptr(counter), int(v), _stream()), "clv_i32_add")
 

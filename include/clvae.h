@@ -305,6 +305,10 @@ int clv_out_head_train(int R, int H, int D, const float* hs, const float* Wo, co
                        float* dhs, float* dWo, float* dbo, void* ws, size_t ws_bytes, clv_reduce_job* job,
                        void* stream);
 
+/* dpre[i] = dy[i] * act'(pre[i]) from the activation's output y: CLV_ACT_RELU -> [y > 0], CLV_ACT_SIGMOID -> y(1-y),
+ * CLV_ACT_NONE -> copy.  Backward of a Dense layer used on its own (the torch module face, clvae_amd/nn.py); the
+ * training engines fold this mask into the epilogue of the neighbouring GEMM instead (CLV_ACT_MASKPOS). */
+int clv_act_grad(int64_t n, int act, const float* y, const float* dy, float* dpre, void* stream);
 /* y[i] += alpha * x[i]  (epoch running sums of the loss scalars stay on the device) */
 int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
 
