@@ -80,44 +80,35 @@ def synthetic_windows(w, n, seed, dev):
     return wt[:, 1:].contiguous(), wt[:, :-1].contiguous(), torch.as_tensor(onehot, device=dev)
 
 
-def cpu_baseline(w, seconds=15.0):
-    """The numpy oracle (CPU restatement of the Keras math, fp32, per-timestep LSTM loop like K.rnn)
-    timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(w, seconds=20.0):
+    """the CPU restatement of the reference math (oracle/torch_cpu.py: fp32, torch-CPU, per-timestep
+    LSTM loop like Keras' K.rnn, autograd backward, Adam with weight norm) timed on this box's host cores at the SAME
+    batch and sequence length as the GPU run: >= 3 warm-up steps, then >= 10 timed steps (about `seconds` of work),
+    median step.  "CPU restatement (Keras-equivalent math), not Keras"."""
+    import torch
     from oracle import clvae_oracle as O
-    rng = np.random.default_rng(0)
-    T, L, C = w['T'], w['L'], w['C']
-    B = min(w['B'], 64)
+    from oracle import torch_cpu as TC
+    T, L, C, B = w['T'], w['L'], w['C'], w['B']
     if w['model'] == 'cl_vrnn':
         cfg = O.vrnn_config(latent_dim=L, seq_length=T, n_classes=C, use_x_prev=True)
-        p = O.vrnn_init_params(cfg, seed=0, dtype=np.float32)
-        win = (rng.random((B, T + 1, 88)) < NOTE_DENSITY).astype(np.float32)
-        X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
-        eZ = rng.standard_normal((B, T, L)).astype(np.float32)
-        fn = O.vrnn_loss_and_grads
     else:
         cfg = O.vae_config(latent_dim=L, n_classes=C, use_x_prev=True)
-        p = O.vae_init_params(cfg, seed=0, dtype=np.float32)
-        X = (rng.random((B, 88)) < NOTE_DENSITY).astype(np.float32)
-        Xp = (rng.random((B, 88)) < NOTE_DENSITY).astype(np.float32)
-        eZ = rng.standard_normal((B, L)).astype(np.float32)
-        fn = O.vae_loss_and_grads
-    wt = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
-    eW = rng.standard_normal((B, C - 1)).astype(np.float32)
-    st = O.adam_wn_init(p)
-    for _ in range(2):
-        r = fn(p, cfg, X, Xp, wt, eW, eZ); O.adam_wn_step(p, r['grads'], st)
-    t0 = time.time(); n = 0
-    while time.time() - t0 < seconds and n < 200:
-        r = fn(p, cfg, X, Xp, wt, eW, eZ); O.adam_wn_step(p, r['grads'], st); n += 1
-    dt = time.time() - t0
-    try:
-        import threadpoolctl
-        threads = max([i['num_threads'] for i in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count()
-    return dict(value=B * T * n / dt, unit="timesteps/s", cores=int(threads), kind="port",
-                sample="%d steps of batch %d x seq_len %d (numpy fp32 oracle, %d host cores visible)"
-                       % (n, B, T, os.cpu_count()))
+    r = TC.time_training_steps(w['model'], cfg, B, T, seconds=seconds)
+    return dict(value=r['timesteps_per_s'], unit="timesteps/s", cores=int(r['threads']), kind="port",
+                sample="%d timed steps (median) of batch %d x seq_len %d after 3 warm-up steps; CPU restatement "
+                       "(Keras-equivalent math, torch-CPU fp32, per-timestep LSTM loop), not Keras; %s, os.cpu_count() "
+                       "= %d, torch.get_num_threads() = %d"
+                       % (r['steps'], B, T, cpu_model_name(), os.cpu_count(), torch.get_num_threads()))
 
 
 def bench_generate(args, w, dev, rank, world):

@@ -593,25 +593,98 @@ __device__ __forceinline__ void reduce_block(const ReduceJob& g, unsigned blk, f
     Cptr[o] = v;
   }
 }
+// The same with 4 consecutive outputs per thread (16-byte loads of the slabs: a quarter of the load instructions; the
+// slabs of the bf16 weight-gradient kernel are 32 MB per LSTM).  Needs N % 4 == 0 and 16-byte aligned rows everywhere
+// (reduce_vec_ok).  A block still covers 64 outputs (the same number of blocks: ~4 per CU for an LSTM's gradients), now
+// as 16 float4 lanes x 16 slab lanes, every thread with up to 8 loads in flight.
+__device__ __forceinline__ void reduce_block_v4(const ReduceJob& g, unsigned blk, float4 (*red)[16]) {
+  const int splits = g.splits;
+  const size_t mn = (size_t)g.M * g.N;
+  const int ex = threadIdx.x & 15, zy = threadIdx.x >> 4;
+  const size_t idx = ((size_t)blk * 16 + ex) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  if (idx < mn) {
+    const float* p = g.partial + idx;
+    auto at = [&](int z) { return *reinterpret_cast<const float4*>(p + (size_t)z * mn); };
+    float4 a0 = v, a1 = v, a2 = v, a3 = v, a4 = v, a5 = v, a6 = v, a7 = v;
+    int z = zy;
+    for (; z + 112 < splits; z += 128) {
+      add(a0, at(z)); add(a1, at(z + 16)); add(a2, at(z + 32)); add(a3, at(z + 48));
+      add(a4, at(z + 64)); add(a5, at(z + 80)); add(a6, at(z + 96)); add(a7, at(z + 112));
+    }
+    for (; z < splits; z += 16) add(a0, at(z));
+    add(a0, a1); add(a2, a3); add(a4, a5); add(a6, a7);
+    add(a0, a2); add(a4, a6);
+    add(a0, a4);
+    v = a0;
+  }
+  red[zy][ex] = v;
+  __syncthreads();
+  if (zy == 0 && idx < mn) {
+    float4 t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                  // fixed order: ((0+1)+(2+3)) per group of four, then the groups
+      t[q] = red[4 * q][ex];
+      float4 u = red[4 * q + 2][ex];
+      add(t[q], red[4 * q + 1][ex]); add(u, red[4 * q + 3][ex]);
+      add(t[q], u);
+    }
+    add(t[0], t[1]); add(t[2], t[3]); add(t[0], t[2]);
+    v = t[0];
+    int row = (int)(idx / g.N);
+    const int col = (int)(idx % g.N);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_PROB; ++i)
+      if (i < g.nprob && row >= g.prob[i].row0) pi = i;
+    float* Cptr = g.prob[pi].C;
+    row -= g.prob[pi].row0;
+    const size_t o = (size_t)row * g.prob[pi].ldc + col;
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float w = r[j] * g.alpha;
+      if (g.bias) w += g.bias[col + j];
+      if (g.beta != 0.f) w += g.beta * Cptr[o + j];
+      r[j] = apply_act(w, g.act, g.act == CLV_ACT_MASKPOS ? g.aux[o + j] : 0.f);
+    }
+    *reinterpret_cast<float4*>(Cptr + o) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+static bool reduce_vec_ok(const ReduceJob& j) {
+  if (j.N % 4 || ((uintptr_t)j.partial) % 16) return false;
+  const int n = j.nprob == 0 ? 1 : j.nprob;
+  for (int i = 0; i < n; ++i)
+    if (j.prob[i].ldc % 4 || ((uintptr_t)j.prob[i].C) % 16) return false;
+  return true;
+}
+static unsigned reduce_blocks(const ReduceJob& j) {          // j.pad_ = 1: the 4-wide form
+  const size_t mn = (size_t)j.M * j.N;
+  return (unsigned)((mn + 63) / 64);
+}
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceJob j) {
-  __shared__ float red[4][64];
-  reduce_block(j, blockIdx.x, red);
+  __shared__ float4 red[16][16];
+  if (j.pad_) reduce_block_v4(j, blockIdx.x, red);
+  else reduce_block(j, blockIdx.x, reinterpret_cast<float (*)[64]>(red));
 }
 // several pending reductions in one launch (the weight gradients of a whole backward pass)
 constexpr int MAX_JOBS = 16;
 struct ReduceTable { int njobs; unsigned blk0[MAX_JOBS + 1]; ReduceJob job[MAX_JOBS]; };
 __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t) {
-  __shared__ float red[4][64];
+  __shared__ float4 red[16][16];
   int ji = 0;
 #pragma unroll
   for (int i = 1; i < MAX_JOBS; ++i)
     if (i < t.njobs && blockIdx.x >= t.blk0[i]) ji = i;
-  reduce_block(t.job[ji], blockIdx.x - t.blk0[ji], red);
+  if (t.job[ji].pad_) reduce_block_v4(t.job[ji], blockIdx.x - t.blk0[ji], red);
+  else reduce_block(t.job[ji], blockIdx.x - t.blk0[ji], reinterpret_cast<float (*)[64]>(red));
 }
-int launch_reduce(const ReduceJob& j, hipStream_t s) {
+int launch_reduce(const ReduceJob& j_in, hipStream_t s) {
   ProfScope p("gemm_splitk_reduce", s);
-  const size_t mn = (size_t)j.M * j.N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, j);
+  ReduceJob j = j_in;
+  j.pad_ = reduce_vec_ok(j) ? 1 : 0;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_blocks(j)), dim3(256), 0, s, j);
   return launch_status();
 }
 
@@ -874,9 +947,10 @@ extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, vo
     memcpy(&j, &jobs[i], sizeof(j));
     if (j.splits <= 1 || !j.partial) continue;          // finished inside its GEMM
     if (t.njobs == MAX_JOBS) return CLV_EINVAL;
+    j.pad_ = reduce_vec_ok(j) ? 1 : 0;
     t.blk0[t.njobs] = blk;
     t.job[t.njobs++] = j;
-    blk += (unsigned)(((size_t)j.M * j.N + 63) / 64);
+    blk += reduce_blocks(j);
   }
   if (t.njobs == 0) return CLV_OK;
   t.blk0[t.njobs] = blk;

@@ -16,7 +16,7 @@ struct ReduceJob {
   const float* bias;
   const float* aux;
   int act;
-  int pad_;
+  int pad_;                // set by the reduce launchers: 1 = 4 outputs per thread (16-byte slab loads)
   ReduceProb prob[MAX_PROB];   // nprob == 0: prob[0] is the single output
 };
 static_assert(sizeof(ReduceJob) <= sizeof(clv_reduce_job), "clv_reduce_job too small");

@@ -1,0 +1,413 @@
+// wgrad_bf16.hip -- every kernel gradient of one LSTM in one pass over dz, on the bf16 matrix cores with EXACT
+// products (gfx950).
+//
+//   dK_x [nx,4H] = X^T . dz      (input frames; binary piano-roll, or any values)
+//   dU   [nh,4H] = H'^T . dz     (H'_k = h of the previous step: row k-1 of hs, zero at window starts)
+//   dK_z [nz,4H] = Z^T . dz      (latent columns of the decoder input, may be absent)
+// over K = B*T rows.  cl_vrnn/model.py:196-199,225-228 (the LSTM layers whose kernels these are); the products are
+// what Keras' backward pass of `K.dot(x, kernel)` / `K.dot(h, recurrent_kernel)` computes.
+//
+// Why not the f32 MFMA (gemm.hip): v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate.  An fp32 number is the exact
+// sum of three bf16 numbers (8 + 8 + 8 mantissa bits, same exponent range), and a product of two bf16 numbers is exact
+// in fp32, so  a.b = sum_{i,j} a_i.b_j  over the 3 x 3 piece pairs has EXACT partial products; the nine partial GEMMs
+// accumulate in fp32 like any other summation order of the same products.  9 bf16 MFMAs (144 cycles per 16x16 tile and
+// 32 k) replace 8 f32 MFMAs (256 cycles).  Frames that are exactly representable in bf16 (0/1 piano-roll, any uint8)
+// need one piece: 3 MFMAs.  The kernel is then bound by streaming dz / X / H once, not by the matrix pipe.
+//
+// Decomposition: a workgroup (4 waves, one per SIMD) owns ALL output rows x half of the 4H columns (176 = 11 column
+// tiles, padded to 12) for K / splits rows; accumulators stay in registers (up to 168 per lane).  Per 32-row stage the
+// operands go global -> registers -> (split into pieces) -> LDS as bf16 [k][column] images, double buffered; fragments
+// come out of LDS with ds_read_b64_tr_b16 (both operands are k-major in memory, the MFMA wants k along the lane's
+// registers).  Partial sums leave as one [rows,176] slab per workgroup into the deferred split-K reduction.
+#include "reduce_job.h"
+
+namespace clv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WB_NT = 512;           // threads: 8 waves as 2 (row halves) x 4 (column quarters), two per SIMD
+constexpr int WB_KS = 32;            // rows of dz per stage = one bf16 MFMA step
+constexpr int WB_NC = 176;           // dz columns per workgroup
+constexpr int WB_XT = 6;             // row tiles of the x block (nx <= 96)
+// LDS row pitches in bytes.  A transposed read takes 4 rows x 32 bytes per 16-lane group and the two groups of a
+// 32-lane half are 8 rows apart: with a pitch of 8 banks more than a multiple of 64 (dz: 416 B = 104 banks) or 48 banks
+// (192 B) the 4 rows of a group fall on different banks; the second group lands on the first one's (2-way, unavoidable
+// with a linear pitch: 8 rows x 8 banks would have to tile all 64 banks AND repeat after 8 rows).
+constexpr int WB_DZP = 416;          // dz image: 192 columns + 16 pad
+constexpr int WB_AP = 192;           // x image: 96 columns;  h image: 16 * HM columns, pitch below
+
+template <int HM> struct WbGeo {
+  static constexpr int HPB = HM == 6 ? 192 : 288;            // h image pitch (bytes): 96 columns, or 128 + 16 pad (72 banks)
+  static constexpr int DZ_BYTES = 3 * WB_KS * WB_DZP;
+  static constexpr int H_BYTES = 3 * WB_KS * HPB;
+  template <int XP> static constexpr int x_bytes() { return XP * WB_KS * WB_AP; }
+  template <int XP> static constexpr int buf_bytes() { return DZ_BYTES + H_BYTES + x_bytes<XP>(); }
+  template <int XP> static constexpr int lds_bytes() { return 2 * buf_bytes<XP>(); }
+};
+
+struct WgradArgs {
+  int K, N, kc;                      // rows, columns (352), rows per split
+  const float* X; int ldx, nx;
+  const float* H; int ldh, nh, h_shift, h_zero_period;
+  const float* Z; int ldz, nz;
+  const float* dz; int lddz;
+  float* partial;                    // [splits][nx + nh + nz][N]
+};
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// x = p0 + p1 + p2 exactly, two values at a time: v_cvt_pk_bf16_f32 rounds a pair to nearest even and packs it (the
+// 4 bytes an image wants), a piece as a float is its 16 bits shifted up, and the residuals are exact in fp32
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[3]) {
+  piece[0] = pack2(a, b);
+  const float ra = a - __builtin_bit_cast(float, piece[0] << 16), rb = b - __builtin_bit_cast(float, piece[0] & 0xffff0000u);
+  piece[1] = pack2(ra, rb);
+  piece[2] = pack2(ra - __builtin_bit_cast(float, piece[1] << 16), rb - __builtin_bit_cast(float, piece[1] & 0xffff0000u));
+}
+// 4 consecutive columns of one image row: one 8-byte LDS store per piece image
+#ifndef WB_ABLATE
+#define WB_ABLATE 0      // measurement builds (tools/build_variant.sh): 1 = no piece splitting, 2 = one MFMA term of nine,
+#endif                   // 3 = no global loads after the first stages.  Results are wrong by design.
+template <int NP>
+__device__ __forceinline__ void put4(char* at, int piece_bytes, const float4& v) {
+  unsigned lo[3], hi[3];
+  if (NP == 1 || WB_ABLATE == 1) { lo[0] = lo[1] = lo[2] = pack2(v.x, v.y); hi[0] = hi[1] = hi[2] = pack2(v.z, v.w); }
+  else { split_pair(v.x, v.y, lo); split_pair(v.z, v.w, hi); }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(at + p * piece_bytes) = u32x2{lo[p], hi[p]};
+}
+
+// the 8 k-values x 16 columns fragment of a bf16 [k][column] image (k rows 0..31 of the stage, columns col0..col0+15):
+// lane l = 16 g + i gets column col0 + i, k = 8 g + j in element j -- the layout of both operands of
+// v_mfma_f32_16x16x32_bf16 when the image holds the operand k-major.  `lane_off` = frag_lane_offset(pitch, lane).
+__device__ __forceinline__ int frag_lane_offset(int pitch, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  return (8 * g + (i >> 2)) * pitch + 8 * (i & 3);
+}
+__device__ __forceinline__ bf16x8 frag(const char* img, int pitch, int col0, int lane_off) {
+  const char* p = img + lane_off + 2 * col0;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * pitch));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// Stage barrier: this wave's LDS traffic is done, its global loads are NOT waited for (__syncthreads() would add
+// s_waitcnt vmcnt(0) and drain the producers' prefetch at every stage).
+__device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int HM, int XP>
+__global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
+  using G = WbGeo<HM>;
+  constexpr int HPB = G::HPB, BUF = G::template buf_bytes<XP>(), LDS_ALL = G::template lds_bytes<XP>();
+  constexpr int HT = HM / 2;                     // h row tiles per consumer wave
+  constexpr int XT = WB_XT / 2;                  // x row tiles per consumer wave
+  constexpr int NTW = 6;                         // column tiles per consumer wave (2 halves x 6 = 12: 11 + 1 padding)
+  constexpr int NP_T = WB_NT / 2;                // producer threads
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Waves w and w + 4 share a SIMD.  Waves 0-3 only issue MFMAs (and the LDS reads that feed them): 2 row halves x 2
+  // column halves, all accumulators in registers.  Waves 4-7 only move data: global loads of stage s + 2, conversion
+  // of stage s + 1 into bf16 pieces, LDS stores -- their VALU work runs in the shadow of the partner's MFMAs.
+  const bool producer = wave >= 4;
+  // grid = (splits, 2): the two column halves of a row range are 128 workgroup ids apart, i.e. on the same XCD under
+  // round-robin placement, so the second read of X / H hits that XCD's L2 (speed only)
+  const int n0 = blockIdx.y * WB_NC;             // first dz column of this workgroup
+  const int split = blockIdx.x;
+  const int k_begin = split * a.kc, k_end = min(a.K, k_begin + a.kc);
+  const int nstage = (k_end - k_begin + WB_KS - 1) / WB_KS;
+
+  // The images' padding (x columns nx..95, h columns nh+nz.., dz columns 176..207) only reaches output rows / columns
+  // that are never stored; everything is zeroed once so that every MFMA input is a finite number.
+  for (int i = tid; i < LDS_ALL / 16; i += WB_NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+  if (producer) {
+    // ---- which elements of a stage this thread moves (the same for every stage) ------------------------------------
+    // dz: 32 rows x 44 float4 = 1408 slots;  h, x: 32 x (n/4);  z: 32 x nz scalars; 256 producer threads take slot
+    // pt + 256 i.  Per slot: the byte offset from the stage's first row in global memory and the byte offset in the
+    // LDS image.  Only the last slot of each kind can lie beyond the tile (its load is clamped, its store skipped).
+    const int pt = tid - NP_T;
+    constexpr int DZ_L = 6, A_L = 3, Z_L = HM == 8 ? 4 : 1;
+    const int nh4 = a.nh / 4, nx4 = a.nx / 4;
+    unsigned dz_g[DZ_L], h_g[A_L], x_g[A_L], z_g[Z_L];
+    int dz_l[DZ_L], h_l[A_L], x_l[A_L], z_l[Z_L];          // LDS offsets; bit 30: row 0 of the stage (h), bit 31: idle slot
+    constexpr int ROW0 = 1 << 30, IDLE = 1 << 31, OFFM = ROW0 - 1;
+#pragma unroll
+    for (int i = 0; i < DZ_L; ++i) {
+      const int e = pt + i * NP_T, ok = e < WB_KS * 44, ec = ok ? e : 0, r = ec / 44, c4 = ec % 44;
+      dz_g[i] = 4u * (unsigned)(r * a.lddz + n0 + 4 * c4);
+      dz_l[i] = (r * WB_DZP + 8 * c4) | (ok ? 0 : IDLE);
+    }
+#pragma unroll
+    for (int i = 0; i < A_L; ++i) {
+      const int e = pt + i * NP_T;
+      const int okh = e < WB_KS * nh4, eh = okh ? e : 0, rh = eh / nh4, ch = eh % nh4;
+      const int okx = e < WB_KS * nx4, ex = okx ? e : 0, rx = ex / nx4, cx = ex % nx4;
+      h_g[i] = 4u * (unsigned)(rh * a.ldh + 4 * ch);
+      h_l[i] = (rh * HPB + 8 * ch) | (rh == 0 ? ROW0 : 0) | (okh ? 0 : IDLE);
+      x_g[i] = 4u * (unsigned)(rx * a.ldx + 4 * cx);
+      x_l[i] = (rx * WB_AP + 8 * cx) | (okx ? 0 : IDLE);
+    }
+#pragma unroll
+    for (int i = 0; i < Z_L; ++i) {
+      const int e = pt + i * NP_T, nz1 = max(a.nz, 1), ok = a.nz > 0 && e < WB_KS * a.nz, ez = ok ? e : 0;
+      z_g[i] = 4u * (unsigned)((ez / nz1) * a.ldz + ez % nz1);
+      z_l[i] = ((ez / nz1) * HPB + 2 * (a.nh + ez % nz1)) | (ok ? 0 : IDLE);
+    }
+    // A stage is "interior" when all of its 32 rows exist, the shifted H rows exist, and a window start can only be its
+    // first row (h_zero_period a multiple of 32; k_begin is one by construction).  Interior stages take the fast
+    // path: no clamps, no masks, one select for the H row of a window start.
+    const bool aligned = a.h_zero_period == 0 || a.h_zero_period % WB_KS == 0;
+    auto interior = [&](int s) { const int k0 = k_begin + s * WB_KS; return aligned && k0 + WB_KS <= k_end && k0 >= a.h_shift; };
+
+    // Two stages of operands in flight per thread (register sets A and B): one stage of MFMAs (~1.5 us) is less than a
+    // load takes under load, with one set the producers waited for memory every stage.
+    struct Regs { float4 dz[DZ_L], h[A_L], x[A_L]; float z[Z_L]; };
+    Regs ra, rb;
+    auto load_stage = [&](Regs& q, int s) {        // nothing uses the values until store_stage()
+      if (WB_ABLATE == 3 && s > 2) return;
+      const int k0 = k_begin + s * WB_KS;
+      if (interior(s)) {                           // uniform base + per-lane 32-bit offset
+        const char* dzb = reinterpret_cast<const char*>(a.dz + (size_t)k0 * a.lddz);
+        const char* hb = reinterpret_cast<const char*>(a.H + (size_t)(k0 - a.h_shift) * a.ldh);
+        const char* xb = reinterpret_cast<const char*>(a.X + (size_t)k0 * a.ldx);
+#pragma unroll
+        for (int i = 0; i < DZ_L; ++i) q.dz[i] = *reinterpret_cast<const float4*>(dzb + dz_g[i]);
+#pragma unroll
+        for (int i = 0; i < A_L; ++i) {
+          q.h[i] = *reinterpret_cast<const float4*>(hb + h_g[i]);
+          q.x[i] = *reinterpret_cast<const float4*>(xb + x_g[i]);
+        }
+        if (a.nz > 0) {
+          const char* zb = reinterpret_cast<const char*>(a.Z + (size_t)k0 * a.ldz);
+#pragma unroll
+          for (int i = 0; i < Z_L; ++i) q.z[i] = *reinterpret_cast<const float*>(zb + z_g[i]);
+        }
+        return;
+      }
+      // first / last stage of the matrix: row indices clamped into it (the values of rows outside are masked later)
+      auto row = [&](unsigned g, int ld, int shift) { const int r = (int)(g / 4u) / ld; return min(max(k0 + r - shift, 0), a.K - 1) - r; };
+#pragma unroll
+      for (int i = 0; i < DZ_L; ++i)
+        q.dz[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dz + (size_t)row(dz_g[i] - 4u * n0, a.lddz, 0) * a.lddz) + dz_g[i]);
+#pragma unroll
+      for (int i = 0; i < A_L; ++i) {
+        q.h[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.H + (size_t)row(h_g[i], a.ldh, a.h_shift) * a.ldh) + h_g[i]);
+        q.x[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.X + (size_t)row(x_g[i], a.ldx, 0) * a.ldx) + x_g[i]);
+      }
+      if (a.nz > 0) {
+#pragma unroll
+        for (int i = 0; i < Z_L; ++i)
+          q.z[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.Z + (size_t)row(z_g[i], a.ldz, 0) * a.ldz) + z_g[i]);
+      }
+    };
+    auto keep = [](const float4& v, bool live) { return live ? v : make_float4(0.f, 0.f, 0.f, 0.f); };
+    auto store_stage = [&](const Regs& q, int s) {    // fp32 -> bf16 pieces -> LDS images of buffer s & 1
+      const int k0 = k_begin + s * WB_KS;
+      char* dzi = lds + (s & 1) * BUF;
+      char* hi = dzi + G::DZ_BYTES;
+      char* xi = hi + G::H_BYTES;
+      const bool fast = interior(s);
+      const bool wstart = a.h_zero_period != 0 && k0 % a.h_zero_period == 0;     // row 0 of the stage starts a window
+#pragma unroll
+      for (int i = 0; i < DZ_L; ++i) {
+        const int r = (dz_l[i] & OFFM) / WB_DZP;
+        const float4 v = fast ? q.dz[i] : keep(q.dz[i], k0 + r < k_end);
+        if (i + 1 < DZ_L || !(dz_l[i] & IDLE)) put4<3>(dzi + (dz_l[i] & OFFM), WB_KS * WB_DZP, v);
+      }
+#pragma unroll
+      for (int i = 0; i < A_L; ++i) {
+        const int rh = (h_l[i] & OFFM) / HPB, rx = (x_l[i] & OFFM) / WB_AP, k = k0 + rh;
+        // H'_k = h of the previous step; zero at the start of a window
+        const bool live = fast ? !(wstart && (h_l[i] & ROW0))
+                               : (k < k_end && k >= a.h_shift && (a.h_zero_period == 0 || k % a.h_zero_period != 0));
+        if (i + 1 < A_L || !(h_l[i] & IDLE)) put4<3>(hi + (h_l[i] & OFFM), WB_KS * HPB, keep(q.h[i], live));
+        if (i + 1 < A_L || !(x_l[i] & IDLE)) put4<XP>(xi + (x_l[i] & OFFM), WB_KS * WB_AP, fast ? q.x[i] : keep(q.x[i], k0 + rx < k_end));
+      }
+      if (a.nz > 0) {
+#pragma unroll
+        for (int i = 0; i < Z_L; ++i) {
+          unsigned p[3];
+          const int r = (z_l[i] & OFFM) / HPB;
+          split_pair((fast || k0 + r < k_end) ? q.z[i] : 0.f, 0.f, p);
+          if (!(z_l[i] & IDLE)) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) *reinterpret_cast<unsigned short*>(hi + w * WB_KS * HPB + (z_l[i] & OFFM)) = (unsigned short)p[w];
+          }
+        }
+      }
+    };
+    // stage s lives in set A for even s, set B for odd s
+    if (nstage > 0) {
+      load_stage(ra, 0);
+      if (nstage > 1) load_stage(rb, 1);
+      store_stage(ra, 0);
+      if (nstage > 2) load_stage(ra, 2);
+    }
+    stage_barrier();
+    // during stage s (consumers on buffer s & 1): convert stage s + 1 into the other buffer (last read in stage s - 1,
+    // i.e. before the barrier every wave has passed), then request stage s + 3 into the registers that just emptied
+    for (int s = 0; s < nstage; s += 2) {
+      if (s + 1 < nstage) store_stage(rb, s + 1);
+      if (s + 3 < nstage) load_stage(rb, s + 3);
+      stage_barrier();
+      if (s + 1 < nstage) {
+        if (s + 2 < nstage) store_stage(ra, s + 2);
+        if (s + 4 < nstage) load_stage(ra, s + 4);
+        stage_barrier();
+      }
+    }
+    return;
+  }
+
+  // ---- consumers ----------------------------------------------------------------------------------------------------
+  const int mh = wave & 1, nh2 = wave >> 1;
+  f32x4 accx[XT][NTW], acch[HT][NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) {
+#pragma unroll
+    for (int m = 0; m < XT; ++m) accx[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < HT; ++m) acch[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int fo_dz = frag_lane_offset(WB_DZP, lane), fo_h = frag_lane_offset(HPB, lane), fo_x = frag_lane_offset(WB_AP, lane);
+  stage_barrier();
+  for (int s = 0; s < nstage; ++s) {
+    const char* dzi = lds + (s & 1) * BUF;
+    const char* hi = dzi + G::DZ_BYTES;
+    const char* xi = hi + G::H_BYTES;
+    bf16x8 ax[XT][XP], ah[HT][3];
+#pragma unroll
+    for (int m = 0; m < XT; ++m)
+#pragma unroll
+      for (int p = 0; p < XP; ++p) ax[m][p] = frag(xi + p * WB_KS * WB_AP, WB_AP, 16 * (mh * XT + m), fo_x);
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ah[m][p] = frag(hi + p * WB_KS * HPB, HPB, 16 * (mh * HT + m), fo_h);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = frag(dzi + p * WB_KS * WB_DZP, WB_DZP, 16 * (nh2 * NTW + n), fo_dz);
+#pragma unroll
+      for (int m = 0; m < XT; ++m)
+#pragma unroll
+        for (int pa = 0; pa < XP; ++pa)
+#pragma unroll
+          for (int pb = 0; pb < 3; ++pb)
+            accx[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[m][pa], b[pb], accx[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int pa = 0; pa < (WB_ABLATE == 2 ? 1 : 3); ++pa)
+#pragma unroll
+          for (int pb = 0; pb < (WB_ABLATE == 2 ? 1 : 3); ++pb)
+            acch[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m][pa], b[pb], acch[m][n], 0, 0, 0);
+    }
+    stage_barrier();
+  }
+
+  // ---- slabs: accumulators -> LDS (row-major) -> 16-byte row pieces to the partial buffer ---------------------------
+  // C/D layout of the MFMA: column = lane & 15, row = 4 (lane >> 4) + register.  (The producers are gone; the four
+  // consumer waves stage in disjoint regions, no barrier needed: LDS operations of one wave execute in order.)
+  constexpr int SP = 16 * NTW + 4;                // floats per staged row (96 columns + 4: the 4 row groups 2-way on banks)
+  float* stg = reinterpret_cast<float*>(lds) + wave * (16 * (HT > XT ? HT : XT) * SP);
+  const int rows_tot = a.nx + a.nh + a.nz;
+  float* slab = a.partial + (size_t)split * rows_tot * a.N;
+  const int c_loc = nh2 * 16 * NTW;               // first column of this wave inside the workgroup's 192
+  const int colw = min(16 * NTW, WB_NC - c_loc);  // valid ones
+  auto flush = [&](auto& acc, int tiles, int row_first, int row_limit, int slab_row0) {
+#pragma unroll
+    for (int m = 0; m < tiles; ++m)
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[(16 * m + 4 * (lane >> 4) + r) * SP + 16 * n + (lane & 15)] = acc[m][n][r];
+    for (int e = lane; e < 16 * tiles * (4 * NTW); e += 64) {
+      const int r = e / (4 * NTW), c4 = e % (4 * NTW), row = row_first + r;
+      if (row < row_limit && 4 * c4 < colw) {
+        const float4 v = *reinterpret_cast<const float4*>(&stg[r * SP + 4 * c4]);
+        *reinterpret_cast<float4*>(slab + (size_t)(slab_row0 + row) * a.N + n0 + c_loc + 4 * c4) = v;
+      }
+    }
+  };
+  flush(accx, XT, mh * XT * 16, a.nx, 0);
+  flush(acch, HT, mh * HT * 16, a.nh + a.nz, a.nx);
+}
+
+}  // namespace clv
+
+extern "C" int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16) {
+  if (!(N == 352 && nx > 0 && nx <= 96 && nx % 4 == 0 && nh > 0 && nh % 4 == 0 && nz >= 0 && nh + nz <= 128 && nz <= 32))
+    return 0;
+  return nh + nz <= 96 || x_exact_bf16;        // 8 h row tiles and three x pieces do not fit the LDS together
+}
+
+static int wgrad_splits(int K) {
+  // one workgroup per CU: 2 column halves x 128 row ranges of whole 32-row stages
+  int kc = (K + 127) / 128;
+  kc = (kc + 31) / 32 * 32;
+  return (K + kc - 1) / kc;
+}
+
+extern "C" size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz) {
+  return (size_t)wgrad_splits(K) * (nx + nh + nz) * N * sizeof(float);
+}
+
+extern "C" int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+                              const float* H, int ldh, int nh, int h_shift, int h_zero_period,
+                              const float* Z, int ldz, int nz, const float* dz, int lddz,
+                              float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
+                              void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream) {
+  using namespace clv;
+  if (job) memset(job, 0, sizeof(*job));
+  if (!clv_lstm_wgrad_supported(N, nx, nh, nz, x_exact_bf16) || K <= 0 || !X || !H || !dz || !dKx || !dU || (nz > 0 && (!Z || !dKz)))
+    return CLV_EINVAL;
+  if (ldx % 4 || ldh % 4 || lddz % 4 || ((uintptr_t)X | (uintptr_t)H | (uintptr_t)dz) % 16) return CLV_EINVAL;
+  if (clv_lstm_wgrad_workspace_bytes(K, N, nx, nh, nz) > ws_bytes || !ws || ((uintptr_t)ws) % 16) return CLV_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = wgrad_splits(K);
+  int kc = (K + 127) / 128;
+  kc = (kc + 31) / 32 * 32;
+  WgradArgs a{K, N, kc, X, ldx, nx, H, ldh, nh, h_shift, h_zero_period, Z, ldz, nz, dz, lddz, (float*)ws};
+  const bool wide = nh + nz > 96;
+  {
+    ProfScope p("lstm_wgrad_bf16", s);
+    dim3 grid(splits, N / WB_NC);
+#define WB_LAUNCH(HM, XP)                                                                                   \
+  do {                                                                                                      \
+    auto kern = lstm_wgrad_bf16_kernel<HM, XP>;                                                             \
+    const int lds = WbGeo<HM>::template lds_bytes<XP>();                                                    \
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;                      \
+    hipLaunchKernelGGL(kern, grid, dim3(WB_NT), lds, s, a);                                                 \
+  } while (0)
+    if (wide) { if (x_exact_bf16) WB_LAUNCH(8, 1); else WB_LAUNCH(8, 3); }
+    else { if (x_exact_bf16) WB_LAUNCH(6, 1); else WB_LAUNCH(6, 3); }
+#undef WB_LAUNCH
+  }
+  int st = launch_status();
+  if (st) return st;
+  ReduceJob j;
+  memset(&j, 0, sizeof(j));
+  j.partial = (const float*)ws;
+  j.M = nx + nh + nz; j.N = N; j.splits = splits; j.nprob = nz > 0 ? 3 : 2;
+  j.alpha = 1.f; j.beta = beta; j.act = CLV_ACT_NONE;
+  j.prob[0] = ReduceProb{dKx, ld_kx, 0};
+  j.prob[1] = ReduceProb{dU, ld_u, nx};
+  if (nz > 0) j.prob[2] = ReduceProb{dKz, ld_kz, nx + nh};
+  // a single slab still goes through the reduction (it scatters the rows to the three tensors), but at once: the
+  // deferred queue skips jobs without a split
+  if (job && splits > 1) memcpy(job, &j, sizeof(j));
+  else st = launch_reduce(j, s);
+  return st;
+}

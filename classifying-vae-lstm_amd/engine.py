@@ -464,6 +464,11 @@ class VrnnEngine(_EngineBase):
         self.fuse_head = bool(cfg.get('fuse_head', os.environ.get('CLV_FUSE_HEAD', '1') != '0')) \
             and ops.out_head_train_supported(H, D)
         self._head_done = False
+        # LSTM kernel gradients as split-bf16 exact products (csrc/wgrad_bf16.hip) instead of the f32 MFMA GEMM;
+        # frames_exact_bf16: every staged frame value is exactly a bf16 number (TrainStep sets it when the data set is
+        # kept as uint8), which lets the frame rows use one bf16 piece instead of three
+        self.bf16_wgrad = bool(cfg.get('bf16_wgrad', os.environ.get('CLV_BF16_WGRAD', '1') != '0'))
+        self.frames_exact_bf16 = bool(cfg.get('frames_exact_bf16', False))
         self.hW = _f(d, B, D)
         self.wargs = _f(d, B, 2 * (Cn - 1))
         self.W = _f(d, B, Cn)
@@ -736,15 +741,31 @@ class VrnnEngine(_EngineBase):
         decoder) and the recurrent kernel (h_{t-1}: shift 1, zero at t == 0).
         Over dzsum [B,4H] (K = B): kernel rows of the repeated label W, and the bias."""
         cfg, P, B = self.cfg, self.P, self.B
-        H, T, Cn = cfg['H'], cfg['T'], cfg['C']
+        H, T, Cn, L = cfg['H'], cfg['T'], cfg['C'], cfg['L']
         BT, G4 = B * T, 4 * H
         rq = self._rq()
-        ops.gemm_grouped_tn([dict(A=X_in, lda=x_ld, M=x_rows, C=P.g(name + '/kernel')),
-                             dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)],
-                            G4, BT, dz, ws, defer=rq, split_scale=2 if self.fine_grid else 1)
+        nz = L if name == 'decoder_h' else 0          # the decoder's per-step inputs are [x_{t-1} | z_t]
+        nx = x_rows - nz                              # 0: a decoder without history frames
+        if self.bf16_wgrad and nx > 0 and ops.lstm_wgrad_supported(G4, nx, H, nz, self.frames_exact_bf16):
+            # split-bf16 exact products on the bf16 matrix cores (csrc/wgrad_bf16.hip): x rows, h rows and z rows at once
+            gk = P.g(name + '/kernel')
+            ops.lstm_wgrad(BT, G4, X_in, x_ld, nx, self.frames_exact_bf16, hs, H, H, T,
+                           X_in[:, nx:] if nz else None, x_ld, nz, dz, gk, P.g(name + '/recurrent_kernel'),
+                           P.rows(P.grads, name + '/kernel', nx) if nz else None, ws, defer=rq)
+        else:
+            self._lstm_wgrads_f32(name, X_in, x_ld, x_rows, hs, dz, ws, rq)
         if not (Cn + 1 <= 16 and B <= 4096):      # else: both LSTMs' label rows + biases in one launch (grads_tail)
             ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
                                  dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)], G4, B, dzsum, ws, defer=rq)
+
+    def _lstm_wgrads_f32(self, name, X_in, x_ld, x_rows, hs, dz, ws, rq):
+        """The same products on the f32 MFMA (grouped GEMM over dz): any shape."""
+        cfg, P = self.cfg, self.P
+        H, T = cfg['H'], cfg['T']
+        BT, G4 = self.B * T, 4 * H
+        ops.gemm_grouped_tn([dict(A=X_in, lda=x_ld, M=x_rows, C=P.g(name + '/kernel')),
+                             dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)],
+                            G4, BT, dz, ws, defer=rq, split_scale=2 if self.fine_grid else 1)
 
     def _dense_wgrad(self, name, A, lda, rows, N, K, Bm, ws, rq):
         """Kernel and bias gradient of a Dense layer in one pass over Bm = dL/d(output) [K,N].  When the bias follows the

@@ -122,6 +122,12 @@ class TrainStep:
 
         def src(x):
             return (x.store, (D, x.t0 * D, x.starts)) if isinstance(x, DevWindows) else (x, ())
+        # frames that arrive as bytes are exactly representable in bf16: the LSTM kernel-gradient products then need
+        # one bf16 piece for the frame rows (VrnnEngine.frames_exact_bf16); the choice is baked into the captured step
+        exact = all(src(x)[0].dtype == torch.uint8 for x in (cur, hist) if x is not None)
+        if hasattr(self.eng, 'frames_exact_bf16') and self.eng.frames_exact_bf16 != exact:
+            self.eng.frames_exact_bf16 = exact
+            self.recapture()
         c, cx = src(cur)
         segs = [(c, self.X, row, 0, 0) + cx]
         if hist is not None:

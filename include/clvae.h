@@ -110,6 +110,27 @@ int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int nprob, int N, i
                                  int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
 int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream);
 
+/* Every kernel gradient of one LSTM in one pass over dz [K,N], N = 4H = 352, K = B*T (cl_vrnn/model.py:196-199,
+ * 225-228; replaces the grouped f32-MFMA product for these shapes):
+ *   dKx [nx,N] = X^T . dz            X [K,ldx]: the input frames (first nx columns)
+ *   dU  [nh,N] = H'^T . dz           H'_k = H[k - h_shift] (h of the previous step), zero where k % h_zero_period == 0
+ *   dKz [nz,N] = Z^T . dz            Z [K,ldz]: the latent columns of the decoder input; nz = 0: absent
+ * computed on the bf16 matrix cores with EXACT products: every fp32 operand is split into three bf16 pieces
+ * (x = p0 + p1 + p2 exactly), the 3 x 3 partial products are exact in fp32 and accumulate in fp32, so the result is a
+ * re-ordered fp32 summation of the same products the f32 path forms (9 bf16 MFMAs instead of 8 f32 MFMAs at 1/16 of the
+ * rate).  x_exact_bf16 != 0 promises that every X value is exactly representable in bf16 (0/1 piano-roll frames, any
+ * uint8): those rows then need one piece.  The products leave as split-K slabs: ws >= clv_lstm_wgrad_workspace_bytes,
+ * and like the *_deferred GEMMs the final sums (C = beta*C + sum) are formed by the reduction, now (job == NULL) or by
+ * clv_splitk_reduce_multi.  Limits (clv_lstm_wgrad_supported): N == 352; nx <= 96, nh + nz <= 128, nz <= 32; nx, nh,
+ * ldx, ldh, lddz multiples of 4, 16-byte aligned bases; more than 96 rows of H and Z together need x_exact_bf16. */
+int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16);
+size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz);
+int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+                   const float* H, int ldh, int nh, int h_shift, int h_zero_period,
+                   const float* Z, int ldz, int nz, const float* dz, int lddz,
+                   float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
+                   void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
+
 
 /* column sums: out[N] = (beta ? out : 0) + sum_m X[m, n]   (bias gradients) */
 size_t clv_colsum_workspace_bytes(int M, int N);

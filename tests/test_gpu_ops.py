@@ -496,3 +496,47 @@ def test_sparse_proj2_matches_two_single_launches(dev):
     torch.cuda.synchronize()
     assert torch.equal(o[0], o[2]) and torch.equal(o[1], o[3])
     np.testing.assert_allclose(o[1].cpu().numpy(), Xb[:, :70].astype(np.float64) @ Kb, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,Tn,nz,exact,defer", [(4096, 128, 0, True, False), (4096, 64, 2, True, True),
+                                                 (1000, 8, 8, False, False), (333 * 3, 3, 2, False, True),
+                                                 (32768, 128, 2, True, True), (8192, 256, 32, True, False),
+                                                 (96, 96, 0, False, False)])
+def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer):
+    """clv_lstm_wgrad: dKx = X^T dz, dU = H'^T dz (h of the previous step, zero at window starts), dKz = Z^T dz as
+    split-bf16 exact products; vs fp64 numpy.  The error is that of an fp32 summation (no product rounding at all)."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(K + nz)
+    N, nx, nh = 352, 88, 88
+    ldx = 92 if nz else 88
+    XZ = np.zeros((K, ldx), np.float32)
+    XZ[:, :nx] = (rng.random((K, nx)) < 0.0443) if exact else rng.standard_normal((K, nx))
+    if nz:
+        XZ[:, nx:nx + min(nz, ldx - nx)] = rng.standard_normal((K, min(nz, ldx - nx)))
+    Zsrc = XZ[:, nx:] if nz <= ldx - nx else rng.standard_normal((K, nz)).astype(np.float32)
+    hs = np.tanh(rng.standard_normal((K, nh))).astype(np.float32)
+    dz = (rng.standard_normal((K, N)) * np.exp(rng.standard_normal((K, 1)) * 2)).astype(np.float32)   # wide dynamic range
+    Hs = np.zeros_like(hs)
+    Hs[1:] = hs[:-1]
+    Hs[::Tn] = 0
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    tXZ, ths, tdz = d(XZ), d(hs), d(dz)
+    tZ = tXZ[:, nx:] if nz <= ldx - nx else d(Zsrc)
+    ldz = ldx if nz <= ldx - nx else nz
+    gx = torch.full((nx, N), 7.0, device=dev)
+    gu = torch.full((nh, N), 7.0, device=dev)
+    gz = torch.full((max(nz, 1), N), 7.0, device=dev)
+    ws = ops.Workspace(dev)
+    rq = ops.ReduceQueue(dev) if defer else None
+    assert ops.lstm_wgrad_supported(N, nx, nh, nz, exact)
+    ops.lstm_wgrad(K, N, tXZ, ldx, nx, exact, ths, nh, nh, Tn, tZ if nz else None, ldz, nz, tdz, gx, gu,
+                   gz if nz else None, ws, defer=rq)
+    if defer:
+        rq.flush()
+    torch.cuda.synchronize()
+    f8 = lambda a: a.astype(np.float64)
+    for got, A in ((gx, XZ[:, :nx]), (gu, Hs)) + (((gz, Zsrc[:, :nz]),) if nz else ()):
+        ref = f8(A).T @ f8(dz)
+        mag = np.abs(f8(A)).T @ np.abs(f8(dz)) + 1e-30
+        err = np.abs(got.cpu().numpy() - ref) / mag
+        assert err.max() < 2e-6, err.max()          # fp32 accumulation of exact products over K terms

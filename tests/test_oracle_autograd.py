@@ -6,45 +6,11 @@ import torch
 from oracle import clvae_oracle as O
 
 
+from oracle import torch_cpu as TC
+
+
 def _t(a):
     return torch.tensor(a, dtype=torch.float64, requires_grad=True)
-
-
-def _hs(z):
-    return torch.clamp(0.2 * z + 0.5, 0.0, 1.0)
-
-
-def _bce(a, y):
-    l = torch.clamp(a, -O.LOGIT_CLIP_HI, O.LOGIT_CLIP_HI)
-    return (torch.clamp(l, min=0) - l * y + torch.log1p(torch.exp(-l.abs()))).sum(-1)
-
-
-def _cce(w, y, scale):
-    q = w + O.W2_SHIFT
-    n = q / q.sum(-1, keepdim=True)
-    return -scale * (y * torch.log(torch.clamp(n, O.EPS_K, 1 - O.EPS_K))).sum(-1)
-
-
-def _logitnormal(m, lv, eps):
-    s = m + torch.exp(lv / 2) * eps
-    s0 = torch.cat([s, torch.zeros_like(s[..., :1])], -1)
-    e = torch.exp(s0)
-    return e / e.sum(-1, keepdim=True)
-
-
-def _lstm(xs, k, r, b, act):
-    B, T, _ = xs.shape
-    H = r.shape[0]
-    h = torch.zeros(B, H, dtype=xs.dtype)
-    c = torch.zeros(B, H, dtype=xs.dtype)
-    outs = []
-    for t in range(T):
-        z = xs[:, t] @ k + b + h @ r
-        i, f, g, o = act(z[:, :H]), act(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), act(z[:, 3 * H:])
-        c = f * c + i * g
-        h = o * torch.tanh(c)
-        outs.append(h)
-    return torch.stack(outs, 1)
 
 
 @pytest.mark.parametrize("use_x_prev", [True, False])
@@ -65,23 +31,8 @@ def test_vae_grads_match_autograd(use_x_prev):
 
     tp = {k: _t(v) for k, v in p.items()}
     X, XP, WT, EW, EZ = map(lambda a: torch.tensor(a), (x, xp, wt, ew, ez))
-    hw = torch.relu(X @ tp['h_w/kernel'] + tp['h_w/bias'])
-    wm = hw @ tp['w_mean/kernel'] + tp['w_mean/bias']
-    wlv = hw @ tp['w_log_var/kernel'] + tp['w_log_var/bias']
-    w = _logitnormal(wm, wlv, EW)
-    h = torch.relu(torch.cat([X, w], -1) @ tp['h/kernel'] + tp['h/bias'])
-    zm = h @ tp['z_mean/kernel'] + tp['z_mean/bias']
-    zlv = h @ tp['z_log_var/kernel'] + tp['z_log_var/bias']
-    z = zm + torch.exp(zlv / 2) * EZ
-    wz = torch.cat([w, XP, z], -1) if use_x_prev else torch.cat([w, z], -1)
-    hd = torch.relu(wz @ tp['decoder_h/kernel'] + tp['decoder_h/bias'])
-    a = hd @ tp['x_decoded_mean/kernel'] + tp['x_decoded_mean/bias']
-    pr = cfg['w_log_var_prior']
-    vae = _bce(a, X).mean()
-    klz = (-0.5 * (1 + zlv - zm ** 2 - torch.exp(zlv)).sum(-1)).mean()
-    wrec = _cce(w, WT, C - 1).mean()
-    klw = (-0.5 * (1 - pr + wlv - torch.exp(wlv) / np.exp(pr) - wm ** 2 / np.exp(pr)).sum(-1)).mean()
-    total = vae + cfg['w_kl_weight'] * klw + cfg['class_weight'] * wrec + cfg['kl_weight'] * klz
+    ls, a = TC.vae_graph(tp, cfg, X, XP, WT, EW, EZ)
+    total, vae, klw = ls['total'], ls['vae'], ls['kl_w']
     total.backward()
     assert abs(total.item() - out['total']) < 1e-10
     assert abs(vae.item() - out['vae']) < 1e-10 and abs(klw.item() - out['kl_w']) < 1e-10
@@ -109,26 +60,8 @@ def test_vrnn_grads_match_autograd(use_x_prev, gate_act):
 
     tp = {k: _t(v) for k, v in p.items()}
     tX, tXp, tW, teW, teZ = map(lambda a: torch.tensor(a), (X, Xp, wt, eW, eZ))
-    act = _hs if gate_act == 'hard_sigmoid' else torch.sigmoid
-    hW = torch.relu(tX.reshape(B, -1) @ tp['hW/kernel'] + tp['hW/bias'])
-    wa = hW @ tp['Wargs/kernel'] + tp['Wargs/bias']
-    wm, wlv = wa[:, :C - 1], wa[:, C - 1:]
-    W = _logitnormal(wm, wlv, teW)
-    Wrep = W[:, None, :].expand(B, T, C)
-    eh = _lstm(torch.cat([tX, Wrep], -1), tp['encoder_h/kernel'], tp['encoder_h/recurrent_kernel'],
-               tp['encoder_h/bias'], act)
-    zm = eh @ tp['Z_mean/kernel'] + tp['Z_mean/bias']
-    zlv = eh @ tp['Z_log_var/kernel'] + tp['Z_log_var/bias']
-    Z = zm + torch.exp(zlv / 2) * teZ
-    din = torch.cat([tXp, Z, Wrep], -1) if use_x_prev else torch.cat([Z, Wrep], -1)
-    dh = _lstm(din, tp['decoder_h/kernel'], tp['decoder_h/recurrent_kernel'], tp['decoder_h/bias'], act)
-    a = dh @ tp['X_decoded_mean/kernel'] + tp['X_decoded_mean/bias']
-    pr = cfg['w_log_var_prior']
-    vae = _bce(a, tX).mean()
-    klz = (-0.5 * (1 + zlv - zm ** 2 - torch.exp(zlv)).sum(-1)).mean()
-    wrec = _cce(W, tW, C - 1).mean()
-    klw = (-0.5 * (1 - pr + wlv - torch.exp(wlv) / np.exp(pr) - wm ** 2 / np.exp(pr)).sum(-1)).mean()
-    total = vae + cfg['w_kl_weight'] * klw + cfg['class_weight'] * wrec + cfg['kl_weight'] * klz
+    ls, a = TC.vrnn_graph(tp, cfg, tX, tXp, tW, teW, teZ)
+    total = ls['total']
     total.backward()
     assert abs(total.item() - out['total']) < 1e-10
     np.testing.assert_allclose(a.detach().numpy(), out['cache']['logits'], atol=1e-12)
@@ -151,6 +84,30 @@ def test_lstm_matches_torch_nn_lstm_with_sigmoid_gates():
         m.bias_ih_l0.copy_(torch.tensor(b)); m.bias_hh_l0.zero_()
         ref, _ = m(torch.tensor(xs))
     np.testing.assert_allclose(hs, ref.numpy(), atol=1e-12)
+
+
+def test_torch_adam_wn_tracks_the_numpy_oracle():
+    """The torch Adam-WN of the CPU baseline == oracle.adam_wn_step over three steps (fp64)."""
+    rng = np.random.default_rng(4)
+    p = {'a/kernel': rng.standard_normal((7, 5)), 'a/bias': rng.standard_normal(5), 'b/kernel': rng.standard_normal((5, 3))}
+    tp = {k: _t(v.copy()) for k, v in p.items()}
+    st, opt = O.adam_wn_init(p), TC.AdamWN(tp)
+    for _ in range(3):
+        g = {k: rng.standard_normal(v.shape) for k, v in p.items()}
+        O.adam_wn_step(p, g, st)
+        for k in tp:
+            tp[k].grad = torch.tensor(g[k])
+        opt.step(tp)
+    for k in p:
+        np.testing.assert_allclose(tp[k].detach().numpy(), p[k], rtol=1e-10, atol=1e-12, err_msg=k)
+
+
+def test_cpu_baseline_timer_runs():
+    cfg = O.vrnn_config(latent_dim=2, seq_length=4, n_classes=3, use_x_prev=True)
+    r = TC.time_training_steps('cl_vrnn', cfg, B=4, T=4, seconds=0.5, min_steps=2, warmup=1)
+    assert r['steps'] >= 2 and r['timesteps_per_s'] > 0 and r['threads'] >= 1
+    cfg = O.vae_config(latent_dim=2, n_classes=3, use_x_prev=True)
+    assert TC.time_training_steps('cl_vae', cfg, B=8, T=1, seconds=0.5, min_steps=2, warmup=1)['steps'] >= 2
 
 
 def test_adam_wn_first_step_keeps_weightnorm_invariants():
