@@ -307,16 +307,32 @@ def main():
             n, ms = by[kname][1], by[kname][2]
             avg_s = ms / n * 1e-3
             achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
-        traffic = None       # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_%s.json' % args.workload)))
-            traffic = round(pm.get('dominant_bytes_per_launch', pm.get('lstm_seq_bytes_per_launch'))) if w['model'] == 'cl_vrnn' else None
-        except Exception:
-            pass
+        traffic = step_traffic = None    # HBM bytes from the committed PMC passes (tools/pmc_traffic.sh -> profiles/)
+        for tag in ('r02', 'r01'):
+            try:
+                pm = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (tag, args.workload))))
+            except Exception:
+                continue
+            if w['model'] == 'cl_vrnn':
+                traffic = round(pm.get('dominant_bytes_per_launch', pm.get('lstm_seq_bytes_per_launch')))
+            step_traffic = pm.get('step_bytes')
+            break
         roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=kname,
                         avg_launch_us=round(avg_s * 1e6, 2),
-                        whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4))
+                        whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4),
+                        step_traffic=step_traffic)
+        if 'lstm_wgrad_bf16' in by:
+            # the batched gate GEMM of the north star: every kernel gradient of an LSTM, [x | h | z]^T . dz over B*T rows
+            # (csrc/wgrad_bf16.hip).  Algorithmic flops of the products / its launch time, against the fp32 matrix peak
+            # (the products are exact fp32 products formed from bf16 pieces on the bf16 matrix cores).
+            gn, gms = by['lstm_wgrad_bf16'][1], by['lstm_wgrad_bf16'][2]
+            rows = (88 + 88) + (88 + w['L'] + 88)
+            gflop = 2.0 * rows * 352 * B * w['T'] * reps
+            roofline['gate_gemm'] = dict(kernel='lstm_wgrad_bf16', avg_launch_us=round(gms / gn * 1e3, 2),
+                                         achieved=round(gflop / (gms * 1e-3) / 1e12, 2), peak=PEAK_F32_TFLOPS,
+                                         frac=round(gflop / (gms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4), unit="TFLOP/s",
+                                         arithmetic="exact fp32 products from 3 bf16 pieces per operand, fp32 accumulate")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -47,18 +47,31 @@ __device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int 
     s_eps[j] = j < C1 ? a.eps[(size_t)b * C1 + j] : 0.f;
     s_oh[j] = a.onehot ? a.onehot[(size_t)b * a.C + j] : 0.f;
   }
-  if (tid < NA) {
-    // 8 kernel rows in flight (a one-load-per-iteration loop pays an L2 round trip per row: 88 of them)
-    float acc = a.ba[tid];
-    for (int k0 = 0; k0 < a.D; k0 += 8) {
-      float kv[8];
+  {
+    // Wargs = hW . K_a + b_a: [D] x [D, NA] with NA <= 62.  All NT threads take part: thread = (column, k-slice), every
+    // thread's few kernel elements are requested at once (one L2 round trip for the layer; a column per thread walks D
+    // rows in dependent batches), partial sums meet in LDS.
+    __shared__ float s_part[16][2 * LH_MAXC];
+    constexpr int KSL = NT / 64 < 16 ? NT / 64 : 16;       // k-slices: one per wave (6 or 16)
+    const int col = tid & 63, sl = tid >> 6;
+    if (sl < KSL) {
+      float kv[(128 + KSL - 1) / KSL];
+      const int cc = min(col, NA - 1);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) kv[q] = a.Ka[(size_t)min(k0 + q, a.D - 1) * NA + tid];
+      for (int i = 0; i < (128 + KSL - 1) / KSL; ++i) kv[i] = a.Ka[(size_t)min(sl + KSL * i, a.D - 1) * NA + cc];
+      float acc = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc = fmaf(k0 + q < a.D ? s_h[k0 + q] : 0.f, kv[q], acc);
+      for (int i = 0; i < (128 + KSL - 1) / KSL; ++i) acc = fmaf(sl + KSL * i < a.D ? s_h[sl + KSL * i] : 0.f, kv[i], acc);
+      if (col < NA) s_part[sl][col] = acc;
     }
-    s_wargs[tid] = acc;
-    a.wargs[(size_t)b * NA + tid] = acc;
+    __syncthreads();
+    if (tid < NA) {
+      float acc = a.ba[tid];
+#pragma unroll
+      for (int i = 0; i < KSL; ++i) acc += s_part[i][tid];
+      s_wargs[tid] = acc;
+      a.wargs[(size_t)b * NA + tid] = acc;
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -150,30 +163,34 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   const float* xr = ax.X + (size_t)b * ax.ldx;
   float2 acc = make_float2(0.f, 0.f);
   const int nchunk = (ax.nx + 63) / 64;
-  float xn = 0.f;
-  if (wave < nchunk) xn = xr[min(wave * 64 + lane, ax.nx - 1)];
-  for (int ch = wave; ch < nchunk; ch += 16) {
-    const float x = xn;
-    const int j0 = ch * 64;
-    if (ch + 16 < nchunk) xn = xr[min((ch + 16) * 64 + lane, ax.nx - 1)];
-    unsigned long long m = __ballot(j0 + lane < ax.nx && x != 0.f);
-    while (m) {
-      int kk[4];
-      float vv[4];
+  // Two chunks of 64 inputs per iteration: their kernel rows (up to 4 each per round) are requested together, so a
+  // wave pays one L2 round trip per PAIR of chunks (a window row has 176 chunks, 11 per wave).
+  auto xload = [&](int ch) { return ch < nchunk ? xr[min(ch * 64 + lane, ax.nx - 1)] : 0.f; };
+  float xa = xload(wave), xb = xload(wave + 16);
+  for (int ch = wave; ch < nchunk; ch += 32) {
+    const float x0 = xa, x1 = xb;
+    const int j0 = ch * 64, j1 = (ch + 16) * 64;
+    xa = xload(ch + 32); xb = xload(ch + 48);
+    unsigned long long m0 = __ballot(j0 + lane < ax.nx && x0 != 0.f);
+    unsigned long long m1 = __ballot(ch + 16 < nchunk && j1 + lane < ax.nx && x1 != 0.f);
+    while (m0 | m1) {
+      int kk[8];
+      float vv[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 8; ++q) {
+        unsigned long long& m = q < 4 ? m0 : m1;
         const bool on = m != 0;
         const int bit = on ? __builtin_ctzll(m) : 0;
         m = on ? (m & (m - 1)) : 0;
-        kk[q] = j0 + bit;
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), bit));
+        kk[q] = (q < 4 ? j0 : j1) + bit;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q < 4 ? x0 : x1), bit));
         vv[q] = on ? v : 0.f;
       }
-      float2 kr[4];
+      float2 kr[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) kr[q] = K2[(size_t)min(kk[q], ax.nx - 1) * n2 + lc];
+      for (int q = 0; q < 8; ++q) kr[q] = K2[(size_t)min(kk[q], ax.nx - 1) * n2 + lc];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
+      for (int q = 0; q < 8; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
     }
   }
   part[wave][lane] = acc;
@@ -256,24 +273,23 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
     s_dw[tid] = v;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (wave == 0) {
+    // label backward of the row, one class per lane (cl_vrnn/model.py:244-252 through the logistic-normal sample):
+    // three wave sums instead of a serial walk over the classes by one thread
     const float ep = __expf(a.prior);
-    float wv[LH_MAXC], dn[LH_MAXC], d[LH_MAXC];
-    float qs = 0.f, dot = 0.f, dsum = 0.f;
-    for (int j = 0; j < a.C; ++j) { wv[j] = s_wv[j]; qs += wv[j] + LW2; }
-    for (int j = 0; j < a.C; ++j) {
-      const float n = (wv[j] + LW2) / qs;
-      const bool inside = (n >= LEPS_K) && (n <= 1.f - LEPS_K);
-      const float nc = fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K);
-      dn[j] = inside ? -(float)C1 * s_oh[j] / nc : 0.f;
-      dot += dn[j] * n;
-    }
-    for (int j = 0; j < a.C; ++j) {
-      d[j] = s_dw[j] + a.class_weight * a.inv_b * ((dn[j] - dot) / qs);
-      dsum += d[j] * wv[j];
-    }
-    for (int j = 0; j < C1; ++j) {
-      const float ds = wv[j] * (d[j] - dsum);
+    const int j = lane;
+    const bool in = j < a.C;
+    const float w = in ? s_wv[j] : 0.f;
+    const float qs = wave_sum(in ? w + LW2 : 0.f);
+    const float n = (w + LW2) / qs;
+    const bool inside = (n >= LEPS_K) && (n <= 1.f - LEPS_K);
+    const float nc = fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K);
+    const float dn = (in && inside) ? -(float)C1 * s_oh[j] / nc : 0.f;
+    const float dot = wave_sum(dn * n);
+    const float d = in ? s_dw[j] + a.class_weight * a.inv_b * ((dn - dot) / qs) : 0.f;
+    const float dsum = wave_sum(d * w);
+    if (j < C1) {
+      const float ds = w * (d - dsum);
       const float m = s_wa[j], lv = s_wa[C1 + j];
       const float sd = expf(0.5f * lv);
       const float dm = ds + a.w_kl_weight * a.inv_b * (m / ep);
@@ -287,12 +303,12 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
   if (tid < a.D) {
     float acc = 0.f;
     const float hv = a.hW[(size_t)b * a.D + tid];
-    for (int j0 = 0; j0 < NA; j0 += 8) {            // 8 loads in flight
-      float kv[8];
+    for (int j0 = 0; j0 < NA; j0 += 32) {           // 32 loads in flight: one round trip for up to 17 classes
+      float kv[32];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) kv[q] = a.Ka[(size_t)tid * NA + min(j0 + q, NA - 1)];
+      for (int q = 0; q < 32; ++q) kv[q] = a.Ka[(size_t)tid * NA + min(j0 + q, NA - 1)];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc = fmaf(j0 + q < NA ? s_dwa[j0 + q] : 0.f, kv[q], acc);
+      for (int q = 0; q < 32; ++q) acc = fmaf(j0 + q < NA ? s_dwa[j0 + q] : 0.f, kv[q], acc);
     }
     a.dhW[(size_t)b * a.D + tid] = hv > 0.f ? acc : 0.f;
   }

@@ -16,7 +16,10 @@
 
 namespace clv {
 
-constexpr int UNIT_ROWS = 16;
+#ifndef CLV_ADAM_UNIT_ROWS
+#define CLV_ADAM_UNIT_ROWS 16
+#endif
+constexpr int UNIT_ROWS = CLV_ADAM_UNIT_ROWS;
 constexpr int SM_RL = 16, SM_RMAX = 8;        // fused small-tensor kernel: 16 row lanes x 8 rows = matrices of <= 128 rows
 constexpr int SM_ROWS = SM_RL * SM_RMAX;
 

@@ -28,8 +28,12 @@ for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) * 2 + sum(w.
                      hbm_read_bytes_corrected=2 * 1024 * sum(fk) / len(fk), hbm_write_bytes=1024 * sum(wk) / len(wk)))
 dom = [r for r in rows if re.match(r'lstm_(pair_)?(fwd|bwd)_kernel', r['kernel'])]      # the kernels bench.py's roofline times
 per_launch = sum(r['hbm_read_bytes_corrected'] + r['hbm_write_bytes'] for r in dom) / max(len(dom), 1)
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 9          # steps the profiled run executed (warm-up + timed)
+step_bytes = sum((r['hbm_read_bytes_corrected'] + r['hbm_write_bytes']) * r['launches'] for r in rows) / steps
 json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --no-graph); FETCH_SIZE x2 "
                     "(gfx950 reports half of the bytes read), both KB -> bytes x1024 (MI355X_MICROARCH.md)",
                workload=workload, dominant_kernels=[r['kernel'] for r in dom], dominant_bytes_per_launch=per_launch,
+               step_bytes=step_bytes, steps_profiled=steps,
                kernels=rows), open(out, 'w'), indent=1)
+print("HBM bytes per step %.0f" % step_bytes)
 print("dominant kernels:", [r['kernel'][:40] for r in dom], "bytes/launch %.0f" % per_launch)
