@@ -103,6 +103,16 @@ def cpu_baseline(w, seconds=20.0):
         cfg = O.vrnn_config(latent_dim=L, seq_length=T, n_classes=C, use_x_prev=True)
     else:
         cfg = O.vae_config(latent_dim=L, n_classes=C, use_x_prev=True)
+    # torch's default of one thread per hardware thread oversubscribes these small matmuls on a many-core host (the
+    # 256-thread GPU box ran 8x slower with 128 threads than an 8-core container): try a few pool sizes on two steps each
+    # and time the fastest
+    best = None
+    for n in sorted({n for n in (8, 16, 32, 64, torch.get_num_threads()) if n <= (os.cpu_count() or 1)}):
+        torch.set_num_threads(n)
+        probe = TC.time_training_steps(w['model'], cfg, B, T, seconds=0.0, min_steps=2, warmup=1)
+        if best is None or probe['timesteps_per_s'] > best[1]:
+            best = (n, probe['timesteps_per_s'])
+    torch.set_num_threads(best[0])
     r = TC.time_training_steps(w['model'], cfg, B, T, seconds=seconds)
     return dict(value=r['timesteps_per_s'], unit="timesteps/s", cores=int(r['threads']), kind="port",
                 sample="%d timed steps (median) of batch %d x seq_len %d after 3 warm-up steps; CPU restatement "
@@ -295,7 +305,7 @@ def main():
         if w['model'] == 'cl_vrnn':
             # dominant kernel: the persistent LSTM sequence kernels (fwd+bwd, 2 LSTMs each)
             # (one launch = one LSTM pass, or both LSTMs of a pass when the pair kernels run): 4 LSTM passes per step
-            names = sorted(k for k in by if k.startswith('lstm_') and not k.endswith('_pack'))
+            names = sorted(k for k in by if k.startswith(('lstm_pair_', 'lstm_seq_')) and not k.endswith('_pack'))
             n = sum(by[k][1] for k in names)
             ms = sum(by[k][2] for k in names)
             avg_s = ms / n * 1e-3

@@ -86,15 +86,17 @@ class ClVaeModel(Model):
         # model.layers in the topological order Keras reports for cl_vae/model.py:136-209
         L = lambda n, w=(), c='Dense': Layer(n, self, w, c)
         kb = ('kernel', 'bias')
+        hidden = engine.cfg['H'] > 0       # intermediate_dim == 0: no `h` / `decoder_h` layers (reference :165-167,188)
         order = [L('x', c='InputLayer'), L('h_w', kb), L('w_mean', kb), L('w_log_var', kb), L('w', c='Lambda'),
-                 L('concatenate_1', c='Concatenate'), L('h', kb), L('z_mean', kb), L('z_log_var', kb)]
+                 L('concatenate_1', c='Concatenate')] + ([L('h', kb)] if hidden else []) + [L('z_mean', kb), L('z_log_var', kb)]
         if use_x_prev:
             order += [L('history', c='InputLayer')]
         order += [L('z', c='Lambda')]
         if use_x_prev:
             order += [L('concatenate_2', c='Concatenate')]
-        order += [L('concatenate_3' if use_x_prev else 'concatenate_2', c='Concatenate'), L('decoder_h', kb),
-                  L('x_decoded_mean', kb), L('w2', c='Lambda'), L('z_args', c='Concatenate')]
+        order += [L('concatenate_3' if use_x_prev else 'concatenate_2', c='Concatenate')] \
+            + ([L('decoder_h', kb)] if hidden else []) \
+            + [L('x_decoded_mean', kb), L('w2', c='Lambda'), L('z_args', c='Concatenate')]
         self.layers = order
 
     def _split_inputs(self, x, y):

@@ -173,8 +173,19 @@ __global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol
 __device__ __forceinline__ void wn_update_body(const AdamUnit& un, int unit_idx, float* params, const float* grads,
                                                float* m, float* v, const float* colscal,
                                                const int32_t* colidx0, float* partC, const AdamHyper& h) {
-  if (un.small && h.weightnorm) return;   // done by the small-tensor blocks
+  if (un.small && h.weightnorm == CLV_OPT_ADAM_WN) return;   // done by the small-tensor blocks
   const float lr_t = adam_lr_t(h);
+  if (h.weightnorm == CLV_OPT_RMSPROP) {  // Keras RMSprop: a = rho a + (1 - rho) g^2 ; p -= lr g / (sqrt(a) + eps)
+    const int n = un.nrows * un.cols;
+    const size_t base = un.offset + (size_t)un.row0 * un.cols;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float g = grads[base + i];
+      const float an = h.b2 * v[base + i] + (1.f - h.b2) * g * g;
+      v[base + i] = an;
+      params[base + i] -= h.lr * g / (sqrtf(an) + h.eps);
+    }
+    return;
+  }
   if (!un.is_matrix || !h.weightnorm) {   // plain Adam (biases; everything when weightnorm is off)
     const int n = un.nrows * un.cols;
     const size_t base = un.offset + (size_t)un.row0 * un.cols;
@@ -439,7 +450,8 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
                                 int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
                                 int weightnorm, void* ws, size_t ws_bytes, void* stream) {
   if (!host_table || n_tensors <= 0 || !plan_dev || !params || !grads || !m || !v) return CLV_EINVAL;
-  if (weightnorm && (!mg || !vg || !s)) return CLV_EINVAL;
+  if (weightnorm < 0 || weightnorm > CLV_OPT_RMSPROP) return CLV_EINVAL;
+  if (weightnorm == CLV_OPT_ADAM_WN && (!mg || !vg || !s)) return CLV_EINVAL;
   PlanCounts c = plan_counts(host_table, n_tensors);
   if (!ws || ws_bytes < clv_adam_wn_workspace_bytes(host_table, n_tensors)) return CLV_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -460,7 +472,7 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   // tensors, advances it)
   int32_t* bump = (iterations_dev && step_t == -1) ? nullptr : iterations_dev;
   ProfScope pr("adam_wn_step", st);
-  const bool wn = weightnorm && c.n_cols > 0;
+  const bool wn = weightnorm == CLV_OPT_ADAM_WN && c.n_cols > 0;
   const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything
   const int n_small = wn ? c.n_small : 0;     // small matrices and biases: whole update in their own blocks of K3
   if (wn && chain) {

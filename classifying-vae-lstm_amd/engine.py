@@ -23,19 +23,22 @@ from .ops import ACT_MASKPOS, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 
 def vae_param_shapes(cfg):
-    """Keras layer order of cl_vae.get_model (cl_vae/model.py:141-186)."""
+    """Keras layer order of cl_vae.get_model (cl_vae/model.py:141-188).  intermediate_dim == 0 (:165-167,188): no `h`
+    and no `decoder_h` layer, the latent heads read [x, w] and the output layer reads [w, (history,) z]."""
     D, H, L, Hc, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
-    if H <= 0:
-        raise ValueError("intermediate_dim must be > 0")
     dec_in = Cn + (D if cfg['use_x_prev'] else 0) + L
-    return [('h_w/kernel', (D, Hc)), ('h_w/bias', (Hc,)),
+    head = [('h_w/kernel', (D, Hc)), ('h_w/bias', (Hc,)),
             ('w_mean/kernel', (Hc, Cn - 1)), ('w_mean/bias', (Cn - 1,)),
-            ('w_log_var/kernel', (Hc, Cn - 1)), ('w_log_var/bias', (Cn - 1,)),
-            ('h/kernel', (D + Cn, H)), ('h/bias', (H,)),
-            ('z_mean/kernel', (H, L)), ('z_mean/bias', (L,)),
-            ('z_log_var/kernel', (H, L)), ('z_log_var/bias', (L,)),
-            ('decoder_h/kernel', (dec_in, H)), ('decoder_h/bias', (H,)),
-            ('x_decoded_mean/kernel', (H, D)), ('x_decoded_mean/bias', (D,))]
+            ('w_log_var/kernel', (Hc, Cn - 1)), ('w_log_var/bias', (Cn - 1,))]
+    if H > 0:
+        return head + [('h/kernel', (D + Cn, H)), ('h/bias', (H,)),
+                       ('z_mean/kernel', (H, L)), ('z_mean/bias', (L,)),
+                       ('z_log_var/kernel', (H, L)), ('z_log_var/bias', (L,)),
+                       ('decoder_h/kernel', (dec_in, H)), ('decoder_h/bias', (H,)),
+                       ('x_decoded_mean/kernel', (H, D)), ('x_decoded_mean/bias', (D,))]
+    return head + [('z_mean/kernel', (D + Cn, L)), ('z_mean/bias', (L,)),
+                   ('z_log_var/kernel', (D + Cn, L)), ('z_log_var/bias', (L,)),
+                   ('x_decoded_mean/kernel', (dec_in, D)), ('x_decoded_mean/bias', (D,))]
 
 
 def vrnn_param_shapes(cfg):
@@ -252,27 +255,27 @@ class VaeEngine(_EngineBase):
         d = self.device
         self.xoff = D if cfg['use_x_prev'] else 0      # decoder_h kernel rows: [w | xp | z]
         L_ = _lib.lib()
-        self.fused = bool(cfg.get('fused_step', True)) and bool(L_.clv_vae_fused_supported(D, H, Hc, Cn, L))
+        self.fused = H > 0 and bool(cfg.get('fused_step', True)) and bool(L_.clv_vae_fused_supported(D, H, Hc, Cn, L))
         names = ['h_w', 'wargs', 'h', 'zargs', 'decoder_h', 'x_decoded_mean']
-        self._offs = (C.c_int64 * 12)(*[self.P.offsets['%s/%s' % (n, w)] for n in names for w in ('kernel', 'bias')])
+        self._offs = (C.c_int64 * 12)(*[self.P.offsets.get('%s/%s' % (n, w), 0) for n in names for w in ('kernel', 'bias')])
         self._fused_ws = torch.empty(max(L_.clv_vae_fused_workspace_bytes(B, self.P.n), 16), dtype=torch.uint8,
                                      device=self.device) if self.fused else None
         self.h_w = _f(d, B, Hc)
         self.wargs = _f(d, B, 2 * (Cn - 1))          # [w_mean | w_log_var]
         self.w = _f(d, B, Cn)
         self.rowloss = _f(d, B, 3)
-        self.h = _f(d, B, H)
+        self.h = _f(d, B, max(H, 1))
         self.zargs = _f(d, B, 2 * L)
         self.z = _f(d, B, L)
-        self.h_dec = _f(d, B, H)
+        self.h_dec = _f(d, B, max(H, 1))
         self.logits = _f(d, B, D)
         self.dlogits = _f(d, B, D)
         self.rownll = _f(d, B)
         self.rowkl = _f(d, B)
-        self.d_hdec = _f(d, B, H)
+        self.d_hdec = _f(d, B, max(H, 1))
         self.dz = _f(d, B, L)
         self.dzargs = _f(d, B, 2 * L)
-        self.d_h = _f(d, B, H)
+        self.d_h = _f(d, B, max(H, 1))
         self.dw = _f(d, B, Cn)
         self.dwargs = _f(d, B, 2 * (Cn - 1))
         self.d_hw = _f(d, B, Hc)
@@ -293,6 +296,10 @@ class VaeEngine(_EngineBase):
         B = self.B if B is None else B
         D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
         g = ops.gemm
+        if H == 0:      # :165-167: the latent heads on [x, w] directly
+            g(x, P.p('zargs/kernel'), self.zargs, B, 2 * L, D, ws=self.ws)
+            g(w, P.rows(P.params, 'zargs/kernel', D), self.zargs, B, 2 * L, Cn, beta=1.0, bias=P.p('zargs/bias'), ws=self.ws)
+            return
         g(x, P.p('h/kernel'), self.h, B, H, D, ws=self.ws)
         g(w, P.rows(P.params, 'h/kernel', D), self.h, B, H, Cn, beta=1.0, bias=P.p('h/bias'), act=ACT_RELU,
           ws=self.ws)
@@ -304,6 +311,14 @@ class VaeEngine(_EngineBase):
         B = self.B if B is None else B
         D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
         g = ops.gemm
+        if H == 0:      # :188: the output layer on [w, (history,) z] directly
+            K = 'x_decoded_mean/kernel'
+            g(w, P.p(K), self.logits, B, D, Cn, ws=self.ws)
+            if cfg['use_x_prev']:
+                g(xp, P.rows(P.params, K, Cn), self.logits, B, D, D, beta=1.0, ws=self.ws)
+            g(z, P.rows(P.params, K, Cn + self.xoff), self.logits, B, D, L, beta=1.0, bias=P.p('x_decoded_mean/bias'),
+              act=act, ws=self.ws)
+            return
         g(w, P.p('decoder_h/kernel'), self.h_dec, B, H, Cn, ws=self.ws)
         if cfg['use_x_prev']:
             g(xp, P.rows(P.params, 'decoder_h/kernel', Cn), self.h_dec, B, H, D, beta=1.0, ws=self.ws)
@@ -315,12 +330,16 @@ class VaeEngine(_EngineBase):
     def x_hat(self):
         """sigmoid(logits) of the last forward -> self.dlogits (the Keras output `x_decoded_mean`)."""
         cfg, P, B = self.cfg, self.P, self.B
+        if cfg['H'] == 0:       # no hidden decoder activations to restart from: run the output layer again with the sigmoid
+            self.decode(self.w, self.z, self._last_xp, act=ACT_SIGMOID)
+            return self.logits
         ops.gemm(self.h_dec, P.p('x_decoded_mean/kernel'), self.dlogits, B, cfg['D'], cfg['H'],
                  bias=P.p('x_decoded_mean/bias'), act=ACT_SIGMOID, ws=self.ws)
         return self.dlogits
 
     def forward(self, x, xp, eps_w, eps_z, w_true=None):
         cfg, B = self.cfg, self.B
+        self._last_xp = xp
         L, Cn = cfg['L'], cfg['C']
         C1 = Cn - 1
         self.encode_w(x)
@@ -402,6 +421,8 @@ class VaeEngine(_EngineBase):
         if not need_grads:
             return
         g, ws, xo = ops.gemm, self.ws, self.xoff
+        if H == 0:
+            return self._grads_without_hidden_layers(x, xp, w_true, eps_w, eps_z, inv)
         # decoder
         g(self.h_dec, self.dlogits, P.g('x_decoded_mean/kernel'), H, D, B, ta=True, ws=ws)
         ops.colsum(self.dlogits, B, D, P.g('x_decoded_mean/bias'), ws)
@@ -423,7 +444,14 @@ class VaeEngine(_EngineBase):
         g(self.w, self.d_h, P.rows(P.grads, 'h/kernel', D), Cn, H, B, ta=True, ws=ws)
         ops.colsum(self.d_h, B, H, P.g('h/bias'), ws)
         g(self.d_h, P.rows(P.params, 'h/kernel', D), self.dw, B, Cn, H, tb=True, beta=1.0, ws=ws)
-        # label head
+        self._label_head_grads(x, w_true, eps_w, inv)
+
+
+    def _label_head_grads(self, x, w_true, eps_w, inv):
+        """label head backward from self.dw (shared by both variants)"""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, Hc, Cn = cfg['D'], cfg['Hc'], cfg['C']
+        C1, g, ws = Cn - 1, ops.gemm, self.ws
         ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_w, w_true, self.w, self.dw,
                       cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv,
                       self.dwargs, self.dwargs[:, C1:], 2 * C1)
@@ -432,6 +460,26 @@ class VaeEngine(_EngineBase):
         g(self.dwargs, P.p('wargs/kernel'), self.d_hw, B, Hc, 2 * C1, tb=True, act=ACT_MASKPOS, aux=self.h_w, ws=ws)
         g(x, self.d_hw, P.g('h_w/kernel'), D, Hc, B, ta=True, ws=ws)
         ops.colsum(self.d_hw, B, Hc, P.g('h_w/bias'), ws)
+
+    def _grads_without_hidden_layers(self, x, xp, w_true, eps_w, eps_z, inv):
+        """Backward of the intermediate_dim == 0 graph (cl_vae/model.py:165-167,188): logits = [w, xp, z].K_o + b_o and
+        zargs = [x, w].K_z + b_z, no relu layers in between."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, L, Cn = cfg['D'], cfg['L'], cfg['C']
+        g, ws, xo, K = ops.gemm, self.ws, self.xoff, 'x_decoded_mean/kernel'
+        g(self.w, self.dlogits, P.g(K), Cn, D, B, ta=True, ws=ws)
+        if cfg['use_x_prev']:
+            g(xp, self.dlogits, P.rows(P.grads, K, Cn), D, D, B, ta=True, ws=ws)
+        g(self.z, self.dlogits, P.rows(P.grads, K, Cn + xo), L, D, B, ta=True, ws=ws)
+        ops.colsum(self.dlogits, B, D, P.g('x_decoded_mean/bias'), ws)
+        g(self.dlogits, P.p(K), self.dw, B, Cn, D, tb=True, ws=ws)
+        g(self.dlogits, P.rows(P.params, K, Cn + xo), self.dz, B, L, D, tb=True, ws=ws)
+        ops.gauss_bwd(B, L, self.zargs, eps_z, self.dz, L, self.kl_weight * inv, self.dzargs)
+        g(x, self.dzargs, P.g('zargs/kernel'), D, 2 * L, B, ta=True, ws=ws)
+        g(self.w, self.dzargs, P.rows(P.grads, 'zargs/kernel', D), Cn, 2 * L, B, ta=True, ws=ws)
+        ops.colsum(self.dzargs, B, 2 * L, P.g('zargs/bias'), ws)
+        g(self.dzargs, P.rows(P.params, 'zargs/kernel', D), self.dw, B, Cn, 2 * L, tb=True, beta=1.0, ws=ws)
+        self._label_head_grads(x, w_true, eps_w, inv)
 
 
 # --------------------------------------------------------------------------- #

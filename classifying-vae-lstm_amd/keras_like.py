@@ -116,7 +116,9 @@ class OptimizerSpec:
             return opt
         if opt in ('adam', 'adam-wn'):
             return OptimizerSpec(opt)
-        raise ValueError("optimizer %r is not supported on the HIP path (use 'adam-wn' or 'adam')" % (opt,))
+        if opt == 'rmsprop':          # Keras 2.0.0 defaults: lr 0.001, rho 0.9 (carried as beta_2), epsilon 1e-8
+            return OptimizerSpec('rmsprop', lr=1e-3, beta_2=0.9, epsilon=1e-8)
+        raise ValueError("optimizer %r is not supported on the HIP path (use 'adam-wn', 'adam' or 'rmsprop')" % (opt,))
 
 
 def _to_dev(a, dev):

@@ -32,9 +32,10 @@ class TrainStep:
                  lr=1e-3, use_graph=True):
         self.eng = engine
         self.seed, self.rank, self.world = int(seed), int(rank), int(world)
-        self.weightnorm = optimizer == 'adam-wn'
-        if optimizer not in ('adam-wn', 'adam'):
-            raise ValueError("optimizer %r is not supported on the HIP path (adam-wn, adam)" % optimizer)
+        if optimizer not in ('adam-wn', 'adam', 'rmsprop'):
+            raise ValueError("optimizer %r is not supported on the HIP path (adam-wn, adam, rmsprop)" % optimizer)
+        self.weightnorm = {'adam': 0, 'adam-wn': 1, 'rmsprop': 2}[optimizer]      # CLV_OPT_* of include/clvae.h
+        self.b2 = 0.9 if optimizer == 'rmsprop' else 0.999                       # rmsprop: rho
         self.lr = lr
         self.use_graph = use_graph
         cfg, B, d = engine.cfg, engine.B, engine.device
@@ -103,15 +104,15 @@ class TrainStep:
             self.eng.grads_tail(self.X)
 
     def _update(self):
-        self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm)
+        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm)
 
     # multi-GPU: the optimizer step in two pieces, the tail bucket's tensor first (its all-reduce has landed under
     # _tail()), the rest once the main bucket is in; `iterations` advances with the second piece
     def _update_tail(self):
-        self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm, only=self.tail_names, advance=False)
+        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.tail_names, advance=False)
 
     def _update_rest(self):
-        self.eng.P.adam_step(lr=self.lr, weightnorm=self.weightnorm, only=self.rest_names)
+        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.rest_names)
 
     # -- public -----------------------------------------------------------
     def _segments(self, cur, hist, w, target=None):

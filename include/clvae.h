@@ -411,6 +411,11 @@ size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tenso
  * (so a captured graph can be replayed); otherwise t = step_t.  iterations_dev with step_t == -1: the
  * counter is read but NOT advanced -- a step may be split over several calls on disjoint tensor subsets (each with its
  * own table and plan over the same flat buffers), of which only the last one advances the counter. */
+/* `weightnorm` selects the update rule: */
+#define CLV_OPT_ADAM     0   /* plain Keras Adam on every tensor                                                   */
+#define CLV_OPT_ADAM_WN  1   /* utils/weightnorm.py:75-143: matrices per output column as g V/||V||, biases plain   */
+#define CLV_OPT_RMSPROP  2   /* Keras RMSprop (the 'rmsprop' optimizer string, cl_vae/train.py:83): a = rho a +     */
+                             /* (1 - rho) g^2, p -= lr g / (sqrt(a) + eps); rho = beta2, `v` holds a, `m` is unused  */
 int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
                      float* params, const float* grads, float* m, float* v,
                      float* mg, float* vg, float* s,

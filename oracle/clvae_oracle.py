@@ -154,17 +154,22 @@ def vae_config(original_dim=88, intermediate_dim=88, latent_dim=2, intermediate_
 
 
 def vae_param_shapes(cfg):
+    """Keras layer/weight order.  intermediate_dim == 0 (cl_vae/model.py:165-167,188): no `h` and no `decoder_h`
+    layer -- the latent heads read [x, w] and the output layer reads [w, (history,) z] directly."""
     D, H, L, Hc, C = cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
-    assert H > 0, "intermediate_dim == 0 variant is not part of the hot path"
     dec_in = C + (D if cfg['use_x_prev'] else 0) + L
-    return [('h_w/kernel', (D, Hc)), ('h_w/bias', (Hc,)),
+    head = [('h_w/kernel', (D, Hc)), ('h_w/bias', (Hc,)),
             ('w_mean/kernel', (Hc, C - 1)), ('w_mean/bias', (C - 1,)),
-            ('w_log_var/kernel', (Hc, C - 1)), ('w_log_var/bias', (C - 1,)),
-            ('h/kernel', (D + C, H)), ('h/bias', (H,)),
-            ('z_mean/kernel', (H, L)), ('z_mean/bias', (L,)),
-            ('z_log_var/kernel', (H, L)), ('z_log_var/bias', (L,)),
-            ('decoder_h/kernel', (dec_in, H)), ('decoder_h/bias', (H,)),
-            ('x_decoded_mean/kernel', (H, D)), ('x_decoded_mean/bias', (D,))]
+            ('w_log_var/kernel', (Hc, C - 1)), ('w_log_var/bias', (C - 1,))]
+    if H > 0:
+        return head + [('h/kernel', (D + C, H)), ('h/bias', (H,)),
+                       ('z_mean/kernel', (H, L)), ('z_mean/bias', (L,)),
+                       ('z_log_var/kernel', (H, L)), ('z_log_var/bias', (L,)),
+                       ('decoder_h/kernel', (dec_in, H)), ('decoder_h/bias', (H,)),
+                       ('x_decoded_mean/kernel', (H, D)), ('x_decoded_mean/bias', (D,))]
+    return head + [('z_mean/kernel', (D + C, L)), ('z_mean/bias', (L,)),
+                   ('z_log_var/kernel', (D + C, L)), ('z_log_var/bias', (L,)),
+                   ('x_decoded_mean/kernel', (dec_in, D)), ('x_decoded_mean/bias', (D,))]
 
 
 def vae_init_params(cfg, seed=0, dtype=np.float64):
@@ -185,8 +190,11 @@ def vae_forward(p, cfg, x, xp, eps_w, eps_z):
     c['w_log_var'] = c['h_w'] @ p['w_log_var/kernel'] + p['w_log_var/bias']  # :143
     c['w'] = logistic_normal(c['w_mean'], c['w_log_var'], eps_w)            # :146-157
     c['xw'] = np.concatenate([x, c['w']], axis=-1)                          # :160
-    c['a_h'] = c['xw'] @ p['h/kernel'] + p['h/bias']                        # :162
-    c['h'] = relu(c['a_h'])
+    if cfg['H'] > 0:
+        c['a_h'] = c['xw'] @ p['h/kernel'] + p['h/bias']                    # :162
+        c['h'] = relu(c['a_h'])
+    else:
+        c['h'] = c['xw']                                                    # :165-167: the heads read [x, w] directly
     c['z_mean'] = c['h'] @ p['z_mean/kernel'] + p['z_mean/bias']            # :163
     c['z_log_var'] = c['h'] @ p['z_log_var/kernel'] + p['z_log_var/bias']   # :164
     c['z'] = c['z_mean'] + np.exp(c['z_log_var'] / 2) * eps_z               # :170-174
@@ -194,8 +202,11 @@ def vae_forward(p, cfg, x, xp, eps_w, eps_z):
         c['wz'] = np.concatenate([c['w'], xp, c['z']], axis=-1)             # :177-181 (w, history, z)
     else:
         c['wz'] = np.concatenate([c['w'], c['z']], axis=-1)
-    c['a_dh'] = c['wz'] @ p['decoder_h/kernel'] + p['decoder_h/bias']       # :184-185
-    c['h_dec'] = relu(c['a_dh'])
+    if cfg['H'] > 0:
+        c['a_dh'] = c['wz'] @ p['decoder_h/kernel'] + p['decoder_h/bias']   # :184-185
+        c['h_dec'] = relu(c['a_dh'])
+    else:
+        c['h_dec'] = c['wz']                                                # :188: decoder_mean(wz)
     c['logits'] = c['h_dec'] @ p['x_decoded_mean/kernel'] + p['x_decoded_mean/bias']  # :182,186
     c['x_hat'] = sigmoid(c['logits'])
     return c
@@ -225,10 +236,13 @@ def vae_loss_and_grads(p, cfg, x, xp, w_true, eps_w, eps_z, need_grads=True, tar
     dlogits = dlogits * inv
     g['x_decoded_mean/kernel'] = c['h_dec'].T @ dlogits
     g['x_decoded_mean/bias'] = dlogits.sum(0)
-    d = (dlogits @ p['x_decoded_mean/kernel'].T) * (c['a_dh'] > 0)
-    g['decoder_h/kernel'] = c['wz'].T @ d
-    g['decoder_h/bias'] = d.sum(0)
-    dwz = d @ p['decoder_h/kernel'].T
+    if cfg['H'] > 0:
+        d = (dlogits @ p['x_decoded_mean/kernel'].T) * (c['a_dh'] > 0)
+        g['decoder_h/kernel'] = c['wz'].T @ d
+        g['decoder_h/bias'] = d.sum(0)
+        dwz = d @ p['decoder_h/kernel'].T
+    else:
+        dwz = dlogits @ p['x_decoded_mean/kernel'].T
     dw = dwz[:, :C].copy()
     dz = dwz[:, -L:]
     dzm = dz + cfg['kl_weight'] * inv * dzm_kl
@@ -237,10 +251,13 @@ def vae_loss_and_grads(p, cfg, x, xp, w_true, eps_w, eps_z, need_grads=True, tar
     g['z_mean/bias'] = dzm.sum(0)
     g['z_log_var/kernel'] = c['h'].T @ dzlv
     g['z_log_var/bias'] = dzlv.sum(0)
-    d = (dzm @ p['z_mean/kernel'].T + dzlv @ p['z_log_var/kernel'].T) * (c['a_h'] > 0)
-    g['h/kernel'] = c['xw'].T @ d
-    g['h/bias'] = d.sum(0)
-    dw += (d @ p['h/kernel'].T)[:, D:]
+    if cfg['H'] > 0:
+        d = (dzm @ p['z_mean/kernel'].T + dzlv @ p['z_log_var/kernel'].T) * (c['a_h'] > 0)
+        g['h/kernel'] = c['xw'].T @ d
+        g['h/bias'] = d.sum(0)
+        dw += (d @ p['h/kernel'].T)[:, D:]
+    else:
+        dw += (dzm @ p['z_mean/kernel'].T + dzlv @ p['z_log_var/kernel'].T)[:, D:]
     dw += cfg['class_weight'] * inv * dw_rec
     ds, dlv_from_s = logistic_normal_bwd(c['w'], dw, c['w_log_var'], eps_w)
     dwm = ds + cfg['w_kl_weight'] * inv * dwm_kl
@@ -498,4 +515,14 @@ def adam_wn_step(params, grads, st, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
             m[...] = b1 * m + (1 - b1) * g
             v[...] = b2 * v + (1 - b2) * g ** 2
             p[...] = p - lr_t * m / (np.sqrt(v) + eps)
+    return params
+
+
+def rmsprop_step(params, grads, acc, lr=1e-3, rho=0.9, eps=1e-8):
+    """Keras 2.0.0 RMSprop (optimizers.py, what the string 'rmsprop' of cl_vae/train.py:83 selects [K]):
+    a <- rho a + (1 - rho) g^2 ; p <- p - lr g / (sqrt(a) + eps).  `acc`: dict of accumulators (zeros at the start)."""
+    for k, p in params.items():
+        a = acc[k]
+        a[...] = rho * a + (1.0 - rho) * grads[k] ** 2
+        p[...] = p - lr * grads[k] / (np.sqrt(a) + eps)
     return params

@@ -70,12 +70,15 @@ def vae_graph(tp, cfg, x, xp, wt, ew, ez):
     wm = hw @ tp['w_mean/kernel'] + tp['w_mean/bias']
     wlv = hw @ tp['w_log_var/kernel'] + tp['w_log_var/bias']
     w = logistic_normal(wm, wlv, ew)
-    h = torch.relu(torch.cat([x, w], -1) @ tp['h/kernel'] + tp['h/bias'])
+    h = torch.cat([x, w], -1)
+    if cfg['H'] > 0:
+        h = torch.relu(h @ tp['h/kernel'] + tp['h/bias'])
     zm = h @ tp['z_mean/kernel'] + tp['z_mean/bias']
     zlv = h @ tp['z_log_var/kernel'] + tp['z_log_var/bias']
     z = zm + torch.exp(zlv / 2) * ez
-    wz = torch.cat([w, xp, z], -1) if cfg['use_x_prev'] else torch.cat([w, z], -1)
-    hd = torch.relu(wz @ tp['decoder_h/kernel'] + tp['decoder_h/bias'])
+    hd = torch.cat([w, xp, z], -1) if cfg['use_x_prev'] else torch.cat([w, z], -1)
+    if cfg['H'] > 0:
+        hd = torch.relu(hd @ tp['decoder_h/kernel'] + tp['decoder_h/bias'])
     a = hd @ tp['x_decoded_mean/kernel'] + tp['x_decoded_mean/bias']
     return _losses(cfg, a, x, zm, zlv, w, wt, wm, wlv), a
 

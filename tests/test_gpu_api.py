@@ -472,6 +472,18 @@ def test_train_clis_under_two_ranks(dev, tmp_path, which, extra):
         np.testing.assert_allclose(w0[k], ws[k], rtol=5e-3, atol=5e-5, err_msg=k)
 
 
+def test_fit_with_the_rmsprop_optimizer_string(dev):
+    """--optimizer rmsprop (the alternative cl_vae/train.py:83 names) trains: the loss goes down."""
+    from clvae_amd.cl_vae.model import get_model
+    rng = np.random.default_rng(1)
+    x = (rng.random((40, 88)) < 0.1).astype(np.float64)
+    wt = np.eye(3)[rng.integers(0, 3, 40)]
+    model, _ = get_model(20, 88, (88, 2), (88, 3), 'rmsprop', seed=2)
+    assert model.optimizer.name == 'rmsprop'
+    h = model.fit(x, [x, wt, wt, x], shuffle=False, epochs=15, batch_size=20, verbose=0)
+    assert h.history['loss'][-1] < 0.8 * h.history['loss'][0]
+
+
 def test_cl_vae_device_generation_matches_stepwise_oracle(dev):
     """cl_vae.generate_samples_device (the frame loop as hipGraph replays, Philox noise) vs an oracle loop that redraws
     the same Philox numbers on the host: encoder input x_{t-1}, decoder history x_{t-2} (cl_vae/model.py:28-41)."""

@@ -101,6 +101,33 @@ def test_cl_vae_step_matches_oracle(dev, B, L, Cn, use_x_prev, weights, fused):
         np.testing.assert_allclose(w[k], p[k], rtol=2e-3, atol=2e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("use_x_prev", [True, False])
+def test_cl_vae_without_hidden_layers_matches_oracle(dev, use_x_prev):
+    """--intermediate_dim 0 (cl_vae/model.py:165-167,188): the latent heads read [x, w], the output layer [w, history, z]."""
+    from clvae_amd.engine import VaeEngine
+    B, L, Cn = 33, 3, 4
+    cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=use_x_prev, intermediate_dim=0, class_weight=0.7,
+                       kl_weight=0.4, w_kl_weight=0.8, w_log_var_prior=0.1)
+    rng = np.random.default_rng(21)
+    p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=6).items()}
+    assert 'h/kernel' not in p and p['x_decoded_mean/kernel'].shape[0] == Cn + (88 if use_x_prev else 0) + L
+    x, xp = frames(rng, B, 88), frames(rng, B, 88)
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    ew, ez = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, L)))
+    ref = O.vae_loss_and_grads(p, cfg, x, xp, wt, ew, ez)
+    eng = VaeEngine(cfg, B, dev)
+    assert not eng.fused
+    eng.P.set_weights(p)
+    eng.loss_and_grads(T(x, dev), T(xp, dev), T(wt, dev), T(ew, dev), T(ez, dev))
+    torch.cuda.synchronize()
+    got = eng.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, k
+    assert np.abs(N(eng.logits) - ref['cache']['logits']).max() < LOGIT_TOL
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'])
+    np.testing.assert_allclose(N(eng.x_hat()), ref['cache']['x_hat'], atol=2e-6)
+
+
 @pytest.mark.parametrize("pair", [True, False])
 @pytest.mark.parametrize("B,Tn,L,Cn,use_x_prev,gate", [
     (6, 5, 2, 10, True, 'hard_sigmoid'),

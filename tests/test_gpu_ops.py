@@ -226,6 +226,27 @@ def test_adam_wn_three_steps(dev, weightnorm):
         np.testing.assert_allclose(N(P.s)[P.col_offsets['a/kernel']:][:88], st['s']['a/kernel'], rtol=3e-5)
 
 
+def test_rmsprop_three_steps(dev):
+    """The 'rmsprop' optimizer string (cl_vae/train.py:83): CLV_OPT_RMSPROP vs the oracle's Keras RMSprop."""
+    from clvae_amd.engine import FlatParams
+    rng = np.random.default_rng(9)
+    shapes = [('a/kernel', (200, 88)), ('a/bias', (88,)), ('c/recurrent_kernel', (88, 352))]
+    P = FlatParams(shapes, dev)
+    p = {n: rng.standard_normal(s) * 0.3 for n, s in shapes}
+    P.set_weights(p)
+    acc = {n: np.zeros(s) for n, s in shapes}
+    for step in range(3):
+        g = {n: rng.standard_normal(s) * (0.1 + step) for n, s in shapes}
+        for n, _ in shapes:
+            P.g(n).copy_(T(g[n], dev))
+        P.adam_step(b2=0.9, weightnorm=2)
+        O.rmsprop_step(p, {k: v.astype(np.float32).astype(np.float64) for k, v in g.items()}, acc)
+        got = P.get_weights()
+        for n, _ in shapes:
+            np.testing.assert_allclose(got[n], p[n], rtol=3e-5, atol=3e-6, err_msg="%s step %d" % (n, step))
+    assert int(P.iterations.item()) == 3
+
+
 def test_philox_matches_oracle(dev):
     from clvae_amd import ops
     for first in (0, 5, 1027):

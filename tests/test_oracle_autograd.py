@@ -13,10 +13,10 @@ def _t(a):
     return torch.tensor(a, dtype=torch.float64, requires_grad=True)
 
 
-@pytest.mark.parametrize("use_x_prev", [True, False])
-def test_vae_grads_match_autograd(use_x_prev):
+@pytest.mark.parametrize("use_x_prev,inter", [(True, 88), (False, 88), (True, 0), (False, 0)])
+def test_vae_grads_match_autograd(use_x_prev, inter):
     rng = np.random.default_rng(1)
-    cfg = O.vae_config(latent_dim=4, n_classes=3, use_x_prev=use_x_prev, class_weight=0.7,
+    cfg = O.vae_config(latent_dim=4, n_classes=3, use_x_prev=use_x_prev, class_weight=0.7, intermediate_dim=inter,
                        kl_weight=0.3, w_kl_weight=0.9, w_log_var_prior=0.4)
     B, D, C, L = 6, cfg['D'], cfg['C'], cfg['L']
     p = O.vae_init_params(cfg, seed=3)

@@ -1,7 +1,8 @@
 """Aggregate rocprofv3 --pmc SQ passes (counter_collection CSVs) into per-kernel busy fractions.
 Usage: python tools/pmc_sq.py out.json pass1.csv [pass2.csv ...]
 Per kernel (average over its dispatches): every counter's sum, and where the inputs are there
-  valu_busy       = SQ_ACTIVE_INST_VALU * 4 / SQ_BUSY_CU_CYCLES   (quad-cycle counter -> cycles, per CU-cycle the kernel had waves)
+  valu_issue      = 2 * SQ_INSTS_VALU / (4 * SQ_BUSY_CU_CYCLES)   (a wave64 VALU instruction holds a SIMD32 for 2 cycles; 4 SIMDs per
+                    CU; SQ_BUSY_CU_CYCLES = cycles summed over the CUs that had waves: 98 us x 2.1 GHz x 256 CUs for pair_fwd)
   mfma_busy       = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4   (per SIMD: 4 matrix pipes per CU)
   lds_conflict    = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (or / SQ_ACTIVE_INST_LDS when IDX_ACTIVE was not collected)
 Units per MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles."""
@@ -26,8 +27,8 @@ for k, cs in acc.items():
     row = dict(kernel=k, dispatches=max(len(v) for v in cs.values()), counters={c: round(v, 1) for c, v in sorted(m.items())})
     busy = m.get('SQ_BUSY_CU_CYCLES') or m.get('SQ_BUSY_CYCLES')
     if busy:
-        if 'SQ_ACTIVE_INST_VALU' in m:
-            row['valu_busy'] = round(4 * m['SQ_ACTIVE_INST_VALU'] / busy / (1 if 'SQ_BUSY_CU_CYCLES' in m else 1), 4)
+        if 'SQ_INSTS_VALU' in m:
+            row['valu_issue'] = round(2 * m['SQ_INSTS_VALU'] / (4 * busy), 4)
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
             row['mfma_busy'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / busy / 4, 4)
     if 'SQ_LDS_BANK_CONFLICT' in m:
@@ -41,5 +42,5 @@ rows.sort(key=lambda r: -r['counters'].get('SQ_BUSY_CU_CYCLES', r['counters'].ge
 json.dump(dict(note=__doc__.split('\n')[0] + " Fractions are per-kernel averages over dispatches of bench.py --no-graph.",
                passes=[p.split('/')[-2] for p in paths], kernels=rows), open(out, 'w'), indent=1)
 for r in rows[:8]:
-    print("%-60s valu_busy %-7s mfma_busy %-7s lds_conflict %-7s" % (r['kernel'][:60], r.get('valu_busy'), r.get('mfma_busy'),
+    print("%-60s valu_issue %-7s mfma_busy %-7s lds_conflict %-7s" % (r['kernel'][:60], r.get('valu_issue'), r.get('mfma_busy'),
                                                                   r.get('lds_conflict_per_lds_cycle')))
