@@ -22,6 +22,14 @@ _u64 = C.c_uint64
 _u32 = C.c_uint32
 
 
+class VaeStepOpts(C.Structure):
+    """clv_vae_step_opts (include/clvae.h)."""
+    _fields_ = [("draw", _i), ("stream_w", _u32), ("stream_z", _u32), ("step", _u32),
+                ("noise_seed", _u64), ("first_w", _u64), ("first_z", _u64),
+                ("step_dev", _p), ("loss_means", _p), ("bump_iterations", _p)]
+
+
+
 class ParamDesc(C.Structure):
     _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
@@ -87,9 +95,11 @@ SIGNATURES = {
     "clv_label_fwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "clv_label_bwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _i, _p]),
     "clv_vae_fused_supported": (_i, [_i, _i, _i, _i, _i]),
-    "clv_vae_fused_workspace_bytes": (_sz, [_i, C.c_long]),
+    "clv_vae_fused_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "clv_vae_fused_step": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i, _p,
                                 _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_vae_fused_step_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i,
+                                   _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p]),

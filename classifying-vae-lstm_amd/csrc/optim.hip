@@ -46,7 +46,8 @@ struct AdamHyper {
 };
 
 __device__ __forceinline__ float adam_lr_t(const AdamHyper& h) {
-  const int t = h.iterations ? (*h.iterations + 1) : h.step_t;
+  // CLV_STEP_ADVANCED: the counter was advanced by the step that produced the gradients, it already holds t
+  const int t = h.iterations ? (*h.iterations + (h.step_t == CLV_STEP_ADVANCED ? 0 : 1)) : h.step_t;
   return h.lr * sqrtf(1.f - powf(h.b2, (float)t)) / (1.f - powf(h.b1, (float)t));
 }
 
@@ -470,7 +471,7 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   AdamHyper h{lr, beta1, beta2, eps, weightnorm, step_t, iterations_dev};
   // step_t == -1 with a device counter: read it, leave it alone (another call of the same step, on another subset of the
   // tensors, advances it)
-  int32_t* bump = (iterations_dev && step_t == -1) ? nullptr : iterations_dev;
+  int32_t* bump = (iterations_dev && (step_t == -1 || step_t == CLV_STEP_ADVANCED)) ? nullptr : iterations_dev;
   ProfScope pr("adam_wn_step", st);
   const bool wn = weightnorm == CLV_OPT_ADAM_WN && c.n_cols > 0;
   const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything

@@ -2,391 +2,685 @@
 //
 // cl_vae is 33 k parameters: as separate layers it is ~45 launches of a few microseconds each, i.e. launch-
 // bound.  Here a workgroup owns RB batch rows and walks the entire graph of cl_vae/model.py:136-219 with its
-// activations resident in LDS (8 wide + 8 narrow [RB x .] buffers, < 140 KB) and the weights streamed from
-// L2 straight into MFMA B operands (v_mfma_f32_16x16x4_f32, exact fp32); per-row sampling / loss math runs
-// on the first RB threads.  Weight gradients are produced per workgroup (K = RB rows of the batch) into a
-// slab laid out like the flat parameter buffer and summed by a second tiny launch, so the result is
-// deterministic (no float atomics).  Dims: D, H, Hc <= 96; C, L <= 16.
+// activations resident in LDS; per-row sampling / loss math runs on the first RB threads.  Weight gradients are
+// produced per workgroup (K = RB rows of the batch) into a slab laid out like the flat parameter buffer and
+// summed by a second tiny launch, so the result is deterministic (no float atomics).
+//
+// The kernel is a latency chain (12 dependent products, ~40 workgroups on 256 CUs), so it is written for latency:
+//   * the graph is a TABLE of 12 stages (6 forward layers, 6 backward) built by the launcher; the kernel is one loop
+//     over it with a single product body, a single weight-gradient body and the per-row hooks between stages --
+//     the code is small enough to stay in the instruction cache instead of being ~70 KB executed once;
+//   * a stage's weights go from L2 into one wave's MFMA B registers (v_mfma_f32_16x16x4_f32, exact fp32) ONE STAGE
+//     AHEAD, with unconditional clamped loads (a predicated load turns into a branch with a wait behind it), and
+//     the barriers do not drain them;
+//   * concatenated Dense inputs ([x, w] and [w, x_prev, z]) are physically adjacent in LDS and every buffer is
+//     zero beyond its width, so an A operand is one ds_read at a constant offset; all A reads of a product are
+//     issued before its first MFMA;
+//   * all global inputs (frames, labels, noise) are staged once at the start; the noise can be drawn in the
+//     kernel (Philox, same values as clv_philox_normal2).
+// Dims: D, H, Hc <= 96; C, L <= 16.
 #include "common.h"
+#include "philox.h"
 
 namespace clv {
 
+#ifndef VAB
+#define VAB 0      // timing ablations (wrong results): 1 no gradient stores, 2 no gradient MFMAs, 3 no gradients, 5 no product MFMAs
+#endif
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int VLW = 98;    // wide LDS row stride  (== 2 mod 32: MFMA A reads of 16 rows x 2 k are conflict-free)
-constexpr int VLS = 34;    // narrow LDS row stride
+constexpr int VRB = 16;    // batch rows per workgroup (one MFMA row tile)
+constexpr int VL = 132;    // LDS row stride of every buffer: == 4 mod 64, so the 16 rows x 4 k of an MFMA A read, the
+                           // 16 columns x 4 rows of a product's output and the (row = 4 q + m) reads of the weight
+                           // gradients each touch 64 different banks; >= 16 + 96 + 16 (the widest concatenated
+                           // input); ONE stride keeps every LDS offset of the bodies an instruction immediate
 constexpr int VNW = 8;     // waves per workgroup: one 16-column tile of an 88-wide layer per wave
 constexpr int VNT = VNW * 64;
+constexpr int VNSTAGE = 12;
 constexpr float VEPS_K = 1e-7f, VW2 = 1e-10f, VLOGIT_CLIP = 16.11809555f;
+
+// One stage of the graph.  Product: out = epilogue(A[16 x K] . B), A in LDS, B(k, c) = W[k*ldw + c] or, with VF_NT,
+// W[c*ldw + k] (the backward product DY . W^T).  VF_PAIR: waves 0 and 1 compute two separate narrow products of the
+// same A (index 0 / 1 below), otherwise wave i owns columns [16 i, 16 i + 16) of product 0.
+// Weight gradient (backward stages): G[g_off][ga_K x K] = GA[16 x ga_K]^T . A, bias gradient = column sums of A.
+enum { VF_MM = 1, VF_NT = 2, VF_PAIR = 4, VF_RELU = 8, VF_ACC = 16, VF_MASK = 32, VF_BIAS = 64 };
+struct VStage {
+  int flags, a_off, K, ldw;
+  int w_off[2], ncol[2], o_off[2];
+  int b_off, mask_off;
+  int ga_off, ga_K;                // ga_K = 0: no weight gradient
+  int tiling;                      // (ceil(K / 16) << 24) | ceil(65536 / ceil(K / 16)): tile index -> (k tile, n tile)
+  int g_off, gb_off;
+};
 
 struct VaeArgs {
   int B, D, H, Hc, C, L, use_xp;
   const float* x; const float* xp; const float* onehot;    // [B,D] [B,D] [B,C]
   const float* y;                                          // [B,D] reconstruction target (NULL: x itself)
-  const float* eps_w; const float* eps_z;                    // [B,C-1] [B,L]
-  const float* P;                                            // flat parameters
-  long o_hw_k, o_hw_b, o_wa_k, o_wa_b, o_h_k, o_h_b, o_za_k, o_za_b, o_d_k, o_d_b, o_x_k, o_x_b;
+  float* eps_w; float* eps_z;                              // [B,C-1] [B,L]: read, or written when draw != 0
+  const float* P;                                          // flat parameters
   float prior, class_weight, kl_weight, w_kl_weight;
-  int need_grads;
-  float* slab; long n_params;                                // [n_wg][n_params] partial gradients
+  int need_grads, draw;
+  uint32_t k0, k1, stream_w, stream_z, step;               // Philox key / streams / step of the in-kernel draw
+  const int32_t* step_dev;
+  uint64_t first_w, first_z;                               // stream index of eps_w[0], eps_z[0]
+  float* slab; long slab_stride;                           // [n_wg][slab_stride] partial gradients
   float* logits; float* w_out; float* wargs_out; float* zargs_out;   // [B,D] [B,C] [B,2(C-1)] [B,2L] (for predict/tests)
-  float* rownll; float* rowkl; float* rowloss;               // [B] [B] [B,3]
+  float* rownll; float* rowkl; float* rowloss;             // [B] [B] [B,3]
+  VStage st[VNSTAGE];
 };
 
-struct MSrc { const float* a; int lda; int K; const float* w; };
+// LDS map (floats): 17 buffers of 16 rows
+struct VMap {
+  int XC, DC, HW, Hh, HD, LG, G1, G2, WARGS, ZARGS, DWV, DWARGS, DZARGS, DZ, EW, EZ, OH, total;
+  __host__ __device__ VMap() {
+    int o = 0;
+    int* f[17] = {&XC, &DC, &HW, &Hh, &HD, &LG, &G1, &G2, &WARGS, &ZARGS, &DWV, &DWARGS, &DZARGS, &DZ, &EW, &EZ, &OH};
+    for (int i = 0; i < 17; ++i) { *f[i] = o; o += VRB * VL; }
+    total = (o + 3) & ~3;
+  }
+};
 
-// out[RB x N] = act(sum_s A_s[RB x K_s] . W_s[K_s x N] + bias) (* mask>0); A in LDS, W in global (row stride ldw)
-template <int RB>
-__device__ void dense(const MSrc* src, int nsrc, int ldw, int N, const float* bias, bool relu, float* out, int ldo) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// -DCLV_VAE_STAMPS: workgroup 0 records the 100 MHz wall clock at every stage boundary (tools/vae_stamps.py)
+#ifdef CLV_VAE_STAMPS
+__device__ unsigned long long g_vae_stamps[64];
+#define VSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_vae_stamps[i] = wall_clock64(); } while (0)
+// inside stages 2, 3 (forward) and 6, 7 (backward): slots 20 + 4 * {0, 1, 2, 3} + point
+#define VSTAMPI(si, k) do { if ((si) == 2 || (si) == 3 || (si) == 6 || (si) == 7) \
+    VSTAMP(20 + 4 * (((si) & 1) + ((si) >= 6 ? 2 : 0)) + (k)); } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#define VSTAMPI(si, k) do { } while (0)
+#endif
+
+// a barrier that does not drain the weight loads in flight (__syncthreads() waits for vmcnt(0))
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One wave's weight operand of one stage: KS k-steps of 4 cover the longest product of the graph (K = C + D + L of
+// the decoder): KS = 24 while that is <= 96, else 32.  What a clamped element multiplies is either a zero A operand
+// or lands in a column nobody stores.
+//
+// The loads and the wait for them are written by hand.  The compiler's own wait-count bookkeeping sees the
+// weight-gradient stores of the previous stage in the same counter as these loads and, not knowing their relative
+// order, makes the first MFMA of a stage wait for the prefetch issued a moment ago -- which is the latency this
+// scheme exists to hide.  Loads return in order among themselves, so "at most KS + 1 operations outstanding" right
+// after the next stage's KS + 1 loads were issued means this stage's have all landed, whatever the stores do.
+// (A register the compiler does not know to be pending must not be moved or spilled before frag_wait: check
+// tools/kres.py -- no scratch -- after touching this kernel.)
+template <int KS> struct WFrag { float v[KS]; float bias; };
+
+__device__ __forceinline__ void wload(float& dst, const float* base, unsigned byte_off) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base));
+}
+
+#define VTIE4(f, b) "+v"(f.v[b]), "+v"(f.v[b + 1]), "+v"(f.v[b + 2]), "+v"(f.v[b + 3])
+// every register of f has landed after this; newer = a prefetch of KS + 1 loads was issued after f's
+template <int KS>
+__device__ __forceinline__ void frag_wait(WFrag<KS>& f, bool newer) {
+  static_assert(KS == 24 || KS == 32, "");
+  // the branch holds an operand-less wait only: with tied operands inside it the compiler copies the registers on one
+  // side BEFORE the wait
+  if (!newer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (KS == 24) asm volatile("s_waitcnt vmcnt(25)" : VTIE4(f, 0), VTIE4(f, 4), VTIE4(f, 8));
+  else asm volatile("s_waitcnt vmcnt(33)" : VTIE4(f, 0), VTIE4(f, 4), VTIE4(f, 8));
+  asm volatile("" : VTIE4(f, 12), VTIE4(f, 16), VTIE4(f, 20), "+v"(f.bias));
+  if (KS == 32) asm volatile("" : VTIE4(f, KS - 8), VTIE4(f, KS - 4));
+}
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// does this wave own a tile of the stage's product?
+__device__ __forceinline__ bool stage_has_tile(const VStage& s, int wave) {
+  if (!(s.flags & VF_MM)) return false;
+  if (s.flags & VF_PAIR) return wave < 2 && (wave == 1 ? s.ncol[1] : s.ncol[0]) > 0;
+  return wave * 16 < s.ncol[0];
+}
+
+template <int KS>
+__device__ __forceinline__ void stage_load(WFrag<KS>& f, const VStage& s, const float* P) {
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int r = lane & 15, q = lane >> 4;
-  for (int nt = wave; nt * 16 < N; nt += VNW) {
-    const int n0 = nt * 16;
-    f32x4v acc[RB / 16];
+  const bool pair = s.flags & VF_PAIR;
+  const bool second = pair && wave == 1;
+  const int ncol = second ? s.ncol[1] : s.ncol[0];
+  const int cc = min((pair ? 0 : wave) * 16 + r, ncol - 1);
+  const int sk = (s.flags & VF_NT) ? 1 : s.ldw, sc = (s.flags & VF_NT) ? s.ldw : 1;
+  const float* base = P + (second ? s.w_off[1] : s.w_off[0]);
+  unsigned o = 4u * (unsigned)(cc * sc + q * sk);
+  const unsigned omax = 4u * (unsigned)(cc * sc + (s.K - 1) * sk), ostep = 16u * (unsigned)sk;
 #pragma unroll
-    for (int mt = 0; mt < RB / 16; ++mt) acc[mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsrc; ++s) {
-      const MSrc sr = src[s];
-      // 8 k-steps per chunk: the 8 weight loads (L2 latency ~0.3 us each) are issued together, then consumed
-      for (int kc = 0; kc < sr.K; kc += 32) {
-        float bv[8];
+  for (int i = 0; i < KS; ++i) { wload(f.v[i], base, min(o, omax)); o += ostep; }
+  wload(f.bias, P + ((s.flags & VF_BIAS) ? s.b_off : 0), 4u * (unsigned)cc);     // ignored without VF_BIAS
+}
+
+// out = epilogue(A . B) for this wave's tile; B in registers once frag_wait returns
+template <int KS>
+__device__ __forceinline__ void stage_mm(const VStage& s, WFrag<KS>& f, float* lds, bool newer) {
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int r = lane & 15, q = lane >> 4;
+  const bool pair = s.flags & VF_PAIR;
+  const bool second = pair && wave == 1;
+  const int ncol = second ? s.ncol[1] : s.ncol[0];
+  const int tile = pair ? 0 : wave;
+  frag_wait(f, newer);
+  const float* ap = lds + s.a_off + r * VL + q;
+  float av[KS];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = kc + 4 * i + q;
-          bv[i] = (k < sr.K && n0 + r < N) ? sr.w[(size_t)k * ldw + n0 + r] : 0.f;
-        }
+  for (int g = 0; g < KS / 8; ++g)
+    if (32 * g < s.K) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = kc + 4 * i + q;
-#pragma unroll
-          for (int mt = 0; mt < RB / 16; ++mt) {
-            const float a = k < sr.K ? sr.a[(mt * 16 + r) * sr.lda + k] : 0.f;
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[i], acc[mt], 0, 0, 0);
-          }
-        }
-      }
+      for (int i = 8 * g; i < 8 * g + 8; ++i) av[i] = ap[4 * i];
     }
-    const int col = n0 + r;
-    if (col < N) {
-      const float bv = bias ? bias[col] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4v acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < RB / 16; ++mt)
+  for (int g = 0; g < KS / 8; ++g)
+    if (32 * g < s.K) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          float v = acc[mt][reg] + bv;
-          if (relu) v = fmaxf(v, 0.f);
-          out[(mt * 16 + q * 4 + reg) * ldo + col] = v;
-        }
+#if VAB == 5
+      for (int i = 8 * g; i < 8 * g + 8; ++i) acc[i & 3] += av[i] * f.v[i];
+#else
+      for (int i = 8 * g; i < 8 * g + 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], f.v[i], acc, 0, 0, 0);
+#endif
+    }
+  const int col = tile * 16 + r;
+  if (col < ncol) {
+    float* out = lds + (second ? s.o_off[1] : s.o_off[0]) + q * 4 * VL + col;
+    const float* mk = lds + s.mask_off + q * 4 * VL + col;
+    const float bias = (s.flags & VF_BIAS) ? f.bias : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      float v = acc[reg] + bias;
+      if (s.flags & VF_ACC) v += out[reg * VL];
+      if (s.flags & VF_RELU) v = fmaxf(v, 0.f);
+      if (s.flags & VF_MASK) v = mk[reg * VL] > 0.f ? v : 0.f;
+      out[reg * VL] = v;
     }
   }
 }
 
-// out[RB x Kr] (+)= (DY[RB x N] . W[Kr x N]^T) (* (mask > 0)); DY, out, mask in LDS
-template <int RB>
-__device__ void dense_t(const float* dy, int ldy, int N, const float* w, int ldw, int Kr, float* out, int ldo,
-                        const float* mask, int ldm, bool accumulate) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// this workgroup's share of the stage's kernel and bias gradients: G = GA^T . DY (DY = the stage's A operand).
+// A wave takes tiles wave, wave + 8, ...; the operands of all its tiles are read before the first MFMA.  The MFMA
+// computes the TRANSPOSED tile (DY^T . GA), so a lane ends up with four consecutive columns of one gradient row: one
+// 16-byte store per tile into the slab, whose rows are padded to a multiple of four columns (ceil4(N)).
+// Batch row of k-step m for lane group q: 4 q + m (any bijection does; this one is bank-conflict-free).
+template <int MT>
+__device__ __forceinline__ void stage_wgrad(const VStage& s, const float* lds, float* G) {
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int r = lane & 15, q = lane >> 4;
-  for (int kt = wave; kt * 16 < Kr; kt += VNW) {
-    const int c0 = kt * 16;
-    f32x4v acc[RB / 16];
+  const int N = s.K, Kin = s.ga_K, Np = (N + 3) & ~3;
+  const int nts = (int)((unsigned)s.tiling >> 24), magic = s.tiling & 0xffffff;
+  const int ntiles = ((Kin + 15) >> 4) * nts;
+  const float* ga = lds + s.ga_off + 4 * q * VL;
+  const float* dy = lds + s.a_off + 4 * q * VL;
+  float av[MT][4], bv[MT][4];
+  int k0[MT], n0[MT];
 #pragma unroll
-    for (int mt = 0; mt < RB / 16; ++mt) acc[mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    for (int nc = 0; nc < N; nc += 32) {
-      float bv[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int n = nc + 4 * i + q;
-        bv[i] = (n < N && c0 + r < Kr) ? w[(size_t)(c0 + r) * ldw + n] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int n = nc + 4 * i + q;
-#pragma unroll
-        for (int mt = 0; mt < RB / 16; ++mt) {
-          const float a = n < N ? dy[(mt * 16 + r) * ldy + n] : 0.f;
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[i], acc[mt], 0, 0, 0);
-        }
-      }
-    }
-    const int col = c0 + r;
-    if (col < Kr) {
-#pragma unroll
-      for (int mt = 0; mt < RB / 16; ++mt)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = mt * 16 + q * 4 + reg;
-          float v = acc[mt][reg];
-          if (accumulate) v += out[row * ldo + col];
-          if (mask) v = mask[row * ldm + col] > 0.f ? v : 0.f;
-          out[row * ldo + col] = v;
-        }
+  for (int j = 0; j < MT; ++j) {
+    const int tc = min(wave + VNW * j, ntiles - 1);
+    const int kt = (tc * magic) >> 16;
+    k0[j] = kt * 16; n0[j] = (tc - kt * nts) * 16;
+    const int ka = min(k0[j] + r, Kin - 1), nb = min(n0[j] + r, N - 1);      // clamped: duplicates are not stored / land
+#pragma unroll                                                                // in the slab's padding columns
+    for (int m = 0; m < 4; ++m) {
+      av[j][m] = dy[m * VL + nb];
+      bv[j][m] = ga[m * VL + ka];
     }
   }
-}
-
-// gout[Kin x N] = A[RB x Kin]^T . DY[RB x N]  (this workgroup's share of a kernel gradient); A, DY in LDS
-template <int RB>
-__device__ void wgrad(const float* a_lds, int lda, int Kin, const float* dy, int ldy, int N, float* gout, int ldo) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int kts = (Kin + 15) / 16, nts = (N + 15) / 16;
-  for (int tile = wave; tile < kts * nts; tile += VNW) {
-    const int k0 = (tile / nts) * 16, n0 = (tile % nts) * 16;
-    f32x4v acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r0 = 0; r0 < RB; r0 += 4) {
-      const float av = k0 + r < Kin ? a_lds[(r0 + q) * lda + k0 + r] : 0.f;
-      const float bv = n0 + r < N ? dy[(r0 + q) * ldy + n0 + r] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  for (int j = 0; j < MT; ++j) {
+    if (wave + VNW * j < ntiles) {
+      f32x4v acc = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#if VAB == 2
+      for (int m = 0; m < 4; ++m) acc[m] += av[j][m] * bv[j][m];
+#else
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][m], bv[j][m], acc, 0, 0, 0);
+#endif
+      const int row = k0[j] + r, col = n0[j] + 4 * q;
+#if VAB == 1
+      if (row < Kin && col < Np && acc[0] == 12345.678f)
+#else
+      if (row < Kin && col < Np)
+#endif
+        *reinterpret_cast<f32x4v*>(G + s.g_off + row * Np + col) = acc;
     }
-    const int col = n0 + r;
-    if (col < N)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = k0 + q * 4 + reg;
-        if (row < Kin) gout[(size_t)row * ldo + col] = acc[reg];
-      }
   }
-}
-
-template <int RB>
-__device__ void bgrad(const float* dy, int ldy, int N, float* gout) {
   for (int c = threadIdx.x; c < N; c += VNT) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < RB; ++r) s += dy[r * ldy + c];
-    gout[c] = s;
+    float t = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < VRB; ++rr) t += lds[s.a_off + rr * VL + c];
+    G[s.gb_off + c] = t;
   }
 }
 
-template <int RB>
+template <int KS>
 __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* X = lds;                 float* XP = X + RB * VLW;    float* HW = XP + RB * VLW;  float* Hh = HW + RB * VLW;
-  float* HD = Hh + RB * VLW;      float* LG = HD + RB * VLW;   float* G1 = LG + RB * VLW;  float* G2 = G1 + RB * VLW;
-  float* WARGS = G2 + RB * VLW;   float* WV = WARGS + RB * VLS; float* ZARGS = WV + RB * VLS; float* ZV = ZARGS + RB * VLS;
-  float* DWV = ZV + RB * VLS;     float* DWARGS = DWV + RB * VLS; float* DZARGS = DWARGS + RB * VLS; float* DZ = DZARGS + RB * VLS;
+  const VMap M;
   const int tid = threadIdx.x;
-  const int row0 = blockIdx.x * RB;
-  const int nvalid = min(RB, a.B - row0);
-  const int D = a.D, H = a.H, Hc = a.Hc, C = a.C, L = a.L, C1 = a.C - 1, NA = 2 * (a.C - 1), NZ = 2 * a.L;
+  const int row0 = blockIdx.x * VRB;
+  const int nvalid = min(VRB, a.B - row0);
+  const int D = a.D, C = a.C, L = a.L, C1 = a.C - 1, NA = 2 * (a.C - 1), NZ = 2 * a.L;
+  const int xo = a.use_xp ? D : 0;
   const float* P = a.P;
   const float inv_b = 1.f / (float)a.B;
+  constexpr int MT = KS == 24 ? 5 : 6;       // weight-gradient tiles per wave: 36 (48) tiles of a 96 (128) x 96 kernel
+  VSTAMP(0);
 
-  // ---- inputs -> LDS (rows beyond the batch are zero) -----------------------------------------------------
-  for (int i = tid; i < RB * D; i += VNT) {
-    const int r = i / D, c = i % D;
-    X[r * VLW + c] = r < nvalid ? a.x[(size_t)(row0 + r) * D + c] : 0.f;
-    XP[r * VLW + c] = (a.use_xp && r < nvalid) ? a.xp[(size_t)(row0 + r) * D + c] : 0.f;
+  // the first stage's weights are on their way while the inputs are staged
+  WFrag<KS> f0, f1;
+  if (stage_has_tile(a.st[0], wave_id())) stage_load(f0, a.st[0], P);
+  // ---- LDS: zero everything (products rely on zeros beyond a buffer's width), then the inputs; the frames are
+  // requested first so that the zero fill runs under their latency -------------------------------------------------
+  constexpr int FPT = (VRB * 96 + VNT - 1) / VNT;          // frame elements per thread
+  float fx[FPT], fp[FPT], fy[FPT];
+#pragma unroll
+  for (int u = 0; u < FPT; ++u) {
+    const int i = min(tid + u * VNT, nvalid * D - 1);
+    const size_t g = (size_t)row0 * D + i;
+    fx[u] = a.x[g];
+    fp[u] = a.use_xp ? a.xp[g] : 0.f;
+    fy[u] = a.y ? a.y[g] : 0.f;
   }
-  __syncthreads();
-  // ---- label encoder (:141-143) ---------------------------------------------------------------------------
-  { MSrc s[1] = {{X, VLW, D, P + a.o_hw_k}}; dense<RB>(s, 1, Hc, Hc, P + a.o_hw_b, true, HW, VLW); }
-  __syncthreads();
-  { MSrc s[1] = {{HW, VLW, Hc, P + a.o_wa_k}}; dense<RB>(s, 1, NA, NA, P + a.o_wa_b, false, WARGS, VLS); }
-  __syncthreads();
-  // ---- w ~ logistic-normal, label losses (:146-157,198-206) -----------------------------------------------
-  if (tid < RB) {
-    const int r = tid;
-    float* wv = WV + r * VLS;
-    float e[16];
-    float S = 1.f, klw = 0.f;
-    const float ep = __expf(a.prior);
-    for (int j = 0; j < C1; ++j) {
-      const float m = WARGS[r * VLS + j], lv = WARGS[r * VLS + C1 + j];
-      const float sd = expf(0.5f * lv);
-      const float ew = r < nvalid ? a.eps_w[(size_t)(row0 + r) * C1 + j] : 0.f;
-      e[j] = expf(m + sd * ew);
-      S += e[j];
-      klw += 1.f - a.prior + lv - sd * sd / ep - m * m / ep;
-    }
-    e[C1] = 1.f;
-    const float invS = 1.f / S;
-    float qs = 0.f, wbest = -1.f, tbest = -1.f;
-    int amax = 0, tmax = 0;
-    for (int j = 0; j < C; ++j) {
-      wv[j] = e[j] * invS;
-      qs += wv[j] + VW2;
-      if (wv[j] > wbest) { wbest = wv[j]; amax = j; }
-      const float tj = (a.onehot && r < nvalid) ? a.onehot[(size_t)(row0 + r) * C + j] : 0.f;
-      if (tj > tbest) { tbest = tj; tmax = j; }
-    }
-    for (int j = C; j < ((C + 3) & ~3); ++j) wv[j] = 0.f;      // zero padding for the MFMA k-steps
-    if (r < nvalid) {
-      float wrec = 0.f;
-      if (a.onehot)
-        for (int j = 0; j < C; ++j)
-          wrec -= a.onehot[(size_t)(row0 + r) * C + j] * logf(fminf(fmaxf((wv[j] + VW2) / qs, VEPS_K), 1.f - VEPS_K));
-      a.rowloss[(size_t)(row0 + r) * 3 + 0] = -0.5f * klw;
-      a.rowloss[(size_t)(row0 + r) * 3 + 1] = (float)C1 * wrec;
-      a.rowloss[(size_t)(row0 + r) * 3 + 2] = (a.onehot && amax == tmax) ? 1.f : 0.f;
-      for (int j = 0; j < C; ++j) a.w_out[(size_t)(row0 + r) * C + j] = wv[j];
-      for (int j = 0; j < NA; ++j) a.wargs_out[(size_t)(row0 + r) * NA + j] = WARGS[r * VLS + j];
+  for (int i = tid; i < M.total / 4; i += VNT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  lds_barrier();
+#pragma unroll
+  for (int u = 0; u < FPT; ++u) {
+    const int i = tid + u * VNT;
+    if (i < nvalid * D) {
+      const int r = i / D, c = i - r * D;
+      lds[M.XC + r * VL + c] = fx[u];
+      if (a.use_xp) lds[M.DC + r * VL + C + c] = fp[u];
+      if (a.y) lds[M.G2 + r * VL + c] = fy[u];            // the target waits in G2 (free until the backward pass)
     }
   }
-  __syncthreads();
-  // ---- latent encoder (:160-174) --------------------------------------------------------------------------
-  { MSrc s[2] = {{X, VLW, D, P + a.o_h_k}, {WV, VLS, C, P + a.o_h_k + (long)D * H}};
-    dense<RB>(s, 2, H, H, P + a.o_h_b, true, Hh, VLW); }
-  __syncthreads();
-  { MSrc s[1] = {{Hh, VLW, H, P + a.o_za_k}}; dense<RB>(s, 1, NZ, NZ, P + a.o_za_b, false, ZARGS, VLS); }
-  __syncthreads();
-  if (tid < RB) {
-    const int r = tid;
-    float kl = 0.f;
-    for (int j = 0; j < L; ++j) {
-      const float m = ZARGS[r * VLS + j], lv = ZARGS[r * VLS + L + j];
-      const float sd = expf(0.5f * lv);
-      const float ez = r < nvalid ? a.eps_z[(size_t)(row0 + r) * L + j] : 0.f;
-      ZV[r * VLS + j] = m + sd * ez;
-      kl += 1.f + lv - m * m - sd * sd;
+  if (a.onehot)
+    for (int i = tid; i < nvalid * C; i += VNT) {
+      const int r = i / C, c = i - r * C;
+      lds[M.OH + r * VL + c] = a.onehot[(size_t)(row0 + r) * C + c];
     }
-    for (int j = L; j < ((L + 3) & ~3); ++j) ZV[r * VLS + j] = 0.f;
-    if (r < nvalid) {
-      a.rowkl[row0 + r] = -0.5f * kl;
-      for (int j = 0; j < NZ; ++j) a.zargs_out[(size_t)(row0 + r) * NZ + j] = ZARGS[r * VLS + j];
-    }
-  }
-  __syncthreads();
-  // ---- decoder on [w, xp, z] (:177-188) -------------------------------------------------------------------
-  const long xo = a.use_xp ? D : 0;
-  { MSrc s[3] = {{WV, VLS, C, P + a.o_d_k}, {XP, VLW, a.use_xp ? D : 0, P + a.o_d_k + (long)C * H},
-                 {ZV, VLS, L, P + a.o_d_k + (long)(C + xo) * H}};
-    dense<RB>(s, 3, H, H, P + a.o_d_b, true, HD, VLW); }
-  __syncthreads();
-  { MSrc s[1] = {{HD, VLW, H, P + a.o_x_k}}; dense<RB>(s, 1, D, D, P + a.o_x_b, false, LG, VLW); }
-  __syncthreads();
-  // ---- Bernoulli NLL on the logits (Keras clip semantics) and its gradient, in place ----------------------
   {
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int r = wave; r < RB; r += VNW) {
-      float acc = 0.f;
-      for (int j = lane; j < D; j += 64) {
-        const float av = LG[r * VLW + j];
-        const float t = a.y ? (r < nvalid ? a.y[(size_t)(row0 + r) * D + j] : 0.f) : X[r * VLW + j];
-        if (r < nvalid && a.logits) a.logits[(size_t)(row0 + r) * D + j] = av;
-        const float l = fminf(fmaxf(av, -VLOGIT_CLIP), VLOGIT_CLIP);
-        const float e = __expf(-fabsf(l));
-        acc += fmaxf(l, 0.f) + __logf(1.f + e) - l * t;
-        const float r1 = fast_rcp(1.f + e);
-        const float sg = l >= 0.f ? r1 : e * r1;
-        const bool inside = (av >= -VLOGIT_CLIP) && (av <= VLOGIT_CLIP);
-        LG[r * VLW + j] = (inside && r < nvalid) ? inv_b * (sg - t) : 0.f;
+    const uint32_t stp = a.step + ((a.draw && a.step_dev) ? (uint32_t)*a.step_dev : 0u);
+    for (int i = tid; i < nvalid * (C1 + L); i += VNT) {
+      const bool zs = i >= nvalid * C1;
+      const int e = zs ? i - nvalid * C1 : i, w_ = zs ? L : C1;
+      const int r = e / w_, c = e - r * w_;
+      const size_t g = (size_t)(row0 + r) * w_ + c;
+      float* ep = zs ? a.eps_z : a.eps_w;
+      float v;
+      if (a.draw) {
+        v = philox_normal_at((zs ? a.first_z : a.first_w) + g, a.k0, a.k1, zs ? a.stream_z : a.stream_w, stp);
+        ep[g] = v;
+      } else {
+        v = ep[g];
       }
-      acc = wave_sum(acc);
-      if (lane == 0 && r < nvalid) a.rownll[row0 + r] = acc;
+      lds[(zs ? M.EZ : M.EW) + r * VL + c] = v;
     }
   }
-  __syncthreads();
-  if (!a.need_grads) return;
-  float* G = a.slab + (size_t)blockIdx.x * a.n_params;
+  lds_barrier(); VSTAMP(1);
 
-  // ---- output layer ---------------------------------------------------------------------------------------
-  wgrad<RB>(HD, VLW, H, LG, VLW, D, G + a.o_x_k, D);
-  bgrad<RB>(LG, VLW, D, G + a.o_x_b);
-  dense_t<RB>(LG, VLW, D, P + a.o_x_k, D, H, G1, VLW, HD, VLW, false);          // G1 = d h_dec
-  __syncthreads();
-  // ---- decoder hidden layer -------------------------------------------------------------------------------
-  wgrad<RB>(WV, VLS, C, G1, VLW, H, G + a.o_d_k, H);
-  if (a.use_xp) wgrad<RB>(XP, VLW, D, G1, VLW, H, G + a.o_d_k + (long)C * H, H);
-  wgrad<RB>(ZV, VLS, L, G1, VLW, H, G + a.o_d_k + (long)(C + xo) * H, H);
-  bgrad<RB>(G1, VLW, H, G + a.o_d_b);
-  dense_t<RB>(G1, VLW, H, P + a.o_d_k, H, C, DWV, VLS, nullptr, 0, false);                         // dL/dw (decoder part)
-  dense_t<RB>(G1, VLW, H, P + a.o_d_k + (long)(C + xo) * H, H, L, DZ, VLS, nullptr, 0, false);    // dL/dz
-  __syncthreads();
-  // ---- gaussian head backward -----------------------------------------------------------------------------
-  if (tid < RB) {
-    const int r = tid;
-    const float ks = a.kl_weight * inv_b;
-    for (int j = 0; j < L; ++j) {
-      const float m = ZARGS[r * VLS + j], lv = ZARGS[r * VLS + L + j];
-      const float sd = expf(0.5f * lv);
-      const float d = DZ[r * VLS + j];
-      const float ez = r < nvalid ? a.eps_z[(size_t)(row0 + r) * L + j] : 0.f;
-      DZARGS[r * VLS + j] = r < nvalid ? d + ks * m : 0.f;
-      DZARGS[r * VLS + L + j] = r < nvalid ? d * ez * 0.5f * sd - 0.5f * ks * (1.f - sd * sd) : 0.f;
+  float* G = a.slab + (size_t)blockIdx.x * a.slab_stride;
+  const int nst = a.need_grads ? VNSTAGE : VNSTAGE / 2;
+
+  // one stage: request the next stage's weights (into fn), multiply with this stage's (fc), weight gradients.
+  // The table entries live in scalar registers and are fetched two stages ahead (sa: this stage, sb: the next,
+  // sc: the one after, arriving), so no stage starts by waiting on its own description.
+  // A wave requests and waits for weights only in stages where it owns a tile.
+  const int wave = wave_id();
+  auto run_stage = [&](int si, const VStage& sa, const VStage& sb, WFrag<KS>& fc, WFrag<KS>& fn) {
+    const bool newer = si + 1 < nst && stage_has_tile(sb, wave);
+    VSTAMPI(si, 0);
+    if (newer) stage_load(fn, sb, P);
+    VSTAMPI(si, 1);
+    if (stage_has_tile(sa, wave)) stage_mm(sa, fc, lds, newer);
+    VSTAMPI(si, 2);
+#if VAB != 3
+    if (sa.ga_K > 0) stage_wgrad<MT>(sa, lds, G);
+#endif
+    VSTAMPI(si, 3);
+    lds_barrier(); VSTAMP(2 + si);
+  };
+
+  VStage sa = a.st[0], sb = a.st[1];
+#pragma unroll 1
+  for (int si = 0; si < nst; si += 2) {
+    VStage sc = a.st[min(si + 2, VNSTAGE - 1)];
+    run_stage(si, sa, sb, f0, f1);
+    sa = a.st[min(si + 3, VNSTAGE - 1)];
+    run_stage(si + 1, sb, sc, f1, f0);
+    sb = sa; sa = sc;
+    // ---- per-row work between stages (every hook follows an odd stage) --------------------------------------
+    if (si == 0) {
+      // w ~ logistic-normal, label losses (:146-157,198-206)
+      if (tid < VRB) {
+        const int r = tid;
+        const float* wargs = lds + M.WARGS + r * VL;
+        const float* oh = lds + M.OH + r * VL;
+        float* wv = lds + M.DC + r * VL;                  // w opens the decoder input ...
+        float* wx = lds + M.XC + r * VL + D;              // ... and follows x in the latent encoder's
+        float S = 1.f, klw = 0.f;
+        const float ep = __expf(a.prior);
+        for (int j = 0; j < C1; ++j) {
+          const float m = wargs[j], lv = wargs[C1 + j];
+          const float sd = expf(0.5f * lv);
+          const float e = expf(m + sd * lds[M.EW + r * VL + j]);
+          wv[j] = e;
+          S += e;
+          klw += 1.f - a.prior + lv - sd * sd / ep - m * m / ep;
+        }
+        wv[C1] = 1.f;
+        const float invS = 1.f / S;
+        float qs = 0.f, wbest = -1.f, tbest = -1.f;
+        int amax = 0, tmax = 0;
+        for (int j = 0; j < C; ++j) {
+          const float wj = wv[j] * invS;
+          wv[j] = wj; wx[j] = wj;
+          qs += wj + VW2;
+          if (wj > wbest) { wbest = wj; amax = j; }
+          if (oh[j] > tbest) { tbest = oh[j]; tmax = j; }
+        }
+        if (r < nvalid) {
+          float wrec = 0.f;
+          if (a.onehot)
+            for (int j = 0; j < C; ++j)
+              wrec -= oh[j] * logf(fminf(fmaxf((wv[j] + VW2) / qs, VEPS_K), 1.f - VEPS_K));
+          a.rowloss[(size_t)(row0 + r) * 3 + 0] = -0.5f * klw;
+          a.rowloss[(size_t)(row0 + r) * 3 + 1] = (float)C1 * wrec;
+          a.rowloss[(size_t)(row0 + r) * 3 + 2] = (a.onehot && amax == tmax) ? 1.f : 0.f;
+          for (int j = 0; j < C; ++j) a.w_out[(size_t)(row0 + r) * C + j] = wv[j];
+          for (int j = 0; j < NA; ++j) a.wargs_out[(size_t)(row0 + r) * NA + j] = wargs[j];
+        }
+      }
+    } else if (si == 2) {
+      // z = mu + sigma eps, KL (:170-174,195-196)
+      if (tid < VRB) {
+        const int r = tid;
+        const float* zargs = lds + M.ZARGS + r * VL;
+        float* zv = lds + M.DC + r * VL + C + xo;
+        float kl = 0.f;
+        for (int j = 0; j < L; ++j) {
+          const float m = zargs[j], lv = zargs[L + j];
+          const float sd = expf(0.5f * lv);
+          zv[j] = m + sd * lds[M.EZ + r * VL + j];
+          kl += 1.f + lv - m * m - sd * sd;
+        }
+        if (r < nvalid) {
+          a.rowkl[row0 + r] = -0.5f * kl;
+          for (int j = 0; j < NZ; ++j) a.zargs_out[(size_t)(row0 + r) * NZ + j] = zargs[j];
+        }
+      }
+    } else if (si == 4) {
+      // Bernoulli NLL on the logits (Keras clip semantics) and its gradient, in place
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int r = wave; r < VRB; r += VNW) {
+        float acc = 0.f;
+        for (int j = lane; j < D; j += 64) {
+          const float av = lds[M.LG + r * VL + j];
+          const float t = a.y ? lds[M.G2 + r * VL + j] : lds[M.XC + r * VL + j];
+          if (a.y) lds[M.G2 + r * VL + j] = 0.f;          // G2 is a zero-padded product operand again
+          if (r < nvalid && a.logits) a.logits[(size_t)(row0 + r) * D + j] = av;
+          const float l = fminf(fmaxf(av, -VLOGIT_CLIP), VLOGIT_CLIP);
+          const float e = __expf(-fabsf(l));
+          acc += fmaxf(l, 0.f) + __logf(1.f + e) - l * t;
+          const float r1 = fast_rcp(1.f + e);
+          const float sg = l >= 0.f ? r1 : e * r1;
+          const bool inside = (av >= -VLOGIT_CLIP) && (av <= VLOGIT_CLIP);
+          lds[M.LG + r * VL + j] = (inside && r < nvalid) ? inv_b * (sg - t) : 0.f;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && r < nvalid) a.rownll[row0 + r] = acc;
+      }
+    } else if (si == 6) {
+      // gaussian head backward
+      if (tid < VRB) {
+        const int r = tid;
+        const float ks = a.kl_weight * inv_b;
+        const float* zargs = lds + M.ZARGS + r * VL;
+        float* dza = lds + M.DZARGS + r * VL;
+        for (int j = 0; j < L; ++j) {
+          const float m = zargs[j], lv = zargs[L + j];
+          const float sd = expf(0.5f * lv);
+          const float d = lds[M.DZ + r * VL + j];
+          const float ez = lds[M.EZ + r * VL + j];
+          dza[j] = r < nvalid ? d + ks * m : 0.f;
+          dza[L + j] = r < nvalid ? d * ez * 0.5f * sd - 0.5f * ks * (1.f - sd * sd) : 0.f;
+        }
+      }
+    } else if (si == 8) {
+      // label head backward
+      if (tid < VRB) {
+        const int r = tid;
+        const float ep = __expf(a.prior);
+        const float* wv = lds + M.DC + r * VL;
+        const float* wargs = lds + M.WARGS + r * VL;
+        const float* oh = lds + M.OH + r * VL;
+        float* dwa = lds + M.DWARGS + r * VL;
+        float dn[16], d[16];
+        float qs = 0.f, dot = 0.f, dsum = 0.f;
+        for (int j = 0; j < C; ++j) qs += wv[j] + VW2;
+        for (int j = 0; j < C; ++j) {
+          const float n = (wv[j] + VW2) / qs;
+          const bool inside = (n >= VEPS_K) && (n <= 1.f - VEPS_K);
+          const float nc = fminf(fmaxf(n, VEPS_K), 1.f - VEPS_K);
+          dn[j] = inside ? -(float)C1 * oh[j] / nc : 0.f;
+          dot += dn[j] * n;
+        }
+        for (int j = 0; j < C; ++j) {
+          d[j] = lds[M.DWV + r * VL + j] + a.class_weight * inv_b * ((dn[j] - dot) / qs);
+          dsum += d[j] * wv[j];
+        }
+        for (int j = 0; j < C1; ++j) {
+          const float ds = wv[j] * (d[j] - dsum);
+          const float m = wargs[j], lv = wargs[C1 + j];
+          const float sd = expf(0.5f * lv);
+          const float ew = lds[M.EW + r * VL + j];
+          dwa[j] = r < nvalid ? ds + a.w_kl_weight * inv_b * (m / ep) : 0.f;
+          dwa[C1 + j] = r < nvalid ? ds * ew * 0.5f * sd + a.w_kl_weight * inv_b * (-0.5f * (1.f - sd * sd / ep)) : 0.f;
+        }
+      }
     }
+    if (si + 2 < nst) { lds_barrier(); }
+    VSTAMP(14 + si / 2);
   }
-  __syncthreads();
-  wgrad<RB>(Hh, VLW, H, DZARGS, VLS, NZ, G + a.o_za_k, NZ);
-  bgrad<RB>(DZARGS, VLS, NZ, G + a.o_za_b);
-  dense_t<RB>(DZARGS, VLS, NZ, P + a.o_za_k, NZ, H, G2, VLW, Hh, VLW, false);    // G2 = d h
-  __syncthreads();
-  wgrad<RB>(X, VLW, D, G2, VLW, H, G + a.o_h_k, H);
-  wgrad<RB>(WV, VLS, C, G2, VLW, H, G + a.o_h_k + (long)D * H, H);
-  bgrad<RB>(G2, VLW, H, G + a.o_h_b);
-  dense_t<RB>(G2, VLW, H, P + a.o_h_k + (long)D * H, H, C, DWV, VLS, nullptr, 0, true);    // dL/dw += encoder part
-  __syncthreads();
-  // ---- label head backward --------------------------------------------------------------------------------
-  if (tid < RB) {
-    const int r = tid;
-    const float ep = __expf(a.prior);
-    const float* wv = WV + r * VLS;
-    float dn[16], d[16];
-    float qs = 0.f, dot = 0.f, dsum = 0.f;
-    for (int j = 0; j < C; ++j) qs += wv[j] + VW2;
-    for (int j = 0; j < C; ++j) {
-      const float n = (wv[j] + VW2) / qs;
-      const bool inside = (n >= VEPS_K) && (n <= 1.f - VEPS_K);
-      const float nc = fminf(fmaxf(n, VEPS_K), 1.f - VEPS_K);
-      const float oh = r < nvalid ? a.onehot[(size_t)(row0 + r) * C + j] : 0.f;
-      dn[j] = inside ? -(float)C1 * oh / nc : 0.f;
-      dot += dn[j] * n;
-    }
-    for (int j = 0; j < C; ++j) {
-      d[j] = DWV[r * VLS + j] + a.class_weight * inv_b * ((dn[j] - dot) / qs);
-      dsum += d[j] * wv[j];
-    }
-    for (int j = 0; j < C1; ++j) {
-      const float ds = wv[j] * (d[j] - dsum);
-      const float m = WARGS[r * VLS + j], lv = WARGS[r * VLS + C1 + j];
-      const float sd = expf(0.5f * lv);
-      const float ew = r < nvalid ? a.eps_w[(size_t)(row0 + r) * C1 + j] : 0.f;
-      DWARGS[r * VLS + j] = r < nvalid ? ds + a.w_kl_weight * inv_b * (m / ep) : 0.f;
-      DWARGS[r * VLS + C1 + j] =
-          r < nvalid ? ds * ew * 0.5f * sd + a.w_kl_weight * inv_b * (-0.5f * (1.f - sd * sd / ep)) : 0.f;
-    }
-  }
-  __syncthreads();
-  wgrad<RB>(HW, VLW, Hc, DWARGS, VLS, NA, G + a.o_wa_k, NA);
-  bgrad<RB>(DWARGS, VLS, NA, G + a.o_wa_b);
-  dense_t<RB>(DWARGS, VLS, NA, P + a.o_wa_k, NA, Hc, G1, VLW, HW, VLW, false);   // G1 = d h_w
-  __syncthreads();
-  wgrad<RB>(X, VLW, D, G1, VLW, Hc, G + a.o_hw_k, Hc);
-  bgrad<RB>(G1, VLW, Hc, G + a.o_hw_b);
 }
 
-// grads[i] = sum_s slab[s][i]
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, int nslabs, long n, float* out) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// The slab of one workgroup: the 12 tensors in host_offsets12 order, each row padded to a multiple of four columns
+// (so the gradient tiles are stored 16 bytes at a time), each tensor starting on a multiple of four floats.
+struct VSlabMap {
+  int flat_off[12], slab_off[12], rows[12], cols[12];
+  unsigned magic[12];              // ceil(2^32 / ceil4(cols)): slab index -> row
+  int stride;
+};
+static VSlabMap vae_slab_map(int D, int H, int Hc, int C, int L, int use_xp, const int64_t* o) {
+  const int NA = 2 * (C - 1), NZ = 2 * L, KD = C + (use_xp ? D : 0) + L;
+  const int rows[12] = {D, 1, Hc, 1, D + C, 1, H, 1, KD, 1, H, 1};
+  const int cols[12] = {Hc, Hc, NA, NA, H, H, NZ, NZ, H, H, D, D};
+  VSlabMap m{};
+  int off = 0;
+  for (int t = 0; t < 12; ++t) {
+    const int np = (cols[t] + 3) & ~3;
+    m.flat_off[t] = o ? (int)o[t] : 0; m.slab_off[t] = off; m.rows[t] = rows[t]; m.cols[t] = cols[t];
+    m.magic[t] = (unsigned)((0x100000000ULL + np - 1) / np);
+    off += rows[t] * np;
+  }
+  m.stride = off;
+  return m;
+}
+
+// grads = sum of the slabs (un-padded into the flat layout); five more blocks reduce the per-row losses to their
+// batch means, and the step counter advances here when the caller asks for it (one launch instead of three)
+struct VaeTail {
+  const float* slab; int nslabs; float* grads; unsigned nblk_grads;
+  const float* rownll; const float* rowkl; const float* rowloss; int B; float* means;   // means NULL: no loss blocks
+  int32_t* bump;
+  VSlabMap map;
+};
+__global__ __launch_bounds__(256) void slab_sum_kernel(VaeTail t) {
+  if (blockIdx.x >= t.nblk_grads) {
+    __shared__ float part[4];
+    const int k = blockIdx.x - t.nblk_grads;            // 0 nll, 1 kl_z, 2..4 the rowloss columns
+    const float* x = k == 0 ? t.rownll : k == 1 ? t.rowkl : t.rowloss + (k - 2);
+    const int st = k < 2 ? 1 : 3;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < t.B; i += 256) acc += x[(size_t)i * st];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) t.means[k] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)t.B;
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && t.bump) *t.bump += 1;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= t.map.stride) return;
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < 12; ++k) seg = j >= t.map.slab_off[k] ? k : seg;
+  int so = 0, fo = 0, nc = 1; unsigned mg = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+    if (seg == k) { so = t.map.slab_off[k]; fo = t.map.flat_off[k]; nc = t.map.cols[k]; mg = t.map.magic[k]; }
+  const int local = j - so, np = (nc + 3) & ~3;
+  const int row = (int)__umulhi((unsigned)local, mg), col = local - row * np;
+  if (col >= nc) return;                                 // padding column
+  const float* slab = t.slab + j;
+  const size_t n = (size_t)t.map.stride;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int s = 0;
-  for (; s + 3 < nslabs; s += 4) {
-    a0 += slab[(size_t)s * n + i]; a1 += slab[(size_t)(s + 1) * n + i];
-    a2 += slab[(size_t)(s + 2) * n + i]; a3 += slab[(size_t)(s + 3) * n + i];
+  for (; s + 3 < t.nslabs; s += 4) {
+    a0 += slab[(size_t)s * n]; a1 += slab[(size_t)(s + 1) * n];
+    a2 += slab[(size_t)(s + 2) * n]; a3 += slab[(size_t)(s + 3) * n];
   }
-  for (; s < nslabs; ++s) a0 += slab[(size_t)s * n + i];
-  out[i] = (a0 + a1) + (a2 + a3);
+  for (; s < t.nslabs; ++s) a0 += slab[(size_t)s * n];
+  t.grads[fo + row * nc + col] = (a0 + a1) + (a2 + a3);
 }
-
-template <int RB>
-static size_t vae_lds_bytes() { return (size_t)(8 * RB * VLW + 8 * RB * VLS) * sizeof(float); }
 
 }  // namespace clv
 
 using namespace clv;
 
-static int vae_rb(int B) { return B <= 2048 ? 16 : 32; }
+
+#ifdef CLV_VAE_STAMPS
+extern "C" int clv_debug_vae_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_vae_stamps), sizeof(unsigned long long) * (n < 64 ? n : 64));
+}
+#endif
 
 extern "C" int clv_vae_fused_supported(int D, int H, int Hc, int C, int L) {
   return D > 0 && D <= 96 && H > 0 && H <= 96 && Hc > 0 && Hc <= 96 && C >= 2 && C <= 16 && L > 0 && L <= 16;
 }
 
-extern "C" size_t clv_vae_fused_workspace_bytes(int B, long n_params) {
-  const int rb = vae_rb(B);
-  return (size_t)((B + rb - 1) / rb) * n_params * sizeof(float);
+extern "C" size_t clv_vae_fused_workspace_bytes(int B, int D, int H, int Hc, int C, int L, int use_x_prev) {
+  if (!clv_vae_fused_supported(D, H, Hc, C, L) || B <= 0) return 0;
+  return (size_t)((B + VRB - 1) / VRB) * (size_t)vae_slab_map(D, H, Hc, C, L, use_x_prev, nullptr).stride * sizeof(float);
+}
+
+// the 12 stages of cl_vae/model.py:136-219 and its backward pass, as the kernel's table
+static void vae_build_stages(VStage* st, int D, int H, int Hc, int C, int L, int use_xp, const int64_t* o,
+                             const VSlabMap& sm) {
+  const VMap M;
+  const int hw_k = (int)o[0], hw_b = (int)o[1], wa_k = (int)o[2], wa_b = (int)o[3], h_k = (int)o[4], h_b = (int)o[5],
+            za_k = (int)o[6], za_b = (int)o[7], d_k = (int)o[8], d_b = (int)o[9], x_k = (int)o[10], x_b = (int)o[11];
+  const int NA = 2 * (C - 1), NZ = 2 * L, xo = use_xp ? D : 0, KD = C + xo + L;
+  auto fwd = [&](int a_off, int K, int w, int N, int b, int relu, int out) {
+    VStage s{};
+    s.flags = VF_MM | VF_BIAS | (relu ? VF_RELU : 0);
+    s.a_off = a_off; s.K = K; s.ldw = N;
+    s.w_off[0] = s.w_off[1] = w; s.ncol[0] = N; s.ncol[1] = 0; s.o_off[0] = s.o_off[1] = out;
+    s.b_off = b;
+    return s;
+  };
+  // backward stage on DY [16 x N]: (optional) product(s) DY . W^T and the gradients of the layer that produced DY
+  auto bwd = [&](int dy, int N, int ga, int ga_K, int g, int gb) {
+    VStage s{};
+    const int nts = (N + 15) / 16;
+    s.flags = VF_NT; s.a_off = dy; s.K = N; s.ldw = N;
+    s.ga_off = ga; s.ga_K = ga_K; s.tiling = (nts << 24) | ((65536 + nts - 1) / nts);
+    s.g_off = g; s.gb_off = gb;
+    return s;
+  };
+  auto prod = [&](VStage& s, int which, int w, int ncol, int out) {
+    s.flags |= VF_MM; s.w_off[which] = w; s.ncol[which] = ncol; s.o_off[which] = out;
+    if (which == 0) { s.w_off[1] = w; s.ncol[1] = 0; s.o_off[1] = out; }
+  };
+  auto mask = [&](VStage& s, int m) { s.flags |= VF_MASK; s.mask_off = m; };
+  st[0] = fwd(M.XC, D, hw_k, Hc, hw_b, 1, M.HW);                         // h_w = relu(x W)            (:141)
+  st[1] = fwd(M.HW, Hc, wa_k, NA, wa_b, 0, M.WARGS);                     // [w_mean, w_log_var]        (:142-143)
+  st[2] = fwd(M.XC, D + C, h_k, H, h_b, 1, M.Hh);                        // h = relu([x, w] W)         (:160-167)
+  st[3] = fwd(M.Hh, H, za_k, NZ, za_b, 0, M.ZARGS);                      // [z_mean, z_log_var]        (:168-169)
+  st[4] = fwd(M.DC, KD, d_k, H, d_b, 1, M.HD);                           // h_dec = relu([w, xp, z] W) (:177-186)
+  st[5] = fwd(M.HD, H, x_k, D, x_b, 0, M.LG);                            // logits                     (:187-188)
+  // (weights are read at their flat offsets, gradients are written at the slab's)
+  st[6] = bwd(M.LG, D, M.HD, H, sm.slab_off[10], sm.slab_off[11]);                               // x_decoded_mean backward
+  prod(st[6], 0, x_k, H, M.G1); mask(st[6], M.HD);                       //   G1 = d h_dec
+  st[7] = bwd(M.G1, H, M.DC, KD, sm.slab_off[8], sm.slab_off[9]);                              // decoder_h backward
+  st[7].flags |= VF_PAIR;
+  prod(st[7], 0, d_k, C, M.DWV);                                         //   dL/dw (decoder part)
+  prod(st[7], 1, d_k + (C + xo) * H, L, M.DZ);                           //   dL/dz
+  st[8] = bwd(M.DZARGS, NZ, M.Hh, H, sm.slab_off[6], sm.slab_off[7]);                        // zargs backward
+  prod(st[8], 0, za_k, H, M.G2); mask(st[8], M.Hh);                      //   G2 = d h
+  st[9] = bwd(M.G2, H, M.XC, D + C, sm.slab_off[4], sm.slab_off[5]);                           // h backward
+  st[9].flags |= VF_PAIR | VF_ACC;
+  prod(st[9], 0, h_k + D * H, C, M.DWV);                                 //   dL/dw += encoder part
+  st[10] = bwd(M.DWARGS, NA, M.HW, Hc, sm.slab_off[2], sm.slab_off[3]);                      // wargs backward
+  prod(st[10], 0, wa_k, Hc, M.G1); mask(st[10], M.HW);                   //   G1 = d h_w
+  st[11] = bwd(M.G1, Hc, M.XC, D, sm.slab_off[0], sm.slab_off[1]);                           // h_w backward (no product)
+}
+
+extern "C" int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
+                                     const float* x, const float* xp, const float* target, const float* onehot,
+                                     float* eps_w, float* eps_z,
+                                     const float* params, const int64_t* host_offsets12, long n_params,
+                                     float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
+                                     int need_grads, float* grads, void* ws, size_t ws_bytes,
+                                     float* logits, float* w_out, float* wargs_out, float* zargs_out,
+                                     float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts,
+                                     void* stream) {
+  if (!clv_vae_fused_supported(D, H, Hc, C, L) || B <= 0 || n_params <= 0 || n_params > 0x7fffffffL) return CLV_EINVAL;
+  if (!x || !eps_w || !eps_z || !params || !host_offsets12 || !w_out || !wargs_out || !zargs_out || !rownll || !rowkl || !rowloss)
+    return CLV_EINVAL;
+  if (use_x_prev && !xp) return CLV_EINVAL;
+  if (need_grads && (!grads || !onehot)) return CLV_EINVAL;
+  const int nwg = (B + VRB - 1) / VRB;
+  const VSlabMap sm = vae_slab_map(D, H, Hc, C, L, use_x_prev, host_offsets12);
+  if (need_grads && (!ws || ws_bytes < (size_t)nwg * sm.stride * sizeof(float))) return CLV_EWORKSPACE;
+  VaeArgs a{};
+  a.B = B; a.D = D; a.H = H; a.Hc = Hc; a.C = C; a.L = L; a.use_xp = use_x_prev;
+  a.x = x; a.xp = xp; a.onehot = onehot; a.y = target == x ? nullptr : target;
+  a.eps_w = eps_w; a.eps_z = eps_z; a.P = params;
+  a.prior = prior_logvar; a.class_weight = class_weight; a.kl_weight = kl_weight; a.w_kl_weight = w_kl_weight;
+  a.need_grads = need_grads;
+  if (opts && opts->draw) {
+    a.draw = 1; a.k0 = (uint32_t)opts->noise_seed; a.k1 = (uint32_t)(opts->noise_seed >> 32);
+    a.stream_w = opts->stream_w; a.stream_z = opts->stream_z; a.step = opts->step; a.step_dev = opts->step_dev;
+    a.first_w = opts->first_w; a.first_z = opts->first_z;
+  }
+  a.slab = (float*)ws; a.slab_stride = sm.stride;
+  a.logits = logits; a.w_out = w_out; a.wargs_out = wargs_out; a.zargs_out = zargs_out;
+  a.rownll = rownll; a.rowkl = rowkl; a.rowloss = rowloss;
+  vae_build_stages(a.st, D, H, Hc, C, L, use_x_prev, host_offsets12, sm);
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope p("vae_fused_step", s);
+    const bool k24 = C + (use_x_prev ? D : 0) + L <= 96 && D + C <= 96;     // the longest products fit 24 k-steps
+    auto k = k24 ? vae_fused_kernel<24> : vae_fused_kernel<32>;
+    const size_t lds = (size_t)VMap().total * sizeof(float);
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds)) return e;
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(VNT), lds, s, a);
+  }
+  int st = launch_status();
+  float* means = opts ? opts->loss_means : nullptr;
+  int32_t* bump = (opts && need_grads) ? opts->bump_iterations : nullptr;
+  if (st || (!need_grads && !means)) return st;
+  {
+    ProfScope p("vae_slab_sum", s);
+    VaeTail t{(const float*)ws, nwg, grads, need_grads ? (unsigned)((sm.stride + 255) / 256) : 0u,
+              rownll, rowkl, rowloss, B, means, bump, sm};
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(t.nblk_grads + (means ? 5u : 0u)), dim3(256), 0, s, t);
+  }
+  return launch_status();
 }
 
 extern "C" int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
@@ -397,38 +691,8 @@ extern "C" int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int
                                   int need_grads, float* grads, void* ws, size_t ws_bytes,
                                   float* logits, float* w_out, float* wargs_out, float* zargs_out,
                                   float* rownll, float* rowkl, float* rowloss, void* stream) {
-  if (!clv_vae_fused_supported(D, H, Hc, C, L) || B <= 0) return CLV_EINVAL;
-  if (!x || !eps_w || !eps_z || !params || !host_offsets12 || !w_out || !wargs_out || !zargs_out || !rownll || !rowkl || !rowloss)
-    return CLV_EINVAL;
-  if (use_x_prev && !xp) return CLV_EINVAL;
-  if (need_grads && (!grads || !onehot)) return CLV_EINVAL;
-  const int rb = vae_rb(B);
-  const int nwg = (B + rb - 1) / rb;
-  if (need_grads && (!ws || ws_bytes < (size_t)nwg * n_params * sizeof(float))) return CLV_EWORKSPACE;
-  const int64_t* o = host_offsets12;
-  VaeArgs a{B, D, H, Hc, C, L, use_x_prev, x, xp, onehot, target == x ? nullptr : target, eps_w, eps_z, params,
-            (long)o[0], (long)o[1], (long)o[2], (long)o[3], (long)o[4], (long)o[5], (long)o[6], (long)o[7], (long)o[8],
-            (long)o[9], (long)o[10], (long)o[11], prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads,
-            (float*)ws, n_params, logits, w_out, wargs_out, zargs_out, rownll, rowkl, rowloss};
-  hipStream_t s = (hipStream_t)stream;
-  {
-    ProfScope p("vae_fused_step", s);
-    if (rb == 16) {
-      auto k = vae_fused_kernel<16>;
-      if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(k), (int)vae_lds_bytes<16>())) return e;
-      hipLaunchKernelGGL(k, dim3(nwg), dim3(VNT), vae_lds_bytes<16>(), s, a);
-    } else {
-      auto k = vae_fused_kernel<32>;
-      if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(k), (int)vae_lds_bytes<32>())) return e;
-      hipLaunchKernelGGL(k, dim3(nwg), dim3(VNT), vae_lds_bytes<32>(), s, a);
-    }
-  }
-  int st = launch_status();
-  if (st || !need_grads) return st;
-  {
-    ProfScope p("vae_slab_sum", s);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, (const float*)ws, nwg,
-                       n_params, grads);
-  }
-  return launch_status();
+  return clv_vae_fused_step_ex(B, D, H, Hc, C, L, use_x_prev, x, xp, target, onehot, const_cast<float*>(eps_w),
+                               const_cast<float*>(eps_z), params, host_offsets12, n_params, prior_logvar, class_weight,
+                               kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out, wargs_out,
+                               zargs_out, rownll, rowkl, rowloss, nullptr, stream);
 }

@@ -178,15 +178,18 @@ class FlatParams:
             self._subplans[key] = (table, len(idx), plan)
         return self._subplans[key]
 
-    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True, only=None, advance=True):
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True, only=None, advance=True, advanced=False):
         """utils/weightnorm.py:75-143; t comes from the device `iterations` counter.
         only: names of the tensors to update (default all); advance=False leaves `iterations` alone, so one optimizer step
-        can be issued in pieces (the multi-GPU schedule updates a bucket as soon as its all-reduce has landed)."""
+        can be issued in pieces (the multi-GPU schedule updates a bucket as soon as its all-reduce has landed).
+        advanced=True: the counter was already advanced by the launch that produced the gradients (the fused cl_vae
+        step) and holds t."""
         table, n, plan = (self.table, len(self.shapes), self.plan) if only is None else self._subplan(only)
         _lib.check(_lib.lib().clv_adam_wn_step(
             table, n, ops._ptr(plan), ops._ptr(self.params), ops._ptr(self.grads),
             ops._ptr(self.m), ops._ptr(self.v), ops._ptr(self.mg), ops._ptr(self.vg), ops._ptr(self.s),
-            ops._ptr(self.iterations), 0 if advance else -1, lr, b1, b2, eps, int(weightnorm), ops._ptr(self.adam_ws),
+            ops._ptr(self.iterations), -2 if advanced else (0 if advance else -1), lr, b1, b2, eps, int(weightnorm),
+            ops._ptr(self.adam_ws),
             self.adam_ws.numel(), ops._stream()), "clv_adam_wn_step")
 
 
@@ -258,8 +261,8 @@ class VaeEngine(_EngineBase):
         self.fused = H > 0 and bool(cfg.get('fused_step', True)) and bool(L_.clv_vae_fused_supported(D, H, Hc, Cn, L))
         names = ['h_w', 'wargs', 'h', 'zargs', 'decoder_h', 'x_decoded_mean']
         self._offs = (C.c_int64 * 12)(*[self.P.offsets.get('%s/%s' % (n, w), 0) for n in names for w in ('kernel', 'bias')])
-        self._fused_ws = torch.empty(max(L_.clv_vae_fused_workspace_bytes(B, self.P.n), 16), dtype=torch.uint8,
-                                     device=self.device) if self.fused else None
+        ws_bytes = L_.clv_vae_fused_workspace_bytes(B, D, H, Hc, Cn, L, int(cfg['use_x_prev'])) if self.fused else 0
+        self._fused_ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.device) if self.fused else None
         self.h_w = _f(d, B, Hc)
         self.wargs = _f(d, B, 2 * (Cn - 1))          # [w_mean | w_log_var]
         self.w = _f(d, B, Cn)
@@ -390,29 +393,46 @@ class VaeEngine(_EngineBase):
             Xs[:, t].copy_(x_next)
         return Xs
 
-    def _fused_step(self, x, xp, w_true, eps_w, eps_z, need_grads, target=None):
-        """The whole step as ONE kernel (csrc/vae_fused.hip) + the slab sum + the loss means."""
+    def _fused_step(self, x, xp, w_true, eps_w, eps_z, need_grads, target=None, noise=None, bump=False):
+        """The whole step as ONE kernel (csrc/vae_fused.hip) + one launch that sums the gradient slabs, takes the loss
+        means and (bump) advances the step counter."""
         cfg, P, B = self.cfg, self.P, self.B
         p_ = ops._ptr
-        _lib.check(_lib.lib().clv_vae_fused_step(
+        opts = _lib.VaeStepOpts()
+        opts.loss_means = p_(self.scal)
+        if noise is not None:
+            (opts.noise_seed, opts.stream_w, opts.stream_z, opts.first_w, opts.first_z, opts.step), step_dev = noise[:6], noise[6]
+            opts.draw, opts.step_dev = 1, p_(step_dev)
+        if bump and need_grads:
+            opts.bump_iterations = p_(P.iterations)
+        _lib.check(_lib.lib().clv_vae_fused_step_ex(
             B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), p_(x), p_(xp), p_(target),
             p_(w_true),
             p_(eps_w), p_(eps_z), p_(P.params), self._offs, P.n, float(cfg['w_log_var_prior']), self.class_weight,
             self.kl_weight, self.w_kl_weight, int(need_grads), p_(P.grads), p_(self._fused_ws), self._fused_ws.numel(),
             p_(self.logits), p_(self.w), p_(self.wargs), p_(self.zargs), p_(self.rownll), p_(self.rowkl),
-            p_(self.rowloss), ops._stream()), "clv_vae_fused_step")
-        ops.loss_sums([(self.rownll, B, 1), (self.rowkl, B, 1), (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
-                       (self.rowloss[:, 2:], B, 3)], self.scal)
+            p_(self.rowloss), C.byref(opts), ops._stream()), "clv_vae_fused_step_ex")
 
-    def loss_and_grads(self, x, xp, w_true, eps_w, eps_z, need_grads=True, target=None):
+    def folds_step(self, w_true):
+        """True when loss_and_grads(noise=..., bump=True) draws the noise and advances `iterations` inside the step's
+        own launches (the fused kernel): the caller then skips its own draw and passes advanced=True to adam_step."""
+        return bool(self.fused and w_true is not None)
+
+    def loss_and_grads(self, x, xp, w_true, eps_w, eps_z, need_grads=True, target=None, noise=None, bump=False):
         """One forward + 4 losses (+ gradients of the weighted total into P.grads).  target: what the decoder output is
-        scored against (default x; the next frame under --predict_next)."""
+        scored against (default x; the next frame under --predict_next).
+        noise = (seed, stream_w, stream_z, first_w, first_z, step, step_dev): draw eps_w / eps_z (into the buffers
+        passed) instead of reading them; bump: advance P.iterations once the gradients are in (only honoured together
+        with folds_step())."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, Hc, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['Hc'], cfg['C']
         C1 = Cn - 1
         inv = 1.0 / B
         if self.fused and w_true is not None:
-            return self._fused_step(x, xp, w_true, eps_w, eps_z, need_grads, target)
+            return self._fused_step(x, xp, w_true, eps_w, eps_z, need_grads, target, noise, bump)
+        if noise is not None:
+            ops.philox_normal2(eps_w, B * C1, noise[1], noise[3], eps_z, B * L, noise[2], noise[4], noise[0], noise[5],
+                               step_dev=noise[6])
         self.forward(x, xp, eps_w, eps_z, w_true)
         ops.bernoulli_nll(B, D, self.logits, x if target is None else target, D, inv, self.rownll,
                           self.dlogits if need_grads else None)

@@ -73,17 +73,29 @@ class TrainStep:
         self._warm = False
 
     # -- pieces -----------------------------------------------------------
-    def draw_noise(self, stream_offset=0, row0=None):
-        """eps_w / eps_z from the Philox streams (2*stream_offset, 2*stream_offset+1) at this rank's global rows
-        (row0 = first global row of the batch held here; default rank * B)."""
+    def noise_spec(self, stream_offset=0, row0=None):
+        """(seed, stream_w, stream_z, first_w, first_z, step, step_dev) of this rank's eps_w / eps_z: the Philox streams
+        (2*stream_offset, 2*stream_offset+1) at its global rows (row0 = first global row of the batch held here; default
+        rank * B), at step `iterations`."""
         eng, B = self.eng, self.eng.B
         C1, L = eng.cfg['C'] - 1, eng.cfg['L']
         T = eng.cfg['T'] if self.is_vrnn else 1
         row0 = self.rank * B if row0 is None else int(row0)      # global row of this rank's first sample
-        it = eng.P.iterations
-        ops.philox_normal2(self.eps_w, B * C1, 2 * stream_offset, eps_first_index(row0, C1),
-                           self.eps_z, B * T * L, 2 * stream_offset + 1, eps_first_index(row0, T * L),
-                           self.seed, 0, step_dev=it)
+        return (self.seed, 2 * stream_offset, 2 * stream_offset + 1, eps_first_index(row0, C1),
+                eps_first_index(row0, T * L), 0, eng.P.iterations)
+
+    def draw_noise(self, stream_offset=0, row0=None):
+        """Fill eps_w / eps_z (noise_spec) with one launch."""
+        eng, B = self.eng, self.eng.B
+        T = eng.cfg['T'] if self.is_vrnn else 1
+        seed, sw, sz, fw, fz, step, it = self.noise_spec(stream_offset, row0)
+        ops.philox_normal2(self.eps_w, B * (eng.cfg['C'] - 1), sw, fw, self.eps_z, B * T * eng.cfg['L'], sz, fz, seed, step,
+                           step_dev=it)
+
+    def _folded(self):
+        """cl_vae's fused step draws its own noise and advances `iterations` in the launches it already has (a step is
+        launch-bound: three launches fewer is a sixth of it)."""
+        return (not self.is_vrnn) and self.eng.folds_step(self.w_true)
 
     def set_target(self, on):
         """on: the decoder output is scored against a separate target batch (staged next to the inputs) instead of the
@@ -93,6 +105,10 @@ class TrainStep:
             self.recapture()
 
     def _main(self):
+        if self._folded():
+            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y,
+                                    noise=self.noise_spec(), bump=True)
+            return
         self.draw_noise()
         if self.is_vrnn:
             self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, do_tail=False, target=self.Y)
@@ -104,15 +120,17 @@ class TrainStep:
             self.eng.grads_tail(self.X)
 
     def _update(self):
-        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm)
+        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, advanced=self._folded())
 
     # multi-GPU: the optimizer step in two pieces, the tail bucket's tensor first (its all-reduce has landed under
     # _tail()), the rest once the main bucket is in; `iterations` advances with the second piece
     def _update_tail(self):
-        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.tail_names, advance=False)
+        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.tail_names, advance=False,
+                             advanced=self._folded())
 
     def _update_rest(self):
-        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.rest_names)
+        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.rest_names,
+                             advanced=self._folded())
 
     # -- public -----------------------------------------------------------
     def _segments(self, cur, hist, w, target=None):

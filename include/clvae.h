@@ -251,12 +251,12 @@ int clv_label_bwd(int B, int C, const float* mean, const float* logvar, int ld_i
  * (sum_rows vae + kl_weight*kl_z + w_kl_weight*kl_w + class_weight*w_rec) / B into `grads` (flat layout).
  * `params` is the flat parameter buffer with the two head pairs stored fused ([in, 2n] kernels:
  * w_mean|w_log_var and z_mean|z_log_var); host_offsets12 = element offsets of
- * {h_w, wargs, h, zargs, decoder_h, x_decoded_mean} x {kernel, bias}.  Activations live in LDS, weights
- * stream from L2 into MFMA operands.  Limits: D, H, Hc <= 96; C, L <= 16 (clv_vae_fused_supported).
- * ws >= clv_vae_fused_workspace_bytes(B, n_params).  logits may be NULL.  target [B,D] is what the decoder output is
+ * {h_w, wargs, h, zargs, decoder_h, x_decoded_mean} x {kernel, bias}.  Activations live in LDS, each layer's
+ * weights are requested from L2 one layer ahead into MFMA operands.  Limits: D, H, Hc <= 96; C, L <= 16 (clv_vae_fused_supported).
+ * ws >= clv_vae_fused_workspace_bytes(B, D, H, Hc, C, L, use_x_prev).  logits may be NULL.  target [B,D] is what the decoder output is
  * scored against: NULL or x for the auto-encoder, the next frame under --predict_next (cl_vae/train.py:15,66). */
 int clv_vae_fused_supported(int D, int H, int Hc, int C, int L);
-size_t clv_vae_fused_workspace_bytes(int B, long n_params);
+size_t clv_vae_fused_workspace_bytes(int B, int D, int H, int Hc, int C, int L, int use_x_prev);
 int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
                        const float* x, const float* xp, const float* target, const float* onehot,
                        const float* eps_w, const float* eps_z,
@@ -265,6 +265,32 @@ int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev
                        int need_grads, float* grads, void* ws, size_t ws_bytes,
                        float* logits, float* w_out, float* wargs_out, float* zargs_out,
                        float* rownll, float* rowkl, float* rowloss, void* stream);
+
+/* The same step with the three small launches around it folded in (a cl_vae training step is launch-bound):
+ *   draw != 0        the kernel draws eps_w / eps_z itself -- the values clv_philox_normal2(eps_w, B*(C-1), noise_seed,
+ *                    step, step_dev, stream_w, first_w, eps_z, B*L, ..., stream_z, first_z) would have written -- and stores
+ *                    them into eps_w / eps_z (which are outputs then);
+ *   loss_means       [5] batch means of rownll, rowkl and the three rowloss columns, by the slab-sum launch
+ *                    (replaces a clv_loss_sums call); NULL: not computed;
+ *   bump_iterations  device step counter incremented once by the slab-sum launch (need_grads only), so that the
+ *                    optimizer call that follows can run with step_t = CLV_STEP_ADVANCED; NULL: left alone.
+ * opts == NULL is clv_vae_fused_step. */
+typedef struct clv_vae_step_opts {
+  int draw;
+  uint32_t stream_w, stream_z, step;
+  uint64_t noise_seed, first_w, first_z;
+  const int32_t* step_dev;
+  float* loss_means;
+  int32_t* bump_iterations;
+} clv_vae_step_opts;
+int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
+                          const float* x, const float* xp, const float* target, const float* onehot,
+                          float* eps_w, float* eps_z,
+                          const float* params, const int64_t* host_offsets12, long n_params,
+                          float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
+                          int need_grads, float* grads, void* ws, size_t ws_bytes,
+                          float* logits, float* w_out, float* wargs_out, float* zargs_out,
+                          float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts, void* stream);
 
 /* The whole cl_vrnn label path of a batch row in one launch (one workgroup per row):
  * fwd: Wargs = hW.K_a + b_a; W = logistic-normal sample; (kl_w, w_rec, hit) -> rowloss[B,3];
@@ -410,7 +436,10 @@ size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tenso
  * t = *iterations_dev + 1 is read on the device and the counter is advanced by the call
  * (so a captured graph can be replayed); otherwise t = step_t.  iterations_dev with step_t == -1: the
  * counter is read but NOT advanced -- a step may be split over several calls on disjoint tensor subsets (each with its
- * own table and plan over the same flat buffers), of which only the last one advances the counter. */
+ * own table and plan over the same flat buffers), of which only the last one advances the counter.
+ * iterations_dev with step_t == CLV_STEP_ADVANCED: the counter already holds t (it was advanced by the launch that
+ * produced the gradients, clv_vae_fused_step_ex's bump_iterations) and is left alone. */
+#define CLV_STEP_ADVANCED (-2)
 /* `weightnorm` selects the update rule: */
 #define CLV_OPT_ADAM     0   /* plain Keras Adam on every tensor                                                   */
 #define CLV_OPT_ADAM_WN  1   /* utils/weightnorm.py:75-143: matrices per output column as g V/||V||, biases plain   */

@@ -369,3 +369,43 @@ def test_adam_step_in_two_pieces_is_bitwise_the_whole_step(dev):
         np.testing.assert_array_equal(res[0][0][k], res[1][0][k])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("B,L,Cn", [(100, 4, 2), (37, 16, 16)])
+def test_cl_vae_fused_step_draws_its_own_noise_and_advances_the_counter(dev, B, L, Cn):
+    """clv_vae_fused_step_ex: the in-kernel Philox draw writes the values clv_philox_normal2 writes (bit for bit), the
+    folded loss means equal clv_loss_sums', and bump + adam_step(advanced=True) is adam_step()."""
+    from clvae_amd import ops
+    from clvae_amd.engine import VaeEngine
+    cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(5)
+    p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=2).items()}
+    x, xp = frames(rng, B, 88), frames(rng, B, 88)
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    a, b = VaeEngine(cfg, B, dev), VaeEngine(cfg, B, dev)
+    assert a.fused and a.folds_step(True)
+    for e in (a, b):
+        e.P.set_weights(p)
+        e.P.iterations.fill_(7)
+    xs = (T(x, dev), T(xp, dev), T(wt, dev))
+    C1 = Cn - 1
+    seed, sw, sz, fw, fz = 0x1234567890, 4, 5, 3 * C1, 3 * L
+    ew, ez = torch.empty(B, C1, device=dev), torch.empty(B, L, device=dev)
+    ops.philox_normal2(ew, B * C1, sw, fw, ez, B * L, sz, fz, seed, 0, step_dev=a.P.iterations)
+    a.loss_and_grads(*xs, ew, ez)
+    a.P.adam_step()
+    ew2, ez2 = torch.zeros(B, C1, device=dev), torch.zeros(B, L, device=dev)
+    b.loss_and_grads(*xs, ew2, ez2, noise=(seed, sw, sz, fw, fz, 0, b.P.iterations), bump=True)
+    torch.cuda.synchronize()
+    assert int(b.P.iterations.item()) == 8
+    b.P.adam_step(advanced=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ew, ew2) and torch.equal(ez, ez2)
+    assert torch.equal(a.P.grads, b.P.grads)
+    la, lb = a.losses(), b.losses()
+    assert all(la[k] == lb[k] for k in la)
+    assert int(a.P.iterations.item()) == int(b.P.iterations.item()) == 8
+    assert torch.equal(a.P.params, b.P.params)
+    # the means of the folded launch against a plain sum of the per-row arrays
+    assert abs(lb['vae'] - float(b.rownll.double().mean())) < 1e-4 * max(1.0, abs(lb['vae']))
+    assert abs(lb['kl_z'] - float(b.rowkl.double().mean())) < 1e-5 * max(1.0, abs(lb['kl_z']))
