@@ -50,7 +50,7 @@ def lstm_seq_flops(w, B):
     return 2.0 * B * w['T'] * 88 * 352
 
 
-def make_engine(w, dev):
+def make_engine(w, dev, bf16=False):
     from clvae_amd.engine import VaeEngine, VrnnEngine
     from clvae_amd.initializers import init_weights
     if w['model'] == 'cl_vrnn':
@@ -59,7 +59,7 @@ def make_engine(w, dev):
         eng = VrnnEngine(cfg, w['B'], dev)
     else:
         cfg = dict(D=88, H=88, L=w['L'], Hc=88, C=w['C'], use_x_prev=True, class_weight=1.0, kl_weight=1.0,
-                   w_kl_weight=1.0, w_log_var_prior=0.0)
+                   w_kl_weight=1.0, w_log_var_prior=0.0, bf16=bool(bf16))
         eng = VaeEngine(cfg, w['B'], dev)
     eng.P.set_weights(init_weights(eng.P.logical, cfg, seed=0))
     return eng, cfg
@@ -213,6 +213,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--bf16', action='store_true',
+                    help='cfg2: the Dense products of the fused cl_vae step on the bf16 matrix cores (fp32 accumulate)')
     ap.add_argument('--no-persistent', action='store_true', help='generation: per-frame hipGraph replay instead of the persistent kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -245,7 +247,7 @@ def main():
 
     if w.get('generate'):
         return bench_generate(args, w, dev, rank, world)
-    eng, cfg = make_engine(w, dev)
+    eng, cfg = make_engine(w, dev, bf16=args.bf16)
     if world > 1:      # replicas start from rank 0's weights and optimizer state
         for t_ in eng.P.state_tensors():
             dist.broadcast(t_, src=0)
@@ -361,7 +363,7 @@ def main():
             "metric": "piano-roll timesteps/sec (train)", "value": round(value, 1), "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if (args.bf16 and w['model'] == 'cl_vae') else "f32", "data": "synthetic",
             "config": {"workload": "%s: %s batch %d/GPU x seq_len %d, latent %d, %d classes, 88-dim piano-roll, "
                                    "Adam-WN, hipGraph=%s" % (args.workload, w['model'], B, T, w['L'], w['C'],
                                                              not args.no_graph),

@@ -26,7 +26,7 @@ class VaeStepOpts(C.Structure):
     """clv_vae_step_opts (include/clvae.h)."""
     _fields_ = [("draw", _i), ("stream_w", _u32), ("stream_z", _u32), ("step", _u32),
                 ("noise_seed", _u64), ("first_w", _u64), ("first_z", _u64),
-                ("step_dev", _p), ("loss_means", _p), ("bump_iterations", _p)]
+                ("step_dev", _p), ("loss_means", _p), ("bump_iterations", _p), ("bf16", _i)]
 
 
 

@@ -211,13 +211,14 @@ def make_decoder(model, latent_dims, class_dim, original_dim=88, use_x_prev=Fals
 
 
 def get_model(batch_size, original_dim, latent_dims, class_dims, optimizer, class_weight=1.0, kl_weight=1.0,
-              use_x_prev=False, w_kl_weight=1.0, w_log_var_prior=0.0, seed=None, device='cuda:0'):
-    """-> (model, enc_model).  latent_dims = (latent_dim_0, latent_dim); class_dims = (class_dim_0, class_dim)."""
+              use_x_prev=False, w_kl_weight=1.0, w_log_var_prior=0.0, seed=None, device='cuda:0', bf16=False):
+    """-> (model, enc_model).  latent_dims = (latent_dim_0, latent_dim); class_dims = (class_dim_0, class_dim).
+    bf16: the Dense products of the fused training step run on the bf16 matrix cores (engine cfg 'bf16')."""
     latent_dim_0, latent_dim = latent_dims
     class_dim_0, class_dim = class_dims
     cfg = dict(D=int(original_dim), H=int(latent_dim_0), L=int(latent_dim), Hc=int(class_dim_0), C=int(class_dim),
                use_x_prev=bool(use_x_prev), class_weight=get_value(class_weight), kl_weight=get_value(kl_weight),
-               w_kl_weight=get_value(w_kl_weight), w_log_var_prior=float(w_log_var_prior))
+               w_kl_weight=get_value(w_kl_weight), w_log_var_prior=float(w_log_var_prior), bf16=bool(bf16))
     eng = VaeEngine(cfg, batch_size, device)
     eng.P.set_weights(init_weights(eng.P.logical, cfg, seed=seed))
     model = ClVaeModel(eng, optimizer, kl_weight, w_kl_weight, class_weight, bool(use_x_prev), seed=seed)

@@ -9,7 +9,7 @@ if __package__ in (None, ''):          # run as a script: make the package impor
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clvae_amd  # noqa: E402,F401
 from clvae_amd.cl_vae.model import get_model  # noqa: E402
-from clvae_amd.cli import TrainPlan, parser_for  # noqa: E402
+from clvae_amd.cli import BF16_FLAGS, TrainPlan, parser_for  # noqa: E402
 from clvae_amd.utils.pianoroll import PianoData  # noqa: E402
 from clvae_amd.utils.weightnorm import data_based_init  # noqa: E402
 
@@ -38,7 +38,7 @@ def train(args):
                                  (args.intermediate_class_dim, args.n_classes), plan.optimizer(), args.class_weight,
                                  plan.kl_weight, use_x_prev=args.use_x_prev, w_kl_weight=plan.w_kl_weight,
                                  w_log_var_prior=args.w_log_var_prior, seed=getattr(args, 'seed', None),
-                                 device=plan.device)
+                                 device=plan.device, bf16=getattr(args, 'bf16', False))
     plan.describe(model)
     data_based_init(model, P.x_train[:100])
     return model, plan.fit(model, P, w_train, w_valid)
@@ -49,4 +49,4 @@ def build_parser():
 
 
 if __name__ == '__main__':
-    train(build_parser().parse_args())
+    train(parser_for('cl_vae.train', BF16_FLAGS).parse_args())

@@ -80,6 +80,11 @@ TABLES = {
 }
 
 # switches of THIS implementation (not in the reference): where the frame loop of sample.py runs
+# cl_vae/train.py only, next to the reference's flags
+BF16_FLAGS = [
+    Flag(('--bf16',), ON, False, 'Dense products of the fused training step on the bf16 matrix cores (fp32 accumulate)'),
+]
+
 DEVICE_LOOP_FLAGS = [
     Flag(('--device_loop',), ON, False, 'generate all -n samples in one device-side frame loop (Philox noise)'),
     Flag(('--host_loop',), ON, False, 'frame loop on the host with np.random, like the reference (default for -n 1)'),

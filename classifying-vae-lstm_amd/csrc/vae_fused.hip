@@ -29,6 +29,21 @@ namespace clv {
 #endif
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+
+// BF16 = true (clv_vae_step_opts.bf16): every Dense product and every weight-gradient product rounds its two operands
+// to bf16 and accumulates in fp32 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16 / 16x16x16) -- 8x the fp32 MFMA
+// rate; sampling, losses and the per-row backward math stay fp32.  The k-slot of an operand register is the same in
+// both modes (slot t of step j is k = 32 j + 4 t + q), so loads and LDS layout do not change.
+__device__ __forceinline__ bf16x8v pack8(const float* v) {
+  return (bf16x8v){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+}
+__device__ __forceinline__ s16x4v pack4(const float* v) {
+  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+  const bf16x4v b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  return __builtin_bit_cast(s16x4v, b);
+}
 
 constexpr int VRB = 16;    // batch rows per workgroup (one MFMA row tile)
 constexpr int VL = 132;    // LDS row stride of every buffer: == 4 mod 64, so the 16 rows x 4 k of an MFMA A read, the
@@ -155,7 +170,7 @@ __device__ __forceinline__ void stage_load(WFrag<KS>& f, const VStage& s, const 
 }
 
 // out = epilogue(A . B) for this wave's tile; B in registers once frag_wait returns
-template <int KS>
+template <int KS, bool BF16>
 __device__ __forceinline__ void stage_mm(const VStage& s, WFrag<KS>& f, float* lds, bool newer) {
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int r = lane & 15, q = lane >> 4;
@@ -177,11 +192,15 @@ __device__ __forceinline__ void stage_mm(const VStage& s, WFrag<KS>& f, float* l
 #pragma unroll
   for (int g = 0; g < KS / 8; ++g)
     if (32 * g < s.K) {
-#pragma unroll
 #if VAB == 5
       for (int i = 8 * g; i < 8 * g + 8; ++i) acc[i & 3] += av[i] * f.v[i];
 #else
-      for (int i = 8 * g; i < 8 * g + 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], f.v[i], acc, 0, 0, 0);
+      if (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack8(av + 8 * g), pack8(f.v + 8 * g), acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 8 * g; i < 8 * g + 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], f.v[i], acc, 0, 0, 0);
+      }
 #endif
     }
   const int col = tile * 16 + r;
@@ -205,7 +224,7 @@ __device__ __forceinline__ void stage_mm(const VStage& s, WFrag<KS>& f, float* l
 // computes the TRANSPOSED tile (DY^T . GA), so a lane ends up with four consecutive columns of one gradient row: one
 // 16-byte store per tile into the slab, whose rows are padded to a multiple of four columns (ceil4(N)).
 // Batch row of k-step m for lane group q: 4 q + m (any bijection does; this one is bank-conflict-free).
-template <int MT>
+template <int MT, bool BF16>
 __device__ __forceinline__ void stage_wgrad(const VStage& s, const float* lds, float* G) {
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int r = lane & 15, q = lane >> 4;
@@ -236,8 +255,12 @@ __device__ __forceinline__ void stage_wgrad(const VStage& s, const float* lds, f
 #if VAB == 2
       for (int m = 0; m < 4; ++m) acc[m] += av[j][m] * bv[j][m];
 #else
+      if (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(av[j]), pack4(bv[j]), acc, 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][m], bv[j][m], acc, 0, 0, 0);
+        for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][m], bv[j][m], acc, 0, 0, 0);
+      }
 #endif
       const int row = k0[j] + r, col = n0[j] + 4 * q;
 #if VAB == 1
@@ -256,7 +279,7 @@ __device__ __forceinline__ void stage_wgrad(const VStage& s, const float* lds, f
   }
 }
 
-template <int KS>
+template <int KS, bool BF16>
 __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VMap M;
@@ -335,10 +358,10 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
     VSTAMPI(si, 0);
     if (newer) stage_load(fn, sb, P);
     VSTAMPI(si, 1);
-    if (stage_has_tile(sa, wave)) stage_mm(sa, fc, lds, newer);
+    if (stage_has_tile(sa, wave)) stage_mm<KS, BF16>(sa, fc, lds, newer);
     VSTAMPI(si, 2);
 #if VAB != 3
-    if (sa.ga_K > 0) stage_wgrad<MT>(sa, lds, G);
+    if (sa.ga_K > 0) stage_wgrad<MT, BF16>(sa, lds, G);
 #endif
     VSTAMPI(si, 3);
     lds_barrier(); VSTAMP(2 + si);
@@ -665,7 +688,9 @@ extern "C" int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, 
   {
     ProfScope p("vae_fused_step", s);
     const bool k24 = C + (use_x_prev ? D : 0) + L <= 96 && D + C <= 96;     // the longest products fit 24 k-steps
-    auto k = k24 ? vae_fused_kernel<24> : vae_fused_kernel<32>;
+    const bool bf16 = opts && opts->bf16;
+    auto k = bf16 ? (k24 ? vae_fused_kernel<24, true> : vae_fused_kernel<32, true>)
+                  : (k24 ? vae_fused_kernel<24, false> : vae_fused_kernel<32, false>);
     const size_t lds = (size_t)VMap().total * sizeof(float);
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds)) return e;
     hipLaunchKernelGGL(k, dim3(nwg), dim3(VNT), lds, s, a);

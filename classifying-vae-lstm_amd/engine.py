@@ -400,6 +400,7 @@ class VaeEngine(_EngineBase):
         p_ = ops._ptr
         opts = _lib.VaeStepOpts()
         opts.loss_means = p_(self.scal)
+        opts.bf16 = int(bool(cfg.get('bf16', False)))
         if noise is not None:
             (opts.noise_seed, opts.stream_w, opts.stream_z, opts.first_w, opts.first_z, opts.step), step_dev = noise[:6], noise[6]
             opts.draw, opts.step_dev = 1, p_(step_dev)

@@ -274,6 +274,10 @@ int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev
  *                    (replaces a clv_loss_sums call); NULL: not computed;
  *   bump_iterations  device step counter incremented once by the slab-sum launch (need_grads only), so that the
  *                    optimizer call that follows can run with step_t = CLV_STEP_ADVANCED; NULL: left alone.
+ *   bf16 != 0        the Dense products and the weight-gradient products round their operands to bf16 and accumulate in
+ *                    fp32 on the bf16 matrix cores (BASELINE configuration 2: "bf16 ... encoder/decoder MFMA kernels
+ *                    only"); sampling, losses and the optimizer stay fp32.  Measured against the fp64 oracle in
+ *                    tests/test_gpu_models.py::test_cl_vae_bf16_step_tolerance.
  * opts == NULL is clv_vae_fused_step. */
 typedef struct clv_vae_step_opts {
   int draw;
@@ -282,6 +286,7 @@ typedef struct clv_vae_step_opts {
   const int32_t* step_dev;
   float* loss_means;
   int32_t* bump_iterations;
+  int bf16;
 } clv_vae_step_opts;
 int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
                           const float* x, const float* xp, const float* target, const float* onehot,

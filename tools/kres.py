@@ -18,7 +18,7 @@ os.makedirs('/tmp/kres', exist_ok=True)
 out = '/tmp/kres/' + os.path.basename(src).replace('.hip', '.s')
 cmd = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only',
        '-I' + os.path.join(root, 'include'), '-Rpass-analysis=kernel-resource-usage', '-o', out, src] + extra
-r = subprocess.run(cmd, capture_output=True, text=True)
+r = subprocess.run(cmd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=600)
 cur = {}
 rows = []
 for line in r.stderr.splitlines():
@@ -34,7 +34,11 @@ for line in r.stderr.splitlines():
     elif ':' in t:
         k, v = t.split(':', 1)
         cur[k.strip()] = v.strip()
-demangle = subprocess.run(['c++filt'] + [r_['name'] for r_ in rows], capture_output=True, text=True)
+if not rows:                      # compile error: show it (c++filt without names would wait on stdin)
+    print(r.stderr[-4000:])
+    sys.exit(1)
+demangle = subprocess.run(['c++filt'] + [r_['name'] for r_ in rows], capture_output=True, text=True,
+                          stdin=subprocess.DEVNULL)
 names = demangle.stdout.splitlines() if demangle.returncode == 0 else [r_['name'] for r_ in rows]
 print("%-100s %5s %5s %6s %6s %4s %7s" % ("kernel", "VGPR", "AGPR", "spill", "scr", "occ", "LDS"))
 for r_, n in zip(rows, names):
