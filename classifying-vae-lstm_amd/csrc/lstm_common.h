@@ -104,6 +104,20 @@ __device__ __forceinline__ void slice_fma_range(const float (&hv)[PKP], const f2
   }
 }
 
+// Packed form without a broadcast: k values in pairs.  Up[j][g] = (U[2j][g], U[2j+1][g]) and a[g] collects (even k,
+// odd k) partial sums, so every v_pk_fma_f32 operand is a natural register pair -- two adjacent h values of a
+// ds_read_b128, two weights the pack kernel stored side by side -- and no operand borrows a foreign register as its
+// unused half (the broadcast form does: a pending load's destination there makes the FMA block wait for the load).
+template <int J0, int J1>
+__device__ __forceinline__ void slice_fma_pairs(const float (&hv)[PKP], const f2 (&Up)[PKK / 2][4], f2 (&a)[4]) {
+#pragma unroll
+  for (int j = J0; j < J1; ++j) {
+    const f2 hp = {hv[2 * j], hv[2 * j + 1]};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) a[g] = __builtin_elementwise_fma(hp, Up[j][g], a[g]);
+  }
+}
+
 // the same product with scalar FMAs: no register pairs, so no v_pk operand can alias the destination of a load in flight
 __device__ __forceinline__ void slice_matvec_scalar(const float* hslice, const f2 (&Ur)[PKK][2], f2 (&acc2)[2]) {
   const float4* hp = reinterpret_cast<const float4*>(hslice);

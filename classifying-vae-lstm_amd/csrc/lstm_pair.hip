@@ -69,13 +69,16 @@ __global__ __launch_bounds__(256) void lstm_pair_pack_kernel(PairPackArgs a) {
     const int s = lane & 3, u_raw = wave * 16 + (lane >> 2), u = min(u_raw, LH - 1), zj = u_raw - LH;
     const bool is_z = !dec && zj >= 0 && 2 * zj < L;
     const float* U = dec ? a.U_d : a.U_e;
+    // float4 kk of a lane = (k0, k1 | gate ga), (k0, k1 | gate gb) with k0 = 2 (kk / 2), (ga, gb) = (0, 1) for even kk
+    // and (2, 3) for odd kk: the operand pairs of slice_fma_pairs
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int g = 2 * (kk & 1) + (e2 >> 1), k = PKK * s + 2 * (kk >> 1) + (e2 & 1);
       if (is_z) {                                  // head column (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)
         const int l = 2 * zj + (g & 1);
-        v[g] = l < L ? a.Wz[(size_t)(PKK * s + kk) * 2 * L + (g >> 1) * L + l] : 0.f;
+        v[e2] = l < L ? a.Wz[(size_t)k * 2 * L + (g >> 1) * L + l] : 0.f;
       } else {
-        v[g] = U[(size_t)(PKK * s + kk) * LG + g * LH + u];
+        v[e2] = U[(size_t)k * LG + g * LH + u];
       }
     }
   } else if (i < PK_BD) {                          // z rows of the decoder input kernel: latent s + 4q
@@ -164,13 +167,13 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   auto zcol = [&](int g) { const int l = 2 * zj + (g & 1); return l < L ? (g >> 1) * L + l : -1; };
   const Sel4 sel_s(s);
 
-  f2 Ur[PKK][2];
+  f2 Up[PKK / 2][4];     // [k pair][gate] = (U[2j][g], U[2j+1][g])
   {
     const float4* pw = reinterpret_cast<const float4*>(a.pack) + PK_FE + wave * PKK * 64 + lane;
 #pragma unroll
     for (int kk = 0; kk < PKK; ++kk) {
       const float4 v = pw[kk * 64];
-      Ur[kk][0][0] = v.x; Ur[kk][0][1] = v.y; Ur[kk][1][0] = v.z; Ur[kk][1][1] = v.w;
+      Up[kk >> 1][2 * (kk & 1)] = (f2){v.x, v.y}; Up[kk >> 1][2 * (kk & 1) + 1] = (f2){v.z, v.w};
     }
   }
   const size_t bt0 = (size_t)b * T;
@@ -213,14 +216,14 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   };
   // the 4 gate sums of this lane's unit: h (LDS) . U slice, reduced over the k-slices
   auto gate_sums = [&](const float* hslice, float x0, float (&z)[4]) {
-    float acc[4];
+    f2 acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (s == g) ? x0 : 0.f;
+    for (int g = 0; g < 4; ++g) acc[g] = (f2){(s == g) ? x0 : 0.f, 0.f};
     float hv[PKP];
     load_hslice(hslice, hv);
-    slice_fma_range<0, PKK>(hv, Ur, acc);
+    slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g]);
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g][0] + acc[g][1]);
   };
 
   for (int i = 0; i < T; ++i) {
@@ -254,15 +257,15 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   }
   // iteration T: only the latent head of step T-1 is left
   if (wave == PNW - 1) {
-    float acc[4];
+    f2 acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (s == g) ? rb : 0.f;
+    for (int g = 0; g < 4; ++g) acc[g] = (f2){(s == g) ? rb : 0.f, 0.f};
     float hv[PKP];
     load_hslice(&hb[T & 1][PKP * s], hv);
-    slice_fma_range<0, PKK>(hv, Ur, acc);
+    slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g]);
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g][0] + acc[g][1]);
     float zv, klv;
     latent(z, en, zv, klv);
     if (lat_ok) {
@@ -282,14 +285,14 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
                                                  float (*zbuf)[PLMAX]) {
   const int s = lane & 3, b = blockIdx.x, T = a.T;
   const int u = min(wave * 16 + (lane >> 2), LH - 1);
-  f2 Ur[PKK][2];
+  f2 Up[PKK / 2][4];     // [k pair][gate] = (U[2j][g], U[2j+1][g])
   f2 Kzr[ZQ][2];         // lane s takes the latents s, s+4, ...
   {
     const float4* pw = reinterpret_cast<const float4*>(a.pack) + PK_FD + wave * PKK * 64 + lane;
 #pragma unroll
     for (int kk = 0; kk < PKK; ++kk) {
       const float4 v = pw[kk * 64];
-      Ur[kk][0][0] = v.x; Ur[kk][0][1] = v.y; Ur[kk][1][0] = v.z; Ur[kk][1][1] = v.w;
+      Up[kk >> 1][2 * (kk & 1)] = (f2){v.x, v.y}; Up[kk >> 1][2 * (kk & 1) + 1] = (f2){v.z, v.w};
     }
     const float4* pz = reinterpret_cast<const float4*>(a.pack) + PK_KZ + wave * PLQ * 64 + lane;
 #pragma unroll
@@ -318,24 +321,27 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     if (HASXP) xn2 = xp[(size_t)min(t + 2, T - 1) * LG];
     // scalar FMAs throughout: with v_pk_fma the allocator pairs a prefetch's destination register with an h value
     // inside a packed operand, and the wave waits for the load in the middle of the FMA block (+4 % step throughput)
-    float acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (s == g) ? xv : 0.f;
+    f2 acc[4];       // (even k, odd k) partial sums; the input projection and z_t . K_z start the odd halves
     {   // z_t . K_z: branch-free (rows of K_z beyond latent_dim are zero registers); does not depend on h
+      float zk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) zk[g] = 0.f;
       const float4 zq = *reinterpret_cast<const float4*>(&zbuf[cur][PLQ * s]);
       const float zl[PLQ] = {zq.x, zq.y, zq.z, zq.w};
 #pragma unroll
       for (int q = 0; q < ZQ; ++q) {
-        acc[0] = fmaf(zl[q], Kzr[q][0][0], acc[0]); acc[1] = fmaf(zl[q], Kzr[q][0][1], acc[1]);
-        acc[2] = fmaf(zl[q], Kzr[q][1][0], acc[2]); acc[3] = fmaf(zl[q], Kzr[q][1][1], acc[3]);
+        zk[0] = fmaf(zl[q], Kzr[q][0][0], zk[0]); zk[1] = fmaf(zl[q], Kzr[q][0][1], zk[1]);
+        zk[2] = fmaf(zl[q], Kzr[q][1][0], zk[2]); zk[3] = fmaf(zl[q], Kzr[q][1][1], zk[3]);
       }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = (f2){(s == g) ? xv : 0.f, zk[g]};
     }
     float hv[PKP];
     load_hslice(&hb[cur][PKP * s], hv);
-    slice_fma_range<0, PKK>(hv, Ur, acc);
+    slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g]);
+    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g][0] + acc[g][1]);
     float h, gg;
     lstm_cell<GATE>(z, c, h, gg);
     hb[cur ^ 1][hslot] = h;
