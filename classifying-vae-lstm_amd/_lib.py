@@ -60,6 +60,7 @@ SIGNATURES = {
     "clv_gemm_f32_deferred": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p, _p]),
     "clv_gemm_grouped_tn_deferred": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p, _p]),
     "clv_splitk_reduce_multi": (_i, [_p, _i, _p]),
+    "clv_splitk_reduce_multi_means": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
     "clv_lstm_wgrad_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_lstm_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "clv_lstm_wgrad": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,

@@ -671,8 +671,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceJob j) {
 // several pending reductions in one launch (the weight gradients of a whole backward pass)
 constexpr int MAX_JOBS = 16;
 struct ReduceTable { int njobs; unsigned blk0[MAX_JOBS + 1]; ReduceJob job[MAX_JOBS]; };
-__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t) {
+// up to five strided means riding in the same launch (the loss terms of a step): one block each, after the jobs' blocks
+struct MeanTerms { int n_terms; const float* x[5]; int n[5]; int stride[5]; float* out; };
+__device__ __forceinline__ void mean_block(const MeanTerms& m, int k, float4 (*red)[16]) {
+  const float* x = m.x[0]; int n = m.n[0], st = m.stride[0];
+#pragma unroll
+  for (int i = 1; i < 5; ++i)
+    if (k == i) { x = m.x[i]; n = m.n[i]; st = m.stride[i]; }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = threadIdx.x;
+  if (st == 1 && ((uintptr_t)x) % 16 == 0) {        // contiguous term: float4 loads, 4 in flight per thread
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const int n4 = n / 4;
+    int j = threadIdx.x;
+    for (; j + 768 < n4; j += 1024) {
+      const float4 a = x4[j], b = x4[j + 256], c = x4[j + 512], d = x4[j + 768];
+      a0 += (a.x + a.y) + (a.z + a.w); a1 += (b.x + b.y) + (b.z + b.w);
+      a2 += (c.x + c.y) + (c.z + c.w); a3 += (d.x + d.y) + (d.z + d.w);
+    }
+    for (; j < n4; j += 256) { const float4 a = x4[j]; a0 += (a.x + a.y) + (a.z + a.w); }
+    i = 4 * n4 + threadIdx.x;
+  }
+  for (; i + 768 < n; i += 1024) {
+    a0 += x[(size_t)i * st]; a1 += x[(size_t)(i + 256) * st];
+    a2 += x[(size_t)(i + 512) * st]; a3 += x[(size_t)(i + 768) * st];
+  }
+  for (; i < n; i += 256) a0 += x[(size_t)i * st];
+  const float acc = wave_sum((a0 + a1) + (a2 + a3));
+  float* part = reinterpret_cast<float*>(red);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) m.out[k] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
+}
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t, MeanTerms m) {
   __shared__ float4 red[16][16];
+  if (blockIdx.x >= t.blk0[t.njobs]) { mean_block(m, blockIdx.x - t.blk0[t.njobs], red); return; }
   int ji = 0;
 #pragma unroll
   for (int i = 1; i < MAX_JOBS; ++i)
@@ -936,8 +969,20 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
 }
 
 extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream) {
+  return clv_splitk_reduce_multi_means(jobs, njobs, nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
+                                             const int* stride, int n_terms, float* means_out, void* stream) {
   using namespace clv;
-  if (!jobs || njobs < 0) return CLV_EINVAL;
+  if (njobs < 0 || (njobs > 0 && !jobs) || n_terms < 0 || n_terms > 5) return CLV_EINVAL;
+  if (n_terms > 0 && (!x || !n || !stride || !means_out)) return CLV_EINVAL;
+  MeanTerms m{};
+  m.n_terms = n_terms; m.out = means_out;
+  for (int i = 0; i < n_terms; ++i) {
+    if (!x[i] || n[i] <= 0) return CLV_EINVAL;
+    m.x[i] = x[i]; m.n[i] = n[i]; m.stride[i] = stride[i];
+  }
   hipStream_t s = (hipStream_t)stream;
   ReduceTable t;
   t.njobs = 0;
@@ -952,10 +997,10 @@ extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, vo
     t.job[t.njobs++] = j;
     blk += reduce_blocks(j);
   }
-  if (t.njobs == 0) return CLV_OK;
+  if (t.njobs == 0 && n_terms == 0) return CLV_OK;
   t.blk0[t.njobs] = blk;
   ProfScope p("gemm_splitk_reduce", s);
-  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blk), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blk + (unsigned)n_terms), dim3(256), 0, s, t, m);
   return launch_status();
 }
 

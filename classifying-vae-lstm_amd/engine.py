@@ -884,8 +884,11 @@ class VrnnEngine(_EngineBase):
             ops.bernoulli_nll(BT, D, self.logits, X if target is None else target, D, inv_bt, self.rownll,
                               self.dlogits if need_grads else None)
         kl = (self.klterm, BT * L, 1) if self.fuse_pair else (self.rowkl, BT, 1)
-        ops.loss_sums([(self.rownll, BT, 1), kl, (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3),
-                       (self.rowloss[:, 2:], B, 3)], self.scal)
+        terms = [(self.rownll, BT, 1), kl, (self.rowloss, B, 3), (self.rowloss[:, 1:], B, 3), (self.rowloss[:, 2:], B, 3)]
+        # the loss means ride in the reduce launch that ends the backward pass (grads_tail) when there is one
+        self._loss_terms = terms if (need_grads and self._rq() is not None) else None
+        if self._loss_terms is None:
+            ops.loss_sums(terms, self.scal)
         if not need_grads:
             self._join()
             return
@@ -935,4 +938,5 @@ class VrnnEngine(_EngineBase):
                                        4 * H, B)
         self._dense_wgrad('Wargs', self.hW, D, D, 2 * C1, B, self.dwargs, ws, rq)
         if rq is not None:
-            rq.flush()
+            rq.flush(means=getattr(self, '_loss_terms', None), out=self.scal)
+            self._loss_terms = None

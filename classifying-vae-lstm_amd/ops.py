@@ -59,8 +59,17 @@ class ReduceQueue:
         self.n += 1
         return j
 
-    def flush(self):
-        if self.n:
+    def flush(self, means=None, out=None):
+        """Run the pending reductions in one launch.  means: up to five (tensor, n, stride) terms whose means go to
+        out[k] from extra blocks of the same launch (a step's loss terms: no launch of their own)."""
+        if means:
+            k = len(means)
+            xs = (C.c_void_p * k)(*[_ptr(t) for t, _, _ in means])
+            ns = (C.c_int * k)(*[int(n) for _, n, _ in means])
+            st = (C.c_int * k)(*[int(s) for _, _, s in means])
+            check(_lib.lib().clv_splitk_reduce_multi_means(self.jobs, self.n, xs, ns, st, k, _ptr(out), _stream()),
+                  "clv_splitk_reduce_multi_means")
+        elif self.n:
             check(_lib.lib().clv_splitk_reduce_multi(self.jobs, self.n, _stream()), "clv_splitk_reduce_multi")
         self.n = 0
 

@@ -109,6 +109,11 @@ int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int nprob, int N, i
                                  const float* B, int ldb, float beta,
                                  int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
 int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream);
+/* The same launch with up to five strided means computed by extra blocks (means_out[i] = mean of the n[i] elements
+ * x[i][k * stride[i]]): a training step takes its loss terms here instead of in a clv_loss_sums launch of its own.
+ * x / n / stride are host arrays of n_terms entries (device pointers in x). */
+int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
+                                  const int* stride, int n_terms, float* means_out, void* stream);
 
 /* Every kernel gradient of one LSTM in one pass over dz [K,N], N = 4H = 352, K = B*T (cl_vrnn/model.py:196-199,
  * 225-228; replaces the grouped f32-MFMA product for these shapes):
