@@ -547,6 +547,12 @@ static int lstm_fwd_dispatch(clv::LstmFwdArgs a, int gate_act, hipStream_t s) {
   ProfScope p("lstm_seq_fwd", s);
   const bool save = a.gates != nullptr;
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
+  // Large batches: four rows per workgroup on the 4x4x1 MFMA (lstm_mfma.hip) once that fills the chip better than one
+  // or two rows per workgroup on the VALU.  CLV_LSTM_MFMA=0 / 1 forces the choice (tests run both on the same inputs).
+  static const int mfma_mode = env_int("CLV_LSTM_MFMA", -1);
+  const bool eligible = save && !a.xin && !a.h0 && !a.c0 && a.T >= 1 && a.xproj;
+  if (eligible && (mfma_mode == 1 || (mfma_mode < 0 && a.B >= 768)))
+    return launch_lstm_fwd_mfma(a.B, a.T, gate_act, a.xproj, a.rowbias, a.U, a.hs, a.cs, a.gates, a.hT, a.cT, s);
   if (lstm_ks() == 8) {
     if (hard) return save ? launch_fwd<8, CLV_GATE_HARD_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_HARD_SIGMOID, false>(a, s);
     return save ? launch_fwd<8, CLV_GATE_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_SIGMOID, false>(a, s);

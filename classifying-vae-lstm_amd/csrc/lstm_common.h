@@ -7,6 +7,11 @@ namespace clv {
 constexpr int LH = 88;          // hidden units
 constexpr int LG = 4 * LH;      // gate columns
 
+// lstm_mfma.hip: the sequence forward with the recurrent product on the multi-block f32 MFMA, four rows per workgroup
+// (training passes from zero state; used from ~3 rows per CU on)
+int launch_lstm_fwd_mfma(int B, int T, int gate_act, const float* xproj, const float* rowbias, const float* U,
+                         float* hs, float* cs, float* gates, float* hT, float* cT, hipStream_t s);
+
 typedef float f2 __attribute__((ext_vector_type(2)));   // register pair: v_pk_fma_f32 does two fp32 FMAs per issue slot
 
 template <int CTRL>

@@ -1,0 +1,190 @@
+// lstm_mfma.hip -- the LSTM sequence forward for LARGE batches: the recurrent product on the matrix cores (gfx950).
+//
+// lstm.hip keeps the recurrence on the VALU because at the reference's batch sizes a GPU has one CU per batch row
+// and a 16-row MFMA tile cannot be filled.  From ~4 rows per CU on (BASELINE configuration 5: 1024 rows per GPU) the
+// multi-block f32 MFMA fits: v_mfma_f32_4x4x1_16B_f32 does 16 independent 4x4 outer products per instruction,
+//     D_b[i][j] += A_b[i] * B_b[j],   block b = lane / 4,  A_b[i] in lane 4b+i,  B_b[j] in lane 4b+j,
+//     D_b[i][j] in register i of lane 4b+j                      (layout and rate: tools/probes/mfma4x4_probe.hip;
+//     8 cycles per instruction and SIMD, 40 cycles from one instruction to the next on the same accumulator),
+// at the f32 vector rate but with no per-lane reduction tree, one instruction per 256 MACs, and the VALU left to
+// the gate math.  A workgroup owns FOUR batch rows (the i index).  Block b = (gate cg = b / 4, k residue kb = b % 4):
+//     A_b[i]  = h[row i][k = 4m + kb]                    (the same in all four gate blocks of a k residue)
+//     B_b[j]  = U[4m + kb][gate cg, unit 4q + j]         (resident in registers: 22 k-steps per unit quad q)
+// so 22 instructions accumulate, for the unit quad q, the partial sums over k = kb (mod 4) of all four gates of four
+// units for four rows.  Two DPP row rotations (lanes 4 and 8 apart) add the four residues; lane (cg, kb, j) then
+// finishes row kb: it activates its gate, the four gate lanes of a (row, unit) -- 16 lanes apart -- exchange the
+// activated values with v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip), every one of them updates c
+// and h (each stores a different output), and h goes back to LDS in the A-operand order [row][k residue][m].
+// 8 waves, unit quads w, w+8, w+16 per wave (22 quads), 66 weights per lane.
+// (The unit is the fastest lane index on purpose: with the GATE there the exchange would be a DPP quad broadcast, but
+// the per-step loads and stores of a quarter wave then touch 16 four-byte pieces instead of 4 sixteen-byte ones and
+// the kernel ran 1.5x slower.)
+#include <stdlib.h>
+
+#include "lstm_common.h"
+
+namespace clv {
+
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+constexpr int MR = 4;             // batch rows per workgroup
+constexpr int MNW = 8;            // waves
+constexpr int MQ = 22;            // unit quads
+constexpr int MKS = LH / 4;       // 22 k-steps of 4
+constexpr int MHS = 28;           // LDS stride of one (row, k residue) slice of h: the 16 slices of a ds_read_b128 lane
+                                  // group start at banks 28 c mod 64, four banks each, all distinct (see lstm_pair.hip)
+
+__device__ float g_mfma_dump[128];
+
+struct LstmMfmaFwdArgs {
+  int B, T;
+  const float* xproj;    // [B,T,352]
+  const float* rowbias;  // [B,352] or null
+  const float* U;        // [88,352]
+  float* hs; float* cs; float* gates;      // [B,T,88] [B,T,88] [B,T,352] (z_i, z_f, tanh(z_c), z_o)
+  float* hT; float* cT;                    // [B,88] or null
+};
+
+template <int GATE, int NQ>
+__device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, float (*hA)[16 * MHS], int wave) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 3, kb = (lane >> 2) & 3, cg = lane >> 4;
+  const int T = a.T;
+  const int row = blockIdx.x * MR + kb;                 // the row this lane finishes
+  const bool live = row < a.B;
+  const size_t rowc = (size_t)min(row, a.B - 1);
+  const Sel4 sel_kb(kb);
+
+  float Ub[NQ][MKS];           // B operands: U[4m + kb][cg*88 + 4 quad + j]
+  int unit[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    unit[q] = 4 * (wave + MNW * q) + j;
+#pragma unroll
+    for (int m = 0; m < MKS; ++m) Ub[q][m] = a.U[(size_t)(4 * m + kb) * LG + cg * LH + unit[q]];
+  }
+  float rb[NQ], c[NQ], xn[NQ], xn2[NQ];
+  const float* xp[NQ];
+  float* gptr[NQ];
+  float* sptr[NQ];             // second store: h (gate lane 0), c (gate lane 1), nothing (gate lanes 2, 3)
+  int sstr;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int col = cg * LH + unit[q];
+    rb[q] = a.rowbias ? a.rowbias[rowc * LG + col] : 0.f;
+    c[q] = 0.f;
+    xp[q] = a.xproj + rowc * T * LG + col;
+    xn[q] = xp[q][0];
+    xn2[q] = xp[q][(size_t)min(1, T - 1) * LG];
+    gptr[q] = live ? a.gates + rowc * T * LG + col : g_mfma_dump + lane;
+    float* second = cg == 0 ? a.hs + rowc * T * LH + unit[q] : a.cs + rowc * T * LH + unit[q];
+    sptr[q] = (live && cg < 2) ? second : g_mfma_dump + 64 + lane;
+  }
+  sstr = (live && cg < 2) ? LH : 0;
+  const int gstr = live ? LG : 0;
+  g_mfma_dump[lane] = 0.f;     // stores after the prologue's loads, like every iteration (counted vmcnt, see lstm.hip)
+  g_mfma_dump[lane + 64] = 0.f;
+
+  // A operand: h[row j][4m + kb], m = 0..21, contiguous in LDS
+  const int aslice = (j * 4 + kb) * MHS;
+  // h write position of unit u = 4 quad + j of row kb: k = u -> residue j, step quad
+  int hpos[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) hpos[q] = (kb * 4 + j) * MHS + (wave + MNW * q);
+
+  float h_last[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) h_last[q] = 0.f;
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    float xv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      xv[q] = xn[q] + rb[q];
+      xn[q] = xn2[q];
+      xn2[q] = xp[q][(size_t)min(t + 2, T - 1) * LG];
+    }
+    float av[MKS + 2];
+    {
+      const float4* ap = reinterpret_cast<const float4*>(&hA[cur][aslice]);
+#pragma unroll
+      for (int i = 0; i < (MKS + 2) / 4; ++i) {
+        const float4 v = ap[i];
+        av[4 * i] = v.x; av[4 * i + 1] = v.y; av[4 * i + 2] = v.z; av[4 * i + 3] = v.w;
+      }
+    }
+    // Two accumulators per quad (even / odd k-steps) issued round-robin: an accumulator is touched every 2 NQ
+    // instructions (48 cycles at three quads), past the 40-cycle dependent latency, so the matrix pipe never waits on
+    // its own result.  The scheduling barriers pin the order: left alone the compiler issues each accumulator's 22
+    // instructions back to back (2640 cycles per step instead of 528).
+    f32x4m D[NQ], E[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) D[q] = E[q] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MKS; m += 2) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) D[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m], Ub[q][m], D[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) E[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m + 1], Ub[q][m + 1], E[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float zr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = D[q][r] + E[q][r];
+        x = dpp_add<0x124>(x);           // row_ror:4, row_ror:8: the four k residues, total in every lane
+        x = dpp_add<0x128>(x);
+        zr[r] = x;
+      }
+      const float z = sel_kb(zr) + xv[q];
+      const float sg = gate_fn<GATE>(z), th = fast_tanh(z);
+      const unsigned act = __builtin_bit_cast(unsigned, cg == 2 ? th : sg);
+      // the four gates of this (row, unit) sit 16 lanes apart (rows of 16 lanes = gates i, f, c, o):
+      // permlane16_swap(x, x) -> ([i i c c], [f f o o]); permlane32_swap(y, y) -> (low half everywhere, high half everywhere)
+      const auto p16 = __builtin_amdgcn_permlane16_swap(act, act, false, false);
+      const auto pic = __builtin_amdgcn_permlane32_swap(p16[0], p16[0], false, false);
+      const auto pfo = __builtin_amdgcn_permlane32_swap(p16[1], p16[1], false, false);
+      const float gi = __builtin_bit_cast(float, pic[0]), gg = __builtin_bit_cast(float, pic[1]);
+      const float gf = __builtin_bit_cast(float, pfo[0]), go = __builtin_bit_cast(float, pfo[1]);
+      c[q] = gf * c[q] + gi * gg;
+      const float h = go * fast_tanh(c[q]);
+      h_last[q] = h;
+      *gptr[q] = cg == 2 ? th : z;
+      *sptr[q] = cg == 0 ? h : c[q];
+      gptr[q] += gstr;
+      sptr[q] += sstr;
+      if (cg == 0) hA[cur ^ 1][hpos[q]] = h;
+    }
+    step_barrier();
+  }
+  if (live && cg < 2) {
+    float* dst = cg == 0 ? a.hT : a.cT;
+    if (dst)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dst[rowc * LH + unit[q]] = cg == 0 ? h_last[q] : c[q];
+  }
+}
+
+template <int GATE>
+__global__ __launch_bounds__(MNW * 64) void lstm_fwd_mfma_kernel(LstmMfmaFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float hA[2][16 * MHS];
+  for (int i = threadIdx.x; i < 2 * 16 * MHS; i += MNW * 64) (&hA[0][0])[i] = 0.f;
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave < MQ - 2 * MNW) lstm_fwd_mfma_body<GATE, 3>(a, hA, wave);     // waves 0-5: quads w, w+8, w+16
+  else lstm_fwd_mfma_body<GATE, 2>(a, hA, wave);                         // waves 6, 7: quads w, w+8
+}
+
+int launch_lstm_fwd_mfma(int B, int T, int gate_act, const float* xproj, const float* rowbias, const float* U,
+                         float* hs, float* cs, float* gates, float* hT, float* cT, hipStream_t s) {
+  LstmMfmaFwdArgs a{B, T, xproj, rowbias, U, hs, cs, gates, hT, cT};
+  const dim3 grid((B + MR - 1) / MR), block(MNW * 64);
+  if (gate_act == CLV_GATE_HARD_SIGMOID) hipLaunchKernelGGL(lstm_fwd_mfma_kernel<CLV_GATE_HARD_SIGMOID>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(lstm_fwd_mfma_kernel<CLV_GATE_SIGMOID>, grid, block, 0, s, a);
+  return launch_status();
+}
+
+}  // namespace clv

@@ -151,6 +151,34 @@ def test_lstm_seq_fwd_bwd(dev, B, Tn, gate):
     np.testing.assert_allclose(N(dzsum), dz.sum(1), atol=1e-4)
 
 
+@pytest.mark.parametrize("B,Tn,gate", [(1027, 7, 0), (768, 3, 1), (2050, 2, 0)])
+def test_lstm_seq_fwd_large_batch_runs_on_the_matrix_cores(dev, B, Tn, gate):
+    """From 768 rows on, a training forward from zero state takes csrc/lstm_mfma.hip (four rows per workgroup, the
+    recurrent product on v_mfma_f32_4x4x1_16B_f32); batch sizes that are not multiples of 4 included."""
+    from clvae_amd import ops
+    H = 88
+    rng = np.random.default_rng(B + Tn)
+    U = O.orthogonal(rng, (H, 4 * H), np.float64) * 1.5
+    xproj = rng.standard_normal((B, Tn, 4 * H)) * 1.5
+    rb = rng.standard_normal((B, 4 * H)) * 0.3
+    act = 'hard_sigmoid' if gate == 0 else 'sigmoid'
+    hs_ref, cache = O.lstm_forward(xproj + rb[:, None, :], np.eye(4 * H), U, np.zeros(4 * H), gate_act=act)
+    gates = T(xproj, dev)
+    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
+    hT = torch.empty(B, H, device=dev); cT = torch.empty(B, H, device=dev)
+    ops.lstm_seq_fwd(B, Tn, gates, T(rb, dev), T(U, dev), hs, cs, gates, hT=hT, cT=cT, gate_act=gate)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(hs), hs_ref, atol=3e-6)
+    np.testing.assert_allclose(N(cs), cache['C'], atol=5e-6)
+    np.testing.assert_allclose(N(hT), hs_ref[:, -1], atol=3e-6)
+    np.testing.assert_allclose(N(cT), cache['C'][:, -1], atol=5e-6)
+    g = N(gates).reshape(B, Tn, 4, H)
+    Zr = cache['Z'].reshape(B, Tn, 4, H)
+    for k in (0, 1, 3):
+        np.testing.assert_allclose(g[:, :, k], Zr[:, :, k], atol=1e-5)
+    np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=3e-6)
+
+
 def test_label_gauss_bernoulli(dev):
     from clvae_amd import ops
     rng = np.random.default_rng(3)
