@@ -13,12 +13,17 @@
 // so 22 instructions accumulate, for the unit quad q, the partial sums over k = kb (mod 4) of all four gates of four
 // units for four rows.  Two DPP row rotations (lanes 4 and 8 apart) add the four residues; lane (cg, kb, j) then
 // finishes row kb: it activates its gate, the four gate lanes of a (row, unit) -- 16 lanes apart -- exchange the
-// activated values with v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip), every one of them updates c
-// and h (each stores a different output), and h goes back to LDS in the A-operand order [row][k residue][m].
+// activated values through ds_bpermute, every one of them updates c and h (each stores a different output), and h
+// goes back to LDS in the A-operand order [row][k residue][m].
 // 8 waves, unit quads w, w+8, w+16 per wave (22 quads), 66 weights per lane.
-// (The unit is the fastest lane index on purpose: with the GATE there the exchange would be a DPP quad broadcast, but
-// the per-step loads and stores of a quarter wave then touch 16 four-byte pieces instead of 4 sixteen-byte ones and
-// the kernel ran 1.5x slower.)
+// (The unit is the fastest lane index on purpose: with the GATE there the exchange is a DPP quad broadcast, but the
+// per-step loads and stores of a quarter wave then touch 16 four-byte pieces instead of 4 sixteen-byte ones and the
+// kernel ran 1.5x slower: 541 us against 354 us per launch at 1024 x 256.)
+//
+// Measured at configuration 5 (1024 rows, T = 256): 354 us per launch against 368 us for the VALU kernel at two rows
+// per workgroup.  A step is the MFMA phase (66 instructions per wave, two waves per SIMD: ~1060 cycles) FOLLOWED by
+// the gate phase (~140 vector instructions per wave: residue sums, activation, exchange, cell, stores): the next
+// step's products need every h of this one, so the two phases of the four rows a CU owns cannot overlap.
 #include <stdlib.h>
 
 #include "lstm_common.h"
@@ -91,6 +96,8 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, flo
   int hpos[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) hpos[q] = (kb * 4 + j) * MHS + (wave + MNW * q);
+  // source lanes (byte addresses for ds_bpermute) of the four activated gates of this lane's (row, unit)
+  const int src0 = 4 * (lane & 15);
 
   float h_last[NQ];
 #pragma unroll
@@ -141,14 +148,12 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, flo
       }
       const float z = sel_kb(zr) + xv[q];
       const float sg = gate_fn<GATE>(z), th = fast_tanh(z);
-      const unsigned act = __builtin_bit_cast(unsigned, cg == 2 ? th : sg);
-      // the four gates of this (row, unit) sit 16 lanes apart (rows of 16 lanes = gates i, f, c, o):
-      // permlane16_swap(x, x) -> ([i i c c], [f f o o]); permlane32_swap(y, y) -> (low half everywhere, high half everywhere)
-      const auto p16 = __builtin_amdgcn_permlane16_swap(act, act, false, false);
-      const auto pic = __builtin_amdgcn_permlane32_swap(p16[0], p16[0], false, false);
-      const auto pfo = __builtin_amdgcn_permlane32_swap(p16[1], p16[1], false, false);
-      const float gi = __builtin_bit_cast(float, pic[0]), gg = __builtin_bit_cast(float, pic[1]);
-      const float gf = __builtin_bit_cast(float, pfo[0]), go = __builtin_bit_cast(float, pfo[1]);
+      const int act = __builtin_bit_cast(int, cg == 2 ? th : sg);
+      // the four gates of this (row, unit) sit 16 lanes apart: four reads through the LDS crossbar
+      const float gi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0, act));
+      const float gf = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0 + 64, act));
+      const float gg = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0 + 128, act));
+      const float go = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src0 + 192, act));
       c[q] = gf * c[q] + gi * gg;
       const float h = go * fast_tanh(c[q]);
       h_last[q] = h;
