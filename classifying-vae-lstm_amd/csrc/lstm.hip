@@ -542,6 +542,11 @@ static int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
 
 }  // namespace clv
 
+bool clv::lstm_fwd_mfma_wanted(int B) {
+  static const int mfma_mode = env_int("CLV_LSTM_MFMA", -1);
+  return mfma_mode == 1 || (mfma_mode < 0 && B >= 768);
+}
+
 static int lstm_fwd_dispatch(clv::LstmFwdArgs a, int gate_act, hipStream_t s) {
   using namespace clv;
   ProfScope p("lstm_seq_fwd", s);
@@ -549,10 +554,10 @@ static int lstm_fwd_dispatch(clv::LstmFwdArgs a, int gate_act, hipStream_t s) {
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
   // Large batches: four rows per workgroup on the 4x4x1 MFMA (lstm_mfma.hip) once that fills the chip better than one
   // or two rows per workgroup on the VALU.  CLV_LSTM_MFMA=0 / 1 forces the choice (tests run both on the same inputs).
-  static const int mfma_mode = env_int("CLV_LSTM_MFMA", -1);
   const bool eligible = save && !a.xin && !a.h0 && !a.c0 && a.T >= 1 && a.xproj;
-  if (eligible && (mfma_mode == 1 || (mfma_mode < 0 && a.B >= 768)))
-    return launch_lstm_fwd_mfma(a.B, a.T, gate_act, a.xproj, a.rowbias, a.U, a.hs, a.cs, a.gates, a.hT, a.cT, s);
+  if (eligible && lstm_fwd_mfma_wanted(a.B))
+    return launch_lstm_fwd_mfma(a.B, a.T, gate_act, a.xproj, a.rowbias, a.U, a.hs, a.cs, a.gates, a.hT, a.cT, nullptr, 0, 0,
+                                nullptr, s);
   if (lstm_ks() == 8) {
     if (hard) return save ? launch_fwd<8, CLV_GATE_HARD_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_HARD_SIGMOID, false>(a, s);
     return save ? launch_fwd<8, CLV_GATE_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_SIGMOID, false>(a, s);
@@ -571,6 +576,22 @@ extern "C" int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
   LstmFwdArgs a{B, T, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT, nullptr, nullptr, 0, 0};
   return lstm_fwd_dispatch(a, gate_act, (hipStream_t)stream);
+}
+
+extern "C" int clv_lstm_seq_fwd_z_supported(int B, int H, int nz) {
+  return H == clv::LH && nz >= 1 && nz <= 32 && clv::lstm_fwd_mfma_wanted(B);
+}
+
+extern "C" int clv_lstm_seq_fwd_z(int B, int T, int H, int gate_act, const float* xproj, const float* rowbias,
+                                  const float* U, const float* zin, int ldz, int nz, const float* Kz,
+                                  float* hs, float* cs, float* gates, float* hT, float* cT, void* stream) {
+  using namespace clv;
+  if (!clv_lstm_seq_fwd_z_supported(B, H, nz) || T < 1 || !xproj || !U || !zin || !Kz || ldz < nz || !hs || !cs || !gates)
+    return CLV_EINVAL;
+  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("lstm_seq_fwd", s);
+  return launch_lstm_fwd_mfma(B, T, gate_act, xproj, rowbias, U, hs, cs, gates, hT, cT, zin, ldz, nz, Kz, s);
 }
 
 extern "C" size_t clv_lstm_seq_fwd_x_lds_bytes(int B, int nx) {

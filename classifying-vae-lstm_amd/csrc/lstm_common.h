@@ -9,8 +9,11 @@ constexpr int LG = 4 * LH;      // gate columns
 
 // lstm_mfma.hip: the sequence forward with the recurrent product on the multi-block f32 MFMA, four rows per workgroup
 // (training passes from zero state; used from ~3 rows per CU on)
+// zin != null: + z_t . Kz inside the kernel (z_t: B*T rows of stride ldz, nz <= 32 columns; Kz [nz,352])
 int launch_lstm_fwd_mfma(int B, int T, int gate_act, const float* xproj, const float* rowbias, const float* U,
-                         float* hs, float* cs, float* gates, float* hT, float* cT, hipStream_t s);
+                         float* hs, float* cs, float* gates, float* hT, float* cT,
+                         const float* zin, int ldz, int nz, const float* Kz, hipStream_t s);
+bool lstm_fwd_mfma_wanted(int B);      // the batch sizes at which lstm.hip hands a training forward to lstm_mfma.hip
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // register pair: v_pk_fma_f32 does two fp32 FMAs per issue slot
 

@@ -48,10 +48,17 @@ struct LstmMfmaFwdArgs {
   const float* U;        // [88,352]
   float* hs; float* cs; float* gates;      // [B,T,88] [B,T,88] [B,T,352] (z_i, z_f, tanh(z_c), z_o)
   float* hT; float* cT;                    // [B,88] or null
+  // a second, per-step input that is multiplied inside the kernel: z_t [B*T rows of stride ldz, nz columns] . Kz [nz,352]
+  // (the latent rows of the decoder's input kernel).  It joins the recurrent product as NZS more k-steps, so the
+  // [B*T, 352] projection is neither a launch of its own nor 2 x 4 bytes per gate column of HBM traffic.
+  const float* zin; const float* Kz; int ldz, nz;
 };
 
-template <int GATE, int NQ>
-__device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, float (*hA)[16 * MHS], int wave) {
+constexpr int MZS = 8;            // LDS slice of z per (row, k residue): up to 8 k-steps (32 latent columns)
+
+template <int GATE, int NQ, int NZS>
+__device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, float (*hA)[16 * MHS], float (*zA)[16 * MZS],
+                                                   int wave) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 3, kb = (lane >> 2) & 3, cg = lane >> 4;
   const int T = a.T;
@@ -67,6 +74,30 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, flo
     unit[q] = 4 * (wave + MNW * q) + j;
 #pragma unroll
     for (int m = 0; m < MKS; ++m) Ub[q][m] = a.U[(size_t)(4 * m + kb) * LG + cg * LH + unit[q]];
+  }
+  float Kb[NQ][NZS > 0 ? NZS : 1];     // B operands of the z product: Kz[4m + kb][cg*88 + unit], zero rows beyond nz
+  if (NZS > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int m = 0; m < NZS; ++m) {
+        const int k = 4 * m + kb;
+        const float v = a.Kz[(size_t)min(k, a.nz - 1) * LG + cg * LH + unit[q]];
+        Kb[q][m] = k < a.nz ? v : 0.f;
+      }
+  }
+  // z_t staging: thread e < 16 * 4 NZS moves element (row r, column k) of z_t from HBM (two steps ahead) into the
+  // A-operand order of LDS (one step ahead); the columns beyond nz stay zero
+  const int ze = threadIdx.x;
+  const int zr = ze / (4 * NZS > 0 ? 4 * NZS : 1), zk = ze - zr * 4 * NZS;
+  const bool zmine = NZS > 0 && ze < 4 * 4 * NZS && zk < a.nz && (int)(blockIdx.x * MR + zr) < a.B;
+  const float* zp = a.zin + ((size_t)min((int)(blockIdx.x * MR + zr), a.B - 1) * T) * (NZS > 0 ? a.ldz : 0) + min(zk, max(a.nz - 1, 0));
+  const int zdst = (zr * 4 + (zk & 3)) * MZS + (zk >> 2);
+  float zn = 0.f;
+  if (NZS > 0) {
+    if (zmine) zA[0][zdst] = zp[0];
+    zn = zmine ? zp[(size_t)min(1, T - 1) * a.ldz] : 0.f;
+    __syncthreads();
   }
   float rb[NQ], c[NQ], xn[NQ], xn2[NQ];
   const float* xp[NQ];
@@ -112,6 +143,21 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, flo
       xn[q] = xn2[q];
       xn2[q] = xp[q][(size_t)min(t + 2, T - 1) * LG];
     }
+    float zv[NZS > 0 ? NZS : 1];
+    if (NZS > 0) {
+      // z_{t+1} (loaded last step) goes to the other LDS buffer, z_{t+2} is requested
+      if (zmine) zA[cur ^ 1][zdst] = zn;
+      zn = zmine ? zp[(size_t)min(t + 2, T - 1) * a.ldz] : 0.f;
+      const float4* zq = reinterpret_cast<const float4*>(&zA[cur][(j * 4 + kb) * MZS]);
+#pragma unroll
+      for (int i = 0; i < (NZS + 3) / 4; ++i) {
+        const float4 v = zq[i];
+        zv[4 * i] = v.x;
+        if (4 * i + 1 < NZS) zv[4 * i + 1] = v.y;
+        if (4 * i + 2 < NZS) zv[4 * i + 2] = v.z;
+        if (4 * i + 3 < NZS) zv[4 * i + 3] = v.w;
+      }
+    }
     float av[MKS + 2];
     {
       const float4* ap = reinterpret_cast<const float4*>(&hA[cur][aslice]);
@@ -135,6 +181,16 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, flo
 #pragma unroll
       for (int q = 0; q < NQ; ++q) E[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m + 1], Ub[q][m + 1], E[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NZS > 0) {
+#pragma unroll
+      for (int m = 0; m < NZS; m += 2) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) D[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv[m], Kb[q][m], D[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) E[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv[m + 1], Kb[q][m + 1], E[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -173,22 +229,35 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, flo
   }
 }
 
-template <int GATE>
+template <int GATE, int NZS>
 __global__ __launch_bounds__(MNW * 64) void lstm_fwd_mfma_kernel(LstmMfmaFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float hA[2][16 * MHS];
+  __shared__ __attribute__((aligned(16))) float zA[2][16 * MZS];
   for (int i = threadIdx.x; i < 2 * 16 * MHS; i += MNW * 64) (&hA[0][0])[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * 16 * MZS; i += MNW * 64) (&zA[0][0])[i] = 0.f;
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (wave < MQ - 2 * MNW) lstm_fwd_mfma_body<GATE, 3>(a, hA, wave);     // waves 0-5: quads w, w+8, w+16
-  else lstm_fwd_mfma_body<GATE, 2>(a, hA, wave);                         // waves 6, 7: quads w, w+8
+  if (wave < MQ - 2 * MNW) lstm_fwd_mfma_body<GATE, 3, NZS>(a, hA, zA, wave);     // waves 0-5: quads w, w+8, w+16
+  else lstm_fwd_mfma_body<GATE, 2, NZS>(a, hA, zA, wave);                         // waves 6, 7: quads w, w+8
+}
+
+template <int GATE>
+static void launch_mfma_nzs(const LstmMfmaFwdArgs& a, hipStream_t s) {
+  const dim3 grid((a.B + MR - 1) / MR), block(MNW * 64);
+  const int nzs = a.zin ? (a.nz + 3) / 4 : 0;
+  if (nzs == 0) hipLaunchKernelGGL((lstm_fwd_mfma_kernel<GATE, 0>), grid, block, 0, s, a);
+  else if (nzs <= 2) hipLaunchKernelGGL((lstm_fwd_mfma_kernel<GATE, 2>), grid, block, 0, s, a);
+  else if (nzs <= 4) hipLaunchKernelGGL((lstm_fwd_mfma_kernel<GATE, 4>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((lstm_fwd_mfma_kernel<GATE, 8>), grid, block, 0, s, a);
 }
 
 int launch_lstm_fwd_mfma(int B, int T, int gate_act, const float* xproj, const float* rowbias, const float* U,
-                         float* hs, float* cs, float* gates, float* hT, float* cT, hipStream_t s) {
-  LstmMfmaFwdArgs a{B, T, xproj, rowbias, U, hs, cs, gates, hT, cT};
-  const dim3 grid((B + MR - 1) / MR), block(MNW * 64);
-  if (gate_act == CLV_GATE_HARD_SIGMOID) hipLaunchKernelGGL(lstm_fwd_mfma_kernel<CLV_GATE_HARD_SIGMOID>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(lstm_fwd_mfma_kernel<CLV_GATE_SIGMOID>, grid, block, 0, s, a);
+                         float* hs, float* cs, float* gates, float* hT, float* cT,
+                         const float* zin, int ldz, int nz, const float* Kz, hipStream_t s) {
+  if (zin && (nz < 1 || nz > 4 * MZS || !Kz || ldz < nz)) return CLV_EINVAL;
+  LstmMfmaFwdArgs a{B, T, xproj, rowbias, U, hs, cs, gates, hT, cT, zin, Kz, ldz, nz};
+  if (gate_act == CLV_GATE_HARD_SIGMOID) launch_mfma_nzs<CLV_GATE_HARD_SIGMOID>(a, s);
+  else launch_mfma_nzs<CLV_GATE_SIGMOID>(a, s);
   return launch_status();
 }
 

@@ -608,6 +608,13 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_fwd_x(B, T, self.XZ, self.xz_ld, off + L, P.p('decoder_h/kernel'), self.wk_dec,
                                P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.cs_dec, self.gates_dec,
                                gate_act=self.gate_act)
+        elif off and self.sparse_inputs and ops.lstm_seq_fwd_z_supported(B, L):
+            # large batches: the history frames' projection as a row gather, z_t . K_z inside the MFMA sequence kernel
+            # (no dense [B*T, 120] x [120, 352] product, no second trip of the gate buffer through HBM)
+            ops.sparse_proj(BT, off, G4, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec)
+            ops.lstm_seq_fwd_z(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.Z, self.xz_ld, L,
+                               P.rows(P.params, 'decoder_h/kernel', off), self.hs_dec, self.cs_dec, self.gates_dec,
+                               gate_act=self.gate_act)
         else:
             g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
             ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,

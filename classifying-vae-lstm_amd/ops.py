@@ -200,6 +200,17 @@ def lstm_seq_fwd(B, T, xproj, rowbias, U, hs, cs, gates, h0=None, c0=None, hT=No
           "clv_lstm_seq_fwd")
 
 
+def lstm_seq_fwd_z_supported(B, nz, H=88):
+    return bool(_lib.lib().clv_lstm_seq_fwd_z_supported(B, H, nz))
+
+
+def lstm_seq_fwd_z(B, T, xproj, rowbias, U, zin, ldz, nz, Kz, hs, cs, gates, hT=None, cT=None, gate_act=0, H=88):
+    """clv_lstm_seq_fwd + z_t . Kz inside the kernel (large batches, csrc/lstm_mfma.hip)."""
+    check(_lib.lib().clv_lstm_seq_fwd_z(B, T, H, gate_act, _ptr(xproj), _ptr(rowbias), _ptr(U), _ptr(zin), ldz, nz,
+                                        _ptr(Kz), _ptr(hs), _ptr(cs), _ptr(gates), _ptr(hT), _ptr(cT), _stream()),
+          "clv_lstm_seq_fwd_z")
+
+
 def lstm_fused_input_fits(B, nx):
     return nx <= 128 and _lib.lib().clv_lstm_seq_fwd_x_lds_bytes(B, nx) <= 156 * 1024
 

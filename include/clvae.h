@@ -163,6 +163,15 @@ int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
  * NONZERO inputs of a frame are visited (a piano-roll frame has ~4 of 88 notes on; any float input is
  * handled exactly, cost grows with its nonzeros), so no [B,T,4H] projection is ever written to HBM.
  * nx <= 128 and clv_lstm_seq_fwd_x_lds_bytes(B, nx) <= 156 KB (else CLV_EINVAL: use the xproj form). */
+/* Large batches (clv_lstm_seq_fwd_z_supported: H == 88, 1 <= nz <= 32 and a batch the MFMA sequence kernel is used
+ * for, >= 768 rows): the decoder's forward with the latent part of its input projection inside the kernel --
+ * z_t . Kz (z_t: B*T rows of stride ldz, nz columns; Kz [nz,4H] = the z rows of decoder_h/kernel,
+ * cl_vrnn/model.py:218-228) joins the recurrent product as nz/4 more k-steps of the 4x4x1 MFMA; xproj then only
+ * carries x_{t-1} . K_x (the sparse projection).  Zero initial state, gates/cs required (a training forward). */
+int clv_lstm_seq_fwd_z_supported(int B, int H, int nz);
+int clv_lstm_seq_fwd_z(int B, int T, int H, int gate_act, const float* xproj, const float* rowbias,
+                       const float* U, const float* zin, int ldz, int nz, const float* Kz,
+                       float* hs, float* cs, float* gates, float* hT, float* cT, void* stream);
 size_t clv_lstm_seq_fwd_x_lds_bytes(int B, int nx);
 int clv_lstm_seq_fwd_x(int B, int T, int H, int gate_act,
                        const float* xin, int ldx, int nx, const float* Kin,

@@ -22,6 +22,10 @@ def T(a, dev):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
 
 
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
 def N(t):
     return t.detach().cpu().numpy().astype(np.float64)
 
@@ -177,6 +181,36 @@ def test_lstm_seq_fwd_large_batch_runs_on_the_matrix_cores(dev, B, Tn, gate):
     for k in (0, 1, 3):
         np.testing.assert_allclose(g[:, :, k], Zr[:, :, k], atol=1e-5)
     np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=3e-6)
+
+
+@pytest.mark.parametrize("B,Tn,nz,ldz,gate", [(1027, 5, 32, 120, 0), (770, 3, 5, 9, 1), (1024, 2, 8, 8, 0)])
+def test_lstm_seq_fwd_z_multiplies_the_latent_rows_in_the_kernel(dev, B, Tn, nz, ldz, gate):
+    """clv_lstm_seq_fwd_z: xproj + rowbias + z_t . Kz + h_{t-1} . U, the z product as extra k-steps of the MFMA."""
+    from clvae_amd import ops
+    H = 88
+    assert ops.lstm_seq_fwd_z_supported(B, nz)
+    rng = np.random.default_rng(B + nz)
+    U = O.orthogonal(rng, (H, 4 * H), np.float64) * 1.5
+    Kz = rng.standard_normal((nz, 4 * H)) * 0.4
+    xproj = rng.standard_normal((B, Tn, 4 * H))
+    rb = rng.standard_normal((B, 4 * H)) * 0.3
+    zbuf = rng.standard_normal((B * Tn, ldz))
+    act = 'hard_sigmoid' if gate == 0 else 'sigmoid'
+    xs = xproj + rb[:, None, :] + (f32(zbuf[:, :nz]) @ f32(Kz)).reshape(B, Tn, 4 * H)
+    hs_ref, cache = O.lstm_forward(xs, np.eye(4 * H), U, np.zeros(4 * H), gate_act=act)
+    gates = T(xproj, dev)
+    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
+    hT = torch.empty(B, H, device=dev)
+    ops.lstm_seq_fwd_z(B, Tn, gates, T(rb, dev), T(U, dev), T(zbuf, dev), ldz, nz, T(Kz, dev), hs, cs, gates, hT=hT,
+                       gate_act=gate)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(hs), hs_ref, atol=5e-6)
+    np.testing.assert_allclose(N(cs), cache['C'], atol=8e-6)
+    np.testing.assert_allclose(N(hT), hs_ref[:, -1], atol=5e-6)
+    g = N(gates).reshape(B, Tn, 4, H)
+    Zr = cache['Z'].reshape(B, Tn, 4, H)
+    np.testing.assert_allclose(g[:, :, 0], Zr[:, :, 0], atol=2e-5)
+    np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=5e-6)
 
 
 def test_label_gauss_bernoulli(dev):
