@@ -500,10 +500,19 @@ __global__ __launch_bounds__(BW_NT) void lstm_bwd_kernel(LstmBwdArgs a) {
   }
 }
 
-// rows per workgroup: one while every CU can get its own row, more as the batch outgrows the chip
+// rows per workgroup: one while every CU can get its own row, then the smallest of 2 / 4 that brings the workgroups back
+// to one per CU (a workgroup's rows share its weights and its barrier; two co-resident workgroups starve each other at
+// the issue port).  Measured at T = 128 (tools/lstm_rows_bench.py, gpurun_out/s19; forward / backward, us):
+//   B  384: R=1 125 / 171   R=2 122 / 131   R=4 181 / 196
+//   B  512:     133 / 176       127 / 138       183 / 198
+//   B  768:     186 / 270       200 / 255       186 / 206
+//   B 1024:     290 / 343       210 / 280       195 / 222
+//   B 2048:     553 / 693       498 / 539       397 / 455
 static int rows_per_wg(int B) {
-  if (B % 4 == 0 && B >= 2048) return 4;
-  if (B % 2 == 0 && B >= 1024) return 2;
+  static const int forced = env_int("CLV_LSTM_ROWS", 0);      // measurement knob: 1, 2 or 4 rows per workgroup
+  if ((forced == 1 || forced == 2 || forced == 4) && B % forced == 0) return forced;
+  if (B > 512 && B % 4 == 0) return 4;
+  if (B > 256 && B % 2 == 0) return 2;
   return 1;
 }
 static int lstm_ks() {
