@@ -371,7 +371,7 @@ def test_adam_step_in_two_pieces_is_bitwise_the_whole_step(dev):
     np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
-@pytest.mark.parametrize("B,L,Cn", [(100, 4, 2), (37, 16, 16)])
+@pytest.mark.parametrize("B,L,Cn", [(100, 4, 2), (37, 16, 16), (1, 3, 5), (17, 1, 2)])
 def test_cl_vae_fused_step_draws_its_own_noise_and_advances_the_counter(dev, B, L, Cn):
     """clv_vae_fused_step_ex: the in-kernel Philox draw writes the values clv_philox_normal2 writes (bit for bit), the
     folded loss means equal clv_loss_sums', and bump + adam_step(advanced=True) is adam_step()."""
@@ -441,3 +441,27 @@ def test_cl_vae_bf16_step_tolerance(dev):
     assert errs[False][0] <= ELBO_TOL and errs[False][2] < 1e-4
     assert errs[True][0] <= 2e-3 and errs[True][1] <= 1e-2 and errs[True][2] <= 1e-1
     assert errs[True][2] > errs[False][2]          # the bf16 path really is the one that ran
+
+
+def test_cl_vae_fused_loss_only_pass_takes_its_means_in_one_launch(dev):
+    """need_grads=False through clv_vae_fused_step_ex: no gradients, no counter bump, the five loss means from the tail
+    launch alone -- equal to the training pass's on the same inputs."""
+    from clvae_amd.engine import VaeEngine
+    B, L, Cn = 50, 4, 2
+    cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(9)
+    p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=4).items()}
+    eng = VaeEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    args = (T(frames(rng, B, 88), dev), T(frames(rng, B, 88), dev), T(np.eye(Cn)[rng.integers(0, Cn, B)], dev),
+            T(rng.standard_normal((B, Cn - 1)), dev), T(rng.standard_normal((B, L)), dev))
+    eng.P.iterations.fill_(3)
+    eng.loss_and_grads(*args)
+    torch.cuda.synchronize()
+    train = eng.losses()
+    eng.P.grads.fill_(123.0)
+    eng.loss_and_grads(*args, need_grads=False, bump=True)
+    torch.cuda.synchronize()
+    ev = eng.losses()
+    assert all(train[k] == ev[k] for k in train)
+    assert float(eng.P.grads.min()) == 123.0 and int(eng.P.iterations.item()) == 3
