@@ -72,6 +72,7 @@ SIGNATURES = {
     "clv_colsum_workspace_bytes": (_sz, [_i, _i]),
     "clv_colsum_f32": (_i, [_i, _i, _p, _i, _f, _p, _p, _sz, _p]),
     "clv_lstm_seq_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_lstm_seq_bwd_z": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p]),
     "clv_lstm_seq_fwd_z_supported": (_i, [_i, _i, _i]),
     "clv_lstm_seq_fwd_z": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_seq_fwd_x_lds_bytes": (_sz, [_i, _i]),

@@ -329,7 +329,14 @@ struct LstmBwdArgs {
   const float* c0;      // [B,88] or null
   float* gates;         // in: (z_i,z_f,g,z_o)  out: dz
   float* dzsum;         // [B,352]
+  // ZW > 0 (the decoder): dZ_t = dz_t . Kz^T as well, by two more waves whose "units" are latents (the rows of Kz sit
+  // where a unit group keeps its rows of U): the [B*T,352] x [352,nz] product is neither a launch nor a second read of dz
+  const float* Kz;      // [nz,352]
+  float* dZ;            // B*T rows of stride lddz
+  int nz, lddz;
 };
+
+__device__ float g_bwd_dump[64];
 
 // Thread layout of the backward kernel: lane = (unit group ug = lane / 16, column slice cs = lane % 16);
 // a thread keeps U[4*ug + j][22*cs .. 22*cs+21] for its 4 units j, so one dz value read from LDS feeds
@@ -343,8 +350,8 @@ constexpr int BW_NW = 6, BW_NT = BW_NW * 64;    // 24 unit groups (22 used)
 constexpr int BW_CW = 22, BW_CP = 24;           // columns per slice, padded slice stride in LDS (16-byte aligned)
 constexpr int BW_LDS = 16 * BW_CP;
 
-template <int R, int GATE>
-__global__ __launch_bounds__(BW_NT) void lstm_bwd_kernel(LstmBwdArgs a) {
+template <int R, int GATE, int ZW = 0>
+__global__ __launch_bounds__(BW_NT + 64 * ZW) void lstm_bwd_kernel(LstmBwdArgs a) {
   constexpr int NC = 4 / R;
   __shared__ __attribute__((aligned(16))) float dzbuf[2][R][BW_LDS];
 
@@ -356,19 +363,26 @@ __global__ __launch_bounds__(BW_NT) void lstm_bwd_kernel(LstmBwdArgs a) {
   const int row0 = blockIdx.x * R;
   const int myrow = q % R, copy = q / R;
   const int T = a.T;
+  // latent groups (ZW): the surplus groups 22, 23 and the two extra waves carry 4 latents each
+  const int zg0 = 4 * (ug - 22);
+  const bool zgroup = ZW > 0 && ug >= 22 && zg0 < a.nz;
+  const int lat = zg0 + (cs & 3);
+  const bool zlane = zgroup && lat < a.nz;
 
-  f2 Ur[BW_CW][2];    // [column][unit pair]
+  f2 Ur[BW_CW][2];    // [column][unit pair]; a latent group holds rows of Kz instead
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float2* up = reinterpret_cast<const float2*>(a.U + (size_t)min(4 * ug + j, LH - 1) * LG + BW_CW * cs);
+    const float* rowp = zgroup ? a.Kz + (size_t)min(zg0 + j, a.nz - 1) * LG : a.U + (size_t)min(4 * ug + j, LH - 1) * LG;
+    const float keep = (zgroup && zg0 + j >= a.nz) ? 0.f : 1.f;
+    const float2* up = reinterpret_cast<const float2*>(rowp + BW_CW * cs);
 #pragma unroll
     for (int c = 0; c < BW_CW / 2; ++c) {
       const float2 v = up[c];
-      Ur[2 * c][j >> 1][j & 1] = v.x;
-      Ur[2 * c + 1][j >> 1][j & 1] = v.y;
+      Ur[2 * c][j >> 1][j & 1] = v.x * keep;
+      Ur[2 * c + 1][j >> 1][j & 1] = v.y * keep;
     }
   }
-  for (int i = tid; i < 2 * R * BW_LDS; i += BW_NT) (&dzbuf[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * R * BW_LDS; i += BW_NT + 64 * ZW) (&dzbuf[0][0][0])[i] = 0.f;
 
   const size_t rowbt = (size_t)(row0 + myrow) * T;
   float dc = 0.f;
@@ -425,7 +439,14 @@ __global__ __launch_bounds__(BW_NT) void lstm_bwd_kernel(LstmBwdArgs a) {
     const int col = ((copy + j * NC) & 3) * LH + u;
     gptr[j] = a.gates + (rowbt + (T > 0 ? T - 1 : 0)) * LG + col;
     lpos[j] = BW_CP * (col / BW_CW) + col % BW_CW;
-  }
+    if (zgroup) { gptr[j] = g_bwd_dump + lane; lpos[j] = BW_CP * cs + BW_CW; }    // a latent lane's dz is nobody's: the
+  }                                                                               // slice's padding and a dump word
+  const int gstr = zgroup ? 0 : LG;
+  // dZ_{t+1} leaves at iteration t (the matvec of iteration t multiplies dz_{t+1}); iteration T-1 writes the zeros
+  // of the empty buffer to row T-1, which iteration T-2 overwrites: the store stays unconditional
+  float* zptr = g_bwd_dump + lane;
+  int zstr = 0;
+  if (ZW > 0 && zlane && T > 0) { zptr = a.dZ + (rowbt + (T - 1)) * a.lddz + lat; zstr = a.lddz; }
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
@@ -466,6 +487,10 @@ __global__ __launch_bounds__(BW_NT) void lstm_bwd_kernel(LstmBwdArgs a) {
     float dhrec = part[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) dhrec = (myrow == r) ? part[r] : dhrec;
+    if (ZW > 0) {                                  // latent lanes: dhrec is dZ_{t+1} of (row, latent)
+      *zptr = dhrec;
+      zptr -= (t < T - 1) ? zstr : 0;
+    }
 
     const float dh = k.dhh + dhrec;
     dc = fmaf(dh, k.kc, dc);
@@ -486,17 +511,50 @@ __global__ __launch_bounds__(BW_NT) void lstm_bwd_kernel(LstmBwdArgs a) {
       for (int qq = 1; qq < 4; ++qq) val = (slot == qq) ? dz[qq] : val;
       dzbuf[cur ^ 1][myrow][lpos[j]] = val;
       *gptr[j] = val;
-      gptr[j] -= LG;
+      gptr[j] -= gstr;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  if (ZW > 0 && wave >= 5 && T > 0) {              // dZ_0 = dz_0 . Kz^T: one more matvec by the waves that hold latents
+    const int cur = T & 1;
+    float dz0 = 0.f;
 #pragma unroll
-  for (int j = 0; j < NSB; ++j) {
-    const int slot = (copy + j * NC) & 3;
-    float val = zs[0];
+    for (int r = 0; r < R; ++r) {
+      const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][BW_CP * cs]);
+      float dv[BW_CP];
 #pragma unroll
-    for (int qq = 1; qq < 4; ++qq) val = (slot == qq) ? zs[qq] : val;
-    a.dzsum[(size_t)(row0 + myrow) * LG + slot * LH + u] = val;
+      for (int j = 0; j < BW_CP / 4; ++j) {
+        const float4 v = dp[j];
+        dv[4 * j] = v.x; dv[4 * j + 1] = v.y; dv[4 * j + 2] = v.z; dv[4 * j + 3] = v.w;
+      }
+      f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < BW_CW; ++c) {
+        const f2 dd = {dv[c], dv[c]};
+        acc01 = __builtin_elementwise_fma(dd, Ur[c][0], acc01);
+        acc23 = __builtin_elementwise_fma(dd, Ur[c][1], acc23);
+      }
+      const float keep_a = b0 ? acc01[1] : acc01[0], send_a = b0 ? acc01[0] : acc01[1];
+      const float keep_b = b0 ? acc23[1] : acc23[0], send_b = b0 ? acc23[0] : acc23[1];
+      const float wa = keep_a + dpp_mov<0xB1>(send_a);
+      const float wb = keep_b + dpp_mov<0xB1>(send_b);
+      const float keep = b1 ? wb : wa, send = b1 ? wa : wb;
+      float x = keep + dpp_mov<0x4E>(send);
+      x = dpp_add<0x124>(x);
+      x = dpp_add<0x128>(x);
+      dz0 = (myrow == r) ? x : dz0;
+    }
+    if (zlane) a.dZ[rowbt * a.lddz + lat] = dz0;
+  }
+  if (!zgroup) {
+#pragma unroll
+    for (int j = 0; j < NSB; ++j) {
+      const int slot = (copy + j * NC) & 3;
+      float val = zs[0];
+#pragma unroll
+      for (int qq = 1; qq < 4; ++qq) val = (slot == qq) ? zs[qq] : val;
+      a.dzsum[(size_t)(row0 + myrow) * LG + slot * LH + u] = val;
+    }
   }
 }
 
@@ -543,6 +601,12 @@ static int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
 template <int GATE>
 static int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
   const int B = a.B, R = rows_per_wg(B);
+  if (a.Kz) {         // + dZ = dz . Kz^T: two more waves
+    if (R == 4) hipLaunchKernelGGL((lstm_bwd_kernel<4, GATE, 2>), dim3(B / 4), dim3(BW_NT + 128), 0, s, a);
+    else if (R == 2) hipLaunchKernelGGL((lstm_bwd_kernel<2, GATE, 2>), dim3(B / 2), dim3(BW_NT + 128), 0, s, a);
+    else hipLaunchKernelGGL((lstm_bwd_kernel<1, GATE, 2>), dim3(B), dim3(BW_NT + 128), 0, s, a);
+    return launch_status();
+  }
   if (R == 4) hipLaunchKernelGGL((lstm_bwd_kernel<4, GATE>), dim3(B / 4), dim3(BW_NT), 0, s, a);
   else if (R == 2) hipLaunchKernelGGL((lstm_bwd_kernel<2, GATE>), dim3(B / 2), dim3(BW_NT), 0, s, a);
   else hipLaunchKernelGGL((lstm_bwd_kernel<1, GATE>), dim3(B), dim3(BW_NT), 0, s, a);
@@ -626,7 +690,22 @@ extern "C" int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
   using namespace clv;
   if (H != LH || B <= 0 || T < 0 || !U || !dhs || !cs || !gates_inout_dz || !dzsum) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
-  LstmBwdArgs a{B, T, U, dhs, cs, c0, gates_inout_dz, dzsum};
+  LstmBwdArgs a{B, T, U, dhs, cs, c0, gates_inout_dz, dzsum, nullptr, nullptr, 0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p("lstm_seq_bwd", s);
+  const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
+  return hard ? launch_bwd<CLV_GATE_HARD_SIGMOID>(a, s) : launch_bwd<CLV_GATE_SIGMOID>(a, s);
+}
+
+extern "C" int clv_lstm_seq_bwd_z(int B, int T, int H, int gate_act,
+                                  const float* U, const float* dhs, const float* cs, const float* c0,
+                                  float* gates_inout_dz, float* dzsum, const float* Kz, int nz, float* dZ, int lddz,
+                                  void* stream) {
+  using namespace clv;
+  if (H != LH || B <= 0 || T < 0 || !U || !dhs || !cs || !gates_inout_dz || !dzsum) return CLV_EINVAL;
+  if (!Kz || !dZ || nz < 1 || nz > 40 || lddz < nz) return CLV_EINVAL;      // 10 latent groups of 4
+  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  LstmBwdArgs a{B, T, U, dhs, cs, c0, gates_inout_dz, dzsum, Kz, dZ, nz, lddz};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_seq_bwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;

@@ -871,9 +871,14 @@ class VrnnEngine(_EngineBase):
         H, L, T = cfg['H'], cfg['L'], cfg['T']
         BT, G4, off = B * T, 4 * H, self.off
         g = ops.gemm
-        ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
-                         self.dzsum_dec, gate_act=self.gate_act)
-        g(self.gates_dec, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
+        if L <= 40 and os.environ.get('CLV_BWD_Z', '1') != '0':      # dZ = dz_dec . Kz^T by two more waves of the decoder's backward kernel
+            ops.lstm_seq_bwd_z(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
+                               self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off), L, self.dZ, L,
+                               gate_act=self.gate_act)
+        else:
+            ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
+                             self.dzsum_dec, gate_act=self.gate_act)
+            g(self.gates_dec, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
         ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight / BT, self.dzargs)
         g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,

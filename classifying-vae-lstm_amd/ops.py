@@ -200,6 +200,12 @@ def lstm_seq_fwd(B, T, xproj, rowbias, U, hs, cs, gates, h0=None, c0=None, hT=No
           "clv_lstm_seq_fwd")
 
 
+def lstm_seq_bwd_z(B, T, U, dhs, cs, gates_inout, dzsum, Kz, nz, dZ, lddz, c0=None, gate_act=0, H=88):
+    """clv_lstm_seq_bwd + dZ = dz . Kz^T in the same launch."""
+    check(_lib.lib().clv_lstm_seq_bwd_z(B, T, H, gate_act, _ptr(U), _ptr(dhs), _ptr(cs), _ptr(c0), _ptr(gates_inout),
+                                        _ptr(dzsum), _ptr(Kz), nz, _ptr(dZ), lddz, _stream()), "clv_lstm_seq_bwd_z")
+
+
 def lstm_seq_fwd_z_supported(B, nz, H=88):
     return bool(_lib.lib().clv_lstm_seq_fwd_z_supported(B, H, nz))
 

@@ -163,6 +163,14 @@ int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
  * NONZERO inputs of a frame are visited (a piano-roll frame has ~4 of 88 notes on; any float input is
  * handled exactly, cost grows with its nonzeros), so no [B,T,4H] projection is ever written to HBM.
  * nx <= 128 and clv_lstm_seq_fwd_x_lds_bytes(B, nx) <= 156 KB (else CLV_EINVAL: use the xproj form). */
+/* clv_lstm_seq_bwd + dZ_t = dz_t . Kz^T (Kz [nz,4H]: the z rows of decoder_h/kernel; dZ: B*T rows of stride lddz;
+ * nz <= 40) inside the same launch: two more waves whose "units" are latents.  The decoder's backward pass without the
+ * [B*T,4H] x [4H,nz] product as a launch of its own and without reading dz a second time
+ * (cl_vrnn/model.py:218-228 under K.gradients). */
+int clv_lstm_seq_bwd_z(int B, int T, int H, int gate_act,
+                       const float* U, const float* dhs, const float* cs, const float* c0,
+                       float* gates_inout_dz, float* dzsum, const float* Kz, int nz, float* dZ, int lddz, void* stream);
+
 /* Large batches (clv_lstm_seq_fwd_z_supported: H == 88, 1 <= nz <= 32 and a batch the MFMA sequence kernel is used
  * for, >= 768 rows): the decoder's forward with the latent part of its input projection inside the kernel --
  * z_t . Kz (z_t: B*T rows of stride ldz, nz columns; Kz [nz,4H] = the z rows of decoder_h/kernel,

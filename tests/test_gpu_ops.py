@@ -213,6 +213,31 @@ def test_lstm_seq_fwd_z_multiplies_the_latent_rows_in_the_kernel(dev, B, Tn, nz,
     np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=5e-6)
 
 
+@pytest.mark.parametrize("B,Tn,nz,gate", [(6, 9, 32, 0), (1028, 3, 32, 0), (514, 4, 5, 1), (3, 1, 40, 0)])
+def test_lstm_seq_bwd_z_also_returns_the_latent_gradient(dev, B, Tn, nz, gate):
+    """clv_lstm_seq_bwd_z == clv_lstm_seq_bwd, plus dZ = dz . Kz^T from the same launch."""
+    from clvae_amd import ops
+    H = 88
+    rng = np.random.default_rng(B + nz)
+    U = T(O.orthogonal(rng, (H, 4 * H), np.float64) * 1.5, dev)
+    Kz = rng.standard_normal((nz, 4 * H)) * 0.4
+    xproj = T(rng.standard_normal((B, Tn, 4 * H)), dev)
+    dHs = T(rng.standard_normal((B, Tn, H)), dev)
+    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
+    g1 = xproj.clone()
+    ops.lstm_seq_fwd(B, Tn, g1, None, U, hs, cs, g1, gate_act=gate)
+    g2 = g1.clone()
+    s1 = torch.empty(B, 4 * H, device=dev); s2 = torch.empty(B, 4 * H, device=dev)
+    ops.lstm_seq_bwd(B, Tn, U, dHs, cs, g1, s1, gate_act=gate)
+    dZ = torch.full((B * Tn, nz + 3), 7.0, device=dev)
+    ops.lstm_seq_bwd_z(B, Tn, U, dHs, cs, g2, s2, T(Kz, dev), nz, dZ, nz + 3, gate_act=gate)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g2) and torch.equal(s1, s2)
+    ref = f32(N(g1).reshape(B * Tn, 4 * H)) @ f32(Kz).T
+    np.testing.assert_allclose(N(dZ)[:, :nz], ref, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    assert float(dZ[:, nz:].min()) == 7.0 and float(dZ[:, nz:].max()) == 7.0
+
+
 def test_label_gauss_bernoulli(dev):
     from clvae_amd import ops
     rng = np.random.default_rng(3)
