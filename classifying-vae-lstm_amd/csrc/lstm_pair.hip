@@ -39,6 +39,28 @@ constexpr int BW_LDS = 16 * BW_CP;
 
 __device__ float g_pair_dump[128];      // target of the stores of lanes that own no output (keeps every store unconditional)
 
+// -DPAIR_STAMPS: the first decoder wave of workgroup 0 records the shader clock at six points of steps 32..39
+// (tools/pair_stamps.py).  The stamps are issued without waiting (s_memtime returns under the step barrier's lgkmcnt(0))
+// and each takes the value it follows as an operand, so it cannot move above that value's computation.
+#ifdef PAIR_STAMPS
+__device__ unsigned long long g_pair_stamps[8][8];
+__device__ unsigned long long g_pair_arrive[8][12][2];     // [step][wave of the workgroup][top of step, arrival at the barrier]
+#define PARRIVE(widx, t, dep)                                                                           \
+  do {                                                                                                   \
+    unsigned long long t1_;                                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) : "v"(dep));                         \
+    if (blockIdx.x == 0 && lane == 0 && (t) >= 32 && (t) < 40) {                                         \
+      g_pair_arrive[(t) - 32][widx][0] = ptop_; g_pair_arrive[(t) - 32][widx][1] = t1_;                  \
+    }                                                                                                    \
+  } while (0)
+#define PTOP(dep) unsigned long long ptop_; asm volatile("s_memtime %0" : "=s"(ptop_) : "v"(dep))
+#define PSTAMP(k, dep) asm volatile("s_memtime %0" : "=s"(pst[k]) : "v"(dep))
+#else
+#define PSTAMP(k, dep) do { } while (0)
+#define PARRIVE(widx, t, dep) do { } while (0)
+#define PTOP(dep) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // Weights in lane order.  A workgroup needs every recurrent weight exactly once, one value per lane: read straight from
 // the [88,352] kernels that is 88 dword loads per lane whose 64 lanes touch four 64-byte pieces of four different rows
@@ -229,6 +251,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   for (int i = 0; i < T; ++i) {
     const int cur = i & 1;
     const float xv = fmaf(xn, xmask, rb);
+    PTOP(xv);
     xn = xn2;
     xn2 = xp[(size_t)min(i + 2, T - 1) * LG];           // prefetch two steps ahead, unconditional (clamped); three: no gain
     const float ecur = en;                              // eps of step i-1
@@ -253,6 +276,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     const bool hold = is_z && i == 0;                   // the head lags one step: its row pointer starts moving at i == 1
     optr[0] += hold ? 0 : ostr[0];
     optr[1] += hold ? 0 : ostr[1];
+    PARRIVE(wave, i + 2, v0 + v1);                      // the encoder runs two steps ahead of the decoder's step index
     step_barrier();
   }
   // iteration T: only the latent head of step T-1 is left
@@ -316,7 +340,12 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   step_barrier();
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
+#ifdef PAIR_STAMPS
+    unsigned long long pst[8];
+#endif
     const float xv = xn + rb;
+    PSTAMP(0, xv);
+    PTOP(xv);
     xn = xn2;
     if (HASXP) xn2 = xp[(size_t)min(t + 2, T - 1) * LG];
     // scalar FMAs throughout: with v_pk_fma the allocator pairs a prefetch's destination register with an h value
@@ -338,12 +367,17 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     }
     float hv[PKP];
     load_hslice(&hb[cur][PKP * s], hv);
+    PSTAMP(1, hv[0]);                      // the first 16 bytes of h have arrived
+    PSTAMP(2, hv[PKP - 4]);                // the last
     slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
+    PSTAMP(3, acc[3][0] + acc[0][1]);
     float z[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g][0] + acc[g][1]);
+    PSTAMP(4, z[0] + z[3]);
     float h, gg;
     lstm_cell<GATE>(z, c, h, gg);
+    PSTAMP(5, h);
     hb[cur ^ 1][hslot] = h;
     float v0, v1;
     pick_pair(s, h, c, z, gg, v0, v1);
@@ -351,7 +385,18 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     *optr[1] = v1;
     optr[0] += ostr[0];
     optr[1] += ostr[1];
+    PSTAMP(6, v0 + v1);
+    PARRIVE(PNW + wave, t, v0 + v1);
     step_barrier();
+#ifdef PAIR_STAMPS
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && t >= 32 && t < 40) {
+      unsigned long long now;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now));
+#pragma unroll
+      for (int k = 0; k < 7; ++k) g_pair_stamps[t - 32][k] = pst[k];
+      g_pair_stamps[t - 32][7] = now;
+    }
+#endif
   }
 }
 
@@ -610,6 +655,15 @@ __global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
 }
 
 }  // namespace clv
+
+#ifdef PAIR_STAMPS
+extern "C" int clv_debug_pair_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_pair_stamps), sizeof(unsigned long long) * 64);
+}
+extern "C" int clv_debug_pair_arrive(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_pair_arrive), sizeof(unsigned long long) * 8 * 12 * 2);
+}
+#endif
 
 extern "C" int clv_lstm_pair_supported(int H, int L) { return H == clv::LH && L >= 1 && L <= clv::QL; }
 
