@@ -253,10 +253,12 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     const float xv = fmaf(xn, xmask, rb);
     PTOP(xv);
     xn = xn2;
-    xn2 = xp[(size_t)min(i + 2, T - 1) * LG];           // prefetch two steps ahead, unconditional (clamped); three: no gain
+    // prefetch two steps ahead, unconditional (clamped); three: no gain.  The row offset is a 32-bit SCALAR product:
+    // `(size_t)step * LG` per lane is a quarter-rate v_mad_i64_i32 on a SIMD that is issue-bound (tools/pair_stamps.py)
+    xn2 = xp[(unsigned)min(i + 2, T - 1) * (unsigned)LG];
     const float ecur = en;                              // eps of step i-1
     en = en2;
-    en2 = ep[(size_t)min(i + 1, T - 1) * L];
+    en2 = ep[(unsigned)min(i + 1, T - 1) * (unsigned)L];
     float z[4];
     gate_sums(&hb[cur][PKP * s], xv, z);
     float h, gg;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     PSTAMP(0, xv);
     PTOP(xv);
     xn = xn2;
-    if (HASXP) xn2 = xp[(size_t)min(t + 2, T - 1) * LG];
+    if (HASXP) xn2 = xp[(unsigned)min(t + 2, T - 1) * (unsigned)LG];
     // scalar FMAs throughout: with v_pk_fma the allocator pairs a prefetch's destination register with an h value
     // inside a packed operand, and the wave waits for the load in the middle of the FMA block (+4 % step throughput)
     f2 acc[4];       // (even k, odd k) partial sums; the input projection and z_t . K_z start the odd halves
