@@ -347,7 +347,11 @@ __device__ float g_bwd_dump[64];
 // (ug, cs) owns unit 4*ug + (cs & 3), replicated over the 4 quads q = cs >> 2; as in the forward
 // kernel the replicas split the rows (R) and the output slots between them.
 constexpr int BW_NW = 6, BW_NT = BW_NW * 64;    // 24 unit groups (22 used)
-constexpr int BW_CW = 22, BW_CP = 24;           // columns per slice, padded slice stride in LDS (16-byte aligned)
+// columns per slice, padded slice stride in LDS.  28 floats: the 16 slices of a ds_read_b128 lane group start at banks
+// 28*cs mod 64, four banks each, all distinct; at a stride of 24 slices cs and cs+8 share banks and every read of the
+// step was a 2-way conflict (SQ_LDS_BANK_CONFLICT 59 % of the LDS cycles at four rows per workgroup, where the kernel is
+// LDS-bound: profiles/r02_e_sq_cfg5.json; lstm_pair.hip made the same change in round 2)
+constexpr int BW_CW = 22, BW_CP = 28;
 constexpr int BW_LDS = 16 * BW_CP;
 
 template <int R, int GATE, int ZW = 0>
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(BW_NT + 64 * ZW) void lstm_bwd_kernel(LstmBwdArgs a
       const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][BW_CP * cs]);
       float dv[BW_CP];
 #pragma unroll
-      for (int j = 0; j < BW_CP / 4; ++j) {
+      for (int j = 0; j < (BW_CW + 3) / 4; ++j) {
         const float4 v = dp[j];
         dv[4 * j] = v.x; dv[4 * j + 1] = v.y; dv[4 * j + 2] = v.z; dv[4 * j + 3] = v.w;
       }
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(BW_NT + 64 * ZW) void lstm_bwd_kernel(LstmBwdArgs a
       const float4* dp = reinterpret_cast<const float4*>(&dzbuf[cur][r][BW_CP * cs]);
       float dv[BW_CP];
 #pragma unroll
-      for (int j = 0; j < BW_CP / 4; ++j) {
+      for (int j = 0; j < (BW_CW + 3) / 4; ++j) {
         const float4 v = dp[j];
         dv[4 * j] = v.x; dv[4 * j + 1] = v.y; dv[4 * j + 2] = v.z; dv[4 * j + 3] = v.w;
       }
