@@ -54,7 +54,8 @@ struct LstmMfmaFwdArgs {
   const float* zin; const float* Kz; int ldz, nz;
 };
 
-constexpr int MZS = 8;            // LDS slice of z per (row, k residue): up to 8 k-steps (32 latent columns)
+constexpr int MZS = 12;           // LDS slice stride of z per (row, k residue): up to 8 k-steps (32 latent columns) used;
+                                  // 12 floats: the 16 slices start at banks 12 c mod 64, all distinct (8: c and c+8 collide)
 
 template <int GATE, int NQ, int NZS>
 __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmMfmaFwdArgs& a, float (*hA)[16 * MHS], float (*zA)[16 * MZS],
@@ -254,7 +255,7 @@ static void launch_mfma_nzs(const LstmMfmaFwdArgs& a, hipStream_t s) {
 int launch_lstm_fwd_mfma(int B, int T, int gate_act, const float* xproj, const float* rowbias, const float* U,
                          float* hs, float* cs, float* gates, float* hT, float* cT,
                          const float* zin, int ldz, int nz, const float* Kz, hipStream_t s) {
-  if (zin && (nz < 1 || nz > 4 * MZS || !Kz || ldz < nz)) return CLV_EINVAL;
+  if (zin && (nz < 1 || nz > 32 || !Kz || ldz < nz)) return CLV_EINVAL;
   LstmMfmaFwdArgs a{B, T, xproj, rowbias, U, hs, cs, gates, hT, cT, zin, Kz, ldz, nz};
   if (gate_act == CLV_GATE_HARD_SIGMOID) launch_mfma_nzs<CLV_GATE_HARD_SIGMOID>(a, s);
   else launch_mfma_nzs<CLV_GATE_SIGMOID>(a, s);
