@@ -320,7 +320,7 @@ def main():
             avg_s = ms / n * 1e-3
             achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
         traffic = step_traffic = None    # HBM bytes from the committed PMC passes (tools/pmc_traffic.sh -> profiles/)
-        for tag in ('r02_e', 'r02_d', 'r02_c', 'r02', 'r01'):      # newest committed PMC summary first
+        for tag in ('r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01'):      # newest committed PMC summary first
             try:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (tag, args.workload))))
             except Exception:
