@@ -23,7 +23,7 @@ namespace clv {
 
 constexpr int PNW = 6;                  // waves per chain (16 units each)
 constexpr int PNT = 2 * PNW * 64;       // 768 threads
-constexpr int PLMAX = 16;               // latent dims the surplus groups can carry
+constexpr int PLMAX = 16;               // latent slots of the K_z pack region (the kernels carry latent_dim <= 8)
 constexpr int PLQ = PLMAX / PK;         // latents per decoder lane (z_t . K_z is split over the k-slice lanes)
 
 // backward layout: gate columns per slice, padded LDS slice stride.  28 floats: the 16 slices of a ds_read_b128 lane
@@ -62,16 +62,32 @@ __device__ unsigned long long g_pair_arrive[8][12][2];     // [step][wave of the
 #endif
 
 // ---------------------------------------------------------------------------
+// Lane layout (round 3).  Forward: a unit's 4 lanes (s = lane & 3) each hold one k-slice of the recurrent kernel (22 k
+// values x 4 gates) -- but lane s keeps the gates in the order (s, s^1, s^2, s^3): accumulator j collects gate j ^ s.
+// The sum over the k-slices is then a REDUCE-SCATTER of three v_add_dpp (no selects: the partner's accumulator 1 / 3 is
+// exactly the gate this lane keeps in 0 / 2), after which lane s holds the pre-activation of gate s only.  It applies
+// ITS activation once (lane 2: tanh, the others: the gate function), and the cell update reads the other three gates as
+// DPP quad-broadcast operands.  The backward pass needs per (unit, step) only six numbers that are products of those
+// activations and their derivatives:
+//     ki = g i'   kf = c_{t-1} f'   kg = i g'   ko = tanh(c) o'   kc = o (1 - tanh(c)^2)   kcarry = f
+// (dz_i = dc ki, dz_f = dc kf, dz_g = dc kg, dz_o = dh ko, dc += dh kc, dc_{t-1} = dc kcarry), and lane s of the forward
+// pass can form "its" k from its own derivative and one neighbour value: so the forward pass stores (ki, kf, kg, ko) in
+// the gate buffer and (kcarry, kc) in the aux buffer, and the backward pass is four loads and six instructions per lane
+// and step where it used to rebuild three gate functions, a tanh and their derivatives from seven loaded values.
+// Backward: thread = 4 units x 22 gate columns as before, accumulator j = unit j ^ (cs & 3) of the lane's group: the
+// same select-free reduce-scatter.
+// ---------------------------------------------------------------------------
 // Weights in lane order.  A workgroup needs every recurrent weight exactly once, one value per lane: read straight from
 // the [88,352] kernels that is 88 dword loads per lane whose 64 lanes touch four 64-byte pieces of four different rows
 // (1056 such wave loads per workgroup, every workgroup at the same time: ~13 us of each launch at config 3).  The pack
 // kernel writes each lane's values as consecutive float4 (one wave load = 1 KB contiguous), once per step, for both
 // passes: regions of [6 waves][n][64 lanes] float4.
-//   PK_FE / PK_FD: forward encoder / decoder, n = 22 k values, components = gates (i,f,c,o); the encoder's latent lanes
-//                  carry columns of the head kernel Wz instead (see pair_fwd_encoder)
-//   PK_KZ:         forward decoder, n = 4: latent s + 4q of the decoder input kernel's z rows, components = gates
-//   PK_BD / PK_BE: backward decoder / encoder, n = 22 gate columns of the lane's slice, components = the 4 units of the
-//                  lane's group; the decoder's surplus groups carry rows of Kz (see pair_bwd_chain)
+//   PK_FE / PK_FD: forward encoder / decoder, n = 22: float4 kk = (k0, k1 | acc ja), (k0, k1 | acc jb), k0 = 22 s +
+//                  2 (kk / 2), (ja, jb) = (0, 1) for even kk, (2, 3) for odd kk, acc j = gate j ^ s; the encoder's
+//                  latent lanes carry columns of the head kernel Wz instead (see pair_fwd_encoder)
+//   PK_KZ:         forward decoder, n = 4: latent s + 4q of the decoder input kernel's z rows, components = acc 0..3
+//   PK_BD / PK_BE: backward decoder / encoder, n = 22 gate columns of the lane's slice, components = acc 0..3 = units
+//                  j ^ (cs & 3) of the lane's group; the decoder's surplus groups carry rows of Kz (see pair_bwd_chain)
 // ---------------------------------------------------------------------------
 constexpr int PK_N = PNW * PKK * 64;               // float4 per 22-deep region
 constexpr int PK_FE = 0, PK_FD = PK_N, PK_KZ = 2 * PK_N, PK_BD = PK_KZ + PNW * PLQ * 64, PK_BE = PK_BD + PK_N;
@@ -79,10 +95,11 @@ constexpr int PK_TOTAL = PK_BE + PK_N;             // float4
 
 struct PairPackArgs { int L; const float* U_e; const float* U_d; const float* Kz; const float* Wz; float4* out; };
 
-__global__ __launch_bounds__(256) void lstm_pair_pack_kernel(PairPackArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= PK_TOTAL) return;
-  const int L = a.L;
+// element i of the pack from the weights as they are in the flat parameter buffer (also called by the optimizer's last
+// launch, which writes the pack of the weights it has just produced: see optim.hip)
+template <class Load>
+__device__ __forceinline__ float4 pair_pack_element(int i, int L, const float* U_e, const float* U_d, const float* Kz,
+                                                    const float* Wz, Load ld) {
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   if (i < PK_KZ) {                                 // forward: lane = (unit, k-slice), n = kk
     const bool dec = i >= PK_FD;
@@ -90,17 +107,15 @@ __global__ __launch_bounds__(256) void lstm_pair_pack_kernel(PairPackArgs a) {
     const int wave = e / (PKK * 64), kk = (e / 64) % PKK, lane = e & 63;
     const int s = lane & 3, u_raw = wave * 16 + (lane >> 2), u = min(u_raw, LH - 1), zj = u_raw - LH;
     const bool is_z = !dec && zj >= 0 && 2 * zj < L;
-    const float* U = dec ? a.U_d : a.U_e;
-    // float4 kk of a lane = (k0, k1 | gate ga), (k0, k1 | gate gb) with k0 = 2 (kk / 2), (ga, gb) = (0, 1) for even kk
-    // and (2, 3) for odd kk: the operand pairs of slice_fma_pairs
+    const float* U = dec ? U_d : U_e;
 #pragma unroll
     for (int e2 = 0; e2 < 4; ++e2) {
-      const int g = 2 * (kk & 1) + (e2 >> 1), k = PKK * s + 2 * (kk >> 1) + (e2 & 1);
-      if (is_z) {                                  // head column (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)
+      const int j = 2 * (kk & 1) + (e2 >> 1), g = j ^ s, k = PKK * s + 2 * (kk >> 1) + (e2 & 1);
+      if (is_z) {                                  // head column g of the group: (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)
         const int l = 2 * zj + (g & 1);
-        v[e2] = l < L ? a.Wz[(size_t)k * 2 * L + (g >> 1) * L + l] : 0.f;
+        v[e2] = l < L ? ld(Wz + (size_t)k * 2 * L + (g >> 1) * L + l) : 0.f;
       } else {
-        v[e2] = U[(size_t)k * LG + g * LH + u];
+        v[e2] = ld(U + (size_t)k * LG + g * LH + u);
       }
     }
   } else if (i < PK_BD) {                          // z rows of the decoder input kernel: latent s + 4q
@@ -108,22 +123,28 @@ __global__ __launch_bounds__(256) void lstm_pair_pack_kernel(PairPackArgs a) {
     const int wave = e / (PLQ * 64), q = (e / 64) % PLQ, lane = e & 63;
     const int s = lane & 3, u = min(wave * 16 + (lane >> 2), LH - 1), l = s + PK * q;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) v[g] = l < L ? a.Kz[(size_t)l * LG + g * LH + u] : 0.f;
+    for (int j = 0; j < 4; ++j) v[j] = l < L ? ld(Kz + (size_t)l * LG + (j ^ s) * LH + u) : 0.f;
   } else {                                         // backward: lane = (unit group, column slice), n = column in the slice
     const bool dec = i < PK_BE;
     const int e = i - (dec ? PK_BD : PK_BE);
     const int wave = e / (BW_CW * 64), c = (e / 64) % BW_CW, lane = e & 63;
-    const int cs = lane & 15, ug = wave * 4 + (lane >> 4), zg0 = 4 * (ug - 22);
+    const int cs = lane & 15, m = cs & 3, ug = wave * 4 + (lane >> 4), zg0 = 4 * (ug - 22);
     const bool zgroup = dec && ug >= 22 && zg0 < L;
-    const float* U = dec ? a.U_d : a.U_e;
+    const float* U = dec ? U_d : U_e;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int lj = zg0 + j;
-      if (zgroup) v[j] = lj < L ? a.Kz[(size_t)lj * LG + BW_CW * cs + c] : 0.f;
-      else v[j] = U[(size_t)min(4 * ug + j, LH - 1) * LG + BW_CW * cs + c];
+      const int lj = zg0 + (j ^ m);
+      if (zgroup) v[j] = lj < L ? ld(Kz + (size_t)lj * LG + BW_CW * cs + c) : 0.f;
+      else v[j] = ld(U + (size_t)min(4 * ug + (j ^ m), LH - 1) * LG + BW_CW * cs + c);
     }
   }
-  a.out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(256) void lstm_pair_pack_kernel(PairPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PK_TOTAL) return;
+  a.out[i] = pair_pack_element(i, a.L, a.U_e, a.U_d, a.Kz, a.Wz, [](const float* p) { return *p; });
 }
 
 struct PairFwdArgs {
@@ -135,61 +156,98 @@ struct PairFwdArgs {
   const float* pack;      // weights in lane order (clv_lstm_pair_pack)
   const float* bz;        // [2L]
   const float* eps;       // [B,T,L]
-  float *hs_e, *cs_e, *gates_e, *hs_d, *cs_d, *gates_d;
+  float *hs_e, *aux_e, *gates_e, *hs_d, *aux_d, *gates_d;      // aux: [B*T, 2, 88] = (kcarry, kc)
   float* zargs;           // [B*T,2L]
   float* Z;               // [B*T] rows of stride ldz
   float* klterm;          // [B*T,L]  L * KL_l: the mean over all entries is the per-frame KL
 };
 
-// output slots of a regular lane: 6 values per unit (h, c, z_i, z_f, g, z_o) over the 4 slice lanes, 2 stores each
-__device__ __forceinline__ void regular_slots(int s, int u, size_t bt0, float* hs, float* cs, float* gates,
-                                              float* (&optr)[2], int (&ostr)[2], int (&oslot)[2]) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int slot = s + 4 * j;
-    slot = slot < 6 ? slot : slot - 6;                   // lanes 2,3 repeat h and c (same value, same address)
-    oslot[j] = slot;
-    optr[j] = slot == 0 ? hs + bt0 * LH + u : slot == 1 ? cs + bt0 * LH + u : gates + bt0 * LG + (slot - 2) * LH + u;
-    ostr[j] = slot < 2 ? LH : LG;
+// lane masks of the k-slice index s (SGPR pairs; selects on them are single v_cndmask: see Sel4 in lstm_common.h)
+struct SliceMasks {
+  unsigned long long m1, m2, odd;
+  __device__ __forceinline__ explicit SliceMasks(int s) {
+    m1 = __builtin_amdgcn_ballot_w64(s == 1);
+    m2 = __builtin_amdgcn_ballot_w64(s == 2);
+    odd = __builtin_amdgcn_ballot_w64(s & 1);
   }
-}
-// the two values lane s stores (slots s and s+4: see regular_slots): 3 selects each instead of a 6-way pick
-__device__ __forceinline__ void pick_pair(int s, float h, float c, const float (&z)[4], float gg, float& v0, float& v1) {
-  v0 = h;                       // flat selects (a nested ?: chain becomes branches around the stores)
-  v0 = s == 1 ? c : v0;
-  v0 = s == 2 ? z[0] : v0;
-  v0 = s == 3 ? z[1] : v0;
-  v1 = gg;
-  v1 = s == 1 ? z[3] : v1;
-  v1 = s == 2 ? h : v1;
-  v1 = s == 3 ? c : v1;
-}
-__device__ __forceinline__ float pick_slot(int slot, float h, float c, const float (&z)[4], float gg) {
-  float v = h;
-  v = slot == 1 ? c : v;
-  v = slot == 2 ? z[0] : v;
-  v = slot == 3 ? z[1] : v;
-  v = slot == 4 ? gg : v;
-  v = slot == 5 ? z[3] : v;
-  return v;
+};
+
+// quad broadcast of lane K of every quad (DPP operand of the consuming instruction where the ISA has the form)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) { return dpp_mov<K * 0x55>(v); }
+
+// One LSTM cell on the reduce-scattered layout.  z: this lane's gate pre-activation (lane s: gate s = i, f, g, o).
+// Returns h (all four lanes); c is updated in all four lanes.  What lane s stores afterwards:
+//   vA = (ki, kf, kg, ko)[s] -> gates[., s*88 + u];  lane 0: h -> hs;  lane 1: act = f = kcarry, lane 2: kc -> aux
+template <int GATE>
+__device__ __forceinline__ float pair_cell(const SliceMasks& sm, float z, float& c, float& vA, float& act, float& kc) {
+  float a, d;                        // activation of this lane's gate and its derivative
+  const float th = fast_tanh(z);
+  if (GATE == CLV_GATE_HARD_SIGMOID) {
+    const float y = fmaf(0.2f, z, 0.5f);
+    const float hsv = __builtin_amdgcn_fmed3f(y, 0.f, 1.f);
+    const float hd = (y == hsv) ? 0.2f : 0.f;          // TF's clip passes the gradient at ties
+    a = Sel4::pick(sm.m2, th, hsv);
+    d = Sel4::pick(sm.m2, fmaf(-th, th, 1.f), hd);
+  } else {
+    const float sg = sigmoidf_(z);
+    a = Sel4::pick(sm.m2, th, sg);
+    d = fmaf(-a, a, Sel4::pick(sm.m2, 1.f, a));       // 1 - g^2  |  a - a^2
+  }
+  const float gg = quad_bcast<2>(a);
+  const float igg = quad_bcast<0>(a) * gg;
+  const float cn = fmaf(quad_bcast<1>(a), c, igg);
+  const float tc = fast_tanh(cn);
+  const float og = quad_bcast<3>(a);
+  const float h = og * tc;
+  // k of this lane: d * (gg, c_{t-1}, ig, tc)[s]: lanes 0 / 2 swap their activations, lanes 1 / 3 take c_{t-1} / tc
+  const float sw = dpp_mov<0xC6>(a);                   // quad_perm [2,1,0,3]
+  const float other = Sel4::pick(sm.m1, c, tc);
+  vA = d * Sel4::pick(sm.odd, other, sw);
+  kc = og * fmaf(-tc, tc, 1.f);
+  act = a;
+  c = cn;
+  return h;
 }
 
-template <int GATE>
+// sum of the four k-slice partials, scattered: lane s ends with the total of ITS accumulator 0 = gate s
+__device__ __forceinline__ float reduce_scatter4(float a0, float a1, float a2, float a3) {
+  const float r0 = a0 + dpp_mov<0xB1>(a1);             // partner s^1: its accumulator 1 is gate s
+  const float r2 = a2 + dpp_mov<0xB1>(a3);             //              its accumulator 3 is gate s^2
+  return r0 + dpp_mov<0x4E>(r2);                       // partner s^2: its r2 is gate s
+}
+
+template <int P> struct ParC { static constexpr int value = P; };
+
+// Every load of the prologue (weights, the first two steps' values) has landed before the step loop is entered: the
+// compiler's wait-count bookkeeping merges the loop-entry state with the back edge's, and with ~25 prologue loads still
+// "in flight" at the entry it places s_waitcnt vmcnt(<small>) INSIDE the loop for the weights' first use -- which in the
+// steady state waits for the loads the previous step has just issued.  vmcnt(0) expcnt(7) lgkmcnt(15): the builtin (not
+// inline asm) so that the bookkeeping sees it.
+__device__ __forceinline__ void prologue_loads_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// h slice of a unit in LDS: 22 values + 2 spare floats.  The DECODER's spare floats carry z_t: slice s' holds the latents
+// s' and s' + 4 behind its h values, so the decoder's sixth ds_read_b128 brings them along (no separate z buffer, no read)
+__device__ __forceinline__ int pair_hslot(int u) { return PKP * (u / PKK) + (u % PKK); }
+
+// LATW: this is the encoder's last wave: its 8 surplus lane groups (units 88..95) carry the latent head
+template <int GATE, bool LATW>
 __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP],
-                                                 float (*zbuf)[PLMAX]) {
+                                                 float (*hbd)[PK * PKP]) {
   const int s = lane & 3, b = blockIdx.x, T = a.T, L = a.L;
   const int u_raw = wave * 16 + (lane >> 2);
   const int u = min(u_raw, LH - 1);          // surplus groups that carry no latent duplicate unit 87
   const int zj = u_raw - LH;
-  const bool is_z = zj >= 0 && 2 * zj < L;
+  const bool is_z = LATW && zj >= 0 && 2 * zj < L;
   const int lat = 2 * zj + (s & 1);          // the latent this lane finishes
   const bool lat_ok = is_z && lat < L;
-  const int zpos = (lat % PK) * PLQ + lat / PK;      // decoder lane s reads the latents s, s+4, .. as one 16-byte LDS word
-  // head column held in accumulator g of a latent group: (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)
-  auto zcol = [&](int g) { const int l = 2 * zj + (g & 1); return l < L ? (g >> 1) * L + l : -1; };
-  const Sel4 sel_s(s);
+  const int zslot = PKP * (lat % PK) + PKK + lat / PK;       // where decoder lane s' = lat % 4 finds it (see pair_hslot)
+  // head column this lane ends with after the reduce-scatter: (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)[s]
+  const int zcol = (s >> 1) * L + lat;
+  const SliceMasks sm(s);
+  const unsigned long long m_lo = __builtin_amdgcn_ballot_w64(s < 2);
 
-  f2 Up[PKK / 2][4];     // [k pair][gate] = (U[2j][g], U[2j+1][g])
+  f2 Up[PKK / 2][4];     // [k pair][acc] = (U[2j][g], U[2j+1][g]), g = acc ^ s
   {
     const float4* pw = reinterpret_cast<const float4*>(a.pack) + PK_FE + wave * PKK * 64 + lane;
 #pragma unroll
@@ -199,120 +257,112 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     }
   }
   const size_t bt0 = (size_t)b * T;
-  const float* xp = a.xproj_e + bt0 * LG + s * LH + u;
-  float rb, xmask;
+  // every per-step access is (uniform row pointer) + (32-bit lane offset): scalar address arithmetic only
+  const unsigned loff = s * LH + u;                          // gate column of this lane
+  const unsigned eoff = lat_ok ? lat : 0;
+  const float* const xp0 = a.xproj_e + bt0 * LG;
+  const float* const ep0 = a.eps + bt0 * L;
+  float* const g0 = a.gates_e + bt0 * LG;
+  float* const h0 = a.hs_e + bt0 * LH;
+  float* const a0 = a.aux_e + bt0 * 2 * LH;
+  float rb;
   {
-    const float* src = is_z ? a.bz + max(zcol(s), 0) : a.rb_e + (size_t)b * LG + s * LH + u;
+    const float* src = lat_ok ? a.bz + zcol : a.rb_e + (size_t)b * LG + loff;
     rb = *src;
     rb = (is_z && !lat_ok) ? 0.f : rb;
-    xmask = is_z ? 0.f : 1.f;
   }
-  const float* ep = a.eps + bt0 * L + (lat_ok ? lat : 0);
-
-  float* optr[2];
-  int ostr[2], oslot[2];
-  regular_slots(s, u, bt0, a.hs_e, a.cs_e, a.gates_e, optr, ostr, oslot);
-  if (is_z) {     // store 0: head pre-activation column; store 1: z (lanes 0,1) or the KL term (lanes 2,3)
-    optr[0] = lat_ok ? a.zargs + bt0 * 2 * L + zcol(s) : g_pair_dump + lane;
-    ostr[0] = lat_ok ? 2 * L : 0;
-    optr[1] = !lat_ok ? g_pair_dump + lane : (s < 2 ? a.Z + bt0 * a.ldz + lat : a.klterm + bt0 * L + lat);
-    ostr[1] = !lat_ok ? 0 : (s < 2 ? a.ldz : L);
-  }
-  const int hslot = PKP * (u / PKK) + (u % PKK);
+  const float xmask = is_z ? 0.f : 1.f;
+  const int hslot = pair_hslot(u);
   const float klscale = -0.5f * (float)L;
 
   float c = 0.f;
-  // The per-step loads are requested two steps ahead: one step (0.75 us) is less than a load takes from HBM under
-  // load, and with one step of lookahead the launch time moved 117..130 us from run to run with the latency.
-  float xn = xp[0], xn2 = xp[(size_t)min(1, T - 1) * LG];      // projections of steps i and i+1
-  float en = 0.f, en2 = ep[0];                                 // eps of steps i-1 and i
-  // two stores after the prologue's loads, like every iteration issues after its loads: the loop-entry and
-  // back-edge memory queues then match and the wait for `xn` stays a counted vmcnt (see lstm.hip)
-  g_pair_dump[lane] = 0.f;
-  g_pair_dump[lane + 64] = 0.f;
-  auto latent = [&](const float (&acc)[4], float e, float& zv, float& klv) {
-    const float m = (s & 1) ? acc[1] : acc[0], lv = (s & 1) ? acc[3] : acc[2];
+  // The per-step loads are requested two steps ahead into TWO register sets (the loop body is two steps): a value is
+  // consumed where it landed, nothing rotates
+  float xA = xp0[loff], xB = xp0[(size_t)min(1, T - 1) * LG + loff];      // projections of steps 0 and 1
+  float eA = 0.f, eB = ep0[eoff];                                        // eps of steps -1 and 0
+  prologue_loads_done();
+
+  // latent lanes: zc = this lane's head column of step i-1; (mean, log_var) of its latent sit in lanes s and s^2
+  auto latent = [&](float zc, float e, float& zv, float& klv) {
+    const float other = dpp_mov<0x4E>(zc);
+    const float m = Sel4::pick(m_lo, zc, other), lv = Sel4::pick(m_lo, other, zc);
     const float sd = __expf(0.5f * lv);
     zv = fmaf(sd, e, m);
     klv = klscale * (1.f + lv - m * m - sd * sd);
   };
-  // the 4 gate sums of this lane's unit: h (LDS) . U slice, reduced over the k-slices
-  auto gate_sums = [&](const float* hslice, float x0, float (&z)[4]) {
+  auto gate_sum = [&](const float* hslice, float x0) {
     f2 acc[4];
+    acc[0] = (f2){x0, 0.f};
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (f2){(s == g) ? x0 : 0.f, 0.f};
+    for (int j = 1; j < 4; ++j) acc[j] = (f2){0.f, 0.f};
     float hv[PKP];
     load_hslice(hslice, hv);
     slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g][0] + acc[g][1]);
+    return reduce_scatter4(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], acc[3][0] + acc[3][1]);
+  };
+  // lanes 0,1 of a latent group store z, lanes 2,3 the KL term: a per-lane pointer (two stores under `if (s < 2) .. else ..`
+  // become one store through a pointer the compiler picks from a stack array)
+  float* const lp = s < 2 ? a.Z + bt0 * a.ldz + lat : a.klterm + bt0 * L + lat;
+  const int lstr = s < 2 ? a.ldz : L;
+  auto store_latent = [&](int row, float zc, float zv, float klv) {      // lat_ok lanes only
+    (a.zargs + (bt0 + row) * 2 * L)[zcol] = zc;
+    lp[(unsigned)row * (unsigned)lstr] = Sel4::pick(m_lo, zv, klv);
   };
 
-  for (int i = 0; i < T; ++i) {
-    const int cur = i & 1;
-    const float xv = fmaf(xn, xmask, rb);
+  auto step = [&](auto parc, int i, float& xa, float& ea) {
+    constexpr int cur = decltype(parc)::value;
+    const float xv = LATW ? fmaf(xa, xmask, rb) : xa + rb;
     PTOP(xv);
-    xn = xn2;
-    // prefetch two steps ahead, unconditional (clamped); three: no gain.  The row offset is a 32-bit SCALAR product:
-    // `(size_t)step * LG` per lane is a quarter-rate v_mad_i64_i32 on a SIMD that is issue-bound (tools/pair_stamps.py)
-    xn2 = xp[(unsigned)min(i + 2, T - 1) * (unsigned)LG];
-    const float ecur = en;                              // eps of step i-1
-    en = en2;
-    en2 = ep[(unsigned)min(i + 1, T - 1) * (unsigned)L];
-    float z[4];
-    gate_sums(&hb[cur][PKP * s], xv, z);
-    float h, gg;
-    lstm_cell<GATE>(z, c, h, gg);
-    float v0, v1;
-    pick_pair(s, h, c, z, gg, v0, v1);
-    if (wave == PNW - 1) {          // wave-uniform: the latent head of step i-1 (garbage at i == 0, rewritten at i == 1)
-      float zv, klv;
-      latent(z, ecur, zv, klv);
-      v0 = is_z ? sel_s(z) : v0;
-      v1 = is_z ? (s < 2 ? zv : klv) : v1;
-      if (lat_ok && s < 2) zbuf[(i + 1) & 1][zpos] = zv;
-    }
+    xa = (xp0 + (unsigned)min(i + 2, T - 1) * (unsigned)LG)[loff];
+    const float z = gate_sum(&hb[cur][PKP * s], xv);
+    float vA, act, kc;
+    const float h = pair_cell<GATE>(sm, z, c, vA, act, kc);
     if (!is_z) hb[cur ^ 1][hslot] = h;
-    *optr[0] = v0;
-    *optr[1] = v1;
-    const bool hold = is_z && i == 0;                   // the head lags one step: its row pointer starts moving at i == 1
-    optr[0] += hold ? 0 : ostr[0];
-    optr[1] += hold ? 0 : ostr[1];
-    PARRIVE(wave, i + 2, v0 + v1);                      // the encoder runs two steps ahead of the decoder's step index
+    if (LATW) {                     // the latent head of step i-1 (garbage at i == 0, rewritten at i == 1)
+      float zv, klv;
+      latent(z, ea, zv, klv);       // ea = eps of step i-1
+      ea = (ep0 + (unsigned)min(i + 1, T - 1) * (unsigned)L)[eoff];
+      if (lat_ok) {
+        if (s < 2) hbd[cur ^ 1][zslot] = zv;
+        store_latent(max(i - 1, 0), z, zv, klv);
+      }
+    }
+    if (!is_z) {
+      (g0 + (unsigned)i * (unsigned)LG)[loff] = vA;
+      if (s == 0) (h0 + (unsigned)i * (unsigned)LH)[u] = h;
+      if (s == 1 || s == 2) (a0 + (unsigned)i * (unsigned)(2 * LH))[(s - 1) * LH + u] = Sel4::pick(sm.m1, act, kc);
+    }
+    PARRIVE(wave, i + 2, vA + h);                       // the encoder runs two steps ahead of the decoder's step index
     step_barrier();
+  };
+  int i = 0;
+  for (; i + 1 < T; i += 2) {
+    step(ParC<0>(), i, xA, eA);
+    step(ParC<1>(), i + 1, xB, eB);
   }
+  if (T & 1) step(ParC<0>(), T - 1, xA, eA);
   // iteration T: only the latent head of step T-1 is left
-  if (wave == PNW - 1) {
-    f2 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (f2){(s == g) ? rb : 0.f, 0.f};
-    float hv[PKP];
-    load_hslice(&hb[T & 1][PKP * s], hv);
-    slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
-    float z[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g][0] + acc[g][1]);
+  if (LATW) {
+    const float z = gate_sum(&hb[T & 1][PKP * s], rb);
     float zv, klv;
-    latent(z, en, zv, klv);
+    latent(z, (T & 1) ? eB : eA, zv, klv);
     if (lat_ok) {
-      *optr[0] = sel_s(z);
-      *optr[1] = s < 2 ? zv : klv;
-      if (s < 2) zbuf[(T + 1) & 1][zpos] = zv;
+      if (s < 2) hbd[(T + 1) & 1][zslot] = zv;
+      store_latent(T - 1, z, zv, klv);
     }
   }
   step_barrier();          // the decoder chain runs two steps behind
   step_barrier();
 }
 
-// ZQ: latents per decoder lane actually present (ceil(latent_dim / 4)): lane s multiplies the latents s, s+4, ..; the
-// slots beyond latent_dim hold zero weights, so they are not issued at all
+// ZQ: latents per decoder lane actually present (ceil(latent_dim / 4) <= 2): lane s multiplies the latents s, s+4
 template <int GATE, bool HASXP, int ZQ>
-__device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP],
-                                                 float (*zbuf)[PLMAX]) {
+__device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP]) {
   const int s = lane & 3, b = blockIdx.x, T = a.T;
   const int u = min(wave * 16 + (lane >> 2), LH - 1);
-  f2 Up[PKK / 2][4];     // [k pair][gate] = (U[2j][g], U[2j+1][g])
-  f2 Kzr[ZQ][2];         // lane s takes the latents s, s+4, ...
+  const SliceMasks sm(s);
+  f2 Up[PKK / 2][4];     // [k pair][acc] = (U[2j][g], U[2j+1][g]), g = acc ^ s
+  float Kzr[ZQ][4];      // lane s takes the latents s, s+4; [acc]
   {
     const float4* pw = reinterpret_cast<const float4*>(a.pack) + PK_FD + wave * PKK * 64 + lane;
 #pragma unroll
@@ -324,71 +374,59 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
 #pragma unroll
     for (int q = 0; q < ZQ; ++q) {
       const float4 v = pz[q * 64];
-      Kzr[q][0][0] = v.x; Kzr[q][0][1] = v.y; Kzr[q][1][0] = v.z; Kzr[q][1][1] = v.w;
+      Kzr[q][0] = v.x; Kzr[q][1] = v.y; Kzr[q][2] = v.z; Kzr[q][3] = v.w;
     }
   }
   const size_t bt0 = (size_t)b * T;
-  const float* xp = a.xproj_d + bt0 * LG + s * LH + u;
-  const float rb = a.rb_d[(size_t)b * LG + s * LH + u];
-  float* optr[2];
-  int ostr[2], oslot[2];
-  regular_slots(s, u, bt0, a.hs_d, a.cs_d, a.gates_d, optr, ostr, oslot);
-  const int hslot = PKP * (u / PKK) + (u % PKK);
+  const unsigned loff = s * LH + u;
+  const float* const xp0 = a.xproj_d + bt0 * LG;
+  float* const g0 = a.gates_d + bt0 * LG;
+  float* const h0 = a.hs_d + bt0 * LH;
+  float* const a0 = a.aux_d + bt0 * 2 * LH;
+  const float rb = a.rb_d[(size_t)b * LG + loff];
+  const int hslot = pair_hslot(u);
   float c = 0.f;
-  float xn = HASXP ? xp[0] : 0.f, xn2 = HASXP ? xp[(size_t)min(1, T - 1) * LG] : 0.f;
-  g_pair_dump[lane] = 0.f;     // see the encoder
-  g_pair_dump[lane + 64] = 0.f;
+  float xA = HASXP ? xp0[loff] : 0.f, xB = HASXP ? xp0[(size_t)min(1, T - 1) * LG + loff] : 0.f;
+  prologue_loads_done();
   step_barrier();          // the encoder is two steps ahead
   step_barrier();
-  for (int t = 0; t < T; ++t) {
-    const int cur = t & 1;
+  auto step = [&](auto parc, int t, float& xa) {
+    constexpr int cur = decltype(parc)::value;
 #ifdef PAIR_STAMPS
     unsigned long long pst[8];
 #endif
-    const float xv = xn + rb;
+    const float xv = xa + rb;
     PSTAMP(0, xv);
     PTOP(xv);
-    xn = xn2;
-    if (HASXP) xn2 = xp[(unsigned)min(t + 2, T - 1) * (unsigned)LG];
-    // scalar FMAs throughout: with v_pk_fma the allocator pairs a prefetch's destination register with an h value
-    // inside a packed operand, and the wave waits for the load in the middle of the FMA block (+4 % step throughput)
-    f2 acc[4];       // (even k, odd k) partial sums; the input projection and z_t . K_z start the odd halves
-    {   // z_t . K_z: branch-free (rows of K_z beyond latent_dim are zero registers); does not depend on h
-      float zk[4];
+    if (HASXP) xa = (xp0 + (unsigned)min(t + 2, T - 1) * (unsigned)LG)[loff];
+    f2 acc[4];       // (even k, odd k) partial sums
+    acc[0] = (f2){xv, 0.f};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) zk[g] = 0.f;
-      const float4 zq = *reinterpret_cast<const float4*>(&zbuf[cur][PLQ * s]);
-      const float zl[PLQ] = {zq.x, zq.y, zq.z, zq.w};
-#pragma unroll
-      for (int q = 0; q < ZQ; ++q) {
-        zk[0] = fmaf(zl[q], Kzr[q][0][0], zk[0]); zk[1] = fmaf(zl[q], Kzr[q][0][1], zk[1]);
-        zk[2] = fmaf(zl[q], Kzr[q][1][0], zk[2]); zk[3] = fmaf(zl[q], Kzr[q][1][1], zk[3]);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = (f2){(s == g) ? xv : 0.f, zk[g]};
-    }
-    float hv[PKP];
+    for (int j = 1; j < 4; ++j) acc[j] = (f2){0.f, 0.f};
+    float hv[PKP];   // 22 h values, then z_t[s], z_t[s + 4]
     load_hslice(&hb[cur][PKP * s], hv);
     PSTAMP(1, hv[0]);                      // the first 16 bytes of h have arrived
     PSTAMP(2, hv[PKP - 4]);                // the last
     slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
     PSTAMP(3, acc[3][0] + acc[0][1]);
-    float z[4];
+    float as[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = reduce_slices<PK>(acc[g][0] + acc[g][1]);
-    PSTAMP(4, z[0] + z[3]);
-    float h, gg;
-    lstm_cell<GATE>(z, c, h, gg);
+    for (int j = 0; j < 4; ++j) {          // + z_t . K_z (rows of K_z beyond latent_dim are zero registers)
+      as[j] = acc[j][0] + acc[j][1];
+#pragma unroll
+      for (int q = 0; q < ZQ; ++q) as[j] = fmaf(hv[PKK + q], Kzr[q][j], as[j]);
+    }
+    const float z = reduce_scatter4(as[0], as[1], as[2], as[3]);
+    PSTAMP(4, z);
+    float vA, act, kc;
+    const float h = pair_cell<GATE>(sm, z, c, vA, act, kc);
     PSTAMP(5, h);
     hb[cur ^ 1][hslot] = h;
-    float v0, v1;
-    pick_pair(s, h, c, z, gg, v0, v1);
-    *optr[0] = v0;
-    *optr[1] = v1;
-    optr[0] += ostr[0];
-    optr[1] += ostr[1];
-    PSTAMP(6, v0 + v1);
-    PARRIVE(PNW + wave, t, v0 + v1);
+    (g0 + (unsigned)t * (unsigned)LG)[loff] = vA;
+    if (s == 0) (h0 + (unsigned)t * (unsigned)LH)[u] = h;
+    if (s == 1 || s == 2) (a0 + (unsigned)t * (unsigned)(2 * LH))[(s - 1) * LH + u] = Sel4::pick(sm.m1, act, kc);
+    PSTAMP(6, vA + h);
+    PARRIVE(PNW + wave, t, vA + h);
     step_barrier();
 #ifdef PAIR_STAMPS
     if (blockIdx.x == 0 && wave == 0 && lane == 0 && t >= 32 && t < 40) {
@@ -399,27 +437,32 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
       g_pair_stamps[t - 32][7] = now;
     }
 #endif
+  };
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(ParC<0>(), t, xA);
+    step(ParC<1>(), t + 1, xB);
   }
+  if (T & 1) step(ParC<0>(), T - 1, xA);
 }
 
 template <int GATE, bool HASXP, int ZQ>
 __global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float hbuf[2][2][PK * PKP];      // [chain][parity][sliced h]
-  __shared__ __attribute__((aligned(16))) float zbuf[2][PLMAX];
+  __shared__ __attribute__((aligned(16))) float hbuf[2][2][PK * PKP];      // [chain][parity][sliced h (+ z in the decoder's)]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < 2 * 2 * PK * PKP; i += PNT) (&hbuf[0][0][0])[i] = 0.f;
-  if (tid < 2 * PLMAX) (&zbuf[0][0])[tid] = 0.f;
   __syncthreads();
-  if (wave < PNW) pair_fwd_encoder<GATE>(a, wave, lane, hbuf[0], zbuf);
-  else pair_fwd_decoder<GATE, HASXP, ZQ>(a, wave - PNW, lane, hbuf[1], zbuf);
+  if (wave < PNW - 1) pair_fwd_encoder<GATE, false>(a, wave, lane, hbuf[0], hbuf[1]);
+  else if (wave == PNW - 1) pair_fwd_encoder<GATE, true>(a, wave, lane, hbuf[0], hbuf[1]);
+  else pair_fwd_decoder<GATE, HASXP, ZQ>(a, wave - PNW, lane, hbuf[1]);
 }
 
 // ---------------------------------------------------------------------------
 // backward: decoder BPTT, the latent head's backward and encoder BPTT in one launch
 // ---------------------------------------------------------------------------
-// Waves 0-5 run the decoder chain (layout of lstm_bwd_kernel: lane = (unit group, column slice), 4 units x
-// 22 gate columns of U per thread), waves 6-11 the encoder chain two steps behind.  Between them:
+// Waves 0-5 run the decoder chain (lane = (unit group, column slice), 4 units x 22 gate columns of U per thread),
+// waves 6-11 the encoder chain two steps behind.  Between them:
 //   dZ_t[l]   = sum_c dz_dec_t[c] * Kz[l][c]              -- rows of Kz ride in the decoder's surplus unit
 //                                                            groups (units 88..95: latent_dim <= 8), so dZ_{t+1}
 //                                                            falls out of the FMA sequence of step t
@@ -435,9 +478,9 @@ struct PairBwdArgs {
   const float* pack;              // weights in lane order (clv_lstm_pair_pack)
   const float* Wz;                // [88,2L]
   const float* dhs_d;             // [B,T,88] dL/dh of the decoder (output head)
-  const float* cs_d;
-  const float* cs_e;
-  float* gates_d;                 // in: (z_i,z_f,g,z_o) of the forward pass   out: dz
+  const float* aux_d;             // [B*T,2,88] (kcarry, kc) of the forward pass
+  const float* aux_e;
+  float* gates_d;                 // in: (ki,kf,kg,ko) of the forward pass   out: dz
   float* gates_e;
   float* dzsum_d;                 // [B,352] sum_t dz
   float* dzsum_e;
@@ -446,23 +489,25 @@ struct PairBwdArgs {
   float* dzargs;                  // [B*T,2L]
 };
 
-template <int GATE, bool DEC, int ZP>
+// LATW: the decoder chain's last wave: its surplus unit groups hold rows of Kz and finish dzargs
+template <int GATE, bool DEC, bool LATW, int ZP>
 __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, int lane, float (*dzb)[BW_LDS],
                                                float (*dza)[QZ]) {
   const int cs = lane & 15, ug = wave * 4 + (lane >> 4), q = cs >> 2;
-  const bool b0 = cs & 1, b1 = cs & 2;
   const int b = blockIdx.x, T = a.T, L = a.L;
   const int u = min(4 * ug + (cs & 3), LH - 1);      // surplus groups without a latent duplicate unit 87
   const int zg0 = 4 * (ug - 22);                     // first latent of a surplus group
-  const bool zgroup = DEC && ug >= 22 && zg0 < L;
+  const bool zgroup = LATW && ug >= 22 && zg0 < L;
   const int lat = zg0 + (cs & 3);                    // latent this lane finishes after the reduce-scatter
   const bool zlane = zgroup && lat < L;
-  const Sel4 sel_q(q);
+  const bool zlive = zlane && q < 2;                 // replica 0: the mean column of dzargs, replica 1: the log_var column
+  const unsigned long long m_q3 = __builtin_amdgcn_ballot_w64(q == 3);
+  const unsigned long long m_q0 = __builtin_amdgcn_ballot_w64(q == 0);
   float* gates = DEC ? a.gates_d : a.gates_e;
-  const float* csp = DEC ? a.cs_d : a.cs_e;
+  const float* aux = DEC ? a.aux_d : a.aux_e;
   float* dzsum = DEC ? a.dzsum_d : a.dzsum_e;
 
-  f2 Ur[BW_CW][2];    // [column][unit pair]; a latent group holds rows of Kz instead
+  f2 Ur[BW_CW][2];    // [column][acc pair]: acc j = unit j ^ (cs & 3) of the group; a latent group holds rows of Kz instead
   {
     const float4* pw = reinterpret_cast<const float4*>(a.pack) + (DEC ? PK_BD : PK_BE) + wave * BW_CW * 64 + lane;
 #pragma unroll
@@ -485,76 +530,50 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   float dc = 0.f;
   float zsum = 0.f;                  // sum_t dz of this lane's gate column (the 4 replicas of a unit share the 4 gates)
 
-  struct Raw { float zi, zf, g, zo, c, cp, dh; };
-  struct Coef { float ko, kc, ki, kf, kg, kcarry, dhh; };
-  const float* g_base = gates + rowbt * LG + u;
-  // per-lane streams behind the (c_t, c_{t-1}, dh_t) load slots: a latent lane reads (mean, log_var, eps) of its
-  // latent there instead (one step later in time, see below), so every lane issues the same loads
-  const float* pc = zlane ? a.zargs + rowbt * 2 * L + lat : csp + rowbt * LH + u;
-  const float* pd = zlane ? a.eps + rowbt * L + lat : (DEC ? a.dhs_d + rowbt * LH + u : pc);
-  const int stc = zlane ? 2 * L : LH, std_ = zlane ? L : (DEC ? LH : 0);
-  const int ppo = zlane ? L : 0;                       // offset of the second stream (log_var column / same array)
+  // What a lane needs of step t: k of its gate, kc, kcarry and (decoder) the upstream dh: (uniform row pointer) +
+  // (32-bit lane offset) each.  A latent lane needs (mean, log_var, eps) of its latent ONE STEP LATER in time: the
+  // values it holds during iteration (step t) are those of step t+1, whose dZ its matvec has just produced from
+  // dz_dec_{t+1}.
+  struct Raw { float kq, kc, kcarry, dh, m, lv, e; };
+  const unsigned col = q * LH + u;
+  float* const g0 = gates + rowbt * LG;
+  const float* const a0 = aux + rowbt * 2 * LH;
+  const float* const d0 = a.dhs_d + rowbt * LH;
+  const float* const z0 = a.zargs + rowbt * 2 * L;
+  const float* const e0 = a.eps + rowbt * L;
+  float* const dz0 = a.dzargs + rowbt * 2 * L;
   const float hk = 0.5f * a.kl_scale;
-  // Offsets stay 32-bit and their per-lane products go through v_mul_u32_u24 (time index < 2^24, strides <= 88): the
-  // 64-bit `(size_t)t * stride` forms compile to quarter-rate v_mul_lo_u32 / v_mad_u64_u32, ~30 issue slots of a step.
-  auto load_raw = [&](int tr) {       // regular lanes: step max(tr, 0); latent lanes: step tr + 1 (clamped to the window)
-    Raw r;
-    const int t = max(tr, 0);
-    const float* gp = g_base + (unsigned)t * (unsigned)LG;                   // uniform offset: scalar multiply
-    r.zi = gp[0]; r.zf = gp[LH]; r.g = gp[2 * LH]; r.zo = gp[3 * LH];
-    const int tz = zlane ? min(max(tr + 1, 0), T - 1) : t;
-    r.c = pc[__umul24(tz, stc)];
-    const float cprev = pc[__umul24(zlane ? tz : max(tz - 1, 0), stc) + (unsigned)ppo];
-    r.cp = (t > 0 || zlane) ? cprev : 0.f;
-    r.dh = DEC ? pd[__umul24(tz, std_)] : 0.f;
-    return r;
-  };
-  auto make_coef = [&](const Raw& r) {
-    Coef k;
-    const float ig = gate_fn<GATE>(r.zi), fg = gate_fn<GATE>(r.zf), og = gate_fn<GATE>(r.zo);
-    const float tc = fast_tanh(r.c);
-    k.ko = tc * gate_grad<GATE>(r.zo, og);
-    k.kc = og * (1.f - tc * tc);
-    k.ki = r.g * gate_grad<GATE>(r.zi, ig);
-    k.kf = r.cp * gate_grad<GATE>(r.zf, fg);
-    k.kg = ig * (1.f - r.g * r.g);
-    k.kcarry = fg;
-    k.dhh = r.dh;
-    if (DEC && wave == PNW - 1) {
-      // latent lanes: (c, cp, dh) = (mean, log_var, eps); dzargs = dZ * ki + kf with
-      //   mean column (replica 0): ki = 1, kf = kl*mean;  log_var column: ki = eps*sd/2, kf = -kl*(1 - sd^2)/2
-      const float sd = __expf(0.5f * r.cp);
-      const float zi_ = q == 0 ? 1.f : 0.5f * r.dh * sd;
-      const float zf_ = q == 0 ? a.kl_scale * r.c : -hk * (1.f - sd * sd);
-      k.ki = zgroup ? zi_ : k.ki;
-      k.kf = zgroup ? zf_ : k.kf;
+  auto load_raw = [&](int tr, Raw& r) {
+    const unsigned t = (unsigned)max(tr, 0);
+    r.kq = (g0 + t * (unsigned)LG)[col];
+    const float* ar = a0 + t * (unsigned)(2 * LH);
+    r.kcarry = ar[u];
+    r.kc = ar[LH + u];
+    if (DEC) r.dh = (d0 + t * (unsigned)LH)[u];
+    if (LATW) {
+      const unsigned tz = (unsigned)min(max(tr + 1, 0), T - 1);
+      if (zlane) {
+        const float* zr = z0 + tz * (unsigned)(2 * L);
+        r.m = zr[lat];
+        r.lv = zr[L + lat];
+        r.e = (e0 + tz * (unsigned)L)[lat];
+      }
     }
-    return k;
   };
-  // With the +1 offset above the coefficients a latent lane holds during iteration (step t) are those of step
-  // t+1, whose dZ its matvec has just produced from dz_dec_{t+1}.
-  // Two steps of loads in flight: the values of step t are requested at iteration t+2 and turned into coefficients at
-  // the top of iteration t (off the recurrence: the coefficients are first used after the matvec).  One step of
-  // lookahead is less than a load takes from HBM under load.
-  Raw raw0 = load_raw(T - 1);         // step t
-  Raw raw1 = load_raw(T - 2);         // step t-1
-  g_pair_dump[lane] = 0.f;           // one store after the prologue's loads (see lstm_bwd_kernel)
+  // Two register sets, the loop body is two steps: the values of step t are requested at the end of iteration t+2
+  // (behind the last use of the set) and consumed where they landed
+  Raw rA, rB;
+  rA.m = rA.lv = rA.e = rB.m = rB.lv = rB.e = 0.f;
+  rA.dh = rB.dh = 0.f;
+  load_raw(T - 1, rA);
+  load_raw(T - 2, rB);
+  prologue_loads_done();
 
-  // output slot: regular lanes: dz of gate q (4 replicas share the 4 gates); latent lanes: replica 0 the
-  // mean column of dzargs, replica 1 the log_var column
-  const int col = q * LH + u;
-  float* gptr = gates + (rowbt + T - 1) * LG + col;
-  int gstr = -LG;
-  int lpos = BW_CP * (col / BW_CW) + col % BW_CW;
-  if (zgroup) {
-    const bool live = zlane && q < 2;
-    gptr = live ? a.dzargs + (rowbt + T - 1) * 2 * L + q * L + lat : g_pair_dump + lane;
-    gstr = live ? -2 * L : 0;
-    lpos = q * L + lat;              // position in the dzargs LDS vector
-  }
+  // LDS slot: regular lanes: dz of gate q (4 replicas share the 4 gates); latent lanes: their dzargs column
+  const int lpos = zgroup ? q * L + lat : BW_CP * ((int)col / BW_CW) + (int)col % BW_CW;
 
-  auto matvec = [&](int cur) {        // reduce-scattered: this lane's unit (or latent) total
-    const float4* dp = reinterpret_cast<const float4*>(&dzb[cur][BW_CP * cs]);
+  auto matvec = [&](const float* dzs) {        // reduce-scattered: this lane's unit (or latent) total
+    const float4* dp = reinterpret_cast<const float4*>(dzs + BW_CP * cs);
     float dv[BW_CP];
 #pragma unroll
     for (int j = 0; j < BW_CP / 4; ++j) {
@@ -568,15 +587,18 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
       acc01 = __builtin_elementwise_fma(dd, Ur[c][0], acc01);
       acc23 = __builtin_elementwise_fma(dd, Ur[c][1], acc23);
     }
-    const float keep_a = b0 ? acc01[1] : acc01[0], send_a = b0 ? acc01[0] : acc01[1];
-    const float keep_b = b0 ? acc23[1] : acc23[0], send_b = b0 ? acc23[0] : acc23[1];
-    const float wa = keep_a + dpp_mov<0xB1>(send_a);
-    const float wb = keep_b + dpp_mov<0xB1>(send_b);
-    const float keep = b1 ? wb : wa, send = b1 ? wa : wb;
-    float x = keep + dpp_mov<0x4E>(send);
-    x = dpp_add<0x124>(x);
+    const float r0 = acc01[0] + dpp_mov<0xB1>(acc01[1]);      // partner m^1: its accumulator 1 is unit m
+    const float r2 = acc23[0] + dpp_mov<0xB1>(acc23[1]);      //              its accumulator 3 is unit m^2
+    float x = r0 + dpp_mov<0x4E>(r2);                         // partner m^2: its r2 is unit m
+    x = dpp_add<0x124>(x);                                    // the four quads of the row (16 column slices)
     x = dpp_add<0x128>(x);
     return x;
+  };
+  auto latent_dz = [&](const Raw& k, float dZ) {    // mean column (replica 0): dZ + kl*mean; log_var column: dZ*eps*sd/2 - kl*(1 - sd^2)/2
+    const float sd = __expf(0.5f * k.lv);
+    const float zi_ = Sel4::pick(m_q0, 1.f, 0.5f * k.e * sd);
+    const float zf_ = Sel4::pick(m_q0, a.kl_scale * k.m, -hk * (1.f - sd * sd));
+    return fmaf(dZ, zi_, zf_);
   };
 
   if (!DEC) {                        // the encoder chain runs two iterations behind: dzargs_t leaves the decoder
@@ -584,56 +606,55 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     step_barrier();
   }
 
-  for (int i = 0; i < T; ++i) {
+  auto step = [&](auto parc, int i, Raw& k) {
+    constexpr int cur = decltype(parc)::value;
     const int t = T - 1 - i;
-    const int cur = i & 1;
-    const Raw raw2 = load_raw(t - 2);
-    const Coef k = make_coef(raw0);
     float dhup;
     if (DEC) {
-      dhup = k.dhh;
+      dhup = k.dh;
     } else {                          // dh_enc_t = dzargs_t . Wz[u,:]  (dzargs_t was written one iteration ago)
-      const int par = (i + 1) & 1;    // written by decoder iteration i + 1
-      float s0 = 0.f, s1 = 0.f;
+      float s0 = 0.f, s1 = 0.f;       // by decoder iteration i + 1: parity cur ^ 1
 #pragma unroll
       for (int j4 = 0; j4 < ZP; j4 += 4) {           // columns beyond 2L: zero weights, zero LDS
-        const float4 v = *reinterpret_cast<const float4*>(&dza[par][j4]);
+        const float4 v = *reinterpret_cast<const float4*>(&dza[cur ^ 1][j4]);
         s0 = fmaf(v.x, Wzr[j4], s0); s1 = fmaf(v.y, Wzr[j4 + 1], s1);
         s0 = fmaf(v.z, Wzr[j4 + 2], s0); s1 = fmaf(v.w, Wzr[j4 + 3], s1);
       }
       dhup = s0 + s1;
     }
-    const float dhrec = matvec(cur);
+    const float dhrec = matvec(dzb[cur]);
     const float dh = dhup + dhrec;
     dc = fmaf(dh, k.kc, dc);
-    float dz[4];
-    dz[0] = dc * k.ki;
-    dz[1] = dc * k.kf;
-    dz[2] = dc * k.kg;
-    dz[3] = dh * k.ko;
+    const float val = Sel4::pick(m_q3, dh, dc) * k.kq;      // dz_o = dh ko; dz_{i,f,g} = dc k
     dc = dc * k.kcarry;
-    float val = sel_q(dz);
     zsum += val;
-    if (DEC && wave == PNW - 1) {     // wave-uniform: latent lanes turn dZ_{t+1} into dzargs_{t+1}
-      const float zv = fmaf(dhrec, k.ki, k.kf);
-      val = zgroup ? zv : val;
-      if (zlane && q < 2) dza[i & 1][lpos] = zv;
+    if (!zgroup) {
+      dzb[cur ^ 1][lpos] = val;
+      (g0 + (unsigned)t * (unsigned)LG)[col] = val;
     }
-    if (!zgroup) dzb[cur ^ 1][lpos] = val;
-    *gptr = val;
-    gptr += (zgroup && i == 0) ? 0 : gstr;            // the head lags one step
-    raw0 = raw1;
-    raw1 = raw2;
+    if (LATW) {                       // latent lanes turn dZ_{t+1} into dzargs_{t+1}
+      if (zlive) {
+        const float zv = latent_dz(k, dhrec);
+        dza[cur][lpos] = zv;
+        (dz0 + (unsigned)min(t + 1, T - 1) * (unsigned)(2 * L))[lpos] = zv;      // i == 0: garbage into row T-1, rewritten at i == 1
+      }
+    }
+    load_raw(t - 2, k);
     step_barrier();
+  };
+  int i = 0;
+  for (; i + 1 < T; i += 2) {
+    step(ParC<0>(), i, rA);
+    step(ParC<1>(), i + 1, rB);
   }
+  if (T & 1) step(ParC<0>(), T - 1, rA);
   if (DEC) {
     // iteration T: dZ_0 -> dzargs_0
-    if (wave == PNW - 1) {
-      const float dZ = matvec(T & 1);
-      const Coef klast = make_coef(raw0);          // raw0 = load_raw(-1): a latent lane's values of step 0
-      const float zv = fmaf(dZ, klast.ki, klast.kf);
-      if (zlane && q < 2) {
-        *gptr = zv;
+    if (LATW) {
+      const float dZ = matvec(dzb[T & 1]);
+      if (zlive) {
+        const float zv = latent_dz((T & 1) ? rB : rA, dZ);      // the set reloaded last holds load_raw(-1): step 0
+        dz0[lpos] = zv;
         dza[T & 1][lpos] = zv;
       }
     }
@@ -652,8 +673,9 @@ __global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
   for (int i = tid; i < 2 * 2 * BW_LDS; i += PNT) (&dzbuf[0][0][0])[i] = 0.f;
   if (tid < 2 * QZ) (&dza[0][0])[tid] = 0.f;
   __syncthreads();
-  if (wave < PNW) pair_bwd_chain<GATE, true, ZP>(a, wave, lane, dzbuf[0], dza);
-  else pair_bwd_chain<GATE, false, ZP>(a, wave - PNW, lane, dzbuf[1], dza);
+  if (wave < PNW - 1) pair_bwd_chain<GATE, true, false, ZP>(a, wave, lane, dzbuf[0], dza);
+  else if (wave == PNW - 1) pair_bwd_chain<GATE, true, true, ZP>(a, wave, lane, dzbuf[0], dza);
+  else pair_bwd_chain<GATE, false, false, ZP>(a, wave - PNW, lane, dzbuf[1], dza);
 }
 
 }  // namespace clv
@@ -687,21 +709,21 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                                  float* gates_enc, const float* rowbias_enc,
                                  float* gates_dec, int dec_has_xproj, const float* rowbias_dec,
                                  const float* pack, const float* bz, const float* eps,
-                                 float* hs_enc, float* cs_enc, float* hs_dec, float* cs_dec,
+                                 float* hs_enc, float* aux_enc, float* hs_dec, float* aux_dec,
                                  float* zargs, float* Z, int ldz, float* klterm, void* stream) {
   using namespace clv;
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0 || ldz < L) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
   if (!gates_enc || !rowbias_enc || !gates_dec || !rowbias_dec || !pack || !bz || !eps ||
-      !hs_enc || !cs_enc || !hs_dec || !cs_dec || !zargs || !Z || !klterm)
+      !hs_enc || !aux_enc || !hs_dec || !aux_dec || !zargs || !Z || !klterm)
     return CLV_EINVAL;
   PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, gates_dec, rowbias_dec, pack, bz, eps,
-                hs_enc, cs_enc, gates_enc, hs_dec, cs_dec, gates_dec, zargs, Z, klterm};
+                hs_enc, aux_enc, gates_enc, hs_dec, aux_dec, gates_dec, zargs, Z, klterm};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_fwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
 #define PAIR_FWD_Z(G, X, Z) hipLaunchKernelGGL((lstm_pair_fwd_kernel<G, X, Z>), dim3(B), dim3(PNT), 0, s, a)
-#define PAIR_FWD(G, X) do { if (L <= 4) PAIR_FWD_Z(G, X, 1); else if (L <= 8) PAIR_FWD_Z(G, X, 2); else PAIR_FWD_Z(G, X, 4); } while (0)
+#define PAIR_FWD(G, X) do { if (L <= 4) PAIR_FWD_Z(G, X, 1); else PAIR_FWD_Z(G, X, 2); } while (0)
   if (hard) { if (dec_has_xproj) PAIR_FWD(CLV_GATE_HARD_SIGMOID, true); else PAIR_FWD(CLV_GATE_HARD_SIGMOID, false); }
   else { if (dec_has_xproj) PAIR_FWD(CLV_GATE_SIGMOID, true); else PAIR_FWD(CLV_GATE_SIGMOID, false); }
 #undef PAIR_FWD_Z
@@ -711,17 +733,17 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
 
 extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
                                  const float* pack, const float* Wz,
-                                 const float* dhs_dec, const float* cs_dec, const float* cs_enc,
+                                 const float* dhs_dec, const float* aux_dec, const float* aux_enc,
                                  float* gates_dec_inout_dz, float* gates_enc_inout_dz,
                                  float* dzsum_dec, float* dzsum_enc,
                                  const float* zargs, const float* eps, float* dzargs, void* stream) {
   using namespace clv;
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
-  if (!pack || !Wz || !dhs_dec || !cs_dec || !cs_enc || !gates_dec_inout_dz || !gates_enc_inout_dz ||
+  if (!pack || !Wz || !dhs_dec || !aux_dec || !aux_enc || !gates_dec_inout_dz || !gates_enc_inout_dz ||
       !dzsum_dec || !dzsum_enc || !zargs || !eps || !dzargs)
     return CLV_EINVAL;
-  PairBwdArgs a{B, T, L, kl_scale, pack, Wz, dhs_dec, cs_dec, cs_enc, gates_dec_inout_dz,
+  PairBwdArgs a{B, T, L, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_dec_inout_dz,
                 gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_bwd", s);

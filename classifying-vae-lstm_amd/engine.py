@@ -546,8 +546,10 @@ class VrnnEngine(_EngineBase):
         self.wk_dec = _f(d, B, 4 * H)
         self.gates_enc = _f(d, BT, 4 * H)           # xproj in, (z_i,z_f,g,z_o) after fwd, dz after bwd
         self.gates_dec = _f(d, BT, 4 * H)
-        self.hs_enc, self.cs_enc = _f(d, BT, H), _f(d, BT, H)
-        self.hs_dec, self.cs_dec = _f(d, BT, H), _f(d, BT, H)
+        # cs_*: the cell states of the separate sequence kernels; the pair kernels keep (kcarry, kc) per unit and step
+        # there instead (two floats: see csrc/lstm_pair.hip), so the buffers hold 2H floats per frame
+        self.hs_enc, self.cs_enc = _f(d, BT, H), _f(d, BT, 2 * H if self.fuse_pair else H)
+        self.hs_dec, self.cs_dec = _f(d, BT, H), _f(d, BT, 2 * H if self.fuse_pair else H)
         self.zargs = _f(d, BT, 2 * L)
         # decoder input [Xp | Z] as ONE matrix (row stride padded to a multiple of 4 floats): the history
         # frames are staged into its first D columns, gauss_fwd writes Z next to them, so the decoder's
