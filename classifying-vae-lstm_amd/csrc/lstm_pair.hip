@@ -219,6 +219,24 @@ __device__ __forceinline__ float reduce_scatter4(float a0, float a1, float a2, f
 
 template <int P> struct ParC { static constexpr int value = P; };
 
+// Per-step global accesses are buffer instructions: a resource descriptor per array (base = this batch row's first
+// frame, num_records = its T frames: 4 SGPRs), the lane's byte offset in ONE VGPR that never changes, the step's row offset
+// in an SGPR.  No vector address arithmetic at all, and a lane that has nothing to store (or load) gets an offset
+// beyond num_records: the hardware drops the store (returns 0), so no store sits under a divergent branch -- which
+// matters beyond the branch itself: with stores on conditional paths the compiler's vmcnt bookkeeping assumes they may
+// not have been issued and waits for the NEXT newer load instead (the waits of the two-step lookahead collapse).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
 // Every load of the prologue (weights, the first two steps' values) has landed before the step loop is entered: the
 // compiler's wait-count bookkeeping merges the loop-entry state with the back edge's, and with ~25 prologue loads still
 // "in flight" at the entry it places s_waitcnt vmcnt(<small>) INSIDE the loop for the weights' first use -- which in the
@@ -257,14 +275,21 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     }
   }
   const size_t bt0 = (size_t)b * T;
-  // every per-step access is (uniform row pointer) + (32-bit lane offset): scalar address arithmetic only
   const unsigned loff = s * LH + u;                          // gate column of this lane
-  const unsigned eoff = lat_ok ? lat : 0;
-  const float* const xp0 = a.xproj_e + bt0 * LG;
-  const float* const ep0 = a.eps + bt0 * L;
-  float* const g0 = a.gates_e + bt0 * LG;
-  float* const h0 = a.hs_e + bt0 * LH;
-  float* const a0 = a.aux_e + bt0 * 2 * LH;
+  const rsrc_t r_g = make_rsrc(a.gates_e + bt0 * LG, T * LG * 4);       // x_t.K_x in, k out (same buffer)
+  const rsrc_t r_h = make_rsrc(a.hs_e + bt0 * LH, T * LH * 4);
+  const rsrc_t r_a = make_rsrc(a.aux_e + bt0 * 2 * LH, T * 2 * LH * 4);
+  const rsrc_t r_e = make_rsrc(a.eps + bt0 * L, T * L * 4);
+  const rsrc_t r_za = make_rsrc(a.zargs + bt0 * 2 * L, T * 2 * L * 4);
+  const rsrc_t r_z = make_rsrc(a.Z + bt0 * a.ldz, T * a.ldz * 4);
+  const rsrc_t r_kl = make_rsrc(a.klterm + bt0 * L, T * L * 4);
+  const unsigned vo_g = is_z ? BUF_OOB : loff * 4;
+  const unsigned vo_h = (!is_z && s == 0) ? u * 4 : BUF_OOB;
+  const unsigned vo_a = (!is_z && (s == 1 || s == 2)) ? ((s - 1) * LH + u) * 4 : BUF_OOB;
+  const unsigned vo_e = (lat_ok ? lat : 0) * 4;
+  const unsigned vo_za = lat_ok ? zcol * 4 : BUF_OOB;
+  const unsigned vo_z = (lat_ok && s < 2) ? lat * 4 : BUF_OOB;
+  const unsigned vo_kl = (lat_ok && s >= 2) ? lat * 4 : BUF_OOB;
   float rb;
   {
     const float* src = lat_ok ? a.bz + zcol : a.rb_e + (size_t)b * LG + loff;
@@ -278,8 +303,8 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   float c = 0.f;
   // The per-step loads are requested two steps ahead into TWO register sets (the loop body is two steps): a value is
   // consumed where it landed, nothing rotates
-  float xA = xp0[loff], xB = xp0[(size_t)min(1, T - 1) * LG + loff];      // projections of steps 0 and 1
-  float eA = 0.f, eB = ep0[eoff];                                        // eps of steps -1 and 0
+  float xA = buf_load(r_g, loff * 4, 0), xB = buf_load(r_g, loff * 4, min(1, T - 1) * LG * 4);      // projections of steps 0 and 1
+  float eA = 0.f, eB = buf_load(r_e, vo_e, 0);                           // eps of steps -1 and 0
   prologue_loads_done();
 
   // latent lanes: zc = this lane's head column of step i-1; (mean, log_var) of its latent sit in lanes s and s^2
@@ -300,38 +325,36 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     slice_fma_pairs<0, PKK / 2>(hv, Up, acc);
     return reduce_scatter4(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], acc[3][0] + acc[3][1]);
   };
-  // lanes 0,1 of a latent group store z, lanes 2,3 the KL term: a per-lane pointer (two stores under `if (s < 2) .. else ..`
-  // become one store through a pointer the compiler picks from a stack array)
-  float* const lp = s < 2 ? a.Z + bt0 * a.ldz + lat : a.klterm + bt0 * L + lat;
-  const int lstr = s < 2 ? a.ldz : L;
-  auto store_latent = [&](int row, float zc, float zv, float klv) {      // lat_ok lanes only
-    (a.zargs + (bt0 + row) * 2 * L)[zcol] = zc;
-    lp[(unsigned)row * (unsigned)lstr] = Sel4::pick(m_lo, zv, klv);
+  auto store_latent = [&](int row, float zc, float zv, float klv) {      // lanes without a latent: dropped (offset out of range)
+    buf_store(zc, r_za, vo_za, (unsigned)row * (unsigned)(2 * L * 4));
+    buf_store(zv, r_z, vo_z, (unsigned)row * (unsigned)(a.ldz * 4));
+    buf_store(klv, r_kl, vo_kl, (unsigned)row * (unsigned)(L * 4));
   };
 
   auto step = [&](auto parc, int i, float& xa, float& ea) {
     constexpr int cur = decltype(parc)::value;
+    asm volatile("" : "+v"(xa));        // pins the use of xa behind the previous step's barrier (else the compiler computes
+                                        // xv half a step early and waits there for a load issued moments before)
     const float xv = LATW ? fmaf(xa, xmask, rb) : xa + rb;
     PTOP(xv);
-    xa = (xp0 + (unsigned)min(i + 2, T - 1) * (unsigned)LG)[loff];
     const float z = gate_sum(&hb[cur][PKP * s], xv);
     float vA, act, kc;
     const float h = pair_cell<GATE>(sm, z, c, vA, act, kc);
     if (!is_z) hb[cur ^ 1][hslot] = h;
     if (LATW) {                     // the latent head of step i-1 (garbage at i == 0, rewritten at i == 1)
       float zv, klv;
+      asm volatile("" : "+v"(ea));
       latent(z, ea, zv, klv);       // ea = eps of step i-1
-      ea = (ep0 + (unsigned)min(i + 1, T - 1) * (unsigned)L)[eoff];
-      if (lat_ok) {
-        if (s < 2) hbd[cur ^ 1][zslot] = zv;
-        store_latent(max(i - 1, 0), z, zv, klv);
-      }
+      if (lat_ok && s < 2) hbd[cur ^ 1][zslot] = zv;
+      store_latent(max(i - 1, 0), z, zv, klv);
     }
-    if (!is_z) {
-      (g0 + (unsigned)i * (unsigned)LG)[loff] = vA;
-      if (s == 0) (h0 + (unsigned)i * (unsigned)LH)[u] = h;
-      if (s == 1 || s == 2) (a0 + (unsigned)i * (unsigned)(2 * LH))[(s - 1) * LH + u] = Sel4::pick(sm.m1, act, kc);
-    }
+    buf_store(vA, r_g, vo_g, (unsigned)i * (unsigned)(LG * 4));
+    buf_store(h, r_h, vo_h, (unsigned)i * (unsigned)(LH * 4));
+    buf_store(Sel4::pick(sm.m1, act, kc), r_a, vo_a, (unsigned)i * (unsigned)(2 * LH * 4));
+    // the loads of step i+2 into the registers this step has just consumed; issued BEHIND the stores, so that the wait at
+    // the top of step i+2 lets everything step i+1 issues stay in flight
+    xa = buf_load(r_g, loff * 4, (unsigned)min(i + 2, T - 1) * (unsigned)(LG * 4));
+    if (LATW) ea = buf_load(r_e, vo_e, (unsigned)min(i + 1, T - 1) * (unsigned)(L * 4));
     PARRIVE(wave, i + 2, vA + h);                       // the encoder runs two steps ahead of the decoder's step index
     step_barrier();
   };
@@ -346,10 +369,8 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     const float z = gate_sum(&hb[T & 1][PKP * s], rb);
     float zv, klv;
     latent(z, (T & 1) ? eB : eA, zv, klv);
-    if (lat_ok) {
-      if (s < 2) hbd[(T + 1) & 1][zslot] = zv;
-      store_latent(T - 1, z, zv, klv);
-    }
+    if (lat_ok && s < 2) hbd[(T + 1) & 1][zslot] = zv;
+    store_latent(T - 1, z, zv, klv);
   }
   step_barrier();          // the decoder chain runs two steps behind
   step_barrier();
@@ -379,14 +400,15 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   }
   const size_t bt0 = (size_t)b * T;
   const unsigned loff = s * LH + u;
-  const float* const xp0 = a.xproj_d + bt0 * LG;
-  float* const g0 = a.gates_d + bt0 * LG;
-  float* const h0 = a.hs_d + bt0 * LH;
-  float* const a0 = a.aux_d + bt0 * 2 * LH;
+  const rsrc_t r_g = make_rsrc(a.gates_d + bt0 * LG, T * LG * 4);       // x_{t-1}.K_x in, k out (same buffer)
+  const rsrc_t r_h = make_rsrc(a.hs_d + bt0 * LH, T * LH * 4);
+  const rsrc_t r_a = make_rsrc(a.aux_d + bt0 * 2 * LH, T * 2 * LH * 4);
+  const unsigned vo_h = s == 0 ? u * 4 : BUF_OOB;
+  const unsigned vo_a = (s == 1 || s == 2) ? ((s - 1) * LH + u) * 4 : BUF_OOB;
   const float rb = a.rb_d[(size_t)b * LG + loff];
   const int hslot = pair_hslot(u);
   float c = 0.f;
-  float xA = HASXP ? xp0[loff] : 0.f, xB = HASXP ? xp0[(size_t)min(1, T - 1) * LG + loff] : 0.f;
+  float xA = HASXP ? buf_load(r_g, loff * 4, 0) : 0.f, xB = HASXP ? buf_load(r_g, loff * 4, min(1, T - 1) * LG * 4) : 0.f;
   prologue_loads_done();
   step_barrier();          // the encoder is two steps ahead
   step_barrier();
@@ -395,10 +417,10 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
 #ifdef PAIR_STAMPS
     unsigned long long pst[8];
 #endif
+    asm volatile("" : "+v"(xa));        // see the encoder
     const float xv = xa + rb;
     PSTAMP(0, xv);
     PTOP(xv);
-    if (HASXP) xa = (xp0 + (unsigned)min(t + 2, T - 1) * (unsigned)LG)[loff];
     f2 acc[4];       // (even k, odd k) partial sums
     acc[0] = (f2){xv, 0.f};
 #pragma unroll
@@ -422,9 +444,10 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     const float h = pair_cell<GATE>(sm, z, c, vA, act, kc);
     PSTAMP(5, h);
     hb[cur ^ 1][hslot] = h;
-    (g0 + (unsigned)t * (unsigned)LG)[loff] = vA;
-    if (s == 0) (h0 + (unsigned)t * (unsigned)LH)[u] = h;
-    if (s == 1 || s == 2) (a0 + (unsigned)t * (unsigned)(2 * LH))[(s - 1) * LH + u] = Sel4::pick(sm.m1, act, kc);
+    buf_store(vA, r_g, loff * 4, (unsigned)t * (unsigned)(LG * 4));
+    buf_store(h, r_h, vo_h, (unsigned)t * (unsigned)(LH * 4));
+    buf_store(Sel4::pick(sm.m1, act, kc), r_a, vo_a, (unsigned)t * (unsigned)(2 * LH * 4));
+    if (HASXP) xa = buf_load(r_g, loff * 4, (unsigned)min(t + 2, T - 1) * (unsigned)(LG * 4));      // behind the stores: see the encoder
     PSTAMP(6, vA + h);
     PARRIVE(PNW + wave, t, vA + h);
     step_barrier();
@@ -536,28 +559,26 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   // dz_dec_{t+1}.
   struct Raw { float kq, kc, kcarry, dh, m, lv, e; };
   const unsigned col = q * LH + u;
-  float* const g0 = gates + rowbt * LG;
-  const float* const a0 = aux + rowbt * 2 * LH;
-  const float* const d0 = a.dhs_d + rowbt * LH;
-  const float* const z0 = a.zargs + rowbt * 2 * L;
-  const float* const e0 = a.eps + rowbt * L;
-  float* const dz0 = a.dzargs + rowbt * 2 * L;
+  const rsrc_t r_g = make_rsrc(gates + rowbt * LG, T * LG * 4);              // k in, dz out
+  const rsrc_t r_a = make_rsrc(aux + rowbt * 2 * LH, T * 2 * LH * 4);
+  const rsrc_t r_d = make_rsrc(a.dhs_d + rowbt * LH, T * LH * 4);
+  const rsrc_t r_za = make_rsrc(a.zargs + rowbt * 2 * L, T * 2 * L * 4);
+  const rsrc_t r_e = make_rsrc(a.eps + rowbt * L, T * L * 4);
+  const rsrc_t r_dz = make_rsrc(a.dzargs + rowbt * 2 * L, T * 2 * L * 4);
+  const unsigned vo_g = zgroup ? BUF_OOB : col * 4;                            // dz store (latent groups: none)
+  const unsigned vo_m = zlane ? lat * 4 : BUF_OOB, vo_lv = zlane ? (L + lat) * 4 : BUF_OOB;
   const float hk = 0.5f * a.kl_scale;
   auto load_raw = [&](int tr, Raw& r) {
     const unsigned t = (unsigned)max(tr, 0);
-    r.kq = (g0 + t * (unsigned)LG)[col];
-    const float* ar = a0 + t * (unsigned)(2 * LH);
-    r.kcarry = ar[u];
-    r.kc = ar[LH + u];
-    if (DEC) r.dh = (d0 + t * (unsigned)LH)[u];
-    if (LATW) {
+    r.kq = buf_load(r_g, col * 4, t * (unsigned)(LG * 4));
+    r.kcarry = buf_load(r_a, u * 4, t * (unsigned)(2 * LH * 4));
+    r.kc = buf_load(r_a, (LH + u) * 4, t * (unsigned)(2 * LH * 4));
+    if (DEC) r.dh = buf_load(r_d, u * 4, t * (unsigned)(LH * 4));
+    if (LATW) {                    // lanes without a latent read beyond num_records: 0
       const unsigned tz = (unsigned)min(max(tr + 1, 0), T - 1);
-      if (zlane) {
-        const float* zr = z0 + tz * (unsigned)(2 * L);
-        r.m = zr[lat];
-        r.lv = zr[L + lat];
-        r.e = (e0 + tz * (unsigned)L)[lat];
-      }
+      r.m = buf_load(r_za, vo_m, tz * (unsigned)(2 * L * 4));
+      r.lv = buf_load(r_za, vo_lv, tz * (unsigned)(2 * L * 4));
+      r.e = buf_load(r_e, vo_m, tz * (unsigned)(L * 4));
     }
   };
   // Two register sets, the loop body is two steps: the values of step t are requested at the end of iteration t+2
@@ -571,6 +592,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
 
   // LDS slot: regular lanes: dz of gate q (4 replicas share the 4 gates); latent lanes: their dzargs column
   const int lpos = zgroup ? q * L + lat : BW_CP * ((int)col / BW_CW) + (int)col % BW_CW;
+  const unsigned vo_dz = zlive ? (unsigned)lpos * 4 : BUF_OOB;
 
   auto matvec = [&](const float* dzs) {        // reduce-scattered: this lane's unit (or latent) total
     const float4* dp = reinterpret_cast<const float4*>(dzs + BW_CP * cs);
@@ -628,16 +650,12 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     const float val = Sel4::pick(m_q3, dh, dc) * k.kq;      // dz_o = dh ko; dz_{i,f,g} = dc k
     dc = dc * k.kcarry;
     zsum += val;
-    if (!zgroup) {
-      dzb[cur ^ 1][lpos] = val;
-      (g0 + (unsigned)t * (unsigned)LG)[col] = val;
-    }
+    if (!zgroup) dzb[cur ^ 1][lpos] = val;
+    buf_store(val, r_g, vo_g, (unsigned)t * (unsigned)(LG * 4));
     if (LATW) {                       // latent lanes turn dZ_{t+1} into dzargs_{t+1}
-      if (zlive) {
-        const float zv = latent_dz(k, dhrec);
-        dza[cur][lpos] = zv;
-        (dz0 + (unsigned)min(t + 1, T - 1) * (unsigned)(2 * L))[lpos] = zv;      // i == 0: garbage into row T-1, rewritten at i == 1
-      }
+      const float zv = latent_dz(k, dhrec);
+      if (zlive) dza[cur][lpos] = zv;
+      buf_store(zv, r_dz, vo_dz, (unsigned)min(t + 1, T - 1) * (unsigned)(2 * L * 4));      // i == 0: garbage into row T-1, rewritten at i == 1
     }
     load_raw(t - 2, k);
     step_barrier();
@@ -652,11 +670,9 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     // iteration T: dZ_0 -> dzargs_0
     if (LATW) {
       const float dZ = matvec(dzb[T & 1]);
-      if (zlive) {
-        const float zv = latent_dz((T & 1) ? rB : rA, dZ);      // the set reloaded last holds load_raw(-1): step 0
-        dz0[lpos] = zv;
-        dza[T & 1][lpos] = zv;
-      }
+      const float zv = latent_dz((T & 1) ? rB : rA, dZ);      // the set reloaded last holds load_raw(-1): step 0
+      buf_store(zv, r_dz, vo_dz, 0);
+      if (zlive) dza[T & 1][lpos] = zv;
     }
     step_barrier();
     step_barrier();
