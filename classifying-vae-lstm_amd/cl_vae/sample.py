@@ -63,8 +63,9 @@ def make_sample(P, dec_model, w_enc_model, z_enc_model, args, margs):
 
 
 def on_device(args):
-    """Where the frame loop runs: on the device for several samples (or --device_loop), else like the reference."""
-    return getattr(args, 'device_loop', False) or (args.n > 1 and not getattr(args, 'host_loop', False))
+    """Where the frame loop runs: like the reference (host loop, np.random) for every -n unless --device_loop asks for
+    the device-side loop (Philox noise: other samples for the same np.random.seed, so it is opt-in)."""
+    return bool(getattr(args, 'device_loop', False)) and not getattr(args, 'host_loop', False)
 
 
 def sample(args):

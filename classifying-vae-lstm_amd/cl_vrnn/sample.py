@@ -54,7 +54,8 @@ def sample(args):
     dec = M.make_decoder(model, margs['original_dim'], margs['intermediate_dim'], margs['latent_dim'],
                          margs['n_classes'], margs['use_x_prev'])
     P = PianoData(args.train_file, batch_size=1, seq_length=args.t, squeeze_x=False)
-    on_device = getattr(args, 'device_loop', False) or (args.n > 1 and not getattr(args, 'host_loop', False))
+    # the reference's host loop (np.random) for every -n; --device_loop opts into the device-side loop (Philox noise)
+    on_device = bool(getattr(args, 'device_loop', False)) and not getattr(args, 'host_loop', False)
     return gen_samples(P, dec, w_enc, z_enc, args, margs, model=model if on_device else None)
 
 

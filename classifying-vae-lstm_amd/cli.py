@@ -86,8 +86,8 @@ BF16_FLAGS = [
 ]
 
 DEVICE_LOOP_FLAGS = [
-    Flag(('--device_loop',), ON, False, 'generate all -n samples in one device-side frame loop (Philox noise)'),
-    Flag(('--host_loop',), ON, False, 'frame loop on the host with np.random, like the reference (default for -n 1)'),
+    Flag(('--device_loop',), ON, False, 'generate all -n samples in one device-side frame loop (Philox noise; opt-in: the default is the reference host loop)'),
+    Flag(('--host_loop',), ON, False, 'frame loop on the host with np.random, like the reference (the default; overrides --device_loop)'),
     Flag(('--seed',), int, 0, 'noise key of the device-side loop'),
 ]
 

@@ -51,6 +51,17 @@ inline int env_int(const char* name, int dflt) {
 // from several host threads and for a process that drives more than one GPU.  Returns a hipError_t / CLV_OK.
 int allow_dynamic_lds(const void* kernel, int bytes);
 
+// ---- Bernoulli NLL clip (cl_vae/model.py:190-191, cl_vrnn/model.py:241-242: keras.losses.binary_crossentropy) -------
+// Keras clips p = sigmoid(a) to [eps, 1 - eps] and takes log(p / (1 - p)); on the logits that is a clip of a, gradient 0
+// outside.  The comparand is the FLOAT32 Keras path: float32(1 - 1e-7) is 1 - 2^-23, so the upper end is
+// log((1 - 2^-23) / 2^-23) = log(2^23 - 1) = 15.942385, while the lower end stays log(1e-7 / (1 - 1e-7)) = -16.118095 (as
+// float32 evaluates it).  -DCLV_BCE_SYMMETRIC_CLIP builds the exact-arithmetic form (+-16.118095) instead.
+#ifdef CLV_BCE_SYMMETRIC_CLIP
+constexpr float BCE_CLIP_LO = -16.11809555f, BCE_CLIP_HI = 16.11809555f;
+#else
+constexpr float BCE_CLIP_LO = -16.11809555f, BCE_CLIP_HI = 15.94238503f;
+#endif
+
 // ---- device math ------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

@@ -482,7 +482,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
     // logits -> Bernoulli NLL with Keras' epsilon clip (same arithmetic as bernoulli_nll_kernel).  One n-tile and
     // WAVES_N == 1 (host-checked): a row's columns sit in this wave, 16 lanes x WN tiles, so the row sum is
     // WN register adds and a 16-lane butterfly.
-    constexpr float CLIP = 16.11809555f;     // log((1-1e-7)/1e-7)
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -496,12 +495,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_kernel(GemmArgs g) {
             float a = acc[i][j][reg] * g.alpha;
             if (g.bias) a += g.bias[col];
             const float t = g.bce_y[(size_t)row * g.bce_ldy + col];
-            const float l = fminf(fmaxf(a, -CLIP), CLIP);
+            const float l = fminf(fmaxf(a, BCE_CLIP_LO), BCE_CLIP_HI);
             const float e = __expf(-fabsf(l));
             s += fmaxf(l, 0.f) + __logf(1.f + e) - l * t;
             const float r1 = fast_rcp(1.f + e);
             const float sg = l >= 0.f ? r1 : e * r1;
-            const bool inside = (a >= -CLIP) && (a <= CLIP);
+            const bool inside = (a >= BCE_CLIP_LO) && (a <= BCE_CLIP_HI);
             const size_t o = (size_t)row * ldc + col;
             if (Cptr) Cptr[o] = a;
             if (g.bce_dl) g.bce_dl[o] = inside ? g.bce_scale * (sg - t) : 0.f;

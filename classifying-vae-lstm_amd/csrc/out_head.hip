@@ -70,7 +70,6 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
   }
   float* myhs = hsT + wave * OH_TILE;
   float* mydl = dlT + wave * OH_TILE;
-  constexpr float CLIP = 16.11809555f;     // log((1-1e-7)/1e-7)
 
   // this wave's 16 rows of hs are one contiguous 5.6 KB piece of HBM: 6 float4 per lane
   float4 hv[6];
@@ -172,12 +171,12 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
         const bool ok = rok && col < OH;
         const float lg = acc[j][reg] + bias[j];
         const float t = y[j][reg];
-        const float l = fminf(fmaxf(lg, -CLIP), CLIP);
+        const float l = fminf(fmaxf(lg, BCE_CLIP_LO), BCE_CLIP_HI);
         const float e = __expf(-fabsf(l));
         const float nl = fmaxf(l, 0.f) + __logf(1.f + e) - l * t;
         const float r1 = fast_rcp(1.f + e);
         const float sg = l >= 0.f ? r1 : e * r1;
-        const bool inside = (lg >= -CLIP) && (lg <= CLIP);
+        const bool inside = (lg >= BCE_CLIP_LO) && (lg <= BCE_CLIP_HI);
         const float dl = (ok && inside) ? a.scale * (sg - t) : 0.f;
         ssum += ok ? nl : 0.f;
         mydl[(4 * q + reg) * OH_LD + col] = dl;

@@ -10,7 +10,6 @@ namespace clv {
 
 constexpr float EPS_K = 1e-7f;                 // keras.backend._EPSILON
 constexpr float W2_SHIFT = 1e-10f;             // cl_vae/model.py:208
-constexpr float LOGIT_CLIP = 16.11809555f;     // log((1-1e-7)/1e-7)
 constexpr int MAXC = 32;
 
 // ------------------------------------------------------------------ label --
@@ -142,13 +141,13 @@ __global__ __launch_bounds__(256) void bernoulli_nll_kernel(int R, int D, const 
   for (int j = lane; j < D; j += 64) {
     const float a = logits[(size_t)row * D + j];
     const float t = y[(size_t)row * ldy + j];
-    const float l = fminf(fmaxf(a, -LOGIT_CLIP), LOGIT_CLIP);
+    const float l = fminf(fmaxf(a, BCE_CLIP_LO), BCE_CLIP_HI);
     // softplus(l) = max(l,0) + log(1 + e^-|l|); e = e^-|l| in (1e-7, 1] so 1+e is exact enough for v_log_f32
     const float e = __expf(-fabsf(l));
     const float sp = fmaxf(l, 0.f) + __logf(1.f + e);
     acc += sp - l * t;
     if (dlogits) {
-      const bool inside = (a >= -LOGIT_CLIP) && (a <= LOGIT_CLIP);
+      const bool inside = (a >= BCE_CLIP_LO) && (a <= BCE_CLIP_HI);
       const float r1 = fast_rcp(1.f + e);
       const float sg = l >= 0.f ? r1 : e * r1;          // sigmoid(l) from the same exponential
       dlogits[(size_t)row * D + j] = inside ? scale * (sg - t) : 0.f;

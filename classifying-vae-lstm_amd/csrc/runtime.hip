@@ -15,15 +15,16 @@ namespace clv {
 
 int allow_dynamic_lds(const void* kernel, int bytes) {
   static std::mutex mu;
-  static std::set<std::pair<int, const void*>> done;
+  static std::map<std::pair<int, const void*>, int> granted;      // largest size set so far per (device, kernel)
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   std::lock_guard<std::mutex> lock(mu);
-  if (done.count({dev, kernel})) return CLV_OK;
+  auto it = granted.find({dev, kernel});
+  if (it != granted.end() && it->second >= bytes) return CLV_OK;
   e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return (int)e;
-  done.insert({dev, kernel});
+  granted[{dev, kernel}] = bytes;
   return CLV_OK;
 }
 

@@ -53,7 +53,7 @@ constexpr int VL = 132;    // LDS row stride of every buffer: == 4 mod 64, so th
 constexpr int VNW = 8;     // waves per workgroup: one 16-column tile of an 88-wide layer per wave
 constexpr int VNT = VNW * 64;
 constexpr int VNSTAGE = 12;
-constexpr float VEPS_K = 1e-7f, VW2 = 1e-10f, VLOGIT_CLIP = 16.11809555f;
+constexpr float VEPS_K = 1e-7f, VW2 = 1e-10f;
 
 // One stage of the graph.  Product: out = epilogue(A[16 x K] . B), A in LDS, B(k, c) = W[k*ldw + c] or, with VF_NT,
 // W[c*ldw + k] (the backward product DY . W^T).  VF_PAIR: waves 0 and 1 compute two separate narrow products of the
@@ -445,12 +445,12 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
           const float t = a.y ? lds[M.G2 + r * VL + j] : lds[M.XC + r * VL + j];
           if (a.y) lds[M.G2 + r * VL + j] = 0.f;          // G2 is a zero-padded product operand again
           if (r < nvalid && a.logits) a.logits[(size_t)(row0 + r) * D + j] = av;
-          const float l = fminf(fmaxf(av, -VLOGIT_CLIP), VLOGIT_CLIP);
+          const float l = fminf(fmaxf(av, BCE_CLIP_LO), BCE_CLIP_HI);
           const float e = __expf(-fabsf(l));
           acc += fmaxf(l, 0.f) + __logf(1.f + e) - l * t;
           const float r1 = fast_rcp(1.f + e);
           const float sg = l >= 0.f ? r1 : e * r1;
-          const bool inside = (av >= -VLOGIT_CLIP) && (av <= VLOGIT_CLIP);
+          const bool inside = (av >= BCE_CLIP_LO) && (av <= BCE_CLIP_HI);
           lds[M.LG + r * VL + j] = (inside && r < nvalid) ? inv_b * (sg - t) : 0.f;
         }
         acc = wave_sum(acc);

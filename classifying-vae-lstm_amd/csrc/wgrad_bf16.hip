@@ -137,6 +137,8 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
     // LDS image.  Only the last slot of each kind can lie beyond the tile (its load is clamped, its store skipped).
     const int pt = tid - NP_T;
     constexpr int DZ_L = 6, A_L = 3, Z_L = HM == 8 ? 4 : 1;
+    static_assert(A_L * NP_T >= WB_KS * (96 / 4), "h / x slots: 32 rows x 96 columns (clv_lstm_wgrad_supported: nh, nx <= 96)");
+    static_assert(Z_L * NP_T >= WB_KS * (HM == 8 ? 32 : 8), "z slots: 32 rows x 8 (32) latent columns (wgrad_wide)");
     const int nh4 = a.nh / 4, nx4 = a.nx / 4;
     unsigned dz_g[DZ_L], h_g[A_L], x_g[A_L], z_g[Z_L];
     int dz_l[DZ_L], h_l[A_L], x_l[A_L], z_l[Z_L];          // LDS offsets; bit 30: row 0 of the stage (h), bit 31: idle slot
@@ -347,10 +349,16 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
 
 }  // namespace clv
 
+// The producers' slot tables cover 32 rows x 96 columns of h and of x (A_L = 3 float4 slots per thread) and 32 x 8 z
+// scalars in the 6-row-tile kernel, 32 x 32 in the 8-row-tile one: the wide kernel is taken when [h | z] needs more
+// than 96 image columns OR more than 8 latent columns.
+static bool wgrad_wide(int nh, int nz) { return nh + nz > 96 || nz > 8; }
+
 extern "C" int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16) {
-  if (!(N == 352 && nx > 0 && nx <= 96 && nx % 4 == 0 && nh > 0 && nh % 4 == 0 && nz >= 0 && nh + nz <= 128 && nz <= 32))
+  if (!(N == 352 && nx > 0 && nx <= 96 && nx % 4 == 0 && nh > 0 && nh <= 96 && nh % 4 == 0 && nz >= 0 && nz <= 32 &&
+        nh + nz <= 128))
     return 0;
-  return nh + nz <= 96 || x_exact_bf16;        // 8 h row tiles and three x pieces do not fit the LDS together
+  return !wgrad_wide(nh, nz) || x_exact_bf16;        // 8 h row tiles and three x pieces do not fit the LDS together
 }
 
 static int wgrad_splits(int K) {
@@ -380,7 +388,7 @@ extern "C" int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int
   int kc = (K + 127) / 128;
   kc = (kc + 31) / 32 * 32;
   WgradArgs a{K, N, kc, X, ldx, nx, H, ldh, nh, h_shift, h_zero_period, Z, ldz, nz, dz, lddz, (float*)ws};
-  const bool wide = nh + nz > 96;
+  const bool wide = wgrad_wide(nh, nz);
   {
     ProfScope p("lstm_wgrad_bf16", s);
     dim3 grid(splits, N / WB_NC);

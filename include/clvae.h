@@ -126,8 +126,9 @@ int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const f
  * rate).  x_exact_bf16 != 0 promises that every X value is exactly representable in bf16 (0/1 piano-roll frames, any
  * uint8): those rows then need one piece.  The products leave as split-K slabs: ws >= clv_lstm_wgrad_workspace_bytes,
  * and like the *_deferred GEMMs the final sums (C = beta*C + sum) are formed by the reduction, now (job == NULL) or by
- * clv_splitk_reduce_multi.  Limits (clv_lstm_wgrad_supported): N == 352; nx <= 96, nh + nz <= 128, nz <= 32; nx, nh,
- * ldx, ldh, lddz multiples of 4, 16-byte aligned bases; more than 96 rows of H and Z together need x_exact_bf16. */
+ * clv_splitk_reduce_multi.  Limits (clv_lstm_wgrad_supported): N == 352; nx <= 96, nh <= 96, nz <= 32; nx, nh,
+ * ldx, ldh, lddz multiples of 4, 16-byte aligned bases; more than 96 rows of H and Z together, or more than 8 rows
+ * of Z, need x_exact_bf16 (the wide form of the kernel has no room for three pieces of X). */
 int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16);
 size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz);
 int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
@@ -354,8 +355,10 @@ int clv_gauss_bwd(int R, int L, const float* zargs, const float* eps, const floa
                   float kl_scale, float* dzargs, void* stream);
 
 /* Bernoulli NLL on logits with Keras' epsilon-clip semantics (A.3), one wave per row:
- * rownll[R] = sum_j softplus(l) - l*y, l = clip(a, +-log((1-1e-7)/1e-7));
- * dlogits[R,D] = scale * (sigmoid(l) - y) * [|a| <= clip]   (dlogits may alias logits,
+ * rownll[R] = sum_j softplus(l) - l*y, l = clip(a, -16.118095, +15.942385): the logits at which the FLOAT32 Keras
+ * path clips p = sigmoid(a) to [float32(1e-7), float32(1 - 1e-7) = 1 - 2^-23] (the upper point is log(2^23 - 1); a
+ * library built with -DCLV_BCE_SYMMETRIC_CLIP uses the exact-arithmetic +-log((1-1e-7)/1e-7) = +-16.118095 instead);
+ * dlogits[R,D] = scale * (sigmoid(l) - y) * [a inside the clip]   (dlogits may alias logits,
  * or be NULL for loss only).  cl_vae/model.py:190-191; cl_vrnn/model.py:241-242. */
 int clv_bernoulli_nll(int R, int D, const float* logits, const float* y, int ldy, float scale,
                       float* rownll, float* dlogits, void* stream);

@@ -66,10 +66,19 @@ def orthogonal(rng, shape, dtype):
 # --------------------------------------------------------------------------- #
 # losses (Keras semantics, Appendix A.3)
 # --------------------------------------------------------------------------- #
-LOGIT_CLIP_HI = float(np.log((1.0 - EPS_K) / EPS_K))   # 16.118095...
+# The comparand is the FLOAT32 Keras path (cl_vae/model.py:190-191, cl_vrnn/model.py:241-242): there
+# p = clip(sigmoid(a), float32(1e-7), float32(1 - 1e-7)) and float32(1 - 1e-7) = 1 - 2^-23, so
+#   upper logit clip = log((1 - 2^-23) / 2^-23) = log(2^23 - 1) = 15.942385
+#   lower logit clip = log(float32(1e-7) / float32(1 - 1e-7)) = -16.118095  (as float32 evaluates the quotient)
+# LOGIT_CLIP_EXACT is the exact-arithmetic (float64 Keras) form, +-log((1 - 1e-7) / 1e-7).
+LOGIT_CLIP_EXACT = float(np.log((1.0 - EPS_K) / EPS_K))   # 16.118095...
+_p_hi = np.float32(1.0) - np.float32(EPS_K)
+_p_lo = np.float32(EPS_K)
+LOGIT_CLIP_HI = float(np.log(np.float64(_p_hi / (np.float32(1.0) - _p_hi))))      # 15.942385...
+LOGIT_CLIP_LO = float(np.log(np.float64(_p_lo / (np.float32(1.0) - _p_lo))))      # -16.118095...
 
 
-def bce_from_logits_keras(a, y):
+def bce_from_logits_keras(a, y, clip='float32'):
     """sum_j binary_crossentropy with the Keras clip, expressed on the logits.
 
     Keras: p = clip(sigmoid(a), eps, 1-eps); l = log(p/(1-p));
@@ -78,12 +87,15 @@ def bce_from_logits_keras(a, y):
     Lc = log((1-eps)/eps), so the loss is softplus(l) - l*y on l = clip(a).
     Restates vae_loss = original_dim * mean_j(...) = sum_j(...)
     (cl_vae/model.py:190-191, cl_vrnn/model.py:241-242).
+    clip='float32' (default): the clip points of the float32 Keras path (asymmetric, see above);
+    clip='exact': +-log((1-eps)/eps).
     Returns (per-row loss summed over the last axis, dloss/da elementwise).
     """
-    l = np.clip(a, -LOGIT_CLIP_HI, LOGIT_CLIP_HI)
+    lo, hi = (LOGIT_CLIP_LO, LOGIT_CLIP_HI) if clip == 'float32' else (-LOGIT_CLIP_EXACT, LOGIT_CLIP_EXACT)
+    l = np.clip(a, lo, hi)
     sp = np.maximum(l, 0) + np.log1p(np.exp(-np.abs(l)))
     loss = (sp - l * y).sum(axis=-1)
-    inside = (a >= -LOGIT_CLIP_HI) & (a <= LOGIT_CLIP_HI)
+    inside = (a >= lo) & (a <= hi)
     grad = np.where(inside, sigmoid(l) - y, 0.0).astype(a.dtype)
     return loss, grad
 

@@ -22,7 +22,7 @@ def hard_sigmoid(z):
 
 def bce_keras(a, y):
     """Keras binary_crossentropy summed over the notes, on logits with the epsilon clip (A.3)"""
-    l = torch.clamp(a, -O.LOGIT_CLIP_HI, O.LOGIT_CLIP_HI)
+    l = torch.clamp(a, O.LOGIT_CLIP_LO, O.LOGIT_CLIP_HI)
     return (torch.clamp(l, min=0) - l * y + torch.log1p(torch.exp(-l.abs()))).sum(-1)
 
 

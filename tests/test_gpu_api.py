@@ -259,6 +259,15 @@ def test_cl_vae_cli_train_then_sample(dev, tmp_path):
     sargs = _ns(S.build_parser(), ['inf', '--infer_w', '--use_z_prior', '-t', '4', '-i', os.path.join(mdir, 'run1.h5'),
                                    '--train_file', data, '--sample_dir', sdir])
     assert S.sample(sargs)[0].shape == (4, 88)
+    # the device-side frame loop is opt-in (--device_loop; the default for every -n is the reference's host loop)
+    from clvae_amd.cli import DEVICE_LOOP_FLAGS, parser_for
+    assert not S.on_device(sargs)
+    dargs = _ns(parser_for('cl_vae.sample', DEVICE_LOOP_FLAGS), ['dev', '-n', '3', '-t', '8', '--device_loop', '--seed', '5', '-i',
+                                                                   os.path.join(mdir, 'run1.h5'), '--train_file', data,
+                                                                   '--sample_dir', sdir])
+    assert S.on_device(dargs)
+    dsamples = S.sample(dargs)
+    assert len(dsamples) == 3 and dsamples[0].shape == (8, 88) and set(np.unique(dsamples[0])) <= {0.0, 1.0}
 
 
 def test_cl_vrnn_cli_train_then_sample(dev, tmp_path):
@@ -282,6 +291,12 @@ def test_cl_vrnn_cli_train_then_sample(dev, tmp_path):
     sargs = _ns(S.build_parser(), ['h', '--infer_w', '--discrete_w', '-t', '8', '-i', os.path.join(mdir, 'r2.h5'),
                                    '--train_file', data, '--sample_dir', sdir])
     assert S.sample(sargs)[0].shape == (8, 88)
+    from clvae_amd.cli import DEVICE_LOOP_FLAGS, parser_for
+    dargs = _ns(parser_for('cl_vrnn.sample', DEVICE_LOOP_FLAGS), ['d', '-n', '3', '-t', '8', '--device_loop', '-i',
+                                                                    os.path.join(mdir, 'r2.h5'), '--train_file', data,
+                                                                    '--sample_dir', sdir])
+    dout = S.sample(dargs)
+    assert len(dout) == 3 and dout[0].shape == (8, 88) and set(np.unique(dout[0])) <= {0.0, 1.0}
 
 
 def test_device_generation_matches_stepwise_oracle(dev):

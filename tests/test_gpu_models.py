@@ -181,14 +181,19 @@ def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate, pair):
         np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("exact_frames", [False, True])
 @pytest.mark.parametrize("B,Tn,L", [(256, 128, 2),         # BASELINE config 3 (and 4 per GPU): what bench.py times
                                     (1024, 256, 32)])      # config 5 per GPU
-def test_cl_vrnn_full_size_step_matches_oracle(dev, B, Tn, L):
+def test_cl_vrnn_full_size_step_matches_oracle(dev, B, Tn, L, exact_frames):
     """One step at the sizes the benchmark runs, against the fp64 oracle on the same weights, frames and noise: ELBO
-    and every loss term to 1e-3, per-note logits, both LSTMs' states, every gradient tensor."""
+    and every loss term to 1e-3, per-note logits, both LSTMs' states, every gradient tensor.
+    exact_frames: what the bench and `fit()` on a uint8 data set run -- the frames are 0/1 bytes, so the engine is told
+    that every frame value is exactly a bf16 number and the LSTM kernel gradients take the one-piece variants of the
+    split-bf16 product (lstm_wgrad_bf16_kernel<6,1> at 256 x 128, <8,1> at 1024 x 256) inside the whole step."""
     from clvae_amd.engine import VrnnEngine
     Cn = 10
     cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    cfg['frames_exact_bf16'] = exact_frames
     rng = np.random.default_rng(B + Tn)
     p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=3).items()}
     win = frames(rng, B, Tn + 1, 88)
@@ -198,6 +203,8 @@ def test_cl_vrnn_full_size_step_matches_oracle(dev, B, Tn, L):
     ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
     eng = VrnnEngine(cfg, B, dev)
     assert eng.fuse_pair == (L <= 8)
+    assert eng.frames_exact_bf16 == exact_frames and eng.bf16_wgrad
+    assert set(np.unique(X)) <= {0.0, 1.0}                  # byte-valued frames: exact in one bf16 piece
     eng.P.set_weights(p)
     eng.loss_and_grads(T(X, dev), T(Xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev))
     torch.cuda.synchronize()

@@ -289,6 +289,48 @@ def test_label_gauss_bernoulli(dev):
     np.testing.assert_allclose(N(dl), 0.5 * g_ref, atol=2e-6)
 
 
+def test_bce_clip_points_are_those_of_float32_keras(dev):
+    """keras.losses.binary_crossentropy in float32 (cl_vae/model.py:190-191, cl_vrnn/model.py:241-242) clips sigmoid(a) to
+    [float32(1e-7), float32(1 - 1e-7)] = [1e-7, 1 - 2^-23]: on the logits the UPPER clip is log(2^23 - 1) = 15.942385, the
+    lower one -16.118095.  Logits on both sides of both points, through every kernel that carries the loss: the
+    stand-alone NLL, the GEMM epilogue and the fused output head."""
+    from clvae_amd import ops
+    assert abs(O.LOGIT_CLIP_HI - 15.942385) < 1e-6 and abs(O.LOGIT_CLIP_LO + 16.118095) < 1e-6
+    pts = np.array([15.9, 15.94, 15.95, 16.0, 16.1, 16.2, 30.0, -15.95, -16.0, -16.1, -16.12, -16.2, -30.0, 0.0, 3.0, -3.0])
+    D = 88
+    a = np.zeros((2, D))
+    a[0, :pts.size] = pts
+    a[1, :pts.size] = pts
+    y = np.zeros((2, D)); y[1] = 1.0                      # both targets at every point
+    loss_ref, g_ref = O.bce_from_logits_keras(a, y)
+    # the exact-arithmetic form differs exactly where the logit lies between the two upper clip points
+    _, g_sym = O.bce_from_logits_keras(a, y, clip='exact')
+    differs = (g_ref != g_sym)
+    assert differs[:, :pts.size].any() and not differs[:, pts.size:].any()
+    assert set(pts[differs[0, :pts.size]]) == {15.95, 16.0, 16.1}
+    nll = torch.empty(2, device=dev); dl = torch.empty(2, D, device=dev)
+    ops.bernoulli_nll(2, D, T(a, dev), T(y, dev), D, 1.0, nll, dl)
+    np.testing.assert_allclose(N(nll), loss_ref, rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(N(dl), g_ref, atol=2e-7)
+    # the same logits out of a product: hs = e_0 row selector, Wo row 0 = the points (bias 0)
+    H = 88
+    hs = np.zeros((2, H)); hs[:, 0] = 1.0
+    Wo = np.zeros((H, D)); Wo[0, :pts.size] = pts
+    bo = np.zeros(D)
+    lg2 = torch.empty(2, D, device=dev); dl2 = torch.empty(2, D, device=dev); rn2 = torch.empty(2, device=dev)
+    ops.gemm_bce(T(hs, dev), T(Wo, dev), T(bo, dev), T(y, dev), 1.0, lg2, dl2, rn2, 2, D, H)
+    np.testing.assert_allclose(N(rn2), loss_ref, rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(N(dl2), g_ref, atol=2e-7)
+    ws = ops.Workspace(dev)
+    rn3 = torch.empty(2, device=dev); dhs = torch.empty(2, H, device=dev)
+    dWo = torch.empty(H, D, device=dev); dbo = torch.empty(D, device=dev); dl3 = torch.empty(2, D, device=dev)
+    ops.out_head_train(2, H, D, T(hs, dev), T(Wo, dev), T(bo, dev), T(y, dev), 1.0, rn3, dhs, dWo, dbo, ws, dlogits=dl3)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(rn3), loss_ref, rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(N(dl3), g_ref, atol=2e-7)
+    np.testing.assert_allclose(N(dbo), g_ref.sum(0), atol=4e-7)
+
+
 @pytest.mark.parametrize("weightnorm", [True, False])
 def test_adam_wn_three_steps(dev, weightnorm):
     from clvae_amd.engine import FlatParams
@@ -573,10 +615,9 @@ def test_out_head_train_matches_numpy(dev, R, defer, store):
         rq.flush()
     torch.cuda.synchronize()
     a = hs.astype(np.float64) @ Wo.astype(np.float64) + bo
-    clip = np.log((1 - 1e-7) / 1e-7)
-    l = np.clip(a, -clip, clip)
+    l = np.clip(a, O.LOGIT_CLIP_LO, O.LOGIT_CLIP_HI)          # the float32 Keras clip points (asymmetric)
     nll = (np.maximum(l, 0) + np.log1p(np.exp(-np.abs(l))) - l * Y).sum(1)
-    dlr = scale * (1 / (1 + np.exp(-l)) - Y) * (np.abs(a) <= clip)
+    dlr = scale * (1 / (1 + np.exp(-l)) - Y) * ((a >= O.LOGIT_CLIP_LO) & (a <= O.LOGIT_CLIP_HI))
     np.testing.assert_allclose(N(rownll), nll, rtol=2e-5, atol=2e-4)
     if store:
         np.testing.assert_allclose(N(logits), a, rtol=1e-5, atol=2e-4)
@@ -606,16 +647,21 @@ def test_sparse_proj2_matches_two_single_launches(dev):
     np.testing.assert_allclose(o[1].cpu().numpy(), Xb[:, :70].astype(np.float64) @ Kb, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("K,Tn,nz,exact,defer", [(4096, 128, 0, True, False), (4096, 64, 2, True, True),
-                                                 (1000, 8, 8, False, False), (333 * 3, 3, 2, False, True),
-                                                 (32768, 128, 2, True, True), (8192, 256, 32, True, False),
-                                                 (96, 96, 0, False, False)])
-def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer):
+@pytest.mark.parametrize("K,Tn,nz,exact,defer,nh", [(4096, 128, 0, True, False, 88), (4096, 64, 2, True, True, 88),
+                                                    (1000, 8, 8, False, False, 88), (333 * 3, 3, 2, False, True, 88),
+                                                    (32768, 128, 2, True, True, 88), (8192, 256, 32, True, False, 88),
+                                                    (96, 96, 0, False, False, 88),
+                                                    # other hidden sizes: every slot table of the producers is exercised
+                                                    (2048, 32, 32, True, False, 64),      # nh + nz = 96 but nz > 8: wide kernel
+                                                    (2048, 32, 8, False, True, 64),       # 6-row-tile kernel, 8 latent columns
+                                                    (1024, 16, 32, True, False, 96),      # nh + nz = 128: the largest image
+                                                    (1024, 16, 0, False, False, 96)])
+def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer, nh):
     """clv_lstm_wgrad: dKx = X^T dz, dU = H'^T dz (h of the previous step, zero at window starts), dKz = Z^T dz as
     split-bf16 exact products; vs fp64 numpy.  The error is that of an fp32 summation (no product rounding at all)."""
     from clvae_amd import ops
     rng = np.random.default_rng(K + nz)
-    N, nx, nh = 352, 88, 88
+    N, nx = 352, 88
     ldx = 92 if nz else 88
     XZ = np.zeros((K, ldx), np.float32)
     XZ[:, :nx] = (rng.random((K, nx)) < 0.0443) if exact else rng.standard_normal((K, nx))
@@ -637,6 +683,8 @@ def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer):
     ws = ops.Workspace(dev)
     rq = ops.ReduceQueue(dev) if defer else None
     assert ops.lstm_wgrad_supported(N, nx, nh, nz, exact)
+    assert not ops.lstm_wgrad_supported(N, nx, 100, 0, True)              # h rows beyond the producers' slots
+    assert not ops.lstm_wgrad_supported(N, nx, 64, 32, False)             # nz > 8 needs the wide kernel, i.e. exact frames
     ops.lstm_wgrad(K, N, tXZ, ldx, nx, exact, ths, nh, nh, Tn, tZ if nz else None, ldz, nz, tdz, gx, gu,
                    gz if nz else None, ws, defer=rq)
     if defer:
