@@ -30,6 +30,11 @@ class VaeStepOpts(C.Structure):
 
 
 
+class NoiseDraw(C.Structure):
+    """clv_noise_draw (include/clvae.h): a kernel draws its own eps, the values of clv_philox_normal."""
+    _fields_ = [("seed", _u64), ("first", _u64), ("stream", _u32), ("step", _u32), ("step_dev", _p)]
+
+
 class ParamDesc(C.Structure):
     _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
@@ -81,7 +86,7 @@ SIGNATURES = {
     "clv_lstm_pair_supported": (_i, [_i, _i]),
     "clv_lstm_pair_pack_floats": (_sz, []),
     "clv_lstm_pair_pack": (_i, [_i, _i, _p, _p, _p, _p, _p, _p]),
-    "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 13),
     "clv_sparse_proj_supported": (_i, [_i, _i]),
     "clv_sparse_proj_lds_bytes": (_sz, [_i, _i]),
@@ -106,7 +111,7 @@ SIGNATURES = {
                                    _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                  _p]),
+                                  _p, _p]),
     "clv_vrnn_label_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "clv_gauss_fwd": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
     "clv_gauss_bwd": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p]),

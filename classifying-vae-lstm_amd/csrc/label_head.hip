@@ -8,6 +8,7 @@
 // Each of these is a handful of 88..352-long dot products per row: far too small for a GEMM launch
 // each (a launch costs ~5 us), so one workgroup does the whole chain for its row out of LDS.
 #include "common.h"
+#include "philox.h"
 
 namespace clv {
 
@@ -21,7 +22,8 @@ struct LabelFwdArgs {
   __device__ float* hW_out() const { return const_cast<float*>(hW); }
   const float* Ka;          // Wargs kernel [D, 2(C-1)]
   const float* ba;          // [2(C-1)]
-  const float* eps;         // [B,C-1]
+  float* eps;               // [B,C-1]: read, or drawn here and written (noise.on)
+  struct { int on; uint32_t k0, k1, stream, step; uint64_t first; const int32_t* step_dev; } noise;
   const float* onehot;      // [B,C] or null
   float prior;
   const float* Kenc_w;      // [C,G4] rows of the encoder kernel that multiply W
@@ -44,7 +46,17 @@ __device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int 
   __shared__ float s_eps[LH_MAXC], s_oh[LH_MAXC];
   if (tid >= NT - 64 && tid - (NT - 64) < a.C) {
     const int j = tid - (NT - 64);
-    s_eps[j] = j < C1 ? a.eps[(size_t)b * C1 + j] : 0.f;
+    float e = 0.f;
+    if (j < C1) {
+      if (a.noise.on) {          // the value clv_philox_normal writes for this element; kept for the backward pass
+        e = philox_normal_at(a.noise.first + (uint64_t)b * C1 + j, a.noise.k0, a.noise.k1, a.noise.stream,
+                             a.noise.step + (a.noise.step_dev ? (uint32_t)*a.noise.step_dev : 0u));
+        a.eps[(size_t)b * C1 + j] = e;
+      } else {
+        e = a.eps[(size_t)b * C1 + j];
+      }
+    }
+    s_eps[j] = e;
     s_oh[j] = a.onehot ? a.onehot[(size_t)b * a.C + j] : 0.f;
   }
   {
@@ -325,7 +337,8 @@ extern "C" int clv_vrnn_label_fwd(int B, int D, int C, int G4, const float* hW, 
   if (B <= 0 || D <= 0 || D > 128 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
   if (!hW || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss || !rb_enc || !rb_dec)
     return CLV_EINVAL;
-  LabelFwdArgs a{B, D, C, G4, hW, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec};
+  LabelFwdArgs a{B, D, C, G4, hW, Ka, ba, const_cast<float*>(eps), {0, 0, 0, 0, 0, 0, nullptr}, onehot, prior_logvar, Kenc_w, benc,
+                 Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("vrnn_label_fwd", s);
   hipLaunchKernelGGL(vrnn_label_fwd_kernel, dim3(B), dim3(LH_T), 0, s, a);
@@ -350,16 +363,22 @@ extern "C" int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsu
 
 extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
                                     const float* bh, float* hW_out, const float* Ka, const float* ba,
-                                    const float* eps, const float* onehot, float prior_logvar,
+                                    float* eps, const float* onehot, float prior_logvar,
                                     const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
-                                    float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec, void* stream) {
+                                    float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                                    const clv_noise_draw* noise, void* stream) {
   if (B <= 0 || D <= 0 || D > 128 || D % 2 != 0 || C < 2 || C > LH_MAXC || G4 <= 0 || nx <= 0 || ldx < nx) return CLV_EINVAL;
   if (!X || !Kh || !bh || !hW_out || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss ||
       !rb_enc || !rb_dec)
     return CLV_EINVAL;
   if (((uintptr_t)Kh) % 8 != 0) return CLV_EINVAL;
-  LabelFwdXArgs a{{B, D, C, G4, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc,
-                   rb_dec}, X, Kh, bh, nx, ldx};
+  LabelFwdXArgs a{{B, D, C, G4, hW_out, Ka, ba, eps, {0, 0, 0, 0, 0, 0, nullptr}, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec,
+                   wargs, W, rowloss, rb_enc, rb_dec}, X, Kh, bh, nx, ldx};
+  if (noise) {
+    a.l.noise.on = 1; a.l.noise.k0 = (uint32_t)noise->seed; a.l.noise.k1 = (uint32_t)(noise->seed >> 32);
+    a.l.noise.stream = noise->stream; a.l.noise.step = noise->step; a.l.noise.first = noise->first;
+    a.l.noise.step_dev = noise->step_dev;
+  }
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("vrnn_label_fwd", s);
   hipLaunchKernelGGL(vrnn_label_fwd_x_kernel, dim3(B), dim3(1024), 0, s, a);

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "lstm_common.h"
+#include "philox.h"
 
 namespace clv {
 
@@ -155,7 +156,8 @@ struct PairFwdArgs {
   const float* rb_d;
   const float* pack;      // weights in lane order (clv_lstm_pair_pack)
   const float* bz;        // [2L]
-  const float* eps;       // [B,T,L]
+  float* eps;             // [B,T,L]: read, or drawn in the kernel's prologue and written (noise.on)
+  struct { int on; uint32_t k0, k1, stream, step; uint64_t first; const int32_t* step_dev; } noise;
   float *hs_e, *aux_e, *gates_e, *hs_d, *aux_d, *gates_d;      // aux: [B*T, 2, 88] = (kcarry, kc)
   float* zargs;           // [B*T,2L]
   float* Z;               // [B*T] rows of stride ldz
@@ -475,6 +477,15 @@ __global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < 2 * 2 * PK * PKP; i += PNT) (&hbuf[0][0][0])[i] = 0.f;
+  if (a.noise.on) {
+    // this row's eps_z, the values clv_philox_normal writes at the row's global indices (a launch of its own was
+    // 5-6 us of a 450 us step); the latent lanes read them back from memory like given noise
+    const int n = a.T * a.L;
+    const uint32_t stp = a.noise.step + (a.noise.step_dev ? (uint32_t)*a.noise.step_dev : 0u);
+    const uint64_t first = a.noise.first + (uint64_t)blockIdx.x * n;
+    float* out = a.eps + (size_t)blockIdx.x * n;
+    for (int e = tid; e < n; e += PNT) out[e] = philox_normal_at(first + e, a.noise.k0, a.noise.k1, a.noise.stream, stp);
+  }
   __syncthreads();
   if (wave < PNW - 1) pair_fwd_encoder<GATE, false>(a, wave, lane, hbuf[0], hbuf[1]);
   else if (wave == PNW - 1) pair_fwd_encoder<GATE, true>(a, wave, lane, hbuf[0], hbuf[1]);
@@ -724,17 +735,22 @@ extern "C" int clv_lstm_pair_pack(int H, int L, const float* U_enc, const float*
 extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                                  float* gates_enc, const float* rowbias_enc,
                                  float* gates_dec, int dec_has_xproj, const float* rowbias_dec,
-                                 const float* pack, const float* bz, const float* eps,
+                                 const float* pack, const float* bz, float* eps,
                                  float* hs_enc, float* aux_enc, float* hs_dec, float* aux_dec,
-                                 float* zargs, float* Z, int ldz, float* klterm, void* stream) {
+                                 float* zargs, float* Z, int ldz, float* klterm, const clv_noise_draw* noise, void* stream) {
   using namespace clv;
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0 || ldz < L) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
   if (!gates_enc || !rowbias_enc || !gates_dec || !rowbias_dec || !pack || !bz || !eps ||
       !hs_enc || !aux_enc || !hs_dec || !aux_dec || !zargs || !Z || !klterm)
     return CLV_EINVAL;
-  PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, gates_dec, rowbias_dec, pack, bz, eps,
+  PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, gates_dec, rowbias_dec, pack, bz, eps, {0, 0, 0, 0, 0, 0, nullptr},
                 hs_enc, aux_enc, gates_enc, hs_dec, aux_dec, gates_dec, zargs, Z, klterm};
+  if (noise) {
+    a.noise.on = 1; a.noise.k0 = (uint32_t)noise->seed; a.noise.k1 = (uint32_t)(noise->seed >> 32);
+    a.noise.stream = noise->stream; a.noise.step = noise->step; a.noise.first = noise->first;
+    a.noise.step_dev = noise->step_dev;
+  }
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_fwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;

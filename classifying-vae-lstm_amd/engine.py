@@ -570,12 +570,26 @@ class VrnnEngine(_EngineBase):
         self.dwargs = _f(d, B, 2 * (Cn - 1))
         self.dhW = _f(d, B, D)
 
-    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None, target=None):
+    def folds_noise(self):
+        """True when forward(noise=...) draws eps_W / eps_Z inside the label and pair kernels (no Philox launch)."""
+        return bool(self.fuse_pair and self.sparse_inputs and self.cfg['D'] % 2 == 0)
+
+    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None, target=None, noise=None):
         """nll = (scale, need_grads): fuse the Bernoulli NLL of the output head into its GEMM; target = the frames the
-        output is scored against (default X)."""
+        output is scored against (default X).
+        noise = (seed, stream_w, stream_z, first_w, first_z, step, step_dev): draw eps_W / eps_Z (into the buffers passed)
+        instead of reading them -- inside the label and pair kernels where they run, else with one Philox launch."""
         target = X if target is None else target
         cfg, P, B = self.cfg, self.P, self.B
         self._nll_done = False
+        self._noise = None
+        if noise is not None:
+            if self.folds_noise():
+                seed, sw, sz, fw, fz, step, step_dev = noise
+                self._noise = (ops.noise_draw(seed, sw, fw, step, step_dev), ops.noise_draw(seed, sz, fz, step, step_dev))
+            else:
+                ops.philox_normal2(eps_W, B * (cfg['C'] - 1), noise[1], noise[3], eps_Z, B * cfg['T'] * cfg['L'], noise[2],
+                                   noise[4], noise[0], noise[5], step_dev=noise[6])
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         g, ws = ops.gemm, self.ws
@@ -635,7 +649,9 @@ class VrnnEngine(_EngineBase):
                 P.rows(P.params, 'decoder_h/kernel', off + L), P.p('decoder_h/bias'),
                 self.wargs, self.W, self.rowloss, self.wk_enc, self.wk_dec)
         if self.sparse_inputs and D % 2 == 0:
-            ops.vrnn_label_fwd_x(B, D, Cn, G4, X, T * D, T * D, P.p('hW/kernel'), P.p('hW/bias'), self.hW, *tail)
+            nz = getattr(self, '_noise', None)
+            ops.vrnn_label_fwd_x(B, D, Cn, G4, X, T * D, T * D, P.p('hW/kernel'), P.p('hW/bias'), self.hW, *tail,
+                                 noise=nz[0] if nz else None)
         else:
             ops.gemm(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=self.ws)
             ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, *tail)
@@ -682,9 +698,10 @@ class VrnnEngine(_EngineBase):
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel
                 g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
         self._label_forward(X, eps_W, w_true)
+        nz = getattr(self, '_noise', None)
         ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, self.gates_dec, off > 0, self.wk_dec, self.pair_pack,
                           P.p('Zargs/bias'), eps_Z, self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z,
-                          self.xz_ld, self.klterm, gate_act=self.gate_act)
+                          self.xz_ld, self.klterm, gate_act=self.gate_act, noise=nz[1] if nz else None)
         self._output_head(X if target is None else target, nll)
 
     def xp_view(self):
@@ -886,14 +903,15 @@ class VrnnEngine(_EngineBase):
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                          self.dzsum_enc, gate_act=self.gate_act)
 
-    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True, target=None):
-        """target: the frames the decoder output is scored against (default X; the next frames under --predict_next)."""
+    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True, target=None, noise=None):
+        """target: the frames the decoder output is scored against (default X; the next frames under --predict_next).
+        noise: see forward()."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         inv_bt, inv_b = 1.0 / BT, 1.0 / B
         g, ws, off = ops.gemm, self.ws, self.off
-        self.forward(X, Xp, eps_W, eps_Z, w_true, nll=(inv_bt, need_grads), target=target)
+        self.forward(X, Xp, eps_W, eps_Z, w_true, nll=(inv_bt, need_grads), target=target, noise=noise)
         if not self._nll_done:
             ops.bernoulli_nll(BT, D, self.logits, X if target is None else target, D, inv_bt, self.rownll,
                               self.dlogits if need_grads else None)

@@ -292,11 +292,12 @@ def lstm_pair_pack(L, U_enc, U_dec, Kz, Wz, pack, H=88):
 
 
 def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, gates_dec, dec_has_xproj, rb_dec, pack, bz, eps,
-                  hs_enc, cs_enc, hs_dec, cs_dec, zargs, Z, ldz, klterm, gate_act=0, H=88):
+                  hs_enc, aux_enc, hs_dec, aux_dec, zargs, Z, ldz, klterm, gate_act=0, H=88, noise=None):
+    """aux_* [B*T, 2H]: (kcarry, kc) of the backward pass; noise: a noise_draw(): eps is drawn in the kernel."""
     check(_lib.lib().clv_lstm_pair_fwd(B, T, H, L, gate_act, _ptr(gates_enc), _ptr(rb_enc), _ptr(gates_dec),
                                        int(bool(dec_has_xproj)), _ptr(rb_dec), _ptr(pack), _ptr(bz),
-                                       _ptr(eps), _ptr(hs_enc), _ptr(cs_enc), _ptr(hs_dec), _ptr(cs_dec), _ptr(zargs),
-                                       _ptr(Z), ldz, _ptr(klterm), _stream()), "clv_lstm_pair_fwd")
+                                       _ptr(eps), _ptr(hs_enc), _ptr(aux_enc), _ptr(hs_dec), _ptr(aux_dec), _ptr(zargs),
+                                       _ptr(Z), ldz, _ptr(klterm), _noise_ref(noise), _stream()), "clv_lstm_pair_fwd")
 
 
 def lstm_pair_bwd(B, T, L, kl_scale, pack, Wz, dhs_dec, cs_dec, cs_enc, gates_dec, gates_enc, dzsum_dec,
@@ -327,13 +328,25 @@ def vrnn_label_fwd(B, D, Cn, G4, hW, Ka, ba, eps, onehot, prior, Kenc_w, benc, K
           "clv_vrnn_label_fwd")
 
 
+def noise_draw(seed, stream, first, step=0, step_dev=None):
+    """clv_noise_draw: the kernel that gets it draws eps itself (the clv_philox_normal values at indices first + e) and
+    writes them to its eps buffer.  The struct is returned by value: keep it alive across the call (ctypes copies the
+    fields when the launch is made / captured)."""
+    return _lib.NoiseDraw(int(seed), int(first), int(stream), int(step), _ptr(step_dev))
+
+
+def _noise_ref(noise):
+    return C.byref(noise) if noise is not None else None
+
+
 def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, onehot, prior, Kenc_w, benc, Kdec_w, bdec, wargs,
-                     W, rowloss, rb_enc, rb_dec):
-    """hW = relu(X . Kh + bh) over the nonzero inputs of each row, then vrnn_label_fwd, one workgroup per row."""
+                     W, rowloss, rb_enc, rb_dec, noise=None):
+    """hW = relu(X . Kh + bh) over the nonzero inputs of each row, then vrnn_label_fwd, one workgroup per row.
+    noise: a noise_draw(): eps is drawn in the kernel (and written to `eps`) instead of read."""
     check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), _ptr(bh), _ptr(hW_out), _ptr(Ka),
                                           _ptr(ba), _ptr(eps), _ptr(onehot), float(prior), _ptr(Kenc_w), _ptr(benc),
                                           _ptr(Kdec_w), _ptr(bdec), _ptr(wargs), _ptr(W), _ptr(rowloss), _ptr(rb_enc),
-                                          _ptr(rb_dec), _stream()), "clv_vrnn_label_fwd_x")
+                                          _ptr(rb_dec), _noise_ref(noise), _stream()), "clv_vrnn_label_fwd_x")
 
 
 def vrnn_label_bwd(B, D, Cn, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior,

@@ -109,11 +109,12 @@ class TrainStep:
             self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y,
                                     noise=self.noise_spec(), bump=True)
             return
+        if self.is_vrnn:     # eps is drawn inside the label / pair kernels where they run (else one Philox launch in forward())
+            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, do_tail=False, target=self.Y,
+                                    noise=self.noise_spec())
+            return
         self.draw_noise()
-        if self.is_vrnn:
-            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, do_tail=False, target=self.Y)
-        else:
-            self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y)
+        self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y)
 
     def _tail(self):
         if self.is_vrnn:

@@ -43,6 +43,17 @@ extern "C" {
 #define CLV_GATE_HARD_SIGMOID 0   /* Keras 2.0.0 default recurrent_activation */
 #define CLV_GATE_SIGMOID      1
 
+/* In-kernel noise: a kernel that takes `const clv_noise_draw* noise` draws its standard-normal eps itself when noise is
+ * not NULL -- element e of the launch's eps tensor gets the clv_philox_normal value of (seed, step + *step_dev, stream,
+ * index first + e), i.e. bit for bit what clv_philox_normal / clv_philox_normal2 would have written -- and WRITES it to
+ * the eps buffer (the backward pass reads it there); noise == NULL: eps is read.  first = the global index of the
+ * launch's element 0 (data-parallel ranks draw at their global sample indices). */
+typedef struct clv_noise_draw {
+  uint64_t seed, first;
+  uint32_t stream, step;
+  const int32_t* step_dev;
+} clv_noise_draw;
+
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
 int clv_device_count(void);
@@ -196,8 +207,12 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  * decoder LSTM, whose input projection gets z_t . Kz (Kz [L,4H] = the z rows of decoder_h/kernel) added
  * inside the kernel.  A workgroup owns one batch row; the encoder chain and the decoder chain (two steps
  * behind) run in different waves of the same CU, so the pair costs about one sequence kernel.
- *   gates_enc : in  x_t.K_x [B,T,4H]          out (z_i, z_f, tanh(z_c), z_o) like clv_lstm_seq_fwd
+ *   gates_enc : in  x_t.K_x [B,T,4H]          out the backward pass's gate coefficients (ki, kf, kg, ko) =
+ *                                             (g i', c_{t-1} f', i g', tanh(c) o'): dz_{i,f,g} = dc k, dz_o = dh ko
  *   gates_dec : in  x_{t-1}.K_x (dec_has_xproj != 0; else ignored)   out likewise
+ *   aux_enc / aux_dec [B*T,2,H]: out (kcarry, kc) = (f, o (1 - tanh(c)^2)): dc += dh kc, dc_{t-1} = dc kcarry.
+ *     (These six numbers per unit and step are all the backward pass needs of the forward pass; the cell states
+ *     themselves are not stored.  The format is private to the clv_lstm_pair_fwd / _bwd pair.)
  *   rowbias_* : [B,4H] per-row bias (W.K_w + b)
  *   zargs [B*T,2L], Z: B*T rows of stride ldz, klterm [B*T,L] = L * KL_l (the mean over ALL entries is
  *   the per-frame KL, which is what clv_loss_sums computes).
@@ -221,12 +236,12 @@ int clv_lstm_pair_pack(int H, int L, const float* U_enc, const float* U_dec, con
 int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                       float* gates_enc, const float* rowbias_enc,
                       float* gates_dec, int dec_has_xproj, const float* rowbias_dec,
-                      const float* pack, const float* bz, const float* eps,
-                      float* hs_enc, float* cs_enc, float* hs_dec, float* cs_dec,
-                      float* zargs, float* Z, int ldz, float* klterm, void* stream);
+                      const float* pack, const float* bz, float* eps,
+                      float* hs_enc, float* aux_enc, float* hs_dec, float* aux_dec,
+                      float* zargs, float* Z, int ldz, float* klterm, const clv_noise_draw* noise, void* stream);
 int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
                       const float* pack, const float* Wz,
-                      const float* dhs_dec, const float* cs_dec, const float* cs_enc,
+                      const float* dhs_dec, const float* aux_dec, const float* aux_enc,
                       float* gates_dec_inout_dz, float* gates_enc_inout_dz,
                       float* dzsum_dec, float* dzsum_enc,
                       const float* zargs, const float* eps, float* dzargs, void* stream);
@@ -336,9 +351,10 @@ int clv_vrnn_label_fwd(int B, int D, int C, int G4, const float* hW, const float
  * [B,D] for the backward pass, then the label path as above.  D even. */
 int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
                          const float* bh, float* hW_out, const float* Ka, const float* ba,
-                         const float* eps, const float* onehot, float prior_logvar,
+                         float* eps, const float* onehot, float prior_logvar,
                          const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
-                         float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec, void* stream);
+                         float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                         const clv_noise_draw* noise, void* stream);
 int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
                        const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
                        const float* onehot, const float* W, const float* hW, const float* Ka,

@@ -418,6 +418,42 @@ def test_cl_vae_fused_step_draws_its_own_noise_and_advances_the_counter(dev, B, 
     assert abs(lb['kl_z'] - float(b.rowkl.double().mean())) < 1e-5 * max(1.0, abs(lb['kl_z']))
 
 
+@pytest.mark.parametrize("B,Tn,L,pair", [(6, 16, 2, True), (5, 7, 8, True), (4, 8, 12, False)])
+def test_cl_vrnn_step_draws_its_own_noise(dev, B, Tn, L, pair):
+    """loss_and_grads(noise=...): eps_W is drawn inside the label kernel and eps_Z inside the pair kernel (no Philox launch
+    in the step) -- bit for bit the values clv_philox_normal2 writes at the same (seed, streams, first indices, step),
+    and therefore the same losses and gradients as a step that is given those tensors.  pair=False (latent_dim > 8):
+    the engine falls back to one Philox launch of its own, same values."""
+    from clvae_amd import ops
+    from clvae_amd.engine import VrnnEngine
+    Cn = 10
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(B * 100 + L)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=4).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    a, b = VrnnEngine(cfg, B, dev), VrnnEngine(cfg, B, dev)
+    assert a.fuse_pair == pair and b.folds_noise() == pair
+    for e in (a, b):
+        e.P.set_weights(p)
+        e.P.iterations.fill_(11)
+    C1 = Cn - 1
+    row0 = 3                                    # as if this were the second rank of a data-parallel group
+    seed, sw, sz, fw, fz = 0xABCDEF012345, 2, 3, row0 * C1, row0 * Tn * L
+    ew, ez = torch.empty(B, C1, device=dev), torch.empty(B * Tn, L, device=dev)
+    ops.philox_normal2(ew, B * C1, sw, fw, ez, B * Tn * L, sz, fz, seed, 0, step_dev=a.P.iterations)
+    xs = (T(X, dev), T(Xp, dev), T(wt, dev))
+    a.loss_and_grads(*xs, ew, ez)
+    ew2, ez2 = torch.zeros(B, C1, device=dev), torch.zeros(B * Tn, L, device=dev)
+    b.loss_and_grads(*xs, ew2, ez2, noise=(seed, sw, sz, fw, fz, 0, b.P.iterations))
+    torch.cuda.synchronize()
+    assert torch.equal(ew, ew2) and torch.equal(ez, ez2)
+    assert torch.equal(a.P.grads, b.P.grads)
+    la, lb = a.losses(), b.losses()
+    assert all(la[k] == lb[k] for k in la)
+
+
 def test_cl_vae_bf16_step_tolerance(dev):
     """BASELINE configuration 2 names bf16 for the encoder / decoder products: cfg['bf16'] rounds the operands of every
     Dense product and weight-gradient product of the fused step to bf16 (fp32 accumulate, fp32 everything else).  Its
