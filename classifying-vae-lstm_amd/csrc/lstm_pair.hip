@@ -156,6 +156,10 @@ struct PairFwdArgs {
   const float* rb_d;
   const float* pack;      // weights in lane order (clv_lstm_pair_pack)
   const float* bz;        // [2L]
+  // note lists (clv_gather_rows_multi_notes) of the frames x_t / x_{t-1} and the kernels' frame rows [88,352]: when
+  // given, the input projections are gathered in this kernel and the gate buffers are not read
+  const unsigned char* notes_e; const float* Kx_e;
+  const unsigned char* notes_d; const float* Kx_d;
   float* eps;             // [B,T,L]: read, or drawn in the kernel's prologue and written (noise.on)
   struct { int on; uint32_t k0, k1, stream, step; uint64_t first; const int32_t* step_dev; } noise;
   float *hs_e, *aux_e, *gates_e, *hs_d, *aux_d, *gates_d;      // aux: [B*T, 2, 88] = (kcarry, kc)
@@ -250,8 +254,99 @@ __device__ __forceinline__ void prologue_loads_done() { __builtin_amdgcn_s_waitc
 // s' and s' + 4 behind its h values, so the decoder's sixth ds_read_b128 brings them along (no separate z buffer, no read)
 __device__ __forceinline__ int pair_hslot(int u) { return PKP * (u / PKK) + (u % PKK); }
 
+// The input projection x_t . K_x of a chain, two steps ahead of its use, in two register sets (even / odd steps).
+//   XL == false: one value per lane and step, read from the gate buffer (written by clv_sparse_proj or a GEMM);
+//   XL == true:  gathered HERE: the frame's note list (bytes, CLV_NOTE_NONE-terminated) comes in through two scalar
+//                registers -- requested two steps before the loads that use them -- and the kernel rows of the (up to) 8
+//                (Not a scalar load: s_load shares lgkmcnt with the LDS, and the step barrier's lgkmcnt(0) then waits
+//                for a scalar-cache miss issued moments before -- 0.6 us per step.  The list's first 8 bytes come through
+//                a broadcast buffer load, counted in vmcnt like everything else, and two v_readfirstlane.)
+//                first notes are 8 buffer loads whose row offset is an SGPR (note * 1408 bytes): no vector address
+//                arithmetic, and an absent note (88) points beyond num_records, i.e. returns 0 without touching
+//                memory.  The kernel rows are L2-resident (124 KB per LSTM).  More than 8 notes in a frame (1.6 % of
+//                the frames at piano-roll density): the rest is added one load at a time, in place.
+//                Lane order of these loads: NOT the (unit, k-slice) order of the recurrence -- there the four lanes of a
+//                quad read four different 64-byte pieces of a kernel row, and the texture path looks up a cache line per
+//                (quad, piece): 64 lookups per wave load instead of 4; with 8 loads per wave and step that alone was
+//                0.7 us per step.  Lane l = 16 g + j loads column g*88 + u0 + j (four contiguous runs of 64 bytes), sums its
+//                notes there, and ONE ds_bpermute per step moves the sum to lane 4 j + g, which owns gate g of unit u0 + j.
+//                Why here: the separate projection launch wrote 92 MB and this kernel read them back (26 us + ~35 us of
+//                HBM time per step); the price is 7 more vector adds per lane and step.
+template <bool XL> struct XSet { float v[XL ? 8 : 1]; bool more; };      // more (uniform): the frame has more than 8 notes
+template <bool XL>
+struct XProj {
+  rsrc_t r_kx;            // XL: the kernel's frame rows; else: the gate buffer of this batch row
+  unsigned vo;            // lane's byte offset (its gate column); BUF_OOB for lanes without a unit
+  // XL: this batch row's note lists, through the CONSTANT address space: nothing in this kernel writes them, and only a
+  // load the compiler knows to be invariant becomes a scalar load (the generic-pointer form was a vector load +
+  // s_waitcnt vmcnt(0) + v_readfirstlane at the top of every step)
+  typedef unsigned nn_t __attribute__((ext_vector_type(2)));      // a list's first 8 bytes
+  typedef const nn_t __attribute__((address_space(4))) * notes_ptr;
+  typedef const unsigned __attribute__((address_space(4))) * notes_ptr32;
+  notes_ptr nrow;
+  rsrc_t r_n;             // XL: the same lists as a buffer (the first 8 bytes of a list travel through vmcnt)
+  int T;
+  __device__ __forceinline__ static notes_ptr as_notes(const unsigned char* p) { return (notes_ptr)(uintptr_t)p; }
+  // the first 8 bytes of frame f's list, in every lane (a broadcast load: one address)
+  __device__ __forceinline__ uint2 notes(int f) const {
+    const nn_t v = __builtin_amdgcn_raw_buffer_load_b64(r_n, 0, (int)((unsigned)min(f, T - 1) * (unsigned)CLV_NOTE_ROW), 0);
+    return make_uint2(v.x, v.y);
+  }
+  __device__ __forceinline__ void load(XSet<XL>& x, uint2 nv, int f) const {
+    f = min(f, T - 1);
+    if constexpr (!XL) {
+      x.v[0] = buf_load(r_kx, vo, (unsigned)f * (unsigned)(LG * 4));
+    } else {
+      uint2 nn;
+      nn.x = __builtin_amdgcn_readfirstlane(nv.x);
+      nn.y = __builtin_amdgcn_readfirstlane(nv.y);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x.v[j] = buf_load(r_kx, vo, ((nn.x >> (8 * j)) & 255u) * (unsigned)(LG * 4));
+        x.v[4 + j] = buf_load(r_kx, vo, ((nn.y >> (8 * j)) & 255u) * (unsigned)(LG * 4));
+      }
+      x.more = (nn.y >> 24) != CLV_NOTE_NONE;
+    }
+  }
+  // the 9th.. note of frame f (uniform, rare: 1.6 % of the frames at piano-roll density): added where the set is consumed,
+  // one waited load at a time -- nothing loop-carried depends on this path
+  __device__ __forceinline__ float extra(int f, int paddr) const {
+    const notes_ptr32 w = (notes_ptr32)nrow + (unsigned)min(f, T - 1) * (CLV_NOTE_ROW / 4) + 2;
+    float e = 0.f;
+    for (int q = 0; q < (CLV_NOTE_ROW - 8) / 4; ++q) {
+      const unsigned ww = w[q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e += buf_load(r_kx, vo, ((ww >> (8 * j)) & 255u) * (unsigned)(LG * 4));
+      if ((ww >> 24) == CLV_NOTE_NONE) break;
+    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(paddr, __builtin_bit_cast(int, e)));
+  }
+  // pins the use of a set behind the previous step's barrier (else the compiler computes the sum half a step early and
+  // waits there for loads issued moments before)
+  __device__ __forceinline__ static void pin(XSet<XL>& x) {
+    if constexpr (XL) asm volatile("" : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7]));
+    else asm volatile("" : "+v"(x.v[0]));
+  }
+  // byte offset of the column a lane LOADS (XL): wave's first unit u0, lane l = 16 g + j -> column g*88 + u0 + j
+  // (unit slots beyond the last unit duplicate it, like the lanes they feed)
+  __device__ __forceinline__ static unsigned load_offset(int u0, int lane, int nunits) {
+    const int g = lane >> 4, j = lane & 15;
+    return (unsigned)(g * LH + min(u0 + j, nunits - 1)) * 4u;
+  }
+  // ds_bpermute address that brings lane (4 j + g) the value of lane (16 g + j)
+  __device__ __forceinline__ static int perm_addr(int lane) { return 4 * (16 * (lane & 3) + (lane >> 2)); }
+  __device__ __forceinline__ static float sum(const XSet<XL>& x, float rb, int paddr, float mask = 1.f) {
+    if constexpr (XL) {
+      const float t = ((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])) + ((x.v[4] + x.v[5]) + (x.v[6] + x.v[7]));
+      return fmaf(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(paddr, __builtin_bit_cast(int, t))), mask, rb);
+    } else {
+      return x.v[0] + rb;
+    }
+  }
+};
+
 // LATW: this is the encoder's last wave: its 8 surplus lane groups (units 88..95) carry the latent head
-template <int GATE, bool LATW>
+template <int GATE, bool LATW, bool XL>
 __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP],
                                                  float (*hbd)[PK * PKP]) {
   const int s = lane & 3, b = blockIdx.x, T = a.T, L = a.L;
@@ -286,6 +381,14 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   const rsrc_t r_z = make_rsrc(a.Z + bt0 * a.ldz, T * a.ldz * 4);
   const rsrc_t r_kl = make_rsrc(a.klterm + bt0 * L, T * L * 4);
   const unsigned vo_g = is_z ? BUF_OOB : loff * 4;
+  XProj<XL> xp;
+  xp.r_kx = XL ? make_rsrc(a.Kx_e, CLV_NOTE_NONE * LG * 4) : r_g;
+  // XL: contiguous lane order for the loads (latent lanes mask what arrives: xmask)
+  xp.vo = XL ? XProj<XL>::load_offset(wave * 16, lane, LH) : loff * 4;
+  const int paddr = XProj<XL>::perm_addr(lane);
+  xp.nrow = XProj<XL>::as_notes(a.notes_e + (XL ? bt0 * CLV_NOTE_ROW : 0));
+  xp.r_n = XL ? make_rsrc(a.notes_e + bt0 * CLV_NOTE_ROW, T * CLV_NOTE_ROW) : r_g;
+  xp.T = T;
   const unsigned vo_h = (!is_z && s == 0) ? u * 4 : BUF_OOB;
   const unsigned vo_a = (!is_z && (s == 1 || s == 2)) ? ((s - 1) * LH + u) * 4 : BUF_OOB;
   const unsigned vo_e = (lat_ok ? lat : 0) * 4;
@@ -305,7 +408,10 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   float c = 0.f;
   // The per-step loads are requested two steps ahead into TWO register sets (the loop body is two steps): a value is
   // consumed where it landed, nothing rotates
-  float xA = buf_load(r_g, loff * 4, 0), xB = buf_load(r_g, loff * 4, min(1, T - 1) * LG * 4);      // projections of steps 0 and 1
+  XSet<XL> xA, xB;                                                       // projections of steps 0 and 1
+  uint2 nA = make_uint2(0, 0), nB = nA;                                  // note lists of steps 2 and 3
+  if constexpr (XL) { xp.load(xA, xp.notes(0), 0); xp.load(xB, xp.notes(1), 1); nA = xp.notes(2); nB = xp.notes(3); }
+  else { xp.load(xA, nA, 0); xp.load(xB, nB, 1); }
   float eA = 0.f, eB = buf_load(r_e, vo_e, 0);                           // eps of steps -1 and 0
   prologue_loads_done();
 
@@ -333,11 +439,11 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     buf_store(klv, r_kl, vo_kl, (unsigned)row * (unsigned)(L * 4));
   };
 
-  auto step = [&](auto parc, int i, float& xa, float& ea) {
+  auto step = [&](auto parc, int i, XSet<XL>& xa, uint2& na, float& ea) {
     constexpr int cur = decltype(parc)::value;
-    asm volatile("" : "+v"(xa));        // pins the use of xa behind the previous step's barrier (else the compiler computes
-                                        // xv half a step early and waits there for a load issued moments before)
-    const float xv = LATW ? fmaf(xa, xmask, rb) : xa + rb;
+    XProj<XL>::pin(xa);
+    float xv = (LATW && !XL) ? fmaf(xa.v[0], xmask, rb) : XProj<XL>::sum(xa, rb, paddr, LATW ? xmask : 1.f);
+    if constexpr (XL) { if (xa.more) xv = fmaf(xp.extra(i, paddr), LATW ? xmask : 1.f, xv); }
     PTOP(xv);
     const float z = gate_sum(&hb[cur][PKP * s], xv);
     float vA, act, kc;
@@ -355,22 +461,24 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     buf_store(Sel4::pick(sm.m1, act, kc), r_a, vo_a, (unsigned)i * (unsigned)(2 * LH * 4));
     // the loads of step i+2 into the registers this step has just consumed; issued BEHIND the stores, so that the wait at
     // the top of step i+2 lets everything step i+1 issues stay in flight
-    xa = buf_load(r_g, loff * 4, (unsigned)min(i + 2, T - 1) * (unsigned)(LG * 4));
+    xp.load(xa, na, i + 2);
+    if constexpr (XL) na = xp.notes(i + 4);
     if (LATW) ea = buf_load(r_e, vo_e, (unsigned)min(i + 1, T - 1) * (unsigned)(L * 4));
     PARRIVE(wave, i + 2, vA + h);                       // the encoder runs two steps ahead of the decoder's step index
     step_barrier();
   };
-  int i = 0;
-  for (; i + 1 < T; i += 2) {
-    step(ParC<0>(), i, xA, eA);
-    step(ParC<1>(), i + 1, xB, eB);
+  // An odd T runs one step more (no separate tail: a second copy of the step after the loop costs register moves at the
+  // loop header): step T reads clamped rows, its stores lie beyond num_records and are dropped, and its latent head is
+  // the one of step T-1, which the epilogue below writes again.
+  for (int i = 0; i < T; i += 2) {
+    step(ParC<0>(), i, xA, nA, eA);
+    step(ParC<1>(), i + 1, xB, nB, eB);
   }
-  if (T & 1) step(ParC<0>(), T - 1, xA, eA);
   // iteration T: only the latent head of step T-1 is left
   if (LATW) {
     const float z = gate_sum(&hb[T & 1][PKP * s], rb);
     float zv, klv;
-    latent(z, (T & 1) ? eB : eA, zv, klv);
+    latent(z, buf_load(r_e, vo_e, (unsigned)(T - 1) * (unsigned)(L * 4)), zv, klv);
     if (lat_ok && s < 2) hbd[(T + 1) & 1][zslot] = zv;
     store_latent(T - 1, z, zv, klv);
   }
@@ -379,7 +487,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
 }
 
 // ZQ: latents per decoder lane actually present (ceil(latent_dim / 4) <= 2): lane s multiplies the latents s, s+4
-template <int GATE, bool HASXP, int ZQ>
+template <int GATE, bool HASXP, int ZQ, bool XL>
 __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave, int lane, float (*hb)[PK * PKP]) {
   const int s = lane & 3, b = blockIdx.x, T = a.T;
   const int u = min(wave * 16 + (lane >> 2), LH - 1);
@@ -407,20 +515,36 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   const rsrc_t r_a = make_rsrc(a.aux_d + bt0 * 2 * LH, T * 2 * LH * 4);
   const unsigned vo_h = s == 0 ? u * 4 : BUF_OOB;
   const unsigned vo_a = (s == 1 || s == 2) ? ((s - 1) * LH + u) * 4 : BUF_OOB;
+  XProj<XL> xp;
+  xp.r_kx = XL ? make_rsrc(a.Kx_d, CLV_NOTE_NONE * LG * 4) : r_g;
+  xp.vo = XL ? XProj<XL>::load_offset(wave * 16, lane, LH) : loff * 4;
+  const int paddr = XProj<XL>::perm_addr(lane);
+  xp.nrow = XProj<XL>::as_notes(a.notes_d + (XL ? bt0 * CLV_NOTE_ROW : 0));
+  xp.r_n = XL ? make_rsrc(a.notes_d + bt0 * CLV_NOTE_ROW, T * CLV_NOTE_ROW) : r_g;
+  xp.T = T;
   const float rb = a.rb_d[(size_t)b * LG + loff];
   const int hslot = pair_hslot(u);
   float c = 0.f;
-  float xA = HASXP ? buf_load(r_g, loff * 4, 0) : 0.f, xB = HASXP ? buf_load(r_g, loff * 4, min(1, T - 1) * LG * 4) : 0.f;
+  XSet<XL> xA, xB;
+  uint2 nA = make_uint2(0, 0), nB = nA;
+#pragma unroll
+  for (int j = 0; j < (XL ? 8 : 1); ++j) xA.v[j] = xB.v[j] = 0.f;
+  xA.more = xB.more = false;
+  if constexpr (HASXP) {
+    if constexpr (XL) { xp.load(xA, xp.notes(0), 0); xp.load(xB, xp.notes(1), 1); nA = xp.notes(2); nB = xp.notes(3); }
+    else { xp.load(xA, nA, 0); xp.load(xB, nB, 1); }
+  }
   prologue_loads_done();
   step_barrier();          // the encoder is two steps ahead
   step_barrier();
-  auto step = [&](auto parc, int t, float& xa) {
+  auto step = [&](auto parc, int t, XSet<XL>& xa, uint2& na) {
     constexpr int cur = decltype(parc)::value;
 #ifdef PAIR_STAMPS
     unsigned long long pst[8];
 #endif
-    asm volatile("" : "+v"(xa));        // see the encoder
-    const float xv = xa + rb;
+    XProj<XL>::pin(xa);
+    float xv = XProj<XL>::sum(xa, rb, paddr);
+    if constexpr (XL) { if (xa.more) xv += xp.extra(t, paddr); }
     PSTAMP(0, xv);
     PTOP(xv);
     f2 acc[4];       // (even k, odd k) partial sums
@@ -449,7 +573,10 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     buf_store(vA, r_g, loff * 4, (unsigned)t * (unsigned)(LG * 4));
     buf_store(h, r_h, vo_h, (unsigned)t * (unsigned)(LH * 4));
     buf_store(Sel4::pick(sm.m1, act, kc), r_a, vo_a, (unsigned)t * (unsigned)(2 * LH * 4));
-    if (HASXP) xa = buf_load(r_g, loff * 4, (unsigned)min(t + 2, T - 1) * (unsigned)(LG * 4));      // behind the stores: see the encoder
+    if constexpr (HASXP) {              // behind the stores: see the encoder
+      xp.load(xa, na, t + 2);
+      if constexpr (XL) na = xp.notes(t + 4);
+    }
     PSTAMP(6, vA + h);
     PARRIVE(PNW + wave, t, vA + h);
     step_barrier();
@@ -463,15 +590,13 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     }
 #endif
   };
-  int t = 0;
-  for (; t + 1 < T; t += 2) {
-    step(ParC<0>(), t, xA);
-    step(ParC<1>(), t + 1, xB);
+  for (int t = 0; t < T; t += 2) {     // an odd T runs one step more: see the encoder
+    step(ParC<0>(), t, xA, nA);
+    step(ParC<1>(), t + 1, xB, nB);
   }
-  if (T & 1) step(ParC<0>(), T - 1, xA);
 }
 
-template <int GATE, bool HASXP, int ZQ>
+template <int GATE, bool HASXP, int ZQ, bool XL>
 __global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float hbuf[2][2][PK * PKP];      // [chain][parity][sliced h (+ z in the decoder's)]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -487,9 +612,9 @@ __global__ __launch_bounds__(PNT) void lstm_pair_fwd_kernel(PairFwdArgs a) {
     for (int e = tid; e < n; e += PNT) out[e] = philox_normal_at(first + e, a.noise.k0, a.noise.k1, a.noise.stream, stp);
   }
   __syncthreads();
-  if (wave < PNW - 1) pair_fwd_encoder<GATE, false>(a, wave, lane, hbuf[0], hbuf[1]);
-  else if (wave == PNW - 1) pair_fwd_encoder<GATE, true>(a, wave, lane, hbuf[0], hbuf[1]);
-  else pair_fwd_decoder<GATE, HASXP, ZQ>(a, wave - PNW, lane, hbuf[1]);
+  if (wave < PNW - 1) pair_fwd_encoder<GATE, false, XL>(a, wave, lane, hbuf[0], hbuf[1]);
+  else if (wave == PNW - 1) pair_fwd_encoder<GATE, true, XL>(a, wave, lane, hbuf[0], hbuf[1]);
+  else pair_fwd_decoder<GATE, HASXP, ZQ, XL>(a, wave - PNW, lane, hbuf[1]);
 }
 
 // ---------------------------------------------------------------------------
@@ -579,8 +704,8 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   const unsigned vo_g = zgroup ? BUF_OOB : col * 4;                            // dz store (latent groups: none)
   const unsigned vo_m = zlane ? lat * 4 : BUF_OOB, vo_lv = zlane ? (L + lat) * 4 : BUF_OOB;
   const float hk = 0.5f * a.kl_scale;
-  auto load_raw = [&](int tr, Raw& r) {
-    const unsigned t = (unsigned)max(tr, 0);
+  auto load_raw = [&](int tr, Raw& r) {      // tr < 0 (the steps beyond the window's start): beyond num_records, i.e. zeros
+    const unsigned t = (unsigned)tr;
     r.kq = buf_load(r_g, col * 4, t * (unsigned)(LG * 4));
     r.kcarry = buf_load(r_a, u * 4, t * (unsigned)(2 * LH * 4));
     r.kc = buf_load(r_a, (LH + u) * 4, t * (unsigned)(2 * LH * 4));
@@ -671,17 +796,20 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     load_raw(t - 2, k);
     step_barrier();
   };
-  int i = 0;
-  for (; i + 1 < T; i += 2) {
+  // An odd T runs one step more (no separate tail, see the forward kernel): step t = -1 has zero coefficients (its
+  // loads lie beyond num_records), so dz = 0 and the column sums are untouched, its stores are dropped, and in the latent
+  // lanes it IS the iteration-T work below (dZ_0 -> dzargs_0), which is then done twice with the same result.
+  for (int i = 0; i < T; i += 2) {
     step(ParC<0>(), i, rA);
     step(ParC<1>(), i + 1, rB);
   }
-  if (T & 1) step(ParC<0>(), T - 1, rA);
   if (DEC) {
     // iteration T: dZ_0 -> dzargs_0
     if (LATW) {
       const float dZ = matvec(dzb[T & 1]);
-      const float zv = latent_dz((T & 1) ? rB : rA, dZ);      // the set reloaded last holds load_raw(-1): step 0
+      Raw k0;                                                  // a latent lane's values of step 0
+      k0.m = buf_load(r_za, vo_m, 0); k0.lv = buf_load(r_za, vo_lv, 0); k0.e = buf_load(r_e, vo_m, 0);
+      const float zv = latent_dz(k0, dZ);
       buf_store(zv, r_dz, vo_dz, 0);
       if (zlive) dza[T & 1][lpos] = zv;
     }
@@ -737,14 +865,21 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                                  float* gates_dec, int dec_has_xproj, const float* rowbias_dec,
                                  const float* pack, const float* bz, float* eps,
                                  float* hs_enc, float* aux_enc, float* hs_dec, float* aux_dec,
-                                 float* zargs, float* Z, int ldz, float* klterm, const clv_noise_draw* noise, void* stream) {
+                                 float* zargs, float* Z, int ldz, float* klterm,
+                                 const unsigned char* notes_enc, const float* Kx_enc,
+                                 const unsigned char* notes_dec, const float* Kx_dec,
+                                 const clv_noise_draw* noise, void* stream) {
   using namespace clv;
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0 || ldz < L) return CLV_EINVAL;
+  const bool xl = notes_enc != nullptr;
+  if (xl && (!Kx_enc || (dec_has_xproj && (!notes_dec || !Kx_dec)) || ((uintptr_t)notes_enc | (uintptr_t)notes_dec) % 8))
+    return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
   if (!gates_enc || !rowbias_enc || !gates_dec || !rowbias_dec || !pack || !bz || !eps ||
       !hs_enc || !aux_enc || !hs_dec || !aux_dec || !zargs || !Z || !klterm)
     return CLV_EINVAL;
-  PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, gates_dec, rowbias_dec, pack, bz, eps, {0, 0, 0, 0, 0, 0, nullptr},
+  PairFwdArgs a{B, T, L, ldz, gates_enc, rowbias_enc, gates_dec, rowbias_dec, pack, bz,
+                notes_enc, Kx_enc, notes_dec, Kx_dec, eps, {0, 0, 0, 0, 0, 0, nullptr},
                 hs_enc, aux_enc, gates_enc, hs_dec, aux_dec, gates_dec, zargs, Z, klterm};
   if (noise) {
     a.noise.on = 1; a.noise.k0 = (uint32_t)noise->seed; a.noise.k1 = (uint32_t)(noise->seed >> 32);
@@ -754,10 +889,12 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_fwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
-#define PAIR_FWD_Z(G, X, Z) hipLaunchKernelGGL((lstm_pair_fwd_kernel<G, X, Z>), dim3(B), dim3(PNT), 0, s, a)
+#define PAIR_FWD_ZX(G, X, Z, XL) hipLaunchKernelGGL((lstm_pair_fwd_kernel<G, X, Z, XL>), dim3(B), dim3(PNT), 0, s, a)
+#define PAIR_FWD_Z(G, X, Z) do { if (xl) PAIR_FWD_ZX(G, X, Z, true); else PAIR_FWD_ZX(G, X, Z, false); } while (0)
 #define PAIR_FWD(G, X) do { if (L <= 4) PAIR_FWD_Z(G, X, 1); else PAIR_FWD_Z(G, X, 2); } while (0)
   if (hard) { if (dec_has_xproj) PAIR_FWD(CLV_GATE_HARD_SIGMOID, true); else PAIR_FWD(CLV_GATE_HARD_SIGMOID, false); }
   else { if (dec_has_xproj) PAIR_FWD(CLV_GATE_SIGMOID, true); else PAIR_FWD(CLV_GATE_SIGMOID, false); }
+#undef PAIR_FWD_ZX
 #undef PAIR_FWD_Z
 #undef PAIR_FWD
   return launch_status();

@@ -303,17 +303,55 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
 // a source row starts at element table[idx] * stride + offset (table optional: then idx itself; stride defaults to
 // row_elems): overlapping windows of a frame store are rows of stride one frame
 struct GatherSeg { const float* src; float* out; const int64_t* table; int64_t row_elems, out_ld, stride, offset;
-                   int chunk, pieces, vec, u8; };
-struct GatherArgs { GatherSeg seg[4]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; };
+                   int chunk, pieces, vec, u8; unsigned char* notes; };
+struct GatherArgs { GatherSeg seg[4]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; int nlist; int list_seg[4]; };
+
+// Note lists (clv_gather_rows_multi_notes): frame p of output row r -> notes[(r * pieces + p) * CLV_NOTE_ROW ..]: the
+// indices of the bytes that are not zero, then CLV_NOTE_NONE up to the end of the row (at least 8 of them: a reader that
+// walks the row 4 bytes at a time always meets the terminator).  One wave per frame: lanes 0..21 take 4 bytes each, the
+// position of a note in the list is a prefix count over four ballots (the order of a list is byte-major, not
+// ascending: the consumer sums kernel rows, any order will do).
+__device__ __forceinline__ void gather_note_lists(const GatherArgs& a, const GatherSeg& sg) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int piece = blockIdx.x * 4 + wave;
+  if (piece >= sg.pieces) return;
+  for (int64_t r = blockIdx.y; r < a.rows; r += gridDim.y) {
+    int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
+    if (sg.table) sr = sg.table[sr];
+    const unsigned char* sp = reinterpret_cast<const unsigned char*>(sg.src) + sr * sg.stride + sg.offset + (int64_t)piece * sg.chunk;
+    const unsigned v = lane < sg.chunk / 4 ? *reinterpret_cast<const unsigned*>(sp + 4 * lane) : 0u;
+    unsigned char* out = sg.notes + ((size_t)r * sg.pieces + piece) * CLV_NOTE_ROW;
+    int before = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool on = ((v >> (8 * j)) & 255u) != 0u;
+      const unsigned long long m = __ballot(on);
+      if (on) out[before + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)(4 * lane + j);
+      before += __popcll(m);
+    }
+    for (int p = before + lane; p < CLV_NOTE_ROW; p += 64) out[p] = (unsigned char)CLV_NOTE_NONE;
+  }
+}
 // grid = (work items of a row / 256, rows, segments): no 64-bit divisions per element (they cost more than the copy)
 __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
+  if ((int)blockIdx.z >= a.nseg) {            // the z-slices behind the copies build note lists
+    const int li = blockIdx.z - a.nseg;
+    int k = a.list_seg[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) k = li == q ? a.list_seg[q] : k;
+    GatherSeg sg = a.seg[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (k == q) sg = a.seg[q];
+    gather_note_lists(a, sg);
+    return;
+  }
   const int si = blockIdx.z;
   const float* src = a.seg[0].src; float* out = a.seg[0].out;
   const int64_t* table = a.seg[0].table;
   int64_t row_elems = a.seg[0].row_elems, out_ld = a.seg[0].out_ld, stride = a.seg[0].stride, offset = a.seg[0].offset;
   int chunk = a.seg[0].chunk, pieces = a.seg[0].pieces, vec = a.seg[0].vec, u8 = a.seg[0].u8;
 #pragma unroll
-  for (int k = 1; k < 3; ++k)
+  for (int k = 1; k < 4; ++k)
     if (si == k) { src = a.seg[k].src; out = a.seg[k].out; table = a.seg[k].table; row_elems = a.seg[k].row_elems;
                    out_ld = a.seg[k].out_ld; stride = a.seg[k].stride; offset = a.seg[k].offset;
                    chunk = a.seg[k].chunk; pieces = a.seg[k].pieces; vec = a.seg[k].vec; u8 = a.seg[k].u8; }
@@ -488,6 +526,15 @@ extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t r
                                      const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
                                      const int64_t* src_stride, const int64_t* src_offset,
                                      const int64_t* const* src_table, void* stream) {
+  return clv_gather_rows_multi_notes(rows, idx, row0, nseg, src, src_u8, out, row_elems, chunk, out_ld, src_stride,
+                                     src_offset, src_table, nullptr, stream);
+}
+
+extern "C" int clv_gather_rows_multi_notes(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
+                                           const void* const* src, const int32_t* src_u8, float* const* out,
+                                           const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
+                                           const int64_t* src_stride, const int64_t* src_offset,
+                                           const int64_t* const* src_table, unsigned char* const* notes_out, void* stream) {
   if (rows <= 0 || nseg < 1 || nseg > 4 || !src || !out || !row_elems || !chunk || !out_ld) return CLV_EINVAL;
   GatherArgs a;
   memset(&a, 0, sizeof(a));
@@ -505,14 +552,20 @@ extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t r
     const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % salign == 0 &&
                     stride % ealign == 0 && offset % ealign == 0 && ((uintptr_t)out[k]) % 16 == 0;
     a.seg[k] = GatherSeg{(const float*)src[k], out[k], src_table ? src_table[k] : nullptr, row_elems[k], ld, stride, offset,
-                         (int)ch, (int)(row_elems[k] / ch), vec, u8};
-    const int64_t w = row_elems[k] / (vec ? 4 : 1);
+                         (int)ch, (int)(row_elems[k] / ch), vec, u8, notes_out ? notes_out[k] : nullptr};
+    int64_t w = row_elems[k] / (vec ? 4 : 1);
+    if (a.seg[k].notes) {      // byte frames of at most 88 notes, read 4 bytes per lane
+      if (!u8 || ch > CLV_NOTE_NONE || ch % 4 || stride % 4 || offset % 4 || ((uintptr_t)src[k]) % 4) return CLV_EINVAL;
+      a.list_seg[a.nlist++] = k;
+      const int64_t wl = (a.seg[k].pieces + 3) / 4 * 256;      // a wave per frame, 4 frames per block
+      w = wl > w ? wl : w;
+    }
     maxw = w > maxw ? w : maxw;
   }
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("gather_rows", s);
-  hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)((maxw + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535), nseg),
-                     dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)((maxw + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535),
+                                               nseg + a.nlist), dim3(256), 0, s, a);
   return launch_status();
 }
 

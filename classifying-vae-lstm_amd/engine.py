@@ -538,6 +538,19 @@ class VrnnEngine(_EngineBase):
         # kept as uint8), which lets the frame rows use one bf16 piece instead of three
         self.bf16_wgrad = bool(cfg.get('bf16_wgrad', os.environ.get('CLV_BF16_WGRAD', '1') != '0'))
         self.frames_exact_bf16 = bool(cfg.get('frames_exact_bf16', False))
+        # Note lists (opt-in: cfg['fuse_notes'] / CLV_FUSE_NOTES=1): when the batch was staged from BINARY uint8 frames,
+        # the staging launch also writes each frame's list of notes (ops.gather_rows_multi(notes=...)) and the pair
+        # forward kernel gathers the LSTM input projections itself -- no projection launch, no [B*T,352] round trip per
+        # LSTM.  Measured (profiles/r03_notes_fusion_ab.txt): it LOSES on MI355X -- every CU re-gathers ~11 KB of kernel
+        # rows per step through its L1 miss path (~10 B/cycle per CU), +48 us on the pair kernel for the 26 us launch it
+        # removes -- so the default stays the projection launch, whose workgroups keep K_x in LDS.
+        # notes_valid: the lists describe the frames now in X / XZ (TrainStep sets it per staged batch).
+        self.fuse_notes = bool(cfg.get('fuse_notes', os.environ.get('CLV_FUSE_NOTES', '0') == '1')) and self.fuse_pair \
+            and self.sparse_inputs and D == ops.NOTE_NONE
+        self.notes_valid = False
+        if self.fuse_notes:
+            self.notes_enc = torch.full((BT, ops.NOTE_ROW), ops.NOTE_NONE, dtype=torch.uint8, device=d)
+            self.notes_dec = torch.full((BT, ops.NOTE_ROW), ops.NOTE_NONE, dtype=torch.uint8, device=d)
         self.hW = _f(d, B, D)
         self.wargs = _f(d, B, 2 * (Cn - 1))
         self.W = _f(d, B, Cn)
@@ -687,7 +700,11 @@ class VrnnEngine(_EngineBase):
         # this step's recurrent kernels, K_z and the head kernel in the lane order of the pair kernels (both passes)
         ops.lstm_pair_pack(L, P.p('encoder_h/recurrent_kernel'), P.p('decoder_h/recurrent_kernel'),
                            P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), self.pair_pack)
-        if self.sparse_inputs:     # piano-roll frames are ~4 % nonzero: add the kernel rows of the notes that are on
+        notes = None
+        if self.fuse_notes and self.notes_valid:      # the projections are gathered inside the pair kernel
+            notes = (self.notes_enc, P.p('encoder_h/kernel'), self.notes_dec if off else None,
+                     P.p('decoder_h/kernel') if off else None)
+        elif self.sparse_inputs:     # piano-roll frames are ~4 % nonzero: add the kernel rows of the notes that are on
             if off:        # both LSTMs in one launch
                 ops.sparse_proj2(BT, G4, (D, X, D, P.p('encoder_h/kernel'), self.gates_enc),
                                  (off, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec))
@@ -701,7 +718,7 @@ class VrnnEngine(_EngineBase):
         nz = getattr(self, '_noise', None)
         ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, self.gates_dec, off > 0, self.wk_dec, self.pair_pack,
                           P.p('Zargs/bias'), eps_Z, self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z,
-                          self.xz_ld, self.klterm, gate_act=self.gate_act, noise=nz[1] if nz else None)
+                          self.xz_ld, self.klterm, gate_act=self.gate_act, noise=nz[1] if nz else None, notes=notes)
         self._output_head(X if target is None else target, nll)
 
     def xp_view(self):

@@ -292,12 +292,16 @@ def lstm_pair_pack(L, U_enc, U_dec, Kz, Wz, pack, H=88):
 
 
 def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, gates_dec, dec_has_xproj, rb_dec, pack, bz, eps,
-                  hs_enc, aux_enc, hs_dec, aux_dec, zargs, Z, ldz, klterm, gate_act=0, H=88, noise=None):
-    """aux_* [B*T, 2H]: (kcarry, kc) of the backward pass; noise: a noise_draw(): eps is drawn in the kernel."""
+                  hs_enc, aux_enc, hs_dec, aux_dec, zargs, Z, ldz, klterm, gate_act=0, H=88, noise=None, notes=None):
+    """aux_* [B*T, 2H]: (kcarry, kc) of the backward pass; noise: a noise_draw(): eps is drawn in the kernel;
+    notes = (notes_enc, Kx_enc, notes_dec, Kx_dec): the input projections are gathered in the kernel from note lists
+    (gather_rows_multi(notes=...)) and the kernels' frame rows; gates_* are then outputs only."""
+    ne, ke, nd, kd = notes if notes is not None else (None, None, None, None)
     check(_lib.lib().clv_lstm_pair_fwd(B, T, H, L, gate_act, _ptr(gates_enc), _ptr(rb_enc), _ptr(gates_dec),
                                        int(bool(dec_has_xproj)), _ptr(rb_dec), _ptr(pack), _ptr(bz),
                                        _ptr(eps), _ptr(hs_enc), _ptr(aux_enc), _ptr(hs_dec), _ptr(aux_dec), _ptr(zargs),
-                                       _ptr(Z), ldz, _ptr(klterm), _noise_ref(noise), _stream()), "clv_lstm_pair_fwd")
+                                       _ptr(Z), ldz, _ptr(klterm), _ptr(ne), _ptr(ke), _ptr(nd), _ptr(kd), _noise_ref(noise),
+                                       _stream()), "clv_lstm_pair_fwd")
 
 
 def lstm_pair_bwd(B, T, L, kl_scale, pack, Wz, dhs_dec, cs_dec, cs_enc, gates_dec, gates_enc, dzsum_dec,
@@ -385,10 +389,15 @@ def gather_rows(rows, row_elems, src, idx, out, chunk=0, out_ld=0):
           "clv_gather_rows")
 
 
-def gather_rows_multi(rows, idx, segs, row0=0):
+NOTE_ROW, NOTE_NONE = 96, 88       # CLV_NOTE_ROW / CLV_NOTE_NONE (include/clvae.h)
+
+
+def gather_rows_multi(rows, idx, segs, row0=0, notes=None):
     """segs: up to 4 (src, out, row_elems, chunk, out_ld[, stride, offset, table]); one launch; idx None = rows
     row0..row0+rows-1.  A uint8 src (binary frames kept as bytes) is converted to float on the way.  With (stride,
-    offset, table) source row r starts at element table[idx[r]] * stride + offset: windows of a frame store."""
+    offset, table) source row r starts at element table[idx[r]] * stride + offset: windows of a frame store.
+    notes: per segment None or a uint8 tensor [rows * pieces, NOTE_ROW] that receives the frames' note lists (uint8
+    sources of binary frames only): what lstm_pair_fwd gathers the input projections from."""
     n = len(segs)
     P, I, U = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     src = P(*[s_[0].data_ptr() for s_ in segs])
@@ -401,6 +410,11 @@ def gather_rows_multi(rows, idx, segs, row0=0):
     st = I(*[int(e[0]) for e in ext])
     of = I(*[int(e[1]) for e in ext])
     tb = P(*[(e[2].data_ptr() if e[2] is not None else None) for e in ext])
+    if notes is not None and any(t is not None for t in notes):
+        nt = P(*[(t.data_ptr() if t is not None else None) for t in notes])
+        check(_lib.lib().clv_gather_rows_multi_notes(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, nt,
+                                                     _stream()), "clv_gather_rows_multi_notes")
+        return
     check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, _stream()),
           "clv_gather_rows_multi")
 

@@ -149,7 +149,7 @@ class TrainStep:
             self.eng.frames_exact_bf16 = exact
             self.recapture()
         c, cx = src(cur)
-        segs = [(c, self.X, row, 0, 0) + cx]
+        segs = [(c, self.X, row, D, D) + cx]          # frame by frame (the same bytes as one piece; note lists are per frame)
         if hist is not None:
             h, hx = src(hist)
             if self.xp_ld:      # history frames go straight into the [Xp | Z] decoder-input buffer
@@ -162,16 +162,49 @@ class TrainStep:
             segs.append((t, self.Y, row, 0, 0) + tx)
         return segs
 
+    def _note_outputs(self, cur, hist, nseg):
+        """Note-list outputs of the staging launch (VrnnEngine.fuse_notes): the current and the history frames get lists
+        when both come from uint8 stores that hold only 0 / 1 (checked once per store: a list says which notes are on,
+        not how loud).  Tells the engine whether its lists describe the staged batch (baked into the captured step)."""
+        eng = self.eng
+        if not getattr(eng, 'fuse_notes', False):
+            return None
+        need = [cur, hist] if eng.off else [cur]           # a decoder without history frames needs no list of them
+        ok = all(x is not None and self._is_binary_u8(x.store if isinstance(x, DevWindows) else x) for x in need)
+        if eng.notes_valid != ok:
+            eng.notes_valid = ok
+            self.recapture()
+        if not ok:
+            return None
+        out = [None] * nseg                                # segments: current frames, [history frames], labels, [targets]
+        out[0] = eng.notes_enc
+        if eng.off:
+            out[1] = eng.notes_dec
+        return out
+
+    def _is_binary_u8(self, t):
+        """uint8 and every value 0 or 1; one reduction (and host sync) per distinct storage, remembered."""
+        if t.dtype != torch.uint8:
+            return False
+        key = (t.untyped_storage().data_ptr(), t.untyped_storage().nbytes())
+        cache = self.__dict__.setdefault('_binary_stores', {})
+        if key not in cache:
+            whole = torch.empty(0, dtype=torch.uint8, device=t.device).set_(t.untyped_storage())
+            cache[key] = bool((whole <= 1).all().item())
+        return cache[key]
+
     def stage_batch(self, X, Xp, w_true, target=None):
         """Copy one batch (contiguous device tensors) into the fixed staging buffers: one launch."""
         self.set_target(target is not None)
-        ops.gather_rows_multi(self.eng.B, None, self._segments(X, Xp, w_true, target))
+        segs = self._segments(X, Xp, w_true, target)
+        ops.gather_rows_multi(self.eng.B, None, segs, notes=self._note_outputs(X, Xp, len(segs)))
 
     def gather_batch(self, d_cur, d_hist, d_w, ib, row0=0, d_target=None):
         """Assemble the batch rows `ib` (device int64 indices; None = rows row0..row0+B-1) from the HBM-resident
         data set (frames float32 or uint8): one launch."""
         self.set_target(d_target is not None)
-        ops.gather_rows_multi(self.eng.B, ib, self._segments(d_cur, d_hist, d_w, d_target), row0=row0)
+        segs = self._segments(d_cur, d_hist, d_w, d_target)
+        ops.gather_rows_multi(self.eng.B, ib, segs, row0=row0, notes=self._note_outputs(d_cur, d_hist, len(segs)))
 
     def _eager(self):
         self._main()

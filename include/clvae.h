@@ -216,6 +216,10 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  *   rowbias_* : [B,4H] per-row bias (W.K_w + b)
  *   zargs [B*T,2L], Z: B*T rows of stride ldz, klterm [B*T,L] = L * KL_l (the mean over ALL entries is
  *   the per-frame KL, which is what clv_loss_sums computes).
+ * notes_enc != NULL: the input projections are formed INSIDE the kernel from note lists (clv_gather_rows_multi_notes:
+ *   notes_enc [B*T, CLV_NOTE_ROW] of the frames x_t, notes_dec of x_{t-1}) and the kernels' frame rows Kx_enc / Kx_dec
+ *   [88,4H] (rows 0..87 of encoder_h/kernel, decoder_h/kernel); gates_* are then outputs only and no projection launch
+ *   (clv_sparse_proj / GEMM) is needed.  Binary frames only (a list says which notes are on, not how loud).
  * Initial states are zero (training windows: cl_vrnn/model.py builds stateless LSTMs for training).
  * clv_lstm_pair_supported: H == 88 and 1 <= L <= 8 (the forward kernel alone carries L <= 16); otherwise
  * use the separate kernels.
@@ -238,7 +242,10 @@ int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                       float* gates_dec, int dec_has_xproj, const float* rowbias_dec,
                       const float* pack, const float* bz, float* eps,
                       float* hs_enc, float* aux_enc, float* hs_dec, float* aux_dec,
-                      float* zargs, float* Z, int ldz, float* klterm, const clv_noise_draw* noise, void* stream);
+                      float* zargs, float* Z, int ldz, float* klterm,
+                      const unsigned char* notes_enc, const float* Kx_enc,
+                      const unsigned char* notes_dec, const float* Kx_dec,
+                      const clv_noise_draw* noise, void* stream);
 int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
                       const float* pack, const float* Wz,
                       const float* dhs_dec, const float* aux_dec, const float* aux_enc,
@@ -442,6 +449,17 @@ int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int
  * uint8, and the sliding windows of utils/pianoroll.py:49-71 are never materialised).
  * src_u8 (may be NULL): src_u8[k] != 0 marks a uint8 source (binary piano-roll frames kept as bytes in HBM,
  * a quarter of the footprint and of the gather's read traffic); the output is float either way. */
+/* clv_gather_rows_multi_notes: the same launch also writes NOTE LISTS for the segments whose notes_out[k] is not NULL
+ * (uint8 sources of binary frames, chunk[k] <= 88 and a multiple of 4): frame p of output row r gets CLV_NOTE_ROW bytes
+ * at notes_out[k] + (r * pieces + p) * CLV_NOTE_ROW -- the indices of its nonzero bytes (any order), then CLV_NOTE_NONE
+ * up to the end of the row.  clv_lstm_pair_fwd gathers the LSTM input projections x_t . K_x from such lists. */
+#define CLV_NOTE_ROW 96
+#define CLV_NOTE_NONE 88
+int clv_gather_rows_multi_notes(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
+                                const void* const* src, const int32_t* src_u8, float* const* out,
+                                const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
+                                const int64_t* src_stride, const int64_t* src_offset,
+                                const int64_t* const* src_table, unsigned char* const* notes_out, void* stream);
 int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                           const void* const* src, const int32_t* src_u8, float* const* out,
                           const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,

@@ -10,6 +10,7 @@ import pytest
 torch = pytest.importorskip("torch")
 
 from oracle import clvae_oracle as O
+from oracle import philox as OP
 
 pytestmark = pytest.mark.gpu
 
@@ -452,6 +453,63 @@ def test_cl_vrnn_step_draws_its_own_noise(dev, B, Tn, L, pair):
     assert torch.equal(a.P.grads, b.P.grads)
     la, lb = a.losses(), b.losses()
     assert all(la[k] == lb[k] for k in la)
+
+
+@pytest.mark.parametrize("B,Tn,L,use_x_prev,dense", [(6, 16, 2, True, 0.0443), (5, 7, 8, True, 0.15), (4, 9, 3, False, 0.0443),
+                                                     (256, 128, 2, True, 0.0443)])
+def test_cl_vrnn_step_from_note_lists_matches_oracle(dev, B, Tn, L, use_x_prev, dense):
+    """The fused input projections (cfg['fuse_notes']): the batch is staged from byte frames, the staging launch writes
+    the frames' note lists, and the pair forward kernel gathers both LSTM input projections from them (no projection
+    launch); noise drawn in the kernels.  Against the fp64 oracle on the same frames / noise: losses, logits, states, every
+    gradient.  Odd sequence lengths, frames with more than 8 notes (dense = 0.15: 13 on average), a decoder without
+    history frames, and the benchmark's shape."""
+    from clvae_amd import ops
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    Cn = 10
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=use_x_prev)
+    cfg['fuse_notes'] = True                # opt-in: slower than the projection launch on MI355X (see VrnnEngine)
+    rng = np.random.default_rng(B + Tn + L)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=5).items()}
+    win = (rng.random((B, Tn + 1, 88)) < dense).astype(np.uint8)
+    win[0, 1] = 0                                           # a frame without notes
+    if dense > 0.1:
+        win[1, 2] = 1                                       # and one with all 88
+    wt = np.eye(Cn, dtype=np.float32)[rng.integers(0, Cn, B)]
+    eng = VrnnEngine(cfg, B, dev)
+    assert eng.fuse_pair and eng.fuse_notes
+    eng.P.set_weights(p)
+    eng.P.iterations.fill_(3)
+    ts = TrainStep(eng, seed=77, use_graph=False)
+    d_win = torch.as_tensor(win, device=dev)
+    ts.stage_batch(d_win[:, 1:].contiguous(), d_win[:, :-1].contiguous(), torch.as_tensor(wt, device=dev))
+    assert eng.notes_valid
+    ts._main()                                              # noise + forward + losses + backward (early part)
+    ts._tail()
+    torch.cuda.synchronize()
+    X, Xp = win[:, 1:].astype(np.float64), win[:, :-1].astype(np.float64)
+    eW, eZ = f32(N(ts.eps_w)), f32(N(ts.eps_z)).reshape(B, Tn, L)
+    seed, sw, sz, fw, fz, step, _ = ts.noise_spec()
+    np.testing.assert_allclose(N(ts.eps_z).ravel(), OP.normal(B * Tn * L, seed, 3, sz, fz), atol=2e-5)
+    ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt.astype(np.float64), eW, eZ)
+    got = eng.losses()
+    for k in ('elbo', 'vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, (k, got[k], ref[k])
+    assert np.abs(N(eng.logits).reshape(B, Tn, 88) - ref['cache']['logits']).max() < LOGIT_TOL
+    np.testing.assert_allclose(N(eng.hs_enc).reshape(B, Tn, 88), ref['cache']['enc_h'], atol=5e-5)
+    np.testing.assert_allclose(N(eng.hs_dec).reshape(B, Tn, 88), ref['cache']['dec_h'], atol=5e-5)
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'], tol=3e-4)
+    # the same step from the same bytes without the lists (projection launch): the two paths agree to rounding
+    eng2 = VrnnEngine(dict(cfg, fuse_notes=False), B, dev)
+    eng2.P.set_weights(p)
+    eng2.P.iterations.fill_(3)
+    ts2 = TrainStep(eng2, seed=77, use_graph=False)
+    ts2.stage_batch(d_win[:, 1:].contiguous(), d_win[:, :-1].contiguous(), torch.as_tensor(wt, device=dev))
+    assert not eng2.fuse_notes and not eng2.notes_valid
+    ts2._main(); ts2._tail()
+    torch.cuda.synchronize()
+    assert abs(eng2.losses()['elbo'] - got['elbo']) < 1e-4
+    np.testing.assert_allclose(N(eng2.hs_dec), N(eng.hs_dec), atol=2e-5)
 
 
 def test_cl_vae_bf16_step_tolerance(dev):

@@ -590,6 +590,37 @@ def test_gather_rows_multi_uint8_store(dev, rows, n, row, chunk, ld, use_idx):
     np.testing.assert_array_equal(wout[0].cpu().numpy(), Wl[sel])
 
 
+@pytest.mark.parametrize("rows,pieces,use_idx,dense", [(5, 7, False, 0.05), (33, 16, True, 0.05), (4, 128, True, 0.3), (3, 2, False, 1.0)])
+def test_gather_note_lists(dev, rows, pieces, use_idx, dense):
+    """clv_gather_rows_multi_notes: next to the float copy of the frames, every frame's NOTE LIST -- the indices of its
+    nonzero bytes (any order), then CLV_NOTE_NONE up to the end of the 96-byte row; frames with no note, more than 8 notes
+    and all 88 notes; windows of a frame store through a start table."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(rows * 100 + pieces)
+    D = 88
+    nwin = rows + 3
+    store = (rng.random((nwin + pieces + 2, D)) < dense).astype(np.uint8)
+    store[1] = 0
+    starts = torch.as_tensor(np.arange(nwin, dtype=np.int64), device=dev)
+    d_store = torch.as_tensor(store, device=dev)
+    idx = torch.as_tensor(rng.permutation(nwin)[:rows].astype(np.int64), device=dev) if use_idx else None
+    out = torch.full((rows, pieces, D), -1.0, device=dev)
+    notes = torch.zeros(rows * pieces, ops.NOTE_ROW, dtype=torch.uint8, device=dev)
+    # window i = frames starts[i] + 1 .. + pieces of the store (stride one frame, offset one frame)
+    ops.gather_rows_multi(rows, idx, [(d_store, out, pieces * D, D, D, D, D, starts)], row0=2, notes=[notes])
+    torch.cuda.synchronize()
+    sel = idx.cpu().numpy() if use_idx else np.arange(2, 2 + rows)
+    want = np.stack([store[i + 1:i + 1 + pieces] for i in sel])
+    np.testing.assert_array_equal(out.cpu().numpy(), want.astype(np.float32))
+    got = notes.cpu().numpy().reshape(rows, pieces, ops.NOTE_ROW)
+    for r in range(rows):
+        for p in range(pieces):
+            on = np.flatnonzero(want[r, p])
+            row = got[r, p]
+            assert sorted(row[:on.size].tolist()) == on.tolist(), (r, p)
+            assert (row[on.size:] == ops.NOTE_NONE).all()
+
+
 @pytest.mark.parametrize("R,defer,store", [(1, False, True), (37, False, True), (128, True, True), (1000, True, False),
                                            (4096, True, True), (128 * 300 + 5, True, False)])
 def test_out_head_train_matches_numpy(dev, R, defer, store):
