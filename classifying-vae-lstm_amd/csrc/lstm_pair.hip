@@ -225,6 +225,15 @@ __device__ __forceinline__ float reduce_scatter4(float a0, float a1, float a2, f
 
 template <int P> struct ParC { static constexpr int value = P; };
 
+// PAIR_CONTIG=1 (measurement build): the forward's one load and three stores per step in the contiguous lane order, through
+// ds_bpermute.  rocprofv3, same session (tools/sessions/r03_contig.sh, profiles/r03_pair_lane_order_ab.txt): 100.5 us
+// against 95.5-96.5 us in the recurrence's own order -- with so few accesses per step the permutes' latency on the step's
+// critical path costs more than the line lookups they save (with the 8 loads of the fused projections it is the other
+// way round: that path always uses the contiguous order).
+#ifndef PAIR_CONTIG
+#define PAIR_CONTIG 0
+#endif
+
 // Per-step global accesses are buffer instructions: a resource descriptor per array (base = this batch row's first
 // frame, num_records = its T frames: 4 SGPRs), the lane's byte offset in ONE VGPR that never changes, the step's row offset
 // in an SGPR.  No vector address arithmetic at all, and a lane that has nothing to store (or load) gets an offset
@@ -241,6 +250,9 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff
 }
 __device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float lane_permute(int addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
 // Every load of the prologue (weights, the first two steps' values) has landed before the step loop is entered: the
@@ -335,13 +347,13 @@ struct XProj {
   }
   // ds_bpermute address that brings lane (4 j + g) the value of lane (16 g + j)
   __device__ __forceinline__ static int perm_addr(int lane) { return 4 * (16 * (lane & 3) + (lane >> 2)); }
+  // ds_bpermute address for the way back (stores): lane (16 g + j) takes the value of lane (4 j + g)
+  __device__ __forceinline__ static int perm_addr_inv(int lane) { return 4 * (4 * (lane & 15) + (lane >> 4)); }
   __device__ __forceinline__ static float sum(const XSet<XL>& x, float rb, int paddr, float mask = 1.f) {
-    if constexpr (XL) {
-      const float t = ((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])) + ((x.v[4] + x.v[5]) + (x.v[6] + x.v[7]));
-      return fmaf(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(paddr, __builtin_bit_cast(int, t))), mask, rb);
-    } else {
-      return x.v[0] + rb;
-    }
+    float t = x.v[0];
+    if constexpr (XL) t = ((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])) + ((x.v[4] + x.v[5]) + (x.v[6] + x.v[7]));
+    if constexpr (XL || PAIR_CONTIG) t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(paddr, __builtin_bit_cast(int, t)));
+    return fmaf(t, mask, rb);
   }
 };
 
@@ -380,17 +392,26 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   const rsrc_t r_za = make_rsrc(a.zargs + bt0 * 2 * L, T * 2 * L * 4);
   const rsrc_t r_z = make_rsrc(a.Z + bt0 * a.ldz, T * a.ldz * 4);
   const rsrc_t r_kl = make_rsrc(a.klterm + bt0 * L, T * L * 4);
-  const unsigned vo_g = is_z ? BUF_OOB : loff * 4;
+  // The CONTIGUOUS lane order (lane 16 g + j <-> gate g of unit u0 + j: four runs of 64 bytes per wave) with a
+  // ds_bpermute from / to the recurrence's (unit, k-slice) order: in the latter the four lanes of a quad touch four
+  // different 64-byte pieces and the texture path looks up a line per (quad, piece) -- 64 lookups per wave access
+  // instead of 4.  Pays for the 8 loads of the fused projections (profiles/r03_notes_fusion_ab.txt), not for the one load
+  // and three stores of the default path: see PAIR_CONTIG
+  const int cg = lane >> 4, cj = lane & 15, cu_raw = wave * 16 + cj, cu = min(cu_raw, LH - 1);
+  const bool c_is_z = LATW && cu_raw >= LH && 2 * (cu_raw - LH) < L;          // the slot of a latent group
+  const int paddr_inv = XProj<XL>::perm_addr_inv(lane);
+  const unsigned vo_g = PAIR_CONTIG ? (c_is_z ? BUF_OOB : (unsigned)(cg * LH + cu) * 4u) : (is_z ? BUF_OOB : loff * 4);
   XProj<XL> xp;
   xp.r_kx = XL ? make_rsrc(a.Kx_e, CLV_NOTE_NONE * LG * 4) : r_g;
-  // XL: contiguous lane order for the loads (latent lanes mask what arrives: xmask)
-  xp.vo = XL ? XProj<XL>::load_offset(wave * 16, lane, LH) : loff * 4;
+  // contiguous lane order for the loads (latent lanes mask what arrives: xmask)
+  xp.vo = (XL || PAIR_CONTIG) ? XProj<XL>::load_offset(wave * 16, lane, LH) : loff * 4;
   const int paddr = XProj<XL>::perm_addr(lane);
   xp.nrow = XProj<XL>::as_notes(a.notes_e + (XL ? bt0 * CLV_NOTE_ROW : 0));
   xp.r_n = XL ? make_rsrc(a.notes_e + bt0 * CLV_NOTE_ROW, T * CLV_NOTE_ROW) : r_g;
   xp.T = T;
-  const unsigned vo_h = (!is_z && s == 0) ? u * 4 : BUF_OOB;
-  const unsigned vo_a = (!is_z && (s == 1 || s == 2)) ? ((s - 1) * LH + u) * 4 : BUF_OOB;
+  const unsigned vo_h = PAIR_CONTIG ? ((!c_is_z && cg == 0) ? cu * 4 : BUF_OOB) : ((!is_z && s == 0) ? u * 4 : BUF_OOB);
+  const unsigned vo_a = PAIR_CONTIG ? ((!c_is_z && (cg == 1 || cg == 2)) ? ((cg - 1) * LH + cu) * 4 : BUF_OOB)
+                                    : ((!is_z && (s == 1 || s == 2)) ? ((s - 1) * LH + u) * 4 : BUF_OOB);
   const unsigned vo_e = (lat_ok ? lat : 0) * 4;
   const unsigned vo_za = lat_ok ? zcol * 4 : BUF_OOB;
   const unsigned vo_z = (lat_ok && s < 2) ? lat * 4 : BUF_OOB;
@@ -442,7 +463,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   auto step = [&](auto parc, int i, XSet<XL>& xa, uint2& na, float& ea) {
     constexpr int cur = decltype(parc)::value;
     XProj<XL>::pin(xa);
-    float xv = (LATW && !XL) ? fmaf(xa.v[0], xmask, rb) : XProj<XL>::sum(xa, rb, paddr, LATW ? xmask : 1.f);
+    float xv = XProj<XL>::sum(xa, rb, paddr, LATW ? xmask : 1.f);
     if constexpr (XL) { if (xa.more) xv = fmaf(xp.extra(i, paddr), LATW ? xmask : 1.f, xv); }
     PTOP(xv);
     const float z = gate_sum(&hb[cur][PKP * s], xv);
@@ -456,9 +477,11 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
       if (lat_ok && s < 2) hbd[cur ^ 1][zslot] = zv;
       store_latent(max(i - 1, 0), z, zv, klv);
     }
-    buf_store(vA, r_g, vo_g, (unsigned)i * (unsigned)(LG * 4));
-    buf_store(h, r_h, vo_h, (unsigned)i * (unsigned)(LH * 4));
-    buf_store(Sel4::pick(sm.m1, act, kc), r_a, vo_a, (unsigned)i * (unsigned)(2 * LH * 4));
+    float pA = vA, pB = Sel4::pick(sm.m2, kc, Sel4::pick(sm.m1, act, h));             // (h, kcarry, kc, -)[s]
+    if (PAIR_CONTIG) { pA = lane_permute(paddr_inv, pA); pB = lane_permute(paddr_inv, pB); }      // -> lane 16 g + j
+    buf_store(pA, r_g, vo_g, (unsigned)i * (unsigned)(LG * 4));
+    buf_store(pB, r_h, vo_h, (unsigned)i * (unsigned)(LH * 4));
+    buf_store(pB, r_a, vo_a, (unsigned)i * (unsigned)(2 * LH * 4));
     // the loads of step i+2 into the registers this step has just consumed; issued BEHIND the stores, so that the wait at
     // the top of step i+2 lets everything step i+1 issues stay in flight
     xp.load(xa, na, i + 2);
@@ -513,11 +536,15 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   const rsrc_t r_g = make_rsrc(a.gates_d + bt0 * LG, T * LG * 4);       // x_{t-1}.K_x in, k out (same buffer)
   const rsrc_t r_h = make_rsrc(a.hs_d + bt0 * LH, T * LH * 4);
   const rsrc_t r_a = make_rsrc(a.aux_d + bt0 * 2 * LH, T * 2 * LH * 4);
-  const unsigned vo_h = s == 0 ? u * 4 : BUF_OOB;
-  const unsigned vo_a = (s == 1 || s == 2) ? ((s - 1) * LH + u) * 4 : BUF_OOB;
+  const int cg = lane >> 4, cu = min(wave * 16 + (lane & 15), LH - 1);        // contiguous order: see the encoder
+  const int paddr_inv = XProj<XL>::perm_addr_inv(lane);
+  const unsigned vo_g = PAIR_CONTIG ? (unsigned)(cg * LH + cu) * 4u : loff * 4;
+  const unsigned vo_h = PAIR_CONTIG ? (cg == 0 ? cu * 4 : BUF_OOB) : (s == 0 ? u * 4 : BUF_OOB);
+  const unsigned vo_a = PAIR_CONTIG ? ((cg == 1 || cg == 2) ? ((cg - 1) * LH + cu) * 4 : BUF_OOB)
+                                    : ((s == 1 || s == 2) ? ((s - 1) * LH + u) * 4 : BUF_OOB);
   XProj<XL> xp;
   xp.r_kx = XL ? make_rsrc(a.Kx_d, CLV_NOTE_NONE * LG * 4) : r_g;
-  xp.vo = XL ? XProj<XL>::load_offset(wave * 16, lane, LH) : loff * 4;
+  xp.vo = (XL || PAIR_CONTIG) ? XProj<XL>::load_offset(wave * 16, lane, LH) : loff * 4;
   const int paddr = XProj<XL>::perm_addr(lane);
   xp.nrow = XProj<XL>::as_notes(a.notes_d + (XL ? bt0 * CLV_NOTE_ROW : 0));
   xp.r_n = XL ? make_rsrc(a.notes_d + bt0 * CLV_NOTE_ROW, T * CLV_NOTE_ROW) : r_g;
@@ -570,9 +597,11 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     const float h = pair_cell<GATE>(sm, z, c, vA, act, kc);
     PSTAMP(5, h);
     hb[cur ^ 1][hslot] = h;
-    buf_store(vA, r_g, loff * 4, (unsigned)t * (unsigned)(LG * 4));
-    buf_store(h, r_h, vo_h, (unsigned)t * (unsigned)(LH * 4));
-    buf_store(Sel4::pick(sm.m1, act, kc), r_a, vo_a, (unsigned)t * (unsigned)(2 * LH * 4));
+    float pA = vA, pB = Sel4::pick(sm.m2, kc, Sel4::pick(sm.m1, act, h));
+    if (PAIR_CONTIG) { pA = lane_permute(paddr_inv, pA); pB = lane_permute(paddr_inv, pB); }
+    buf_store(pA, r_g, vo_g, (unsigned)t * (unsigned)(LG * 4));
+    buf_store(pB, r_h, vo_h, (unsigned)t * (unsigned)(LH * 4));
+    buf_store(pB, r_a, vo_a, (unsigned)t * (unsigned)(2 * LH * 4));
     if constexpr (HASXP) {              // behind the stores: see the encoder
       xp.load(xa, na, t + 2);
       if constexpr (XL) na = xp.notes(t + 4);
