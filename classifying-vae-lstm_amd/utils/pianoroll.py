@@ -107,119 +107,97 @@ def _load_pickle(path):
             return pickle.load(f, encoding='latin1')      # Python-2 pickles of the reference
 
 
+SPLITS = ('train', 'test', 'valid')          # the order the reference builds them in
+
+
+class _WindowPlan:
+    """Where the windows of one split start.  Every song is rasterised ONCE into a shared uint8 frame store; a window is
+    a start frame in it.  Songs too short for a window contribute frames but no starts, and -- the reference's quirk B2
+    (utils/pianoroll.py:68-71: indices are assigned after the empty songs are dropped) -- the song number of a window
+    counts only the songs that did yield windows unless fix_song_index is set."""
+
+    def __init__(self, songs, window, step, fix_song_index):
+        rolls, starts, owner = [], [], []
+        first_frame = counted = 0
+        for number, song in enumerate(songs):
+            roll = song_to_pianoroll(song, dtype=np.uint8)
+            begin = sliding_inds(roll.shape[0], window, step)
+            if len(begin):
+                starts.append(first_frame + begin)
+                owner.append(np.full(len(begin), number if fix_song_index else counted, dtype=np.float64))
+                counted += 1
+            rolls.append(roll)
+            first_frame += roll.shape[0]
+        self.store = np.vstack(rolls)
+        self.starts = np.hstack(starts)
+        self.song_of_window = np.hstack(owner)
+        self.window = window
+
+    def keep_whole_batches(self, batch_size):
+        """rows beyond the last full batch are dropped (utils/pianoroll.py:154-158)"""
+        if batch_size is not None:
+            n = len(self.starts) - len(self.starts) % batch_size
+            self.starts, self.song_of_window = self.starts[:n], self.song_of_window[:n]
+
+
 class PianoData:
+    """The reference's loader (utils/pianoroll.py:73-158) by attribute: x_<split>, y_<split>, <split>_song_inds and, when the
+    pickle has them, <split>_song_modes, <split>_song_keys and key_map, for split in train / test / valid.
+
+      x: the first seq_length frames of a window; y: the frame after them (return_y_next), or the window shifted by one
+      frame (return_y_hist), or x itself (return_y_next=False).
+      lazy=True: x_* / y_* are `Windows` views of one uint8 frame store per split instead of materialised arrays (same
+      values: np.asarray(view) == the eager array)."""
+
     def __init__(self, train_file, batch_size=None, seq_length=1, step_length=1, return_y_next=True,
                  return_y_hist=False, squeeze_x=True, squeeze_y=True, use_rel_major=True,
                  fix_song_index=False, dtype=np.float64, lazy=False):
-        """lazy=True: x_* / y_* are `Windows` views of one uint8 frame store per split instead of materialised arrays
-        (same values: np.asarray(view) == the eager array)."""
-        D = _load_pickle(train_file)
-        self.lazy = lazy
-        self.train_file = train_file
-        self.batch_size = batch_size
-        self.seq_length = seq_length
-        self.step_length = step_length
-        self.return_y_next = return_y_next
-        self.return_y_hist = return_y_hist
-        self.squeeze_x = squeeze_x
-        self.squeeze_y = squeeze_y
-        self.use_rel_major = use_rel_major
-        self.fix_song_index = fix_song_index
-        self.dtype = dtype
+        for name, value in list(locals().items()):          # every option is a public attribute, like in the reference
+            if name != 'self':
+                setattr(self, name, value)
+        pickled = _load_pickle(train_file)
+        for split in SPLITS:
+            x, y, owner = self._windows_of(pickled[split])
+            setattr(self, 'x_' + split, x)
+            setattr(self, 'y_' + split, y)
+            setattr(self, split + '_song_inds', owner)
+        self._label_windows(pickled)
 
-        self.x_train, self.y_train, self.train_song_inds = self.make_xy(D['train'])
-        self.x_test, self.y_test, self.test_song_inds = self.make_xy(D['test'])
-        self.x_valid, self.y_valid, self.valid_song_inds = self.make_xy(D['valid'])
-
-        if 'train_mode' in D:
-            self.train_song_modes = self.song_modes(D['train_mode'], self.train_song_inds)
-            self.test_song_modes = self.song_modes(D['test_mode'], self.test_song_inds)
-            self.valid_song_modes = self.song_modes(D['valid_mode'], self.valid_song_inds)
-        if 'train_key' in D:
-            D = self.update_keys(D)
-            self.key_map = self.make_keymap(D)
-            self.train_song_keys = self.song_keys(D['train_key'], self.train_song_inds)
-            self.test_song_keys = self.song_keys(D['test_key'], self.test_song_inds)
-            self.valid_song_keys = self.song_keys(D['valid_key'], self.valid_song_inds)
-
-    def make_xy(self, songs):
-        win = self.seq_length + int(self.return_y_next)
-        if self.lazy:
-            return self._make_xy_lazy(songs, win)
-        rolls, inds = [], []
-        kept = 0
-        for si, s in enumerate(songs):
-            r = sliding_window(song_to_pianoroll(s, dtype=np.uint8), win, self.step_length)
-            if len(r) == 0:
-                continue
-            rolls.append(r)
-            # the reference numbers songs AFTER dropping the empty ones (B2)
-            inds.append(np.full(len(r), si if self.fix_song_index else kept, dtype=np.float64))
-            kept += 1
-        x_rolls = np.vstack(rolls).astype(self.dtype)
-        song_inds = np.hstack(inds)
-        x_rolls = self.adjust_for_batch_size(x_rolls)
-        song_inds = self.adjust_for_batch_size(song_inds)
-        if self.return_y_next:
-            y_rolls = x_rolls[:, 1:, :] if self.return_y_hist else x_rolls[:, -1, :]
-            x_rolls = x_rolls[:, :-1, :]
-        else:
-            y_rolls = x_rolls
-        if self.squeeze_x:
-            x_rolls = x_rolls.squeeze()
-        if self.squeeze_y:
-            y_rolls = y_rolls.squeeze()
-        return x_rolls, y_rolls, song_inds
-
-    def _make_xy_lazy(self, songs, win):
-        """The same windows as make_xy, as views: every song is rasterised once into a shared uint8 store and a window
-        is its start frame."""
-        store, starts, inds = [], [], []
-        kept = frames = 0
-        for si, s in enumerate(songs):
-            roll = song_to_pianoroll(s, dtype=np.uint8)
-            st = sliding_inds(roll.shape[0], win, self.step_length)
-            if len(st) > 0:
-                starts.append(frames + st)
-                inds.append(np.full(len(st), si if self.fix_song_index else kept, dtype=np.float64))
-                kept += 1
-            store.append(roll)
-            frames += roll.shape[0]
-        store = np.vstack(store)
-        starts = self.adjust_for_batch_size(np.hstack(starts))
-        song_inds = self.adjust_for_batch_size(np.hstack(inds))
-        T = self.seq_length
-        if self.return_y_next:
-            x = Windows(store, starts, 0, T, self.dtype)
-            y = Windows(store, starts, 1, T, self.dtype) if self.return_y_hist else Windows(store, starts, T, 1, self.dtype)
-        else:
-            x = y = Windows(store, starts, 0, win, self.dtype)
+    # -- frames ---------------------------------------------------------------
+    def _windows_of(self, songs):
+        T, nxt = self.seq_length, int(self.return_y_next)
+        plan = _WindowPlan(songs, T + nxt, self.step_length, self.fix_song_index)
+        plan.keep_whole_batches(self.batch_size)
+        # (first frame, length) of x and y inside a window
+        x_span = (0, T) if nxt else (0, plan.window)
+        y_span = x_span if not nxt else ((1, T) if self.return_y_hist else (T, 1))
+        view = lambda span: Windows(plan.store, plan.starts, span[0], span[1], self.dtype)
+        x, y = view(x_span), (view(y_span) if y_span != x_span else None)
+        if not self.lazy:
+            x = np.asarray(x)
+            y = x if y is None else np.asarray(y)
+        elif y is None:
+            y = x
+        if nxt and not self.return_y_hist and not self.lazy:
+            y = y[:, 0, :]                                   # the reference slices one frame out: [n, 88], not [n, 1, 88]
         if self.squeeze_x:
             x = x.squeeze()
         if self.squeeze_y:
             y = y.squeeze()
-        return x, y, song_inds
+        return x, y, plan.song_of_window
 
-    def song_modes(self, modes, song_inds):
-        return np.array(modes)[song_inds.astype(int)]
-
-    def update_keys(self, D):
-        if not self.use_rel_major:
-            return D
-        for k in ('train_key', 'test_key', 'valid_key'):
-            D[k] = [relative_major(x) for x in D[k]]
-        return D
-
-    def make_keymap(self, D):
-        all_keys = np.unique(np.hstack([D['train_key'], D['test_key'], D['valid_key']]))
-        return dict(zip([str(k) for k in all_keys], range(len(all_keys))))
-
-    def song_keys(self, keys, song_inds):
-        key_inds = [self.key_map[k] for k in keys]
-        return np.array(key_inds)[song_inds.astype(int)]
-
-    def adjust_for_batch_size(self, items):
-        if self.batch_size is None:
-            return items
-        mod = items.shape[0] % self.batch_size
-        return items[:-mod] if mod > 0 else items
+    # -- labels ---------------------------------------------------------------
+    def _label_windows(self, pickled):
+        """Per-window mode and key of the song a window came from; keys as integers through key_map (the sorted union of
+        the three splits' keys, minor keys folded onto their relative major when use_rel_major)."""
+        per_window = lambda values, split: np.array(values)[getattr(self, split + '_song_inds').astype(int)]
+        if 'train_mode' in pickled:
+            for split in SPLITS:
+                setattr(self, split + '_song_modes', per_window(pickled[split + '_mode'], split))
+        if 'train_key' in pickled:
+            fold = relative_major if self.use_rel_major else (lambda k: k)
+            keys = {split: [fold(k) for k in pickled[split + '_key']] for split in SPLITS}
+            names = np.unique(np.hstack([keys[split] for split in SPLITS]))
+            self.key_map = {str(k): i for i, k in enumerate(names)}
+            for split in SPLITS:
+                setattr(self, split + '_song_keys', per_window([self.key_map[k] for k in keys[split]], split))

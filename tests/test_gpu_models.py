@@ -102,6 +102,66 @@ def test_cl_vae_step_matches_oracle(dev, B, L, Cn, use_x_prev, weights, fused):
         np.testing.assert_allclose(w[k], p[k], rtol=2e-3, atol=2e-5, err_msg=k)
 
 
+def _gi(G, prefix):
+    return {k[len(prefix):]: G[k].astype(np.float64) for k in G.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_cl_vae_matches_the_independent_fixture(dev, fused):
+    """The HIP step against tests/golden/g4_independent.npz: losses, logits and gradients that a float64 torch.autograd
+    graph written from cl_vae/model.py:130-224 (no import of oracle/) produced for real JSB frames -- a pin that is not
+    the oracle grading itself.  One note column's logits lie far beyond both Bernoulli clip points."""
+    from helpers import golden
+    from clvae_amd.engine import VaeEngine
+    G = golden("g4_independent.npz")
+    cw, kw, wkw = G['vae/wts']
+    cfg = O.vae_config(latent_dim=4, n_classes=2, use_x_prev=True, class_weight=cw, kl_weight=kw, w_kl_weight=wkw,
+                       w_log_var_prior=float(G['vae/prior']))
+    cfg['fused_step'] = fused
+    B = G['vae/x'].shape[0]
+    eng = VaeEngine(cfg, B, dev)
+    assert eng.fused == fused
+    eng.P.set_weights(_gi(G, 'vae/p/'))
+    eng.loss_and_grads(T(G['vae/x'], dev), T(G['vae/xp'], dev), T(G['vae/wt'], dev), T(G['vae/ew'], dev), T(G['vae/ez'], dev))
+    torch.cuda.synchronize()
+    got = eng.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - float(G['vae/loss/' + k])) <= ELBO_TOL, (k, got[k], float(G['vae/loss/' + k]))
+    assert abs(got['acc'] - float(G['vae/loss/acc'])) < 1e-6
+    ref_l = G['vae/logits']
+    assert np.abs(N(eng.logits) - ref_l).max() < LOGIT_TOL * max(1.0, np.abs(ref_l).max() / 16)
+    check_grads(eng.P.get_weights(eng.P.grads), _gi(G, 'vae/g/'))
+
+
+@pytest.mark.parametrize("pair", [True, False])
+def test_cl_vrnn_matches_the_independent_fixture(dev, pair):
+    """cl_vrnn against the independent fixture (float64 torch.autograd from cl_vrnn/model.py:164-267): every loss term,
+    per-note logits (several note columns sit beyond, between and just inside the two Bernoulli clip points), both LSTMs'
+    states (gate biases push units into the flat regions of the hard sigmoid) and every gradient tensor; the pair
+    kernels and the separate sequence kernels."""
+    from helpers import golden
+    from clvae_amd.engine import VrnnEngine
+    G = golden("g4_independent.npz")
+    cw, kw, wkw = G['vrnn/wts']
+    B, Tn = G['vrnn/X'].shape[:2]
+    cfg = O.vrnn_config(latent_dim=2, seq_length=Tn, n_classes=10, use_x_prev=True, class_weight=cw, kl_weight=kw,
+                        w_kl_weight=wkw, w_log_var_prior=float(G['vrnn/prior']))
+    cfg['fuse_pair'] = pair
+    eng = VrnnEngine(cfg, B, dev)
+    assert eng.fuse_pair == pair
+    eng.P.set_weights(_gi(G, 'vrnn/p/'))
+    eng.loss_and_grads(T(G['vrnn/X'], dev), T(G['vrnn/Xp'], dev), T(G['vrnn/wt'], dev), T(G['vrnn/eW'], dev),
+                       T(G['vrnn/eZ'].reshape(B * Tn, -1), dev))
+    torch.cuda.synchronize()
+    got = eng.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - float(G['vrnn/loss/' + k])) <= ELBO_TOL, (k, got[k], float(G['vrnn/loss/' + k]))
+    assert np.abs(N(eng.logits).reshape(B, Tn, 88) - G['vrnn/logits']).max() < LOGIT_TOL
+    np.testing.assert_allclose(N(eng.hs_enc).reshape(B, Tn, 88), G['vrnn/enc_h'], atol=2e-5)
+    np.testing.assert_allclose(N(eng.hs_dec).reshape(B, Tn, 88), G['vrnn/dec_h'], atol=2e-5)
+    check_grads(eng.P.get_weights(eng.P.grads), _gi(G, 'vrnn/g/'), tol=2e-4)
+
+
 @pytest.mark.parametrize("use_x_prev", [True, False])
 def test_cl_vae_without_hidden_layers_matches_oracle(dev, use_x_prev):
     """--intermediate_dim 0 (cl_vae/model.py:165-167,188): the latent heads read [x, w], the output layer [w, history, z]."""
