@@ -32,6 +32,8 @@ WORKLOADS = {
     'gen1': dict(model='cl_vrnn', B=1, T=256, L=32, C=10, generate=True),
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (never the 2:1-sparsity figure)
+PROFILE_TAGS = ('r03_b', 'r03_a', 'r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01')      # newest committed profile set first
 NOTE_DENSITY = 0.0443        # measured JSB note density
 
 
@@ -163,6 +165,33 @@ def bench_generate(args, w, dev, rank, world):
                           "note_density_out": round(float(out.mean().item()), 4)}))
 
 
+def allreduce_microbench(ts, dev, iters=50):
+    """The step's two gradient buckets alone (N > 1): the hW-kernel bucket and the rest, issued back to back on the side
+    stream like the step issues them, nothing else on the GPU.  Tells a reader of the first multi-GPU run how much of a
+    step the collectives need when nothing hides them."""
+    import torch
+    import torch.distributed as dist
+    ar = ts.ar
+    if ar is None:
+        return None
+    tail_b = 4 * (ar.tail.numel() if ar.tail is not None else 0)
+    main_b = 4 * sum(t.numel() for t in ar.main)
+    keep = ar.flat.clone()
+    for _ in range(5):
+        ar.reduce_tail(); ar.reduce_main(); ar.wait()
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ar.reduce_tail(); ar.reduce_main(); ar.wait()
+    torch.cuda.synchronize()
+    us = 1e6 * (time.perf_counter() - t0) / iters
+    tt = torch.tensor([us], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ar.flat.copy_(keep)
+    return dict(tail_bucket_bytes=tail_b, main_bucket_bytes=main_b, both_buckets_us=round(float(tt.item()), 2),
+                note="two all-reduces (AVG) per step on a side stream; measured alone, max over ranks, %d iterations" % iters)
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -272,10 +301,15 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [round(1e3 * dt / args.steps, 4)]
+    allreduce = None
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [round(1e3 * float(t.item()) / args.steps, 4) for t in every]      # each rank's own clock over the same K steps
+        dt = max(float(t.item()) for t in every)
+        allreduce = allreduce_microbench(ts, dev)
     loss = eng.losses()
     value = world * B * T * args.steps / dt
 
@@ -319,32 +353,68 @@ def main():
             n, ms = by[kname][1], by[kname][2]
             avg_s = ms / n * 1e-3
             achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
-        traffic = step_traffic = None    # HBM bytes from the committed PMC passes (tools/pmc_traffic.sh -> profiles/)
-        for tag in ('r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01'):      # newest committed PMC summary first
+        # HBM bytes: NOT measured in this run -- read from the newest committed PMC summary of the SAME workload and
+        # arithmetic (tools/round_profile.sh -> profiles/<tag>_pmc_traffic_<workload>.json; separate --pmc passes, the
+        # guide's gfx950 corrections); the JSON names the file, and carries null when none matches
+        traffic = step_traffic = traffic_source = None
+        wl_tag = args.workload + ('_bf16' if args.bf16 else '')
+        for tag in PROFILE_TAGS:
+            path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (tag, wl_tag))
             try:
-                pm = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (tag, args.workload))))
+                pm = json.load(open(path))
             except Exception:
+                continue
+            if pm.get('workload') != args.workload:
                 continue
             if w['model'] == 'cl_vrnn':
                 traffic = round(pm.get('dominant_bytes_per_launch', pm.get('lstm_seq_bytes_per_launch')))
             step_traffic = pm.get('step_bytes')
+            traffic_source = os.path.relpath(path, ROOT)
             break
         roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=kname,
                         avg_launch_us=round(avg_s * 1e6, 2),
                         whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4),
-                        step_traffic=step_traffic)
+                        step_traffic=step_traffic, traffic_source=traffic_source,
+                        traffic_measured_in_this_run=False)
+        if w['model'] == 'cl_vrnn':
+            # the recurrent products run on the fp32 VECTOR pipe (v_pk_fma_f32; one batch row per CU leaves the matrix
+            # cores' M dimension empty); its peak equals the fp32 MFMA peak, which is what `peak` holds
+            roofline['executes_on'] = "fp32 VALU (v_pk_fma_f32): the fp32 vector peak equals the fp32 MFMA peak (157.3 TFLOP/s)"
         if 'lstm_wgrad_bf16' in by:
             # the batched gate GEMM of the north star: every kernel gradient of an LSTM, [x | h | z]^T . dz over B*T rows
-            # (csrc/wgrad_bf16.hip).  Algorithmic flops of the products / its launch time, against the fp32 matrix peak
-            # (the products are exact fp32 products formed from bf16 pieces on the bf16 matrix cores).
+            # (csrc/wgrad_bf16.hip), formed on the BF16 matrix cores from exact pieces.  Reported against the pipe it
+            # runs on: (a) issued bf16 MFMA flops / 2.5 PFLOP/s, (b) the MFMA-busy counter of the committed SQ pass;
+            # the algorithmic fp32-equivalent rate is given by name, never as a fraction of a peak it does not use.
             gn, gms = by['lstm_wgrad_bf16'][1], by['lstm_wgrad_bf16'][2]
             rows = (88 + 88) + (88 + w['L'] + 88)
-            gflop = 2.0 * rows * 352 * B * w['T'] * reps
-            roofline['gate_gemm'] = dict(kernel='lstm_wgrad_bf16', avg_launch_us=round(gms / gn * 1e3, 2),
-                                         achieved=round(gflop / (gms * 1e-3) / 1e12, 2), peak=PEAK_F32_TFLOPS,
-                                         frac=round(gflop / (gms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4), unit="TFLOP/s",
-                                         arithmetic="exact fp32 products from 3 bf16 pieces per operand, fp32 accumulate")
+            alg = 2.0 * rows * 352 * B * w['T'] * reps                     # algorithmic flops of the products, both LSTMs
+            exact = bool(getattr(eng, 'frames_exact_bf16', False))
+            issued = 0.0
+            for nz in (0, w['L']):                                         # encoder, decoder
+                wide = 88 + nz > 96 or nz > 8
+                h_tiles, x_tiles, col_tiles = (8 if wide else 6), 6, 24   # 16-row tiles of [h | z] and x; 2 x 12 column tiles
+                mfmas = (x_tiles * (1 if exact else 3) * 3 + h_tiles * 9) * col_tiles * (B * w['T'] // 32)
+                issued += mfmas * 2.0 * 16 * 16 * 32
+            issued *= reps
+            sq = None
+            for tag in PROFILE_TAGS:
+                try:
+                    sj = json.load(open(os.path.join(ROOT, 'profiles', '%s_sq_%s.json' % (tag, args.workload))))
+                    k = [k for k in sj['kernels'] if 'lstm_wgrad_bf16' in k['kernel']]
+                    if k:
+                        sq = dict(mfma_busy=k[0].get('mfma_busy'), source='profiles/%s_sq_%s.json' % (tag, args.workload))
+                        break
+                except Exception:
+                    continue
+            roofline['gate_gemm'] = dict(
+                kernel='lstm_wgrad_bf16', avg_launch_us=round(gms / gn * 1e3, 2), bound="mfma", pipe="bf16 MFMA (v_mfma_f32_16x16x32_bf16)",
+                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                achieved=round(issued / (gms * 1e-3) / 1e12, 1), frac=round(issued / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                achieved_is="issued bf16 MFMA flops (padded tiles, 9 piece pairs per fp32 product, 3 for byte-valued frames) / launch time",
+                mfma_busy_counter=sq,
+                fp32_equivalent_tflops=round(alg / (gms * 1e-3) / 1e12, 2),
+                arithmetic="exact fp32 products from 3 bf16 pieces per operand, fp32 accumulate")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -371,6 +441,11 @@ def main():
             "final_loss": round(float(loss['total']), 4),
             "roofline": roofline, "cpu_baseline": cpu,
             "devices": devices, "rccl": rccl if world > 1 else None,
+            "ms_per_step_by_rank": rank_ms, "allreduce_alone": allreduce,
+            "dp_schedule": None if world == 1 else {
+                "graphs_per_step": len(ts._graphs) if ts._graphs else 0, "collectives_per_step": 2,
+                "wgrad_split_scale": 2 if getattr(eng, 'fine_grid', False) else 1,
+                "optimizer": "hW kernel updated under the main bucket's all-reduce, the rest after it"},
         }
         print(json.dumps(out))
     if world > 1:

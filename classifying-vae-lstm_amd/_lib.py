@@ -70,6 +70,9 @@ SIGNATURES = {
     "clv_lstm_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "clv_lstm_wgrad": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,
                             _p, _sz, _p, _p]),
+    "clv_lstm_wgrad_workspace_bytes_ex": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "clv_lstm_wgrad_ex": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,
+                               _i, _p, _sz, _p, _p]),
     "clv_gemm_grouped_tn_small2": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _p]),
     "clv_gemm_grouped_auto_split": (_i, [_p, _i, _i, _i]),
     "clv_gemm_grouped_workspace_bytes": (_sz, [_p, _i, _i, _i]),

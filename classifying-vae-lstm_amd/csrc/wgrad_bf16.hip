@@ -361,15 +361,24 @@ extern "C" int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exa
   return !wgrad_wide(nh, nz) || x_exact_bf16;        // 8 h row tiles and three x pieces do not fit the LDS together
 }
 
-static int wgrad_splits(int K) {
-  // one workgroup per CU: 2 column halves x 128 row ranges of whole 32-row stages
-  int kc = (K + 127) / 128;
-  kc = (kc + 31) / 32 * 32;
+// rows per split: one workgroup per CU (2 column halves x 128 row ranges of whole 32-row stages); split_scale s: s times
+// as many, shorter ranges (a grid of exactly one workgroup per CU needs a whole second round as soon as something else
+// -- the gradient all-reduce's kernel -- holds a few CUs; 2 x 256 half-length workgroups lose only the share that is taken)
+static int wgrad_kc(int K, int split_scale) {
+  const int ranges = 128 * (split_scale < 1 ? 1 : split_scale);
+  int kc = (K + ranges - 1) / ranges;
+  return (kc + 31) / 32 * 32;
+}
+static int wgrad_splits(int K, int split_scale) {
+  const int kc = wgrad_kc(K, split_scale);
   return (K + kc - 1) / kc;
 }
 
+extern "C" size_t clv_lstm_wgrad_workspace_bytes_ex(int K, int N, int nx, int nh, int nz, int split_scale) {
+  return (size_t)wgrad_splits(K, split_scale) * (nx + nh + nz) * N * sizeof(float);
+}
 extern "C" size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz) {
-  return (size_t)wgrad_splits(K) * (nx + nh + nz) * N * sizeof(float);
+  return clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, 1);
 }
 
 extern "C" int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
@@ -377,16 +386,25 @@ extern "C" int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int
                               const float* Z, int ldz, int nz, const float* dz, int lddz,
                               float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
                               void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream) {
+  return clv_lstm_wgrad_ex(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, h_shift, h_zero_period, Z, ldz, nz, dz, lddz, dKx, ld_kx,
+                           dU, ld_u, dKz, ld_kz, beta, 1, ws, ws_bytes, job, stream);
+}
+
+extern "C" int clv_lstm_wgrad_ex(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+                                 const float* H, int ldh, int nh, int h_shift, int h_zero_period,
+                                 const float* Z, int ldz, int nz, const float* dz, int lddz,
+                                 float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
+                                 int split_scale, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream) {
   using namespace clv;
+  if (split_scale < 1 || split_scale > 8) return CLV_EINVAL;
   if (job) memset(job, 0, sizeof(*job));
   if (!clv_lstm_wgrad_supported(N, nx, nh, nz, x_exact_bf16) || K <= 0 || !X || !H || !dz || !dKx || !dU || (nz > 0 && (!Z || !dKz)))
     return CLV_EINVAL;
   if (ldx % 4 || ldh % 4 || lddz % 4 || ((uintptr_t)X | (uintptr_t)H | (uintptr_t)dz) % 16) return CLV_EINVAL;
-  if (clv_lstm_wgrad_workspace_bytes(K, N, nx, nh, nz) > ws_bytes || !ws || ((uintptr_t)ws) % 16) return CLV_EWORKSPACE;
+  if (clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, split_scale) > ws_bytes || !ws || ((uintptr_t)ws) % 16) return CLV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int splits = wgrad_splits(K);
-  int kc = (K + 127) / 128;
-  kc = (kc + 31) / 32 * 32;
+  const int splits = wgrad_splits(K, split_scale);
+  const int kc = wgrad_kc(K, split_scale);
   WgradArgs a{K, N, kc, X, ldx, nx, H, ldh, nh, h_shift, h_zero_period, Z, ldz, nz, dz, lddz, (float*)ws};
   const bool wide = wgrad_wide(nh, nz);
   {

@@ -863,7 +863,8 @@ class VrnnEngine(_EngineBase):
             gk = P.g(name + '/kernel')
             ops.lstm_wgrad(BT, G4, X_in, x_ld, nx, self.frames_exact_bf16, hs, H, H, T,
                            X_in[:, nx:] if nz else None, x_ld, nz, dz, gk, P.g(name + '/recurrent_kernel'),
-                           P.rows(P.grads, name + '/kernel', nx) if nz else None, ws, defer=rq)
+                           P.rows(P.grads, name + '/kernel', nx) if nz else None, ws, defer=rq,
+                           split_scale=2 if self.fine_grid else 1)
         else:
             self._lstm_wgrads_f32(name, X_in, x_ld, x_rows, hs, dz, ws, rq)
         if not (Cn + 1 <= 16 and B <= 4096):      # else: both LSTMs' label rows + biases in one launch (grads_tail)

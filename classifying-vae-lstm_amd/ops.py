@@ -125,16 +125,18 @@ def lstm_wgrad_supported(N, nx, nh, nz, x_exact_bf16):
     return bool(_lib.lib().clv_lstm_wgrad_supported(N, nx, nh, nz, int(bool(x_exact_bf16))))
 
 
-def lstm_wgrad(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dKx, dU, dKz, ws, defer=None, beta=0.0):
+def lstm_wgrad(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dKx, dU, dKz, ws, defer=None, beta=0.0,
+               split_scale=1):
     """All kernel gradients of one LSTM in one pass over dz (split-bf16 exact products, csrc/wgrad_bf16.hip):
-    dKx = X^T dz, dU = H'^T dz (H' = hs shifted by one step, zero at window starts: period T), dKz = Z^T dz."""
+    dKx = X^T dz, dU = H'^T dz (H' = hs shifted by one step, zero at window starts: period T), dKz = Z^T dz.
+    split_scale: that many times as many, shorter row ranges (2 under the data-parallel step: see include/clvae.h)."""
     L = _lib.lib()
-    need = L.clv_lstm_wgrad_workspace_bytes(K, N, nx, nh, nz)
+    need = L.clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, int(split_scale))
     buf = defer.scratch(need) if defer is not None else ws.ensure(need)
     job = defer.next_job() if defer is not None else None
-    check(L.clv_lstm_wgrad(K, N, _ptr(X), ldx, nx, int(bool(x_exact_bf16)), _ptr(H), ldh, nh, 1, T,
-                           _ptr(Z), ldz, nz, _ptr(dz), N, _ptr(dKx), N, _ptr(dU), N, _ptr(dKz), N, float(beta),
-                           _ptr(buf), buf.numel(), job, _stream()), "clv_lstm_wgrad")
+    check(L.clv_lstm_wgrad_ex(K, N, _ptr(X), ldx, nx, int(bool(x_exact_bf16)), _ptr(H), ldh, nh, 1, T,
+                              _ptr(Z), ldz, nz, _ptr(dz), N, _ptr(dKx), N, _ptr(dU), N, _ptr(dKz), N, float(beta),
+                              int(split_scale), _ptr(buf), buf.numel(), job, _stream()), "clv_lstm_wgrad_ex")
 
 
 def gemm_bce(A, B, bias, Y, scale, logits, dlogits, rownll, M, N, K, lda=None, ldb=None, ldy=None, ldc=None):

@@ -142,6 +142,15 @@ int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const f
  * of Z, need x_exact_bf16 (the wide form of the kernel has no room for three pieces of X). */
 int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16);
 size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz);
+/* split_scale (1..8): that many times as many, proportionally shorter row ranges (and slabs).  1 = one workgroup per CU,
+ * the fastest grid on an idle GPU; 2 is what the data-parallel step uses: the gradient all-reduce's kernel holds a few
+ * CUs while these products run, and a grid of exactly one workgroup per CU would then need a whole second round. */
+size_t clv_lstm_wgrad_workspace_bytes_ex(int K, int N, int nx, int nh, int nz, int split_scale);
+int clv_lstm_wgrad_ex(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+                      const float* H, int ldh, int nh, int h_shift, int h_zero_period,
+                      const float* Z, int ldz, int nz, const float* dz, int lddz,
+                      float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
+                      int split_scale, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
 int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
                    const float* H, int ldh, int nh, int h_shift, int h_zero_period,
                    const float* Z, int ldz, int nz, const float* dz, int lddz,
