@@ -91,7 +91,8 @@ SIGNATURES = {
     "clv_lstm_pair_pack": (_i, [_i, _i, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p,
                                _p, _p]),
-    "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 13),
+    "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 12 + [_p, _p, _p, _p, _sz, _p, _p]),
+    "clv_lstm_pair_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_sparse_proj_supported": (_i, [_i, _i]),
     "clv_sparse_proj_lds_bytes": (_sz, [_i, _i]),
     "clv_sparse_proj": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p]),

@@ -19,6 +19,7 @@
 
 #include "lstm_common.h"
 #include "philox.h"
+#include "reduce_job.h"
 
 namespace clv {
 
@@ -675,10 +676,15 @@ struct PairBwdArgs {
   const float* zargs;             // [B*T,2L]
   const float* eps;               // [B*T,L]
   float* dzargs;                  // [B*T,2L]
+  // WZG: the latent head's weight gradient [hs_enc | 1]^T . dzargs, accumulated per batch row while the chains run
+  // (a GEMM of its own re-read hs_enc and cost a 10 us launch): hs_e [B*T,88] in, wz_slab [B][89][2L] out
+  const float* hs_e;
+  float* wz_slab;
 };
 
 // LATW: the decoder chain's last wave: its surplus unit groups hold rows of Kz and finish dzargs
-template <int GATE, bool DEC, bool LATW, int ZP>
+// WZG: also accumulate this batch row's share of the latent head's kernel / bias gradient (PairBwdArgs::wz_slab)
+template <int GATE, bool DEC, bool LATW, int ZP, bool WZG>
 __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, int lane, float (*dzb)[BW_LDS],
                                                float (*dza)[QZ]) {
   const int cs = lane & 15, ug = wave * 4 + (lane >> 4), q = cs >> 2;
@@ -722,7 +728,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   // (32-bit lane offset) each.  A latent lane needs (mean, log_var, eps) of its latent ONE STEP LATER in time: the
   // values it holds during iteration (step t) are those of step t+1, whose dZ its matvec has just produced from
   // dz_dec_{t+1}.
-  struct Raw { float kq, kc, kcarry, dh, m, lv, e; };
+  struct Raw { float kq, kc, kcarry, dh, m, lv, e, hh; };
   const unsigned col = q * LH + u;
   const rsrc_t r_g = make_rsrc(gates + rowbt * LG, T * LG * 4);              // k in, dz out
   const rsrc_t r_a = make_rsrc(aux + rowbt * 2 * LH, T * 2 * LH * 4);
@@ -730,6 +736,12 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   const rsrc_t r_za = make_rsrc(a.zargs + rowbt * 2 * L, T * 2 * L * 4);
   const rsrc_t r_e = make_rsrc(a.eps + rowbt * L, T * L * 4);
   const rsrc_t r_dz = make_rsrc(a.dzargs + rowbt * 2 * L, T * 2 * L * 4);
+  const rsrc_t r_hs = make_rsrc((WZG && !DEC) ? a.hs_e + rowbt * LH : a.zargs, (WZG && !DEC) ? T * LH * 4 : 4);
+  constexpr int WZC = ZP / 4;              // head columns per replica lane: replica q takes columns q*WZC ..
+  float wz[WZC];
+#pragma unroll
+  for (int j = 0; j < WZC; ++j) wz[j] = 0.f;
+  float zb = 0.f;                          // latent lanes (WZG): sum_t dzargs of their column = the head's bias gradient
   const unsigned vo_g = zgroup ? BUF_OOB : col * 4;                            // dz store (latent groups: none)
   const unsigned vo_m = zlane ? lat * 4 : BUF_OOB, vo_lv = zlane ? (L + lat) * 4 : BUF_OOB;
   const float hk = 0.5f * a.kl_scale;
@@ -739,6 +751,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     r.kcarry = buf_load(r_a, u * 4, t * (unsigned)(2 * LH * 4));
     r.kc = buf_load(r_a, (LH + u) * 4, t * (unsigned)(2 * LH * 4));
     if (DEC) r.dh = buf_load(r_d, u * 4, t * (unsigned)(LH * 4));
+    if (WZG && !DEC) r.hh = buf_load(r_hs, u * 4, t * (unsigned)(LH * 4));
     if (LATW) {                    // lanes without a latent read beyond num_records: 0
       const unsigned tz = (unsigned)min(max(tr + 1, 0), T - 1);
       r.m = buf_load(r_za, vo_m, tz * (unsigned)(2 * L * 4));
@@ -750,7 +763,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   // (behind the last use of the set) and consumed where they landed
   Raw rA, rB;
   rA.m = rA.lv = rA.e = rB.m = rB.lv = rB.e = 0.f;
-  rA.dh = rB.dh = 0.f;
+  rA.dh = rB.dh = rA.hh = rB.hh = 0.f;
   load_raw(T - 1, rA);
   load_raw(T - 2, rB);
   prologue_loads_done();
@@ -808,6 +821,11 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
         s0 = fmaf(v.z, Wzr[j4 + 2], s0); s1 = fmaf(v.w, Wzr[j4 + 3], s1);
       }
       dhup = s0 + s1;
+      if (WZG) {                      // dWz[u][q*WZC + j] += h_enc_t[u] * dzargs_t[q*WZC + j]  (h of a step beyond the window: 0)
+        const float* dzc = &dza[cur ^ 1][q * WZC];
+#pragma unroll
+        for (int j = 0; j < WZC; ++j) wz[j] = fmaf(k.hh, dzc[j], wz[j]);
+      }
     }
     const float dhrec = matvec(dzb[cur]);
     const float dh = dhup + dhrec;
@@ -820,6 +838,7 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     if (LATW) {                       // latent lanes turn dZ_{t+1} into dzargs_{t+1}
       const float zv = latent_dz(k, dhrec);
       if (zlive) dza[cur][lpos] = zv;
+      if (WZG) zb = fmaf(zv, (i >= 1 && i < T) ? 1.f : 0.f, zb);      // i == 0: no step T; i == T (odd T): the epilogue's step 0
       buf_store(zv, r_dz, vo_dz, (unsigned)min(t + 1, T - 1) * (unsigned)(2 * L * 4));      // i == 0: garbage into row T-1, rewritten at i == 1
     }
     load_raw(t - 2, k);
@@ -841,14 +860,20 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
       const float zv = latent_dz(k0, dZ);
       buf_store(zv, r_dz, vo_dz, 0);
       if (zlive) dza[T & 1][lpos] = zv;
+      if (WZG && zlive) a.wz_slab[((size_t)b * (LH + 1) + LH) * 2 * L + lpos] = zb + zv;
     }
     step_barrier();
     step_barrier();
   }
   if (!zgroup) dzsum[(size_t)b * LG + col] = zsum;
+  if (WZG && !DEC && 4 * ug + (cs & 3) < LH) {
+#pragma unroll
+    for (int j = 0; j < WZC; ++j)
+      if (q * WZC + j < 2 * L) a.wz_slab[((size_t)b * (LH + 1) + u) * 2 * L + q * WZC + j] = wz[j];
+  }
 }
 
-template <int GATE, int ZP>
+template <int GATE, int ZP, bool WZG>
 __global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float dzbuf[2][2][BW_LDS];       // [chain][parity][sliced dz]
   __shared__ __attribute__((aligned(16))) float dza[2][QZ];
@@ -857,9 +882,9 @@ __global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
   for (int i = tid; i < 2 * 2 * BW_LDS; i += PNT) (&dzbuf[0][0][0])[i] = 0.f;
   if (tid < 2 * QZ) (&dza[0][0])[tid] = 0.f;
   __syncthreads();
-  if (wave < PNW - 1) pair_bwd_chain<GATE, true, false, ZP>(a, wave, lane, dzbuf[0], dza);
-  else if (wave == PNW - 1) pair_bwd_chain<GATE, true, true, ZP>(a, wave, lane, dzbuf[0], dza);
-  else pair_bwd_chain<GATE, false, false, ZP>(a, wave - PNW, lane, dzbuf[1], dza);
+  if (wave < PNW - 1) pair_bwd_chain<GATE, true, false, ZP, WZG>(a, wave, lane, dzbuf[0], dza);
+  else if (wave == PNW - 1) pair_bwd_chain<GATE, true, true, ZP, WZG>(a, wave, lane, dzbuf[0], dza);
+  else pair_bwd_chain<GATE, false, false, ZP, WZG>(a, wave - PNW, lane, dzbuf[1], dza);
 }
 
 }  // namespace clv
@@ -934,24 +959,47 @@ extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float
                                  const float* dhs_dec, const float* aux_dec, const float* aux_enc,
                                  float* gates_dec_inout_dz, float* gates_enc_inout_dz,
                                  float* dzsum_dec, float* dzsum_enc,
-                                 const float* zargs, const float* eps, float* dzargs, void* stream) {
+                                 const float* zargs, const float* eps, float* dzargs,
+                                 const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
+                                 void* stream) {
   using namespace clv;
+  if (job) memset(job, 0, sizeof(*job));
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0) return CLV_EINVAL;
+  const bool wzg = hs_enc != nullptr;
+  if (wzg && (!dWz || !dbz || !ws || ws_bytes < clv_lstm_pair_bwd_workspace_bytes(B, H, L))) return CLV_EWORKSPACE;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
   if (!pack || !Wz || !dhs_dec || !aux_dec || !aux_enc || !gates_dec_inout_dz || !gates_enc_inout_dz ||
       !dzsum_dec || !dzsum_enc || !zargs || !eps || !dzargs)
     return CLV_EINVAL;
   PairBwdArgs a{B, T, L, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_dec_inout_dz,
-                gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs};
+                gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs, hs_enc, (float*)ws};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_bwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
-#define PAIR_BWD(G, Z) hipLaunchKernelGGL((lstm_pair_bwd_kernel<G, Z>), dim3(B), dim3(PNT), 0, s, a)
+#define PAIR_BWD_W(G, Z, W) hipLaunchKernelGGL((lstm_pair_bwd_kernel<G, Z, W>), dim3(B), dim3(PNT), 0, s, a)
+#define PAIR_BWD(G, Z) do { if (wzg) PAIR_BWD_W(G, Z, true); else PAIR_BWD_W(G, Z, false); } while (0)
 #define PAIR_BWD_Z(Z) do { if (hard) PAIR_BWD(CLV_GATE_HARD_SIGMOID, Z); else PAIR_BWD(CLV_GATE_SIGMOID, Z); } while (0)
   if (2 * L <= 4) PAIR_BWD_Z(4);
   else if (2 * L <= 8) PAIR_BWD_Z(8);
   else PAIR_BWD_Z(16);
 #undef PAIR_BWD_Z
 #undef PAIR_BWD
-  return launch_status();
+#undef PAIR_BWD_W
+  int st = launch_status();
+  if (st || !wzg) return st;
+  // the per-row slabs [B][89][2L] -> dWz [88,2L] and dbz [2L]: a pending reduction like a split-K product's
+  ReduceJob j;
+  memset(&j, 0, sizeof(j));
+  j.partial = (const float*)ws;
+  j.M = LH + 1; j.N = 2 * L; j.splits = B; j.nprob = 2;
+  j.alpha = 1.f; j.beta = 0.f; j.act = CLV_ACT_NONE;
+  j.prob[0] = ReduceProb{dWz, 2 * L, 0};
+  j.prob[1] = ReduceProb{dbz, 2 * L, LH};
+  if (job && B > 1) memcpy(job, &j, sizeof(j));
+  else st = launch_reduce(j, s);
+  return st;
+}
+
+extern "C" size_t clv_lstm_pair_bwd_workspace_bytes(int B, int H, int L) {
+  return (size_t)B * (H + 1) * 2 * L * sizeof(float);
 }

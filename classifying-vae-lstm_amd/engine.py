@@ -949,9 +949,12 @@ class VrnnEngine(_EngineBase):
             g(self.dlogits, P.p('X_decoded_mean/kernel'), self.dhs, BT, H, D, tb=True, ws=ws)
         if self.fuse_pair:
             # decoder BPTT, dZ, the latent head's backward, dh_enc and encoder BPTT: one persistent launch
+            # ... and the latent head's own weight gradient (per-row slabs into the pass's pending reductions)
             ops.lstm_pair_bwd(B, T, L, self.kl_weight * inv_bt, self.pair_pack, P.p('Zargs/kernel'), self.dhs,
                               self.cs_dec, self.cs_enc, self.gates_dec, self.gates_enc, self.dzsum_dec, self.dzsum_enc,
-                              self.zargs, eps_Z, self.dzargs, gate_act=self.gate_act)
+                              self.zargs, eps_Z, self.dzargs, gate_act=self.gate_act,
+                              head_grad=(self.hs_enc, P.g('Zargs/kernel'), P.g('Zargs/bias')), ws=ws, defer=self._rq())
+            self._head_grad_done = True
         else:
             self._bptt_separate(eps_Z, ws)
         # label head: dW from both LSTMs, label backward, dWargs and dhW in one launch
@@ -979,7 +982,9 @@ class VrnnEngine(_EngineBase):
             self._dense_wgrad('X_decoded_mean', self.hs_dec, H, H, D, BT, self.dlogits, ws, rq)
         self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec, self.dzsum_dec,
                           off + L, ws)
-        self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)
+        if not getattr(self, '_head_grad_done', False):
+            self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)
+        self._head_grad_done = False
         self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
         if Cn + 1 <= 16 and B <= 4096:
             wprobs = lambda name, w_row: [dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),

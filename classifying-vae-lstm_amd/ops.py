@@ -306,11 +306,22 @@ def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, gates_dec, dec_has_xproj, rb_dec, 
                                        _stream()), "clv_lstm_pair_fwd")
 
 
-def lstm_pair_bwd(B, T, L, kl_scale, pack, Wz, dhs_dec, cs_dec, cs_enc, gates_dec, gates_enc, dzsum_dec,
-                  dzsum_enc, zargs, eps, dzargs, gate_act=0, H=88):
-    check(_lib.lib().clv_lstm_pair_bwd(B, T, H, L, gate_act, float(kl_scale), _ptr(pack), _ptr(Wz),
-                                       _ptr(dhs_dec), _ptr(cs_dec), _ptr(cs_enc), _ptr(gates_dec), _ptr(gates_enc),
-                                       _ptr(dzsum_dec), _ptr(dzsum_enc), _ptr(zargs), _ptr(eps), _ptr(dzargs), _stream()),
+def lstm_pair_bwd(B, T, L, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_dec, gates_enc, dzsum_dec,
+                  dzsum_enc, zargs, eps, dzargs, gate_act=0, H=88, head_grad=None, ws=None, defer=None):
+    """head_grad = (hs_enc, dWz, dbz): the latent head's kernel / bias gradient is accumulated inside the kernel (per-row
+    slabs, summed by the pending reduction of `defer`, or at once) instead of by a GEMM over hs_enc."""
+    Lb = _lib.lib()
+    hs, dWz, dbz, buf, nbytes, job = None, None, None, None, 0, None
+    if head_grad is not None:
+        hs, dWz, dbz = head_grad
+        need = Lb.clv_lstm_pair_bwd_workspace_bytes(B, H, L)
+        buf = defer.scratch(need) if defer is not None else ws.ensure(need)
+        nbytes = buf.numel()
+        job = defer.next_job() if defer is not None else None
+    check(Lb.clv_lstm_pair_bwd(B, T, H, L, gate_act, float(kl_scale), _ptr(pack), _ptr(Wz),
+                               _ptr(dhs_dec), _ptr(aux_dec), _ptr(aux_enc), _ptr(gates_dec), _ptr(gates_enc),
+                               _ptr(dzsum_dec), _ptr(dzsum_enc), _ptr(zargs), _ptr(eps), _ptr(dzargs),
+                               _ptr(hs), _ptr(dWz), _ptr(dbz), _ptr(buf), nbytes, job, _stream()),
           "clv_lstm_pair_bwd")
 
 

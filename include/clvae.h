@@ -237,7 +237,11 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  * head's backward (dzargs = [dZ + kl*mean | dZ*eps*sd/2 - kl*(1 - sd^2)/2], kl = kl_scale, written to
  * dzargs [B*T,2L] for the head's weight gradient), dh_enc_t = dzargs_t . Wz^T and encoder BPTT, one
  * launch; gates_* are overwritten in place with dz and dzsum_* [B,4H] = sum_t dz like clv_lstm_seq_bwd.
- * dhs_dec [B,T,H] is the decoder's upstream gradient (from the output head). */
+ * dhs_dec [B,T,H] is the decoder's upstream gradient (from the output head).
+ * hs_enc != NULL: the latent head's weight gradient rides along -- dWz [H,2L] = hs_enc^T . dzargs and dbz [2L] = column sums
+ * of dzargs (cl_vrnn/model.py:201-210, the two TimeDistributed Dense heads as one [H,2L] kernel), accumulated per batch
+ * row in the chains' spare lanes into ws (>= clv_lstm_pair_bwd_workspace_bytes) and summed over the rows by the pending
+ * reduction `job` (NULL: summed at once), like a split-K product's slabs; no GEMM launch, no second read of hs_enc. */
 int clv_lstm_pair_supported(int H, int L);
 /* Both passes read the recurrent kernels U_enc / U_dec [H,4H], Kz and (forward) Wz from `pack`: every workgroup needs
  * each weight exactly once, one value per lane, and clv_lstm_pair_pack lays them out in that order (one wave load = 1 KB
@@ -260,7 +264,10 @@ int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
                       const float* dhs_dec, const float* aux_dec, const float* aux_enc,
                       float* gates_dec_inout_dz, float* gates_enc_inout_dz,
                       float* dzsum_dec, float* dzsum_enc,
-                      const float* zargs, const float* eps, float* dzargs, void* stream);
+                      const float* zargs, const float* eps, float* dzargs,
+                      const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
+                      void* stream);
+size_t clv_lstm_pair_bwd_workspace_bytes(int B, int H, int L);
 
 /* ------------------------------------------------ cl_vrnn generation, persistent --
  * cl_vrnn/model.py:9-60 (generate_sample's frame loop) for N independent sequences, one workgroup per
