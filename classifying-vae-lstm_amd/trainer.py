@@ -69,6 +69,15 @@ class TrainStep:
         if world > 1 and hasattr(engine, 'fine_grid') and 'fine_grid' not in cfg:
             # the big bucket's all-reduce runs next to the LSTM weight-gradient products: see VrnnEngine.fine_grid
             engine.fine_grid = True
+        # CLV_OVERLAP_UPDATE=1 (measurement option, single GPU): the optimizer step of the hW kernel (87 % of the parameters;
+        # a chain of five small, latency-bound launches) on a side stream NEXT TO the weight-gradient products of the
+        # backward pass's late part -- its gradient is final before they start and nothing they read is touched -- as a
+        # fork / join inside the step's one graph.  Measured on MI355X (three alternating pairs, 200 steps): 0.4346 /
+        # 0.4385 / 0.4321 ms with the fork against 0.4299 / 0.4274 / 0.4273 serial: the branches do not overlap to any
+        # gain (the same finding as round 1's two-stream backward), so the default is the serial order.
+        self.overlap_update = (self.ar is None and self.is_vrnn and len(self.tail_names) == 1
+                               and optimizer == 'adam-wn' and os.environ.get('CLV_OVERLAP_UPDATE', '0') == '1')
+        self._upd_stream = torch.cuda.Stream(device=d) if self.overlap_update else None
         self._graphs = None
         self._warm = False
 
@@ -206,7 +215,24 @@ class TrainStep:
         segs = self._segments(d_cur, d_hist, d_w, d_target)
         ops.gather_rows_multi(self.eng.B, ib, segs, row0=row0, notes=self._note_outputs(d_cur, d_hist, len(segs)))
 
+    def _single(self):
+        """The whole step on one GPU (eager or under capture)."""
+        self._main()
+        if not self.overlap_update:
+            self._tail()
+            self._update()
+            return
+        cur = torch.cuda.current_stream()
+        self._upd_stream.wait_stream(cur)
+        with torch.cuda.stream(self._upd_stream):
+            self._update_tail()
+        self._tail()
+        cur.wait_stream(self._upd_stream)
+        self._update_rest()
+
     def _eager(self):
+        if self.ar is None:
+            return self._single()
         self._main()
         if self.ar is not None:
             self.ar.reduce_tail()       # the hW-kernel bucket (most of the bytes) is complete: reduce it under _tail()
@@ -238,7 +264,7 @@ class TrainStep:
         if self._graphs is None:
             if self.ar is None:
                 with ops.Graph() as g:
-                    self._main(); self._tail(); self._update()
+                    self._single()
                 self._graphs = (g,)
             else:
                 with ops.Graph() as g1:
