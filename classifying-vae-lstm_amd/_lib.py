@@ -35,6 +35,11 @@ class NoiseDraw(C.Structure):
     _fields_ = [("seed", _u64), ("first", _u64), ("stream", _u32), ("step", _u32), ("step_dev", _p)]
 
 
+class PairPackSrc(C.Structure):
+    """clv_pair_pack_src (include/clvae.h)."""
+    _fields_ = [("H", _i), ("L", _i), ("U_enc", _p), ("U_dec", _p), ("Kz", _p), ("Wz", _p), ("pack", _p)]
+
+
 class ParamDesc(C.Structure):
     _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
@@ -116,8 +121,11 @@ SIGNATURES = {
                                    _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                  _p, _p]),
+                                  _p, _p, _p]),
     "clv_vrnn_label_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
+    "clv_vrnn_label_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "clv_vrnn_label_bwd_ex": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, _p, _sz,
+                                   _p, _p]),
     "clv_gauss_fwd": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
     "clv_gauss_bwd": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p]),
     "clv_bernoulli_nll": (_i, [_i, _i, _p, _p, _i, _f, _p, _p, _p]),

@@ -8,7 +8,9 @@
 // Each of these is a handful of 88..352-long dot products per row: far too small for a GEMM launch
 // each (a launch costs ~5 us), so one workgroup does the whole chain for its row out of LDS.
 #include "common.h"
+#include "lstm_pair_pack.h"
 #include "philox.h"
+#include "reduce_job.h"
 
 namespace clv {
 
@@ -161,12 +163,20 @@ struct LabelFwdXArgs {
   const float* Kh;         // [nx, D]
   const float* bh;         // [D]
   int nx, ldx;
+  PairPackArgs pack;       // out != null: also write the pair kernels' weight pack
 };
 __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax) {
   __shared__ float2 part[16][64];
   __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
   const LabelFwdArgs& a = ax.l;
   const int tid = threadIdx.x, lane = tid & 63;
+  if (ax.pack.out) {
+    // by-product: the pair LSTM kernels' lane-order weight pack (clv_lstm_pair_pack), a few elements per thread; the pair
+    // forward kernel is the next launch but one and nothing in this kernel reads the pack
+    for (int i = blockIdx.x * 1024 + tid; i < PK_TOTAL; i += gridDim.x * 1024)
+      ax.pack.out[i] = pair_pack_element(i, ax.pack.L, ax.pack.U_e, ax.pack.U_d, ax.pack.Kz, ax.pack.Wz,
+                                         [](const float* p) { return *p; });
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   const int n2 = a.D / 2;
@@ -235,6 +245,7 @@ struct LabelBwdArgs {
   float prior, class_weight, w_kl_weight, inv_b;
   float* dwargs;            // [B,2(C-1)]
   float* dhW;               // [B,D]
+  float* wa_slab;           // optional [B][D+1][2(C-1)]: this row's share of the Wargs layer's kernel / bias gradient
 };
 
 __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
@@ -324,6 +335,15 @@ __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
     }
     a.dhW[(size_t)b * a.D + tid] = hv > 0.f ? acc : 0.f;
   }
+  if (a.wa_slab) {
+    // [hW_b | 1]^T . dwargs_b: the row's outer product; the rows are summed by the backward pass's pending reductions
+    // (a GEMM of its own over K = batch was a 10 us launch for 0.4 MFLOP)
+    float* slab = a.wa_slab + (size_t)b * (a.D + 1) * NA;
+    for (int e = tid; e < (a.D + 1) * NA; e += LH_T) {
+      const int r = e / NA, j = e - r * NA;
+      slab[e] = (r < a.D ? a.hW[(size_t)b * a.D + r] : 1.f) * s_dwa[j];
+    }
+  }
 }
 
 }  // namespace clv
@@ -353,12 +373,46 @@ extern "C" int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsu
   if (B <= 0 || D <= 0 || D > 128 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
   if (!dzsum_enc || !dzsum_dec || !Kenc_w || !Kdec_w || !wargs || !eps || !onehot || !W || !hW || !Ka || !dwargs || !dhW)
     return CLV_EINVAL;
+  return clv_vrnn_label_bwd_ex(B, D, C, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior_logvar,
+                               class_weight, w_kl_weight, inv_b, dwargs, dhW, nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" size_t clv_vrnn_label_bwd_workspace_bytes(int B, int D, int C) {
+  return (size_t)B * (D + 1) * 2 * (C - 1) * sizeof(float);
+}
+
+extern "C" int clv_vrnn_label_bwd_ex(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
+                                     const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
+                                     const float* onehot, const float* W, const float* hW, const float* Ka,
+                                     float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
+                                     float* dwargs, float* dhW, float* dKa, float* dba, void* ws, size_t ws_bytes,
+                                     clv_reduce_job* job, void* stream) {
+  if (job) memset(job, 0, sizeof(*job));
+  if (B <= 0 || D <= 0 || D > 128 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
+  if (!dzsum_enc || !dzsum_dec || !Kenc_w || !Kdec_w || !wargs || !eps || !onehot || !W || !hW || !Ka || !dwargs || !dhW)
+    return CLV_EINVAL;
+  const bool wg = dKa != nullptr;
+  if (wg && (!dba || !ws || ws_bytes < clv_vrnn_label_bwd_workspace_bytes(B, D, C))) return CLV_EWORKSPACE;
   LabelBwdArgs a{B, D, C, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka,
-                 prior_logvar, class_weight, w_kl_weight, inv_b, dwargs, dhW};
+                 prior_logvar, class_weight, w_kl_weight, inv_b, dwargs, dhW, wg ? (float*)ws : nullptr};
   hipStream_t s = (hipStream_t)stream;
-  ProfScope p("vrnn_label_bwd", s);
-  hipLaunchKernelGGL(vrnn_label_bwd_kernel, dim3(B), dim3(LH_T), 0, s, a);
-  return launch_status();
+  {
+    ProfScope p("vrnn_label_bwd", s);
+    hipLaunchKernelGGL(vrnn_label_bwd_kernel, dim3(B), dim3(LH_T), 0, s, a);
+  }
+  int st = launch_status();
+  if (st || !wg) return st;
+  ReduceJob j;
+  memset(&j, 0, sizeof(j));
+  const int NA = 2 * (C - 1);
+  j.partial = (const float*)ws;
+  j.M = D + 1; j.N = NA; j.splits = B; j.nprob = 2;
+  j.alpha = 1.f; j.beta = 0.f; j.act = CLV_ACT_NONE;
+  j.prob[0] = ReduceProb{dKa, NA, 0};
+  j.prob[1] = ReduceProb{dba, NA, D};
+  if (job && B > 1) memcpy(job, &j, sizeof(j));
+  else st = launch_reduce(j, s);
+  return st;
 }
 
 extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
@@ -366,14 +420,18 @@ extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X,
                                     float* eps, const float* onehot, float prior_logvar,
                                     const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                                     float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                                    const clv_noise_draw* noise, void* stream) {
+                                    const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+  if (pack && (pack->H != LH || !clv_lstm_pair_supported(pack->H, pack->L) || !pack->U_enc || !pack->U_dec || !pack->Kz ||
+               !pack->Wz || !pack->pack || ((uintptr_t)pack->pack) % 16))
+    return CLV_EINVAL;
   if (B <= 0 || D <= 0 || D > 128 || D % 2 != 0 || C < 2 || C > LH_MAXC || G4 <= 0 || nx <= 0 || ldx < nx) return CLV_EINVAL;
   if (!X || !Kh || !bh || !hW_out || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss ||
       !rb_enc || !rb_dec)
     return CLV_EINVAL;
   if (((uintptr_t)Kh) % 8 != 0) return CLV_EINVAL;
   LabelFwdXArgs a{{B, D, C, G4, hW_out, Ka, ba, eps, {0, 0, 0, 0, 0, 0, nullptr}, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec,
-                   wargs, W, rowloss, rb_enc, rb_dec}, X, Kh, bh, nx, ldx};
+                   wargs, W, rowloss, rb_enc, rb_dec}, X, Kh, bh, nx, ldx, {0, nullptr, nullptr, nullptr, nullptr, nullptr}};
+  if (pack) a.pack = PairPackArgs{pack->L, pack->U_enc, pack->U_dec, pack->Kz, pack->Wz, reinterpret_cast<float4*>(pack->pack)};
   if (noise) {
     a.l.noise.on = 1; a.l.noise.k0 = (uint32_t)noise->seed; a.l.noise.k1 = (uint32_t)(noise->seed >> 32);
     a.l.noise.stream = noise->stream; a.l.noise.step = noise->step; a.l.noise.first = noise->first;

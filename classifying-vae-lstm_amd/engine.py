@@ -651,7 +651,7 @@ class VrnnEngine(_EngineBase):
         # output head (:229-234), with the NLL fused into its epilogue when the caller wants the loss
         self._output_head(target, nll)
 
-    def _label_forward(self, X, eps_W, w_true):
+    def _label_forward(self, X, eps_W, w_true, pack=None):
         """Label path (:174-191): hW Dense layer over the flattened window, Wargs head, logistic-normal sample, label
         losses and both per-row LSTM biases (W.K_w + b).  One launch when the window is handled sparsely."""
         cfg, P, B = self.cfg, self.P, self.B
@@ -664,7 +664,7 @@ class VrnnEngine(_EngineBase):
         if self.sparse_inputs and D % 2 == 0:
             nz = getattr(self, '_noise', None)
             ops.vrnn_label_fwd_x(B, D, Cn, G4, X, T * D, T * D, P.p('hW/kernel'), P.p('hW/bias'), self.hW, *tail,
-                                 noise=nz[0] if nz else None)
+                                 noise=nz[0] if nz else None, pack=pack)
         else:
             ops.gemm(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=self.ws)
             ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, *tail)
@@ -697,9 +697,13 @@ class VrnnEngine(_EngineBase):
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         BT, G4, off = B * T, 4 * H, self.off
         g, ws = ops.gemm, self.ws
-        # this step's recurrent kernels, K_z and the head kernel in the lane order of the pair kernels (both passes)
-        ops.lstm_pair_pack(L, P.p('encoder_h/recurrent_kernel'), P.p('decoder_h/recurrent_kernel'),
-                           P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), self.pair_pack)
+        # this step's recurrent kernels, K_z and the head kernel in the lane order of the pair kernels (both passes): a
+        # by-product of the label kernel's launch where that runs, else a launch of its own
+        pack = (L, P.p('encoder_h/recurrent_kernel'), P.p('decoder_h/recurrent_kernel'),
+                P.rows(P.params, 'decoder_h/kernel', off), P.p('Zargs/kernel'), self.pair_pack)
+        pack_in_label = self.sparse_inputs and D % 2 == 0
+        if not pack_in_label:
+            ops.lstm_pair_pack(*pack)
         notes = None
         if self.fuse_notes and self.notes_valid:      # the projections are gathered inside the pair kernel
             notes = (self.notes_enc, P.p('encoder_h/kernel'), self.notes_dec if off else None,
@@ -714,7 +718,7 @@ class VrnnEngine(_EngineBase):
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel
                 g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
-        self._label_forward(X, eps_W, w_true)
+        self._label_forward(X, eps_W, w_true, pack=pack if pack_in_label else None)
         nz = getattr(self, '_noise', None)
         ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, self.gates_dec, off > 0, self.wk_dec, self.pair_pack,
                           P.p('Zargs/bias'), eps_Z, self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z,
@@ -961,7 +965,7 @@ class VrnnEngine(_EngineBase):
         ops.vrnn_label_bwd(B, D, Cn, G4, self.dzsum_enc, self.dzsum_dec, P.rows(P.params, 'encoder_h/kernel', D),
                            P.rows(P.params, 'decoder_h/kernel', off + L), self.wargs, eps_W, w_true, self.W, self.hW,
                            P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
-                           self.dwargs, self.dhW)
+                           self.dwargs, self.dhW, layer_grad=(P.g('Wargs/kernel'), P.g('Wargs/bias')), ws=ws, defer=self._rq())
         if self.sparse_inputs and ops.sparse_dense_supported(D):      # kernel gradient and bias gradient (column sums of dhW)
             ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'))
         else:
@@ -991,7 +995,7 @@ class VrnnEngine(_EngineBase):
                                           dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)]
             ops.gemm_grouped_tn_small2(wprobs('encoder_h', D), self.dzsum_enc, wprobs('decoder_h', off + L), self.dzsum_dec,
                                        4 * H, B)
-        self._dense_wgrad('Wargs', self.hW, D, D, 2 * C1, B, self.dwargs, ws, rq)
+        # (the Wargs layer's gradient: per-row slabs of the label backward kernel, already among the pending reductions)
         if rq is not None:
             rq.flush(means=getattr(self, '_loss_terms', None), out=self.scal)
             self._loss_terms = None

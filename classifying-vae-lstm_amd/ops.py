@@ -357,21 +357,38 @@ def _noise_ref(noise):
 
 
 def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, onehot, prior, Kenc_w, benc, Kdec_w, bdec, wargs,
-                     W, rowloss, rb_enc, rb_dec, noise=None):
+                     W, rowloss, rb_enc, rb_dec, noise=None, pack=None):
     """hW = relu(X . Kh + bh) over the nonzero inputs of each row, then vrnn_label_fwd, one workgroup per row.
-    noise: a noise_draw(): eps is drawn in the kernel (and written to `eps`) instead of read."""
+    noise: a noise_draw(): eps is drawn in the kernel (and written to `eps`) instead of read.
+    pack = (L, U_enc, U_dec, Kz, Wz, out): the launch also writes the pair LSTM kernels' weight pack (lstm_pair_pack)."""
+    ps = None
+    if pack is not None:
+        L_, ue, ud, kz, wz, out = pack
+        ps = _lib.PairPackSrc(88, int(L_), _ptr(ue), _ptr(ud), _ptr(kz), _ptr(wz), _ptr(out))
     check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), _ptr(bh), _ptr(hW_out), _ptr(Ka),
                                           _ptr(ba), _ptr(eps), _ptr(onehot), float(prior), _ptr(Kenc_w), _ptr(benc),
                                           _ptr(Kdec_w), _ptr(bdec), _ptr(wargs), _ptr(W), _ptr(rowloss), _ptr(rb_enc),
-                                          _ptr(rb_dec), _noise_ref(noise), _stream()), "clv_vrnn_label_fwd_x")
+                                          _ptr(rb_dec), _noise_ref(noise), C.byref(ps) if ps is not None else None, _stream()),
+          "clv_vrnn_label_fwd_x")
 
 
 def vrnn_label_bwd(B, D, Cn, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior,
-                   class_weight, w_kl_weight, inv_b, dwargs, dhW):
-    check(_lib.lib().clv_vrnn_label_bwd(B, D, Cn, G4, _ptr(dzsum_enc), _ptr(dzsum_dec), _ptr(Kenc_w), _ptr(Kdec_w),
-                                        _ptr(wargs), _ptr(eps), _ptr(onehot), _ptr(W), _ptr(hW), _ptr(Ka),
-                                        float(prior), float(class_weight), float(w_kl_weight), float(inv_b),
-                                        _ptr(dwargs), _ptr(dhW), _stream()), "clv_vrnn_label_bwd")
+                   class_weight, w_kl_weight, inv_b, dwargs, dhW, layer_grad=None, ws=None, defer=None):
+    """layer_grad = (dKa, dba): the Wargs layer's kernel / bias gradient as per-row slabs summed by `defer`'s pending
+    reductions (or at once) instead of a GEMM over K = batch."""
+    Lb = _lib.lib()
+    dKa, dba, buf, nbytes, job = None, None, None, 0, None
+    if layer_grad is not None:
+        dKa, dba = layer_grad
+        need = Lb.clv_vrnn_label_bwd_workspace_bytes(B, D, Cn)
+        buf = defer.scratch(need) if defer is not None else ws.ensure(need)
+        nbytes = buf.numel()
+        job = defer.next_job() if defer is not None else None
+    check(Lb.clv_vrnn_label_bwd_ex(B, D, Cn, G4, _ptr(dzsum_enc), _ptr(dzsum_dec), _ptr(Kenc_w), _ptr(Kdec_w),
+                                   _ptr(wargs), _ptr(eps), _ptr(onehot), _ptr(W), _ptr(hW), _ptr(Ka),
+                                   float(prior), float(class_weight), float(w_kl_weight), float(inv_b),
+                                   _ptr(dwargs), _ptr(dhW), _ptr(dKa), _ptr(dba), _ptr(buf), nbytes, job, _stream()),
+          "clv_vrnn_label_bwd_ex")
 
 
 def gauss_fwd(R, Ld, zargs, eps, z, ldz, rowkl):

@@ -43,6 +43,14 @@ extern "C" {
 #define CLV_GATE_HARD_SIGMOID 0   /* Keras 2.0.0 default recurrent_activation */
 #define CLV_GATE_SIGMOID      1
 
+/* The sources of clv_lstm_pair_pack, for a kernel that writes the pack as a by-product of its own launch
+ * (clv_vrnn_label_fwd_x: it runs right before the pair forward kernel). */
+typedef struct clv_pair_pack_src {
+  int H, L;
+  const float *U_enc, *U_dec, *Kz, *Wz;
+  float* pack;
+} clv_pair_pack_src;
+
 /* In-kernel noise: a kernel that takes `const clv_noise_draw* noise` draws its standard-normal eps itself when noise is
  * not NULL -- element e of the launch's eps tensor gets the clv_philox_normal value of (seed, step + *step_dev, stream,
  * index first + e), i.e. bit for bit what clv_philox_normal / clv_philox_normal2 would have written -- and WRITES it to
@@ -377,12 +385,22 @@ int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, i
                          float* eps, const float* onehot, float prior_logvar,
                          const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                          float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                         const clv_noise_draw* noise, void* stream);
+                         const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
 int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
                        const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
                        const float* onehot, const float* W, const float* hW, const float* Ka,
                        float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
                        float* dwargs, float* dhW, void* stream);
+/* ..._ex: dKa != NULL -- the Wargs layer's own gradient rides along: dKa [D,2(C-1)] = hW^T . dwargs, dba = column sums of
+ * dwargs, as per-row outer products in ws (>= clv_vrnn_label_bwd_workspace_bytes) summed by the pending reduction `job`
+ * (NULL: at once), like a split-K product's slabs: no GEMM launch over K = batch. */
+size_t clv_vrnn_label_bwd_workspace_bytes(int B, int D, int C);
+int clv_vrnn_label_bwd_ex(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
+                          const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
+                          const float* onehot, const float* W, const float* hW, const float* Ka,
+                          float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
+                          float* dwargs, float* dhW, float* dKa, float* dba, void* ws, size_t ws_bytes,
+                          clv_reduce_job* job, void* stream);
 
 /* gaussian reparameterisation rows: zargs[R, 2L] = [mean | log_var];
  * z[R, ldz] (written at column offset 0..L-1) = mean + exp(lv/2)*eps; rowkl[R] = KL(N(mean,exp(lv))||N(0,1)).
