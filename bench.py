@@ -30,6 +30,9 @@ WORKLOADS = {
     # BASELINE config 5, second half: autoregressive generation under hipGraph (frames/s, N seeds at once)
     'gen1024': dict(model='cl_vrnn', B=1024, T=256, L=32, C=10, generate=True),
     'gen1': dict(model='cl_vrnn', B=1, T=256, L=32, C=10, generate=True),
+    # cl_vae generation (cl_vae/model.py:9-42): N seeds at once, one persistent kernel (csrc/vae_generate.hip)
+    'gen_vae1024': dict(model='cl_vae', B=1024, T=1, L=4, C=2, generate=True),
+    'gen_vae1': dict(model='cl_vae', B=1, T=1, L=4, C=2, generate=True),
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (never the 2:1-sparsity figure)
@@ -127,9 +130,11 @@ def bench_generate(args, w, dev, rank, world):
     """Replicas-only sampling benchmark: N seeds per GPU, 16 teacher-forced frames, then free-running frames;
     a "step" is one generated frame for all N sequences (one hipGraph replay)."""
     import torch
-    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.engine import VaeEngine, VrnnEngine
     from clvae_amd.initializers import init_weights
     N, L, C = w['B'], w['L'], w['C']
+    if w['model'] == 'cl_vae':
+        return bench_generate_vae(args, w, dev, rank, world)
     cfg = dict(D=88, H=88, L=L, T=16, C=C, use_x_prev=True, class_weight=1.0, kl_weight=1.0, w_kl_weight=1.0,
                w_log_var_prior=0.0, gate_act='hard_sigmoid')
     eng = VrnnEngine(cfg, 1, dev)
@@ -190,6 +195,45 @@ def allreduce_microbench(ts, dev, iters=50):
     ar.flat.copy_(keep)
     return dict(tail_bucket_bytes=tail_b, main_bucket_bytes=main_b, both_buckets_us=round(float(tt.item()), 2),
                 note="two all-reduces (AVG) per step on a side stream; measured alone, max over ranks, %d iterations" % iters)
+
+
+def bench_generate_vae(args, w, dev, rank, world):
+    """cl_vae sampling: N seed frames per GPU, `steps` generated frames each (cl_vae/model.py:9-42); a "step" is one
+    frame for all N sequences."""
+    import torch
+    from clvae_amd.engine import VaeEngine
+    from clvae_amd.initializers import init_weights
+    N, L, C = w['B'], w['L'], w['C']
+    cfg = dict(D=88, H=88, L=L, Hc=88, C=C, use_x_prev=True, class_weight=1.0, kl_weight=1.0, w_kl_weight=1.0,
+               w_log_var_prior=0.0)
+    persistent = not args.no_persistent
+    eng = VaeEngine(cfg, N if not persistent else 4, dev)
+    wts = init_weights(eng.P.logical, cfg, seed=0)
+    wts['x_decoded_mean/bias'] = np.full_like(wts['x_decoded_mean/bias'], float(np.log(NOTE_DENSITY / (1 - NOTE_DENSITY))))
+    eng.P.set_weights(wts)
+    rng = np.random.default_rng(1234 + rank)
+    seeds = torch.as_tensor((rng.random((N, 88)) < NOTE_DENSITY).astype(np.float32), device=dev)
+    wv = torch.as_tensor(np.eye(C, dtype=np.float32)[rng.integers(0, C, N)], device=dev)
+    eng.generate(seeds, wv, max(args.warmup, 2), seed=1, persistent=persistent)
+    torch.cuda.synchronize()
+    dt = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        out = eng.generate(seeds, wv, args.steps, seed=2 + rep, persistent=persistent)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t0
+        dt = d1 if dt is None else min(dt, d1)
+    if rank == 0:
+        print(json.dumps({"metric": "generated piano-roll frames/sec (sample)", "value": round(world * N * args.steps / dt, 1),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "%s: cl_vae generation, %d seeds/GPU, latent %d, %s, output bias = "
+                                                 "logit(%.4f), best of 3 runs"
+                                                 % (args.workload, N, L, "one persistent kernel (workgroup per sequence)"
+                                                    if persistent else "hipGraph replay per frame", NOTE_DENSITY),
+                                     "parallelism": "replicas%d" % world},
+                          "note_density_out": round(float(out.mean().item()), 4)}))
 
 
 def free_port():

@@ -111,6 +111,8 @@ SIGNATURES = {
     "clv_out_head_train": (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "clv_vrnn_generate_supported": (_i, [_i, _i, _i, _i]),
     "clv_vrnn_generate": (_i, [_i] * 9 + [_u64] + [_p] * 18),
+    "clv_vae_generate_supported": (_i, [_i, _i, _i, _i]),
+    "clv_vae_generate": (_i, [_i] * 8 + [_u64] + [_p] * 13),
     "clv_label_fwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "clv_label_bwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _i, _p]),
     "clv_vae_fused_supported": (_i, [_i, _i, _i, _i, _i]),

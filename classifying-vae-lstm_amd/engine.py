@@ -352,13 +352,24 @@ class VaeEngine(_EngineBase):
         ops.gauss_fwd(B, L, self.zargs, eps_z, self.z, L, self.rowkl)
         self.decode(self.w, self.z, xp)
 
-    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False):
+    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False, persistent=True, xhat_out=None):
         """N independent sequences of `nsteps` frames on the device: the frame loop of cl_vae/model.py:28-41
         (z-encoder on the last frame, z ~ N(mean, exp(lv)) or N(0, 1), decoder on (w, z, frame before last),
-        x ~ Bernoulli) captured once as a hipGraph and replayed per frame with no host synchronisation; eps and u come
-        from the Philox streams 0 / 1 at step = frame index.  x_seed [N,D], w [N,C] device tensors, N <= batch size."""
+        x ~ Bernoulli); eps and u come from the Philox streams 0 / 1 at step = frame index.  x_seed [N,D], w [N,C] device
+        tensors.  persistent=True (default where the shapes allow): the whole loop is ONE kernel, a workgroup per
+        sequence (csrc/vae_generate.hip; any N); otherwise the layer chain captured once as a hipGraph and replayed per
+        frame (N <= batch size).  Same noise, same samples either way."""
         cfg, d = self.cfg, self.device
         N, D, L = int(x_seed.shape[0]), cfg['D'], cfg['L']
+        if persistent and cfg['H'] > 0 and ops.vae_generate_supported(D, cfg['H'], L, cfg['C']):
+            P = self.P
+            f = dict(dtype=torch.float32, device=d)
+            Xs = torch.zeros(N, nsteps, D, **f)
+            ops.vae_generate(N, nsteps, D, cfg['H'], L, cfg['C'], cfg['use_x_prev'], z_prior, seed,
+                             x_seed.to(**f).contiguous(), w.to(**f).contiguous(), P.p('h/kernel'), P.p('h/bias'),
+                             P.p('zargs/kernel'), P.p('zargs/bias'), P.p('decoder_h/kernel'), P.p('decoder_h/bias'),
+                             P.p('x_decoded_mean/kernel'), P.p('x_decoded_mean/bias'), Xs, xhat_out)
+            return Xs
         if N > self.B:
             raise ValueError("%d sequences exceed the engine's batch size %d" % (N, self.B))
         f = dict(dtype=torch.float32, device=d)

@@ -279,6 +279,17 @@ def vrnn_generate(N, S, nsteps, D, H, L, Cn, gate_act, z_prior, seed, x_seed, w,
                                        _ptr(Xs), _ptr(xhat), _stream()), "clv_vrnn_generate")
 
 
+def vae_generate_supported(D, H, L, Cn):
+    return bool(_lib.lib().clv_vae_generate_supported(D, H, L, Cn))
+
+
+def vae_generate(N, nsteps, D, H, L, Cn, use_x_prev, z_prior, seed, x_seed, w, Kh, bh, Kz, bz, Kd, bd, Ko, bo, Xs, xhat=None):
+    """cl_vae frame loop for N sequences in one persistent launch (csrc/vae_generate.hip)."""
+    check(_lib.lib().clv_vae_generate(N, nsteps, D, H, L, Cn, int(bool(use_x_prev)), int(bool(z_prior)), int(seed), _ptr(x_seed),
+                                      _ptr(w), _ptr(Kh), _ptr(bh), _ptr(Kz), _ptr(bz), _ptr(Kd), _ptr(bd), _ptr(Ko), _ptr(bo),
+                                      _ptr(Xs), _ptr(xhat), _stream()), "clv_vae_generate")
+
+
 def lstm_pair_supported(L, H=88):
     return bool(_lib.lib().clv_lstm_pair_supported(H, L))
 

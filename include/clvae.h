@@ -297,6 +297,22 @@ int clv_vrnn_generate(int N, int S, int nsteps, int D, int H, int L, int C, int 
                       const float* U_dec, const float* Wo, const float* bo,
                       float* Xs, float* xhat, void* stream);
 
+/* ------------------------------------------------- cl_vae generation, persistent --
+ * cl_vae/model.py:9-42 (generate_sample's frame loop) for N independent sequences, one workgroup per sequence for its
+ * whole length, one launch: per frame  h = relu([x_prev | w] . Kh + bh), [z_mean | z_log_var] = h . Kz + bz,
+ * z = mean + exp(log_var/2)*eps (z_prior != 0: z = eps), h_d = relu([w | x_prev_t | z] . Kd + bd) (the history rows only
+ * with use_x_prev; x_prev_t = the frame BEFORE x_prev, :38-40), x_hat = sigmoid(h_d . Ko + bo), x_t = [u <= x_hat].
+ * x_seed [N,D] is both x_prev and x_prev_t of frame 0.  eps = the clv_philox_normal value for (seed, step t, stream 0,
+ * index n*L+l), u = the clv_philox_uniform value for (seed, step t, stream 1, index n*D+j).  Kernels in Keras layout:
+ * Kh = h/kernel [D+C,H] (frame rows, label rows), Kz = the fused head [H,2L], Kd = decoder_h/kernel [C+(D)+L,H]
+ * (label rows, history rows, latent rows), Ko = x_decoded_mean/kernel [H,D].  Xs [N,nsteps,D]; xhat (optional) the
+ * probabilities.  clv_vae_generate_supported: D == H == 88, L <= 32, C <= 32 (models with hidden layers). */
+int clv_vae_generate_supported(int D, int H, int L, int C);
+int clv_vae_generate(int N, int nsteps, int D, int H, int L, int C, int use_x_prev, int z_prior, uint64_t seed,
+                     const float* x_seed, const float* w, const float* Kh, const float* bh, const float* Kz,
+                     const float* bz, const float* Kd, const float* bd, const float* Ko, const float* bo,
+                     float* Xs, float* xhat, void* stream);
+
 /* ------------------------------------------------------------ pointwise --
  * logistic-normal label sample + its two losses, one thread per row:
  *   w = softmax([mean + exp(lv/2)*eps, 0]); kl_w, w_rec = (C-1)*CCE(onehot, w+1e-10), hit

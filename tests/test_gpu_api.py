@@ -531,6 +531,43 @@ def test_cl_vae_device_generation_matches_stepwise_oracle(dev):
         assert flips <= 2
 
 
+@pytest.mark.parametrize("N,L,C,use_x_prev,z_prior", [(5, 3, 4, True, False), (40, 32, 2, True, True), (3, 1, 10, False, False)])
+def test_cl_vae_persistent_generation_matches_the_frame_graph(dev, N, L, C, use_x_prev, z_prior):
+    """csrc/vae_generate.hip (the whole generate_sample loop of cl_vae/model.py:9-42 in one kernel, a workgroup per
+    sequence) against the layer chain replayed per frame with the same Philox noise: the probabilities of every frame agree
+    to fp32 rounding and a sample differs only where its uniform draw lies within that rounding of its probability; every
+    sample is [u <= x_hat] of the kernel's own probabilities; more sequences than the engine's batch size."""
+    from clvae_amd import ops
+    from clvae_amd.engine import VaeEngine
+    nsteps, seed = 9, 99
+    cfg = O.vae_config(latent_dim=L, n_classes=C, use_x_prev=use_x_prev)
+    rng = np.random.default_rng(N + L)
+    p = {k: np.asarray(v, np.float32) for k, v in O.vae_init_params(cfg, seed=6).items()}
+    for k in p:                                    # livelier weights than the initialisers give
+        p[k] = (p[k] + 0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    p['x_decoded_mean/bias'] = (p['x_decoded_mean/bias'] - 2.0).astype(np.float32)
+    eng = VaeEngine(cfg, max(N, 4), dev)
+    eng.P.set_weights(p)
+    f = dict(dtype=torch.float32, device=dev)
+    x_seed = torch.as_tensor((rng.random((N, 88)) < 0.06).astype(np.float32), device=dev)
+    w = torch.as_tensor(np.eye(C, dtype=np.float32)[rng.integers(0, C, N)], device=dev)
+    xhat = torch.zeros(N, nsteps, 88, **f)
+    Xs = eng.generate(x_seed, w, nsteps, seed=seed, z_prior=z_prior, xhat_out=xhat)
+    Xg = eng.generate(x_seed, w, nsteps, seed=seed, z_prior=z_prior, persistent=False)
+    torch.cuda.synchronize()
+    assert Xs.shape == Xg.shape == (N, nsteps, 88) and 0.0 < float(Xs.mean()) < 0.5
+    for t in range(nsteps):
+        u = torch.zeros(N, 88, **f)
+        ops.philox_uniform(u, N * 88, seed, t, 1, 0)
+        np.testing.assert_array_equal(Xs[:, t].cpu().numpy(), (u <= xhat[:, t]).float().cpu().numpy())
+        diff = (Xs[:, t] != Xg[:, t])
+        if diff.any():          # only draws within rounding of their probability may differ (and then the sequences part)
+            assert float((u - xhat[:, t]).abs()[diff].max()) < 1e-5
+            break
+    # a second call gives the same frames (nothing is left over from the first)
+    assert torch.equal(Xs, eng.generate(x_seed, w, nsteps, seed=seed, z_prior=z_prior))
+
+
 def test_fit_with_predict_next_targets(dev):
     """Model.fit with targets [next frames, w, w, next frames] (what train.py passes under --predict_next) pulls the
     decoder towards the NEXT frames, not towards its input."""
