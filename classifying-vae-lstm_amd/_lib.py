@@ -40,6 +40,11 @@ class PairPackSrc(C.Structure):
     _fields_ = [("H", _i), ("L", _i), ("U_enc", _p), ("U_dec", _p), ("Kz", _p), ("Wz", _p), ("pack", _p)]
 
 
+class AdamKnownSums(C.Structure):
+    """clv_adam_known_sums (include/clvae.h)."""
+    _fields_ = [("tensor", _i), ("use", _i), ("gdot", _p), ("vnorm2", _p)]
+
+
 class ParamDesc(C.Structure):
     _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
@@ -105,6 +110,7 @@ SIGNATURES = {
     "clv_sparse_dense_supported": (_i, [_i]),
     "clv_sparse_dense": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p]),
+    "clv_sparse_outer_ex": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "clv_gemm_bce_f32": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _i, _p, _p]),
     "clv_out_head_train_supported": (_i, [_i, _i]),
     "clv_out_head_train_workspace_bytes": (_sz, [_i]),
@@ -140,6 +146,7 @@ SIGNATURES = {
     "clv_adam_wn_plan_build": (_i, [_p, _i, _p]),
     "clv_adam_wn_workspace_bytes": (_sz, [_p, _i]),
     "clv_adam_wn_step": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _p, _sz, _p]),
+    "clv_adam_wn_step_ex": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _p, _p, _sz, _p]),
     "clv_philox_normal2": (_i, [_p, _i64, _u32, _u64, _p, _i64, _u32, _u64, _u64, _u32, _p, _p]),
     "clv_gather_rows_multi": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_gather_rows_multi_notes": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

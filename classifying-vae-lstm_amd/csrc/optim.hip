@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void wn_cols_kernel(int n_cols, const AdamCol*
 
 // s' = g'/||V'|| per column -> colscal[4j+0] (reused) and the persistent s; advances `iterations`
 __global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol* cols, const float* partC, float* s,
-                                                       float* colscal, int32_t* iterations) {
+                                                       float* colscal, int32_t* iterations, float* vn2) {
   __shared__ float red[CL][CPB];
   if (blockIdx.x == 0 && threadIdx.x == 0 && iterations) *iterations += 1;
   const int cx = threadIdx.x & (CPB - 1), zy = threadIdx.x / CPB;
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void wn_cols2_kernel(int n_cols, const AdamCol
   const float snew = colscal[4 * j + 3] / sqrtf(a);
   colscal[4 * j + 0] = snew;
   s[c.col_global] = snew;
+  if (vn2) vn2[c.col_global] = a;          // ||V'||^2: after the rescale V = W / s' = V', so this is the next step's sum V^2
 }
 
 __device__ __forceinline__ void wn_update_body(const AdamUnit& un, int unit_idx, float* params, const float* grads,
@@ -386,6 +387,134 @@ __global__ __launch_bounds__(256) void wn_update_kernel(int n_units, const AdamU
 
 __global__ void adam_bump_kernel(int32_t* iterations) { *iterations += 1; }
 
+// ---------------------------------------------------------------------------
+// Two-launch Adam-WN of ONE tall matrix (cl_vrnn's hW/kernel: 87 % of the parameters) when both column sums of the
+// first pass are known BEFORE the optimizer runs (clv_adam_wn_step_ex):
+//   sum_r V^2    = ||V||^2 of the previous step's result (kept per column in vn2: the rescale leaves W = s' V', so the
+//                  next step's V is this step's V');
+//   sum_r g.V    = (1/s) sum_r g[r,c] W[r,c], and with g = X^T dH (the layer's own gradient) that is
+//                  (1/s) sum_b (X W)[b,c] dH[b,c]: a sum over the BATCH of pre-activation x upstream gradient, which the
+//                  kernel that forms g has in LDS anyway (clv_sparse_outer's gdot) -- no pass over the 4 MB of W and g.
+// Launch 1 (wn_fast_update): every block derives its columns' scalars itself and updates 64 rows; block 0 also steps the
+// per-column Adam state of g.  Launch 2 (wn_fast_rescale): every block sums the 176 partial ||V'||^2 rows of its
+// columns (62 KB, L2-resident), rescales its 64 rows; block 0 stores s', ||V'||^2 and advances `iterations`.
+// The classic chain needs five launches (stats, columns, update, columns, rescale).
+// ---------------------------------------------------------------------------
+constexpr int FAST_ROWS = 64;
+struct AdamFast {
+  int64_t offset, col_offset;
+  int rows, cols, nunits;
+  const float* gdot;      // [cols] sum_b (X W)[b,c] dH[b,c]
+  float* vn2;             // per-column ||V||^2 (global column layout like s / mg / vg)
+  float* gnew;            // [cols] scratch: the new gain, launch 1 -> launch 2
+  float* partC;           // [nunits][cols]
+};
+
+__device__ __forceinline__ void wn_fast_update_body(const AdamFast& f, int unit, float* params, const float* grads, float* m,
+                                                    float* v, float* mg, float* vg, const float* s, const AdamHyper& h) {
+  __shared__ float cs[3][128], red[4][128];
+  const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6;
+  const float lr_t = adam_lr_t(h);
+  for (int c = tid; c < f.cols; c += 256) {                 // this block's copy of the column scalars
+    const size_t cg = f.col_offset + c;
+    const float sc = s[cg], a = f.vn2[cg];
+    const float Vn = sqrtf(a), inv_s = 1.f / sc;
+    const float grad_g = f.gdot[c] * inv_s / Vn;           // sum g.V / ||V||
+    cs[0][c] = inv_s; cs[1][c] = grad_g / Vn; cs[2][c] = sc;
+    if (unit == 0) {                                        // Adam on the gain (utils/weightnorm.py:109-121), once per column
+      const float mgn = h.b1 * mg[cg] + (1.f - h.b1) * grad_g;
+      const float vgn = h.b2 * vg[cg] + (1.f - h.b2) * grad_g * grad_g;
+      mg[cg] = mgn; vg[cg] = vgn;
+      f.gnew[c] = sc * Vn - lr_t * mgn / (sqrtf(vgn) + h.eps);
+    }
+  }
+  __syncthreads();
+  const int row0 = unit * FAST_ROWS, nrows = min(FAST_ROWS, f.rows - row0);
+  for (int c0 = 0; c0 < f.cols; c0 += 64) {
+    const int col = c0 + cx;
+    float acc = 0.f;
+    if (col < f.cols) {
+      const float inv_s = cs[0][col], gov = cs[1][col], sc = cs[2][col];
+#pragma unroll
+      for (int blk = 0; blk < FAST_ROWS / 16; ++blk) {      // 4 rows per thread and pass: 16 loads in flight
+        float pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 16 * blk + ry + 4 * i;
+          const size_t o = f.offset + (size_t)(row0 + min(r, nrows - 1)) * f.cols + col;
+          pv[i] = params[o]; gv[i] = grads[o]; mv[i] = m[o]; vv[i] = v[o];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 16 * blk + ry + 4 * i;
+          if (r < nrows) {
+            const size_t o = f.offset + (size_t)(row0 + r) * f.cols + col;
+            const float V = pv[i] * inv_s;
+            const float gV = sc * (gv[i] - gov * V);
+            const float mn = h.b1 * mv[i] + (1.f - h.b1) * gV;
+            const float vn = h.b2 * vv[i] + (1.f - h.b2) * gV * gV;
+            m[o] = mn; v[o] = vn;
+            const float Vp = V - lr_t * mn / (sqrtf(vn) + h.eps);
+            params[o] = Vp;
+            acc += Vp * Vp;
+          }
+        }
+      }
+    }
+    red[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && col < f.cols) f.partC[(size_t)unit * f.cols + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_fast_update_kernel(AdamFast f, const SmallItem* items, float* params,
+                                                             const float* grads, float* m, float* v, float* mg, float* vg,
+                                                             float* s, AdamHyper h) {
+  if ((int)blockIdx.x >= f.nunits) {
+    wn_small_body(items[blockIdx.x - f.nunits], params, grads, m, v, mg, vg, s, h);
+    return;
+  }
+  wn_fast_update_body(f, (int)blockIdx.x, params, grads, m, v, mg, vg, s, h);
+}
+
+__global__ __launch_bounds__(256) void wn_fast_rescale_kernel(AdamFast f, float* params, float* s, int32_t* iterations) {
+  __shared__ float red[4][128], snew[128];
+  const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6, unit = blockIdx.x;
+  if (unit == 0 && tid == 0 && iterations) *iterations += 1;
+  for (int c0 = 0; c0 < f.cols; c0 += 64) {
+    const int col = c0 + cx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < f.cols) {
+      int k = ry;
+      for (; k + 12 < f.nunits; k += 16) {                   // 4 partial rows in flight per thread
+        a0 += f.partC[(size_t)k * f.cols + col]; a1 += f.partC[(size_t)(k + 4) * f.cols + col];
+        a2 += f.partC[(size_t)(k + 8) * f.cols + col]; a3 += f.partC[(size_t)(k + 12) * f.cols + col];
+      }
+      for (; k < f.nunits; k += 4) a0 += f.partC[(size_t)k * f.cols + col];
+    }
+    red[ry][cx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ry == 0 && col < f.cols) {
+      const float a = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+      const float sn = f.gnew[col] / sqrtf(a);
+      snew[col] = sn;
+      if (unit == 0) { s[f.col_offset + col] = sn; f.vn2[f.col_offset + col] = a; }
+    }
+    __syncthreads();
+  }
+  const int row0 = unit * FAST_ROWS, nrows = min(FAST_ROWS, f.rows - row0);
+  for (int c0 = 0; c0 < f.cols; c0 += 64) {
+    const int col = c0 + cx;
+    if (col >= f.cols) continue;
+    const float sn = snew[col];
+    for (int r = ry; r < nrows; r += 4) {
+      const size_t o = f.offset + (size_t)(row0 + r) * f.cols + col;
+      params[o] *= sn;
+    }
+  }
+}
+
 struct PlanCounts { int n_units, n_cols, n_part, n_small, n_big; };
 
 static bool is_small(const clv_param_desc& t) { return !t.is_matrix || t.rows <= SM_ROWS; }
@@ -470,7 +599,17 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
                                 float* mg, float* vg, float* s,
                                 int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
                                 int weightnorm, void* ws, size_t ws_bytes, void* stream) {
+  return clv_adam_wn_step_ex(host_table, n_tensors, plan_dev, params, grads, m, v, mg, vg, s, iterations_dev, step_t, lr, beta1,
+                             beta2, eps, weightnorm, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int clv_adam_wn_step_ex(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
+                                   float* params, const float* grads, float* m, float* v,
+                                   float* mg, float* vg, float* s,
+                                   int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
+                                   int weightnorm, const clv_adam_known_sums* known, void* ws, size_t ws_bytes, void* stream) {
   if (!host_table || n_tensors <= 0 || !plan_dev || !params || !grads || !m || !v) return CLV_EINVAL;
+  float* vn2 = known ? known->vnorm2 : nullptr;
   if (weightnorm < 0 || weightnorm > CLV_OPT_RMSPROP) return CLV_EINVAL;
   if (weightnorm == CLV_OPT_ADAM_WN && (!mg || !vg || !s)) return CLV_EINVAL;
   PlanCounts c = plan_counts(host_table, n_tensors);
@@ -494,6 +633,20 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   int32_t* bump = (iterations_dev && (step_t == -1 || step_t == CLV_STEP_ADVANCED)) ? nullptr : iterations_dev;
   ProfScope pr("adam_wn_step", st);
   const bool wn = weightnorm == CLV_OPT_ADAM_WN && c.n_cols > 0;
+  if (known && known->use && wn) {
+    // the two-launch form: exactly one tall matrix, whose sum g.V the caller brings and whose ||V||^2 vn2 holds
+    const int ti = known->tensor;
+    if (ti < 0 || ti >= n_tensors || c.n_big != 1 || is_small(host_table[ti]) || !known->gdot || !vn2) return CLV_EINVAL;
+    const clv_param_desc& t = host_table[ti];
+    if (t.cols > 128) return CLV_EINVAL;
+    const int nunits = (t.rows + FAST_ROWS - 1) / FAST_ROWS;
+    if ((size_t)nunits * t.cols > (size_t)c.n_part) return CLV_EWORKSPACE;      // partC lives where the classic chain keeps its own
+    AdamFast f{t.offset, t.col_offset, t.rows, t.cols, nunits, known->gdot, vn2, colscal, partC};
+    hipLaunchKernelGGL(wn_fast_update_kernel, dim3(nunits + c.n_small), dim3(256), 0, st, f, small, params, grads, m, v, mg, vg,
+                       s, h);
+    hipLaunchKernelGGL(wn_fast_rescale_kernel, dim3(nunits), dim3(256), 0, st, f, params, s, bump);
+    return launch_status();
+  }
   const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything
   const int n_small = wn ? c.n_small : 0;     // small matrices and biases: whole update in their own blocks of K3
   if (wn && chain) {
@@ -509,7 +662,7 @@ extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors,
   }
   if (wn && chain) {
     hipLaunchKernelGGL(wn_cols2_kernel, dim3((c.n_cols + CPB - 1) / CPB), dim3(256), 0, st, c.n_cols, cols, partC, s, colscal,
-                       bump);
+                       bump, vn2);
     hipLaunchKernelGGL(wn_rescale_kernel, dim3(c.n_units), dim3(256), 0, st, units, params, colscal, colidx0);
   } else if (bump) {
     hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, bump);

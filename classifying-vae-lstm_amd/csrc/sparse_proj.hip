@@ -179,6 +179,10 @@ struct SparseOuterArgs {
   const float* G;
   float* out;          // [nx, ldo]
   float* colsum;       // [N] = sum_b G[b,:] (the layer's bias gradient) or null; written by workgroup 0
+  // gdot [N] = sum_b (Hact[b,c] - hbias[c]) G[b,c] (or null): Hact = relu(X.K + hbias) is the layer's output and G its
+  // relu-masked upstream gradient, so this is sum_b (X.K)[b,c] G[b,c] = sum_j K[j,c] dK[j,c]: the weight-norm optimizer's
+  // sum g.W per column without a pass over K and dK (clv_adam_wn_step_ex).  Formed by one extra workgroup of the launch.
+  const float* Hact; const float* hbias; float* gdot; int ldh;
 };
 
 __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
@@ -194,6 +198,42 @@ __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float2(0.f, 0.f);
   float2 csum = make_float2(0.f, 0.f);
+  if (a.gdot && (int)blockIdx.x == (int)gridDim.x - 1) {
+    // the extra workgroup behind the tiles: gdot[c] = sum_b (Hact[b,c] - hbias[c]) G[b,c].  It runs next to the tile
+    // workgroups (fewer of them than CUs), every thread takes one column pair and every RL-th batch row with all of
+    // its loads in flight, the row lanes meet in LDS.
+    constexpr int RL = 16;                       // row lanes (x 64 column-pair lanes = 1024 threads)
+    float2* redl = reinterpret_cast<float2*>(so_lds);      // [RL][64]
+    const int rl = wave;
+    float2 acc = make_float2(0.f, 0.f);
+    if (lane < n2) {
+      const float2 hb = make_float2(a.hbias[2 * lane], a.hbias[2 * lane + 1]);
+      for (int b0 = rl; b0 < a.Bn; b0 += 8 * RL) {
+        float2 hv[8], gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int bb = min(b0 + i * RL, a.Bn - 1);
+          hv[i] = *reinterpret_cast<const float2*>(a.Hact + (size_t)bb * a.ldh + 2 * lane);
+          gv[i] = *reinterpret_cast<const float2*>(a.G + (size_t)bb * a.ldg + 2 * lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float mk = b0 + i * RL < a.Bn ? 1.f : 0.f;
+          acc.x = fmaf((hv[i].x - hb.x) * mk, gv[i].x, acc.x);
+          acc.y = fmaf((hv[i].y - hb.y) * mk, gv[i].y, acc.y);
+        }
+      }
+    }
+    redl[rl * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < n2) {
+      float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < RL; ++w) { t.x += redl[w * 64 + lane].x; t.y += redl[w * 64 + lane].y; }
+      a.gdot[2 * lane] = t.x; a.gdot[2 * lane + 1] = t.y;
+    }
+    return;
+  }
   for (int b0 = 0; b0 < a.Bn; b0 += SO_BB) {
     const int nb = min(SO_BB, a.Bn - b0);
     // stage X[b0:b0+nb, j0:j0+64] and G[b0:b0+nb, :]
@@ -219,6 +259,7 @@ __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
       }
       csum.x += t.x; csum.y += t.y;
     }
+
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int jj = wave + 16 * i;                 // this wave's i-th input of the tile
@@ -245,6 +286,7 @@ __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
     a.colsum[2 * lane] = csum.x;
     a.colsum[2 * lane + 1] = csum.y;
   }
+
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int j = j0 + wave + 16 * i;
@@ -314,15 +356,21 @@ extern "C" int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, c
 
 extern "C" int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
                                 float* colsum, void* stream) {
+  return clv_sparse_outer_ex(Bn, nx, N, X, ldx, G, ldg, out, ldo, colsum, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int clv_sparse_outer_ex(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+                                   float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream) {
   using namespace clv;
+  if (gdot && (!Hact || !hbias || ldh < N || ldh % 2 != 0 || ((uintptr_t)Hact) % 8 != 0)) return CLV_EINVAL;
   if (Bn <= 0 || nx <= 0 || !X || !G || !out || ldx < nx || ldg < N || ldo < N || !clv_sparse_dense_supported(N))
     return CLV_EINVAL;
   if (((uintptr_t)G) % 8 != 0 || ldg % 2 != 0) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)(SO_BB * SO_XS + SO_BB * N) * sizeof(float);
   if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(sparse_outer_kernel), 150 * 1024)) return e;
-  SparseOuterArgs a{Bn, nx, N, ldx, ldg, ldo, X, G, out, colsum};
+  SparseOuterArgs a{Bn, nx, N, ldx, ldg, ldo, X, G, out, colsum, Hact, hbias, gdot, ldh};
   ProfScope p("sparse_outer", s);
-  hipLaunchKernelGGL(sparse_outer_kernel, dim3((nx + SO_JT - 1) / SO_JT), dim3(1024), lds, s, a);
+  hipLaunchKernelGGL(sparse_outer_kernel, dim3((nx + SO_JT - 1) / SO_JT + (gdot ? 1 : 0)), dim3(1024), lds, s, a);
   return launch_status();
 }

@@ -115,6 +115,10 @@ class FlatParams:
         self.mg = torch.zeros(self.n_cols, **f)
         self.vg = torch.zeros(self.n_cols, **f)
         self.s = torch.ones(self.n_cols, **f)
+        # ||V||^2 per column of the tall matrices, kept by every Adam-WN step (clv_adam_wn_step_ex): the next step's first
+        # column sum.  norms_valid: it describes the parameters as they are now (cleared by anything else that writes them)
+        self.vn2 = torch.zeros(self.n_cols, **f)
+        self.norms_valid = False
         self.iterations = torch.zeros(1, dtype=torch.int32, device=device)
         L = _lib.lib()
         nb = L.clv_adam_wn_plan_bytes(table, len(self.shapes))
@@ -149,6 +153,7 @@ class FlatParams:
     def set_weights(self, weights):
         for name, _ in self.logical:
             self.p(name).copy_(torch.as_tensor(np.asarray(weights[name], dtype=np.float32)))
+        self.norms_valid = False
 
     def get_weights(self, buf=None):
         buf = self.params if buf is None else buf
@@ -157,13 +162,14 @@ class FlatParams:
     def state_tensors(self):
         """Everything a replica must share to step identically: parameters, Adam moments, the weight-norm column state
         and the step counter (which also keys the Philox noise stream)."""
-        return [self.params, self.m, self.v, self.mg, self.vg, self.s, self.iterations]
+        return [self.params, self.m, self.v, self.mg, self.vg, self.s, self.vn2, self.iterations]
 
     def reset_optimizer(self):
         for t in (self.m, self.v, self.mg, self.vg):
             t.zero_()
         self.s.fill_(1.0)
         self.iterations.zero_()
+        self.norms_valid = False
 
     def _subplan(self, names):
         """(table, n, device plan) of the update restricted to the tensors in `names` (same flat buffers)."""
@@ -178,19 +184,34 @@ class FlatParams:
             self._subplans[key] = (table, len(idx), plan)
         return self._subplans[key]
 
-    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True, only=None, advance=True, advanced=False):
+    def tall_tensor(self):
+        """Index and name of the one matrix of more than 128 rows (cl_vrnn's hW/kernel), or None."""
+        tall = [(i, name) for i, (name, shp) in enumerate(self.shapes) if len(shp) > 1 and int(np.prod(shp[:-1])) > 128]
+        return tall[0] if len(tall) == 1 else None
+
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True, only=None, advance=True, advanced=False,
+                  gdot=None):
         """utils/weightnorm.py:75-143; t comes from the device `iterations` counter.
         only: names of the tensors to update (default all); advance=False leaves `iterations` alone, so one optimizer step
         can be issued in pieces (the multi-GPU schedule updates a bucket as soon as its all-reduce has landed).
         advanced=True: the counter was already advanced by the launch that produced the gradients (the fused cl_vae
-        step) and holds t."""
+        step) and holds t.
+        gdot [cols]: sum_j K[j,c] dK[j,c] of the tall matrix (ops.sparse_outer(gdot=...)), for gradients that were not
+        averaged across ranks afterwards: with norms_valid the step takes the two-launch form (clv_adam_wn_step_ex)."""
         table, n, plan = (self.table, len(self.shapes), self.plan) if only is None else self._subplan(only)
-        _lib.check(_lib.lib().clv_adam_wn_step(
+        known, tall = None, self.tall_tensor()
+        if int(weightnorm) == 1 and only is None and tall is not None:
+            use = gdot is not None and self.norms_valid
+            known = _lib.AdamKnownSums(tall[0], int(use), ops._ptr(gdot) if use else None, ops._ptr(self.vn2))
+        _lib.check(_lib.lib().clv_adam_wn_step_ex(
             table, n, ops._ptr(plan), ops._ptr(self.params), ops._ptr(self.grads),
             ops._ptr(self.m), ops._ptr(self.v), ops._ptr(self.mg), ops._ptr(self.vg), ops._ptr(self.s),
             ops._ptr(self.iterations), -2 if advanced else (0 if advance else -1), lr, b1, b2, eps, int(weightnorm),
-            ops._ptr(self.adam_ws),
+            C.byref(known) if known is not None else None, ops._ptr(self.adam_ws),
             self.adam_ws.numel(), ops._stream()), "clv_adam_wn_step")
+        # vn2 follows the parameters through whole Adam-WN steps only
+        self.norms_valid = known is not None or (self.norms_valid and tall is not None and only is not None
+                                                 and tall[1] not in only)
 
 
 def _f(device, *shape):
@@ -593,6 +614,8 @@ class VrnnEngine(_EngineBase):
         self.dW = _f(d, B, Cn)
         self.dwargs = _f(d, B, 2 * (Cn - 1))
         self.dhW = _f(d, B, D)
+        self.gdot = _f(d, D)                        # sum_j hW/kernel[j,c] * its gradient[j,c]: see FlatParams.adam_step
+        self.gdot_fresh = False
 
     def folds_noise(self):
         """True when forward(noise=...) draws eps_W / eps_Z inside the label and pair kernels (no Philox launch)."""
@@ -978,7 +1001,10 @@ class VrnnEngine(_EngineBase):
                            P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
                            self.dwargs, self.dhW, layer_grad=(P.g('Wargs/kernel'), P.g('Wargs/bias')), ws=ws, defer=self._rq())
         if self.sparse_inputs and ops.sparse_dense_supported(D):      # kernel gradient and bias gradient (column sums of dhW)
-            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'))
+            # ... and sum_j K dK per column for the optimizer's two-launch form (the batch sum of pre-activation x gradient)
+            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'),
+                             gdot=(self.hW, D, P.p('hW/bias'), self.gdot))
+            self.gdot_fresh = True
         else:
             g(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)
             ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)

@@ -100,6 +100,7 @@ class Layer:
             if tuple(arr.shape) != tuple(dst.shape):
                 raise ValueError("layer %s weight %s: shape %s != %s" % (self.name, w, arr.shape, tuple(dst.shape)))
             dst.copy_(torch.as_tensor(arr))
+        P.norms_valid = False
 
 
 class OptimizerSpec:

@@ -29,7 +29,7 @@ class DevWindows:
 
 class TrainStep:
     def __init__(self, engine, seed=1234, rank=0, world=1, group=None, optimizer='adam-wn',
-                 lr=1e-3, use_graph=True):
+                 lr=1e-3, use_graph=True, fast_adam=True):
         self.eng = engine
         self.seed, self.rank, self.world = int(seed), int(rank), int(world)
         if optimizer not in ('adam-wn', 'adam', 'rmsprop'):
@@ -38,6 +38,7 @@ class TrainStep:
         self.b2 = 0.9 if optimizer == 'rmsprop' else 0.999                       # rmsprop: rho
         self.lr = lr
         self.use_graph = use_graph
+        self.fast_adam = bool(fast_adam) and os.environ.get('CLV_FAST_ADAM', '1') != '0'      # see _update()
         cfg, B, d = engine.cfg, engine.B, engine.device
         self.is_vrnn = 'T' in cfg
         T = cfg['T'] if self.is_vrnn else 1
@@ -130,7 +131,13 @@ class TrainStep:
             self.eng.grads_tail(self.X)
 
     def _update(self):
-        self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, advanced=self._folded())
+        # single GPU, cl_vrnn: the backward pass left sum_j K dK of the hW kernel (VrnnEngine.gdot), so Adam-WN runs in two
+        # launches instead of five (FlatParams.adam_step); not under data parallelism (the gradient is averaged afterwards)
+        eng = self.eng
+        gdot = eng.gdot if (self.fast_adam and self.ar is None and getattr(eng, 'gdot_fresh', False)) else None
+        eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, advanced=self._folded(), gdot=gdot)
+        if hasattr(eng, 'gdot_fresh'):
+            eng.gdot_fresh = False
 
     # multi-GPU: the optimizer step in two pieces, the tail bucket's tensor first (its all-reduce has landed under
     # _tail()), the rest once the main bucket is in; `iterations` advances with the second piece
@@ -263,6 +270,9 @@ class TrainStep:
             return
         if self._graphs is None:
             if self.ar is None:
+                # the captured optimizer takes its short form only while the column norms follow the parameters
+                # (FlatParams.norms_valid); a step after they were written from outside runs eagerly (and re-validates)
+                self._graph_fast = bool(getattr(self.eng.P, 'norms_valid', False))
                 with ops.Graph() as g:
                     self._single()
                 self._graphs = (g,)
@@ -282,6 +292,9 @@ class TrainStep:
                         self._update()
                     self._graphs = (g1, g2, g3)
         if self.ar is None:
+            if getattr(self, '_graph_fast', False) and not self.eng.P.norms_valid:
+                self._eager()
+                return
             self._graphs[0].launch()
         else:
             g1, g2, g3 = self._graphs[:3]

@@ -483,6 +483,11 @@ int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, const float*
                      float* out, int ldo, void* stream);
 int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
                      float* colsum /* [N] = sum_b G[b,:], the layer's bias gradient; may be NULL */, void* stream);
+/* ..._ex: gdot != NULL also returns gdot[c] = sum_b (Hact[b,c] - hbias[c]) G[b,c], Hact [Bn,ldh] = the layer's relu output
+ * and G its (relu-masked) upstream gradient: = sum_j K[j,c] dK[j,c], the weight-norm optimizer's sum g.W per column
+ * without a pass over K and dK (clv_adam_wn_step_ex). */
+int clv_sparse_outer_ex(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+                        float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream);
 
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
  * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71).
@@ -559,6 +564,26 @@ size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tenso
 #define CLV_OPT_ADAM_WN  1   /* utils/weightnorm.py:75-143: matrices per output column as g V/||V||, biases plain   */
 #define CLV_OPT_RMSPROP  2   /* Keras RMSprop (the 'rmsprop' optimizer string, cl_vae/train.py:83): a = rho a +     */
                              /* (1 - rho) g^2, p -= lr g / (sqrt(a) + eps); rho = beta2, `v` holds a, `m` is unused  */
+/* clv_adam_wn_step_ex: `known` (may be NULL = clv_adam_wn_step) concerns the ONE tall matrix of the table (more than 128
+ * rows: cl_vrnn's hW/kernel) under CLV_OPT_ADAM_WN:
+ *   vnorm2 [n columns, laid out like s]: every call keeps ||V||^2 per column of the tall matrix there (the rescale leaves
+ *     W = s' V', so the next step's sum V^2 is this step's ||V'||^2);
+ *   use != 0: both column sums of the first pass are known -- sum V^2 from vnorm2 (valid after any earlier call that was
+ *     given vnorm2 and no write to the parameters since) and sum g.V = gdot[c] / s[c] with gdot[c] = sum_b (X W)[b,c]
+ *     dH[b,c] (clv_sparse_outer's gdot: the layer's pre-activation times its upstream gradient, summed over the batch) --
+ *     and the update runs in TWO launches instead of five, with no pass over W and g for the statistics.
+ * Not for gradients that were averaged across ranks after gdot was formed. */
+typedef struct clv_adam_known_sums {
+  int tensor;            /* index of the tall matrix in host_table */
+  int use;
+  const float* gdot;     /* [cols] */
+  float* vnorm2;
+} clv_adam_known_sums;
+int clv_adam_wn_step_ex(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
+                        float* params, const float* grads, float* m, float* v,
+                        float* mg, float* vg, float* s,
+                        int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
+                        int weightnorm, const clv_adam_known_sums* known, void* ws, size_t ws_bytes, void* stream);
 int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
                      float* params, const float* grads, float* m, float* v,
                      float* mg, float* vg, float* s,

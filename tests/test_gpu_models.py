@@ -396,19 +396,24 @@ def test_cl_vrnn_dp_graph_schedule_matches_single_graph(dev, monkeypatch):
     win = frames(rng, B, Tn + 1, 88)
     X, Xp, wt = T(win[:, 1:], dev), T(win[:, :-1], dev), T(np.eye(10)[rng.integers(0, 10, B)], dev)
     out = []
-    for force in ('0', '1'):
+    for force, fast in (('0', False), ('1', False), ('0', True)):
         monkeypatch.setenv('CLV_FORCE_DP_GRAPHS', force)
         eng = VrnnEngine(cfg, B, dev)
         eng.P.set_weights(p)
-        ts = TrainStep(eng, seed=77)
+        ts = TrainStep(eng, seed=77, fast_adam=fast)
         assert (ts.ar is not None) == (force == '1')
         for _ in range(4):
             ts.stage_batch(X, Xp, wt)
             ts.step()
         torch.cuda.synchronize()
+        assert eng.P.norms_valid == (force == '0')          # whole Adam-WN steps keep the column norms; split ones do not
         out.append(eng.P.get_weights())
     for k in out[0]:
         np.testing.assert_array_equal(out[0][k], out[1][k])
+        # the single-GPU default: Adam-WN of the hW kernel in two launches, its first column sums taken from the backward
+        # pass (sum over the batch of pre-activation x gradient) and from the previous step's norms: the same update up to
+        # the rounding of those sums
+        np.testing.assert_allclose(out[2][k], out[0][k], rtol=2e-5, atol=2e-7, err_msg=k)
 
 
 def test_adam_step_in_two_pieces_is_bitwise_the_whole_step(dev):
