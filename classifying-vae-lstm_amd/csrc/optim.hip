@@ -398,9 +398,12 @@ __global__ void adam_bump_kernel(int32_t* iterations) { *iterations += 1; }
 // Launch 1 (wn_fast_update): every block derives its columns' scalars itself and updates 64 rows; block 0 also steps the
 // per-column Adam state of g.  Launch 2 (wn_fast_rescale): every block sums the 176 partial ||V'||^2 rows of its
 // columns (62 KB, L2-resident), rescales its 64 rows; block 0 stores s', ||V'||^2 and advances `iterations`.
+// Measured at config 3 (rocprofv3): 12.5 + 6.5 us against 34.6 us for the classic chain; 128-row blocks (88 of them):
+// 16.2 + 5.8 (too few CUs stream), 64-row blocks of 256 threads: 17.2 + 11.3.
 // The classic chain needs five launches (stats, columns, update, columns, rescale).
 // ---------------------------------------------------------------------------
-constexpr int FAST_ROWS = 64;
+constexpr int FAST_ROWS = 64;       // rows per workgroup: 176 workgroups for hW/kernel, i.e. 176 partial rows for the second launch
+constexpr int FAST_NT = 1024;       // 64 column-pair lanes x 16 row lanes
 struct AdamFast {
   int64_t offset, col_offset;
   int rows, cols, nunits;
@@ -412,10 +415,11 @@ struct AdamFast {
 
 __device__ __forceinline__ void wn_fast_update_body(const AdamFast& f, int unit, float* params, const float* grads, float* m,
                                                     float* v, float* mg, float* vg, const float* s, const AdamHyper& h) {
-  __shared__ float cs[3][128], red[4][128];
+  __shared__ float cs[3][128];
+  __shared__ float2 red[16][64];
   const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6;
   const float lr_t = adam_lr_t(h);
-  for (int c = tid; c < f.cols; c += 256) {                 // this block's copy of the column scalars
+  for (int c = tid; c < f.cols; c += FAST_NT) {             // this block's copy of the column scalars
     const size_t cg = f.col_offset + c;
     const float sc = s[cg], a = f.vn2[cg];
     const float Vn = sqrtf(a), inv_s = 1.f / sc;
@@ -429,89 +433,99 @@ __device__ __forceinline__ void wn_fast_update_body(const AdamFast& f, int unit,
     }
   }
   __syncthreads();
-  const int row0 = unit * FAST_ROWS, nrows = min(FAST_ROWS, f.rows - row0);
-  for (int c0 = 0; c0 < f.cols; c0 += 64) {
-    const int col = c0 + cx;
-    float acc = 0.f;
-    if (col < f.cols) {
-      const float inv_s = cs[0][col], gov = cs[1][col], sc = cs[2][col];
+  const int row0 = unit * FAST_ROWS, nrows = min(FAST_ROWS, f.rows - row0), n2 = f.cols / 2;
+  float2 acc = make_float2(0.f, 0.f);
+  if (cx < n2) {
+    // a thread owns a column pair and every 16th row: its 8 rows x 4 arrays are 32 eight-byte loads in flight at once
+    const float2 inv_s = make_float2(cs[0][2 * cx], cs[0][2 * cx + 1]), gov = make_float2(cs[1][2 * cx], cs[1][2 * cx + 1]);
+    const float2 sc = make_float2(cs[2][2 * cx], cs[2][2 * cx + 1]);
+    float2 pv[FAST_ROWS / 16], gv[FAST_ROWS / 16], mv[FAST_ROWS / 16], vv[FAST_ROWS / 16];
 #pragma unroll
-      for (int blk = 0; blk < FAST_ROWS / 16; ++blk) {      // 4 rows per thread and pass: 16 loads in flight
-        float pv[4], gv[4], mv[4], vv[4];
+    for (int i = 0; i < FAST_ROWS / 16; ++i) {
+      const size_t o = f.offset + (size_t)(row0 + min(ry + 16 * i, nrows - 1)) * f.cols + 2 * cx;
+      pv[i] = *reinterpret_cast<const float2*>(params + o); gv[i] = *reinterpret_cast<const float2*>(grads + o);
+      mv[i] = *reinterpret_cast<const float2*>(m + o); vv[i] = *reinterpret_cast<const float2*>(v + o);
+    }
+    auto one = [&](float p, float g, float m0, float v0, float is, float go, float s0, float& mo, float& vo, float& a2) {
+      const float V = p * is;
+      const float gV = s0 * (g - go * V);
+      mo = h.b1 * m0 + (1.f - h.b1) * gV;
+      vo = h.b2 * v0 + (1.f - h.b2) * gV * gV;
+      const float Vp = V - lr_t * mo / (sqrtf(vo) + h.eps);
+      a2 += Vp * Vp;
+      return Vp;
+    };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 16 * blk + ry + 4 * i;
-          const size_t o = f.offset + (size_t)(row0 + min(r, nrows - 1)) * f.cols + col;
-          pv[i] = params[o]; gv[i] = grads[o]; mv[i] = m[o]; vv[i] = v[o];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 16 * blk + ry + 4 * i;
-          if (r < nrows) {
-            const size_t o = f.offset + (size_t)(row0 + r) * f.cols + col;
-            const float V = pv[i] * inv_s;
-            const float gV = sc * (gv[i] - gov * V);
-            const float mn = h.b1 * mv[i] + (1.f - h.b1) * gV;
-            const float vn = h.b2 * vv[i] + (1.f - h.b2) * gV * gV;
-            m[o] = mn; v[o] = vn;
-            const float Vp = V - lr_t * mn / (sqrtf(vn) + h.eps);
-            params[o] = Vp;
-            acc += Vp * Vp;
-          }
-        }
+    for (int i = 0; i < FAST_ROWS / 16; ++i) {
+      const int r = ry + 16 * i;
+      if (r < nrows) {
+        const size_t o = f.offset + (size_t)(row0 + r) * f.cols + 2 * cx;
+        float2 mo, vo, po;
+        po.x = one(pv[i].x, gv[i].x, mv[i].x, vv[i].x, inv_s.x, gov.x, sc.x, mo.x, vo.x, acc.x);
+        po.y = one(pv[i].y, gv[i].y, mv[i].y, vv[i].y, inv_s.y, gov.y, sc.y, mo.y, vo.y, acc.y);
+        *reinterpret_cast<float2*>(m + o) = mo;
+        *reinterpret_cast<float2*>(v + o) = vo;
+        *reinterpret_cast<float2*>(params + o) = po;
       }
     }
-    red[ry][cx] = acc;
-    __syncthreads();
-    if (ry == 0 && col < f.cols) f.partC[(size_t)unit * f.cols + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
-    __syncthreads();
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && cx < n2) {
+    float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { t.x += red[w][cx].x; t.y += red[w][cx].y; }
+    *reinterpret_cast<float2*>(f.partC + (size_t)unit * f.cols + 2 * cx) = t;
   }
 }
 
-__global__ __launch_bounds__(256) void wn_fast_update_kernel(AdamFast f, const SmallItem* items, float* params,
-                                                             const float* grads, float* m, float* v, float* mg, float* vg,
-                                                             float* s, AdamHyper h) {
+__global__ __launch_bounds__(FAST_NT) void wn_fast_update_kernel(AdamFast f, const SmallItem* items, float* params,
+                                                                 const float* grads, float* m, float* v, float* mg, float* vg,
+                                                                 float* s, AdamHyper h) {
   if ((int)blockIdx.x >= f.nunits) {
+    if (threadIdx.x >= 256) return;           // the small-tensor blocks are 256-thread work: the other waves leave at once
     wn_small_body(items[blockIdx.x - f.nunits], params, grads, m, v, mg, vg, s, h);
     return;
   }
   wn_fast_update_body(f, (int)blockIdx.x, params, grads, m, v, mg, vg, s, h);
 }
 
-__global__ __launch_bounds__(256) void wn_fast_rescale_kernel(AdamFast f, float* params, float* s, int32_t* iterations) {
-  __shared__ float red[4][128], snew[128];
-  const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6, unit = blockIdx.x;
+__global__ __launch_bounds__(FAST_NT) void wn_fast_rescale_kernel(AdamFast f, float* params, float* s, int32_t* iterations) {
+  __shared__ float2 red[16][64], snew[64];
+  const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6, unit = blockIdx.x, n2 = f.cols / 2;
   if (unit == 0 && tid == 0 && iterations) *iterations += 1;
-  for (int c0 = 0; c0 < f.cols; c0 += 64) {
-    const int col = c0 + cx;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (col < f.cols) {
-      int k = ry;
-      for (; k + 12 < f.nunits; k += 16) {                   // 4 partial rows in flight per thread
-        a0 += f.partC[(size_t)k * f.cols + col]; a1 += f.partC[(size_t)(k + 4) * f.cols + col];
-        a2 += f.partC[(size_t)(k + 8) * f.cols + col]; a3 += f.partC[(size_t)(k + 12) * f.cols + col];
-      }
-      for (; k < f.nunits; k += 4) a0 += f.partC[(size_t)k * f.cols + col];
+  float2 a = make_float2(0.f, 0.f);
+  if (cx < n2)
+    for (int k = ry; k < f.nunits; k += 16) {
+      const float2 t = *reinterpret_cast<const float2*>(f.partC + (size_t)k * f.cols + 2 * cx);
+      a.x += t.x; a.y += t.y;
     }
-    red[ry][cx] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (ry == 0 && col < f.cols) {
-      const float a = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
-      const float sn = f.gnew[col] / sqrtf(a);
-      snew[col] = sn;
-      if (unit == 0) { s[f.col_offset + col] = sn; f.vn2[f.col_offset + col] = a; }
+  red[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && cx < n2) {
+    float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { t.x += red[w][cx].x; t.y += red[w][cx].y; }
+    const float2 sn = make_float2(f.gnew[2 * cx] / sqrtf(t.x), f.gnew[2 * cx + 1] / sqrtf(t.y));
+    snew[cx] = sn;
+    if (unit == 0) {
+      *reinterpret_cast<float2*>(s + f.col_offset + 2 * cx) = sn;
+      *reinterpret_cast<float2*>(f.vn2 + f.col_offset + 2 * cx) = t;
     }
-    __syncthreads();
   }
+  __syncthreads();
   const int row0 = unit * FAST_ROWS, nrows = min(FAST_ROWS, f.rows - row0);
-  for (int c0 = 0; c0 < f.cols; c0 += 64) {
-    const int col = c0 + cx;
-    if (col >= f.cols) continue;
-    const float sn = snew[col];
-    for (int r = ry; r < nrows; r += 4) {
-      const size_t o = f.offset + (size_t)(row0 + r) * f.cols + col;
-      params[o] *= sn;
-    }
+  if (cx < n2) {
+    const float2 sn = snew[cx];
+    float2 pv[FAST_ROWS / 16];
+#pragma unroll
+    for (int i = 0; i < FAST_ROWS / 16; ++i)
+      pv[i] = *reinterpret_cast<const float2*>(params + f.offset + (size_t)(row0 + min(ry + 16 * i, nrows - 1)) * f.cols + 2 * cx);
+#pragma unroll
+    for (int i = 0; i < FAST_ROWS / 16; ++i)
+      if (ry + 16 * i < nrows)
+        *reinterpret_cast<float2*>(params + f.offset + (size_t)(row0 + ry + 16 * i) * f.cols + 2 * cx) =
+            make_float2(pv[i].x * sn.x, pv[i].y * sn.y);
   }
 }
 
@@ -638,13 +652,13 @@ extern "C" int clv_adam_wn_step_ex(const clv_param_desc* host_table, int n_tenso
     const int ti = known->tensor;
     if (ti < 0 || ti >= n_tensors || c.n_big != 1 || is_small(host_table[ti]) || !known->gdot || !vn2) return CLV_EINVAL;
     const clv_param_desc& t = host_table[ti];
-    if (t.cols > 128) return CLV_EINVAL;
+    if (t.cols > 128 || t.cols % 2 || t.offset % 2 || t.col_offset % 2) return CLV_EINVAL;      // 8-byte accesses
     const int nunits = (t.rows + FAST_ROWS - 1) / FAST_ROWS;
     if ((size_t)nunits * t.cols > (size_t)c.n_part) return CLV_EWORKSPACE;      // partC lives where the classic chain keeps its own
     AdamFast f{t.offset, t.col_offset, t.rows, t.cols, nunits, known->gdot, vn2, colscal, partC};
-    hipLaunchKernelGGL(wn_fast_update_kernel, dim3(nunits + c.n_small), dim3(256), 0, st, f, small, params, grads, m, v, mg, vg,
-                       s, h);
-    hipLaunchKernelGGL(wn_fast_rescale_kernel, dim3(nunits), dim3(256), 0, st, f, params, s, bump);
+    hipLaunchKernelGGL(wn_fast_update_kernel, dim3(nunits + c.n_small), dim3(FAST_NT), 0, st, f, small, params, grads, m, v, mg,
+                       vg, s, h);
+    hipLaunchKernelGGL(wn_fast_rescale_kernel, dim3(nunits), dim3(FAST_NT), 0, st, f, params, s, bump);
     return launch_status();
   }
   const bool chain = !wn || c.n_big > 0;      // tall matrices (partial slabs), or plain Adam for everything
