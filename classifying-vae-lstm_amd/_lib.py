@@ -60,6 +60,12 @@ class ReduceJob(C.Structure):
     _fields_ = [("opaque", C.c_ubyte * 160)]
 
 
+class SkinnyProduct(C.Structure):
+    """clv_skinny_product: a few-row product riding in the reduction launch (include/clvae.h)."""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("rows", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
+                ("N", C.c_int), ("K", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int), ("bias_row", C.c_void_p)]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
 
@@ -76,6 +82,7 @@ SIGNATURES = {
     "clv_gemm_grouped_tn_deferred": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p, _p]),
     "clv_splitk_reduce_multi": (_i, [_p, _i, _p]),
     "clv_splitk_reduce_multi_means": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
+    "clv_splitk_reduce_multi_ex": (_i, [_p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
     "clv_lstm_wgrad_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_lstm_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "clv_lstm_wgrad": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,

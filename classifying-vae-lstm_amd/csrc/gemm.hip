@@ -702,8 +702,75 @@ __device__ __forceinline__ void mean_block(const MeanTerms& m, int k, float4 (*r
   __syncthreads();
   if (threadIdx.x == 0) m.out[k] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
 }
-__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t, MeanTerms m) {
+// Few-row products over a short K riding in the same launch (clv_splitk_reduce_multi_ex): C[r, :] = sum_k A[k, r] B[k, :] for
+// r < R rows of A [K, lda] plus, with `ones`, the column sums of B as one more row -- the label rows and the bias of an
+// LSTM input-kernel gradient over K = batch rows of sum_t dz (cl_vrnn/model.py:194,223: the RepeatVector(W) columns).
+// A launch of their own was 8.6 us for 2 MFLOP.  A block owns 64 columns; 4 k-lanes stride through K with every row's
+// accumulator in registers; the A chunk is staged in LDS (broadcast reads).
+constexpr int SR_ROWS = 16, SR_KC = 256;
+struct SkinnySet { const float* A; int lda, R, ones; const float* B; int ldb, N, K; float* C; int ldc; float* Cones; };
+struct SkinnyRider { int nsets, blocks_per_set; SkinnySet set[2]; };
+__device__ __forceinline__ void skinny_rider_block(const SkinnyRider& sr, int blk) {
+  __shared__ __attribute__((aligned(16))) float At[SR_KC][SR_ROWS];
+  __shared__ float redk[3][SR_ROWS][64];
+  const bool second = blk >= sr.blocks_per_set;
+  const SkinnySet g = second ? sr.set[1] : sr.set[0];
+  const int tid = threadIdx.x, cx = tid & 63, kl = tid >> 6;
+  const int col = (blk - (second ? sr.blocks_per_set : 0)) * 64 + cx;
+  const bool live = col < g.N;
+  const int R = g.R + (g.ones ? 1 : 0);
+  float acc[SR_ROWS];
+#pragma unroll
+  for (int r = 0; r < SR_ROWS; ++r) acc[r] = 0.f;
+  for (int kc = 0; kc < g.K; kc += SR_KC) {
+    __syncthreads();
+    for (int e = tid; e < SR_KC * SR_ROWS; e += 256) {       // A^T chunk (+ the ones row) -> LDS
+      const int kk = e / SR_ROWS, r = e % SR_ROWS, k = kc + kk;
+      float v = 0.f;
+      if (k < g.K) v = r < g.R ? g.A[(size_t)k * g.lda + r] : (r == g.R && g.ones ? 1.f : 0.f);
+      At[kk][r] = v;
+    }
+    float breg[SR_KC / 4];
+#pragma unroll
+    for (int j = 0; j < SR_KC / 4; ++j) {                    // this thread's B values of the chunk, all in flight
+      const int k = kc + kl + 4 * j;
+      const float v = g.B[(size_t)min(k, g.K - 1) * g.ldb + min(col, g.N - 1)];
+      breg[j] = v * ((live && k < g.K) ? 1.f : 0.f);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < SR_KC / 4; ++j) {
+      const float4* arow = reinterpret_cast<const float4*>(At[kl + 4 * j]);
+#pragma unroll
+      for (int r4 = 0; r4 < SR_ROWS / 4; ++r4) {
+        const float4 a = arow[r4];
+        acc[4 * r4] = fmaf(a.x, breg[j], acc[4 * r4]);
+        acc[4 * r4 + 1] = fmaf(a.y, breg[j], acc[4 * r4 + 1]);
+        acc[4 * r4 + 2] = fmaf(a.z, breg[j], acc[4 * r4 + 2]);
+        acc[4 * r4 + 3] = fmaf(a.w, breg[j], acc[4 * r4 + 3]);
+      }
+    }
+  }
+  if (kl > 0) {
+#pragma unroll
+    for (int r = 0; r < SR_ROWS; ++r) redk[kl - 1][r][cx] = acc[r];
+  }
+  __syncthreads();
+  if (kl == 0 && live) {
+#pragma unroll
+    for (int r = 0; r < SR_ROWS; ++r) {
+      if (r < R) {
+        const float v = ((acc[r] + redk[0][r][cx]) + (redk[1][r][cx] + redk[2][r][cx]));
+        if (r < g.R) g.C[(size_t)r * g.ldc + col] = v;
+        else g.Cones[col] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t, MeanTerms m, SkinnyRider sr) {
   __shared__ float4 red[16][16];
+  if (blockIdx.x >= t.blk0[t.njobs] + (unsigned)m.n_terms) { skinny_rider_block(sr, blockIdx.x - t.blk0[t.njobs] - m.n_terms); return; }
   if (blockIdx.x >= t.blk0[t.njobs]) { mean_block(m, blockIdx.x - t.blk0[t.njobs], red); return; }
   int ji = 0;
 #pragma unroll
@@ -973,7 +1040,24 @@ extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, vo
 
 extern "C" int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
                                              const int* stride, int n_terms, float* means_out, void* stream) {
+  return clv_splitk_reduce_multi_ex(jobs, njobs, x, n, stride, n_terms, means_out, nullptr, 0, stream);
+}
+
+extern "C" int clv_splitk_reduce_multi_ex(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
+                                          const int* stride, int n_terms, float* means_out,
+                                          const clv_skinny_product* riders, int n_riders, void* stream) {
   using namespace clv;
+  SkinnyRider sr{};
+  if (n_riders < 0 || n_riders > 2 || (n_riders > 0 && !riders)) return CLV_EINVAL;
+  for (int i = 0; i < n_riders; ++i) {
+    const clv_skinny_product& r = riders[i];
+    if (!r.A || !r.B || !r.C || r.rows < 1 || r.rows + (r.bias_row ? 1 : 0) > SR_ROWS || r.N <= 0 || r.K <= 0 ||
+        (i > 0 && r.N != riders[0].N))
+      return CLV_EINVAL;
+    sr.set[i] = SkinnySet{r.A, r.lda, r.rows, r.bias_row ? 1 : 0, r.B, r.ldb, r.N, r.K, r.C, r.ldc, r.bias_row};
+  }
+  sr.nsets = n_riders;
+  sr.blocks_per_set = n_riders ? (riders[0].N + 63) / 64 : 0;
   if (njobs < 0 || (njobs > 0 && !jobs) || n_terms < 0 || n_terms > 5) return CLV_EINVAL;
   if (n_terms > 0 && (!x || !n || !stride || !means_out)) return CLV_EINVAL;
   MeanTerms m{};
@@ -996,10 +1080,11 @@ extern "C" int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njo
     t.job[t.njobs++] = j;
     blk += reduce_blocks(j);
   }
-  if (t.njobs == 0 && n_terms == 0) return CLV_OK;
+  if (t.njobs == 0 && n_terms == 0 && n_riders == 0) return CLV_OK;
   t.blk0[t.njobs] = blk;
   ProfScope p("gemm_splitk_reduce", s);
-  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blk + (unsigned)n_terms), dim3(256), 0, s, t, m);
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blk + (unsigned)n_terms + (unsigned)(sr.nsets * sr.blocks_per_set)),
+                     dim3(256), 0, s, t, m, sr);
   return launch_status();
 }
 

@@ -1027,12 +1027,19 @@ class VrnnEngine(_EngineBase):
             self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)
         self._head_grad_done = False
         self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
+        skinny = None
         if Cn + 1 <= 16 and B <= 4096:
-            wprobs = lambda name, w_row: [dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
-                                          dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)]
-            ops.gemm_grouped_tn_small2(wprobs('encoder_h', D), self.dzsum_enc, wprobs('decoder_h', off + L), self.dzsum_dec,
-                                       4 * H, B)
+            # label rows + bias of both LSTMs' input-kernel gradients (K = batch rows of sum_t dz)
+            if rq is not None:      # ... as rider blocks of the reduction launch
+                skinny = [dict(A=self.W, lda=Cn, rows=Cn, B=dzs, ldb=4 * H, N=4 * H, K=B,
+                               C=P.rows(P.grads, name + '/kernel', w_row), ldc=4 * H, bias_row=P.g(name + '/bias'))
+                          for name, w_row, dzs in (('encoder_h', D, self.dzsum_enc), ('decoder_h', off + L, self.dzsum_dec))]
+            else:
+                wprobs = lambda name, w_row: [dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
+                                              dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)]
+                ops.gemm_grouped_tn_small2(wprobs('encoder_h', D), self.dzsum_enc, wprobs('decoder_h', off + L),
+                                           self.dzsum_dec, 4 * H, B)
         # (the Wargs layer's gradient: per-row slabs of the label backward kernel, already among the pending reductions)
         if rq is not None:
-            rq.flush(means=getattr(self, '_loss_terms', None), out=self.scal)
+            rq.flush(means=getattr(self, '_loss_terms', None), out=self.scal, skinny=skinny)
             self._loss_terms = None

@@ -59,16 +59,23 @@ class ReduceQueue:
         self.n += 1
         return j
 
-    def flush(self, means=None, out=None):
+    def flush(self, means=None, out=None, skinny=None):
         """Run the pending reductions in one launch.  means: up to five (tensor, n, stride) terms whose means go to
-        out[k] from extra blocks of the same launch (a step's loss terms: no launch of their own)."""
-        if means:
+        out[k] from extra blocks of the same launch (a step's loss terms: no launch of their own).  skinny: up to two
+        dict(A, lda, rows, B, ldb, N, K, C, ldc, bias_row) few-row products A[:, :rows]^T B riding along as well."""
+        if means or skinny:
+            means = means or []
             k = len(means)
-            xs = (C.c_void_p * k)(*[_ptr(t) for t, _, _ in means])
-            ns = (C.c_int * k)(*[int(n) for _, n, _ in means])
-            st = (C.c_int * k)(*[int(s) for _, _, s in means])
-            check(_lib.lib().clv_splitk_reduce_multi_means(self.jobs, self.n, xs, ns, st, k, _ptr(out), _stream()),
-                  "clv_splitk_reduce_multi_means")
+            xs = (C.c_void_p * max(k, 1))(*[_ptr(t) for t, _, _ in means])
+            ns = (C.c_int * max(k, 1))(*[int(n) for _, n, _ in means])
+            st = (C.c_int * max(k, 1))(*[int(s) for _, _, s in means])
+            skinny = skinny or []
+            riders = (_lib.SkinnyProduct * max(len(skinny), 1))()
+            for i, p in enumerate(skinny):
+                riders[i] = _lib.SkinnyProduct(_ptr(p['A']), p['lda'], p['rows'], _ptr(p['B']), p['ldb'], p['N'], p['K'],
+                                               _ptr(p['C']), p['ldc'], _ptr(p.get('bias_row')))
+            check(_lib.lib().clv_splitk_reduce_multi_ex(self.jobs, self.n, xs, ns, st, k, _ptr(out), riders, len(skinny),
+                                                        _stream()), "clv_splitk_reduce_multi_ex")
         elif self.n:
             check(_lib.lib().clv_splitk_reduce_multi(self.jobs, self.n, _stream()), "clv_splitk_reduce_multi")
         self.n = 0

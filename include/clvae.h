@@ -133,6 +133,18 @@ int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream)
  * x / n / stride are host arrays of n_terms entries (device pointers in x). */
 int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
                                   const int* stride, int n_terms, float* means_out, void* stream);
+/* ... and with up to two few-row products riding in the launch as well: C[r, :N] = sum_k A[k, r] B[k, :N] for r < rows
+ * (rows + (bias_row != NULL) <= 16), bias_row[:N] = column sums of B -- the label rows and the bias of an LSTM
+ * input-kernel gradient over K = batch rows of sum_t dz; both products must have the same N. */
+typedef struct clv_skinny_product {
+  const float* A; int lda, rows;      /* A [K, lda]: the first `rows` columns are the products' rows */
+  const float* B; int ldb, N, K;
+  float* C; int ldc;
+  float* bias_row;                    /* may be NULL */
+} clv_skinny_product;
+int clv_splitk_reduce_multi_ex(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
+                               const int* stride, int n_terms, float* means_out,
+                               const clv_skinny_product* riders, int n_riders, void* stream);
 
 /* Every kernel gradient of one LSTM in one pass over dz [K,N], N = 4H = 352, K = B*T (cl_vrnn/model.py:196-199,
  * 225-228; replaces the grouped f32-MFMA product for these shapes):

@@ -727,3 +727,43 @@ def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer, nh):
         mag = np.abs(f8(A)).T @ np.abs(f8(dz)) + 1e-30
         err = np.abs(got.cpu().numpy() - ref) / mag
         assert err.max() < 2e-6, err.max()          # fp32 accumulation of exact products over K terms
+
+
+@pytest.mark.parametrize("K,N,R,with_jobs", [(256, 352, 5, True), (1, 352, 5, False), (300, 100, 15, False),
+                                              (1000, 64, 1, True), (37, 353, 9, False)])
+def test_reduce_launch_skinny_riders(dev, K, N, R, with_jobs):
+    """clv_splitk_reduce_multi_ex: two few-row products A[:, :R]^T B (+ the column sums of B) from rider blocks of the
+    reduction launch -- the label rows and biases of both LSTM input-kernel gradients (cl_vrnn/model.py:194,223) --
+    with and without pending reductions and loss means in the same launch, ragged N / K and one chunk and several."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(K + N)
+    lda = R + 2
+    A = rng.standard_normal((K, lda)).astype(np.float32)
+    Bs = [rng.standard_normal((K, N)).astype(np.float32) for _ in range(2)]
+    Cs = [torch.full((R + 1, N + 3), -7.0, dtype=torch.float32, device=dev) for _ in range(2)]
+    bias = [torch.full((N,), -7.0, dtype=torch.float32, device=dev) for _ in range(2)]
+    Ad, Bd = T(A, dev), [T(b, dev) for b in Bs]
+    rq, ws = ops.ReduceQueue(dev), ops.Workspace(dev)
+    out = torch.zeros(8, dtype=torch.float32, device=dev)
+    means, ref_c = None, None
+    if with_jobs:
+        M2, N2, K2 = 40, 48, 5000
+        a2, b2 = rng.standard_normal((K2, M2)).astype(np.float32), rng.standard_normal((K2, N2)).astype(np.float32)
+        c2 = torch.zeros(M2, N2, dtype=torch.float32, device=dev)
+        ops.gemm(T(a2, dev), T(b2, dev), c2, M2, N2, K2, ta=True, split_k=8, ws=ws, defer=rq)
+        ref_c = a2.astype(np.float64).T @ b2
+        means = [(Bd[0], K * N, 1)]
+    skinny = [dict(A=Ad, lda=lda, rows=R, B=Bd[i], ldb=N, N=N, K=K, C=Cs[i], ldc=N + 3, bias_row=bias[i] if i == 0 else None)
+              for i in range(2)]
+    rq.flush(means=means, out=out, skinny=skinny)
+    torch.cuda.synchronize()
+    for i in range(2):
+        ref = A[:, :R].astype(np.float64).T @ Bs[i]
+        got = Cs[i].cpu().numpy()
+        np.testing.assert_allclose(got[:R, :N], ref, rtol=1e-5, atol=1e-5 * np.sqrt(K))
+        assert (got[R:, :] == -7.0).all() and (got[:, N:] == -7.0).all()
+    np.testing.assert_allclose(bias[0].cpu().numpy(), Bs[0].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5 * np.sqrt(K))
+    assert (bias[1].cpu().numpy() == -7.0).all()
+    if with_jobs:
+        np.testing.assert_allclose(c2.cpu().numpy(), ref_c, rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(out[0].item(), Bs[0].astype(np.float64).mean(), rtol=1e-4, atol=1e-5)
