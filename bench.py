@@ -325,6 +325,23 @@ def main():
         for t_ in eng.P.state_tensors():
             dist.broadcast(t_, src=0)
     X_all, Xp_all, w_all = synthetic_windows(w, 4 * B, 1234 + rank, dev)
+    recs, reps = None, 40
+    if rank == 0 and not args.no_roofline:
+        # The roofline object's per-kernel HIP-event timing (eager launches on the same stream, same shapes), BEFORE the
+        # warm-up and the timed region: its steps are rank 0's alone, so parameters and optimizer state are put back
+        # afterwards; the timed steps then start on a device that has already been running this workload
+        saved = [t_.clone() for t_ in eng.P.state_tensors()]
+        ts_e = TrainStep(eng, seed=1234, rank=rank, world=1, use_graph=False)
+        ts_e.stage_batch(X_all[:B], Xp_all[:B], w_all[:B])
+        ts_e.step(); torch.cuda.synchronize()
+        ops.prof_enable(True)
+        for _ in range(reps):
+            ts_e.step()
+        recs = ops.prof_collect()
+        ops.prof_enable(False)
+        for t_, sv in zip(eng.P.state_tensors(), saved):
+            t_.copy_(sv)
+        del ts_e, saved
     ts = TrainStep(eng, seed=1234, rank=rank, world=world, use_graph=not args.no_graph)
     nb = X_all.shape[0] // B
 
@@ -358,21 +375,7 @@ def main():
     value = world * B * T * args.steps / dt
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
-        # per-kernel HIP-event timing (eager launches on the same stream, same shapes); the steps of this pass are
-        # rank 0's alone, so parameters and optimizer state are put back afterwards
-        saved = [t_.clone() for t_ in eng.P.state_tensors()]
-        ts_e = TrainStep(eng, seed=1234, rank=rank, world=1, use_graph=False)
-        ts_e.stage_batch(X_all[:B], Xp_all[:B], w_all[:B])
-        ts_e.step(); torch.cuda.synchronize()
-        ops.prof_enable(True)
-        reps = 10
-        for _ in range(reps):
-            ts_e.step()
-        recs = ops.prof_collect()
-        ops.prof_enable(False)
-        for t_, sv in zip(eng.P.state_tensors(), saved):
-            t_.copy_(sv)
+    if recs is not None:
         if args.kernel_times:
             tot = sum(r[2] for r in recs)
             for name, n, ms in sorted(recs, key=lambda r: -r[2]):
@@ -420,7 +423,8 @@ def main():
                         avg_launch_us=round(avg_s * 1e6, 2),
                         whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4),
                         step_traffic=step_traffic, traffic_source=traffic_source,
-                        traffic_measured_in_this_run=False)
+                        traffic_measured_in_this_run=False,
+                        kernel_time_pass="%d eager steps with HIP events around every launch, before the warm-up" % reps)
         if w['model'] == 'cl_vrnn':
             # the recurrent products run on the fp32 VECTOR pipe (v_pk_fma_f32; one batch row per CU leaves the matrix
             # cores' M dimension empty); its peak equals the fp32 MFMA peak, which is what `peak` holds

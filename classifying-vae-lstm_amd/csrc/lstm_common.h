@@ -52,7 +52,14 @@ constexpr int PK = 4;                   // k-slices per unit
 constexpr int PKK = LH / PK;            // 22 k values per slice
 constexpr int PKP = 24;                 // padded slice stride in LDS (16-byte aligned)
 
-__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef PAIR_ABL
+#define PAIR_ABL 0
+#endif
+// (PAIR_ABL == 3: timing ablation without the barrier itself)
+__device__ __forceinline__ void step_barrier() {
+  if (PAIR_ABL == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // v[i] for a per-lane i in 0..3 as three v_cndmask_b32 on lane masks kept in SGPR pairs.  Written as a chain of selects
 // on `i == const` the compiler recognises a dynamic index into a 4-element array and puts the array in LDS
@@ -93,11 +100,19 @@ __device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)
 }
 
 // the same product in pieces: the slice's h values, then the k range [K0, K1) with scalar FMAs
+// -DPAIR_ABL=1 / 2 (timing ablations, wrong results): only the first half of a slice is read (the rest reuses it) / nothing is
+// read at all -- what the 72 ds_read_b128 of a step cost on its critical path (profiles/r03_pair_lds_ablation.txt)
+#ifndef PAIR_ABL
+#define PAIR_ABL 0
+#endif
 __device__ __forceinline__ void load_hslice(const float* hslice, float (&hv)[PKP]) {
   const float4* hp = reinterpret_cast<const float4*>(hslice);
 #pragma unroll
   for (int q = 0; q < PKP / 4; ++q) {
-    const float4 v = hp[q];
+    float4 v;
+    if (PAIR_ABL == 2) { asm volatile("; no read" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
+    else if (PAIR_ABL == 1 && q >= 3) { v = make_float4(hv[4 * (q - 3)], hv[4 * (q - 3) + 1], hv[4 * (q - 3) + 2], hv[4 * (q - 3) + 3]); }
+    else v = hp[q];
     hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
   }
 }

@@ -52,6 +52,42 @@ __device__ unsigned long long g_pair_arrive[8][12][2];     // [step][wave of the
 #define PARRIVE(widx, t, dep) do { } while (0)
 #define PTOP(dep) do { } while (0)
 #endif
+// -DPAIR_PHASES: every wave of workgroup 0 sums, over all steps of the forward kernel, the shader-clock time it spends
+//   [0] from leaving the barrier to having its prefetched input (the s_waitcnt vmcnt at the top of the step),
+//   [1] from there to the reduced gate sum (LDS reads, 44 packed FMAs, slice reduce),
+//   [2] from there to its arrival at the barrier (activation, cell, LDS write, stores issued),
+//   [3] in the barrier (incl. the lgkmcnt(0) in front of it), until it runs again
+// in SGPR accumulators (nothing is stored inside the loop); tools/pair_phases.py prints them per wave.
+#ifdef PAIR_PHASES
+__device__ unsigned g_pair_phase[12][4];
+#define PH_DECL unsigned long long phA = 0, phB = 0, phD = 0, phC = 0; unsigned phPrev = 0, phAcc0 = 0, phAcc1 = 0, phAcc2 = 0, phAcc3 = 0, phN = 0
+#define PH_A() asm volatile("s_memtime %0" : "=s"(phA))
+#define PH_B(dep) asm volatile("s_memtime %0" : "=s"(phB) : "v"(dep))
+#define PH_D(dep) asm volatile("s_memtime %0" : "=s"(phD) : "v"(dep))
+#define PH_C(dep) asm volatile("s_memtime %0" : "=s"(phC) : "v"(dep))
+#define PH_ACC()                                                                     \
+  do {                                                                               \
+    phAcc0 += (unsigned)phB - (unsigned)phA; phAcc1 += (unsigned)phD - (unsigned)phB;   \
+    phAcc2 += (unsigned)phC - (unsigned)phD;                                          \
+    phAcc3 += phN ? (unsigned)phA - phPrev : 0u;                                      \
+    phPrev = (unsigned)phC; phN = 1;                                                  \
+  } while (0)
+#define PH_OUT(widx)                                                                 \
+  do {                                                                               \
+    if (blockIdx.x == 0 && lane == 0) {                                              \
+      g_pair_phase[widx][0] = phAcc0; g_pair_phase[widx][1] = phAcc1;                \
+      g_pair_phase[widx][2] = phAcc2; g_pair_phase[widx][3] = phAcc3;                \
+    }                                                                                \
+  } while (0)
+#else
+#define PH_DECL do { } while (0)
+#define PH_A() do { } while (0)
+#define PH_B(dep) do { } while (0)
+#define PH_D(dep) do { } while (0)
+#define PH_C(dep) do { } while (0)
+#define PH_ACC() do { } while (0)
+#define PH_OUT(widx) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256) void lstm_pair_pack_kernel(PairPackArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -99,7 +135,7 @@ __device__ __forceinline__ float quad_bcast(float v) { return dpp_mov<K * 0x55>(
 template <int GATE>
 __device__ __forceinline__ float pair_cell(const SliceMasks& sm, float z, float& c, float& vA, float& act, float& kc) {
   float a, d;                        // activation of this lane's gate and its derivative
-  const float th = fast_tanh(z);
+  const float th = PAIR_ABL == 4 ? z * 0.25f : fast_tanh(z);
   if (GATE == CLV_GATE_HARD_SIGMOID) {
     const float y = fmaf(0.2f, z, 0.5f);
     const float hsv = __builtin_amdgcn_fmed3f(y, 0.f, 1.f);
@@ -114,7 +150,7 @@ __device__ __forceinline__ float pair_cell(const SliceMasks& sm, float z, float&
   const float gg = quad_bcast<2>(a);
   const float igg = quad_bcast<0>(a) * gg;
   const float cn = fmaf(quad_bcast<1>(a), c, igg);
-  const float tc = fast_tanh(cn);
+  const float tc = PAIR_ABL == 4 ? cn * 0.25f : fast_tanh(cn);
   const float og = quad_bcast<3>(a);
   const float h = og * tc;
   // k of this lane: d * (gg, c_{t-1}, ig, tc)[s]: lanes 0 / 2 swap their activations, lanes 1 / 3 take c_{t-1} / tc
@@ -160,6 +196,8 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
+  if (PAIR_ABL == 5) { asm volatile("" :: "v"(v)); return; }
+  if (PAIR_ABL == 9) soff = 0;      // every step's stores land on the row's first frame: no write traffic beyond L2
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 __device__ __forceinline__ float lane_permute(int addr, float v) {
@@ -325,6 +363,12 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
                                     : ((!is_z && (s == 1 || s == 2)) ? ((s - 1) * LH + u) * 4 : BUF_OOB);
   const unsigned vo_e = (lat_ok ? lat : 0) * 4;
   const unsigned vo_za = lat_ok ? zcol * 4 : BUF_OOB;
+  if (PAIR_ABL == 6) {      // timing ablation: lane-contiguous addresses (wrong layout, same instruction count)
+    const_cast<unsigned&>(vo_g) = is_z ? BUF_OOB : (wave * 64 + lane) * 4;
+    const_cast<unsigned&>(vo_h) = (!is_z && lane < 16) ? (wave * 16 + lane) * 4 : BUF_OOB;
+    const_cast<unsigned&>(vo_a) = (!is_z && lane >= 16 && lane < 48) ? (wave * 32 + lane - 16) * 4 : BUF_OOB;
+    xp.vo = (wave * 64 + lane) * 4;
+  }
   const unsigned vo_z = (lat_ok && s < 2) ? lat * 4 : BUF_OOB;
   const unsigned vo_kl = (lat_ok && s >= 2) ? lat * 4 : BUF_OOB;
   float rb;
@@ -371,13 +415,17 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     buf_store(klv, r_kl, vo_kl, (unsigned)row * (unsigned)(L * 4));
   };
 
+  PH_DECL;
   auto step = [&](auto parc, int i, XSet<XL>& xa, uint2& na, float& ea) {
     constexpr int cur = decltype(parc)::value;
-    XProj<XL>::pin(xa);
-    float xv = XProj<XL>::sum(xa, rb, paddr, LATW ? xmask : 1.f);
+    PH_A();
+    if (PAIR_ABL != 7) XProj<XL>::pin(xa);
+    float xv = PAIR_ABL == 7 ? rb : XProj<XL>::sum(xa, rb, paddr, LATW ? xmask : 1.f);
     if constexpr (XL) { if (xa.more) xv = fmaf(xp.extra(i, paddr), LATW ? xmask : 1.f, xv); }
     PTOP(xv);
+    PH_B(xv);
     const float z = gate_sum(&hb[cur][PKP * s], xv);
+    PH_D(z);
     float vA, act, kc;
     const float h = pair_cell<GATE>(sm, z, c, vA, act, kc);
     if (!is_z) hb[cur ^ 1][hslot] = h;
@@ -395,11 +443,14 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     buf_store(pB, r_a, vo_a, (unsigned)i * (unsigned)(2 * LH * 4));
     // the loads of step i+2 into the registers this step has just consumed; issued BEHIND the stores, so that the wait at
     // the top of step i+2 lets everything step i+1 issues stay in flight
+    if (PAIR_ABL == 7) XProj<XL>::pin(xa);      // (timing ablation: the prefetched value is "used" here, 0.8 steps later)
     xp.load(xa, na, i + 2);
     if constexpr (XL) na = xp.notes(i + 4);
     if (LATW) ea = buf_load(r_e, vo_e, (unsigned)min(i + 1, T - 1) * (unsigned)(L * 4));
     PARRIVE(wave, i + 2, vA + h);                       // the encoder runs two steps ahead of the decoder's step index
+    PH_C(vA + h);
     step_barrier();
+    PH_ACC();
   };
   // An odd T runs one step more (no separate tail: a second copy of the step after the loop costs register moves at the
   // loop header): step T reads clamped rows, its stores lie beyond num_records and are dropped, and its latent head is
@@ -408,6 +459,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
     step(ParC<0>(), i, xA, nA, eA);
     step(ParC<1>(), i + 1, xB, nB, eB);
   }
+  PH_OUT(wave);
   // iteration T: only the latent head of step T-1 is left
   if (LATW) {
     const float z = gate_sum(&hb[T & 1][PKP * s], rb);
@@ -462,6 +514,12 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   xp.T = T;
   const float rb = a.rb_d[(size_t)b * LG + loff];
   const int hslot = pair_hslot(u);
+  if (PAIR_ABL == 6) {
+    const_cast<unsigned&>(vo_g) = min(wave * 64 + lane, LG - 1) * 4;
+    const_cast<unsigned&>(vo_h) = lane < 16 ? min(wave * 16 + lane, LH - 1) * 4 : BUF_OOB;
+    const_cast<unsigned&>(vo_a) = (lane >= 16 && lane < 48) ? min(wave * 32 + lane - 16, 2 * LH - 1) * 4 : BUF_OOB;
+    xp.vo = min(wave * 64 + lane, LG - 1) * 4;
+  }
   float c = 0.f;
   XSet<XL> xA, xB;
   uint2 nA = make_uint2(0, 0), nB = nA;
@@ -475,16 +533,19 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   prologue_loads_done();
   step_barrier();          // the encoder is two steps ahead
   step_barrier();
+  PH_DECL;
   auto step = [&](auto parc, int t, XSet<XL>& xa, uint2& na) {
     constexpr int cur = decltype(parc)::value;
 #ifdef PAIR_STAMPS
     unsigned long long pst[8];
 #endif
-    XProj<XL>::pin(xa);
-    float xv = XProj<XL>::sum(xa, rb, paddr);
+    PH_A();
+    if (PAIR_ABL != 7) XProj<XL>::pin(xa);
+    float xv = PAIR_ABL == 7 ? rb : XProj<XL>::sum(xa, rb, paddr);
     if constexpr (XL) { if (xa.more) xv += xp.extra(t, paddr); }
     PSTAMP(0, xv);
     PTOP(xv);
+    PH_B(xv);
     f2 acc[4];       // (even k, odd k) partial sums
     acc[0] = (f2){xv, 0.f};
 #pragma unroll
@@ -504,6 +565,7 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     }
     const float z = reduce_scatter4(as[0], as[1], as[2], as[3]);
     PSTAMP(4, z);
+    PH_D(z);
     float vA, act, kc;
     const float h = pair_cell<GATE>(sm, z, c, vA, act, kc);
     PSTAMP(5, h);
@@ -514,12 +576,15 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     buf_store(pB, r_h, vo_h, (unsigned)t * (unsigned)(LH * 4));
     buf_store(pB, r_a, vo_a, (unsigned)t * (unsigned)(2 * LH * 4));
     if constexpr (HASXP) {              // behind the stores: see the encoder
+      if (PAIR_ABL == 7) XProj<XL>::pin(xa);
       xp.load(xa, na, t + 2);
       if constexpr (XL) na = xp.notes(t + 4);
     }
     PSTAMP(6, vA + h);
     PARRIVE(PNW + wave, t, vA + h);
+    PH_C(vA + h);
     step_barrier();
+    PH_ACC();
 #ifdef PAIR_STAMPS
     if (blockIdx.x == 0 && wave == 0 && lane == 0 && t >= 32 && t < 40) {
       unsigned long long now;
@@ -534,6 +599,7 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
     step(ParC<0>(), t, xA, nA);
     step(ParC<1>(), t + 1, xB, nB);
   }
+  PH_OUT(PNW + wave);
 }
 
 template <int GATE, bool HASXP, int ZQ, bool XL>
@@ -687,7 +753,10 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     float dv[BW_CP];
 #pragma unroll
     for (int j = 0; j < BW_CP / 4; ++j) {
-      const float4 v = dp[j];
+      float4 v;
+      if (PAIR_ABL == 2) { asm volatile("; no read" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
+      else if (PAIR_ABL == 1 && j >= 3) { v = make_float4(dv[4 * (j - 3)], dv[4 * (j - 3) + 1], dv[4 * (j - 3) + 2], dv[4 * (j - 3) + 3]); }
+      else v = dp[j];
       dv[4 * j] = v.x; dv[4 * j + 1] = v.y; dv[4 * j + 2] = v.z; dv[4 * j + 3] = v.w;
     }
     f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
@@ -799,6 +868,11 @@ __global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
 
 }  // namespace clv
 
+#ifdef PAIR_PHASES
+extern "C" int clv_debug_pair_phases(unsigned* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_pair_phase), sizeof(unsigned) * 48);
+}
+#endif
 #ifdef PAIR_STAMPS
 extern "C" int clv_debug_pair_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_pair_stamps), sizeof(unsigned long long) * 64);

@@ -23,8 +23,10 @@ for w in cfg3 cfg5; do
   done
   python3 tools/pmc_traffic.py $w $G/${TAG}_pmc_FETCH_SIZE_$w/t_counter_collection.csv $G/${TAG}_pmc_WRITE_SIZE_$w/t_counter_collection.csv $G/${TAG}_pmc_traffic_$w.json 9
 done
-(cd /tmp && rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $G/${TAG}_sq1 -o s --output-format csv -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $G/${TAG}_sq1.log 2>&1)
-(cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY --kernel-trace -d $G/${TAG}_sq2 -o s --output-format csv -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $G/${TAG}_sq2.log 2>&1)
-python3 tools/pmc_sq.py $G/${TAG}_sq_cfg3.json $G/${TAG}_sq1/s_counter_collection.csv $G/${TAG}_sq2/s_counter_collection.csv
+for w in cfg3 cfg5; do
+  (cd /tmp && rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $G/${TAG}_sq1_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $G/${TAG}_sq1_$w.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY --kernel-trace -d $G/${TAG}_sq2_$w -o s --output-format csv -- python3 $R/bench.py --workload $w --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $G/${TAG}_sq2_$w.log 2>&1)
+  python3 tools/pmc_sq.py $G/${TAG}_sq_$w.json $G/${TAG}_sq1_$w/s_counter_collection.csv $G/${TAG}_sq2_$w/s_counter_collection.csv
+done
 tail -n 1 $G/${TAG}_bench_*.json | cut -c1-300
 head -12 $G/${TAG}_kernel_stats_cfg3.csv | cut -c1-150
