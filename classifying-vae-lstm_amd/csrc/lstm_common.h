@@ -101,7 +101,7 @@ __device__ __forceinline__ void slice_matvec(const float* hslice, const f2 (&Ur)
 
 // the same product in pieces: the slice's h values, then the k range [K0, K1) with scalar FMAs
 // -DPAIR_ABL=1 / 2 (timing ablations, wrong results): only the first half of a slice is read (the rest reuses it) / nothing is
-// read at all -- what the 72 ds_read_b128 of a step cost on its critical path (profiles/r03_pair_lds_ablation.txt)
+// read at all -- what the 72 ds_read_b128 of a step cost on its critical path (profiles/r03_pair_ablation.txt)
 #ifndef PAIR_ABL
 #define PAIR_ABL 0
 #endif
