@@ -707,12 +707,13 @@ __device__ __forceinline__ void mean_block(const MeanTerms& m, int k, float4 (*r
 // LSTM input-kernel gradient over K = batch rows of sum_t dz (cl_vrnn/model.py:194,223: the RepeatVector(W) columns).
 // A launch of their own was 8.6 us for 2 MFLOP.  A block owns 64 columns; 4 k-lanes stride through K with every row's
 // accumulator in registers; the A chunk is staged in LDS (broadcast reads).
-constexpr int SR_ROWS = 16, SR_KC = 256;
+constexpr int SR_ROWS = 16, SR_KC = 32;
 struct SkinnySet { const float* A; int lda, R, ones; const float* B; int ldb, N, K; float* C; int ldc; float* Cones; };
 struct SkinnyRider { int nsets, blocks_per_set; SkinnySet set[2]; };
 __device__ __forceinline__ void skinny_rider_block(const SkinnyRider& sr, int blk) {
-  __shared__ __attribute__((aligned(16))) float At[SR_KC][SR_ROWS];
-  __shared__ float redk[3][SR_ROWS][64];
+  // one buffer: the A^T chunk [SR_KC][SR_ROWS] while the products run, the k-lanes' partial sums [3][SR_ROWS][64] at the end
+  __shared__ __attribute__((aligned(16))) float sbuf[3 * SR_ROWS * 64];
+  float (*At)[SR_ROWS] = reinterpret_cast<float (*)[SR_ROWS]>(sbuf);
   const bool second = blk >= sr.blocks_per_set;
   const SkinnySet g = second ? sr.set[1] : sr.set[0];
   const int tid = threadIdx.x, cx = tid & 63, kl = tid >> 6;
@@ -724,8 +725,9 @@ __device__ __forceinline__ void skinny_rider_block(const SkinnyRider& sr, int bl
   for (int r = 0; r < SR_ROWS; ++r) acc[r] = 0.f;
   for (int kc = 0; kc < g.K; kc += SR_KC) {
     __syncthreads();
-    for (int e = tid; e < SR_KC * SR_ROWS; e += 256) {       // A^T chunk (+ the ones row) -> LDS
-      const int kk = e / SR_ROWS, r = e % SR_ROWS, k = kc + kk;
+#pragma unroll
+    for (int e0 = 0; e0 < SR_KC * SR_ROWS; e0 += 256) {      // A^T chunk (+ the ones row) -> LDS
+      const int e = e0 + tid, kk = e / SR_ROWS, r = e % SR_ROWS, k = kc + kk;
       float v = 0.f;
       if (k < g.K) v = r < g.R ? g.A[(size_t)k * g.lda + r] : (r == g.R && g.ones ? 1.f : 0.f);
       At[kk][r] = v;
@@ -738,7 +740,7 @@ __device__ __forceinline__ void skinny_rider_block(const SkinnyRider& sr, int bl
       breg[j] = v * ((live && k < g.K) ? 1.f : 0.f);
     }
     __syncthreads();
-#pragma unroll 8
+#pragma unroll
     for (int j = 0; j < SR_KC / 4; ++j) {
       const float4* arow = reinterpret_cast<const float4*>(At[kl + 4 * j]);
 #pragma unroll
@@ -751,6 +753,8 @@ __device__ __forceinline__ void skinny_rider_block(const SkinnyRider& sr, int bl
       }
     }
   }
+  __syncthreads();
+  float (*redk)[SR_ROWS][64] = reinterpret_cast<float (*)[SR_ROWS][64]>(sbuf);
   if (kl > 0) {
 #pragma unroll
     for (int r = 0; r < SR_ROWS; ++r) redk[kl - 1][r][cx] = acc[r];
@@ -770,14 +774,18 @@ __device__ __forceinline__ void skinny_rider_block(const SkinnyRider& sr, int bl
 
 __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceTable t, MeanTerms m, SkinnyRider sr) {
   __shared__ float4 red[16][16];
-  if (blockIdx.x >= t.blk0[t.njobs] + (unsigned)m.n_terms) { skinny_rider_block(sr, blockIdx.x - t.blk0[t.njobs] - m.n_terms); return; }
-  if (blockIdx.x >= t.blk0[t.njobs]) { mean_block(m, blockIdx.x - t.blk0[t.njobs], red); return; }
+  // the rider blocks come FIRST: they are short chains of dependent loads, and at the end of the grid they were the
+  // launch's tail (the launch got as much longer as the products' own launch had taken)
+  const unsigned nrider = (unsigned)(sr.nsets * sr.blocks_per_set);
+  if (blockIdx.x < nrider) { skinny_rider_block(sr, blockIdx.x); return; }
+  const unsigned bid = blockIdx.x - nrider;
+  if (bid >= t.blk0[t.njobs]) { mean_block(m, bid - t.blk0[t.njobs], red); return; }
   int ji = 0;
 #pragma unroll
   for (int i = 1; i < MAX_JOBS; ++i)
-    if (i < t.njobs && blockIdx.x >= t.blk0[i]) ji = i;
-  if (t.job[ji].pad_) reduce_block_v4(t.job[ji], blockIdx.x - t.blk0[ji], red);
-  else reduce_block(t.job[ji], blockIdx.x - t.blk0[ji], reinterpret_cast<float (*)[64]>(red));
+    if (i < t.njobs && bid >= t.blk0[i]) ji = i;
+  if (t.job[ji].pad_) reduce_block_v4(t.job[ji], bid - t.blk0[ji], red);
+  else reduce_block(t.job[ji], bid - t.blk0[ji], reinterpret_cast<float (*)[64]>(red));
 }
 int launch_reduce(const ReduceJob& j_in, hipStream_t s) {
   ProfScope p("gemm_splitk_reduce", s);
