@@ -234,21 +234,39 @@ __global__ __launch_bounds__(1024) void sparse_outer_kernel(SparseOuterArgs a) {
     }
     return;
   }
-  for (int b0 = 0; b0 < a.Bn; b0 += SO_BB) {
+  // The next block of batch rows is fetched into registers while this one is walked (the kernel is two or three round
+  // trips to L2 and a handful of FMAs: the fetch of block 2 under the walk of block 1 is a third of its time)
+  constexpr int XR = SO_BB * SO_JT / 1024, GR = SO_BB * 64 / 1024;      // values per thread: 8 of X, up to 8 pairs of G
+  float xr[XR];
+  float2 gr[GR];
+  auto fetch = [&](int b0) {
     const int nb = min(SO_BB, a.Bn - b0);
-    // stage X[b0:b0+nb, j0:j0+64] and G[b0:b0+nb, :]
-    for (int e = tid; e < SO_BB * SO_JT; e += 1024) {
-      const int bb = e / SO_JT, jj = e % SO_JT;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int e = tid + 1024 * i, bb = e / SO_JT, jj = e % SO_JT;
       const bool ok = bb < nb && j0 + jj < a.nx;
       const float v = a.X[(size_t)(b0 + min(bb, nb - 1)) * a.ldx + min(j0 + jj, a.nx - 1)];
-      Xt[bb * SO_XS + jj] = v * (ok ? 1.f : 0.f);
+      xr[i] = v * (ok ? 1.f : 0.f);
     }
-    for (int e = tid; e < SO_BB * n2; e += 1024) {
-      const int bb = e / n2, c = e % n2;
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      const int e = min(tid + 1024 * i, SO_BB * n2 - 1), bb = e / n2, c = e % n2;
       const float2 v = *reinterpret_cast<const float2*>(a.G + (size_t)(b0 + min(bb, nb - 1)) * a.ldg + 2 * c);
       const float mk = bb < nb ? 1.f : 0.f;
-      Gl[bb * n2 + c] = make_float2(v.x * mk, v.y * mk);
+      gr[i] = make_float2(v.x * mk, v.y * mk);
     }
+  };
+  fetch(0);
+  for (int b0 = 0; b0 < a.Bn; b0 += SO_BB) {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int e = tid + 1024 * i;
+      Xt[(e / SO_JT) * SO_XS + e % SO_JT] = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < GR; ++i)
+      if (tid + 1024 * i < SO_BB * n2) Gl[tid + 1024 * i] = gr[i];
+    if (b0 + SO_BB < a.Bn) fetch(b0 + SO_BB);
     __syncthreads();
     if (a.colsum && blockIdx.x == 0 && wave == 15 && lane < n2) {      // bias gradient: column sums of the staged G block
       float2 t = make_float2(0.f, 0.f);
