@@ -122,6 +122,10 @@ SIGNATURES = {
     "clv_out_head_train_supported": (_i, [_i, _i]),
     "clv_out_head_train_workspace_bytes": (_sz, [_i]),
     "clv_out_head_train": (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
+    "clv_latent_head_supported": (_i, [_i, _i]),
+    "clv_latent_head_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "clv_latent_head_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "clv_latent_head_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "clv_vrnn_generate_supported": (_i, [_i, _i, _i, _i]),
     "clv_vrnn_generate": (_i, [_i] * 9 + [_u64] + [_p] * 18),
     "clv_vae_generate_supported": (_i, [_i, _i, _i, _i]),

@@ -577,6 +577,9 @@ class VrnnEngine(_EngineBase):
         # rows per step through its L1 miss path (~10 B/cycle per CU), +48 us on the pair kernel for the 26 us launch it
         # removes -- so the default stays the projection launch, whose workgroups keep K_x in LDS.
         # notes_valid: the lists describe the frames now in X / XZ (TrainStep sets it per staged batch).
+        # outside the pair kernels: the latent head's forward / backward as one MFMA launch each (csrc/latent_head.hip)
+        self.fuse_latent = bool(cfg.get('fuse_latent', os.environ.get('CLV_FUSE_LATENT', '1') != '0')) \
+            and ops.latent_head_supported(H, L)
         self.fuse_notes = bool(cfg.get('fuse_notes', os.environ.get('CLV_FUSE_NOTES', '0') == '1')) and self.fuse_pair \
             and self.sparse_inputs and D == ops.NOTE_NONE
         self.notes_valid = False
@@ -663,8 +666,12 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
                              self.cs_enc, self.gates_enc, gate_act=self.gate_act)
         # latent heads + sample (:200-216)
-        g(self.hs_enc, P.p('Zargs/kernel'), self.zargs, BT, 2 * L, H, bias=P.p('Zargs/bias'), ws=ws)
-        ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
+        if self.fuse_latent:       # one launch on the matrix cores (csrc/latent_head.hip)
+            ops.latent_head_fwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z, self.zargs, self.Z,
+                                self.xz_ld, self.rowkl)
+        else:
+            g(self.hs_enc, P.p('Zargs/kernel'), self.zargs, BT, 2 * L, H, bias=P.p('Zargs/bias'), ws=ws)
+            ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
         # decoder LSTM on [Xp, Z, repeat(W)] (:218-228): one projection of the [Xp | Z] rows
         self._join()
         if fuse_dec:
@@ -954,8 +961,13 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
                              self.dzsum_dec, gate_act=self.gate_act)
             g(self.gates_dec, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
-        ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight / BT, self.dzargs)
-        g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
+        if self.fuse_latent:       # dzargs, dh_enc and the head's own kernel / bias gradient in one launch; dzargs stays on chip
+            ops.latent_head_bwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), self.zargs, eps_Z, self.dZ, L,
+                                self.kl_weight / BT, self.dhs, P.g('Zargs/kernel'), P.g('Zargs/bias'), ws, defer=self._rq())
+            self._head_grad_done = True
+        else:
+            ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight / BT, self.dzargs)
+            g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
         ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                          self.dzsum_enc, gate_act=self.gate_act)
 

@@ -171,6 +171,28 @@ def out_head_train(R, H, D, hs, Wo, bo, Y, scale, rownll, dhs, dWo, dbo, ws, log
                                _ptr(buf), buf.numel(), job, _stream()), "clv_out_head_train")
 
 
+def latent_head_supported(H, L):
+    return bool(_lib.lib().clv_latent_head_supported(H, L))
+
+
+def latent_head_fwd(R, H, L, hs, Wz, bz, eps, zargs, Z, ldz, rowkl=None):
+    """zargs = hs.Wz + bz, the reparametrised sample into Z (row stride ldz) and the rows' KL in one launch."""
+    check(_lib.lib().clv_latent_head_fwd(R, H, L, _ptr(hs), _ptr(Wz), _ptr(bz), _ptr(eps), _ptr(zargs), _ptr(Z), ldz,
+                                         _ptr(rowkl), _stream()), "clv_latent_head_fwd")
+
+
+def latent_head_bwd(R, H, L, hs, Wz, zargs, eps, dZ, lddz, kl_scale, dhs, dWz, dbz, ws, dzargs=None, defer=None):
+    """The latent head's backward in one launch: dzargs (kept on chip unless a buffer is given), dhs = dzargs.Wz^T and the
+    layer's kernel / bias gradient.  defer: a ReduceQueue that takes the pending reduction of the weight-gradient slabs."""
+    Lb = _lib.lib()
+    need = Lb.clv_latent_head_bwd_workspace_bytes(R, L)
+    buf = defer.scratch(need) if defer is not None else ws.ensure(need)
+    job = defer.next_job() if defer is not None else None
+    check(Lb.clv_latent_head_bwd(R, H, L, _ptr(hs), _ptr(Wz), _ptr(zargs), _ptr(eps), _ptr(dZ), lddz, float(kl_scale),
+                                 _ptr(dzargs), _ptr(dhs), _ptr(dWz), _ptr(dbz), _ptr(buf), buf.numel(), job, _stream()),
+          "clv_latent_head_bwd")
+
+
 def _prob_array(probs, N):
     arr = (_lib.GemmProb * len(probs))()
     for i, p in enumerate(probs):

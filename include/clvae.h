@@ -467,6 +467,24 @@ int clv_out_head_train(int R, int H, int D, const float* hs, const float* Wo, co
                        float* dhs, float* dWo, float* dbo, void* ws, size_t ws_bytes, clv_reduce_job* job,
                        void* stream);
 
+/* The latent head of cl_vrnn outside the pair kernels (H == 88, latent_dim <= 32; cl_vrnn/model.py:200-216, 243 and their
+ * K.gradients), one launch per pass (csrc/latent_head.hip):
+ *   forward:  zargs = hs.Wz + bz [R,2L] = (mean | log_var), Z[r, :L] = mean + exp(log_var/2) * eps (row stride ldz),
+ *             rowkl[r] = -0.5 sum_l (1 + log_var - mean^2 - exp(log_var)) (may be NULL)
+ *             -- replaces clv_gemm_f32 + clv_gauss_fwd;
+ *   backward: dzargs = (dZ + kl_scale*mean | dZ*eps*sd/2 - kl_scale*(1 - sd^2)/2) (stored only when dzargs != NULL),
+ *             dhs = dzargs.Wz^T [R,88], dWz = hs^T.dzargs, dbz = sum_r dzargs -- replaces clv_gauss_bwd + clv_gemm_f32 (NT)
+ *             + clv_gemm_grouped_tn.  dWz/dbz leave as one partial slab per workgroup in `ws`: with job == NULL they are
+ *             reduced at once, otherwise *job receives the pending reduction for clv_splitk_reduce_multi.
+ * hs 16-byte aligned. */
+int clv_latent_head_supported(int H, int L);
+size_t clv_latent_head_bwd_workspace_bytes(int R, int L);
+int clv_latent_head_fwd(int R, int H, int L, const float* hs, const float* Wz, const float* bz, const float* eps,
+                        float* zargs, float* Z, int ldz, float* rowkl, void* stream);
+int clv_latent_head_bwd(int R, int H, int L, const float* hs, const float* Wz, const float* zargs, const float* eps,
+                        const float* dZ, int lddz, float kl_scale, float* dzargs, float* dhs, float* dWz, float* dbz,
+                        void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
+
 /* dpre[i] = dy[i] * act'(pre[i]) from the activation's output y: CLV_ACT_RELU -> [y > 0], CLV_ACT_SIGMOID -> y(1-y),
  * CLV_ACT_NONE -> copy.  Backward of a Dense layer used on its own (the torch module face, clvae_amd/nn.py); the
  * training engines fold this mask into the epilogue of the neighbouring GEMM instead (CLV_ACT_MASKPOS). */

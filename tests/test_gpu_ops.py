@@ -767,3 +767,57 @@ def test_reduce_launch_skinny_riders(dev, K, N, R, with_jobs):
     if with_jobs:
         np.testing.assert_allclose(c2.cpu().numpy(), ref_c, rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(out[0].item(), Bs[0].astype(np.float64).mean(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("R,L,defer", [(1, 2, False), (37, 9, False), (128, 16, True), (1000, 17, True), (4096, 32, True),
+                                       (128 * 300 + 5, 32, True), (300, 1, False)])
+def test_latent_head_matches_numpy(dev, R, L, defer):
+    """clv_latent_head_fwd / _bwd (cl_vrnn/model.py:200-216, 243 and their gradients) against fp64 numpy: zargs, the
+    sample, the rows' KL; dzargs, dh_enc, dWz, dbz -- ragged row counts, one block per workgroup and the persistent
+    multi-block case, both padded widths (latent_dim <= 16 / <= 32), immediate and deferred reduction, Z and dZ strided."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(R + L)
+    H = 88
+    hs = np.tanh(rng.standard_normal((R, H))).astype(np.float32)
+    Wz = (rng.standard_normal((H, 2 * L)) * 0.2).astype(np.float32)
+    bz = (rng.standard_normal(2 * L) * 0.3).astype(np.float32)
+    eps = rng.standard_normal((R, L)).astype(np.float32)
+    ldz, lddz = L + 3, L + 1
+    z = lambda *sh: torch.full(sh, -7.0, dtype=torch.float32, device=dev)
+    zargs, Z, rowkl = z(R, 2 * L), z(R, ldz), z(R)
+    hs_d, Wz_d, eps_d = T(hs, dev), T(Wz, dev), T(eps, dev)
+    ops.latent_head_fwd(R, H, L, hs_d, Wz_d, T(bz, dev), eps_d, zargs, Z, ldz, rowkl)
+    torch.cuda.synchronize()
+    za = hs.astype(np.float64) @ Wz + bz
+    m, lv = za[:, :L], za[:, L:]
+    sd = np.exp(0.5 * lv)
+    np.testing.assert_allclose(N(zargs), za, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(N(Z)[:, :L], m + sd * eps, rtol=1e-5, atol=3e-5)
+    assert (N(Z)[:, L:] == -7.0).all()
+    np.testing.assert_allclose(N(rowkl), -0.5 * (1 + lv - m * m - sd * sd).sum(1), rtol=2e-5, atol=2e-4)
+    # backward from the device's own zargs (what the step does)
+    dZ = np.full((R, lddz), 55.0, dtype=np.float32)
+    dZ[:, :L] = rng.standard_normal((R, L)) / R
+    kl = 0.37 / R
+    dzargs, dhs, dWz, dbz = z(R, 2 * L), z(R, H), z(H, 2 * L), z(2 * L)
+    ws = ops.Workspace(dev)
+    rq = ops.ReduceQueue(dev) if defer else None
+    ops.latent_head_bwd(R, H, L, hs_d, Wz_d, zargs, eps_d, T(dZ, dev), lddz, kl, dhs, dWz, dbz, ws, dzargs=dzargs, defer=rq)
+    if rq is not None:
+        rq.flush()
+    torch.cuda.synchronize()
+    zd = N(zargs).astype(np.float64)
+    m, lv = zd[:, :L], zd[:, L:]
+    sd = np.exp(0.5 * lv)
+    d = dZ[:, :L].astype(np.float64)
+    dz_ref = np.concatenate([d + kl * m, d * eps * 0.5 * sd - 0.5 * kl * (1 - sd * sd)], axis=1)
+    sc = 1.0 / R
+    np.testing.assert_allclose(N(dzargs), dz_ref, rtol=2e-5, atol=2e-6 * sc * 10)
+    np.testing.assert_allclose(N(dhs), dz_ref @ Wz.astype(np.float64).T, rtol=1e-4, atol=2e-5 * sc * 10)
+    np.testing.assert_allclose(N(dWz), hs.astype(np.float64).T @ dz_ref, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(N(dbz), dz_ref.sum(0), rtol=1e-4, atol=2e-5)
+    # the same launch without a dzargs buffer
+    dhs2, dWz2, dbz2 = z(R, H), z(H, 2 * L), z(2 * L)
+    ops.latent_head_bwd(R, H, L, hs_d, Wz_d, zargs, eps_d, T(dZ, dev), lddz, kl, dhs2, dWz2, dbz2, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dhs2, dhs) and torch.equal(dWz2, dWz) and torch.equal(dbz2, dbz)
