@@ -16,7 +16,7 @@ for w in cfg5 cfg2; do
   cp $G/${TAG}_prof_$w/p_kernel_stats.csv $G/${TAG}_kernel_stats_$w.csv
 done
 python bench.py --workload cfg2 --bf16 --steps 200 --warmup 10 --no-cpu-baseline > $G/${TAG}_bench_cfg2_bf16.json 2> $G/${TAG}_bench_cfg2_bf16.err
-for w in gen1024 gen1; do python bench.py --workload $w --steps 2000 --warmup 10 --no-cpu-baseline > $G/${TAG}_bench_$w.json 2> $G/${TAG}_bench_$w.err; done
+for w in gen1024 gen1 gen_vae1024 gen_vae1; do python bench.py --workload $w --steps 2000 --warmup 10 --no-cpu-baseline > $G/${TAG}_bench_$w.json 2> $G/${TAG}_bench_$w.err; done
 for w in cfg3 cfg5; do
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $G/${TAG}_pmc_${c}_$w -o t --output-format csv -- python3 $R/bench.py --workload $w --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $G/${TAG}_pmc_${c}_$w.log 2>&1)
