@@ -24,6 +24,10 @@
 // per workgroup.  A step is the MFMA phase (66 instructions per wave, two waves per SIMD: ~1060 cycles) FOLLOWED by
 // the gate phase (~140 vector instructions per wave: residue sums, activation, exchange, cell, stores): the next
 // step's products need every h of this one, so the two phases of the four rows a CU owns cannot overlap.
+// Round 3, tried: 16 waves (four per SIMD, one or two unit quads each, 122 registers) so that the gate phase's dependent
+// chains have four waves to interleave: 1.29 ms for the two forward launches of configuration 5 against 0.767 ms -- with
+// one or two quads a wave touches each accumulator every 16-32 cycles, inside the 40-cycle dependent latency of the 4x4x1
+// MFMA, and the z variant spills.
 #include <stdlib.h>
 
 #include "lstm_common.h"
