@@ -186,7 +186,9 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   float2 acc = make_float2(0.f, 0.f);
   const int nchunk = (ax.nx + 63) / 64;
   // Two chunks of 64 inputs per iteration: their kernel rows (up to 4 each per round) are requested together, so a
-  // wave pays one L2 round trip per PAIR of chunks (a window row has 176 chunks, 11 per wave).
+  // wave pays one L2 round trip per PAIR of chunks (a window row has 176 chunks, 11 per wave).  (Four chunks per iteration,
+  // 16 rows in flight per lane: 74 registers instead of 62, i.e. one workgroup per CU instead of two, and slower -- 24.9 us
+  // against 22.8 at configuration 3, 131 against 119 at configuration 5.)
   auto xload = [&](int ch) { return ch < nchunk ? xr[min(ch * 64 + lane, ax.nx - 1)] : 0.f; };
   float xa = xload(wave), xb = xload(wave + 16);
   for (int ch = wave; ch < nchunk; ch += 32) {
