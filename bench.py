@@ -500,7 +500,8 @@ def main():
             "dp_schedule": None if world == 1 else {
                 "graphs_per_step": len(ts._graphs) if ts._graphs else 0, "collectives_per_step": 2,
                 "wgrad_split_scale": 2 if getattr(eng, 'fine_grid', False) else 1,
-                "optimizer": "hW kernel updated under the main bucket's all-reduce, the rest after it"},
+                "optimizer": "hW kernel updated (two launches, its sum g.V averaged with its gradient bucket) under the "
+                                                  "main bucket's all-reduce, the rest after it"},
         }
         print(json.dumps(out))
     if world > 1:

@@ -87,7 +87,10 @@ class FlatParams:
     `shapes` are the logical (Keras) tensors; `aliases` maps some of them onto column slices of fused
     physical tensors (see fuse_heads)."""
 
-    def __init__(self, shapes, device, phys=None, aliases=None):
+    def __init__(self, shapes, device, phys=None, aliases=None, pre=0):
+        """pre: floats of scratch IN FRONT of the gradient buffer, contiguous with it (`grads_pre`): what lives there is
+        averaged across ranks together with the first gradient bucket (cl_vrnn: the optimizer's sum g.V of the hW kernel,
+        which is linear in the gradient like the gradient itself)."""
         self.logical = list(shapes)
         self.aliases = dict(aliases or {})
         self.shapes = list(phys) if phys is not None else list(shapes)
@@ -109,7 +112,9 @@ class FlatParams:
         self._subplans = {}
         f = dict(dtype=torch.float32, device=device)
         self.params = torch.zeros(self.n, **f)
-        self.grads = torch.zeros(self.n, **f)
+        pre = (int(pre) + 3) // 4 * 4
+        self.grads_store = torch.zeros(pre + self.n, **f)
+        self.grads_pre, self.grads = self.grads_store[:pre], self.grads_store[pre:]
         self.m = torch.zeros(self.n, **f)
         self.v = torch.zeros(self.n, **f)
         self.mg = torch.zeros(self.n_cols, **f)
@@ -200,9 +205,10 @@ class FlatParams:
         averaged across ranks afterwards: with norms_valid the step takes the two-launch form (clv_adam_wn_step_ex)."""
         table, n, plan = (self.table, len(self.shapes), self.plan) if only is None else self._subplan(only)
         known, tall = None, self.tall_tensor()
-        if int(weightnorm) == 1 and only is None and tall is not None:
+        if int(weightnorm) == 1 and tall is not None and (only is None or tall[1] in only):
             use = gdot is not None and self.norms_valid
-            known = _lib.AdamKnownSums(tall[0], int(use), ops._ptr(gdot) if use else None, ops._ptr(self.vn2))
+            pos = tall[0] if only is None else [name for name, _ in self.shapes if name in only].index(tall[1])
+            known = _lib.AdamKnownSums(pos, int(use), ops._ptr(gdot) if use else None, ops._ptr(self.vn2))
         _lib.check(_lib.lib().clv_adam_wn_step_ex(
             table, n, ops._ptr(plan), ops._ptr(self.params), ops._ptr(self.grads),
             ops._ptr(self.m), ops._ptr(self.v), ops._ptr(self.mg), ops._ptr(self.vg), ops._ptr(self.s),
@@ -219,13 +225,13 @@ def _f(device, *shape):
 
 
 class _EngineBase:
-    def __init__(self, cfg, batch_size, shapes, device, head_pairs=()):
+    def __init__(self, cfg, batch_size, shapes, device, head_pairs=(), grads_pre=0):
         _lib.require_gpu()
         self.cfg = dict(cfg)
         self.B = int(batch_size)
         self.device = torch.device(device)
         phys, aliases = fuse_heads(shapes, head_pairs)
-        self.P = FlatParams(shapes, self.device, phys, aliases)
+        self.P = FlatParams(shapes, self.device, phys, aliases, pre=grads_pre)
         self.ws = ops.Workspace(self.device, 8 << 20)
         self.ws2 = ops.Workspace(self.device, 8 << 20)        # scratch of the side stream
         self.rq = ops.ReduceQueue(self.device)                # split-K reductions of the weight gradients, one launch per pass
@@ -541,7 +547,7 @@ class VrnnEngine(_EngineBase):
 
     def __init__(self, cfg, batch_size, device='cuda:0'):
         super().__init__(cfg, batch_size, vrnn_param_shapes(cfg), device,
-                         head_pairs=[('Z_mean', 'Z_log_var', 'Zargs')])
+                         head_pairs=[('Z_mean', 'Z_log_var', 'Zargs')], grads_pre=cfg['D'])
         B, D, H, L, T, Cn = self.B, cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         if H != 88:
             raise ValueError("the LSTM sequence kernels are built for intermediate_dim == 88")
@@ -617,7 +623,9 @@ class VrnnEngine(_EngineBase):
         self.dW = _f(d, B, Cn)
         self.dwargs = _f(d, B, 2 * (Cn - 1))
         self.dhW = _f(d, B, D)
-        self.gdot = _f(d, D)                        # sum_j hW/kernel[j,c] * its gradient[j,c]: see FlatParams.adam_step
+        # sum_j hW/kernel[j,c] * its gradient[j,c] (FlatParams.adam_step): in front of the gradient buffer, so that the
+        # data-parallel step averages it with the hW kernel's bucket
+        self.gdot = self.P.grads_pre[:D] if (self.P.grads_pre.numel() >= D and self.P.offsets['hW/kernel'] == 0) else _f(d, D)
         self.gdot_fresh = False
 
     def folds_noise(self):

@@ -61,7 +61,15 @@ class TrainStep:
         # CLV_FORCE_DP_GRAPHS=1: take the multi-GPU schedule (main graph, tail graph, update graph around the two
         # gradient buckets) on a single GPU too, with the collectives as no-ops -- lets one box test that path
         force = os.environ.get('CLV_FORCE_DP_GRAPHS') == '1'
-        self.ar = GradAllReduce(engine.P.grads, tail[0], tail[1], group) if (world > 1 or force) else None
+        # the scratch in front of the gradients (cl_vrnn: the optimizer's sum g.V of the hW kernel) travels with the tail bucket
+        P = engine.P
+        self.pre_in_tail = bool(self.is_vrnn and tail[1] and tail[0] == 0 and P.grads_pre.numel() > 0
+                                and getattr(engine, 'gdot', None) is not None
+                                and engine.gdot.data_ptr() == P.grads_pre.data_ptr())
+        if self.pre_in_tail:
+            self.ar = GradAllReduce(P.grads_store, 0, P.grads_pre.numel() + tail[1], group) if (world > 1 or force) else None
+        else:
+            self.ar = GradAllReduce(P.grads, tail[0], tail[1], group) if (world > 1 or force) else None
         # the tail bucket is exactly one tensor (the hW kernel): its update can run while the main bucket is reduced
         self.tail_names = [n for n, _ in engine.P.shapes if tail[1] and engine.P.offsets[n] == tail[0]
                            and int(np.prod(dict(engine.P.shapes)[n])) == tail[1]]
@@ -134,16 +142,22 @@ class TrainStep:
         # single GPU, cl_vrnn: the backward pass left sum_j K dK of the hW kernel (VrnnEngine.gdot), so Adam-WN runs in two
         # launches instead of five (FlatParams.adam_step); not under data parallelism (the gradient is averaged afterwards)
         eng = self.eng
-        gdot = eng.gdot if (self.fast_adam and self.ar is None and getattr(eng, 'gdot_fresh', False)) else None
-        eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, advanced=self._folded(), gdot=gdot)
+        eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, advanced=self._folded(), gdot=self._gdot())
+
+    def _gdot(self):
+        """The hW kernel's sum g.V when this step's backward pass left it AND it went through whatever averaged the
+        gradient (single GPU: nothing; data parallel: the tail bucket, which then carries it)."""
+        eng = self.eng
+        ok = self.fast_adam and getattr(eng, 'gdot_fresh', False) and (self.ar is None or self.pre_in_tail)
         if hasattr(eng, 'gdot_fresh'):
             eng.gdot_fresh = False
+        return eng.gdot if ok else None
 
     # multi-GPU: the optimizer step in two pieces, the tail bucket's tensor first (its all-reduce has landed under
     # _tail()), the rest once the main bucket is in; `iterations` advances with the second piece
     def _update_tail(self):
         self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.tail_names, advance=False,
-                             advanced=self._folded())
+                             advanced=self._folded(), gdot=self._gdot())
 
     def _update_rest(self):
         self.eng.P.adam_step(lr=self.lr, b2=self.b2, weightnorm=self.weightnorm, only=self.rest_names,
@@ -277,6 +291,7 @@ class TrainStep:
                     self._single()
                 self._graphs = (g,)
             else:
+                self._graph_fast = bool(getattr(self.eng.P, 'norms_valid', False))
                 with ops.Graph() as g1:
                     self._main()
                 with ops.Graph() as g2:
@@ -297,6 +312,9 @@ class TrainStep:
                 return
             self._graphs[0].launch()
         else:
+            if getattr(self, '_graph_fast', False) and not self.eng.P.norms_valid:
+                self._eager()
+                return
             g1, g2, g3 = self._graphs[:3]
             g1.launch()
             self.ar.reduce_tail()       # hW-kernel bucket, overlaps the weight-gradient products of g2

@@ -396,7 +396,7 @@ def test_cl_vrnn_dp_graph_schedule_matches_single_graph(dev, monkeypatch):
     win = frames(rng, B, Tn + 1, 88)
     X, Xp, wt = T(win[:, 1:], dev), T(win[:, :-1], dev), T(np.eye(10)[rng.integers(0, 10, B)], dev)
     out = []
-    for force, fast in (('0', False), ('1', False), ('0', True)):
+    for force, fast in (('0', False), ('1', False), ('0', True), ('1', True)):
         monkeypatch.setenv('CLV_FORCE_DP_GRAPHS', force)
         eng = VrnnEngine(cfg, B, dev)
         eng.P.set_weights(p)
@@ -406,7 +406,8 @@ def test_cl_vrnn_dp_graph_schedule_matches_single_graph(dev, monkeypatch):
             ts.stage_batch(X, Xp, wt)
             ts.step()
         torch.cuda.synchronize()
-        assert eng.P.norms_valid == (force == '0')          # whole Adam-WN steps keep the column norms; split ones do not
+        assert eng.P.norms_valid          # whole steps and (round 3) the split ones keep the hW kernel's column norms
+        assert ts.pre_in_tail             # ... and the optimizer's sum g.V travels with the hW kernel's gradient bucket
         out.append(eng.P.get_weights())
     for k in out[0]:
         np.testing.assert_array_equal(out[0][k], out[1][k])
@@ -414,6 +415,8 @@ def test_cl_vrnn_dp_graph_schedule_matches_single_graph(dev, monkeypatch):
         # pass (sum over the batch of pre-activation x gradient) and from the previous step's norms: the same update up to
         # the rounding of those sums
         np.testing.assert_allclose(out[2][k], out[0][k], rtol=2e-5, atol=2e-7, err_msg=k)
+        # the multi-GPU schedule takes the same two-launch form for its hW piece (same kernels, same sums)
+        np.testing.assert_array_equal(out[3][k], out[2][k])
 
 
 def test_adam_step_in_two_pieces_is_bitwise_the_whole_step(dev):
