@@ -187,6 +187,11 @@ template <int P> struct ParC { static constexpr int value = P; };
 // beyond num_records: the hardware drops the store (returns 0), so no store sits under a divergent branch -- which
 // matters beyond the branch itself: with stores on conditional paths the compiler's vmcnt bookkeeping assumes they may
 // not have been issued and waits for the NEXT newer load instead (the waits of the two-step lookahead collapse).
+// cache-policy bits of the per-step stores (measurement builds: 2 = nt, 1 = sc0, 17 = sc0 sc1; the default write-back policy
+// is the fastest, profiles/r03_pair_ablation.txt)
+#ifndef PAIR_STORE_AUX
+#define PAIR_STORE_AUX 0
+#endif
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr unsigned BUF_OOB = 0x80000000u;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -198,7 +203,7 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff
 __device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
   if (PAIR_ABL == 5) { asm volatile("" :: "v"(v)); return; }
   if (PAIR_ABL == 9) soff = 0;      // every step's stores land on the row's first frame: no write traffic beyond L2
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, PAIR_STORE_AUX);
 }
 __device__ __forceinline__ float lane_permute(int addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
