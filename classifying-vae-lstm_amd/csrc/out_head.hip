@@ -30,6 +30,19 @@ constexpr int OH_TILE = 16 * OH_LD;
 constexpr int OH_SLAB_ROWS = OH + 1;      // dWo rows + the dbo row
 constexpr int OH_P3 = 5;           // weight-gradient tiles per wave (36 tiles over 8 waves: 4 x 5 + 4 x 4)
 
+// -DOH_STAMPS: wave 0 of workgroup 0 records the shader clock at the phase boundaries of its first block
+// (tools/out_head_stamps.py).  Configuration 3, one block per workgroup (us): Wo -> LDS + first loads + barrier 4.1, hs tile
+// 0.7, first product 3.5, NLL + dl tile + logits stores 4.25, second product + dhs stores 3.6, barrier 1.2, weight gradient
+// 5.1, slab store 2.15 = 24.6 of a 28.9 us launch.  Tried on that evidence: the 48 per-lane stores of a block as buffer
+// instructions with immediate offsets and out-of-range lanes instead of predicated global stores -- SLOWER (NLL phase 4.8,
+// second product 4.5, launch 30.4 -> 33.0 us), removed.
+#ifdef OH_STAMPS
+__device__ unsigned long long g_oh_stamps[16];
+#define OHS(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_oh_stamps[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define OHS(k) do { } while (0)
+#endif
+
 struct OutHeadArgs {
   int R, ldy;
   float scale;
@@ -52,6 +65,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
+  OHS(0);
 
   float bias[OH_T];
 #pragma unroll
@@ -110,6 +124,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
     for (int e = tid; e < OH * 8; e += 64 * OH_NW) WoL[(e >> 3) * OH_LD + OH + (e & 7)] = 0.f;      // columns 88..95
   }
   __syncthreads();
+  OHS(1);
 
   for (int blk = blockIdx.x; blk * OH_RB < a.R; blk += gridDim.x) {
     const int row0 = blk * OH_RB + wave * 16;
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is wave-private: no barrier
+    OHS(2);
 
     // ---- logits = hs.Wo
     f32x4 acc[OH_T];
@@ -159,6 +175,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
         }
       }
     }
+    OHS(3);
     // ---- Bernoulli NLL with Keras' epsilon clip (same arithmetic as the gemm_bce epilogue); dl -> LDS tile
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
       if (r == 0 && rok) a.rownll[row] = ssum;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    OHS(4);
 
     // ---- dhs = dl.Wo^T   (k = output note, n = hidden unit: B[k][n] = Wo[n][k])
 #pragma unroll
@@ -232,7 +250,9 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
         if (row < a.R && col < OH) a.dhs[(size_t)row * OH + col] = acc[j][reg];
       }
     }
+    OHS(5);
     __syncthreads();         // every wave's hs and dl tiles are in LDS
+    OHS(6);
 
     // ---- [dWo ; dbo] += [hs | 1]^T . dl over the block's 128 rows: the 6 x 6 output tiles are dealt 5,5,5,5,4,4,4,4
     {
@@ -261,6 +281,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
         for (int i = 0; i < OH_P3; ++i) { av[i] = an[i]; bv[i] = bn[i]; }
       }
     }
+    OHS(7);
     __syncthreads();         // before the next block overwrites the tiles
   }
   float* slab = a.partial + (size_t)blockIdx.x * OH_SLAB_ROWS * OH;
@@ -271,8 +292,16 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
       const int h = 16 * tm[i] + 4 * q + reg, o = 16 * tn[i] + r;
       if (i < nt && h < OH_SLAB_ROWS && o < OH) slab[h * OH + o] = acc3[i][reg];
     }
+  OHS(8);
 }
 
+#ifdef OH_STAMPS
+}
+extern "C" int clv_debug_out_head_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_oh_stamps), sizeof(unsigned long long) * 16);
+}
+namespace clv {
+#endif
 static int out_head_wgs(int R) {
   const int blocks = (R + OH_RB - 1) / OH_RB;
   return blocks < 256 ? blocks : 256;
