@@ -29,6 +29,9 @@ struct SparseProjArgs {
 // A wave handles a frame on its own: lane k holds inputs k and k+64, two ballots give the nonzero sets as
 // scalar masks, and a scalar bit-scan loop adds the listed kernel rows (LDS) into the lane's 6 output columns.
 // No lists, no LDS traffic besides the kernel rows, no barriers after the kernel is staged.
+// (Round 3, tried: four consecutive columns per lane -- 2 ds_read_b128 per note and 2 float4 stores per frame instead of 6
+// + 6 dword accesses: 34.3 us against 32.6 at configuration 3 (HIP events), 202 against 196 at configuration 5.  The dword
+// form's 256-byte wave stores are what the write path likes.)
 __global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs g) {
   extern __shared__ __attribute__((aligned(16))) float Kl[];            // [nx][N]
   const int tid = threadIdx.x, lane = tid & 63;
