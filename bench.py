@@ -498,7 +498,7 @@ def main():
             "devices": devices, "rccl": rccl if world > 1 else None,
             "ms_per_step_by_rank": rank_ms, "allreduce_alone": allreduce,
             "dp_schedule": None if world == 1 else {
-                "graphs_per_step": len(ts._graphs) if ts._graphs else 0, "collectives_per_step": 2,
+                "graphs_per_step": len([g for g in ts._graphs if g is not None]) if ts._graphs else 0, "collectives_per_step": 2,
                 "wgrad_split_scale": 2 if getattr(eng, 'fine_grid', False) else 1,
                 "optimizer": "hW kernel updated (two launches, its sum g.V averaged with its gradient bucket) under the "
                                                   "main bucket's all-reduce, the rest after it"},
