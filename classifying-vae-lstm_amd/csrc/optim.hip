@@ -20,7 +20,10 @@ namespace clv {
 #define CLV_ADAM_UNIT_ROWS 16
 #endif
 constexpr int UNIT_ROWS = CLV_ADAM_UNIT_ROWS;
-constexpr int SM_RL = 16, SM_RMAX = 8;        // fused small-tensor kernel: 16 row lanes x 8 rows = matrices of <= 128 rows
+// fused small-tensor kernel: 16 row lanes x 9 rows = matrices of <= 144 rows (round 3: 9, so that cl_vrnn's decoder input
+// kernel at latent_dim 32 -- 88 + 32 + 10 = 130 rows -- is a small tensor and the hW kernel stays the ONLY tall one: the
+// two-launch form of clv_adam_wn_step_ex then applies at configuration 5 as well)
+constexpr int SM_RL = 16, SM_RMAX = 9;
 constexpr int SM_ROWS = SM_RL * SM_RMAX;
 
 struct AdamUnit {
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void wn_rescale_kernel(const AdamUnit* units, 
 }
 
 // ---------------------------------------------------------------------------
-// Matrices of <= 128 rows (every tensor of cl_vae; everything but hW/kernel in cl_vrnn) and the biases: the whole
+// Matrices of <= 144 rows (every tensor of cl_vae; everything but hW/kernel in cl_vrnn) and the biases: the whole
 // Adam-WN update of 16 columns in ONE workgroup -- both column reductions stay in LDS, parameters and gradients are
 // read once -- instead of five launches with partial slabs in between.
 // ---------------------------------------------------------------------------

@@ -190,8 +190,8 @@ class FlatParams:
         return self._subplans[key]
 
     def tall_tensor(self):
-        """Index and name of the one matrix of more than 128 rows (cl_vrnn's hW/kernel), or None."""
-        tall = [(i, name) for i, (name, shp) in enumerate(self.shapes) if len(shp) > 1 and int(np.prod(shp[:-1])) > 128]
+        """Index and name of the one matrix of more than 144 rows (csrc/optim.hip SM_ROWS; cl_vrnn's hW/kernel), or None."""
+        tall = [(i, name) for i, (name, shp) in enumerate(self.shapes) if len(shp) > 1 and int(np.prod(shp[:-1])) > 144]
         return tall[0] if len(tall) == 1 else None
 
     def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True, only=None, advance=True, advanced=False,

@@ -594,7 +594,7 @@ size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tenso
 #define CLV_OPT_ADAM_WN  1   /* utils/weightnorm.py:75-143: matrices per output column as g V/||V||, biases plain   */
 #define CLV_OPT_RMSPROP  2   /* Keras RMSprop (the 'rmsprop' optimizer string, cl_vae/train.py:83): a = rho a +     */
                              /* (1 - rho) g^2, p -= lr g / (sqrt(a) + eps); rho = beta2, `v` holds a, `m` is unused  */
-/* clv_adam_wn_step_ex: `known` (may be NULL = clv_adam_wn_step) concerns the ONE tall matrix of the table (more than 128
+/* clv_adam_wn_step_ex: `known` (may be NULL = clv_adam_wn_step) concerns the ONE tall matrix of the table (more than 144
  * rows: cl_vrnn's hW/kernel) under CLV_OPT_ADAM_WN:
  *   vnorm2 [n columns, laid out like s]: every call keeps ||V||^2 per column of the tall matrix there (the rescale leaves
  *     W = s' V', so the next step's sum V^2 is this step's ||V'||^2);
