@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
 
   for (int blk = blockIdx.x; blk * OH_RB < a.R; blk += gridDim.x) {
     const int row0 = blk * OH_RB + wave * 16;
-    if (blk != (int)blockIdx.x) { load_hs(row0); load_y(row0); }
+    if (blk != (int)blockIdx.x) load_y(row0);                  // (the block's hs rows were requested one block ago)
     {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
         myhs[rr * OH_LD + OH + c] = (c == 0 && row0 + rr < a.R) ? 1.f : 0.f;
       }
     }
+    if ((blk + (int)gridDim.x) * OH_RB < a.R) load_hs(row0 + (int)gridDim.x * OH_RB);      // the next block's rows, under this block's products
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is wave-private: no barrier
     OHS(2);
 
