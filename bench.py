@@ -36,7 +36,7 @@ WORKLOADS = {
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (never the 2:1-sparsity figure)
-PROFILE_TAGS = ('r03_d', 'r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01')      # newest committed profile set first
+PROFILE_TAGS = ('r03_e', 'r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01')      # newest committed profile set first
 NOTE_DENSITY = 0.0443        # measured JSB note density
 
 
