@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
     const int nh4 = a.nh / 4, nx4 = a.nx / 4;
     unsigned dz_g[DZ_L], h_g[A_L], x_g[A_L], z_g[Z_L];
     int dz_l[DZ_L], h_l[A_L], x_l[A_L], z_l[Z_L];          // LDS offsets; bit 30: row 0 of the stage (h), bit 31: idle slot
-    constexpr int ROW0 = 1 << 30, IDLE = 1 << 31, OFFM = ROW0 - 1;
+    constexpr int ROW0 = 1 << 30, ROW16 = 1 << 29, IDLE = 1 << 31, OFFM = ROW16 - 1;
 #pragma unroll
     for (int i = 0; i < DZ_L; ++i) {
       const int e = pt + i * NP_T, ok = e < WB_KS * 44, ec = ok ? e : 0, r = ec / 44, c4 = ec % 44;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
       const int okh = e < WB_KS * nh4, eh = okh ? e : 0, rh = eh / nh4, ch = eh % nh4;
       const int okx = e < WB_KS * nx4, ex = okx ? e : 0, rx = ex / nx4, cx = ex % nx4;
       h_g[i] = 4u * (unsigned)(rh * a.ldh + 4 * ch);
-      h_l[i] = (rh * HPB + 8 * ch) | (rh == 0 ? ROW0 : 0) | (okh ? 0 : IDLE);
+      h_l[i] = (rh * HPB + 8 * ch) | (rh == 0 ? ROW0 : 0) | (rh == 16 ? ROW16 : 0) | (okh ? 0 : IDLE);
       x_g[i] = 4u * (unsigned)(rx * a.ldx + 4 * cx);
       x_l[i] = (rx * WB_AP + 8 * cx) | (okx ? 0 : IDLE);
     }
@@ -166,9 +166,10 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
       z_l[i] = ((ez / nz1) * HPB + 2 * (a.nh + ez % nz1)) | (ok ? 0 : IDLE);
     }
     // A stage is "interior" when all of its 32 rows exist, the shifted H rows exist, and a window start can only be its
-    // first row (h_zero_period a multiple of 32; k_begin is one by construction).  Interior stages take the fast
-    // path: no clamps, no masks, one select for the H row of a window start.
-    const bool aligned = a.h_zero_period == 0 || a.h_zero_period % WB_KS == 0;
+    // first row or its 17th (h_zero_period a multiple of 16 -- the reference's default seq_length is 16; k_begin is a
+    // multiple of 32 by construction).  Interior stages take the fast path: no clamps, no masks, one select for the H
+    // rows of a window start.
+    const bool aligned = a.h_zero_period == 0 || a.h_zero_period % (WB_KS / 2) == 0;
     auto interior = [&](int s) { const int k0 = k_begin + s * WB_KS; return aligned && k0 + WB_KS <= k_end && k0 >= a.h_shift; };
 
     // Two stages of operands in flight per thread (register sets A and B): one stage of MFMAs (~1.5 us) is less than a
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
       char* xi = hi + G::H_BYTES;
       const bool fast = interior(s);
       const bool wstart = a.h_zero_period != 0 && k0 % a.h_zero_period == 0;     // row 0 of the stage starts a window
+      const bool wstart16 = a.h_zero_period != 0 && (k0 + WB_KS / 2) % a.h_zero_period == 0;      // ... row 16 does
 #pragma unroll
       for (int i = 0; i < DZ_L; ++i) {
         const int r = (dz_l[i] & OFFM) / WB_DZP;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
       for (int i = 0; i < A_L; ++i) {
         const int rh = (h_l[i] & OFFM) / HPB, rx = (x_l[i] & OFFM) / WB_AP, k = k0 + rh;
         // H'_k = h of the previous step; zero at the start of a window
-        const bool live = fast ? !(wstart && (h_l[i] & ROW0))
+        const bool live = fast ? !((wstart && (h_l[i] & ROW0)) || (wstart16 && (h_l[i] & ROW16)))
                                : (k < k_end && k >= a.h_shift && (a.h_zero_period == 0 || k % a.h_zero_period != 0));
         if (i + 1 < A_L || !(h_l[i] & IDLE)) put4<3>(hi + (h_l[i] & OFFM), WB_KS * HPB, keep(q.h[i], live));
         if (i + 1 < A_L || !(x_l[i] & IDLE)) put4<XP>(xi + (x_l[i] & OFFM), WB_KS * WB_AP, fast ? q.x[i] : keep(q.x[i], k0 + rx < k_end));

@@ -682,6 +682,8 @@ def test_sparse_proj2_matches_two_single_launches(dev):
                                                     (1000, 8, 8, False, False, 88), (333 * 3, 3, 2, False, True, 88),
                                                     (32768, 128, 2, True, True, 88), (8192, 256, 32, True, False, 88),
                                                     (96, 96, 0, False, False, 88),
+                                                    # windows that start at row 16 of a 32-row stage (the fast loader's second case)
+                                                    (4096, 16, 2, True, True, 88), (2304, 48, 2, False, False, 88),
                                                     # other hidden sizes: every slot table of the producers is exercised
                                                     (2048, 32, 32, True, False, 64),      # nh + nz = 96 but nz > 8: wide kernel
                                                     (2048, 32, 8, False, True, 64),       # 6-row-tile kernel, 8 latent columns
