@@ -27,6 +27,9 @@ WORKLOADS = {
     'cfg3': dict(model='cl_vrnn', B=256, T=128, L=2, C=10),
     'cfg5': dict(model='cl_vrnn', B=1024, T=256, L=32, C=10),
     'cfg2': dict(model='cl_vae', B=512, T=1, L=4, C=2),
+    # the reference CLIs' own defaults (cl_vae/train.py: batch 100 = BASELINE config 1; cl_vrnn/train.py: batch 200 x seq_length 16)
+    'cfg1': dict(model='cl_vae', B=100, T=1, L=4, C=2),
+    'cli_vrnn': dict(model='cl_vrnn', B=200, T=16, L=2, C=10),
     # BASELINE config 5, second half: autoregressive generation under hipGraph (frames/s, N seeds at once)
     'gen1024': dict(model='cl_vrnn', B=1024, T=256, L=32, C=10, generate=True),
     'gen1': dict(model='cl_vrnn', B=1, T=256, L=32, C=10, generate=True),
