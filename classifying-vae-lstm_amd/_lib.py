@@ -66,6 +66,15 @@ class SkinnyProduct(C.Structure):
                 ("N", C.c_int), ("K", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int), ("bias_row", C.c_void_p)]
 
 
+class LabelBwdRider(C.Structure):
+    """clv_label_bwd_rider: the label path's backward as the pair backward kernel's epilogue (include/clvae.h)."""
+    _fields_ = [("D", C.c_int), ("C", C.c_int), ("Kenc_w", C.c_void_p), ("Kdec_w", C.c_void_p), ("wargs", C.c_void_p),
+                ("eps", C.c_void_p), ("onehot", C.c_void_p), ("W", C.c_void_p), ("hW", C.c_void_p), ("Ka", C.c_void_p),
+                ("prior_logvar", C.c_float), ("class_weight", C.c_float), ("w_kl_weight", C.c_float), ("inv_b", C.c_float),
+                ("dwargs", C.c_void_p), ("dhW", C.c_void_p), ("dKa", C.c_void_p), ("dba", C.c_void_p),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("job", C.c_void_p)]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
 
@@ -109,6 +118,7 @@ SIGNATURES = {
     "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p,
                                _p, _p]),
     "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 12 + [_p, _p, _p, _p, _sz, _p, _p]),
+    "clv_lstm_pair_bwd_ex": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 12 + [_p, _p, _p, _p, _sz, _p, _p, _p]),
     "clv_lstm_pair_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_sparse_proj_supported": (_i, [_i, _i]),
     "clv_sparse_proj_lds_bytes": (_sz, [_i, _i]),

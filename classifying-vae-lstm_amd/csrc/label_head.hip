@@ -11,12 +11,9 @@
 #include "lstm_pair_pack.h"
 #include "philox.h"
 #include "reduce_job.h"
+#include "label_bwd_row.h"
 
 namespace clv {
-
-constexpr int LH_T = 384;     // threads (6 waves) >= 4H = 352
-constexpr int LH_MAXC = 32;
-constexpr float LEPS_K = 1e-7f, LW2 = 1e-10f;
 
 struct LabelFwdArgs {
   int B, D, C, G4;
@@ -232,120 +229,8 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   label_fwd_row<1024>(a, b, tid, s_h, s_wargs, s_w);
 }
 
-struct LabelBwdArgs {
-  int B, D, C, G4;
-  const float* dzsum_enc;   // [B,G4]
-  const float* dzsum_dec;
-  const float* Kenc_w;      // [C,G4]
-  const float* Kdec_w;
-  const float* wargs;       // [B,2(C-1)]
-  const float* eps;
-  const float* onehot;
-  const float* W;           // [B,C]
-  const float* hW;          // [B,D]
-  const float* Ka;          // [D,2(C-1)]
-  float prior, class_weight, w_kl_weight, inv_b;
-  float* dwargs;            // [B,2(C-1)]
-  float* dhW;               // [B,D]
-  float* wa_slab;           // optional [B][D+1][2(C-1)]: this row's share of the Wargs layer's kernel / bias gradient
-};
-
 __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
-  __shared__ float s_part[LH_T / 64][LH_MAXC], s_dw[LH_MAXC], s_dwa[2 * LH_MAXC];
-  __shared__ float s_wv[LH_MAXC], s_oh[LH_MAXC], s_wa[2 * LH_MAXC], s_eps[LH_MAXC];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int C1 = a.C - 1, NA = 2 * C1;
-  // the row's small vectors -> LDS in one round trip (the serial label backward below reads them element by element)
-  if (tid < a.C) { s_wv[tid] = a.W[(size_t)b * a.C + tid]; s_oh[tid] = a.onehot[(size_t)b * a.C + tid]; }
-  if (tid >= 64 && tid - 64 < NA) s_wa[tid - 64] = a.wargs[(size_t)b * NA + tid - 64];
-  if (tid >= 128 && tid - 128 < C1) s_eps[tid - 128] = a.eps[(size_t)b * C1 + tid - 128];
-  // dW[j] = sum_c dzsum_dec[c] K_dec_w[j,c] + dzsum_enc[c] K_enc_w[j,c]
-  float part[LH_MAXC];
-#pragma unroll
-  for (int j = 0; j < LH_MAXC; ++j) part[j] = 0.f;
-  for (int c = tid; c < a.G4; c += LH_T) {
-    const float de = a.dzsum_enc[(size_t)b * a.G4 + c], dd = a.dzsum_dec[(size_t)b * a.G4 + c];
-    // kernel rows in batches of 8 classes, loads unconditional (clamped) so that 16 are in flight; a load under
-    // `if (j < C)` is waited for where it is issued: one L2 round trip per class
-#pragma unroll
-    for (int j0 = 0; j0 < LH_MAXC; j0 += 8) {
-      if (j0 < a.C) {                    // uniform
-        float ke[8], kd[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int j = min(j0 + q, a.C - 1);
-          ke[q] = a.Kenc_w[(size_t)j * a.G4 + c];
-          kd[q] = a.Kdec_w[(size_t)j * a.G4 + c];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float m = j0 + q < a.C ? 1.f : 0.f;
-          part[j0 + q] = fmaf(dd * m, kd[q], fmaf(de * m, ke[q], part[j0 + q]));
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < LH_MAXC; ++j)
-    if (j < a.C) {
-      const float v = wave_sum(part[j]);
-      if (lane == 0) s_part[wave][j] = v;
-    }
-  __syncthreads();
-  if (tid < a.C) {
-    float v = 0.f;
-    for (int w = 0; w < LH_T / 64; ++w) v += s_part[w][tid];
-    s_dw[tid] = v;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    // label backward of the row, one class per lane (cl_vrnn/model.py:244-252 through the logistic-normal sample):
-    // three wave sums instead of a serial walk over the classes by one thread
-    const float ep = __expf(a.prior);
-    const int j = lane;
-    const bool in = j < a.C;
-    const float w = in ? s_wv[j] : 0.f;
-    const float qs = wave_sum(in ? w + LW2 : 0.f);
-    const float n = (w + LW2) / qs;
-    const bool inside = (n >= LEPS_K) && (n <= 1.f - LEPS_K);
-    const float nc = fminf(fmaxf(n, LEPS_K), 1.f - LEPS_K);
-    const float dn = (in && inside) ? -(float)C1 * s_oh[j] / nc : 0.f;
-    const float dot = wave_sum(dn * n);
-    const float d = in ? s_dw[j] + a.class_weight * a.inv_b * ((dn - dot) / qs) : 0.f;
-    const float dsum = wave_sum(d * w);
-    if (j < C1) {
-      const float ds = w * (d - dsum);
-      const float m = s_wa[j], lv = s_wa[C1 + j];
-      const float sd = expf(0.5f * lv);
-      const float dm = ds + a.w_kl_weight * a.inv_b * (m / ep);
-      const float dl = ds * s_eps[j] * 0.5f * sd + a.w_kl_weight * a.inv_b * (-0.5f * (1.f - sd * sd / ep));
-      s_dwa[j] = dm; s_dwa[C1 + j] = dl;
-      a.dwargs[(size_t)b * NA + j] = dm;
-      a.dwargs[(size_t)b * NA + C1 + j] = dl;
-    }
-  }
-  __syncthreads();
-  if (tid < a.D) {
-    float acc = 0.f;
-    const float hv = a.hW[(size_t)b * a.D + tid];
-    for (int j0 = 0; j0 < NA; j0 += 32) {           // 32 loads in flight: one round trip for up to 17 classes
-      float kv[32];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) kv[q] = a.Ka[(size_t)tid * NA + min(j0 + q, NA - 1)];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) acc = fmaf(j0 + q < NA ? s_dwa[j0 + q] : 0.f, kv[q], acc);
-    }
-    a.dhW[(size_t)b * a.D + tid] = hv > 0.f ? acc : 0.f;
-  }
-  if (a.wa_slab) {
-    // [hW_b | 1]^T . dwargs_b: the row's outer product; the rows are summed by the backward pass's pending reductions
-    // (a GEMM of its own over K = batch was a 10 us launch for 0.4 MFLOP)
-    float* slab = a.wa_slab + (size_t)b * (a.D + 1) * NA;
-    for (int e = tid; e < (a.D + 1) * NA; e += LH_T) {
-      const int r = e / NA, j = e - r * NA;
-      slab[e] = (r < a.D ? a.hW[(size_t)b * a.D + r] : 1.f) * s_dwa[j];
-    }
-  }
+  label_bwd_row<LH_T>(a, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 }  // namespace clv

@@ -19,6 +19,7 @@
 
 #include "lstm_common.h"
 #include "lstm_pair_pack.h"
+#include "label_bwd_row.h"
 #include "philox.h"
 #include "reduce_job.h"
 
@@ -661,6 +662,9 @@ struct PairBwdArgs {
   // (a GEMM of its own re-read hs_enc and cost a 10 us launch): hs_e [B*T,88] in, wz_slab [B][89][2L] out
   const float* hs_e;
   float* wz_slab;
+  // the label path's backward of the same batch row as this workgroup's epilogue (label_bwd_row.h): lab_on != 0
+  LabelBwdArgs lab;
+  int lab_on;
 };
 
 // LATW: the decoder chain's last wave: its surplus unit groups hold rows of Kz and finish dzargs
@@ -869,6 +873,10 @@ __global__ __launch_bounds__(PNT) void lstm_pair_bwd_kernel(PairBwdArgs a) {
   if (wave < PNW - 1) pair_bwd_chain<GATE, true, false, ZP, WZG>(a, wave, lane, dzbuf[0], dza);
   else if (wave == PNW - 1) pair_bwd_chain<GATE, true, true, ZP, WZG>(a, wave, lane, dzbuf[0], dza);
   else pair_bwd_chain<GATE, false, false, ZP, WZG>(a, wave - PNW, lane, dzbuf[1], dza);
+  if (a.lab_on) {            // uniform: row b's sum_t dz of both chains is complete in HBM / L2 after the barrier
+    __syncthreads();
+    label_bwd_row<PNT>(a.lab, (int)blockIdx.x, tid);
+  }
 }
 
 }  // namespace clv
@@ -951,8 +959,29 @@ extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float
                                  const float* zargs, const float* eps, float* dzargs,
                                  const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
                                  void* stream) {
+  return clv_lstm_pair_bwd_ex(B, T, H, L, gate_act, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_dec_inout_dz,
+                              gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs, hs_enc, dWz, dbz, ws, ws_bytes, job,
+                              nullptr, stream);
+}
+
+extern "C" int clv_lstm_pair_bwd_ex(int B, int T, int H, int L, int gate_act, float kl_scale,
+                                    const float* pack, const float* Wz,
+                                    const float* dhs_dec, const float* aux_dec, const float* aux_enc,
+                                    float* gates_dec_inout_dz, float* gates_enc_inout_dz,
+                                    float* dzsum_dec, float* dzsum_enc,
+                                    const float* zargs, const float* eps, float* dzargs,
+                                    const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
+                                    const clv_label_bwd_rider* label, void* stream) {
   using namespace clv;
   if (job) memset(job, 0, sizeof(*job));
+  if (label && label->job) memset(label->job, 0, sizeof(*label->job));
+  if (label) {
+    const clv_label_bwd_rider& r = *label;
+    if (r.D <= 0 || r.D > 128 || r.C < 2 || r.C > LH_MAXC) return CLV_EINVAL;
+    if (!r.Kenc_w || !r.Kdec_w || !r.wargs || !r.eps || !r.onehot || !r.W || !r.hW || !r.Ka || !r.dwargs || !r.dhW)
+      return CLV_EINVAL;
+    if (r.dKa && (!r.dba || !r.ws || r.ws_bytes < (size_t)B * (r.D + 1) * 2 * (r.C - 1) * sizeof(float))) return CLV_EWORKSPACE;
+  }
   if (!clv_lstm_pair_supported(H, L) || B <= 0 || T <= 0) return CLV_EINVAL;
   const bool wzg = hs_enc != nullptr;
   if (wzg && (!dWz || !dbz || !ws || ws_bytes < clv_lstm_pair_bwd_workspace_bytes(B, H, L))) return CLV_EWORKSPACE;
@@ -961,7 +990,14 @@ extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float
       !dzsum_dec || !dzsum_enc || !zargs || !eps || !dzargs)
     return CLV_EINVAL;
   PairBwdArgs a{B, T, L, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_dec_inout_dz,
-                gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs, hs_enc, (float*)ws};
+                gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs, hs_enc, (float*)ws, {}, 0};
+  if (label) {
+    const clv_label_bwd_rider& r = *label;
+    a.lab = LabelBwdArgs{B, r.D, r.C, LG, dzsum_enc, dzsum_dec, r.Kenc_w, r.Kdec_w, r.wargs, r.eps, r.onehot, r.W, r.hW, r.Ka,
+                         r.prior_logvar, r.class_weight, r.w_kl_weight, r.inv_b, r.dwargs, r.dhW,
+                         r.dKa ? (float*)r.ws : nullptr};
+    a.lab_on = 1;
+  }
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_pair_bwd", s);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
@@ -975,7 +1011,21 @@ extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float
 #undef PAIR_BWD
 #undef PAIR_BWD_W
   int st = launch_status();
-  if (st || !wzg) return st;
+  if (st) return st;
+  if (label && label->dKa) {       // the Wargs layer's per-row slabs, exactly as clv_vrnn_label_bwd_ex leaves them
+    ReduceJob jl;
+    memset(&jl, 0, sizeof(jl));
+    const int NA = 2 * (label->C - 1);
+    jl.partial = (const float*)label->ws;
+    jl.M = label->D + 1; jl.N = NA; jl.splits = B; jl.nprob = 2;
+    jl.alpha = 1.f; jl.beta = 0.f; jl.act = CLV_ACT_NONE;
+    jl.prob[0] = ReduceProb{label->dKa, NA, 0};
+    jl.prob[1] = ReduceProb{label->dba, NA, label->D};
+    if (label->job && B > 1) memcpy(label->job, &jl, sizeof(jl));
+    else st = launch_reduce(jl, s);
+    if (st) return st;
+  }
+  if (!wzg) return st;
   // the per-row slabs [B][89][2L] -> dWz [88,2L] and dbz [2L]: a pending reduction like a split-K product's
   ReduceJob j;
   memset(&j, 0, sizeof(j));

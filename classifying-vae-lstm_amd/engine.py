@@ -583,6 +583,8 @@ class VrnnEngine(_EngineBase):
         # rows per step through its L1 miss path (~10 B/cycle per CU), +48 us on the pair kernel for the 26 us launch it
         # removes -- so the default stays the projection launch, whose workgroups keep K_x in LDS.
         # notes_valid: the lists describe the frames now in X / XZ (TrainStep sets it per staged batch).
+        # the label path's backward as the pair backward kernel's epilogue (CLV_LABEL_IN_PAIR=0: its own launch)
+        self.label_in_pair = bool(cfg.get('label_in_pair', os.environ.get('CLV_LABEL_IN_PAIR', '1') != '0')) and self.fuse_pair
         # outside the pair kernels: the latent head's forward / backward as one MFMA launch each (csrc/latent_head.hip)
         self.fuse_latent = bool(cfg.get('fuse_latent', os.environ.get('CLV_FUSE_LATENT', '1') != '0')) \
             and ops.latent_head_supported(H, L)
@@ -1008,18 +1010,30 @@ class VrnnEngine(_EngineBase):
         if self.fuse_pair:
             # decoder BPTT, dZ, the latent head's backward, dh_enc and encoder BPTT: one persistent launch
             # ... and the latent head's own weight gradient (per-row slabs into the pass's pending reductions)
+            # ... and (round 3) the label path's backward of the same batch row as every workgroup's epilogue: row b's
+            # sum_t dz is all it needs of the BPTT, a launch of its own was 10.7 us
+            label = None
+            if self.label_in_pair:
+                label = dict(D=D, C=Cn, Kenc_w=P.rows(P.params, 'encoder_h/kernel', D),
+                             Kdec_w=P.rows(P.params, 'decoder_h/kernel', off + L), wargs=self.wargs, eps=eps_W, onehot=w_true,
+                             W=self.W, hW=self.hW, Ka=P.p('Wargs/kernel'), prior=cfg['w_log_var_prior'],
+                             class_weight=self.class_weight, w_kl_weight=self.w_kl_weight, inv_b=inv_b, dwargs=self.dwargs,
+                             dhW=self.dhW, layer_grad=(P.g('Wargs/kernel'), P.g('Wargs/bias')))
             ops.lstm_pair_bwd(B, T, L, self.kl_weight * inv_bt, self.pair_pack, P.p('Zargs/kernel'), self.dhs,
                               self.cs_dec, self.cs_enc, self.gates_dec, self.gates_enc, self.dzsum_dec, self.dzsum_enc,
                               self.zargs, eps_Z, self.dzargs, gate_act=self.gate_act,
-                              head_grad=(self.hs_enc, P.g('Zargs/kernel'), P.g('Zargs/bias')), ws=ws, defer=self._rq())
+                              head_grad=(self.hs_enc, P.g('Zargs/kernel'), P.g('Zargs/bias')), ws=ws, defer=self._rq(),
+                              label=label)
             self._head_grad_done = True
         else:
             self._bptt_separate(eps_Z, ws)
         # label head: dW from both LSTMs, label backward, dWargs and dhW in one launch
-        ops.vrnn_label_bwd(B, D, Cn, G4, self.dzsum_enc, self.dzsum_dec, P.rows(P.params, 'encoder_h/kernel', D),
-                           P.rows(P.params, 'decoder_h/kernel', off + L), self.wargs, eps_W, w_true, self.W, self.hW,
-                           P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
-                           self.dwargs, self.dhW, layer_grad=(P.g('Wargs/kernel'), P.g('Wargs/bias')), ws=ws, defer=self._rq())
+        if not (self.fuse_pair and self.label_in_pair):
+            ops.vrnn_label_bwd(B, D, Cn, G4, self.dzsum_enc, self.dzsum_dec, P.rows(P.params, 'encoder_h/kernel', D),
+                               P.rows(P.params, 'decoder_h/kernel', off + L), self.wargs, eps_W, w_true, self.W, self.hW,
+                               P.p('Wargs/kernel'), cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, inv_b,
+                               self.dwargs, self.dhW, layer_grad=(P.g('Wargs/kernel'), P.g('Wargs/bias')), ws=ws,
+                               defer=self._rq())
         if self.sparse_inputs and ops.sparse_dense_supported(D):      # kernel gradient and bias gradient (column sums of dhW)
             # ... and sum_j K dK per column for the optimizer's two-launch form (the batch sum of pre-activation x gradient)
             ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'),

@@ -59,6 +59,12 @@ class ReduceQueue:
         self.n += 1
         return j
 
+    def next_job_addr(self):
+        """the next slot's address (for a job pointer that travels inside a struct)"""
+        a = C.addressof(self.jobs) + self.n * C.sizeof(_lib.ReduceJob)
+        self.n += 1
+        return a
+
     def flush(self, means=None, out=None, skinny=None):
         """Run the pending reductions in one launch.  means: up to five (tensor, n, stride) terms whose means go to
         out[k] from extra blocks of the same launch (a step's loss terms: no launch of their own).  skinny: up to two
@@ -349,22 +355,46 @@ def lstm_pair_fwd(B, T, L, gates_enc, rb_enc, gates_dec, dec_has_xproj, rb_dec, 
 
 
 def lstm_pair_bwd(B, T, L, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_dec, gates_enc, dzsum_dec,
-                  dzsum_enc, zargs, eps, dzargs, gate_act=0, H=88, head_grad=None, ws=None, defer=None):
+                  dzsum_enc, zargs, eps, dzargs, gate_act=0, H=88, head_grad=None, ws=None, defer=None, label=None):
     """head_grad = (hs_enc, dWz, dbz): the latent head's kernel / bias gradient is accumulated inside the kernel (per-row
-    slabs, summed by the pending reduction of `defer`, or at once) instead of by a GEMM over hs_enc."""
+    slabs, summed by the pending reduction of `defer`, or at once) instead of by a GEMM over hs_enc.
+    label = dict(D, C, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior, class_weight, w_kl_weight, inv_b, dwargs, dhW,
+    layer_grad=(dKa, dba) | None): the label path's backward (vrnn_label_bwd) as the kernel's epilogue."""
     Lb = _lib.lib()
     hs, dWz, dbz, buf, nbytes, job = None, None, None, None, 0, None
+    need_h = Lb.clv_lstm_pair_bwd_workspace_bytes(B, H, L) if head_grad is not None else 0
+    lg = label.get('layer_grad') if label is not None else None
+    need_l = Lb.clv_vrnn_label_bwd_workspace_bytes(B, label['D'], label['C']) if lg is not None else 0
+    lbuf_ptr, ljob = None, None
     if head_grad is not None:
         hs, dWz, dbz = head_grad
-        need = Lb.clv_lstm_pair_bwd_workspace_bytes(B, H, L)
-        buf = defer.scratch(need) if defer is not None else ws.ensure(need)
-        nbytes = buf.numel()
-        job = defer.next_job() if defer is not None else None
-    check(Lb.clv_lstm_pair_bwd(B, T, H, L, gate_act, float(kl_scale), _ptr(pack), _ptr(Wz),
-                               _ptr(dhs_dec), _ptr(aux_dec), _ptr(aux_enc), _ptr(gates_dec), _ptr(gates_enc),
-                               _ptr(dzsum_dec), _ptr(dzsum_enc), _ptr(zargs), _ptr(eps), _ptr(dzargs),
-                               _ptr(hs), _ptr(dWz), _ptr(dbz), _ptr(buf), nbytes, job, _stream()),
-          "clv_lstm_pair_bwd")
+        if defer is not None:
+            buf = defer.scratch(need_h)
+            job = defer.next_job()
+        else:                              # one scratch buffer, two regions
+            buf = ws.ensure((need_h + 255) // 256 * 256 + need_l)
+        nbytes = need_h
+    rider = None
+    if label is not None:
+        if lg is not None:
+            if defer is not None:
+                lbuf = defer.scratch(need_l)
+                lbuf_ptr, ljob = lbuf.data_ptr(), defer.next_job_addr()
+            else:
+                base = buf if buf is not None else ws.ensure(need_l)
+                lbuf_ptr = base.data_ptr() + ((need_h + 255) // 256 * 256 if buf is not None else 0)
+        rider = _lib.LabelBwdRider(label['D'], label['C'], _ptr(label['Kenc_w']), _ptr(label['Kdec_w']), _ptr(label['wargs']),
+                                   _ptr(label['eps']), _ptr(label['onehot']), _ptr(label['W']), _ptr(label['hW']),
+                                   _ptr(label['Ka']), float(label['prior']), float(label['class_weight']),
+                                   float(label['w_kl_weight']), float(label['inv_b']), _ptr(label['dwargs']),
+                                   _ptr(label['dhW']), _ptr(lg[0]) if lg else None, _ptr(lg[1]) if lg else None,
+                                   lbuf_ptr, need_l, ljob)
+    check(Lb.clv_lstm_pair_bwd_ex(B, T, H, L, gate_act, float(kl_scale), _ptr(pack), _ptr(Wz),
+                                  _ptr(dhs_dec), _ptr(aux_dec), _ptr(aux_enc), _ptr(gates_dec), _ptr(gates_enc),
+                                  _ptr(dzsum_dec), _ptr(dzsum_enc), _ptr(zargs), _ptr(eps), _ptr(dzargs),
+                                  _ptr(hs), _ptr(dWz), _ptr(dbz), _ptr(buf), nbytes, job,
+                                  C.byref(rider) if rider is not None else None, _stream()),
+          "clv_lstm_pair_bwd_ex")
 
 
 def label_fwd(B, Cn, mean, logvar, ld_in, eps, onehot, prior, w, rowloss):

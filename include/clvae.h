@@ -288,6 +288,28 @@ int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
                       const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
                       void* stream);
 size_t clv_lstm_pair_bwd_workspace_bytes(int B, int H, int L);
+/* ... with the label path's backward (clv_vrnn_label_bwd_ex: same arithmetic, same outputs) as the epilogue of every
+ * workgroup: row b's sum_t dz of both LSTMs is what the label backward of row b reads, so it needs no launch of its own
+ * (cl_vrnn/model.py:174-191, 244-252 under K.gradients).  label == NULL: clv_lstm_pair_bwd.  dKa / dba / ws / job as in
+ * clv_vrnn_label_bwd_ex (dKa == NULL: no layer gradient). */
+typedef struct clv_label_bwd_rider {
+  int D, C;
+  const float *Kenc_w, *Kdec_w;         /* [C,352] the kernel rows that multiply W */
+  const float *wargs, *eps, *onehot, *W, *hW, *Ka;
+  float prior_logvar, class_weight, w_kl_weight, inv_b;
+  float *dwargs, *dhW;
+  float *dKa, *dba;
+  void* ws; size_t ws_bytes;
+  clv_reduce_job* job;
+} clv_label_bwd_rider;
+int clv_lstm_pair_bwd_ex(int B, int T, int H, int L, int gate_act, float kl_scale,
+                         const float* pack, const float* Wz,
+                         const float* dhs_dec, const float* aux_dec, const float* aux_enc,
+                         float* gates_dec_inout_dz, float* gates_enc_inout_dz,
+                         float* dzsum_dec, float* dzsum_enc,
+                         const float* zargs, const float* eps, float* dzargs,
+                         const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
+                         const clv_label_bwd_rider* label, void* stream);
 
 /* ------------------------------------------------ cl_vrnn generation, persistent --
  * cl_vrnn/model.py:9-60 (generate_sample's frame loop) for N independent sequences, one workgroup per
