@@ -39,7 +39,7 @@ WORKLOADS = {
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (never the 2:1-sparsity figure)
-PROFILE_TAGS = ('r03_e', 'r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01')      # newest committed profile set first
+PROFILE_TAGS = ('r03_f', 'r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01')      # newest committed profile set first
 NOTE_DENSITY = 0.0443        # measured JSB note density
 
 
@@ -360,6 +360,7 @@ def main():
         ops.prof_enable(True)
         for _ in range(reps):
             ts_e.step()
+            ops.prof_empty_scope()          # what a bracket of the profiler's events costs by itself ("event_pair")
         recs = ops.prof_collect()
         ops.prof_enable(False)
         for t_, sv in zip(eng.P.state_tensors(), saved):
@@ -386,7 +387,11 @@ def main():
 
     roofline = None
     if recs is not None:
+        pair_ms = [r[2] / max(r[1], 1) for r in recs if r[0] == 'event_pair']
+        event_pair_us = 1e3 * pair_ms[0] if pair_ms else 0.0
+        recs = [r for r in recs if r[0] != 'event_pair']
         if args.kernel_times:
+            print("  event_pair (empty bracket)  %.2f us" % event_pair_us, file=sys.stderr)
             tot = sum(r[2] for r in recs)
             for name, n, ms in sorted(recs, key=lambda r: -r[2]):
                 print("  %-22s launches/step %5.1f  ms/step %8.4f  %5.1f%%" % (name, n / reps, ms / reps, 100 * ms / tot),
@@ -400,14 +405,16 @@ def main():
             # (one launch = one LSTM pass, or both LSTMs of a pass when the pair kernels run): 4 LSTM passes per step
             names = sorted(k for k in by if k.startswith(('lstm_pair_', 'lstm_seq_')) and not k.endswith('_pack'))
             n = sum(by[k][1] for k in names)
-            ms = sum(by[k][2] for k in names)
+            ms_raw = sum(by[k][2] for k in names)
+            ms = ms_raw - n * event_pair_us * 1e-3         # minus what the brackets themselves cost (see `event_pair_us`)
             avg_s = ms / n * 1e-3
             achieved = 4 * reps * lstm_seq_flops(w, B) / (ms * 1e-3) / 1e12
             kname = '+'.join(names)
         else:
             # cl_vae: the whole step is one fused launch (all 8 Dense layers, forward + backward)
             kname = 'vae_fused_step' if 'vae_fused_step' in by else 'gemm_f32'
-            n, ms = by[kname][1], by[kname][2]
+            n, ms_raw = by[kname][1], by[kname][2]
+            ms = ms_raw - n * event_pair_us * 1e-3
             avg_s = ms / n * 1e-3
             achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
         # HBM bytes: NOT measured in this run -- read from the newest committed PMC summary of the SAME workload and
@@ -430,7 +437,11 @@ def main():
             break
         roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=kname,
-                        avg_launch_us=round(avg_s * 1e6, 2),
+                        avg_launch_us=round(avg_s * 1e6, 2), avg_launch_us_raw=round(ms_raw / n * 1e3, 2),
+                        event_pair_us=round(event_pair_us, 2),
+                        timing="HIP events around every launch on the launch stream; avg_launch_us = the bracketed time minus "
+                               "event_pair_us, an EMPTY bracket measured in the same pass (the two event records cost that much "
+                               "by themselves); achieved / frac use avg_launch_us, the raw figure is avg_launch_us_raw",
                         whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4),
                         step_traffic=step_traffic, traffic_source=traffic_source,
                         traffic_measured_in_this_run=False,
@@ -439,12 +450,19 @@ def main():
             # the recurrent products run on the fp32 VECTOR pipe (v_pk_fma_f32; one batch row per CU leaves the matrix
             # cores' M dimension empty); its peak equals the fp32 MFMA peak, which is what `peak` holds
             roofline['executes_on'] = "fp32 VALU (v_pk_fma_f32): the fp32 vector peak equals the fp32 MFMA peak (157.3 TFLOP/s)"
+            if getattr(eng, 'fuse_pair', False) and getattr(eng, 'label_in_pair', False):
+                # honest denominator: the backward launch is not only recurrent products any more
+                roofline['kernel_also_runs'] = ("lstm_pair_bwd ends with the label path's backward of every batch row (no launch of "
+                                                "its own): ~13.9 us of the launch by rocprofv3 (profiles/r03_e_kernel_stats_cfg3.csv "
+                                                "without it: 76.8 us, r03_f with it: 90.7 us); the recurrent products alone sit at "
+                                                "8.12 GFLOP / (94.0 + 76.8 us) = 0.30 of the peak")
         if 'lstm_wgrad_bf16' in by:
             # the batched gate GEMM of the north star: every kernel gradient of an LSTM, [x | h | z]^T . dz over B*T rows
             # (csrc/wgrad_bf16.hip), formed on the BF16 matrix cores from exact pieces.  Reported against the pipe it
             # runs on: (a) issued bf16 MFMA flops / 2.5 PFLOP/s, (b) the MFMA-busy counter of the committed SQ pass;
             # the algorithmic fp32-equivalent rate is given by name, never as a fraction of a peak it does not use.
             gn, gms = by['lstm_wgrad_bf16'][1], by['lstm_wgrad_bf16'][2]
+            gms -= gn * event_pair_us * 1e-3
             rows = (88 + 88) + (88 + w['L'] + 88)
             alg = 2.0 * rows * 352 * B * w['T'] * reps                     # algorithmic flops of the products, both LSTMs
             exact = bool(getattr(eng, 'frames_exact_bf16', False))

@@ -181,6 +181,7 @@ SIGNATURES = {
     "clv_graph_destroy": (_i, [_p]),
     "clv_prof_enable": (_i, [_i]),
     "clv_prof_collect": (_i, [C.POINTER(ProfRecord), _i]),
+    "clv_prof_empty_scope": (_i, [_p]),
 }
 
 _lib = None

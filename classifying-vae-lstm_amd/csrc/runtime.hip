@@ -221,6 +221,13 @@ extern "C" int clv_prof_enable(int on) {
   return CLV_OK;
 }
 
+// an EMPTY bracket on `stream` (two event records, nothing between them), recorded as "event_pair": what the profiler's
+// events themselves add to every bracketed launch -- bench.py reports it next to the kernel durations it measures
+extern "C" int clv_prof_empty_scope(void* stream) {
+  ProfScope p("event_pair", (hipStream_t)stream);
+  return CLV_OK;
+}
+
 extern "C" int clv_prof_collect(clv_prof_record* host_out, int cap) {
   CLV_HIP_TRY(hipDeviceSynchronize());
   std::lock_guard<std::mutex> lk(g_prof.mu);

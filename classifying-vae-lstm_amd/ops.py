@@ -586,6 +586,11 @@ def prof_enable(on=True):
     check(_lib.lib().clv_prof_enable(int(on)))
 
 
+def prof_empty_scope():
+    """an empty bracket of the profiler's events on the current stream (record name "event_pair")"""
+    check(_lib.lib().clv_prof_empty_scope(_stream()))
+
+
 def prof_collect(cap=64):
     arr = (_lib.ProfRecord * cap)()
     n = _lib.lib().clv_prof_collect(arr, cap)

@@ -684,6 +684,9 @@ typedef struct clv_prof_record {
 } clv_prof_record;
 int clv_prof_enable(int on);
 int clv_prof_collect(clv_prof_record* host_out, int cap);
+/* records an empty bracket ("event_pair": two event records, no launch between them) when the profiler is on: the time the
+ * events themselves add to a bracketed launch */
+int clv_prof_empty_scope(void* stream);
 
 #ifdef __cplusplus
 }
