@@ -258,3 +258,37 @@ def test_initializers_distributions():
     k = w['encoder_h/kernel']
     assert abs(np.abs(k).max() - np.sqrt(6.0 / (98 + 352))) < 1e-3              # glorot_uniform limit
     assert (w['hW/bias'] == 0).all()
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """Every ctypes.Structure of _lib.py against the struct of include/clvae.h it mirrors: size and the offset of every field,
+    as gcc lays the header out (a hand-written mirror that drifts would pass garbage to the kernels without any error)."""
+    import ctypes as C
+    import subprocess
+    lib_py = _lib
+    pairs = {'VaeStepOpts': 'clv_vae_step_opts', 'NoiseDraw': 'clv_noise_draw', 'PairPackSrc': 'clv_pair_pack_src',
+             'AdamKnownSums': 'clv_adam_known_sums', 'ParamDesc': 'clv_param_desc', 'GemmProb': 'clv_gemm_prob',
+             'ReduceJob': 'clv_reduce_job', 'SkinnyProduct': 'clv_skinny_product', 'LabelBwdRider': 'clv_label_bwd_rider',
+             'ProfRecord': 'clv_prof_record'}
+    # every Structure of the module is covered
+    mirrored = {n for n in dir(lib_py) if isinstance(getattr(lib_py, n), type) and issubclass(getattr(lib_py, n), C.Structure)
+                and getattr(lib_py, n) is not C.Structure}
+    assert mirrored == set(pairs), mirrored ^ set(pairs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "clvae.h"', 'int main(void) {']
+    for py, cn in pairs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (py, cn))
+        for fname, _ in getattr(lib_py, py)._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (py, fname, cn, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I' + os.path.join(ROOT, 'include'), '-o', str(exe), str(src)], check=True, stdin=subprocess.DEVNULL)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout
+    for line in out.splitlines():
+        py, what, val = line.split()
+        cls = getattr(lib_py, py)
+        if what == 'size':
+            assert C.sizeof(cls) == int(val), (py, C.sizeof(cls), int(val))
+        else:
+            assert getattr(cls, what).offset == int(val), (py, what, getattr(cls, what).offset, int(val))
