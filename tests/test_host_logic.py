@@ -292,3 +292,27 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
             assert C.sizeof(cls) == int(val), (py, C.sizeof(cls), int(val))
         else:
             assert getattr(cls, what).offset == int(val), (py, what, getattr(cls, what).offset, int(val))
+
+
+def test_ctypes_signatures_have_the_headers_argument_counts():
+    """_lib.SIGNATURES against the prototypes of include/clvae.h: same number of arguments per function, pointer arguments
+    bound as pointers and 64-bit / float arguments as such (a binding that drops or reorders an argument would still load)."""
+    hdr = open(os.path.join(ROOT, "include", "clvae.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = dict(re.findall(r"\b(clv_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", hdr))
+    assert set(protos) >= set(_lib.SIGNATURES)
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        args = [a.strip() for a in protos[name].split(",")]
+        if args == ["void"] or args == [""]:
+            args = []
+        assert len(args) == len(argtypes), (name, len(args), len(argtypes))
+        for a, t in zip(args, argtypes):
+            is_ptr = "*" in a
+            if is_ptr:
+                assert t is ctypes.c_void_p or hasattr(t, "contents") or t is ctypes.c_char_p, (name, a, t)
+            elif re.match(r"(const\s+)?float\b", a):
+                assert t is ctypes.c_float, (name, a, t)
+            elif re.match(r"(const\s+)?(size_t|int64_t|uint64_t|long)\b", a):
+                assert ctypes.sizeof(t) == 8, (name, a, t)
+            elif re.match(r"(const\s+)?(int|int32_t|uint32_t|unsigned)\b", a):
+                assert ctypes.sizeof(t) == 4 and t is not ctypes.c_float, (name, a, t)
