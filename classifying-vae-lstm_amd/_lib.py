@@ -112,6 +112,9 @@ SIGNATURES = {
     "clv_lstm_seq_fwd_x_lds_bytes": (_sz, [_i, _i]),
     "clv_lstm_seq_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_seq_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_lstm_mx_supported": (_i, [_i, _i, _i, _i]),
+    "clv_lstm_mx_fwd": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_lstm_mx_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p]),
     "clv_lstm_pair_supported": (_i, [_i, _i]),
     "clv_lstm_pair_pack_floats": (_sz, []),
     "clv_lstm_pair_pack": (_i, [_i, _i, _p, _p, _p, _p, _p, _p]),

@@ -270,6 +270,23 @@ def lstm_seq_bwd(B, T, U, dhs, cs, gates_inout, dzsum, c0=None, gate_act=0, H=88
                                       _ptr(dzsum), _stream()), "clv_lstm_seq_bwd")
 
 
+def lstm_mx_supported(B, nx, nz, H=88):
+    """the large-batch LSTM kernels on the bf16 matrix cores (csrc/lstm_mx.hip) take this shape"""
+    return bool(_lib.lib().clv_lstm_mx_supported(B, H, nx, nz))
+
+
+def lstm_mx_fwd(B, T, X, ldx, nx, Kx, Z, ldz, nz, Kz, rowbias, U, hs, coef, aux, gate_act=0, H=88):
+    """LSTM training forward with the input products inside the kernel: frames X (sparse rows of Kx) and latents Z."""
+    check(_lib.lib().clv_lstm_mx_fwd(B, T, H, gate_act, _ptr(X), ldx, nx, _ptr(Kx), _ptr(Z), ldz, nz, _ptr(Kz),
+                                     _ptr(rowbias), _ptr(U), _ptr(hs), _ptr(coef), _ptr(aux), _stream()), "clv_lstm_mx_fwd")
+
+
+def lstm_mx_bwd(B, T, U, dhs, aux, coef_inout, dzsum, Kz=None, nz=0, dZ=None, lddz=0, H=88):
+    """BPTT of lstm_mx_fwd; coef_inout becomes dz; nz > 0: dZ = dz . Kz^T from the same launch."""
+    check(_lib.lib().clv_lstm_mx_bwd(B, T, H, _ptr(U), _ptr(dhs), _ptr(aux), _ptr(coef_inout), _ptr(dzsum), _ptr(Kz), nz,
+                                     _ptr(dZ), lddz, _stream()), "clv_lstm_mx_bwd")
+
+
 def sparse_proj_supported(nx, N):
     return bool(_lib.lib().clv_sparse_proj_supported(nx, N))
 

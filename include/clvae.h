@@ -230,6 +230,33 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
                      const float* U, const float* dhs, const float* cs, const float* c0,
                      float* gates_inout_dz, float* dzsum, void* stream);
 
+/* ----------------------------------------- LSTM, large batches: bf16-split MFMA --
+ * The training pass of one LSTM layer (cl_vrnn/model.py:196-199 encoder_h, :225-228 decoder_h; Keras LSTM under
+ * K.rnn / K.gradients) for batches of >= 4 rows per CU (BASELINE configuration 5: 1024 rows per GPU), csrc/lstm_mx.hip.
+ * A workgroup owns four batch rows; the recurrent product runs on v_mfma_f32_16x16x32_bf16 with EXACT fp32 products
+ * (an fp32 number = three bf16 pieces; the pieces of h sit in the MFMA's N dimension, so the nine piece products cost
+ * three MFMAs per tile and k-step), accumulated in fp32.  The per-step inputs are multiplied INSIDE the kernel:
+ *   z_t = X[b,t,:nx] . Kx + Z[b,t,:nz] . Kz + rowbias[b,:] + h_{t-1} . U
+ * X: B*T rows of stride ldx (piano-roll frames; any float values are handled exactly, cost grows with the nonzeros of a
+ * frame: Kx [nx,4H] stays in LDS and only the rows of the notes that are on are added), nx <= 96, nx == 0: no frames;
+ * Z: B*T rows of stride ldz, nz <= 32 latent inputs times Kz [nz,4H] as one more MFMA k-step, nz == 0: none.
+ * No [B*T,4H] projection buffer exists (clv_sparse_proj + clv_lstm_seq_fwd read and write one).  Zero initial state.
+ * Outputs: hs [B*T,H] and the backward pass's coefficients in the format of clv_lstm_pair_fwd:
+ *   coef [B*T,4H] = (ki, kf, kg, ko) = (g i', c_{t-1} f', i g', tanh(c) o'),  aux [B*T,2,H] = (kcarry, kc) = (f, o (1 - tanh(c)^2)).
+ * clv_lstm_mx_bwd: BPTT from dhs [B*T,H]: dc += dh kc; dz = (dc ki, dc kf, dc kg, dh ko); dc *= kcarry, with
+ * dh = dhs_t + dz_{t+1} . U^T on the same matrix cores; coef is overwritten in place with dz [B*T,4H], dzsum [B,4H] =
+ * sum_t dz.  nz > 0: dZ_t = dz_t . Kz^T as well (dZ: B*T rows of stride lddz), by one or two more waves.
+ * clv_lstm_mx_supported: H == 88, nx <= 96, nz <= 32 and a batch the engine hands to these kernels (>= 512 rows;
+ * CLV_LSTM_MX=1 / 0 forces / forbids them for measurements and tests). */
+int clv_lstm_mx_supported(int B, int H, int nx, int nz);
+int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,
+                    const float* X, int ldx, int nx, const float* Kx,
+                    const float* Z, int ldz, int nz, const float* Kz,
+                    const float* rowbias, const float* U,
+                    float* hs, float* coef, float* aux, void* stream);
+int clv_lstm_mx_bwd(int B, int T, int H, const float* U, const float* dhs, const float* aux,
+                    float* coef_inout_dz, float* dzsum, const float* Kz, int nz, float* dZ, int lddz, void* stream);
+
 /* ------------------------------------------ cl_vrnn: both LSTMs in one launch --
  * cl_vrnn/model.py:193-228 as ONE persistent kernel: encoder LSTM, the fused latent head
  * [Z_mean | Z_log_var] (Wz [H,2L], bz [2L]), z = mean + exp(log_var/2)*eps, its KL term, and the

@@ -823,3 +823,86 @@ def test_latent_head_matches_numpy(dev, R, L, defer):
     ops.latent_head_bwd(R, H, L, hs_d, Wz_d, zargs, eps_d, T(dZ, dev), lddz, kl, dhs2, dWz2, dbz2, ws)
     torch.cuda.synchronize()
     assert torch.equal(dhs2, dhs) and torch.equal(dWz2, dWz) and torch.equal(dbz2, dbz)
+
+
+def _mx_case(rng, B, Tn, nx, nz, density, gate):
+    """inputs of one clv_lstm_mx_fwd / _bwd call and the oracle's forward / backward for them"""
+    H = 88
+    U = O.orthogonal(rng, (H, 4 * H), np.float64) * 1.5
+    Kx = rng.standard_normal((max(nx, 1), 4 * H)) * 0.7
+    Kz = rng.standard_normal((max(nz, 1), 4 * H)) * 0.4
+    ldx, ldz = nx + 4, nz + 3
+    Xb = np.zeros((B * Tn, ldx))
+    if nx:
+        Xb[:, :nx] = rng.random((B * Tn, nx)) < density
+        Xb[1 % (B * Tn), :nx] = 1.0                       # a frame with every note on (the list loop's long path)
+        Xb[:, nx:] = 7.0                                   # padding columns must not be read as inputs
+    Zb = rng.standard_normal((B * Tn, ldz))
+    rb = rng.standard_normal((B, 4 * H)) * 0.3
+    xs = rb[:, None, :] + np.zeros((B, Tn, 4 * H))
+    if nx:
+        xs = xs + (f32(Xb[:, :nx]) @ f32(Kx[:nx])).reshape(B, Tn, 4 * H)
+    if nz:
+        xs = xs + (f32(Zb[:, :nz]) @ f32(Kz[:nz])).reshape(B, Tn, 4 * H)
+    act = 'hard_sigmoid' if gate == 0 else 'sigmoid'
+    hs_ref, cache = O.lstm_forward(f32(xs), np.eye(4 * H), f32(U), np.zeros(4 * H), gate_act=act)
+    return dict(H=H, U=U, Kx=Kx, Kz=Kz, ldx=ldx, ldz=ldz, Xb=Xb, Zb=Zb, rb=rb, hs_ref=hs_ref, cache=cache, act=act)
+
+
+MX_CASES = [(4, 9, 88, 0, 0.05, 0), (7, 5, 88, 32, 0.05, 0), (1024, 3, 88, 32, 0.0443, 0), (1030, 2, 88, 5, 0.2, 1),
+            (5, 1, 88, 17, 0.05, 0), (8, 6, 0, 32, 0.0, 0), (6, 4, 96, 2, 0.3, 0), (3, 12, 60, 0, 0.05, 1)]
+
+
+@pytest.mark.parametrize("B,Tn,nx,nz,density,gate", MX_CASES)
+def test_lstm_mx_fwd_bwd_match_the_oracle(dev, B, Tn, nx, nz, density, gate):
+    """clv_lstm_mx_fwd / _bwd (csrc/lstm_mx.hip): the recurrent product as split-bf16 exact products on the matrix cores,
+    the frame rows of the input kernel gathered inside the kernel, z_t . Kz as one more k-step; odd and even T, batches
+    that are not multiples of four, frames from empty to full, no frames at all, the dZ tiles of the backward pass."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(B * 7 + Tn + nx + nz)
+    c = _mx_case(rng, B, Tn, nx, nz, density, gate)
+    H = c['H']
+    hs = torch.full((B * Tn, H), 9.0, device=dev)
+    coef = torch.full((B * Tn, 4 * H), 9.0, device=dev)
+    aux = torch.full((B * Tn, 2 * H), 9.0, device=dev)
+    Ud = T(c['U'], dev)
+    Xd, Zd, Kxd, Kzd = T(c['Xb'], dev), T(c['Zb'], dev), T(c['Kx'], dev), T(c['Kz'], dev)
+    ops.lstm_mx_fwd(B, Tn, Xd if nx else None, c['ldx'], nx, Kxd if nx else None, Zd if nz else None, c['ldz'], nz,
+                    Kzd if nz else None, T(c['rb'], dev), Ud, hs, coef, aux, gate_act=gate)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(hs).reshape(B, Tn, H), c['hs_ref'], atol=5e-6)
+    # the coefficients, from the oracle's pre-activations and cell states
+    Zr = c['cache']['Z'].reshape(B, Tn, 4, H)
+    Cs = c['cache']['C']
+    if c['act'] == 'hard_sigmoid':
+        fa, da = O.hard_sigmoid, O.hard_sigmoid_grad
+    else:
+        fa = O.sigmoid
+        da = lambda z: O.sigmoid(z) * (1 - O.sigmoid(z))
+    i, f, g, o = fa(Zr[:, :, 0]), fa(Zr[:, :, 1]), np.tanh(Zr[:, :, 2]), fa(Zr[:, :, 3])
+    cprev = np.concatenate([np.zeros((B, 1, H)), Cs[:, :-1]], 1)
+    tc = np.tanh(Cs)
+    want = np.stack([g * da(Zr[:, :, 0]), cprev * da(Zr[:, :, 1]), i * (1 - g * g), tc * da(Zr[:, :, 3])], 2)
+    got = N(coef).reshape(B, Tn, 4, H)
+    # a hard-sigmoid pre-activation within fp32 noise of a kink may fall on its other side
+    bad = np.abs(got - want) > 2e-5 * (1 + np.abs(want))
+    assert bad.mean() < 2e-4, bad.mean()
+    ga = N(aux).reshape(B, Tn, 2, H)
+    np.testing.assert_allclose(ga[:, :, 0], f, atol=5e-6)
+    np.testing.assert_allclose(ga[:, :, 1], o * (1 - tc * tc), atol=1e-5)
+
+    dHs = rng.standard_normal((B, Tn, H))
+    _, _, _, _, dZ_ref = O.lstm_backward(f32(dHs), c['cache'], np.eye(4 * H), f32(c['U']))
+    dzsum = torch.full((B, 4 * H), 9.0, device=dev)
+    dZ = torch.full((B * Tn, nz + 2), 7.0, device=dev)
+    ops.lstm_mx_bwd(B, Tn, Ud, T(dHs, dev), aux, coef, dzsum, Kz=Kzd if nz else None, nz=nz, dZ=dZ if nz else None,
+                    lddz=nz + 2)
+    torch.cuda.synchronize()
+    dz = N(coef).reshape(B, Tn, 4 * H)
+    bad = np.abs(dz - dZ_ref) > 3e-5 * (1 + np.abs(dZ_ref))
+    assert bad.mean() < 2e-4, bad.mean()
+    np.testing.assert_allclose(N(dzsum), dz.sum(1), atol=2e-4)
+    if nz:
+        ref = f32(dz.reshape(B * Tn, 4 * H)) @ f32(c['Kz'][:nz]).T
+        np.testing.assert_allclose(N(dZ)[:, :nz], ref, atol=3e-5 * max(1.0, np.abs(ref).max()))
+        assert float(dZ[:, nz:].min()) == 7.0 and float(dZ[:, nz:].max()) == 7.0
