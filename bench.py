@@ -403,7 +403,7 @@ def main():
         if w['model'] == 'cl_vrnn':
             # dominant kernel: the persistent LSTM sequence kernels (fwd+bwd, 2 LSTMs each)
             # (one launch = one LSTM pass, or both LSTMs of a pass when the pair kernels run): 4 LSTM passes per step
-            names = sorted(k for k in by if k.startswith(('lstm_pair_', 'lstm_seq_')) and not k.endswith('_pack'))
+            names = sorted(k for k in by if k.startswith(('lstm_pair_', 'lstm_seq_', 'lstm_mx_')) and not k.endswith('_pack'))
             n = sum(by[k][1] for k in names)
             ms_raw = sum(by[k][2] for k in names)
             ms = ms_raw - n * event_pair_us * 1e-3         # minus what the brackets themselves cost (see `event_pair_us`)
@@ -449,7 +449,11 @@ def main():
         if w['model'] == 'cl_vrnn':
             # the recurrent products run on the fp32 VECTOR pipe (v_pk_fma_f32; one batch row per CU leaves the matrix
             # cores' M dimension empty); its peak equals the fp32 MFMA peak, which is what `peak` holds
-            roofline['executes_on'] = "fp32 VALU (v_pk_fma_f32): the fp32 vector peak equals the fp32 MFMA peak (157.3 TFLOP/s)"
+            if getattr(eng, 'use_mx', False):
+                roofline['executes_on'] = ("bf16 MFMA (v_mfma_f32_16x16x32_bf16), exact fp32 products from 3 x 3 bf16 pieces, fp32 "
+                                           "accumulate; priced against the fp32 peak because the ARITHMETIC is fp32")
+            else:
+                roofline['executes_on'] = "fp32 VALU (v_pk_fma_f32): the fp32 vector peak equals the fp32 MFMA peak (157.3 TFLOP/s)"
             if getattr(eng, 'fuse_pair', False) and getattr(eng, 'label_in_pair', False):
                 # honest denominator: the backward launch is not only recurrent products any more
                 roofline['kernel_also_runs'] = ("lstm_pair_bwd ends with the label path's backward of every batch row (no launch of "

@@ -34,7 +34,18 @@ namespace clv {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// measurement builds (tools/build_variant.sh, results are wrong by design), a bit mask: forward 1 = the producer idles
+// after the prologue, 2 = no global stores, 4 = no input gather, 8 = one MFMA per tile, 16 = every step's stores land on
+// the first frame; backward 32 = no per-step loads, 64 = no global stores, 128 = one MFMA, 256 = no dz image writes
+#ifndef MX_ABL
+#define MX_ABL 0
+#endif
+// (tried: s_setprio 2 for the first wave of every SIMD, so that the two waves sharing a SIMD leave their MFMA phases one
+// after the other -- no change in either kernel, profiles/r04_mx_log.txt)
+
 constexpr int MX_R = 4;              // batch rows per workgroup
+constexpr int MX_KP = LH * 16 + 16;  // bytes per row of the K_x image [k][unit][gate]: 356 words = 36 mod 64, so the rows of the 16 (row,
+                                     // piece) lane groups of a gather start on 16 different bank offsets (1408 B = 32 mod 64: two)
 constexpr int MX_HP = 208;           // bytes per (row, piece) line of the h image: 96 bf16 + 16 pad = 52 banks: the 16 lines of
                                      // a ds_read_b128 lane group start at banks 52 n mod 64 = distinct multiples of 4
 constexpr int MX_ZP = 80;            // z image: 32 bf16 + 16 pad = 20 banks (same property)
@@ -72,32 +83,52 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[3]) {
   }
 }
 
+// Per-step global accesses of the backward pass are buffer instructions (lstm_pair.hip): a descriptor per array over the
+// workgroup's rows, the lane's byte offset in one VGPR, the step's row offset in an SGPR; a lane (or a step) without an
+// element gets an offset beyond num_records -- the load returns 0, the store is dropped -- so no access sits under a
+// divergent branch and the compiler's vmcnt waits stay counted.
+typedef __amdgpu_buffer_rsrc_t mx_rsrc_t;
+constexpr unsigned MX_OOB = 0x80000000u;
+__device__ __forceinline__ mx_rsrc_t mx_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float mx_load(mx_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void mx_store(float v, mx_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// forward.  8 waves; wave w < 7 owns the tiles 3w .. 3w+2 (units 12w .. 12w+11), wave 7 owns tile 21 (units 84..87) and
-// is the PRODUCER: frames -> note lists (two steps ahead), z_t -> bf16 pieces in the B-operand image (one step ahead).
+// forward.  8 waves; wave w < 7 owns three tiles = the units 12w .. 12w+11 (tile tl: units 12w + 3 j + tl, j = 0..3, so
+// that after the butterfly the piece lanes p = 0, 1, 2 of a quad own three CONSECUTIVE units: 12-byte pieces per quad
+// in every per-step store instead of isolated floats); wave 7 owns the units 84..87 (one tile) and is the PRODUCER:
+// frames -> note lists (two steps ahead), z_t -> bf16 pieces in the B-operand image (one step ahead).
+// Batch rows beyond B (the last workgroup of a batch that is no multiple of four) are clones of row B-1: same inputs,
+// same values, same addresses -- every access stays unconditional.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int GATE, bool HASZ, int NT, bool PROD>
-__device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int tile0) {
+__device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int ubase) {
   const int lane = threadIdx.x & 63;
   const int ul = lane >> 4, n = lane & 15, r = n >> 2, p = n & 3;
   const int T = a.T;
   const int row0 = blockIdx.x * MX_R;
   char* Kimg = lds;
-  const int zero_off = a.nx * LH * 16;
-  char* hB = lds + (a.nx + 1) * LH * 16;
+  const int zero_off = a.nx * MX_KP;
+  char* hB = lds + (a.nx + 1) * MX_KP;
   char* zB = hB + 2 * 16 * MX_HP;
   MxItem* lists = reinterpret_cast<MxItem*>(zB + 2 * 16 * MX_ZP);
   int* maxcount = reinterpret_cast<int*>(lists + 2 * MX_R * MX_CAP);
 
   // ---- A operands: the three pieces of U (and K_z) for this wave's tiles, resident in registers ---------------------
-  // lane l holds row m = l & 15 = (unit 4 tile + (m >> 2), gate m & 3) and k = 32 s + 8 (l >> 4) + e, e = 0..7
+  // lane l holds row m = l & 15 = (unit ubase + NT (m >> 2) + tl, gate m & 3) and k = 32 s + 8 (l >> 4) + e, e = 0..7
   bf16x8 Ar[NT][3][3];
   bf16x8 Az[NT][3];
   {
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
-      const int col = (m & 3) * LH + 4 * (tile0 + tl) + (m >> 2);
+      const int col = (m & 3) * LH + ubase + NT * (m >> 2) + tl;
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         float v[8];
@@ -123,26 +154,18 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
   }
 
   // ---- per-lane constants --------------------------------------------------------------------------------------------
-  const int row = row0 + r;
-  const size_t rowc = (size_t)min(row, a.B - 1);
-  // accumulator layout (before the butterfly): tile tl, register i = gate i of unit 4 (tile0 + tl) + ul, for (row r, piece p);
-  // the per-row bias enters through the p == 3 lanes (their B column is zero)
-  float rbm[NT][4];
+  const size_t rowc = (size_t)min(row0 + r, a.B - 1);
+  // accumulator layout (before the butterfly): tile tl, register i = gate i of unit ubase + NT ul + tl, for (row r, piece p)
   int ucol[NT];
 #pragma unroll
-  for (int tl = 0; tl < NT; ++tl) {
-    const int u = 4 * (tile0 + tl) + ul;
-    ucol[tl] = u * 16;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float b = a.rowbias ? a.rowbias[rowc * LG + i * LH + u] : 0.f;
-      rbm[tl][i] = p == 3 ? b : 0.f;
-    }
-  }
-  // after the butterfly this lane finishes tile tp of its wave: unit `unit` of row r
+  for (int tl = 0; tl < NT; ++tl) ucol[tl] = (ubase + NT * ul + tl) * 16;
+  // after the butterfly this lane finishes tile tp of its wave: unit `unit` of row r (p == 3: a second copy of p == 2;
+  // one tile: all four lanes hold the same cell)
   const int tp = NT == 3 ? min(p, 2) : 0;
-  const int unit = 4 * (tile0 + tp) + ul;
-  const bool owner = (NT == 3 ? p < 3 : p == 0) && row < a.B;
+  const int unit = ubase + NT * ul + tp;
+  float rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rb[i] = a.rowbias ? a.rowbias[rowc * LG + i * LH + unit] : 0.f;
   const bool even = !(p & 1), lo = !(p & 2);
   float c = 0.f;
   float* hs_p = a.hs + rowc * T * LH + unit;
@@ -160,19 +183,23 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
 #pragma unroll
     for (int rr = 0; rr < MX_R; ++rr) {
       const float* fp = a.X + ((size_t)min(row0 + rr, a.B - 1) * T + tc) * a.ldx;
-      const float v0 = fp[min(lane, a.nx - 1)], v1 = fp[min(lane + 64, a.nx - 1)];
-      f[rr][0] = lane < a.nx ? v0 : 0.f;
-      f[rr][1] = lane + 64 < a.nx ? v1 : 0.f;
+      f[rr][0] = fp[min(lane, a.nx - 1)];            // raw: nothing may touch a requested value before its consumer does
+      f[rr][1] = fp[min(lane + 64, a.nx - 1)];       // (a select here is a wait for the load right behind its issue)
     }
   };
   auto load_z = [&](float (&z)[2], int t) {
     const int tc = min(t, T - 1);
     const float* zp = a.Z + ((size_t)min(row0 + zrow, a.B - 1) * T + tc) * a.ldz;
-    const float v0 = zp[min(zlat, a.nz - 1)], v1 = zp[min(zlat + 1, a.nz - 1)];
-    z[0] = zlat < a.nz ? v0 : 0.f;
-    z[1] = zlat + 1 < a.nz ? v1 : 0.f;
+    z[0] = zp[min(zlat, a.nz - 1)];
+    z[1] = zp[min(zlat + 1, a.nz - 1)];
   };
-  auto compact = [&](const float (&f)[MX_R][2], int buf) {      // frames -> lists[buf], maxcount[buf]
+  auto compact = [&](const float (&fraw)[MX_R][2], int buf) {      // frames -> lists[buf], maxcount[buf]
+    float f[MX_R][2];
+#pragma unroll
+    for (int rr = 0; rr < MX_R; ++rr) {
+      f[rr][0] = lane < a.nx ? fraw[rr][0] : 0.f;
+      f[rr][1] = lane + 64 < a.nx ? fraw[rr][1] : 0.f;
+    }
     MxItem* L = lists + buf * MX_R * MX_CAP;
     L[(lane >> 4) * MX_CAP + (lane & 15)] = MxItem{zero_off, 0.f};       // padding first (LDS operations of a wave are in order)
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -182,8 +209,8 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
     for (int rr = 0; rr < MX_R; ++rr) {
       const unsigned long long m0 = __ballot(f[rr][0] != 0.f), m1 = __ballot(f[rr][1] != 0.f);
       const int n0 = __popcll(m0);
-      if (f[rr][0] != 0.f) L[rr * MX_CAP + __popcll(m0 & lt)] = MxItem{lane * LH * 16, f[rr][0]};
-      if (f[rr][1] != 0.f) L[rr * MX_CAP + n0 + __popcll(m1 & lt)] = MxItem{(lane + 64) * LH * 16, f[rr][1]};
+      if (f[rr][0] != 0.f) L[rr * MX_CAP + __popcll(m0 & lt)] = MxItem{lane * MX_KP, f[rr][0]};
+      if (f[rr][1] != 0.f) L[rr * MX_CAP + n0 + __popcll(m1 & lt)] = MxItem{(lane + 64) * MX_KP, f[rr][1]};
       cnt[rr] = n0 + __popcll(m1);
       mx = max(mx, cnt[rr]);
     }
@@ -197,36 +224,54 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
   };
   auto stage_z = [&](const float (&z)[2], int buf) {           // z pair -> three piece images, 4 bytes each
     __bf16 p0[3], p1[3];
-    split3(z[0], p0);
-    split3(z[1], p1);
+    split3(zlat < a.nz ? z[0] : 0.f, p0);
+    split3(zlat + 1 < a.nz ? z[1] : 0.f, p1);
     char* at = zB + buf * 16 * MX_ZP + (4 * zrow) * MX_ZP + 2 * zlat;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       *reinterpret_cast<unsigned*>(at + q * MX_ZP) = (unsigned)bf16_bits(p0[q]) | ((unsigned)bf16_bits(p1[q]) << 16);
   };
 
-  // next step's input contribution + bias, in the accumulator layout: lane p takes the notes p, p + 4, ... of its row
+  // next step's input contribution in the accumulator layout: lane p takes the notes p, p + 4, ... of its row.  The
+  // reads (two dependent LDS round trips: list entry -> kernel row) are issued AHEAD of the step's MFMAs, the FMAs
+  // behind them.
   float xinit[NT][4];
-  auto gather = [&](int buf) {
-#pragma unroll
-    for (int tl = 0; tl < NT; ++tl)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xinit[tl][i] = rbm[tl][i];
+  struct Rows { float v[MX_FAST / 4]; float4 k[MX_FAST / 4][NT]; };
+  auto gather_items = [&](int buf, MxItem (&items)[MX_FAST / 4]) {
     const MxItem* Lr = lists + (buf * MX_R + r) * MX_CAP;
-    auto visit = [&](const MxItem it) {
+#pragma unroll
+    for (int rd = 0; rd < MX_FAST / 4; ++rd) items[rd] = Lr[p + 4 * rd];
+  };
+  auto gather_rows = [&](const MxItem (&items)[MX_FAST / 4], Rows& g) {
+#pragma unroll
+    for (int rd = 0; rd < MX_FAST / 4; ++rd) {
+      g.v[rd] = items[rd].v;
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl) g.k[rd][tl] = *reinterpret_cast<const float4*>(Kimg + items[rd].koff + ucol[tl]);
+    }
+  };
+  auto gather_finish = [&](int buf, const Rows& g) {
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      xinit[tl][0] = g.v[0] * g.k[0][tl].x; xinit[tl][1] = g.v[0] * g.k[0][tl].y;
+      xinit[tl][2] = g.v[0] * g.k[0][tl].z; xinit[tl][3] = g.v[0] * g.k[0][tl].w;
+#pragma unroll
+      for (int rd = 1; rd < MX_FAST / 4; ++rd) {
+        xinit[tl][0] = fmaf(g.v[rd], g.k[rd][tl].x, xinit[tl][0]); xinit[tl][1] = fmaf(g.v[rd], g.k[rd][tl].y, xinit[tl][1]);
+        xinit[tl][2] = fmaf(g.v[rd], g.k[rd][tl].z, xinit[tl][2]); xinit[tl][3] = fmaf(g.v[rd], g.k[rd][tl].w, xinit[tl][3]);
+      }
+    }
+    const int mc = __builtin_amdgcn_readfirstlane(maxcount[buf]);
+    const MxItem* Lr = lists + (buf * MX_R + r) * MX_CAP;
+    for (int j = MX_FAST; j < mc; j += 4) {           // denser frames (rare for piano-rolls)
+      const MxItem it = Lr[j + p];
 #pragma unroll
       for (int tl = 0; tl < NT; ++tl) {
         const float4 kr = *reinterpret_cast<const float4*>(Kimg + it.koff + ucol[tl]);
-        xinit[tl][0] = fmaf(it.v, kr.x, xinit[tl][0]);
-        xinit[tl][1] = fmaf(it.v, kr.y, xinit[tl][1]);
-        xinit[tl][2] = fmaf(it.v, kr.z, xinit[tl][2]);
-        xinit[tl][3] = fmaf(it.v, kr.w, xinit[tl][3]);
+        xinit[tl][0] = fmaf(it.v, kr.x, xinit[tl][0]); xinit[tl][1] = fmaf(it.v, kr.y, xinit[tl][1]);
+        xinit[tl][2] = fmaf(it.v, kr.z, xinit[tl][2]); xinit[tl][3] = fmaf(it.v, kr.w, xinit[tl][3]);
       }
-    };
-#pragma unroll
-    for (int rd = 0; rd < MX_FAST / 4; ++rd) visit(Lr[p + 4 * rd]);
-    const int mc = __builtin_amdgcn_readfirstlane(maxcount[buf]);
-    for (int j = MX_FAST; j < mc; j += 4) visit(Lr[j + p]);
+    }
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------------
@@ -250,18 +295,33 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
     }
   }
   __syncthreads();
-  gather(0);
+  {
+    Rows g;
+    MxItem items[MX_FAST / 4];
+    gather_items(0, items);
+    gather_rows(items, g);
+    gather_finish(0, g);
+  }
+  // every load of the prologue has landed before the loop is entered (the wait-count bookkeeping merges the loop-entry
+  // state with the back edge's: see lstm_pair.hip)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
   auto step = [&](int t, auto PAR) {
     constexpr int cur = decltype(PAR)::value;
-    // B operands: pieces of h_{t-1} (and z_t)
+    // LDS reads in the order they are needed: the list entries of the NEXT step's inputs (their kernel rows are a second,
+    // dependent round trip), this step's B operands = pieces of h_{t-1} (and z_t), then the kernel rows, which come back
+    // under the MFMAs
+    Rows g;
+    MxItem items[MX_FAST / 4];
+    if (!(MX_ABL & 4)) gather_items(cur ^ 1, items);
     const char* hb = hB + cur * 16 * MX_HP + n * MX_HP + (lane >> 4) * 16;
     bf16x8 bh[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) bh[s] = *reinterpret_cast<const bf16x8*>(hb + 64 * s);
     bf16x8 bz;
     if (HASZ) bz = *reinterpret_cast<const bf16x8*>(zB + cur * 16 * MX_ZP + n * MX_ZP + (lane >> 4) * 16);
+    if (!(MX_ABL & 4)) gather_rows(items, g);
     f32x4v acc[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) acc[tl] = f32x4v{xinit[tl][0], xinit[tl][1], xinit[tl][2], xinit[tl][3]};
@@ -270,7 +330,8 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ar[tl][s][q], bh[s], acc[tl], 0, 0, 0);
+        for (int tl = 0; tl < NT; ++tl)
+          if (!(MX_ABL & 8) || (s == 0 && q == 0)) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ar[tl][s][q], bh[s], acc[tl], 0, 0, 0);
     if (HASZ) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
@@ -278,17 +339,11 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
         for (int tl = 0; tl < NT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Az[tl][q], bz, acc[tl], 0, 0, 0);
     }
     // work that does not depend on the recurrence: the producer's lists / z image, next step's input contribution
-    if (PROD) {
-      if (a.nx > 0) {
-        compact(fr[cur], cur);                 // frame t + 2 -> the list buffer step t - 1 finished with
-        load_frames(fr[cur], t + 4);
-      }
-      if (HASZ) {
-        stage_z(zr[cur], cur ^ 1);             // z_{t+1}
-        load_z(zr[cur], t + 3);
-      }
+    if (PROD && !(MX_ABL & 1)) {
+      if (a.nx > 0) compact(fr[cur], cur);     // frame t + 2 -> the list buffer step t - 1 finished with
+      if (HASZ) stage_z(zr[cur], cur ^ 1);     // z_{t+1}
     }
-    gather(cur ^ 1);
+    if (!(MX_ABL & 4)) gather_finish(cur ^ 1, g);
     // butterfly over the piece lanes: sums the pieces (and the note shares) and deals the tiles to the lanes
     float z[4];
 #pragma unroll
@@ -299,12 +354,12 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
         const float wA = keepA + dpp_mov<0xB1>(sendA);
         const float wB = a2 + dpp_mov<0xB1>(a2);
         const float keep = lo ? wA : wB, send = lo ? wB : wA;
-        z[i] = keep + dpp_mov<0x4E>(send);
+        z[i] = keep + dpp_mov<0x4E>(send) + rb[i];
       } else {
         float x = acc[0][i];
         x = dpp_add<0xB1>(x);
         x = dpp_add<0x4E>(x);
-        z[i] = x;
+        z[i] = x + rb[i];
       }
     }
     const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);
@@ -313,8 +368,8 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
     c = fg * c + ig * gg;
     const float tc = fast_tanh(c);
     const float h = og * tc;
-    if (owner) {
-      const size_t o = (size_t)t;
+    if (!(MX_ABL & 2)) {
+      const size_t o = (MX_ABL & 16) ? 0 : (size_t)t;
       coef_p[o * LG] = gg * gate_grad<GATE>(z[0], ig);
       coef_p[o * LG + LH] = kf;
       coef_p[o * LG + 2 * LH] = ig * (1.f - gg * gg);
@@ -328,14 +383,19 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int t
       split3(h, hp);
       char* at = hB + (cur ^ 1) * 16 * MX_HP + hw_off;
       if (NT == 3) {
-        if (p < 3) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned short*>(at + q * MX_HP) = bf16_bits(hp[q]);
-        }
-      } else {             // four lanes hold the same h: lane p writes piece p
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned short*>(at + q * MX_HP) = bf16_bits(hp[q]);
+      } else {             // four lanes hold the same h: lane p writes piece min(p, 2)
         const __bf16 mine = p == 0 ? hp[0] : (p == 1 ? hp[1] : hp[2]);
-        if (p < 3) *reinterpret_cast<unsigned short*>(at + p * MX_HP) = bf16_bits(mine);
+        *reinterpret_cast<unsigned short*>(at + min(p, 2) * MX_HP) = bf16_bits(mine);
       }
+    }
+    // the producer's requests for two steps ahead, BEHIND the last use of the register set they land in (issued ahead of
+    // it they need fresh registers, and the copies back at the loop's end wait for the loads just issued: every step
+    // then costs a trip to HBM -- lstm_pair.hip)
+    if (PROD && !(MX_ABL & 1)) {
+      if (a.nx > 0) load_frames(fr[cur], t + 4);
+      if (HASZ) load_z(zr[cur], t + 3);
     }
     step_barrier();
   };
@@ -354,21 +414,23 @@ template <int GATE, bool HASZ>
 __global__ __launch_bounds__(512) void lstm_mx_fwd_kernel(MxFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char mx_lds[];
   const int tid = threadIdx.x;
-  // K_x image [k][unit][gate] (one ds_read_b128 = the four gates of a unit) + a zero row for the lists' padding
+  // K_x image [k][unit][gate] (one ds_read_b128 = the four gates of a unit), row pitch MX_KP, + a zero row for the lists'
+  // padding
   {
-    const int nv = a.nx * LG;
     float* Kimg = reinterpret_cast<float*>(mx_lds);
+    const int nv = a.nx * LG;
     for (int i = tid; i < nv; i += 512) {
       const int k = i / LG, rem = i - k * LG, g = rem / LH, u = rem - g * LH;
-      Kimg[(k * LH + u) * 4 + g] = a.Kx[i];
+      Kimg[k * (MX_KP / 4) + u * 4 + g] = a.Kx[i];
     }
-    const int tail = (2 * 16 * MX_HP + 2 * 16 * MX_ZP) / 4 + LH * 4;     // zero row, h image, z image
-    for (int i = tid; i < tail; i += 512) Kimg[nv + i] = 0.f;
+    float* rest = Kimg + a.nx * (MX_KP / 4);
+    const int tail = (MX_KP + 2 * 16 * MX_HP + 2 * 16 * MX_ZP) / 4;      // zero row, h image, z image
+    for (int i = tid; i < tail; i += 512) rest[i] = 0.f;
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave < 7) mx_fwd_body<GATE, HASZ, 3, false>(a, mx_lds, 3 * wave);
-  else mx_fwd_body<GATE, HASZ, 1, true>(a, mx_lds, 21);
+  if (wave < 7) mx_fwd_body<GATE, HASZ, 3, false>(a, mx_lds, 12 * wave);
+  else mx_fwd_body<GATE, HASZ, 1, true>(a, mx_lds, 84);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -381,131 +443,182 @@ struct MxBwdArgs {
   const float* Kz; int nz; float* dZ; int lddz;
 };
 
-template <int ZT>
-__global__ __launch_bounds__((6 + ZT) * 64) void lstm_mx_bwd_kernel(MxBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char dzB[2 * 16 * MX_DP];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// A operand of a backward tile: 16 rows of U (or K_z).  The reduction index is k = 4 u + gate (NOT the gate-major column
+// order of dz in memory): a lane's four dz values of a step are then four consecutive bf16 of an image line, one 8-byte
+// LDS store per piece instead of four 2-byte ones.  k = 32 s + 8 (l >> 4) + e  <->  column (k & 3) * 88 + (k >> 2).
+__device__ __forceinline__ void mx_bwd_weights(const float* W, int first, int limit, bf16x8 (&Ar)[11][3]) {
+  const int lane = threadIdx.x & 63, m = lane & 15, kg = lane >> 4;
+  const int idx = first + m;
+  const bool ok = idx < limit;
+  const float* src = W + (size_t)min(idx, limit - 1) * LG;
+#pragma unroll
+  for (int s = 0; s < 11; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * s + 8 * kg + e;
+      const float w = src[(k & 3) * LH + (k >> 2)];
+      v[e] = ok ? w : 0.f;
+    }
+    split8(v, Ar[s]);
+  }
+}
+// four floats -> three piece images of four bf16 each (v_cvt_pk_bf16_f32 rounds and packs a pair)
+__device__ __forceinline__ unsigned mx_pack2(float lo, float hi) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  const bf16x2v v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void mx_split4(const float (&x)[4], uint2 (&piece)[3]) {
+  float a0 = x[0], a1 = x[1], a2 = x[2], a3 = x[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const unsigned lo = mx_pack2(a0, a1), hi = mx_pack2(a2, a3);
+    piece[q] = make_uint2(lo, hi);
+    if (q < 2) {
+      a0 -= __builtin_bit_cast(float, lo << 16); a1 -= __builtin_bit_cast(float, lo & 0xffff0000u);
+      a2 -= __builtin_bit_cast(float, hi << 16); a3 -= __builtin_bit_cast(float, hi & 0xffff0000u);
+    }
+  }
+}
+
+// dz_{t+1} (image `buf`) . the tile's rows; the butterfly leaves lane (ul, r, p) with row 4 ul + p of the tile
+__device__ __forceinline__ float mx_bwd_matvec(const char* dzB, int buf, const bf16x8 (&Ar)[11][3]) {
+  const int lane = threadIdx.x & 63, n = lane & 15, p = n & 3;
+  const bool even = !(p & 1), lo = !(p & 2);
+  const char* bp = dzB + buf * 16 * MX_DP + n * MX_DP + (lane >> 4) * 16;
+  bf16x8 b[11];
+#pragma unroll
+  for (int s = 0; s < 11; ++s) b[s] = *reinterpret_cast<const bf16x8*>(bp + 64 * s);
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 11; ++s)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (!(MX_ABL & 128) || (s == 0 && q == 0)) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ar[s][q], b[s], acc, 0, 0, 0);
+  const float kA = even ? acc[0] : acc[1], sA = even ? acc[1] : acc[0];
+  const float kB = even ? acc[2] : acc[3], sB = even ? acc[3] : acc[2];
+  const float wA = kA + dpp_mov<0xB1>(sA);
+  const float wB = kB + dpp_mov<0xB1>(sB);
+  const float keep = lo ? wA : wB, send = lo ? wB : wA;
+  return keep + dpp_mov<0x4E>(send);
+}
+
+// a unit tile: the BPTT of 16 units x 4 rows
+__device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int wave) {
+  const int lane = threadIdx.x & 63;
   const int ul = lane >> 4, n = lane & 15, r = n >> 2, p = n & 3;
   const int T = a.T;
   const int row0 = blockIdx.x * MX_R;
-  const bool is_lat = ZT > 0 && wave >= 6;
-  for (int i = tid; i < 2 * 16 * MX_DP / 4; i += (6 + ZT) * 64) reinterpret_cast<float*>(dzB)[i] = 0.f;
-
-  // A operand: rows of U (or K_z), k = gate column c = 32 s + 8 (l >> 4) + e
+  const int nrows = min(MX_R, a.B - row0);
   bf16x8 Ar[11][3];
-  {
-    const int m = lane & 15, kg = lane >> 4;
-    const int idx = is_lat ? 16 * (wave - 6) + m : 16 * wave + m;
-    const bool ok = is_lat ? idx < a.nz : idx < LH;
-    const float* src = is_lat ? a.Kz + (size_t)min(idx, max(a.nz, 1) - 1) * LG : a.U + (size_t)min(idx, LH - 1) * LG;
-#pragma unroll
-    for (int s = 0; s < 11; ++s) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float w = src[32 * s + 8 * kg + e];
-        v[e] = ok ? w : 0.f;
-      }
-      split8(v, Ar[s]);
-    }
-  }
-  // after the butterfly: lane (ul, r, p) owns row 4 ul + p of the tile, for batch row r
-  const int idx = (is_lat ? 16 * (wave - 6) : 16 * wave) + 4 * ul + p;
-  const int row = row0 + r;
-  const size_t rowc = (size_t)min(row, a.B - 1);
-  const bool valid = (is_lat ? idx < a.nz : idx < LH) && row < a.B;
+  mx_bwd_weights(a.U, 16 * wave, LH, Ar);
+  const int idx = 16 * wave + 4 * ul + p;
+  const bool valid = idx < LH;
   const int u = min(idx, LH - 1);
-  const bool even = !(p & 1), lo = !(p & 2);
-  const float* coef_r = a.coef + rowc * T * LG + u;
-  const float* aux_r = a.aux + rowc * T * 2 * LH + u;
-  const float* dh_r = a.dhs + rowc * T * LH + u;
-  float* coef_w = a.coef + rowc * T * LG + u;
-  float* dz_w = a.dZ + (is_lat ? rowc * T * a.lddz + min(idx, max(a.nz, 1) - 1) : 0);
-  const int dzl_off = (4 * r) * MX_DP + 2 * u;          // dz pieces: line 4 r + q, k = gate * 88 + u
+  const unsigned rloc = (unsigned)min(r, nrows - 1);              // rows beyond the batch: clones of its last row
+  const mx_rsrc_t r_c = mx_rsrc(a.coef + (size_t)row0 * T * LG, (size_t)nrows * T * LG * 4);
+  const mx_rsrc_t r_a = mx_rsrc(a.aux + (size_t)row0 * T * 2 * LH, (size_t)nrows * T * 2 * LH * 4);
+  const mx_rsrc_t r_d = mx_rsrc(a.dhs + (size_t)row0 * T * LH, (size_t)nrows * T * LH * 4);
+  const unsigned v_c = valid ? (rloc * T * LG + u) * 4u : MX_OOB;
+  const unsigned v_a = valid ? (rloc * T * 2 * LH + u) * 4u : MX_OOB;
+  const unsigned v_d = valid ? (rloc * T * LH + u) * 4u : MX_OOB;
+  // dz pieces: line 4 r + q, k = 4 u + gate: 8 bytes; a lane without a unit writes into the line's padding
+  const int dzl_off = (4 * r) * MX_DP + (valid ? 8 * u : 2 * LG);
 
+  // Two register sets, the loop body is two steps: the coefficients of step t are requested at the end of step t + 2,
+  // behind the last use of the set they land in (lstm_pair.hip).  An odd T runs one step more: step t = -1 lies beyond
+  // num_records -- zero coefficients, dz = 0, stores dropped.
   struct Coef { float ki, kf, kg, ko, kcarry, kc, dh; };
-  Coef S[2];
   auto load_set = [&](Coef& k, int t) {
-    const size_t tc = (size_t)max(t, 0);
-    k.ki = coef_r[tc * LG]; k.kf = coef_r[tc * LG + LH]; k.kg = coef_r[tc * LG + 2 * LH]; k.ko = coef_r[tc * LG + 3 * LH];
-    k.kcarry = aux_r[tc * 2 * LH]; k.kc = aux_r[tc * 2 * LH + LH];
-    k.dh = dh_r[tc * LH];
+    const unsigned tc = (unsigned)t;
+    k.ki = mx_load(r_c, v_c, tc * (LG * 4)); k.kf = mx_load(r_c, v_c + LH * 4, tc * (LG * 4));
+    k.kg = mx_load(r_c, v_c + 2 * LH * 4, tc * (LG * 4)); k.ko = mx_load(r_c, v_c + 3 * LH * 4, tc * (LG * 4));
+    k.kcarry = mx_load(r_a, v_a, tc * (2 * LH * 4)); k.kc = mx_load(r_a, v_a + LH * 4, tc * (2 * LH * 4));
+    k.dh = mx_load(r_d, v_d, tc * (LH * 4));
   };
-  S[0] = S[1] = Coef{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (!is_lat && T > 0) {
-    if (T & 1) { load_set(S[0], T - 1); load_set(S[1], T - 2); }        // compile-time indices: S stays in registers
-    else { load_set(S[1], T - 1); load_set(S[0], T - 2); }
-  }
+  Coef SA, SB;
+  load_set(SA, T - 1);
+  load_set(SB, T - 2);
   float dc = 0.f;
   float zs[4] = {0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // the prologue's loads have landed (see the forward kernel)
   __syncthreads();
 
-  // dz_{t+1} (image `buf`) . this tile's rows -> the butterfly's result for this lane
-  auto matvec = [&](int buf) {
-    const char* bp = dzB + buf * 16 * MX_DP + n * MX_DP + (lane >> 4) * 16;
-    bf16x8 b[11];
+  auto step = [&](int i, auto PAR, Coef& k) {
+    constexpr int par = decltype(PAR)::value;        // i & 1: this step writes image `par`, reads the other one
+    const int t = T - 1 - i;
+    const float x = mx_bwd_matvec(dzB, par ^ 1, Ar);
+    const float dh = k.dh + x;
+    dc = fmaf(dh, k.kc, dc);
+    float dz[4];
+    dz[0] = dc * k.ki; dz[1] = dc * k.kf; dz[2] = dc * k.kg; dz[3] = dh * k.ko;
+    dc *= k.kcarry;
+    char* at = dzB + par * 16 * MX_DP + dzl_off;
 #pragma unroll
-    for (int s = 0; s < 11; ++s) b[s] = *reinterpret_cast<const bf16x8*>(bp + 64 * s);
-    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 11; ++s)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ar[s][q], b[s], acc, 0, 0, 0);
-    const float kA = even ? acc[0] : acc[1], sA = even ? acc[1] : acc[0];
-    const float kB = even ? acc[2] : acc[3], sB = even ? acc[3] : acc[2];
-    const float wA = kA + dpp_mov<0xB1>(sA);
-    const float wB = kB + dpp_mov<0xB1>(sB);
-    const float keep = lo ? wA : wB, send = lo ? wB : wA;
-    return keep + dpp_mov<0x4E>(send);
-  };
-
-  auto step = [&](int t, auto PAR) {
-    constexpr int par = decltype(PAR)::value;        // t & 1: this step writes image `par`, reads the other one
-    const float x = matvec(par ^ 1);
-    if (is_lat) {
-      if (valid && t + 1 < T) dz_w[(size_t)(t + 1) * a.lddz] = x;         // dZ_{t+1}
-    } else {
-      const Coef k = S[par];
-      load_set(S[par], t - 2);
-      const float dh = k.dh + x;
-      dc = fmaf(dh, k.kc, dc);
-      float dz[4];
-      dz[0] = dc * k.ki; dz[1] = dc * k.kf; dz[2] = dc * k.kg; dz[3] = dh * k.ko;
-      dc *= k.kcarry;
-      if (valid) {
-        char* at = dzB + par * 16 * MX_DP + dzl_off;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          zs[g] += dz[g];
-          coef_w[(size_t)t * LG + g * LH] = dz[g];
-          __bf16 pc[3];
-          split3(dz[g], pc);
-#pragma unroll
-          for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned short*>(at + q * MX_DP + 2 * g * LH) = bf16_bits(pc[q]);
-        }
-      }
+    for (int g = 0; g < 4; ++g) {
+      zs[g] += dz[g];
+      if (!(MX_ABL & 64)) mx_store(dz[g], r_c, v_c + g * LH * 4, (unsigned)t * (LG * 4));
     }
+    uint2 pc[3];
+    mx_split4(dz, pc);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (!(MX_ABL & 256)) *reinterpret_cast<uint2*>(at + q * MX_DP) = pc[q];
+    if (!(MX_ABL & 32)) load_set(k, t - 2);
     step_barrier();
   };
-
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  int t = T - 1;
-  if (T & 1) { step(t, P0{}); --t; }          // T odd: step T-1 has even parity
-  for (; t >= 1; t -= 2) {
-    step(t, P1{});
-    step(t - 1, P0{});
+  for (int i = 0; i < T; i += 2) {
+    step(i, P0{}, SA);
+    step(i + 1, P1{}, SB);
   }
-  if (is_lat) {
-    if (T > 0) {
-      const float x = matvec(0);                 // dz_0 is in image 0
-      if (valid) dz_w[0] = x;
-    }
-  } else if (valid) {
+  if (valid) {
+    const size_t rowc = (size_t)row0 + rloc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) a.dzsum[rowc * LG + g * LH + u] = zs[g];
   }
+}
+
+// a latent tile: dZ_t = dz_t . K_z^T for 16 latents x 4 rows
+__device__ __forceinline__ void mx_bwd_latents(const MxBwdArgs& a, char* dzB, int tile) {
+  const int lane = threadIdx.x & 63;
+  const int ul = lane >> 4, n = lane & 15, r = n >> 2, p = n & 3;
+  const int T = a.T;
+  const int row0 = blockIdx.x * MX_R;
+  const int nrows = min(MX_R, a.B - row0);
+  bf16x8 Ar[11][3];
+  mx_bwd_weights(a.Kz, 16 * tile, a.nz, Ar);
+  const int lat = 16 * tile + 4 * ul + p;
+  const unsigned rloc = (unsigned)min(r, nrows - 1);
+  const mx_rsrc_t r_z = mx_rsrc(a.dZ + (size_t)row0 * T * a.lddz, (size_t)nrows * T * a.lddz * 4);
+  const unsigned v_z = lat < a.nz ? (rloc * T * a.lddz + lat) * 4u : MX_OOB;
+  __syncthreads();
+  auto step = [&](int i, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    const int t = T - 1 - i;
+    const float x = mx_bwd_matvec(dzB, par ^ 1, Ar);                   // dZ_{t+1}; nothing to store at t == T-1
+    mx_store(x, r_z, v_z, t + 1 < T ? (unsigned)(t + 1) * a.lddz * 4 : MX_OOB);
+    step_barrier();
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  for (int i = 0; i < T; i += 2) {       // odd T: the padded step t = -1 already writes dZ_0
+    step(i, P0{});
+    step(i + 1, P1{});
+  }
+  mx_store(mx_bwd_matvec(dzB, (T - 1) & 1, Ar), r_z, v_z, 0);        // dz_0 is in the image of step i = T - 1
+}
+
+template <int ZT>
+__global__ __launch_bounds__((6 + ZT) * 64) void lstm_mx_bwd_kernel(MxBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char dzB[2 * 16 * MX_DP];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 2 * 16 * MX_DP / 4; i += (6 + ZT) * 64) reinterpret_cast<float*>(dzB)[i] = 0.f;
+  if (ZT > 0 && wave >= 6) mx_bwd_latents(a, dzB, wave - 6);
+  else mx_bwd_units(a, dzB, wave);
 }
 
 static bool mx_auto(int B) {
@@ -531,7 +644,7 @@ extern "C" int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_mx_fwd", s);
   MxFwdArgs a{B, T, X, ldx, nx, Kx, Z, ldz, nz, Kz, rowbias, U, hs, coef, aux};
-  const size_t lds = (size_t)(nx + 1) * LH * 16 + 2 * 16 * MX_HP + 2 * 16 * MX_ZP + 2 * MX_R * MX_CAP * sizeof(MxItem) + 16;
+  const size_t lds = (size_t)(nx + 1) * MX_KP + 2 * 16 * MX_HP + 2 * 16 * MX_ZP + 2 * MX_R * MX_CAP * sizeof(MxItem) + 16;
   const dim3 grid((B + MX_R - 1) / MX_R), block(512);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
 #define MX_LAUNCH(G, Zf)                                                                      \

@@ -588,6 +588,11 @@ class VrnnEngine(_EngineBase):
         # outside the pair kernels: the latent head's forward / backward as one MFMA launch each (csrc/latent_head.hip)
         self.fuse_latent = bool(cfg.get('fuse_latent', os.environ.get('CLV_FUSE_LATENT', '1') != '0')) \
             and ops.latent_head_supported(H, L)
+        # large batches (>= 512 rows per GPU: BASELINE configuration 5) outside the pair kernels: both LSTMs' training passes
+        # on the bf16 matrix cores with the frame rows of their input kernels gathered inside the kernel (csrc/lstm_mx.hip):
+        # no projection launch, no [B*T,4H] projection buffer; gates_* / cs_* then hold the coefficient format
+        self.use_mx = bool(cfg.get('lstm_mx', os.environ.get('CLV_USE_MX', '1') != '0')) and not self.fuse_pair \
+            and self.sparse_inputs and not self.fuse_xproj and ops.lstm_mx_supported(B, D, L)
         self.fuse_notes = bool(cfg.get('fuse_notes', os.environ.get('CLV_FUSE_NOTES', '0') == '1')) and self.fuse_pair \
             and self.sparse_inputs and D == ops.NOTE_NONE
         self.notes_valid = False
@@ -604,8 +609,9 @@ class VrnnEngine(_EngineBase):
         self.gates_dec = _f(d, BT, 4 * H)
         # cs_*: the cell states of the separate sequence kernels; the pair kernels keep (kcarry, kc) per unit and step
         # there instead (two floats: see csrc/lstm_pair.hip), so the buffers hold 2H floats per frame
-        self.hs_enc, self.cs_enc = _f(d, BT, H), _f(d, BT, 2 * H if self.fuse_pair else H)
-        self.hs_dec, self.cs_dec = _f(d, BT, H), _f(d, BT, 2 * H if self.fuse_pair else H)
+        aux2 = self.fuse_pair or self.use_mx
+        self.hs_enc, self.cs_enc = _f(d, BT, H), _f(d, BT, 2 * H if aux2 else H)
+        self.hs_dec, self.cs_dec = _f(d, BT, H), _f(d, BT, 2 * H if aux2 else H)
         self.zargs = _f(d, BT, 2 * L)
         # decoder input [Xp | Z] as ONE matrix (row stride padded to a multiple of 4 floats): the history
         # frames are staged into its first D columns, gauss_fwd writes Z next to them, so the decoder's
@@ -657,6 +663,8 @@ class VrnnEngine(_EngineBase):
             self.XZ.view(B, T, self.xz_ld)[:, :, :D].copy_(Xp.view(B, T, D))     # staging copy only
         if self.fuse_pair:
             return self._forward_pair(X, eps_W, eps_Z, w_true, nll, target)
+        if self.use_mx:
+            return self._forward_mx(X, eps_W, eps_Z, w_true, nll, target)
         fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
         fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)
         if not fuse_enc:
@@ -700,6 +708,26 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
                              self.cs_dec, self.gates_dec, gate_act=self.gate_act)
         # output head (:229-234), with the NLL fused into its epilogue when the caller wants the loss
+        self._output_head(target, nll)
+
+    def _forward_mx(self, X, eps_W, eps_Z, w_true, nll, target):
+        """Forward for large batches: label path, encoder LSTM, latent head, decoder LSTM, output head; the LSTMs' input
+        products (frame rows gathered from LDS, z_t . K_z as one more MFMA k-step) run inside csrc/lstm_mx.hip."""
+        cfg, P, B = self.cfg, self.P, self.B
+        D, H, L, T = cfg['D'], cfg['H'], cfg['L'], cfg['T']
+        BT, off = B * T, self.off
+        self._label_forward(X, eps_W, w_true)
+        ops.lstm_mx_fwd(B, T, X, D, D, P.p('encoder_h/kernel'), None, 0, 0, None, self.wk_enc,
+                        P.p('encoder_h/recurrent_kernel'), self.hs_enc, self.gates_enc, self.cs_enc, gate_act=self.gate_act)
+        if self.fuse_latent:
+            ops.latent_head_fwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z, self.zargs, self.Z,
+                                self.xz_ld, self.rowkl)
+        else:
+            ops.gemm(self.hs_enc, P.p('Zargs/kernel'), self.zargs, BT, 2 * L, H, bias=P.p('Zargs/bias'), ws=self.ws)
+            ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
+        ops.lstm_mx_fwd(B, T, self.XZ if off else None, self.xz_ld, off, P.p('decoder_h/kernel') if off else None,
+                        self.Z, self.xz_ld, L, P.rows(P.params, 'decoder_h/kernel', off), self.wk_dec,
+                        P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.gates_dec, self.cs_dec, gate_act=self.gate_act)
         self._output_head(target, nll)
 
     def _label_forward(self, X, eps_W, w_true, pack=None):
@@ -963,7 +991,10 @@ class VrnnEngine(_EngineBase):
         H, L, T = cfg['H'], cfg['L'], cfg['T']
         BT, G4, off = B * T, 4 * H, self.off
         g = ops.gemm
-        if L <= 40 and os.environ.get('CLV_BWD_Z', '1') != '0':      # dZ = dz_dec . Kz^T by two more waves of the decoder's backward kernel
+        if self.use_mx:      # the backward pass of csrc/lstm_mx.hip, dZ = dz_dec . Kz^T as its latent tiles
+            ops.lstm_mx_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec, self.dzsum_dec,
+                            Kz=P.rows(P.params, 'decoder_h/kernel', off), nz=L, dZ=self.dZ, lddz=L)
+        elif L <= 40 and os.environ.get('CLV_BWD_Z', '1') != '0':      # dZ = dz_dec . Kz^T by two more waves of the decoder's backward kernel
             ops.lstm_seq_bwd_z(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
                                self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off), L, self.dZ, L,
                                gate_act=self.gate_act)
@@ -978,8 +1009,11 @@ class VrnnEngine(_EngineBase):
         else:
             ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight / BT, self.dzargs)
             g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
-        ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
-                         self.dzsum_enc, gate_act=self.gate_act)
+        if self.use_mx:
+            ops.lstm_mx_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc, self.dzsum_enc)
+        else:
+            ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
+                             self.dzsum_enc, gate_act=self.gate_act)
 
     def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True, target=None, noise=None):
         """target: the frames the decoder output is scored against (default X; the next frames under --predict_next).
