@@ -622,8 +622,8 @@ __global__ __launch_bounds__((6 + ZT) * 64) void lstm_mx_bwd_kernel(MxBwdArgs a)
 }
 
 static bool mx_auto(int B) {
-  static const int mode = env_int("CLV_LSTM_MX", -1);       // 0: never, 1: any batch, default: from 512 rows on
-  return mode == 1 || (mode < 0 && B >= 512);
+  static const int mode = env_int("CLV_LSTM_MX", -1);       // 0: never, 1: any batch, default: from 768 rows on (three rows per CU; at 512 rows half the CUs would idle)
+  return mode == 1 || (mode < 0 && B >= 768);
 }
 
 }  // namespace clv

@@ -588,7 +588,7 @@ class VrnnEngine(_EngineBase):
         # outside the pair kernels: the latent head's forward / backward as one MFMA launch each (csrc/latent_head.hip)
         self.fuse_latent = bool(cfg.get('fuse_latent', os.environ.get('CLV_FUSE_LATENT', '1') != '0')) \
             and ops.latent_head_supported(H, L)
-        # large batches (>= 512 rows per GPU: BASELINE configuration 5) outside the pair kernels: both LSTMs' training passes
+        # large batches (>= 768 rows per GPU: BASELINE configuration 5) outside the pair kernels: both LSTMs' training passes
         # on the bf16 matrix cores with the frame rows of their input kernels gathered inside the kernel (csrc/lstm_mx.hip):
         # no projection launch, no [B*T,4H] projection buffer; gates_* / cs_* then hold the coefficient format
         self.use_mx = bool(cfg.get('lstm_mx', os.environ.get('CLV_USE_MX', '1') != '0')) and not self.fuse_pair \

@@ -246,7 +246,7 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  * clv_lstm_mx_bwd: BPTT from dhs [B*T,H]: dc += dh kc; dz = (dc ki, dc kf, dc kg, dh ko); dc *= kcarry, with
  * dh = dhs_t + dz_{t+1} . U^T on the same matrix cores; coef is overwritten in place with dz [B*T,4H], dzsum [B,4H] =
  * sum_t dz.  nz > 0: dZ_t = dz_t . Kz^T as well (dZ: B*T rows of stride lddz), by one or two more waves.
- * clv_lstm_mx_supported: H == 88, nx <= 96, nz <= 32 and a batch the engine hands to these kernels (>= 512 rows;
+ * clv_lstm_mx_supported: H == 88, nx <= 96, nz <= 32 and a batch the engine hands to these kernels (>= 768 rows;
  * CLV_LSTM_MX=1 / 0 forces / forbids them for measurements and tests). */
 int clv_lstm_mx_supported(int B, int H, int nx, int nz);
 int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,

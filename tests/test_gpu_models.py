@@ -264,7 +264,7 @@ def test_cl_vrnn_full_size_step_matches_oracle(dev, B, Tn, L, exact_frames):
     ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
     eng = VrnnEngine(cfg, B, dev)
     assert eng.fuse_pair == (L <= 8)
-    assert eng.use_mx == (L > 8 and B >= 512)          # config 5: both LSTMs on the bf16 matrix cores (csrc/lstm_mx.hip)
+    assert eng.use_mx == (L > 8 and B >= 768)          # config 5: both LSTMs on the bf16 matrix cores (csrc/lstm_mx.hip)
     assert eng.frames_exact_bf16 == exact_frames and eng.bf16_wgrad
     assert set(np.unique(X)) <= {0.0, 1.0}                  # byte-valued frames: exact in one bf16 piece
     eng.P.set_weights(p)
