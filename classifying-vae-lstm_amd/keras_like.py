@@ -272,6 +272,10 @@ class Model:
         if world > 1:           # replicas start from rank 0's weights, optimizer state and noise key
             for t in eng.P.state_tensors():     # incl. the weight-norm column state and `iterations` (resumed fits)
                 dist.broadcast(t, src=0)
+            # the host-side flag "vn2 describes the parameters" is per rank and did not travel: clear it everywhere, the
+            # first step then takes the five-launch optimizer on EVERY rank and re-validates it (ranks must not pick
+            # different Adam-WN forms, nor consume rank 0's column norms on the strength of their own flag)
+            eng.P.norms_valid = False
             seed_t = torch.tensor([self.seed], dtype=torch.int64, device=dev)
             dist.broadcast(seed_t, src=0)
             if int(seed_t.item()) != self.seed:

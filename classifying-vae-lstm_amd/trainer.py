@@ -294,6 +294,9 @@ class TrainStep:
                 self._graph_fast = bool(getattr(self.eng.P, 'norms_valid', False))
                 with ops.Graph() as g1:
                     self._main()
+                # whether the captured backward pass writes the hW kernel's sum g.V (only its sparse form does): the
+                # replayed steps restore the flag from this, never assume it
+                self._main_leaves_gdot = bool(getattr(self.eng, 'gdot_fresh', False))
                 with ops.Graph() as g2:
                     self._tail()
                 if self.split_update and os.environ.get('CLV_DP_EAGER_UPDATE', '1') != '0':
@@ -331,7 +334,7 @@ class TrainStep:
                     g3.launch()
                 else:
                     if hasattr(self.eng, 'gdot_fresh'):
-                        self.eng.gdot_fresh = True   # (the replayed backward pass has left it)
+                        self.eng.gdot_fresh = self._main_leaves_gdot      # what the replayed backward pass has left
                     self._update_tail()
                 self.ar.wait()
                 if self._graphs[3] is not None:

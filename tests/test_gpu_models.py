@@ -420,6 +420,38 @@ def test_cl_vrnn_dp_graph_schedule_matches_single_graph(dev, monkeypatch):
         np.testing.assert_array_equal(out[3][k], out[2][k])
 
 
+def test_cl_vrnn_dp_graph_schedule_with_dense_inputs(dev, monkeypatch):
+    """The replayed data-parallel schedule with the DENSE hW path (sparse_inputs=False): its backward pass never writes
+    the optimizer's sum g.V, so the hW piece of the split update must take the five-launch form -- the replay used to
+    claim the sum was fresh (round-3 advice).  Same weights as the single-graph step, bitwise."""
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    cfg = O.vrnn_config(latent_dim=2, seq_length=12, n_classes=10, use_x_prev=True)
+    cfg['sparse_inputs'] = False
+    B, Tn = 8, 12
+    rng = np.random.default_rng(19)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=6).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    X, Xp, wt = T(win[:, 1:], dev), T(win[:, :-1], dev), T(np.eye(10)[rng.integers(0, 10, B)], dev)
+    out = []
+    for force in ('0', '1'):
+        monkeypatch.setenv('CLV_FORCE_DP_GRAPHS', force)
+        eng = VrnnEngine(cfg, B, dev)
+        assert not eng.sparse_inputs
+        eng.P.set_weights(p)
+        ts = TrainStep(eng, seed=78)
+        for _ in range(5):
+            ts.stage_batch(X, Xp, wt)
+            ts.step()
+        torch.cuda.synchronize()
+        assert not eng.gdot_fresh
+        if force == '1':
+            assert ts._main_leaves_gdot is False
+        out.append(eng.P.get_weights())
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+
+
 def test_adam_step_in_two_pieces_is_bitwise_the_whole_step(dev):
     """FlatParams.adam_step(only=..., advance=False) then the rest == one call (per-tensor independence of Adam-WN,
     `iterations` advanced once): the multi-GPU schedule updates the hW kernel while the other bucket is still reduced."""
