@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CLV_LIB: another build of the same ABI (A/B measurements inside one GPU session; tools/build_variant.sh)
 LIB_PATH = os.environ.get("CLV_LIB") or os.path.join(_HERE, "libclvae_hip.so")
 
+ABI_VERSION = 400      # CLV_ABI_VERSION of include/clvae.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_MASKPOS = 0, 1, 2, 3
 GATE_HARD_SIGMOID, GATE_SIGMOID = 0, 1
 
@@ -210,6 +211,10 @@ def lib():
             fn = getattr(h, name)      # AttributeError if the ABI drifted
             fn.restype = res
             fn.argtypes = args
+        if h.clv_version() != ABI_VERSION:      # a library of another round: same symbols, other argument lists
+            raise ClvError("libclvae_hip.so has ABI version %d, this binding was written for %d (include/clvae.h: "
+                           "CLV_ABI_VERSION); rebuild with `make -C classifying-vae-lstm_amd/csrc`"
+                           % (h.clv_version(), ABI_VERSION))
         _lib = h
     return _lib
 

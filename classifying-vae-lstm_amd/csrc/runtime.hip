@@ -128,7 +128,7 @@ static int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t step, co
 
 using namespace clv;
 
-extern "C" int clv_version(void) { return 100; }
+extern "C" int clv_version(void) { return CLV_ABI_VERSION; }
 
 extern "C" int clv_device_count(void) {
   int n = 0;

@@ -62,6 +62,14 @@ typedef struct clv_noise_draw {
   const int32_t* step_dev;
 } clv_noise_draw;
 
+/* ABI version = CLV_ABI_VERSION of the header the library was built from.  It changes whenever an existing entry point
+ * changes its argument list or the size / meaning of a buffer (a caller built against an older header would still resolve
+ * the symbol): the binding compares it at load time and refuses a mismatch.
+ *   100  rounds 1-2
+ *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
+ *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
+ *   400  round 4: + clv_lstm_mx_* (additions only) */
+#define CLV_ABI_VERSION 400
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
 int clv_device_count(void);

@@ -26,7 +26,19 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libclvae_hip.so does not export " + name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib().clv_version() >= 100
+    # the library, the header it was built from and the ctypes binding agree on the ABI version (a library of another
+    # round resolves the same symbols with other argument lists: the binding refuses it at load time)
+    hdr_version = int(re.search(r"#define\s+CLV_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert _lib.lib().clv_version() == hdr_version == _lib.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.ClvError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib().clv_version() == _lib.ABI_VERSION
 
 
 def test_no_gpu_fails_loudly():
