@@ -103,9 +103,17 @@ def test_fit_tracks_an_oracle_training_loop(dev):
             it += 1
         ref_epoch.append(tot / (n // B))
     np.testing.assert_allclose(hist.history['loss'], ref_epoch, rtol=2e-4)
+    # Parameters after the six steps.  An Adam step moves an entry by +-lr whatever the size of its gradient, so an entry
+    # whose gradient is within rounding of zero may go the other way in two correct implementations (|dw| up to 2 lr per
+    # step); everywhere else the two agree to rounding (tests/test_gpu_timed_step.py measures 8e-6 at 256 x 128).  At most
+    # 1e-3 of a tensor's entries may leave rtol 1e-3 / atol 2e-5, none may leave 2 lr x 6 steps.  (Round 3 asserted
+    # rtol 2e-2 / atol 3e-4 on every entry, which this replaces.)
     w = model.engine.P.get_weights()
     for k in p:
-        np.testing.assert_allclose(w[k], p[k], rtol=2e-2, atol=3e-4, err_msg=k)
+        d = np.abs(w[k] - p[k])
+        off = d > 1e-3 * np.abs(p[k]) + 2e-5
+        assert off.mean() <= 1e-3, (k, off.mean(), d.max())
+        assert d.max() <= 2 * 1e-3 * 6, (k, d.max())
     assert set(hist.history) == {'loss', 'X_decoded_mean_loss', 'W_loss', 'W2_loss', 'Z_args_loss', 'W_acc',
                                  'val_loss', 'val_X_decoded_mean_loss', 'val_W_loss', 'val_W2_loss',
                                  'val_Z_args_loss', 'val_W_acc'}

@@ -1,0 +1,145 @@
+"""-m gpu: the step bench.py TIMES, as it is timed, against the oracle at the sizes it is timed at.
+
+tests/test_gpu_models.py checks `loss_and_grads` with injected noise and steps the optimizer separately.  What the
+benchmark (and `fit()`) replays is something else: a captured hipGraph whose kernels draw their own Philox noise, pack the
+recurrent weights inside the label launch, run the label path's backward inside the pair backward kernel, stage uint8
+frames, and update with the two-launch Adam-with-weight-norm from sums the backward pass left behind.  Here that exact
+path -- TrainStep(use_graph=True) with every default -- runs for a few steps on fresh batches, and an oracle loop
+(`vrnn_loss_and_grads` / `vae_loss_and_grads` + `adam_wn_step`, cl_vrnn/train.py:66-71, utils/weightnorm.py:75-143) fed the
+noise of oracle/philox.py at the same (seed, step, stream) follows it: every loss term of every step to 1e-3, the
+parameters after the last step.
+
+Tolerance of the parameters.  One Adam step moves an entry by lr * m_hat / (sqrt(v_hat) + eps) = +-lr for ANY gradient
+that is not ~0, so two correct implementations can differ by up to 2 lr = 2e-3 (absolute) per step on an entry whose
+gradient is within rounding of zero (its sign decides the direction), and agree to rounding everywhere else.  The bar is
+therefore: at most a 1e-4 fraction of a tensor's entries may differ by more than rtol 1e-4 / atol 2e-5 (measured on
+MI355X: max |dw| 8e-6 after three steps at 256 x 128, 5e-6 after two at 1024 x 256), and none by more than 2 lr per step
+taken.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import clvae_oracle as O
+from oracle import philox as OP
+
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL = 1e-3
+LR = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import clvae_amd  # noqa: F401
+    from clvae_amd import _lib
+    _lib.require_gpu()
+    return torch.device("cuda:0")
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def u8(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.uint8), device=dev)
+
+
+def ft(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+
+
+def check_params(got, want, steps, rtol=1e-4, atol=2e-5, frac=1e-4, what=""):
+    worst = 0.0
+    for k in want:
+        d = np.abs(got[k] - want[k])
+        off = d > rtol * np.abs(want[k]) + atol
+        assert off.mean() <= frac, "%s %s: %.2e of the entries beyond rtol %g / atol %g" % (what, k, off.mean(), rtol, atol)
+        assert d.max() <= 2 * LR * steps, "%s %s: max |dw| %.2e" % (what, k, d.max())
+        worst = max(worst, float(d.max()))
+    return worst
+
+
+@pytest.mark.parametrize("B,Tn,L,steps", [(256, 128, 2, 3),        # BASELINE config 3 (config 4 per GPU): bench.py's default
+                                          (1024, 256, 32, 2)])     # config 5 per GPU
+def test_cl_vrnn_timed_step_tracks_the_oracle(dev, B, Tn, L, steps):
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    Cn, seed = 10, 4321
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(B + L)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=5).items()}
+    win = (rng.random((steps * B, Tn + 1, 88)) < 0.0443)
+    keys = np.eye(Cn)[rng.integers(0, Cn, steps * B)]
+    eng = VrnnEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    ts = TrainStep(eng, seed=seed)             # every default: graph, in-kernel noise, fast Adam, label-in-pair
+    assert ts.use_graph and ts.fast_adam and ts.ar is None
+    Xd, Xpd, wd = u8(win[:, 1:], dev), u8(win[:, :-1], dev), ft(keys, dev)
+    st = O.adam_wn_init(p)
+    for it in range(steps):
+        sl = slice(it * B, (it + 1) * B)
+        ts.stage_batch(Xd[sl], Xpd[sl], wd[sl])
+        ts.step()
+        torch.cuda.synchronize()
+        got = eng.losses()
+        eW = f32(OP.normal(B * (Cn - 1), seed, step=it, stream_id=0).reshape(B, Cn - 1))
+        eZ = f32(OP.normal(B * Tn * L, seed, step=it, stream_id=1).reshape(B, Tn, L))
+        ref = O.vrnn_loss_and_grads(p, cfg, win[sl, 1:].astype(np.float64), win[sl, :-1].astype(np.float64), keys[sl], eW, eZ)
+        O.adam_wn_step(p, ref['grads'], st)
+        print("cl_vrnn %dx%d L=%d step %d (%s): total gpu %.6f oracle %.6f |d| %.2e" %
+              (B, Tn, L, it, "eager" if it == 0 else "graph replay", got['total'], ref['total'], abs(got['total'] - ref['total'])))
+        for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total', 'elbo'):
+            assert abs(got[k] - ref[k]) <= LOSS_TOL, (it, k, got[k], ref[k])
+    # the path that ran is the one bench.py times
+    assert ts._graphs is not None and len(ts._graphs) == 1 and eng.frames_exact_bf16
+    assert eng.P.norms_valid and int(eng.P.iterations.item()) == steps
+    if L <= 8:
+        assert eng.fuse_pair and eng.label_in_pair and eng.folds_noise()
+    else:
+        assert eng.use_mx and eng.fuse_latent
+    worst = check_params(eng.P.get_weights(), p, steps, what="cl_vrnn %dx%d" % (B, Tn))
+    print("cl_vrnn %dx%d: parameters after %d steps, max |dw| %.2e" % (B, Tn, steps, worst))
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_cl_vae_timed_step_tracks_the_oracle(dev, bf16):
+    """BASELINE config 2: the fused cl_vae step (one launch: 6 Dense layers forward and backward, Philox noise inside,
+    loss means and the step counter in the slab-sum launch) + Adam-WN, replayed as a graph, batch 512.  bf16=True rounds
+    the operands of every product to bf16 (tests/test_gpu_models.py::test_cl_vae_bf16_step_tolerance states its bars
+    for one step; three steps of it stay inside 2e-3 on every loss term)."""
+    from clvae_amd.engine import VaeEngine
+    from clvae_amd.trainer import TrainStep
+    B, L, Cn, steps, seed = 512, 4, 2, 3, 99
+    cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(7)
+    p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=2).items()}
+    fr = (rng.random((steps * B, 2, 88)) < 0.0443)
+    keys = np.eye(Cn)[rng.integers(0, Cn, steps * B)]
+    eng = VaeEngine(dict(cfg, bf16=bf16), B, dev)
+    assert eng.fused
+    eng.P.set_weights(p)
+    ts = TrainStep(eng, seed=seed)
+    xd, xpd, wd = u8(fr[:, 1], dev), u8(fr[:, 0], dev), ft(keys, dev)
+    st = O.adam_wn_init(p)
+    tol = 2e-3 if bf16 else LOSS_TOL
+    for it in range(steps):
+        sl = slice(it * B, (it + 1) * B)
+        ts.stage_batch(xd[sl], xpd[sl], wd[sl])
+        ts.step()
+        torch.cuda.synchronize()
+        got = eng.losses()
+        ew = f32(OP.normal(B * (Cn - 1), seed, step=it, stream_id=0).reshape(B, Cn - 1))
+        ez = f32(OP.normal(B * L, seed, step=it, stream_id=1).reshape(B, L))
+        ref = O.vae_loss_and_grads(p, cfg, fr[sl, 1].astype(np.float64), fr[sl, 0].astype(np.float64), keys[sl], ew, ez)
+        O.adam_wn_step(p, ref['grads'], st)
+        print("cl_vae 512 %s step %d: total gpu %.6f oracle %.6f |d| %.2e" %
+              ("bf16" if bf16 else "fp32", it, got['total'], ref['total'], abs(got['total'] - ref['total'])))
+        for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total', 'elbo'):
+            assert abs(got[k] - ref[k]) <= tol, (it, k, got[k], ref[k])
+    assert ts._graphs is not None and ts._folded() and int(eng.P.iterations.item()) == steps
+    if bf16:       # products rounded to 8 bits: the parameters follow to a few percent of a step
+        check_params(eng.P.get_weights(), p, steps, rtol=5e-2, atol=5e-4, frac=2e-2, what="cl_vae bf16")
+    else:
+        check_params(eng.P.get_weights(), p, steps, what="cl_vae fp32")
