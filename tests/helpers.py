@@ -66,3 +66,22 @@ class StubModel:
             return [(base[:L] * 0.3).reshape(shp), (base[:L] * 0.1 - 0.5).reshape(shp)]
         D, lead = self.dims
         return (1 / (1 + np.exp(-3 * base[:D]))).reshape((1,) * lead + (D,))
+
+
+def write_jsb_cs_pickle(path):
+    """The real `JSB Chorales_Cs` data set (tests/golden/g7_jsb_cs_notes.npz, made from the reference's pickle in the build
+    container) as a pickle of the reference's schema: {'train' | 'valid' | 'test': list[song], song: list[frame], frame:
+    list[int MIDI]; '<split>_key': list[str]; '<split>_mode': list[bool]}."""
+    G = golden("g7_jsb_cs_notes.npz")
+    D = {}
+    for split in ('train', 'valid', 'test'):
+        notes, per_frame, frames = G[split + '/notes'], G[split + '/per_frame'], G[split + '/frames']
+        frame_end = np.cumsum(per_frame.astype(np.int64))
+        frame_lists = [[int(n) for n in notes[e - c:e]] for e, c in zip(frame_end, per_frame)]
+        song_end = np.cumsum(frames.astype(np.int64))
+        D[split] = [frame_lists[e - c:e] for e, c in zip(song_end, frames)]
+        D[split + '_key'] = [str(k) for k in G[split + '/key']]
+        D[split + '_mode'] = [bool(m) for m in G[split + '/mode']]
+    with open(path, 'wb') as f:
+        pickle.dump(D, f, protocol=2)
+    return path
