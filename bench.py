@@ -10,6 +10,13 @@ JSON line.  Workloads (BASELINE.json configs):
   cfg5            cl_vrnn, 1024 windows/GPU x seq_len 256, latent 32, 10 classes  (configs[4])
   cfg2            cl_vae --use_x_prev, batch 512/GPU, latent 4, 2 classes (fp32 path)
 Weak scaling: per-GPU work is fixed, the global batch grows with N.
+
+The timed region is exactly K steps between a barrier + torch.cuda.synchronize() on both sides.  When K steps take less
+than 50 ms (the driver's K = 20 at 0.4 ms is 8 ms: one clock-state hiccup of the device moves it by 5-10 %), the region is
+repeated as 5..9 such blocks and the line carries the MEDIAN block (`timed_blocks`: every block, its min and max).
+A default single-GPU run (`python bench.py`, workload cfg3) appends `also`: the other BASELINE workloads -- cfg5, cfg2
+fp32 / bf16, generation of 1 and 1024 sequences -- measured in the same process right after the headline (a few seconds
+each: value, ms per step, dominant-kernel fraction), so that those numbers are witnessed by whoever runs the line.
 """
 import argparse
 import json
@@ -39,7 +46,7 @@ WORKLOADS = {
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (never the 2:1-sparsity figure)
-PROFILE_TAGS = ('r03_f', 'r02_f', 'r02_e', 'r02_d', 'r02_c', 'r02', 'r01')      # newest committed profile set first
+PROFILE_TAGS = ('r04_b', 'r04_a', 'r03_f')      # committed profile sets (profiles/<tag>_*), newest first
 NOTE_DENSITY = 0.0443        # measured JSB note density
 
 
@@ -161,7 +168,7 @@ def bench_generate(args, w, dev, rank, world):
         dt = d1 if dt is None else min(dt, d1)
     frames = world * N * (args.steps + 16)
     if rank == 0:
-        print(json.dumps({"metric": "generated piano-roll frames/sec (sample)", "value": round(frames / dt, 1),
+        return ({"metric": "generated piano-roll frames/sec (sample)", "value": round(frames / dt, 1),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * dt / (args.steps + 16), 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -170,7 +177,8 @@ def bench_generate(args, w, dev, rank, world):
                                                  % (args.workload, N, L, "one persistent kernel (workgroup per sequence)"
                                                     if persistent else "hipGraph replay per frame", NOTE_DENSITY),
                                      "parallelism": "replicas%d" % world},
-                          "note_density_out": round(float(out.mean().item()), 4)}))
+                          "note_density_out": round(float(out.mean().item()), 4)})
+    return None
 
 
 def allreduce_microbench(ts, dev, iters=50):
@@ -227,7 +235,7 @@ def bench_generate_vae(args, w, dev, rank, world):
         d1 = time.perf_counter() - t0
         dt = d1 if dt is None else min(dt, d1)
     if rank == 0:
-        print(json.dumps({"metric": "generated piano-roll frames/sec (sample)", "value": round(world * N * args.steps / dt, 1),
+        return ({"metric": "generated piano-roll frames/sec (sample)", "value": round(world * N * args.steps / dt, 1),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -236,7 +244,8 @@ def bench_generate_vae(args, w, dev, rank, world):
                                                  % (args.workload, N, L, "one persistent kernel (workgroup per sequence)"
                                                     if persistent else "hipGraph replay per frame", NOTE_DENSITY),
                                      "parallelism": "replicas%d" % world},
-                          "note_density_out": round(float(out.mean().item()), 4)}))
+                          "note_density_out": round(float(out.mean().item()), 4)})
+    return None
 
 
 def free_port():
@@ -282,48 +291,202 @@ def launch_selftest(args):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
-    ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--bf16', action='store_true',
-                    help='cfg2: the Dense products of the fused cl_vae step on the bf16 matrix cores (fp32 accumulate)')
-    ap.add_argument('--no-persistent', action='store_true', help='generation: per-frame hipGraph replay instead of the persistent kernel')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--kernel-times', action='store_true', help='print per-kernel event times to stderr')
-    ap.add_argument('--selftest-launch', action='store_true', help='launcher / rendezvous check on CPU (gloo), no timing')
-    args = ap.parse_args()
-
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
-        sys.exit(self_launch(args.gpus))
-    if args.selftest_launch:
-        return launch_selftest(args)
-
+def timed_blocks(run, barrier, steps, world, dev):
+    """K = `steps` steps between barrier + synchronize, as 1 block, or 5..9 blocks when a block is shorter than 50 ms.
+    Returns (seconds of the median block, [ms per step of every block], per-rank ms per step of the median block)."""
     import torch
     import torch.distributed as dist
-    import clvae_amd  # noqa: F401
-    from clvae_amd import _lib, ops
-    from clvae_amd.parallel import init_from_env
+
+    def one():
+        barrier()
+        t0 = time.perf_counter()
+        run(steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            return [float(t.item()) for t in every]
+        return [dt]
+
+    blocks = [one()]
+    first = max(blocks[0])
+    if first < 0.05:
+        n = int(min(9, max(5, np.ceil(0.05 / max(first, 1e-6)))))
+        if world > 1:                      # every rank must run the same number of blocks
+            t = torch.tensor([n], dtype=torch.int32, device=dev)
+            dist.broadcast(t, src=0)
+            n = int(t.item())
+        blocks += [one() for _ in range(n - 1)]
+    worst = [max(b) for b in blocks]                         # a block takes as long as its slowest rank
+    mid = int(np.argsort(worst)[len(worst) // 2])
+    return worst[mid], [round(1e3 * x / steps, 4) for x in worst], [round(1e3 * x / steps, 4) for x in blocks[mid]]
+
+
+def kernel_time_pass(eng, ts_args, batch, reps, label_off=False):
+    """Per-kernel HIP-event times of `reps` eager steps of the same shapes on the launch stream; parameters and optimizer
+    state are put back afterwards.  label_off: the label path's backward as a launch of its own (what the pair backward
+    kernel costs WITHOUT that epilogue)."""
+    import torch
+    from clvae_amd import ops
     from clvae_amd.trainer import TrainStep
+    saved = [t_.clone() for t_ in eng.P.state_tensors()]
+    keep = getattr(eng, 'label_in_pair', None)
+    if label_off:
+        eng.label_in_pair = False
+    ts_e = TrainStep(eng, use_graph=False, **ts_args)
+    ts_e.stage_batch(*batch)
+    ts_e.step(); torch.cuda.synchronize()
+    ops.prof_enable(True)
+    for _ in range(reps):
+        ts_e.step()
+        ops.prof_empty_scope()          # what a bracket of the profiler's events costs by itself ("event_pair")
+    recs = ops.prof_collect()
+    ops.prof_enable(False)
+    for t_, sv in zip(eng.P.state_tensors(), saved):
+        t_.copy_(sv)
+    if label_off:
+        eng.label_in_pair = keep
+    del ts_e, saved
+    return recs
 
-    rank, local, world = init_from_env()
-    if world != args.gpus:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d (launch with torch.distributed.run --nproc-per-node %d, or run "
-                         "`python bench.py --gpus %d` outside a process group and it starts the ranks itself)"
-                         % (world, args.gpus, args.gpus, args.gpus))
-    _lib.require_gpu()
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    w = WORKLOADS[args.workload]
+
+def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_gpu, bf16, kernel_times=False):
+    B = w['B']
+    pair_ms = [r[2] / max(r[1], 1) for r in recs if r[0] == 'event_pair']
+    event_pair_us = 1e3 * pair_ms[0] if pair_ms else 0.0
+    recs = [r for r in recs if r[0] != 'event_pair']
+    if kernel_times:
+        print("  event_pair (empty bracket)  %.2f us" % event_pair_us, file=sys.stderr)
+        tot = sum(r[2] for r in recs)
+        for name, n, ms in sorted(recs, key=lambda r: -r[2]):
+            print("  %-22s launches/step %5.1f  ms/step %8.4f  %5.1f%%" % (name, n / reps, ms / reps, 100 * ms / tot),
+                  file=sys.stderr)
+
+    def table(rs):
+        by = {}
+        for r in rs:
+            if r[0] == 'event_pair':
+                continue
+            k = "gemm_f32" if r[0].startswith("gemm ") else r[0]
+            by[k] = (k, by.get(k, (k, 0, 0.0))[1] + r[1], by.get(k, (k, 0, 0.0))[2] + r[2])
+        return by
+    by = table(recs)
+    if w['model'] == 'cl_vrnn':
+        # dominant kernels: the persistent LSTM sequence kernels (one launch = one LSTM pass, or both LSTMs of a pass when
+        # the pair kernels run): 4 LSTM passes per step
+        names = sorted(k for k in by if k.startswith(('lstm_pair_', 'lstm_seq_', 'lstm_mx_')) and not k.endswith('_pack'))
+        n = sum(by[k][1] for k in names)
+        ms_raw = sum(by[k][2] for k in names)
+        ms = ms_raw - n * event_pair_us * 1e-3         # minus what the brackets themselves cost (see `event_pair_us`)
+        avg_s = ms / n * 1e-3
+        achieved = 4 * reps * lstm_seq_flops(w, B) / (ms * 1e-3) / 1e12
+        kname = '+'.join(names)
+    else:
+        # cl_vae: the whole step is one fused launch (all 8 Dense layers, forward + backward)
+        kname = 'vae_fused_step' if 'vae_fused_step' in by else 'gemm_f32'
+        n, ms_raw = by[kname][1], by[kname][2]
+        ms = ms_raw - n * event_pair_us * 1e-3
+        avg_s = ms / n * 1e-3
+        achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
+    # HBM bytes: NOT measured in this run -- read from the newest committed PMC summary of the SAME workload
+    # (tools/round_profile.sh -> profiles/<tag>_pmc_traffic_<workload>.json; separate --pmc passes, the guide's gfx950
+    # corrections); the JSON names the file, and carries null when none matches
+    traffic = step_traffic = traffic_source = None
+    wl_tag = wl_name + ('_bf16' if bf16 else '')
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (tag, wl_tag))
+        try:
+            pm = json.load(open(path))
+        except Exception:
+            continue
+        if pm.get('workload') != wl_name:
+            continue
+        if w['model'] == 'cl_vrnn':
+            traffic = round(pm.get('dominant_bytes_per_launch', pm.get('lstm_seq_bytes_per_launch')))
+        step_traffic = pm.get('step_bytes')
+        traffic_source = os.path.relpath(path, ROOT)
+        break
+    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=kname,
+                    avg_launch_us=round(avg_s * 1e6, 2), avg_launch_us_raw=round(ms_raw / n * 1e3, 2),
+                    event_pair_us=round(event_pair_us, 2),
+                    timing="HIP events around every launch on the launch stream; avg_launch_us = the bracketed time minus "
+                           "event_pair_us, an EMPTY bracket measured in the same pass (the two event records cost that much "
+                           "by themselves); achieved / frac use avg_launch_us, the raw figure is avg_launch_us_raw",
+                    algorithmic_step_frac=round(value_per_gpu * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4),
+                    algorithmic_step_frac_is="whole-step ALGORITHMIC flop rate (SURVEY.md 8d: dense-equivalent GEMM flops, which the "
+                                             "sparse input kernels never execute) / the fp32 peak: a throughput figure, not a utilisation",
+                    step_traffic=step_traffic, traffic_source=traffic_source,
+                    traffic_measured_in_this_run=False,
+                    kernel_time_pass="%d eager steps with HIP events around every launch, after the graph capture and before the warm-up" % reps)
+    if w['model'] == 'cl_vrnn':
+        if getattr(eng, 'use_mx', False):
+            roofline['executes_on'] = ("bf16 MFMA (v_mfma_f32_16x16x32_bf16), exact fp32 products from 3 x 3 bf16 pieces, fp32 "
+                                       "accumulate; priced against the fp32 peak because the ARITHMETIC is fp32")
+        else:
+            # one batch row per CU leaves the matrix cores' M dimension empty; the fp32 vector peak equals the fp32 MFMA peak
+            roofline['executes_on'] = "fp32 VALU (v_pk_fma_f32): the fp32 vector peak equals the fp32 MFMA peak (157.3 TFLOP/s)"
+        if recs_nolabel is not None:
+            # honest denominator: the pair backward launch is not only recurrent products -- measured in THIS run by a
+            # second kernel-time pass with the label path's backward as a launch of its own
+            alt = table(recs_nolabel)
+            ep = [r[2] / max(r[1], 1) for r in recs_nolabel if r[0] == 'event_pair']
+            ep_us = 1e3 * ep[0] if ep else event_pair_us
+            us = lambda t, k: round(1e3 * t[k][2] / t[k][1] - ep_us, 2) if k in t else None
+            roofline['kernel_also_runs'] = dict(
+                what="lstm_pair_bwd ends with the label path's backward of every batch row (no launch of its own)",
+                lstm_pair_bwd_with_it_us=round(1e3 * by['lstm_pair_bwd'][2] / by['lstm_pair_bwd'][1] - event_pair_us, 2),
+                lstm_pair_bwd_without_it_us=us(alt, 'lstm_pair_bwd'), label_bwd_own_launch_us=us(alt, 'vrnn_label_bwd'),
+                measured="this run: a second pass of %d eager steps with CLV_LABEL_IN_PAIR off" % max(reps // 2, 4))
+    if 'lstm_wgrad_bf16' in by:
+        # the batched gate GEMM of the north star: every kernel gradient of an LSTM, [x | h | z]^T . dz over B*T rows
+        # (csrc/wgrad_bf16.hip), formed on the BF16 matrix cores from exact pieces.  Reported against the pipe it
+        # runs on: (a) issued bf16 MFMA flops / 2.5 PFLOP/s, (b) the MFMA-busy counter of the committed SQ pass;
+        # the algorithmic fp32-equivalent rate is given by name, never as a fraction of a peak it does not use.
+        gn, gms = by['lstm_wgrad_bf16'][1], by['lstm_wgrad_bf16'][2]
+        gms -= gn * event_pair_us * 1e-3
+        rows = (88 + 88) + (88 + w['L'] + 88)
+        alg = 2.0 * rows * 352 * B * w['T'] * reps                     # algorithmic flops of the products, both LSTMs
+        exact = bool(getattr(eng, 'frames_exact_bf16', False))
+        issued = 0.0
+        for nz in (0, w['L']):                                         # encoder, decoder
+            wide = 88 + nz > 96 or nz > 8
+            h_tiles, x_tiles, col_tiles = (8 if wide else 6), 6, 24   # 16-row tiles of [h | z] and x; 2 x 12 column tiles
+            mfmas = (x_tiles * (1 if exact else 3) * 3 + h_tiles * 9) * col_tiles * (B * w['T'] // 32)
+            issued += mfmas * 2.0 * 16 * 16 * 32
+        issued *= reps
+        sq = None
+        for tag in PROFILE_TAGS:
+            try:
+                sj = json.load(open(os.path.join(ROOT, 'profiles', '%s_sq_%s.json' % (tag, wl_name))))
+                k = [k for k in sj['kernels'] if 'lstm_wgrad_bf16' in k['kernel']]
+                if k:
+                    sq = dict(mfma_busy=k[0].get('mfma_busy'), source='profiles/%s_sq_%s.json' % (tag, wl_name))
+                    break
+            except Exception:
+                continue
+        roofline['gate_gemm'] = dict(
+            kernel='lstm_wgrad_bf16', avg_launch_us=round(gms / gn * 1e3, 2), bound="mfma", pipe="bf16 MFMA (v_mfma_f32_16x16x32_bf16)",
+            peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+            achieved=round(issued / (gms * 1e-3) / 1e12, 1), frac=round(issued / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            achieved_is="issued bf16 MFMA flops (padded tiles, 9 piece pairs per fp32 product, 3 for byte-valued frames) / launch time",
+            mfma_busy_counter=sq,
+            fp32_equivalent_tflops=round(alg / (gms * 1e-3) / 1e12, 2),
+            arithmetic="exact fp32 products from 3 bf16 pieces per operand, fp32 accumulate")
+    return roofline
+
+
+def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, reps=40, want_roofline=True):
+    """One training workload: engine, synthetic windows resident in HBM, set-up (graph capture + the kernel-time pass),
+    warm-up, the timed blocks.  Returns the pieces of the JSON line."""
+    import torch
+    import torch.distributed as dist
+    from clvae_amd.trainer import TrainStep
+    w = WORKLOADS[wl_name]
     B, T = w['B'], w['T']
-
-    if w.get('generate'):
-        return bench_generate(args, w, dev, rank, world)
-    eng, cfg = make_engine(w, dev, bf16=args.bf16)
+    eng, cfg = make_engine(w, dev, bf16=bf16)
     if world > 1:      # replicas start from rank 0's weights and optimizer state
         for t_ in eng.P.state_tensors():
             dist.broadcast(t_, src=0)
@@ -343,158 +506,120 @@ def main():
         torch.cuda.synchronize()
 
     # Set-up, before the W warm-up steps: (1) the step's hipGraph is captured (an eager step, the capture, a first
-    # replay); (2) on rank 0 the roofline object's per-kernel HIP-event timing: 40 eager steps of the same shapes on the
-    # same stream -- its steps are rank 0's alone, so parameters and optimizer state are put back afterwards.  The
-    # warm-up and the timed region follow at once, on a device that has been running this workload.
+    # replay); (2) on rank 0 the roofline object's per-kernel HIP-event timing: eager steps of the same shapes on the same
+    # stream -- its steps are rank 0's alone, so parameters and optimizer state are put back afterwards.  The warm-up and
+    # the timed region follow at once, on a device that has been running this workload.
     run(3)
     barrier()
-    recs, reps = None, 40
-    if rank == 0 and not args.no_roofline:
-        # The roofline object's per-kernel HIP-event timing (eager launches on the same stream, same shapes), BEFORE the
-        # warm-up and the timed region: its steps are rank 0's alone, so parameters and optimizer state are put back
-        # afterwards; the timed steps then start on a device that has already been running this workload
-        saved = [t_.clone() for t_ in eng.P.state_tensors()]
-        ts_e = TrainStep(eng, seed=1234, rank=rank, world=1, use_graph=False)
-        ts_e.stage_batch(X_all[:B], Xp_all[:B], w_all[:B])
-        ts_e.step(); torch.cuda.synchronize()
-        ops.prof_enable(True)
-        for _ in range(reps):
-            ts_e.step()
-            ops.prof_empty_scope()          # what a bracket of the profiler's events costs by itself ("event_pair")
-        recs = ops.prof_collect()
-        ops.prof_enable(False)
-        for t_, sv in zip(eng.P.state_tensors(), saved):
-            t_.copy_(sv)
-        del ts_e, saved
+    recs = recs_nolabel = None
+    if rank == 0 and want_roofline:
+        batch = (X_all[:B], Xp_all[:B], w_all[:B])
+        recs = kernel_time_pass(eng, dict(seed=1234, rank=rank, world=1), batch, reps)
+        if getattr(eng, 'fuse_pair', False) and getattr(eng, 'label_in_pair', False):
+            recs_nolabel = kernel_time_pass(eng, dict(seed=1234, rank=rank, world=1), batch, max(reps // 2, 4), label_off=True)
     barrier()
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    rank_ms = [round(1e3 * dt / args.steps, 4)]
-    allreduce = None
-    if world > 1:
-        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        rank_ms = [round(1e3 * float(t.item()) / args.steps, 4) for t in every]      # each rank's own clock over the same K steps
-        dt = max(float(t.item()) for t in every)
-        allreduce = allreduce_microbench(ts, dev)
+    run(warmup)
+    dt, block_ms, rank_ms = timed_blocks(run, barrier, steps, world, dev)
+    allreduce = allreduce_microbench(ts, dev) if world > 1 else None
     loss = eng.losses()
-    value = world * B * T * args.steps / dt
-
+    value = world * B * T * steps / dt
     roofline = None
     if recs is not None:
-        pair_ms = [r[2] / max(r[1], 1) for r in recs if r[0] == 'event_pair']
-        event_pair_us = 1e3 * pair_ms[0] if pair_ms else 0.0
-        recs = [r for r in recs if r[0] != 'event_pair']
-        if args.kernel_times:
-            print("  event_pair (empty bracket)  %.2f us" % event_pair_us, file=sys.stderr)
-            tot = sum(r[2] for r in recs)
-            for name, n, ms in sorted(recs, key=lambda r: -r[2]):
-                print("  %-22s launches/step %5.1f  ms/step %8.4f  %5.1f%%" % (name, n / reps, ms / reps, 100 * ms / tot),
-                      file=sys.stderr)
-        by = {}
-        for r in recs:
-            k = "gemm_f32" if r[0].startswith("gemm ") else r[0]
-            by[k] = (k, by.get(k, (k, 0, 0.0))[1] + r[1], by.get(k, (k, 0, 0.0))[2] + r[2])
-        if w['model'] == 'cl_vrnn':
-            # dominant kernel: the persistent LSTM sequence kernels (fwd+bwd, 2 LSTMs each)
-            # (one launch = one LSTM pass, or both LSTMs of a pass when the pair kernels run): 4 LSTM passes per step
-            names = sorted(k for k in by if k.startswith(('lstm_pair_', 'lstm_seq_', 'lstm_mx_')) and not k.endswith('_pack'))
-            n = sum(by[k][1] for k in names)
-            ms_raw = sum(by[k][2] for k in names)
-            ms = ms_raw - n * event_pair_us * 1e-3         # minus what the brackets themselves cost (see `event_pair_us`)
-            avg_s = ms / n * 1e-3
-            achieved = 4 * reps * lstm_seq_flops(w, B) / (ms * 1e-3) / 1e12
-            kname = '+'.join(names)
-        else:
-            # cl_vae: the whole step is one fused launch (all 8 Dense layers, forward + backward)
-            kname = 'vae_fused_step' if 'vae_fused_step' in by else 'gemm_f32'
-            n, ms_raw = by[kname][1], by[kname][2]
-            ms = ms_raw - n * event_pair_us * 1e-3
-            avg_s = ms / n * 1e-3
-            achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
-        # HBM bytes: NOT measured in this run -- read from the newest committed PMC summary of the SAME workload and
-        # arithmetic (tools/round_profile.sh -> profiles/<tag>_pmc_traffic_<workload>.json; separate --pmc passes, the
-        # guide's gfx950 corrections); the JSON names the file, and carries null when none matches
-        traffic = step_traffic = traffic_source = None
-        wl_tag = args.workload + ('_bf16' if args.bf16 else '')
-        for tag in PROFILE_TAGS:
-            path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (tag, wl_tag))
-            try:
-                pm = json.load(open(path))
-            except Exception:
-                continue
-            if pm.get('workload') != args.workload:
-                continue
-            if w['model'] == 'cl_vrnn':
-                traffic = round(pm.get('dominant_bytes_per_launch', pm.get('lstm_seq_bytes_per_launch')))
-            step_traffic = pm.get('step_bytes')
-            traffic_source = os.path.relpath(path, ROOT)
-            break
-        roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=kname,
-                        avg_launch_us=round(avg_s * 1e6, 2), avg_launch_us_raw=round(ms_raw / n * 1e3, 2),
-                        event_pair_us=round(event_pair_us, 2),
-                        timing="HIP events around every launch on the launch stream; avg_launch_us = the bracketed time minus "
-                               "event_pair_us, an EMPTY bracket measured in the same pass (the two event records cost that much "
-                               "by themselves); achieved / frac use avg_launch_us, the raw figure is avg_launch_us_raw",
-                        whole_step_frac=round(value / world * flop_per_timestep(w) / 1e12 / PEAK_F32_TFLOPS, 4),
-                        step_traffic=step_traffic, traffic_source=traffic_source,
-                        traffic_measured_in_this_run=False,
-                        kernel_time_pass="%d eager steps with HIP events around every launch, after the graph capture and before the warm-up" % reps)
-        if w['model'] == 'cl_vrnn':
-            # the recurrent products run on the fp32 VECTOR pipe (v_pk_fma_f32; one batch row per CU leaves the matrix
-            # cores' M dimension empty); its peak equals the fp32 MFMA peak, which is what `peak` holds
-            if getattr(eng, 'use_mx', False):
-                roofline['executes_on'] = ("bf16 MFMA (v_mfma_f32_16x16x32_bf16), exact fp32 products from 3 x 3 bf16 pieces, fp32 "
-                                           "accumulate; priced against the fp32 peak because the ARITHMETIC is fp32")
-            else:
-                roofline['executes_on'] = "fp32 VALU (v_pk_fma_f32): the fp32 vector peak equals the fp32 MFMA peak (157.3 TFLOP/s)"
-            if getattr(eng, 'fuse_pair', False) and getattr(eng, 'label_in_pair', False):
-                # honest denominator: the backward launch is not only recurrent products any more
-                roofline['kernel_also_runs'] = ("lstm_pair_bwd ends with the label path's backward of every batch row (no launch of "
-                                                "its own): ~13.9 us of the launch by rocprofv3 (profiles/r03_e_kernel_stats_cfg3.csv "
-                                                "without it: 76.8 us, r03_f with it: 90.7 us); the recurrent products alone sit at "
-                                                "8.12 GFLOP / (94.0 + 76.8 us) = 0.30 of the peak")
-        if 'lstm_wgrad_bf16' in by:
-            # the batched gate GEMM of the north star: every kernel gradient of an LSTM, [x | h | z]^T . dz over B*T rows
-            # (csrc/wgrad_bf16.hip), formed on the BF16 matrix cores from exact pieces.  Reported against the pipe it
-            # runs on: (a) issued bf16 MFMA flops / 2.5 PFLOP/s, (b) the MFMA-busy counter of the committed SQ pass;
-            # the algorithmic fp32-equivalent rate is given by name, never as a fraction of a peak it does not use.
-            gn, gms = by['lstm_wgrad_bf16'][1], by['lstm_wgrad_bf16'][2]
-            gms -= gn * event_pair_us * 1e-3
-            rows = (88 + 88) + (88 + w['L'] + 88)
-            alg = 2.0 * rows * 352 * B * w['T'] * reps                     # algorithmic flops of the products, both LSTMs
-            exact = bool(getattr(eng, 'frames_exact_bf16', False))
-            issued = 0.0
-            for nz in (0, w['L']):                                         # encoder, decoder
-                wide = 88 + nz > 96 or nz > 8
-                h_tiles, x_tiles, col_tiles = (8 if wide else 6), 6, 24   # 16-row tiles of [h | z] and x; 2 x 12 column tiles
-                mfmas = (x_tiles * (1 if exact else 3) * 3 + h_tiles * 9) * col_tiles * (B * w['T'] // 32)
-                issued += mfmas * 2.0 * 16 * 16 * 32
-            issued *= reps
-            sq = None
-            for tag in PROFILE_TAGS:
-                try:
-                    sj = json.load(open(os.path.join(ROOT, 'profiles', '%s_sq_%s.json' % (tag, args.workload))))
-                    k = [k for k in sj['kernels'] if 'lstm_wgrad_bf16' in k['kernel']]
-                    if k:
-                        sq = dict(mfma_busy=k[0].get('mfma_busy'), source='profiles/%s_sq_%s.json' % (tag, args.workload))
-                        break
-                except Exception:
-                    continue
-            roofline['gate_gemm'] = dict(
-                kernel='lstm_wgrad_bf16', avg_launch_us=round(gms / gn * 1e3, 2), bound="mfma", pipe="bf16 MFMA (v_mfma_f32_16x16x32_bf16)",
-                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                achieved=round(issued / (gms * 1e-3) / 1e12, 1), frac=round(issued / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                achieved_is="issued bf16 MFMA flops (padded tiles, 9 piece pairs per fp32 product, 3 for byte-valued frames) / launch time",
-                mfma_busy_counter=sq,
-                fp32_equivalent_tflops=round(alg / (gms * 1e-3) / 1e12, 2),
-                arithmetic="exact fp32 products from 3 bf16 pieces per operand, fp32 accumulate")
+        roofline = roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value / world, bf16,
+                                   kernel_times=args.kernel_times)
+    return dict(w=w, eng=eng, ts=ts, value=value, dt=dt, block_ms=block_ms, rank_ms=rank_ms, allreduce=allreduce, loss=loss,
+                roofline=roofline)
+
+
+def also_list(args, dev):
+    """The other BASELINE workloads, measured in this process right after the headline (single GPU, default run only)."""
+    import copy
+    import gc
+    import torch
+    out = []
+
+    def drop():
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    for name, bf16, steps, warmup, reps in (('cfg5', False, 40, 8, 8), ('cfg2', False, 400, 40, 20), ('cfg2', True, 400, 40, 20)):
+        try:
+            m = measure_train(args, name, dev, 0, 1, steps, warmup, bf16=bf16, reps=reps)
+            r = m['roofline'] or {}
+            e = {"workload": name + ('_bf16' if bf16 else ''), "metric": "piano-roll timesteps/sec (train)",
+                 "value": round(m['value'], 1), "unit": "timesteps/s", "ms_per_step": round(1e3 * m['dt'] / steps, 4),
+                 "steps": steps, "warmup": warmup, "timed_blocks_ms_per_step": m['block_ms'],
+                 "dtype": "bf16" if bf16 else "f32", "final_loss": round(float(m['loss']['total']), 4),
+                 "config": "%s batch %d x seq_len %d, latent %d" % (m['w']['model'], m['w']['B'], m['w']['T'], m['w']['L']),
+                 "roofline": {k: r.get(k) for k in ('kernel', 'frac', 'achieved', 'peak', 'unit', 'avg_launch_us', 'executes_on',
+                                                    'algorithmic_step_frac')}}
+            if 'gate_gemm' in r:
+                e['roofline']['gate_gemm'] = {k: r['gate_gemm'].get(k) for k in ('avg_launch_us', 'frac', 'fp32_equivalent_tflops')}
+            out.append(e)
+            del m
+        except Exception as ex:      # an extra must never cost the headline
+            out.append({"workload": name, "error": repr(ex)[:200]})
+        drop()
+    for name, steps in (('gen1', 240), ('gen1024', 240), ('gen_vae1', 240), ('gen_vae1024', 240)):
+        try:
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.workload = steps, 4, name
+            g = bench_generate(a2, WORKLOADS[name], dev, 0, 1)
+            out.append({"workload": name, "metric": g["metric"], "value": g["value"], "unit": g["unit"],
+                        "ms_per_step": g["ms_per_step"], "steps": steps, "config": g["config"]["workload"]})
+        except Exception as ex:
+            out.append({"workload": name, "error": repr(ex)[:200]})
+        drop()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--bf16', action='store_true',
+                    help='cfg2: the Dense products of the fused cl_vae step on the bf16 matrix cores (fp32 accumulate)')
+    ap.add_argument('--no-persistent', action='store_true', help='generation: per-frame hipGraph replay instead of the persistent kernel')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the `also` list (the other workloads after a default cfg3 run)')
+    ap.add_argument('--kernel-times', action='store_true', help='print per-kernel event times to stderr')
+    ap.add_argument('--selftest-launch', action='store_true', help='launcher / rendezvous check on CPU (gloo), no timing')
+    args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.selftest_launch:
+        return launch_selftest(args)
+
+    import torch
+    import torch.distributed as dist
+    import clvae_amd  # noqa: F401
+    from clvae_amd import _lib
+    from clvae_amd.parallel import init_from_env
+
+    rank, local, world = init_from_env()
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d (launch with torch.distributed.run --nproc-per-node %d, or run "
+                         "`python bench.py --gpus %d` outside a process group and it starts the ranks itself)"
+                         % (world, args.gpus, args.gpus, args.gpus))
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    w = WORKLOADS[args.workload]
+    B, T = w['B'], w['T']
+
+    if w.get('generate'):
+        g = bench_generate(args, w, dev, rank, world)
+        if rank == 0:
+            print(json.dumps(g))
+        return
+    m = measure_train(args, args.workload, dev, rank, world, args.steps, args.warmup, bf16=args.bf16,
+                      want_roofline=not args.no_roofline)
+    eng, ts = m['eng'], m['ts']
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -510,24 +635,31 @@ def main():
         except Exception:
             rccl = None
         out = {
-            "metric": "piano-roll timesteps/sec (train)", "value": round(value, 1), "unit": "timesteps/s",
+            "metric": "piano-roll timesteps/sec (train)", "value": round(m['value'], 1), "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * m['dt'] / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if (args.bf16 and w['model'] == 'cl_vae') else "f32", "data": "synthetic",
             "config": {"workload": "%s: %s batch %d/GPU x seq_len %d, latent %d, %d classes, 88-dim piano-roll, "
                                    "Adam-WN, hipGraph=%s" % (args.workload, w['model'], B, T, w['L'], w['C'],
                                                              not args.no_graph),
                        "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
-            "final_loss": round(float(loss['total']), 4),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "timed_blocks": {"ms_per_step": m['block_ms'], "min": min(m['block_ms']), "max": max(m['block_ms']),
+                             "reported": "median block" if len(m['block_ms']) > 1 else "the one block",
+                             "rule": "every block = exactly --steps steps between barrier + synchronize; more than one block "
+                                     "only when a block is shorter than 50 ms"},
+            "final_loss": round(float(m['loss']['total']), 4),
+            "roofline": m['roofline'], "cpu_baseline": cpu,
             "devices": devices, "rccl": rccl if world > 1 else None,
-            "ms_per_step_by_rank": rank_ms, "allreduce_alone": allreduce,
+            "ms_per_step_by_rank": m['rank_ms'], "allreduce_alone": m['allreduce'],
             "dp_schedule": None if world == 1 else {
                 "graphs_per_step": len([g for g in ts._graphs if g is not None]) if ts._graphs else 0, "collectives_per_step": 2,
                 "wgrad_split_scale": 2 if getattr(eng, 'fine_grid', False) else 1,
                 "optimizer": "hW kernel updated (two launches, its sum g.V averaged with its gradient bucket) under the "
-                                                  "main bucket's all-reduce, the rest after it"},
+                             "main bucket's all-reduce, the rest after it"},
         }
+        if world == 1 and args.workload == 'cfg3' and not args.bf16 and not args.no_also and not args.no_graph:
+            del m, eng, ts
+            out["also"] = also_list(args, dev)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
