@@ -511,6 +511,10 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
     # the timed region follow at once, on a device that has been running this workload.
     run(3)
     barrier()
+    if world > 1:          # coarse or fine weight-gradient grid: measured here, on this node, next to the real collectives
+        ts.stage_batch(X_all[:B], Xp_all[:B], w_all[:B])
+        ts.tune_dp_schedule()
+        barrier()
     recs = recs_nolabel = None
     if rank == 0 and want_roofline:
         batch = (X_all[:B], Xp_all[:B], w_all[:B])
@@ -521,6 +525,13 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
     run(warmup)
     dt, block_ms, rank_ms = timed_blocks(run, barrier, steps, world, dev)
     allreduce = allreduce_microbench(ts, dev) if world > 1 else None
+    # what the host spends per step issuing it (staging launch + graph replays / plain launches / collectives), device idle
+    # or not: 50 steps issued back to back, clock stopped BEFORE the synchronize
+    barrier()
+    t0 = time.perf_counter()
+    run(50)
+    host_us = 1e6 * (time.perf_counter() - t0) / 50
+    barrier()
     loss = eng.losses()
     value = world * B * T * steps / dt
     roofline = None
@@ -528,7 +539,7 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
         roofline = roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value / world, bf16,
                                    kernel_times=args.kernel_times)
     return dict(w=w, eng=eng, ts=ts, value=value, dt=dt, block_ms=block_ms, rank_ms=rank_ms, allreduce=allreduce, loss=loss,
-                roofline=roofline)
+                roofline=roofline, host_us=round(host_us, 1))
 
 
 def also_list(args, dev):
@@ -651,8 +662,12 @@ def main():
             "roofline": m['roofline'], "cpu_baseline": cpu,
             "devices": devices, "rccl": rccl if world > 1 else None,
             "ms_per_step_by_rank": m['rank_ms'], "allreduce_alone": m['allreduce'],
+            "host_issue_us_per_step": m['host_us'],
             "dp_schedule": None if world == 1 else {
-                "graphs_per_step": len([g for g in ts._graphs if g is not None]) if ts._graphs else 0, "collectives_per_step": 2,
+                "graphs_per_step": (1 if ts._graphs and ts._graphs[0] == 'whole' else
+                                    len([g for g in ts._graphs if g is not None]) if ts._graphs else 0),
+                "collectives_per_step": 2, "collectives_captured": ts.capture_note,
+                "wgrad_grid_trials": ts.dp_trials,
                 "wgrad_split_scale": 2 if getattr(eng, 'fine_grid', False) else 1,
                 "optimizer": "hW kernel updated (two launches, its sum g.V averaged with its gradient bucket) under the "
                              "main bucket's all-reduce, the rest after it"},

@@ -43,6 +43,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (tried: s_setprio 2 for the first wave of every SIMD, so that the two waves sharing a SIMD leave their MFMA phases one
 // after the other -- no change in either kernel, profiles/r04_mx_log.txt)
 
+// -DMX_STAMPS: every wave of workgroup 0 records the shader clock at seven points of the forward steps 64..71
+// (tools/mx_stamps.py); each stamp takes the value it follows as an operand, so it cannot move above its computation
+#ifdef MX_STAMPS
+__device__ unsigned long long g_mx_stamps[8][8][8];      // [step][wave][stamp]
+#define MXSTAMP(k, dep) asm volatile("s_memtime %0" : "=s"(mst[k]) : "v"(dep))
+#else
+#define MXSTAMP(k, dep)
+#endif
+
 constexpr int MX_R = 4;              // batch rows per workgroup
 constexpr int MX_KP = LH * 16 + 16;  // bytes per row of the K_x image [k][unit][gate]: 356 words = 36 mod 64, so the rows of the 16 (row,
                                      // piece) lane groups of a gather start on 16 different bank offsets (1408 B = 32 mod 64: two)
@@ -314,6 +323,10 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     // under the MFMAs
     Rows g;
     MxItem items[MX_FAST / 4];
+#ifdef MX_STAMPS
+    unsigned long long mst[8];
+#endif
+    MXSTAMP(0, c);
     if (!(MX_ABL & 4)) gather_items(cur ^ 1, items);
     const char* hb = hB + cur * 16 * MX_HP + n * MX_HP + (lane >> 4) * 16;
     bf16x8 bh[3];
@@ -322,6 +335,7 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     bf16x8 bz;
     if (HASZ) bz = *reinterpret_cast<const bf16x8*>(zB + cur * 16 * MX_ZP + n * MX_ZP + (lane >> 4) * 16);
     if (!(MX_ABL & 4)) gather_rows(items, g);
+    MXSTAMP(1, bh[2][0]);                           // the B operands are here
     f32x4v acc[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) acc[tl] = f32x4v{xinit[tl][0], xinit[tl][1], xinit[tl][2], xinit[tl][3]};
@@ -338,12 +352,14 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Az[tl][q], bz, acc[tl], 0, 0, 0);
     }
+    MXSTAMP(2, acc[NT - 1][0]);                     // the last MFMA's result is here
     // work that does not depend on the recurrence: the producer's lists / z image, next step's input contribution
     if (PROD && !(MX_ABL & 1)) {
       if (a.nx > 0) compact(fr[cur], cur);     // frame t + 2 -> the list buffer step t - 1 finished with
       if (HASZ) stage_z(zr[cur], cur ^ 1);     // z_{t+1}
     }
     if (!(MX_ABL & 4)) gather_finish(cur ^ 1, g);
+    MXSTAMP(3, xinit[0][0]);
     // butterfly over the piece lanes: sums the pieces (and the note shares) and deals the tiles to the lanes
     float z[4];
 #pragma unroll
@@ -362,12 +378,14 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
         z[i] = x + rb[i];
       }
     }
+    MXSTAMP(4, z[3]);
     const float ig = gate_fn<GATE>(z[0]), fg = gate_fn<GATE>(z[1]), og = gate_fn<GATE>(z[3]);
     const float gg = fast_tanh(z[2]);
     const float kf = c * gate_grad<GATE>(z[1], fg);
     c = fg * c + ig * gg;
     const float tc = fast_tanh(c);
     const float h = og * tc;
+    MXSTAMP(5, h);
     if (!(MX_ABL & 2)) {
       const size_t o = (MX_ABL & 16) ? 0 : (size_t)t;
       coef_p[o * LG] = gg * gate_grad<GATE>(z[0], ig);
@@ -397,6 +415,14 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
       if (a.nx > 0) load_frames(fr[cur], t + 4);
       if (HASZ) load_z(zr[cur], t + 3);
     }
+#ifdef MX_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mst[6]));          // arrival at the barrier
+    if (blockIdx.x == 0 && lane == 0 && t >= 64 && t < 72) {
+      const int wv = threadIdx.x >> 6;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) g_mx_stamps[t - 64][wv][k] = mst[k];
+    }
+#endif
     step_barrier();
   };
 
@@ -627,6 +653,12 @@ static bool mx_auto(int B) {
 }
 
 }  // namespace clv
+
+#ifdef MX_STAMPS
+extern "C" int clv_debug_mx_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_mx_stamps), sizeof(unsigned long long) * 8 * 8 * 8);
+}
+#endif
 
 extern "C" int clv_lstm_mx_supported(int B, int H, int nx, int nz) {
   return H == clv::LH && B >= 1 && nx >= 0 && nx <= clv::MX_NXMAX && nz >= 0 && nz <= 32 && clv::mx_auto(B);

@@ -302,6 +302,10 @@ class Model:
             self._acc.zero_()
             for b0 in range(0, n, GB):
                 ts.gather_batch(d_cur, d_hist, d_w, idx_dev[b0 + rank * B:b0 + (rank + 1) * B], d_target=d_tgt)
+                if world > 1 and ts.dp_trials is None and ts.ar is not None:
+                    # once per fit: which weight-gradient grid is faster next to the real all-reduce on this node
+                    # (timed on the first batch; parameters and optimizer state are restored)
+                    ts.dp_trials = ts.tune_dp_schedule() or {}
                 ts.step()
                 ops.axpy(5, 1.0, eng.scal, self._acc)
             if world > 1:

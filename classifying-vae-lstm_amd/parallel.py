@@ -52,10 +52,13 @@ class GradAllReduce:
     range, bucket 'tail' = [tail_off, tail_off + tail_n).  On CUDA tensors the collectives run on
     a side stream; `wait()` joins it back into the current stream."""
 
-    def __init__(self, flat_grads, tail_off=0, tail_n=0, group=None):
+    def __init__(self, flat_grads, tail_off=0, tail_n=0, group=None, always=False):
+        """always: issue the collectives even in a group of one rank (a one-GPU box can then run -- and try to capture --
+        the real RCCL calls of the schedule; the average over one rank is the identity)."""
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.live = self.world > 1 or (bool(always) and dist.is_initialized())
         n = flat_grads.numel()
         self.tail = flat_grads[tail_off:tail_off + tail_n] if tail_n else None
         self.main = []
@@ -71,7 +74,7 @@ class GradAllReduce:
         self.tail_done = None
 
     def _reduce(self, t):
-        if self.world == 1:
+        if not self.live:
             return
         if dist.get_backend(self.group) == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
@@ -80,7 +83,7 @@ class GradAllReduce:
             t.div_(self.world)
 
     def _on_side(self, tensors):
-        if self.world == 1:
+        if not self.live:
             return
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream())
@@ -97,15 +100,15 @@ class GradAllReduce:
     def reduce_tail(self):
         if self.tail is not None:
             self._on_side([self.tail])
-            if self.cuda and self.world > 1:
+            if self.cuda and self.live:
                 self.tail_done = torch.cuda.Event()
                 self.tail_done.record(self.side)
 
     def wait_tail(self):
         """The current stream waits for the tail bucket only (the main bucket may still be in flight on the side stream)."""
-        if self.cuda and self.world > 1 and self.tail is not None and self.tail_done is not None:
+        if self.cuda and self.live and self.tail is not None and self.tail_done is not None:
             torch.cuda.current_stream().wait_event(self.tail_done)
 
     def wait(self):
-        if self.cuda and self.world > 1:
+        if self.cuda and self.live:
             torch.cuda.current_stream().wait_stream(self.side)

@@ -66,18 +66,29 @@ class TrainStep:
         self.pre_in_tail = bool(self.is_vrnn and tail[1] and tail[0] == 0 and P.grads_pre.numel() > 0
                                 and getattr(engine, 'gdot', None) is not None
                                 and engine.gdot.data_ptr() == P.grads_pre.data_ptr())
+        # CLV_DP_REAL_COLLECTIVES=1 (with the forced schedule, inside a one-rank RCCL group): the collectives are issued
+        # for real -- the only way a one-GPU box can run RCCL inside this schedule, and try to capture it
+        real = os.environ.get('CLV_DP_REAL_COLLECTIVES') == '1'
         if self.pre_in_tail:
-            self.ar = GradAllReduce(P.grads_store, 0, P.grads_pre.numel() + tail[1], group) if (world > 1 or force) else None
+            self.ar = GradAllReduce(P.grads_store, 0, P.grads_pre.numel() + tail[1], group, always=real) \
+                if (world > 1 or force) else None
         else:
-            self.ar = GradAllReduce(P.grads, tail[0], tail[1], group) if (world > 1 or force) else None
+            self.ar = GradAllReduce(P.grads, tail[0], tail[1], group, always=real) if (world > 1 or force) else None
         # the tail bucket is exactly one tensor (the hW kernel): its update can run while the main bucket is reduced
         self.tail_names = [n for n, _ in engine.P.shapes if tail[1] and engine.P.offsets[n] == tail[0]
                            and int(np.prod(dict(engine.P.shapes)[n])) == tail[1]]
         self.rest_names = [n for n, _ in engine.P.shapes if n not in self.tail_names]
         self.split_update = self.ar is not None and len(self.tail_names) == 1
-        if world > 1 and hasattr(engine, 'fine_grid') and 'fine_grid' not in cfg:
-            # the big bucket's all-reduce runs next to the LSTM weight-gradient products: see VrnnEngine.fine_grid
-            engine.fine_grid = True
+        # The big bucket's all-reduce runs next to the LSTM weight-gradient products (VrnnEngine.fine_grid: twice the
+        # workgroups, half the K each, so that a few CUs held by RCCL do not cost a whole second round).  Alone on a GPU
+        # the fine grid is 8-15 % slower (profiles/r03_dp_schedule_one_gpu.txt) and nobody has measured it next to a real
+        # all-reduce, so it is no longer assumed: tune_dp_schedule() times both on the hardware at hand and keeps the
+        # faster (bench.py and Model.fit call it before their first step).  Until then: the coarse grid.
+        self.dp_trials = None
+        # One graph for the whole data-parallel step, collectives included, when RCCL can be captured (tried once, at the
+        # first capture; `capture_note` says what happened); else two graphs + plain launches around eager collectives.
+        self.capture_collectives = os.environ.get('CLV_CAPTURE_COLLECTIVES', '1') != '0'
+        self.capture_note = None
         # CLV_OVERLAP_UPDATE=1 (measurement option, single GPU): the optimizer step of the hW kernel (87 % of the parameters;
         # a chain of five small, latency-bound launches) on a side stream NEXT TO the weight-gradient products of the
         # backward pass's late part -- its gradient is final before they start and nothing they read is touched -- as a
@@ -269,6 +280,46 @@ class TrainStep:
             self.ar.wait()
         self._update()
 
+    def tune_dp_schedule(self, steps=20, warm=3):
+        """Data parallel only: time `steps` steps of the staged batch with the coarse and the fine weight-gradient grid
+        (VrnnEngine.fine_grid) on THIS hardware, next to the real collectives, and keep the faster; parameters and
+        optimizer state are restored.  Every rank runs the same trials, the times are MAX-reduced, so every rank takes
+        the same decision.  Returns (and keeps in `dp_trials`) {'coarse_ms', 'fine_ms', 'chosen'}."""
+        import time
+        eng = self.eng
+        if self.ar is None or not hasattr(eng, 'fine_grid') or 'fine_grid' in eng.cfg:
+            return None
+        import torch.distributed as dist
+        saved = [t.clone() for t in eng.P.state_tensors()]
+        flags = (eng.P.norms_valid, getattr(eng, 'gdot_fresh', False))
+        res = {}
+        for name, fine in (('coarse_ms', False), ('fine_ms', True)):
+            eng.fine_grid = fine
+            self.recapture()
+            for _ in range(warm):
+                self.step()
+            torch.cuda.synchronize()
+            if self.ar.world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            ms = torch.tensor([1e3 * (time.perf_counter() - t0) / steps], dtype=torch.float64, device=eng.device)
+            if self.ar.world > 1:
+                dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+            res[name] = round(float(ms.item()), 4)
+            for t, sv in zip(eng.P.state_tensors(), saved):
+                t.copy_(sv)
+            eng.P.norms_valid = flags[0]
+            if hasattr(eng, 'gdot_fresh'):
+                eng.gdot_fresh = flags[1]
+        eng.fine_grid = res['fine_ms'] < res['coarse_ms']
+        res['chosen'] = 'fine' if eng.fine_grid else 'coarse'
+        self.recapture()
+        self.dp_trials = res
+        return res
+
     def recapture(self):
         """Drop the captured graphs (values baked into them changed, e.g. annealed loss weights); the next step()
         captures again.  Buffers, streams and the all-reduce buckets stay."""
@@ -292,6 +343,8 @@ class TrainStep:
                 self._graphs = (g,)
             else:
                 self._graph_fast = bool(getattr(self.eng.P, 'norms_valid', False))
+                if self._capture_whole_dp_step():
+                    return self._launch_dp()
                 with ops.Graph() as g1:
                     self._main()
                 # whether the captured backward pass writes the hW kernel's sum g.V (only its sparse form does): the
@@ -319,28 +372,57 @@ class TrainStep:
                 return
             self._graphs[0].launch()
         else:
-            if getattr(self, '_graph_fast', False) and not self.eng.P.norms_valid:
+            self._launch_dp()
+
+    def _capture_whole_dp_step(self):
+        """Try ONE graph for the data-parallel step: backward (early part), bucket 1 all-reduce on the side stream,
+        backward (late part), bucket 2, the two optimizer pieces.  RCCL (torch's ProcessGroupNCCL) under a foreign
+        stream capture is not promised to work: any failure is caught, noted, and the split schedule is used."""
+        if not (self.capture_collectives and self.ar is not None and self.ar.live and self.ar.cuda):
+            if self.capture_note is None:
+                self.capture_note = ("not tried: " + ("no live collective in this process" if not (self.ar is not None and self.ar.live)
+                                                       else "CLV_CAPTURE_COLLECTIVES=0"))
+            return False
+        if self.capture_note is not None and not self.capture_note.startswith('captured'):
+            return False                     # failed before: do not try again
+        try:
+            with ops.Graph() as g:
                 self._eager()
-                return
-            g1, g2, g3 = self._graphs[:3]
-            g1.launch()
-            self.ar.reduce_tail()       # hW-kernel bucket, overlaps the weight-gradient products of g2
-            g2.launch()
-            self.ar.reduce_main()
-            if self.split_update:
-                self.ar.wait_tail()
-                # Adam-WN of the hW kernel (87 % of the parameters) under the main bucket's all-reduce
-                if g3 is not None:
-                    g3.launch()
-                else:
-                    if hasattr(self.eng, 'gdot_fresh'):
-                        self.eng.gdot_fresh = self._main_leaves_gdot      # what the replayed backward pass has left
-                    self._update_tail()
-                self.ar.wait()
-                if self._graphs[3] is not None:
-                    self._graphs[3].launch()
-                else:
-                    self._update_rest()
-            else:
-                self.ar.wait()
+            self._main_leaves_gdot = False   # (the optimizer pieces are inside the graph: nothing reads the host flag)
+            self._graphs = ('whole', g)
+            self.capture_note = "captured: one graph per step, 2 all-reduces inside"
+            return True
+        except Exception as e:               # noqa: BLE001 -- whatever RCCL / HIP / torch raised during the capture
+            self.capture_note = "capture failed, split schedule kept: %s" % (repr(e)[:300],)
+            torch.cuda.synchronize()
+            return False
+
+    def _launch_dp(self):
+        if getattr(self, '_graph_fast', False) and not self.eng.P.norms_valid:
+            self._eager()
+            return
+        if self._graphs[0] == 'whole':
+            self._graphs[1].launch()
+            return
+        g1, g2, g3 = self._graphs[:3]
+        g1.launch()
+        self.ar.reduce_tail()       # hW-kernel bucket, overlaps the weight-gradient products of g2
+        g2.launch()
+        self.ar.reduce_main()
+        if self.split_update:
+            self.ar.wait_tail()
+            # Adam-WN of the hW kernel (87 % of the parameters) under the main bucket's all-reduce
+            if g3 is not None:
                 g3.launch()
+            else:
+                if hasattr(self.eng, 'gdot_fresh'):
+                    self.eng.gdot_fresh = self._main_leaves_gdot      # what the replayed backward pass has left
+                self._update_tail()
+            self.ar.wait()
+            if self._graphs[3] is not None:
+                self._graphs[3].launch()
+            else:
+                self._update_rest()
+        else:
+            self.ar.wait()
+            g3.launch()

@@ -620,3 +620,55 @@ def test_fit_from_lazy_windows_equals_fit_from_arrays(dev, tmp_path):
     for k in res[0][0]:
         np.testing.assert_array_equal(res[0][0][k], res[1][0][k], err_msg=k)
     assert res[0][1] == res[1][1]
+
+
+def test_dp_schedule_with_real_rccl_calls_tunes_itself_and_tries_capture(dev, monkeypatch):
+    """The data-parallel step with its two all-reduces issued for REAL (a one-rank RCCL group is all a one-GPU box has):
+    (a) TrainStep.tune_dp_schedule() times the coarse and the fine weight-gradient grid, keeps the faster and puts
+    parameters and optimizer state back; (b) the first capture tries ONE graph for the whole step, collectives included,
+    and either keeps it or notes why not and falls back to the split schedule; (c) either way four steps give the
+    weights of the plain single-graph step, bitwise (the average over one rank is the identity)."""
+    import torch.distributed as dist
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    cfg = O.vrnn_config(latent_dim=2, seq_length=12, n_classes=10, use_x_prev=True)
+    B, Tn = 8, 12
+    rng = np.random.default_rng(29)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=8).items()}
+    win = (rng.random((B, Tn + 1, 88)) < 0.05).astype(np.float32)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+    X, Xp, wt = t(win[:, 1:]), t(win[:, :-1]), t(np.eye(10)[rng.integers(0, 10, B)])
+
+    def run(ts, eng, n=4):
+        for _ in range(n):
+            ts.stage_batch(X, Xp, wt)
+            ts.step()
+        torch.cuda.synchronize()
+        return eng.P.get_weights()
+
+    eng = VrnnEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    plain = run(TrainStep(eng, seed=5), eng)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29619', rank=0, world_size=1)
+    try:
+        monkeypatch.setenv('CLV_FORCE_DP_GRAPHS', '1')
+        monkeypatch.setenv('CLV_DP_REAL_COLLECTIVES', '1')
+        eng = VrnnEngine(cfg, B, dev)
+        eng.P.set_weights(p)
+        ts = TrainStep(eng, seed=5)
+        assert ts.ar is not None and ts.ar.live and not eng.fine_grid
+        ts.stage_batch(X, Xp, wt)
+        trials = ts.tune_dp_schedule(steps=10)
+        assert set(trials) == {'coarse_ms', 'fine_ms', 'chosen'} and eng.fine_grid == (trials['chosen'] == 'fine')
+        assert int(eng.P.iterations.item()) == 0
+        for k, v in eng.P.get_weights().items():          # the trials left no trace
+            np.testing.assert_array_equal(v, np.asarray(p[k], np.float32))
+        got = run(ts, eng)
+        print("DP schedule on a one-rank RCCL group: trials %s; capture: %s" % (trials, ts.capture_note))
+        assert ts.capture_note is not None and (ts.capture_note.startswith('captured') or 'failed' in ts.capture_note)
+        if ts.capture_note.startswith('captured'):
+            assert ts._graphs[0] == 'whole'
+    finally:
+        dist.destroy_process_group()
+    for k in plain:
+        np.testing.assert_array_equal(got[k], plain[k], err_msg=k)

@@ -26,11 +26,11 @@ for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) * 2 + sum(w.
     short = re.sub(r'^void ', '', k).replace('clv::', '')
     rows.append(dict(kernel=short[:120], launches=len(fk), fetch_size_kb_avg=sum(fk) / len(fk), write_size_kb_avg=sum(wk) / len(wk),
                      hbm_read_bytes_corrected=2 * 1024 * sum(fk) / len(fk), hbm_write_bytes=1024 * sum(wk) / len(wk)))
-dom = [r for r in rows if re.match(r'lstm_(pair_)?(fwd|bwd)(_mfma)?_kernel', r['kernel'])]      # the kernels bench.py's roofline times
+dom = [r for r in rows if re.match(r'lstm_(pair_|mx_)?(fwd|bwd)(_mfma)?_kernel', r['kernel'])]      # the kernels bench.py's roofline times
 per_launch = sum(r['hbm_read_bytes_corrected'] + r['hbm_write_bytes'] for r in dom) / max(len(dom), 1)
 # steps the profiled run executed (set-up + warm-up + timed): the launch count of a kernel that runs once per LSTM pass
 # (bench.py's set-up steps changed in round 3; a number on the command line is only the fallback)
-per_step = {'lstm_pair_fwd_kernel': 1, 'lstm_fwd_mfma_kernel': 2, 'vae_fused_kernel': 1}
+per_step = {'lstm_pair_fwd_kernel': 1, 'lstm_mx_fwd_kernel': 2, 'lstm_fwd_mfma_kernel': 2, 'vae_fused_kernel': 1}
 steps = None
 for r in rows:
     for key, n in per_step.items():

@@ -7,8 +7,8 @@
 # PMC passes never carry another trace domain; the program after `--` is python3 itself.
 TAG=${1:-r02}; export TMPDIR=/tmp; R=$PWD; G=$R/gpurun_out; mkdir -p $G
 python bench.py > $G/${TAG}_bench_cfg3.json 2> $G/${TAG}_bench_cfg3.err
-python bench.py --no-cpu-baseline --kernel-times > /dev/null 2> $G/${TAG}_kernel_times_cfg3.txt
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $G/${TAG}_prof -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $G/${TAG}_prof.log 2>&1)
+python bench.py --no-cpu-baseline --no-also --kernel-times > /dev/null 2> $G/${TAG}_kernel_times_cfg3.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $G/${TAG}_prof -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-also > $G/${TAG}_prof.log 2>&1)
 cp $G/${TAG}_prof/p_kernel_stats.csv $G/${TAG}_kernel_stats_cfg3.csv
 for w in cfg5 cfg2; do
   python bench.py --workload $w --steps 200 --warmup 10 > $G/${TAG}_bench_$w.json 2> $G/${TAG}_bench_$w.err
