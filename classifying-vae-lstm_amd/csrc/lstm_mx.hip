@@ -47,19 +47,33 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (tools/mx_stamps.py); each stamp takes the value it follows as an operand, so it cannot move above its computation
 #ifdef MX_STAMPS
 __device__ unsigned long long g_mx_stamps[8][8][8];      // [step][wave][stamp]
+__device__ unsigned long long g_mx_pstamps[8][4];        // [step][producer sub-stamp]
 #define MXSTAMP(k, dep) asm volatile("s_memtime %0" : "=s"(mst[k]) : "v"(dep))
+#define MXPSTAMP(k, dep) asm volatile("s_memtime %0" : "=s"(pst[k]) : "v"(dep))
 #else
 #define MXSTAMP(k, dep)
+#define MXPSTAMP(k, dep)
 #endif
 
 constexpr int MX_R = 4;              // batch rows per workgroup
 constexpr int MX_KP = LH * 16 + 16;  // bytes per row of the K_x image [k][unit][gate]: 356 words = 36 mod 64, so the rows of the 16 (row,
                                      // piece) lane groups of a gather start on 16 different bank offsets (1408 B = 32 mod 64: two)
-constexpr int MX_HP = 208;           // bytes per (row, piece) line of the h image: 96 bf16 + 16 pad = 52 banks: the 16 lines of
-                                     // a ds_read_b128 lane group start at banks 52 n mod 64 = distinct multiples of 4
-constexpr int MX_ZP = 80;            // z image: 32 bf16 + 16 pad = 20 banks (same property)
-constexpr int MX_DP = 720;           // dz image (backward): 352 bf16 + 16 pad = 180 banks = 52 mod 64
-constexpr int MX_CAP = 96;           // note-list capacity per row
+// B-operand images (h, z pieces in the forward kernel, dz pieces in the backward kernel): a [16 columns] x [K] bf16 matrix
+// stored by CHUNKS of 8 k values: chunk kc is one 256-byte row of the LDS (all 64 banks), column n's 16 bytes sit in slot
+// mx_slot(n, kc).  A ds_read_b128 is served in four groups of 16 lanes that are NOT contiguous ({0-3,12-15,20-27}, ...:
+// MI355X_MICROARCH.md, LDS): every group holds each column n exactly once, half of them with one k group and half with
+// the next, so "a line of 208 bytes per column" (round-4's first layout) put 5 of a group's 16 lanes on a busy bank (SQ
+// counters: 50-54 % of the LDS cycles were conflict cycles, and the shader-clock stamps showed every wave waiting 530-860
+// cycles for its B operands at the top of a step).  With one bank row per chunk a group's 16 lanes read 16 different slots
+// whatever their k group.  The slot order (piece-major, rows xor-swapped on odd chunks) is chosen for the WRITERS: the
+// 16 lanes of a ds_write_b64 group of the backward kernel land on 16 different bank pairs.
+constexpr int MX_CHUNK = 256;        // bytes per chunk row
+constexpr int MX_HC = 12;            // chunks of the h image (K = 96)
+constexpr int MX_ZC = 4;             // chunks of the z image (K = 32)
+constexpr int MX_DC = 44;            // chunks of the dz image (K = 352)
+__device__ __forceinline__ int mx_slot_q(int r, int q, int kc) { return (((q ^ (kc & 1)) << 2) | r); }      // column n = 4 r + q
+constexpr int MX_CAP = 100;          // note-list stride per row (items): 800 bytes = 8 banks more than a multiple of 64, so the
+                                     // four rows' lists start on different banks (96 put all four on the same ones)
 constexpr int MX_FAST = 8;           // list entries handled without a loop (two rounds of the four piece lanes)
 constexpr int MX_PAD = 16;           // entries the producer always pads
 constexpr int MX_NXMAX = 96;
@@ -111,23 +125,39 @@ __device__ __forceinline__ void mx_store(float v, mx_rsrc_t r, unsigned voff, un
 // ---------------------------------------------------------------------------------------------------------------------
 // forward.  8 waves; wave w < 7 owns three tiles = the units 12w .. 12w+11 (tile tl: units 12w + 3 j + tl, j = 0..3, so
 // that after the butterfly the piece lanes p = 0, 1, 2 of a quad own three CONSECUTIVE units: 12-byte pieces per quad
-// in every per-step store instead of isolated floats); wave 7 owns the units 84..87 (one tile) and is the PRODUCER:
-// frames -> note lists (two steps ahead), z_t -> bf16 pieces in the B-operand image (one step ahead).
+// in every per-step store instead of isolated floats); wave 7 owns the units 84..87 (one tile).  Wave 0 also turns the
+// frames into note lists (two steps ahead), wave 1 the latent inputs z_t into bf16 pieces (one step ahead).
 // Batch rows beyond B (the last workgroup of a batch that is no multiple of four) are clones of row B-1: same inputs,
 // same values, same addresses -- every access stays unconditional.
+//
+// Order of a step (shader-clock stamps, tools/mx_stamps.py, decided it): the B operands are requested FIRST and alone --
+// with the gather's kernel rows requested next to them every wave waited 530-860 cycles at the top of a step for the LDS
+// to work through 8 waves x 9 conflicted ds_read_b128; the rows are requested behind the MFMAs instead and come back
+// under the butterfly and the gate math, their FMAs are the last thing before the barrier.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int GATE, bool HASZ, int NT, bool PROD>
+// ROLE: what a wave does besides its tiles -- bit 0: frames -> note lists (two steps ahead), bit 1: z_t -> pieces in the
+// B-operand image (one step ahead).  The stamps showed a step's length to be the instruction count of its longest
+// wave (~5 cycles per instruction of a wave, whatever the instruction): with both jobs in the one-tile wave 7 that wave
+// ran ~400 instructions per step (2770 cycles) while waves 0-3 sat at the barrier after 1500; the jobs now ride in
+// waves 0 and 1, which are the first to be served on their SIMDs (decoder: lists in wave 7, z pieces in wave 1).
+template <int GATE, bool HASZ, bool HASX, int NT, int ROLE>
 __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int ubase) {
+  // HASX is a template parameter, not `a.nx > 0`: requests under a run-time branch, even a uniform one, count as "maybe
+  // not issued" in the compiler's vmcnt bookkeeping, and the wait for the frames requested two steps ago then also waited
+  // for the stores of the previous step -- 980 cycles per step in the producer wave (tools/mx_stamps.py)
+  constexpr bool PROD = (ROLE & 1) != 0, ZPROD = (ROLE & 2) != 0 && HASZ;
   const int lane = threadIdx.x & 63;
   const int ul = lane >> 4, n = lane & 15, r = n >> 2, p = n & 3;
   const int T = a.T;
   const int row0 = blockIdx.x * MX_R;
+  const int nrows = min(MX_R, a.B - row0);
   char* Kimg = lds;
   const int zero_off = a.nx * MX_KP;
-  char* hB = lds + (a.nx + 1) * MX_KP;
-  char* zB = hB + 2 * 16 * MX_HP;
-  MxItem* lists = reinterpret_cast<MxItem*>(zB + 2 * 16 * MX_ZP);
-  int* maxcount = reinterpret_cast<int*>(lists + 2 * MX_R * MX_CAP);
+  char* hB = lds + (a.nx + 1) * MX_KP;                       // [2][MX_HC chunks][256]
+  char* zB = hB + 2 * MX_HC * MX_CHUNK;                      // [2][MX_ZC chunks][256]
+  MxItem* lists = reinterpret_cast<MxItem*>(zB + 2 * MX_ZC * MX_CHUNK);      // [2][4 rows][MX_CAP]
+  MxItem* dump = lists + 2 * MX_R * MX_CAP;                  // [64]: where a producer lane without a note writes
+  int* counts = reinterpret_cast<int*>(dump + 64);           // [2][4]
 
   // ---- A operands: the three pieces of U (and K_z) for this wave's tiles, resident in registers ---------------------
   // lane l holds row m = l & 15 = (unit ubase + NT (m >> 2) + tl, gate m & 3) and k = 32 s + 8 (l >> 4) + e, e = 0..7
@@ -163,11 +193,10 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   }
 
   // ---- per-lane constants --------------------------------------------------------------------------------------------
-  const size_t rowc = (size_t)min(row0 + r, a.B - 1);
+  const unsigned rloc = (unsigned)min(r, nrows - 1);
+  const size_t rowc = (size_t)row0 + rloc;
   // accumulator layout (before the butterfly): tile tl, register i = gate i of unit ubase + NT ul + tl, for (row r, piece p)
-  int ucol[NT];
-#pragma unroll
-  for (int tl = 0; tl < NT; ++tl) ucol[tl] = (ubase + NT * ul + tl) * 16;
+  const int ucol0 = (ubase + NT * ul) * 16;                    // tile tl: + 16 tl
   // after the butterfly this lane finishes tile tp of its wave: unit `unit` of row r (p == 3: a second copy of p == 2;
   // one tile: all four lanes hold the same cell)
   const int tp = NT == 3 ? min(p, 2) : 0;
@@ -177,106 +206,120 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   for (int i = 0; i < 4; ++i) rb[i] = a.rowbias ? a.rowbias[rowc * LG + i * LH + unit] : 0.f;
   const bool even = !(p & 1), lo = !(p & 2);
   float c = 0.f;
-  float* hs_p = a.hs + rowc * T * LH + unit;
-  float* coef_p = a.coef + rowc * T * LG + unit;
-  float* aux_p = a.aux + rowc * T * 2 * LH + unit;
-  // h pieces -> B-operand image: line 4 r + q, k = unit
-  const int hw_off = (4 * r) * MX_HP + 2 * unit;
-
-  // ---- producer state (wave 7) ---------------------------------------------------------------------------------------
-  float fr[2][MX_R][2];      // two register sets of frames in flight (set = step parity)
-  float zr[2][2];            // ... and of z pairs
-  const int zrow = lane >> 4, zlat = 2 * (lane & 15);
-  auto load_frames = [&](float (&f)[MX_R][2], int t) {
-    const int tc = min(t, T - 1);
+  // per-step stores: buffer instructions, the step's row offset in an SGPR (no vector address arithmetic)
+  const mx_rsrc_t r_c = mx_rsrc(a.coef + (size_t)row0 * T * LG, (size_t)nrows * T * LG * 4);
+  const mx_rsrc_t r_a = mx_rsrc(a.aux + (size_t)row0 * T * 2 * LH, (size_t)nrows * T * 2 * LH * 4);
+  const mx_rsrc_t r_h = mx_rsrc(a.hs + (size_t)row0 * T * LH, (size_t)nrows * T * LH * 4);
+  const unsigned v_c = (rloc * T * LG + unit) * 4u, v_a = (rloc * T * 2 * LH + unit) * 4u, v_h = (rloc * T * LH + unit) * 4u;
+  // h pieces -> B-operand image: chunk unit / 8, slot of column 4 r + q, element unit % 8
+  int hw_off[3];
 #pragma unroll
-    for (int rr = 0; rr < MX_R; ++rr) {
-      const float* fp = a.X + ((size_t)min(row0 + rr, a.B - 1) * T + tc) * a.ldx;
-      f[rr][0] = fp[min(lane, a.nx - 1)];            // raw: nothing may touch a requested value before its consumer does
-      f[rr][1] = fp[min(lane + 64, a.nx - 1)];       // (a select here is a wait for the load right behind its issue)
-    }
-  };
+  for (int q = 0; q < 3; ++q) hw_off[q] = (unit >> 3) * MX_CHUNK + mx_slot_q(r, q, unit >> 3) * 16 + 2 * (unit & 7);
+  // B-operand reads: column n = 4 r + p of chunk 4 s + (lane >> 4)
+  const int kg = lane >> 4;
+  const int b_off = kg * MX_CHUNK + mx_slot_q(r, p, kg) * 16;     // + s * 4 * MX_CHUNK (chunk parity = kg & 1)
+
+  // ---- producer (wave 0): lane = (row pr = lane >> 4, j = lane & 15) takes the columns 6 j .. 6 j + 5 of its row ------
+  // Branch-free: per-lane note count, exclusive prefix over the row's 16 lanes by four DPP row shifts, six stores whose
+  // address is the list slot or the lane's dump slot.  (Round 4's first version walked the rows one after the other with
+  // ballots and stores under divergent branches: 1340 cycles of the producer's 2650-cycle step, with every other wave
+  // parked at the barrier for 500-1200 cycles.)
+  constexpr int PC = 6;
+#ifdef MX_STAMPS
+  unsigned long long pst[4] = {0, 0, 0, 0};
+#endif
+  const int pr = lane >> 4, pj = lane & 15;
+  float fr[2][PC];           // two register sets of frame values in flight (set = step parity)
+  float zr[2][2];            // ... and of z pairs
+  const int zlat = 2 * pj;
+  auto load_frames = [&](float (&f)[PC], int t) {
+    const float* fp = a.X + ((size_t)min(row0 + pr, a.B - 1) * T + min(t, T - 1)) * a.ldx;
+#pragma unroll
+    for (int i = 0; i < PC; ++i) f[i] = fp[min(PC * pj + i, a.nx - 1)];      // raw: nothing touches a requested value before
+  };                                                                          // its consumer does
   auto load_z = [&](float (&z)[2], int t) {
-    const int tc = min(t, T - 1);
-    const float* zp = a.Z + ((size_t)min(row0 + zrow, a.B - 1) * T + tc) * a.ldz;
+    const float* zp = a.Z + ((size_t)min(row0 + pr, a.B - 1) * T + min(t, T - 1)) * a.ldz;
     z[0] = zp[min(zlat, a.nz - 1)];
     z[1] = zp[min(zlat + 1, a.nz - 1)];
   };
-  auto compact = [&](const float (&fraw)[MX_R][2], int buf) {      // frames -> lists[buf], maxcount[buf]
-    float f[MX_R][2];
+  auto compact = [&](const float (&f)[PC], int buf) {      // frame of row pr -> lists[buf][pr], counts[buf][pr]
+    MxItem* L = lists + (buf * MX_R + pr) * MX_CAP;
+    const MxItem padding = MxItem{zero_off, 0.f};
+    L[pj] = padding;                                       // slots 0..15 (LDS operations of a wave are in order)
+    bool on[PC];
+    int cnt = 0;
 #pragma unroll
-    for (int rr = 0; rr < MX_R; ++rr) {
-      f[rr][0] = lane < a.nx ? fraw[rr][0] : 0.f;
-      f[rr][1] = lane + 64 < a.nx ? fraw[rr][1] : 0.f;
+    for (int i = 0; i < PC; ++i) {
+      on[i] = PC * pj + i < a.nx && f[i] != 0.f;
+      cnt += on[i] ? 1 : 0;
     }
-    MxItem* L = lists + buf * MX_R * MX_CAP;
-    L[(lane >> 4) * MX_CAP + (lane & 15)] = MxItem{zero_off, 0.f};       // padding first (LDS operations of a wave are in order)
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int mx = 0;
-    int cnt[MX_R];
+    MXPSTAMP(0, cnt);                                      // the frame values are here
+    int incl = cnt;                                        // inclusive prefix over the 16 lanes of the row
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);     // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);     // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);     // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);     // row_shr:8
+    const int total = __builtin_amdgcn_ds_bpermute((lane | 15) << 2, incl);  // the row's last lane holds its count
+    MXPSTAMP(1, total);
+    int pos = incl - cnt;
+    MxItem* mine = dump + lane;
 #pragma unroll
-    for (int rr = 0; rr < MX_R; ++rr) {
-      const unsigned long long m0 = __ballot(f[rr][0] != 0.f), m1 = __ballot(f[rr][1] != 0.f);
-      const int n0 = __popcll(m0);
-      if (f[rr][0] != 0.f) L[rr * MX_CAP + __popcll(m0 & lt)] = MxItem{lane * MX_KP, f[rr][0]};
-      if (f[rr][1] != 0.f) L[rr * MX_CAP + n0 + __popcll(m1 & lt)] = MxItem{(lane + 64) * MX_KP, f[rr][1]};
-      cnt[rr] = n0 + __popcll(m1);
-      mx = max(mx, cnt[rr]);
+    for (int i = 0; i < PC; ++i) {
+      MxItem* at = on[i] ? L + pos : mine;
+      *at = MxItem{(PC * pj + i) * MX_KP, f[i]};
+      pos += on[i] ? 1 : 0;
     }
-    if (mx > MX_PAD) {       // dense frames: pad every row up to the longest list (rounded up to a round of four)
-      const int upto = (mx + 3) & ~3;
-#pragma unroll
-      for (int rr = 0; rr < MX_R; ++rr)
-        for (int j = max(cnt[rr], MX_PAD) + lane; j < upto; j += 64) L[rr * MX_CAP + j] = MxItem{zero_off, 0.f};
-    }
-    if (lane == 0) maxcount[buf] = mx;
+    // beyond 16 notes: pad up to the next round of four (a row's consumers walk its own count)
+    MxItem* tail = (total >= MX_PAD && pj < ((total + 3) & ~3) - total) ? L + total + pj : mine;
+    *tail = padding;
+    if (pj == 0) counts[buf * MX_R + pr] = total;
+    MXPSTAMP(2, pos);
   };
   auto stage_z = [&](const float (&z)[2], int buf) {           // z pair -> three piece images, 4 bytes each
     __bf16 p0[3], p1[3];
     split3(zlat < a.nz ? z[0] : 0.f, p0);
     split3(zlat + 1 < a.nz ? z[1] : 0.f, p1);
-    char* at = zB + buf * 16 * MX_ZP + (4 * zrow) * MX_ZP + 2 * zlat;
+    const int kc = zlat >> 3;
+    char* at = zB + buf * MX_ZC * MX_CHUNK + kc * MX_CHUNK + 2 * (zlat & 7);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      *reinterpret_cast<unsigned*>(at + q * MX_ZP) = (unsigned)bf16_bits(p0[q]) | ((unsigned)bf16_bits(p1[q]) << 16);
+      *reinterpret_cast<unsigned*>(at + mx_slot_q(pr, q, kc) * 16) = (unsigned)bf16_bits(p0[q]) | ((unsigned)bf16_bits(p1[q]) << 16);
   };
 
-  // next step's input contribution in the accumulator layout: lane p takes the notes p, p + 4, ... of its row.  The
-  // reads (two dependent LDS round trips: list entry -> kernel row) are issued AHEAD of the step's MFMAs, the FMAs
-  // behind them.
+  // next step's input contribution in the accumulator layout: lane p takes the notes p, p + 4, ... of its row
   float xinit[NT][4];
-  struct Rows { float v[MX_FAST / 4]; float4 k[MX_FAST / 4][NT]; };
-  auto gather_items = [&](int buf, MxItem (&items)[MX_FAST / 4]) {
+  struct Rows { float v[2]; float4 k[2][NT]; int cnt; };
+  auto gather_items = [&](int buf, MxItem (&items)[2], int& cnt) {
     const MxItem* Lr = lists + (buf * MX_R + r) * MX_CAP;
-#pragma unroll
-    for (int rd = 0; rd < MX_FAST / 4; ++rd) items[rd] = Lr[p + 4 * rd];
+    items[0] = Lr[p];
+    items[1] = Lr[p + 4];
+    cnt = counts[buf * MX_R + r];
   };
-  auto gather_rows = [&](const MxItem (&items)[MX_FAST / 4], Rows& g) {
+  auto gather_rows = [&](const MxItem (&items)[2], int cnt, Rows& g) {
+    g.cnt = cnt;
+    g.v[0] = items[0].v; g.v[1] = items[1].v;
 #pragma unroll
-    for (int rd = 0; rd < MX_FAST / 4; ++rd) {
-      g.v[rd] = items[rd].v;
-#pragma unroll
-      for (int tl = 0; tl < NT; ++tl) g.k[rd][tl] = *reinterpret_cast<const float4*>(Kimg + items[rd].koff + ucol[tl]);
+    for (int tl = 0; tl < NT; ++tl) {
+      g.k[0][tl] = *reinterpret_cast<const float4*>(Kimg + items[0].koff + ucol0 + 16 * tl);
+      g.k[1][tl] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (cnt > 4) {                 // a second round only for the rows that have one (65 % of piano-roll frames do not):
+#pragma unroll                     // fewer active lanes = fewer LDS cycles
+      for (int tl = 0; tl < NT; ++tl) g.k[1][tl] = *reinterpret_cast<const float4*>(Kimg + items[1].koff + ucol0 + 16 * tl);
     }
   };
   auto gather_finish = [&](int buf, const Rows& g) {
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
-      xinit[tl][0] = g.v[0] * g.k[0][tl].x; xinit[tl][1] = g.v[0] * g.k[0][tl].y;
-      xinit[tl][2] = g.v[0] * g.k[0][tl].z; xinit[tl][3] = g.v[0] * g.k[0][tl].w;
-#pragma unroll
-      for (int rd = 1; rd < MX_FAST / 4; ++rd) {
-        xinit[tl][0] = fmaf(g.v[rd], g.k[rd][tl].x, xinit[tl][0]); xinit[tl][1] = fmaf(g.v[rd], g.k[rd][tl].y, xinit[tl][1]);
-        xinit[tl][2] = fmaf(g.v[rd], g.k[rd][tl].z, xinit[tl][2]); xinit[tl][3] = fmaf(g.v[rd], g.k[rd][tl].w, xinit[tl][3]);
-      }
+      xinit[tl][0] = fmaf(g.v[1], g.k[1][tl].x, g.v[0] * g.k[0][tl].x); xinit[tl][1] = fmaf(g.v[1], g.k[1][tl].y, g.v[0] * g.k[0][tl].y);
+      xinit[tl][2] = fmaf(g.v[1], g.k[1][tl].z, g.v[0] * g.k[0][tl].z); xinit[tl][3] = fmaf(g.v[1], g.k[1][tl].w, g.v[0] * g.k[0][tl].w);
     }
-    const int mc = __builtin_amdgcn_readfirstlane(maxcount[buf]);
     const MxItem* Lr = lists + (buf * MX_R + r) * MX_CAP;
-    for (int j = MX_FAST; j < mc; j += 4) {           // denser frames (rare for piano-rolls)
+    for (int j = MX_FAST; j < g.cnt; j += 4) {        // denser frames (rare for piano-rolls); a row walks its own count
       const MxItem it = Lr[j + p];
 #pragma unroll
       for (int tl = 0; tl < NT; ++tl) {
-        const float4 kr = *reinterpret_cast<const float4*>(Kimg + it.koff + ucol[tl]);
+        const float4 kr = *reinterpret_cast<const float4*>(Kimg + it.koff + ucol0 + 16 * tl);
         xinit[tl][0] = fmaf(it.v, kr.x, xinit[tl][0]); xinit[tl][1] = fmaf(it.v, kr.y, xinit[tl][1]);
         xinit[tl][2] = fmaf(it.v, kr.z, xinit[tl][2]); xinit[tl][3] = fmaf(it.v, kr.w, xinit[tl][3]);
       }
@@ -285,7 +328,7 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
 
   // ---- prologue ------------------------------------------------------------------------------------------------------
   if (PROD) {
-    if (a.nx > 0) {
+    if (HASX) {
       load_frames(fr[0], 0);
       load_frames(fr[1], 1);
       compact(fr[0], 0);
@@ -294,21 +337,22 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
       load_frames(fr[1], 3);
     } else {
       for (int j = lane; j < 2 * MX_R * MX_CAP; j += 64) lists[j] = MxItem{zero_off, 0.f};
-      if (lane < 2) maxcount[lane] = 0;                         // never rewritten: every list is padding
+      if (lane < 2 * MX_R) counts[lane] = 0;                    // never rewritten: every list is padding
     }
-    if (HASZ) {
-      load_z(zr[0], 0);
-      stage_z(zr[0], 0);
-      load_z(zr[0], 1);       // set 0: z_{t+1} of step 0;  set 1: of step 1
-      load_z(zr[1], 2);
-    }
+  }
+  if (ZPROD) {
+    load_z(zr[0], 0);
+    stage_z(zr[0], 0);
+    load_z(zr[0], 1);       // set 0: z_{t+1} of step 0;  set 1: of step 1
+    load_z(zr[1], 2);
   }
   __syncthreads();
   {
     Rows g;
-    MxItem items[MX_FAST / 4];
-    gather_items(0, items);
-    gather_rows(items, g);
+    MxItem items[2];
+    int cnt;
+    gather_items(0, items, cnt);
+    gather_rows(items, cnt, g);
     gather_finish(0, g);
   }
   // every load of the prologue has landed before the loop is entered (the wait-count bookkeeping merges the loop-entry
@@ -318,23 +362,21 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
 
   auto step = [&](int t, auto PAR) {
     constexpr int cur = decltype(PAR)::value;
-    // LDS reads in the order they are needed: the list entries of the NEXT step's inputs (their kernel rows are a second,
-    // dependent round trip), this step's B operands = pieces of h_{t-1} (and z_t), then the kernel rows, which come back
-    // under the MFMAs
-    Rows g;
-    MxItem items[MX_FAST / 4];
 #ifdef MX_STAMPS
     unsigned long long mst[8];
+    mst[7] = 0;
 #endif
     MXSTAMP(0, c);
-    if (!(MX_ABL & 4)) gather_items(cur ^ 1, items);
-    const char* hb = hB + cur * 16 * MX_HP + n * MX_HP + (lane >> 4) * 16;
+    // B operands first: pieces of h_{t-1} (and z_t); then the (small) list entries of the NEXT step's inputs
+    const char* hb = hB + cur * MX_HC * MX_CHUNK + b_off;
     bf16x8 bh[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bh[s] = *reinterpret_cast<const bf16x8*>(hb + 64 * s);
+    for (int s = 0; s < 3; ++s) bh[s] = *reinterpret_cast<const bf16x8*>(hb + s * 4 * MX_CHUNK);
     bf16x8 bz;
-    if (HASZ) bz = *reinterpret_cast<const bf16x8*>(zB + cur * 16 * MX_ZP + n * MX_ZP + (lane >> 4) * 16);
-    if (!(MX_ABL & 4)) gather_rows(items, g);
+    if (HASZ) bz = *reinterpret_cast<const bf16x8*>(zB + cur * MX_ZC * MX_CHUNK + b_off);
+    MxItem items[2];
+    int cnt = 0;
+    if (!(MX_ABL & 4)) gather_items(cur ^ 1, items, cnt);
     MXSTAMP(1, bh[2][0]);                           // the B operands are here
     f32x4v acc[NT];
 #pragma unroll
@@ -352,14 +394,14 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Az[tl][q], bz, acc[tl], 0, 0, 0);
     }
+    // the kernel rows of the next step's notes: requested behind the MFMAs, back under the butterfly and the gate math
+    Rows g;
+    if (!(MX_ABL & 4)) gather_rows(items, cnt, g);
     MXSTAMP(2, acc[NT - 1][0]);                     // the last MFMA's result is here
-    // work that does not depend on the recurrence: the producer's lists / z image, next step's input contribution
-    if (PROD && !(MX_ABL & 1)) {
-      if (a.nx > 0) compact(fr[cur], cur);     // frame t + 2 -> the list buffer step t - 1 finished with
-      if (HASZ) stage_z(zr[cur], cur ^ 1);     // z_{t+1}
-    }
-    if (!(MX_ABL & 4)) gather_finish(cur ^ 1, g);
-    MXSTAMP(3, xinit[0][0]);
+    // the producer's lists / z image for later steps
+    if (PROD && HASX && !(MX_ABL & 1)) compact(fr[cur], cur);     // frame t + 2 -> the list buffer step t - 1 finished with
+    if (ZPROD && !(MX_ABL & 1)) stage_z(zr[cur], cur ^ 1);            // z_{t+1}
+    MXSTAMP(3, acc[0][1]);
     // butterfly over the piece lanes: sums the pieces (and the note shares) and deals the tiles to the lanes
     float z[4];
 #pragma unroll
@@ -386,41 +428,45 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     const float tc = fast_tanh(c);
     const float h = og * tc;
     MXSTAMP(5, h);
-    if (!(MX_ABL & 2)) {
-      const size_t o = (MX_ABL & 16) ? 0 : (size_t)t;
-      coef_p[o * LG] = gg * gate_grad<GATE>(z[0], ig);
-      coef_p[o * LG + LH] = kf;
-      coef_p[o * LG + 2 * LH] = ig * (1.f - gg * gg);
-      coef_p[o * LG + 3 * LH] = tc * gate_grad<GATE>(z[3], og);
-      aux_p[o * 2 * LH] = fg;
-      aux_p[o * 2 * LH + LH] = og * (1.f - tc * tc);
-      hs_p[o * LH] = h;
-    }
-    {
+    {          // h pieces first: they are what the next step of EVERY wave waits for
       __bf16 hp[3];
       split3(h, hp);
-      char* at = hB + (cur ^ 1) * 16 * MX_HP + hw_off;
+      char* at = hB + (cur ^ 1) * MX_HC * MX_CHUNK;
       if (NT == 3) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned short*>(at + q * MX_HP) = bf16_bits(hp[q]);
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned short*>(at + hw_off[q]) = bf16_bits(hp[q]);
       } else {             // four lanes hold the same h: lane p writes piece min(p, 2)
         const __bf16 mine = p == 0 ? hp[0] : (p == 1 ? hp[1] : hp[2]);
-        *reinterpret_cast<unsigned short*>(at + min(p, 2) * MX_HP) = bf16_bits(mine);
+        const int off = p == 0 ? hw_off[0] : (p == 1 ? hw_off[1] : hw_off[2]);
+        *reinterpret_cast<unsigned short*>(at + off) = bf16_bits(mine);
       }
     }
+    if (!(MX_ABL & 2)) {
+      const unsigned tt = (MX_ABL & 16) ? 0u : (unsigned)t;
+      mx_store(gg * gate_grad<GATE>(z[0], ig), r_c, v_c, tt * (LG * 4));
+      mx_store(kf, r_c, v_c + LH * 4, tt * (LG * 4));
+      mx_store(ig * (1.f - gg * gg), r_c, v_c + 2 * LH * 4, tt * (LG * 4));
+      mx_store(tc * gate_grad<GATE>(z[3], og), r_c, v_c + 3 * LH * 4, tt * (LG * 4));
+      mx_store(fg, r_a, v_a, tt * (2 * LH * 4));
+      mx_store(og * (1.f - tc * tc), r_a, v_a + LH * 4, tt * (2 * LH * 4));
+      mx_store(h, r_h, v_h, tt * (LH * 4));
+    }
+    if (!(MX_ABL & 4)) gather_finish(cur ^ 1, g);
     // the producer's requests for two steps ahead, BEHIND the last use of the register set they land in (issued ahead of
     // it they need fresh registers, and the copies back at the loop's end wait for the loads just issued: every step
     // then costs a trip to HBM -- lstm_pair.hip)
-    if (PROD && !(MX_ABL & 1)) {
-      if (a.nx > 0) load_frames(fr[cur], t + 4);
-      if (HASZ) load_z(zr[cur], t + 3);
-    }
+    if (PROD && HASX && !(MX_ABL & 1)) load_frames(fr[cur], t + 4);
+    if (ZPROD && !(MX_ABL & 1)) load_z(zr[cur], t + 3);
 #ifdef MX_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mst[6]));          // arrival at the barrier
     if (blockIdx.x == 0 && lane == 0 && t >= 64 && t < 72) {
       const int wv = threadIdx.x >> 6;
 #pragma unroll
       for (int k = 0; k < 7; ++k) g_mx_stamps[t - 64][wv][k] = mst[k];
+      if (PROD) {
+        g_mx_pstamps[t - 64][0] = pst[0] - mst[2]; g_mx_pstamps[t - 64][1] = pst[1] - pst[0];
+        g_mx_pstamps[t - 64][2] = pst[2] - pst[1]; g_mx_pstamps[t - 64][3] = mst[3] - pst[2];
+      }
     }
 #endif
     step_barrier();
@@ -436,7 +482,11 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   if (t < T) step(t, P0{});
 }
 
-template <int GATE, bool HASZ>
+constexpr size_t mx_fwd_lds(int nx) {
+  return (size_t)(nx + 1) * MX_KP + 2 * MX_HC * MX_CHUNK + 2 * MX_ZC * MX_CHUNK + (2 * MX_R * MX_CAP + 64) * sizeof(MxItem) + 2 * MX_R * 4;
+}
+
+template <int GATE, bool HASZ, bool HASX>
 __global__ __launch_bounds__(512) void lstm_mx_fwd_kernel(MxFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char mx_lds[];
   const int tid = threadIdx.x;
@@ -450,13 +500,17 @@ __global__ __launch_bounds__(512) void lstm_mx_fwd_kernel(MxFwdArgs a) {
       Kimg[k * (MX_KP / 4) + u * 4 + g] = a.Kx[i];
     }
     float* rest = Kimg + a.nx * (MX_KP / 4);
-    const int tail = (MX_KP + 2 * 16 * MX_HP + 2 * 16 * MX_ZP) / 4;      // zero row, h image, z image
+    const int tail = (MX_KP + 2 * MX_HC * MX_CHUNK + 2 * MX_ZC * MX_CHUNK) / 4;      // zero row, h images, z images
     for (int i = tid; i < tail; i += 512) rest[i] = 0.f;
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave < 7) mx_fwd_body<GATE, HASZ, 3, false>(a, mx_lds, 12 * wave);
-  else mx_fwd_body<GATE, HASZ, 1, true>(a, mx_lds, 84);
+  // encoder (no z): the note lists in wave 0 (first served on its SIMD, done 1300 cycles before the step ends); decoder:
+  // both jobs in the one-tile wave 7 -- a three-tile wave that also holds K_z has no registers left for values in
+  // flight (the z job in wave 1 spilled two registers per step, the frames in wave 0 eight)
+  if (wave == 0) mx_fwd_body<GATE, HASZ, HASX, 3, HASZ ? 0 : 1>(a, mx_lds, 0);
+  else if (wave < 7) mx_fwd_body<GATE, HASZ, HASX, 3, 0>(a, mx_lds, 12 * wave);
+  else mx_fwd_body<GATE, HASZ, HASX, 1, HASZ ? 3 : 0>(a, mx_lds, 84);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -510,12 +564,12 @@ __device__ __forceinline__ void mx_split4(const float (&x)[4], uint2 (&piece)[3]
 
 // dz_{t+1} (image `buf`) . the tile's rows; the butterfly leaves lane (ul, r, p) with row 4 ul + p of the tile
 __device__ __forceinline__ float mx_bwd_matvec(const char* dzB, int buf, const bf16x8 (&Ar)[11][3]) {
-  const int lane = threadIdx.x & 63, n = lane & 15, p = n & 3;
+  const int lane = threadIdx.x & 63, n = lane & 15, p = n & 3, kg = lane >> 4;
   const bool even = !(p & 1), lo = !(p & 2);
-  const char* bp = dzB + buf * 16 * MX_DP + n * MX_DP + (lane >> 4) * 16;
+  const char* bp = dzB + buf * MX_DC * MX_CHUNK + kg * MX_CHUNK + mx_slot_q(n >> 2, p, kg) * 16;
   bf16x8 b[11];
 #pragma unroll
-  for (int s = 0; s < 11; ++s) b[s] = *reinterpret_cast<const bf16x8*>(bp + 64 * s);
+  for (int s = 0; s < 11; ++s) b[s] = *reinterpret_cast<const bf16x8*>(bp + s * 4 * MX_CHUNK);
   f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 11; ++s)
@@ -549,8 +603,12 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
   const unsigned v_c = valid ? (rloc * T * LG + u) * 4u : MX_OOB;
   const unsigned v_a = valid ? (rloc * T * 2 * LH + u) * 4u : MX_OOB;
   const unsigned v_d = valid ? (rloc * T * LH + u) * 4u : MX_OOB;
-  // dz pieces: line 4 r + q, k = 4 u + gate: 8 bytes; a lane without a unit writes into the line's padding
-  const int dzl_off = (4 * r) * MX_DP + (valid ? 8 * u : 2 * LG);
+  // dz pieces: k = 4 u + gate: chunk u / 2, the lane's four gates are 8 contiguous bytes; a lane without a unit writes to
+  // its own dump slot behind the images
+  int dzl_off[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    dzl_off[q] = valid ? (u >> 1) * MX_CHUNK + mx_slot_q(r, q, u >> 1) * 16 + (u & 1) * 8 : 2 * MX_DC * MX_CHUNK + (int)(threadIdx.x & 63) * 8;
 
   // Two register sets, the loop body is two steps: the coefficients of step t are requested at the end of step t + 2,
   // behind the last use of the set they land in (lstm_pair.hip).  An odd T runs one step more: step t = -1 lies beyond
@@ -580,17 +638,17 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
     float dz[4];
     dz[0] = dc * k.ki; dz[1] = dc * k.kf; dz[2] = dc * k.kg; dz[3] = dh * k.ko;
     dc *= k.kcarry;
-    char* at = dzB + par * 16 * MX_DP + dzl_off;
+    char* at = dzB + (valid ? par * MX_DC * MX_CHUNK : 0);
+    uint2 pc[3];
+    mx_split4(dz, pc);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (!(MX_ABL & 256)) *reinterpret_cast<uint2*>(at + dzl_off[q]) = pc[q];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       zs[g] += dz[g];
       if (!(MX_ABL & 64)) mx_store(dz[g], r_c, v_c + g * LH * 4, (unsigned)t * (LG * 4));
     }
-    uint2 pc[3];
-    mx_split4(dz, pc);
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (!(MX_ABL & 256)) *reinterpret_cast<uint2*>(at + q * MX_DP) = pc[q];
     if (!(MX_ABL & 32)) load_set(k, t - 2);
     step_barrier();
   };
@@ -639,10 +697,10 @@ __device__ __forceinline__ void mx_bwd_latents(const MxBwdArgs& a, char* dzB, in
 
 template <int ZT>
 __global__ __launch_bounds__((6 + ZT) * 64) void lstm_mx_bwd_kernel(MxBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char dzB[2 * 16 * MX_DP];
+  __shared__ __attribute__((aligned(16))) char dzB[2 * MX_DC * MX_CHUNK + 64 * 8];       // two images + the dump slots
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 2 * 16 * MX_DP / 4; i += (6 + ZT) * 64) reinterpret_cast<float*>(dzB)[i] = 0.f;
+  for (int i = tid; i < (2 * MX_DC * MX_CHUNK + 64 * 8) / 4; i += (6 + ZT) * 64) reinterpret_cast<float*>(dzB)[i] = 0.f;
   if (ZT > 0 && wave >= 6) mx_bwd_latents(a, dzB, wave - 6);
   else mx_bwd_units(a, dzB, wave);
 }
@@ -657,6 +715,9 @@ static bool mx_auto(int B) {
 #ifdef MX_STAMPS
 extern "C" int clv_debug_mx_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_mx_stamps), sizeof(unsigned long long) * 8 * 8 * 8);
+}
+extern "C" int clv_debug_mx_pstamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_mx_pstamps), sizeof(unsigned long long) * 8 * 4);
 }
 #endif
 
@@ -676,17 +737,22 @@ extern "C" int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_mx_fwd", s);
   MxFwdArgs a{B, T, X, ldx, nx, Kx, Z, ldz, nz, Kz, rowbias, U, hs, coef, aux};
-  const size_t lds = (size_t)(nx + 1) * MX_KP + 2 * 16 * MX_HP + 2 * 16 * MX_ZP + 2 * MX_R * MX_CAP * sizeof(MxItem) + 16;
+  const size_t lds = mx_fwd_lds(nx);
   const dim3 grid((B + MX_R - 1) / MX_R), block(512);
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
-#define MX_LAUNCH(G, Zf)                                                                      \
+#define MX_LAUNCH(G, Zf, Xf)                                                                  \
   do {                                                                                        \
-    auto kern = lstm_mx_fwd_kernel<G, Zf>;                                                    \
+    auto kern = lstm_mx_fwd_kernel<G, Zf, Xf>;                                                \
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds)) return e;   \
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);                                         \
   } while (0)
-  if (nz > 0) { if (hard) MX_LAUNCH(CLV_GATE_HARD_SIGMOID, true); else MX_LAUNCH(CLV_GATE_SIGMOID, true); }
-  else { if (hard) MX_LAUNCH(CLV_GATE_HARD_SIGMOID, false); else MX_LAUNCH(CLV_GATE_SIGMOID, false); }
+#define MX_LAUNCH_G(G)                                                                        \
+  do {                                                                                        \
+    if (nz > 0) { if (nx > 0) MX_LAUNCH(G, true, true); else MX_LAUNCH(G, true, false); }     \
+    else { if (nx > 0) MX_LAUNCH(G, false, true); else MX_LAUNCH(G, false, false); }          \
+  } while (0)
+  if (hard) MX_LAUNCH_G(CLV_GATE_HARD_SIGMOID); else MX_LAUNCH_G(CLV_GATE_SIGMOID);
+#undef MX_LAUNCH_G
 #undef MX_LAUNCH
   return launch_status();
 }

@@ -28,7 +28,10 @@ hs, cs, gates = torch.empty(B * T, H, device=dev), torch.empty(B * T, 2 * H, dev
 fn = _lib.lib().clv_debug_mx_stamps
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p]
-rows = []
+fp = _lib.lib().clv_debug_mx_pstamps
+fp.restype = ctypes.c_int
+fp.argtypes = [ctypes.c_void_p]
+rows, prow = [], []
 for it in range(6):
     ops.lstm_mx_fwd(B, T, XZd, ld, D, K, XZd[:, D:] if withz else None, ld, L if withz else 0, K[D:] if withz else None, rb, U,
                     hs, gates, cs)
@@ -36,6 +39,9 @@ for it in range(6):
     buf = (ctypes.c_ulonglong * 512)()
     assert fn(buf) == 0
     rows.append(np.array(buf[:], dtype=np.float64).reshape(8, 8, 8)[:, :, :7])
+    b2 = (ctypes.c_ulonglong * 32)()
+    assert fp(b2) == 0
+    prow.append(np.array(b2[:], dtype=np.int64).astype(np.float64).reshape(8, 4))
 a = np.array(rows[2:])                      # [launch, step, wave, stamp]
 names = ['top -> B operands in registers', 'B operands -> last MFMA result', 'MFMA -> gather FMAs done (wave 7: + compaction)',
          'gather -> butterfly done', 'gate math', 'stores + LDS writes issued -> at the barrier']
@@ -50,3 +56,6 @@ for k, nm in enumerate(names):
 print("%-52s" % "top -> barrier" + "".join("%8.0f" % np.median(a[:, :, w, 6] - a[:, :, w, 0]) for w in range(8)))
 print("%-52s" % "waits at the barrier for the last wave" + "".join("%8.0f" % early[w] for w in range(8)))
 print("%-52s" % "whole step" + "".join("%8.0f" % step[w] for w in range(8)))
+pp = np.median(np.array(prow[2:]).reshape(-1, 4), axis=0)
+print("producer wave, inside the compaction: MFMA result -> frame values in registers %.0f, -> prefix + row count %.0f, -> list "
+      "written %.0f, -> out %.0f cycles" % tuple(pp))
