@@ -494,10 +494,12 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
     ts = TrainStep(eng, seed=1234, rank=rank, world=world, use_graph=not args.no_graph)
     nb = X_all.shape[0] // B
 
+    # the step assembles its own batch from the HBM-resident windows (batch = device step counter mod nb), inside its graph:
+    # one graph launch per step, nothing staged from the host (TrainStep.bind_batches; Model.fit does the same)
+    ts.bind_batches(X_all, Xp_all, w_all, idx=None, period=nb, stride=B)
+
     def run(k):
         for i in range(k):
-            j = i % nb
-            ts.stage_batch(X_all[j * B:(j + 1) * B], Xp_all[j * B:(j + 1) * B], w_all[j * B:(j + 1) * B])
             ts.step()
 
     def barrier():
@@ -512,7 +514,6 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
     run(3)
     barrier()
     if world > 1:          # coarse or fine weight-gradient grid: measured here, on this node, next to the real collectives
-        ts.stage_batch(X_all[:B], Xp_all[:B], w_all[:B])
         ts.tune_dp_schedule()
         barrier()
     recs = recs_nolabel = None

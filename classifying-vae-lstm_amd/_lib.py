@@ -46,6 +46,11 @@ class AdamKnownSums(C.Structure):
     _fields_ = [("tensor", _i), ("use", _i), ("gdot", _p), ("vnorm2", _p)]
 
 
+class BatchCursor(C.Structure):
+    """clv_batch_cursor (include/clvae.h)."""
+    _fields_ = [("step_dev", _p), ("step0", C.c_int32), ("period", C.c_int32), ("stride", _i64), ("offset", _i64)]
+
+
 class ParamDesc(C.Structure):
     _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
@@ -175,6 +180,7 @@ SIGNATURES = {
     "clv_philox_normal2": (_i, [_p, _i64, _u32, _u64, _p, _i64, _u32, _u64, _u64, _u32, _p, _p]),
     "clv_gather_rows_multi": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_gather_rows_multi_notes": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_gather_rows_multi_cursor": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_philox_normal": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
     "clv_philox_uniform": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
     "clv_i32_add": (_i, [_p, C.c_int32, _p]),

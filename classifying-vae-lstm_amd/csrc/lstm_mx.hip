@@ -632,7 +632,13 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
   auto step = [&](int i, auto PAR, Coef& k) {
     constexpr int par = decltype(PAR)::value;        // i & 1: this step writes image `par`, reads the other one
     const int t = T - 1 - i;
+#ifdef MX_STAMPS
+    unsigned long long mst[8];
+    mst[4] = mst[5] = mst[6] = mst[7] = 0;
+#endif
+    MXSTAMP(0, dc);
     const float x = mx_bwd_matvec(dzB, par ^ 1, Ar);
+    MXSTAMP(1, x);                                   // MFMAs + butterfly done
     const float dh = k.dh + x;
     dc = fmaf(dh, k.kc, dc);
     float dz[4];
@@ -649,7 +655,15 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
       zs[g] += dz[g];
       if (!(MX_ABL & 64)) mx_store(dz[g], r_c, v_c + g * LH * 4, (unsigned)t * (LG * 4));
     }
+    MXSTAMP(2, zs[3]);                               // cell math, dz pieces written, stores issued
     if (!(MX_ABL & 32)) load_set(k, t - 2);
+#ifdef MX_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mst[3]));          // arrival at the barrier
+    if (blockIdx.x == 0 && lane == 0 && i >= 64 && i < 72) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g_mx_stamps[i - 64][wave][q] = mst[q];
+    }
+#endif
     step_barrier();
   };
   using P0 = std::integral_constant<int, 0>;

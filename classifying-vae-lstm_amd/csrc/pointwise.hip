@@ -304,7 +304,16 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
 // row_elems): overlapping windows of a frame store are rows of stride one frame
 struct GatherSeg { const float* src; float* out; const int64_t* table; int64_t row_elems, out_ld, stride, offset;
                    int chunk, pieces, vec, u8; unsigned char* notes; };
-struct GatherArgs { GatherSeg seg[4]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; int nlist; int list_seg[4]; };
+struct GatherArgs { GatherSeg seg[4]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; int nlist; int list_seg[4];
+                    // batch cursor (clv_gather_rows_multi_cursor): the launch reads the device step counter and takes batch
+                    // j = (step - step0) mod period: rows j * cur_stride + cur_offset .. of the row list
+                    const int32_t* step_dev; int32_t step0, period; int64_t cur_stride, cur_offset; };
+__device__ __forceinline__ int64_t gather_base(const GatherArgs& a) {
+  if (!a.step_dev) return 0;
+  int j = (*a.step_dev - a.step0) % a.period;
+  j = j < 0 ? j + a.period : j;
+  return (int64_t)j * a.cur_stride + a.cur_offset;
+}
 
 // Note lists (clv_gather_rows_multi_notes): frame p of output row r -> notes[(r * pieces + p) * CLV_NOTE_ROW ..]: the
 // indices of the bytes that are not zero, then CLV_NOTE_NONE up to the end of the row (at least 8 of them: a reader that
@@ -315,8 +324,9 @@ __device__ __forceinline__ void gather_note_lists(const GatherArgs& a, const Gat
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int piece = blockIdx.x * 4 + wave;
   if (piece >= sg.pieces) return;
+  const int64_t base = gather_base(a);
   for (int64_t r = blockIdx.y; r < a.rows; r += gridDim.y) {
-    int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
+    int64_t sr = a.idx ? a.idx[base + r] : a.row0 + base + r;
     if (sg.table) sr = sg.table[sr];
     const unsigned char* sp = reinterpret_cast<const unsigned char*>(sg.src) + sr * sg.stride + sg.offset + (int64_t)piece * sg.chunk;
     const unsigned v = lane < sg.chunk / 4 ? *reinterpret_cast<const unsigned*>(sp + 4 * lane) : 0u;
@@ -360,8 +370,9 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
   if ((int64_t)c >= row_elems) return;
   unsigned piece = 0, within = c;
   if (pieces > 1) { piece = c / (unsigned)chunk; within = c - piece * (unsigned)chunk; }
+  const int64_t base = gather_base(a);
   for (int64_t r = blockIdx.y; r < a.rows; r += gridDim.y) {
-    int64_t sr = a.idx ? a.idx[r] : a.row0 + r;
+    int64_t sr = a.idx ? a.idx[base + r] : a.row0 + base + r;
     if (table) sr = table[sr];
     const int64_t s0 = sr * stride + offset;       // first element of the source row
     float* dp = out + (r * pieces + piece) * out_ld + within;
@@ -535,10 +546,23 @@ extern "C" int clv_gather_rows_multi_notes(int64_t rows, const int64_t* idx, int
                                            const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
                                            const int64_t* src_stride, const int64_t* src_offset,
                                            const int64_t* const* src_table, unsigned char* const* notes_out, void* stream) {
+  return clv_gather_rows_multi_cursor(rows, idx, row0, nseg, src, src_u8, out, row_elems, chunk, out_ld, src_stride, src_offset,
+                                      src_table, notes_out, nullptr, stream);
+}
+
+extern "C" int clv_gather_rows_multi_cursor(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
+                                            const void* const* src, const int32_t* src_u8, float* const* out,
+                                            const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
+                                            const int64_t* src_stride, const int64_t* src_offset,
+                                            const int64_t* const* src_table, unsigned char* const* notes_out,
+                                            const clv_batch_cursor* cursor, void* stream) {
   if (rows <= 0 || nseg < 1 || nseg > 4 || !src || !out || !row_elems || !chunk || !out_ld) return CLV_EINVAL;
+  if (cursor && (!cursor->step_dev || cursor->period < 1)) return CLV_EINVAL;
   GatherArgs a;
   memset(&a, 0, sizeof(a));
   a.nseg = nseg; a.rows = rows; a.idx = idx; a.row0 = row0;
+  if (cursor) { a.step_dev = cursor->step_dev; a.step0 = cursor->step0; a.period = cursor->period;
+                a.cur_stride = cursor->stride; a.cur_offset = cursor->offset; }
   int64_t maxw = 0;
   for (int k = 0; k < nseg; ++k) {
     if (!src[k] || !out[k] || row_elems[k] <= 0 || row_elems[k] >= (1ll << 31)) return CLV_EINVAL;

@@ -300,14 +300,18 @@ class Model:
             if world > 1:
                 dist.broadcast(idx_dev, src=0)                  # every rank walks rank 0's permutation
             self._acc.zero_()
+            if ts._bound is None or ts._bound['cur'] is not d_cur:
+                # the epoch's batches are assembled by the step itself, from the device step counter: batch j of an epoch
+                # = rows idx_dev[j * GB + rank * B ..] (the permutation is rewritten in place per epoch)
+                ts.bind_batches(d_cur, d_hist, d_w, idx=idx_dev, period=n // GB, stride=GB, offset=rank * B, d_target=d_tgt)
+                ts.loss_acc = self._acc
+            if world > 1 and ts.dp_trials is None and ts.ar is not None:
+                # once per fit: which weight-gradient grid is faster next to the real all-reduce on this node (timed on
+                # the first batch; parameters, optimizer state and the epoch's loss sums are restored)
+                ts.dp_trials = ts.tune_dp_schedule() or {}
+                self._acc.zero_()
             for b0 in range(0, n, GB):
-                ts.gather_batch(d_cur, d_hist, d_w, idx_dev[b0 + rank * B:b0 + (rank + 1) * B], d_target=d_tgt)
-                if world > 1 and ts.dp_trials is None and ts.ar is not None:
-                    # once per fit: which weight-gradient grid is faster next to the real all-reduce on this node
-                    # (timed on the first batch; parameters and optimizer state are restored)
-                    ts.dp_trials = ts.tune_dp_schedule() or {}
                 ts.step()
-                ops.axpy(5, 1.0, eng.scal, self._acc)
             if world > 1:
                 dist.all_reduce(self._acc)                      # once per epoch (sum over ranks of per-batch means)
             logs = self._logs_from(self._acc, (n // GB) * world)

@@ -511,12 +511,14 @@ def gather_rows(rows, row_elems, src, idx, out, chunk=0, out_ld=0):
 NOTE_ROW, NOTE_NONE = 96, 88       # CLV_NOTE_ROW / CLV_NOTE_NONE (include/clvae.h)
 
 
-def gather_rows_multi(rows, idx, segs, row0=0, notes=None):
+def gather_rows_multi(rows, idx, segs, row0=0, notes=None, cursor=None):
     """segs: up to 4 (src, out, row_elems, chunk, out_ld[, stride, offset, table]); one launch; idx None = rows
     row0..row0+rows-1.  A uint8 src (binary frames kept as bytes) is converted to float on the way.  With (stride,
     offset, table) source row r starts at element table[idx[r]] * stride + offset: windows of a frame store.
     notes: per segment None or a uint8 tensor [rows * pieces, NOTE_ROW] that receives the frames' note lists (uint8
-    sources of binary frames only): what lstm_pair_fwd gathers the input projections from."""
+    sources of binary frames only): what lstm_pair_fwd gathers the input projections from.
+    cursor = (step_dev, step0, period, stride, offset): batch j = (step - step0) mod period, rows j * stride + offset ..
+    of the row list, chosen by the launch itself from the device step counter (a node of the step's graph)."""
     n = len(segs)
     P, I, U = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     src = P(*[s_[0].data_ptr() for s_ in segs])
@@ -529,6 +531,12 @@ def gather_rows_multi(rows, idx, segs, row0=0, notes=None):
     st = I(*[int(e[0]) for e in ext])
     of = I(*[int(e[1]) for e in ext])
     tb = P(*[(e[2].data_ptr() if e[2] is not None else None) for e in ext])
+    if cursor is not None:      # (step_dev int32 tensor, step0, period, stride, offset): the batch is chosen on the device
+        nt = P(*[(t.data_ptr() if t is not None else None) for t in (notes or [None] * n)])
+        cur = _lib.BatchCursor(cursor[0].data_ptr(), int(cursor[1]), int(cursor[2]), int(cursor[3]), int(cursor[4]))
+        check(_lib.lib().clv_gather_rows_multi_cursor(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, nt,
+                                                      C.byref(cur), _stream()), "clv_gather_rows_multi_cursor")
+        return
     if notes is not None and any(t is not None for t in notes):
         nt = P(*[(t.data_ptr() if t is not None else None) for t in notes])
         check(_lib.lib().clv_gather_rows_multi_notes(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, nt,

@@ -87,7 +87,10 @@ class TrainStep:
         self.dp_trials = None
         # One graph for the whole data-parallel step, collectives included, when RCCL can be captured (tried once, at the
         # first capture; `capture_note` says what happened); else two graphs + plain launches around eager collectives.
-        self.capture_collectives = os.environ.get('CLV_CAPTURE_COLLECTIVES', '1') != '0'
+        # OPT-IN (CLV_CAPTURE_COLLECTIVES=1): on the one-rank RCCL group a one-GPU box can build, the capture works or fails
+        # cleanly (tests/test_gpu_api.py records which); nobody has run it across GPUs, and a capture that wedges RCCL on a
+        # real node would cost the whole run, so the default stays the split schedule.
+        self.capture_collectives = os.environ.get('CLV_CAPTURE_COLLECTIVES', '0') == '1'
         self.capture_note = None
         # CLV_OVERLAP_UPDATE=1 (measurement option, single GPU): the optimizer step of the hW kernel (87 % of the parameters;
         # a chain of five small, latency-bound launches) on a side stream NEXT TO the weight-gradient products of the
@@ -100,6 +103,8 @@ class TrainStep:
         self._upd_stream = torch.cuda.Stream(device=d) if self.overlap_update else None
         self._graphs = None
         self._warm = False
+        self._bound = None          # bind_batches(): the mini-batch assembly as the first node of the captured step
+        self.loss_acc = None        # a [>= 5] float tensor: every step adds its five loss means to it (inside the graph)
 
     # -- pieces -----------------------------------------------------------
     def noise_spec(self, stream_offset=0, row0=None):
@@ -133,7 +138,32 @@ class TrainStep:
             self.Y = torch.zeros_like(self.X) if on else None
             self.recapture()
 
+    def bind_batches(self, d_cur, d_hist, d_w, idx=None, period=1, stride=None, offset=0, d_target=None):
+        """From now on step() assembles its own mini-batch, as the first node of the captured graph: batch j =
+        (iterations - iterations at the first bound step) mod `period`, rows idx[j * stride + offset + r] (idx None: rows
+        j * stride + offset + r) of the device-resident data set, r < B.  `iterations` is the optimizer's device counter,
+        so nothing is staged from the host: a step is one graph launch (Model.fit: idx = the epoch's permutation, rewritten
+        in place per epoch; period = batches per epoch; stride = global batch; offset = rank * B)."""
+        self.set_target(d_target is not None)
+        self._bound = dict(cur=d_cur, hist=d_hist, w=d_w, idx=idx, period=int(period),
+                           stride=int(self.eng.B if stride is None else stride), offset=int(offset), target=d_target,
+                           step0=int(self.eng.P.iterations.item()))       # (one host read, here: never inside a capture)
+        self.recapture()
+
+    def unbind_batches(self):
+        if self._bound is not None:
+            self._bound = None
+            self.recapture()
+
+    def _stage_bound(self):
+        b = self._bound
+        segs = self._segments(b['cur'], b['hist'], b['w'], b['target'])
+        ops.gather_rows_multi(self.eng.B, b['idx'], segs, notes=self._note_outputs(b['cur'], b['hist'], len(segs)),
+                              cursor=(self.eng.P.iterations, b['step0'], b['period'], b['stride'], b['offset']))
+
     def _main(self):
+        if self._bound is not None:
+            self._stage_bound()
         if self._folded():
             self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y,
                                     noise=self.noise_spec(), bump=True)
@@ -247,12 +277,17 @@ class TrainStep:
         segs = self._segments(d_cur, d_hist, d_w, d_target)
         ops.gather_rows_multi(self.eng.B, ib, segs, row0=row0, notes=self._note_outputs(d_cur, d_hist, len(segs)))
 
+    def _accumulate(self):
+        if self.loss_acc is not None:
+            ops.axpy(5, 1.0, self.eng.scal, self.loss_acc)
+
     def _single(self):
         """The whole step on one GPU (eager or under capture)."""
         self._main()
         if not self.overlap_update:
             self._tail()
             self._update()
+            self._accumulate()
             return
         cur = torch.cuda.current_stream()
         self._upd_stream.wait_stream(cur)
@@ -261,6 +296,7 @@ class TrainStep:
         self._tail()
         cur.wait_stream(self._upd_stream)
         self._update_rest()
+        self._accumulate()
 
     def _eager(self):
         if self.ar is None:
@@ -276,9 +312,11 @@ class TrainStep:
                 self._update_tail()
                 self.ar.wait()
                 self._update_rest()
+                self._accumulate()
                 return
             self.ar.wait()
         self._update()
+        self._accumulate()
 
     def tune_dp_schedule(self, steps=20, warm=3):
         """Data parallel only: time `steps` steps of the staged batch with the coarse and the fine weight-gradient grid
@@ -296,6 +334,7 @@ class TrainStep:
         for name, fine in (('coarse_ms', False), ('fine_ms', True)):
             eng.fine_grid = fine
             self.recapture()
+            self._warm = False             # like a fresh run: one eager step (it validates the column norms), then the capture
             for _ in range(warm):
                 self.step()
             torch.cuda.synchronize()
@@ -317,6 +356,7 @@ class TrainStep:
         eng.fine_grid = res['fine_ms'] < res['coarse_ms']
         res['chosen'] = 'fine' if eng.fine_grid else 'coarse'
         self.recapture()
+        self._warm = False                 # the restored state has no valid norms: the next step is eager, then the capture
         self.dp_trials = res
         return res
 
@@ -378,10 +418,12 @@ class TrainStep:
         """Try ONE graph for the data-parallel step: backward (early part), bucket 1 all-reduce on the side stream,
         backward (late part), bucket 2, the two optimizer pieces.  RCCL (torch's ProcessGroupNCCL) under a foreign
         stream capture is not promised to work: any failure is caught, noted, and the split schedule is used."""
-        if not (self.capture_collectives and self.ar is not None and self.ar.live and self.ar.cuda):
+        import torch.distributed as dist
+        rccl = self.ar is not None and self.ar.live and self.ar.cuda and dist.get_backend(self.ar.group) == 'nccl'
+        if not (self.capture_collectives and rccl):
             if self.capture_note is None:
-                self.capture_note = ("not tried: " + ("no live collective in this process" if not (self.ar is not None and self.ar.live)
-                                                       else "CLV_CAPTURE_COLLECTIVES=0"))
+                self.capture_note = "not tried: " + ("the collectives of this process are not RCCL calls on device buffers"
+                                                     if not rccl else "off by default (CLV_CAPTURE_COLLECTIVES=1 tries it)")
             return False
         if self.capture_note is not None and not self.capture_note.startswith('captured'):
             return False                     # failed before: do not try again
@@ -395,6 +437,7 @@ class TrainStep:
         except Exception as e:               # noqa: BLE001 -- whatever RCCL / HIP / torch raised during the capture
             self.capture_note = "capture failed, split schedule kept: %s" % (repr(e)[:300],)
             torch.cuda.synchronize()
+            self.ar.side = torch.cuda.Stream(device=self.eng.device)     # the old side stream may still count as capturing
             return False
 
     def _launch_dp(self):
@@ -426,3 +469,4 @@ class TrainStep:
         else:
             self.ar.wait()
             g3.launch()
+        self._accumulate()

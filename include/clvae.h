@@ -602,6 +602,22 @@ int clv_gather_rows_multi_notes(int64_t rows, const int64_t* idx, int64_t row0, 
                                 const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
                                 const int64_t* src_stride, const int64_t* src_offset,
                                 const int64_t* const* src_table, unsigned char* const* notes_out, void* stream);
+/* ... with a BATCH CURSOR read on the device: the launch takes batch j = (*step_dev - step0) mod period, i.e. the rows
+ * i = (idx ? idx[base + r] : row0 + base + r), base = j * stride + offset, r < rows.  step_dev is the optimizer's
+ * `iterations` counter (clv_adam_wn_step advances it at the end of a step), so the mini-batch assembly of
+ * Model.fit (cl_vae/train.py:66-71: one contiguous slice of the shuffled index per step) becomes a node of the step's
+ * hipGraph: a step is ONE graph launch, nothing is staged from the host.  cursor == NULL: clv_gather_rows_multi_notes. */
+typedef struct clv_batch_cursor {
+  const int32_t* step_dev;
+  int32_t step0, period;
+  int64_t stride, offset;
+} clv_batch_cursor;
+int clv_gather_rows_multi_cursor(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
+                                 const void* const* src, const int32_t* src_u8, float* const* out,
+                                 const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
+                                 const int64_t* src_stride, const int64_t* src_offset,
+                                 const int64_t* const* src_table, unsigned char* const* notes_out,
+                                 const clv_batch_cursor* cursor, void* stream);
 int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                           const void* const* src, const int32_t* src_u8, float* const* out,
                           const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,

@@ -627,7 +627,7 @@ def test_dp_schedule_with_real_rccl_calls_tunes_itself_and_tries_capture(dev, mo
     (a) TrainStep.tune_dp_schedule() times the coarse and the fine weight-gradient grid, keeps the faster and puts
     parameters and optimizer state back; (b) the first capture tries ONE graph for the whole step, collectives included,
     and either keeps it or notes why not and falls back to the split schedule; (c) either way four steps give the
-    weights of the plain single-graph step, bitwise (the average over one rank is the identity)."""
+    weights of the plain single-graph step (the average over one rank is the identity)."""
     import torch.distributed as dist
     from clvae_amd.engine import VrnnEngine
     from clvae_amd.trainer import TrainStep
@@ -653,6 +653,7 @@ def test_dp_schedule_with_real_rccl_calls_tunes_itself_and_tries_capture(dev, mo
     try:
         monkeypatch.setenv('CLV_FORCE_DP_GRAPHS', '1')
         monkeypatch.setenv('CLV_DP_REAL_COLLECTIVES', '1')
+        monkeypatch.setenv('CLV_CAPTURE_COLLECTIVES', '1')
         eng = VrnnEngine(cfg, B, dev)
         eng.P.set_weights(p)
         ts = TrainStep(eng, seed=5)
@@ -670,5 +671,8 @@ def test_dp_schedule_with_real_rccl_calls_tunes_itself_and_tries_capture(dev, mo
             assert ts._graphs[0] == 'whole'
     finally:
         dist.destroy_process_group()
-    for k in plain:
-        np.testing.assert_array_equal(got[k], plain[k], err_msg=k)
+    for k in plain:      # bitwise with the coarse grid; the fine grid sums the weight-gradient slabs in another order
+        if trials['chosen'] == 'coarse':
+            np.testing.assert_array_equal(got[k], plain[k], err_msg=k)
+        else:
+            np.testing.assert_allclose(got[k], plain[k], rtol=2e-5, atol=2e-7, err_msg=k)

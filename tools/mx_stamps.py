@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clvae_amd  # noqa: F401,E402
 from clvae_amd import _lib, ops  # noqa: E402
 
-withz = len(sys.argv) > 1
+withz = 'z' in sys.argv[1:]
+bwd = 'bwd' in sys.argv[1:]
 B, T, L, H, D = 1024, 256, 32, 88, 88
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(0)
@@ -32,9 +33,13 @@ fp = _lib.lib().clv_debug_mx_pstamps
 fp.restype = ctypes.c_int
 fp.argtypes = [ctypes.c_void_p]
 rows, prow = [], []
+dhs = t(rng.standard_normal((B * T, H)) * 0.1)
+dzsum, dZ = torch.empty(B, 4 * H, device=dev), torch.empty(B * T, L, device=dev)
 for it in range(6):
     ops.lstm_mx_fwd(B, T, XZd, ld, D, K, XZd[:, D:] if withz else None, ld, L if withz else 0, K[D:] if withz else None, rb, U,
                     hs, gates, cs)
+    if bwd:
+        ops.lstm_mx_bwd(B, T, U, dhs, cs, gates, dzsum, K[D:] if withz else None, L if withz else 0, dZ if withz else None, L)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 512)()
     assert fn(buf) == 0
@@ -43,6 +48,16 @@ for it in range(6):
     assert fp(b2) == 0
     prow.append(np.array(b2[:], dtype=np.int64).astype(np.float64).reshape(8, 4))
 a = np.array(rows[2:])                      # [launch, step, wave, stamp]
+if bwd:
+    a = a[..., :4]
+    print("backward kernel, cycles (median); unit waves 0..5 (+ latent waves record nothing)")
+    print("%-40s" % "wave" + "".join("%8d" % w for w in range(6)))
+    for k, nm in enumerate(['top -> dh_rec (11 reads, 33 MFMAs, butterfly)', 'cell math, dz pieces, stores', 'loads issued -> at the barrier']):
+        print("%-40s" % nm[:40] + "".join("%8.0f" % np.median(a[:, :, w, k + 1] - a[:, :, w, k]) for w in range(6)))
+    print("%-40s" % "whole step" + "".join("%8.0f" % np.median(np.diff(a[:, :, w, 0], axis=1)) for w in range(6)))
+    last = a[:, :, :6, 3].max(axis=2, keepdims=True)
+    print("%-40s" % "waits at the barrier" + "".join("%8.0f" % np.median(last[:, :, 0] - a[:, :, w, 3]) for w in range(6)))
+    sys.exit(0)
 names = ['top -> B operands in registers', 'B operands -> last MFMA result', 'MFMA -> gather FMAs done (wave 7: + compaction)',
          'gather -> butterfly done', 'gate math', 'stores + LDS writes issued -> at the barrier']
 d = np.diff(a, axis=3)
