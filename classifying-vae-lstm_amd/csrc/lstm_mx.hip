@@ -229,7 +229,9 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   unsigned long long pst[4] = {0, 0, 0, 0};
 #endif
   const int pr = lane >> 4, pj = lane & 15;
-  float fr[2][PC];           // two register sets of frame values in flight (set = step parity)
+  float fr[2][PC];           // two register sets of frame values in flight (set = step parity): requested at the end of step t
+                             // for frame t + 4, compacted in step t + 2.  (One set, one step of lookahead: +70 us per launch --
+                             // the wait then also covers the stores issued in between, and their acknowledgements are slow.)
   float zr[2][2];            // ... and of z pairs
   const int zlat = 2 * pj;
   auto load_frames = [&](float (&f)[PC], int t) {
@@ -288,31 +290,35 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
 
   // next step's input contribution in the accumulator layout: lane p takes the notes p, p + 4, ... of its row
   float xinit[NT][4];
-  struct Rows { float v[2]; float4 k[2][NT]; int cnt; };
+  struct Rows { float v[2]; float4 k[NT]; int koff1; int cnt; };      // one set of kernel rows: round 0, then reused by round 1
   auto gather_items = [&](int buf, MxItem (&items)[2], int& cnt) {
     const MxItem* Lr = lists + (buf * MX_R + r) * MX_CAP;
     items[0] = Lr[p];
     items[1] = Lr[p + 4];
     cnt = counts[buf * MX_R + r];
   };
-  auto gather_rows = [&](const MxItem (&items)[2], int cnt, Rows& g) {
+  auto gather_rows = [&](const MxItem (&items)[2], int cnt, Rows& g) {          // round 0: the row's notes 0..3
     g.cnt = cnt;
     g.v[0] = items[0].v; g.v[1] = items[1].v;
+    g.koff1 = items[1].koff;
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl) {
-      g.k[0][tl] = *reinterpret_cast<const float4*>(Kimg + items[0].koff + ucol0 + 16 * tl);
-      g.k[1][tl] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (cnt > 4) {                 // a second round only for the rows that have one (65 % of piano-roll frames do not):
-#pragma unroll                     // fewer active lanes = fewer LDS cycles
-      for (int tl = 0; tl < NT; ++tl) g.k[1][tl] = *reinterpret_cast<const float4*>(Kimg + items[1].koff + ucol0 + 16 * tl);
-    }
+    for (int tl = 0; tl < NT; ++tl) g.k[tl] = *reinterpret_cast<const float4*>(Kimg + items[0].koff + ucol0 + 16 * tl);
   };
-  auto gather_finish = [&](int buf, const Rows& g) {
+  auto gather_rows1 = [&](Rows& g) {                                            // round 1 (notes 4..7) into the same registers
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) g.k[tl] = *reinterpret_cast<const float4*>(Kimg + g.koff1 + ucol0 + 16 * tl);
+  };
+  auto gather_finish = [&](int buf, Rows& g) {           // the prologue's (unpipelined) form
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
-      xinit[tl][0] = fmaf(g.v[1], g.k[1][tl].x, g.v[0] * g.k[0][tl].x); xinit[tl][1] = fmaf(g.v[1], g.k[1][tl].y, g.v[0] * g.k[0][tl].y);
-      xinit[tl][2] = fmaf(g.v[1], g.k[1][tl].z, g.v[0] * g.k[0][tl].z); xinit[tl][3] = fmaf(g.v[1], g.k[1][tl].w, g.v[0] * g.k[0][tl].w);
+      xinit[tl][0] = g.v[0] * g.k[tl].x; xinit[tl][1] = g.v[0] * g.k[tl].y;
+      xinit[tl][2] = g.v[0] * g.k[tl].z; xinit[tl][3] = g.v[0] * g.k[tl].w;
+    }
+    gather_rows1(g);
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+      xinit[tl][0] = fmaf(g.v[1], g.k[tl].x, xinit[tl][0]); xinit[tl][1] = fmaf(g.v[1], g.k[tl].y, xinit[tl][1]);
+      xinit[tl][2] = fmaf(g.v[1], g.k[tl].z, xinit[tl][2]); xinit[tl][3] = fmaf(g.v[1], g.k[tl].w, xinit[tl][3]);
     }
     const MxItem* Lr = lists + (buf * MX_R + r) * MX_CAP;
     for (int j = MX_FAST; j < g.cnt; j += 4) {        // denser frames (rare for piano-rolls); a row walks its own count
@@ -360,6 +366,31 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
+  // Software pipeline (MX_PIPE, default): what does not depend on a step's MFMAs is issued BETWEEN them, two vector
+  // instructions per MFMA (an MFMA holds the issue port for 8 of its 16 cycles): the seven stores of the PREVIOUS step's
+  // outputs (held in registers across the barrier) and the FMAs of the NEXT step's input gather (kernel rows requested
+  // right behind the B operands).  A step's post-MFMA phase -- what every wave's SIMD partner waits out -- shrinks by
+  // ~40 instructions per wave.
+  float pend[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto store_pending = [&](int k, unsigned tt) {        // tt = the step the values belong to; (unsigned)-1: beyond num_records
+    if (MX_ABL & 2) return;
+    if (MX_ABL & 16) tt = tt == 0xffffffffu ? tt : 0u;
+    switch (k) {
+      case 0: mx_store(pend[0], r_c, v_c, tt * (LG * 4)); break;
+      case 1: mx_store(pend[1], r_c, v_c + LH * 4, tt * (LG * 4)); break;
+      case 2: mx_store(pend[2], r_c, v_c + 2 * LH * 4, tt * (LG * 4)); break;
+      case 3: mx_store(pend[3], r_c, v_c + 3 * LH * 4, tt * (LG * 4)); break;
+      case 4: mx_store(pend[4], r_a, v_a, tt * (2 * LH * 4)); break;
+      case 5: mx_store(pend[5], r_a, v_a + LH * 4, tt * (2 * LH * 4)); break;
+      default: mx_store(pend[6], r_h, v_h, tt * (LH * 4)); break;
+    }
+  };
+  float xin[2][NT][4];        // input contribution of the step of parity [.]: written during the previous step's MFMAs
+#pragma unroll
+  for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xin[0][tl][i] = xinit[tl][i]; xin[1][tl][i] = 0.f; }
+
   auto step = [&](int t, auto PAR) {
     constexpr int cur = decltype(PAR)::value;
 #ifdef MX_STAMPS
@@ -367,40 +398,71 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     mst[7] = 0;
 #endif
     MXSTAMP(0, c);
-    // B operands first: pieces of h_{t-1} (and z_t); then the (small) list entries of the NEXT step's inputs
+    // list entries of the NEXT step's inputs (small), then this step's B operands = pieces of h_{t-1} (and z_t)
+    MxItem items[2];
+    int cnt = 0;
+    if (!(MX_ABL & 4)) gather_items(cur ^ 1, items, cnt);
     const char* hb = hB + cur * MX_HC * MX_CHUNK + b_off;
     bf16x8 bh[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) bh[s] = *reinterpret_cast<const bf16x8*>(hb + s * 4 * MX_CHUNK);
     bf16x8 bz;
     if (HASZ) bz = *reinterpret_cast<const bf16x8*>(zB + cur * MX_ZC * MX_CHUNK + b_off);
-    MxItem items[2];
-    int cnt = 0;
-    if (!(MX_ABL & 4)) gather_items(cur ^ 1, items, cnt);
+    Rows g;
+    if (!(MX_ABL & 4)) gather_rows(items, cnt, g);        // the kernel rows come back under the first MFMAs
+    // the producer's lists / z image for later steps, AHEAD of its (few) MFMAs: nothing here depends on this step, and the
+    // SIMD partner (a three-tile wave, served first) is in its MFMA phase now -- behind the MFMAs this work was the tail
+    // every other wave waited for (wave 7: MFMA phase 1034 + compaction 634 cycles, stamps)
+    if (PROD && HASX && !(MX_ABL & 1)) compact(fr[cur], cur);     // frame t + 2 -> the list buffer step t - 1 finished with
+    if (ZPROD && !(MX_ABL & 1)) stage_z(zr[cur], cur ^ 1);        // z_{t+1}
     MXSTAMP(1, bh[2][0]);                           // the B operands are here
     f32x4v acc[NT];
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl) acc[tl] = f32x4v{xinit[tl][0], xinit[tl][1], xinit[tl][2], xinit[tl][3]};
+    for (int tl = 0; tl < NT; ++tl) acc[tl] = f32x4v{xin[cur][tl][0], xin[cur][tl][1], xin[cur][tl][2], xin[cur][tl][3]};
+    // vector work of MFMA slot m: stores of the previous step in slots 0..6, two gather FMAs per slot from slot F0 on
+    // slots 0..6: the previous step's stores; A0 .. A0+2NT-1: round-0 FMAs (two per slot); slot A0+2NT: the round-1 rows are
+    // requested into the same registers; B0 .. B0+2NT-1: round-1 FMAs
+    constexpr int NM = 9 * NT, A0 = NT == 3 ? 7 : 1, B0 = NT == 3 ? 20 : 6;
+    auto slot = [&](int m) {
+      if (m < 7) store_pending(m, (unsigned)(t - 1));
+      if (!(MX_ABL & 4)) {
+        if (m >= A0 && m < A0 + 2 * NT) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = 2 * (m - A0) + h, tl = e / 4, i = e % 4;
+            const float kv = i == 0 ? g.k[tl].x : i == 1 ? g.k[tl].y : i == 2 ? g.k[tl].z : g.k[tl].w;
+            xin[cur ^ 1][tl][i] = g.v[0] * kv;
+          }
+        }
+        if (m == A0 + 2 * NT) gather_rows1(g);
+        if (m >= B0 && m < B0 + 2 * NT) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = 2 * (m - B0) + h, tl = e / 4, i = e % 4;
+            const float kv = i == 0 ? g.k[tl].x : i == 1 ? g.k[tl].y : i == 2 ? g.k[tl].z : g.k[tl].w;
+            xin[cur ^ 1][tl][i] = fmaf(g.v[1], kv, xin[cur ^ 1][tl][i]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl)
+        for (int tl = 0; tl < NT; ++tl) {
           if (!(MX_ABL & 8) || (s == 0 && q == 0)) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ar[tl][s][q], bh[s], acc[tl], 0, 0, 0);
+          slot((s * 3 + q) * NT + tl);
+        }
     if (HASZ) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Az[tl][q], bz, acc[tl], 0, 0, 0);
     }
-    // the kernel rows of the next step's notes: requested behind the MFMAs, back under the butterfly and the gate math
-    Rows g;
-    if (!(MX_ABL & 4)) gather_rows(items, cnt, g);
+    static_assert(B0 + 2 * NT <= NM && A0 + 2 * NT < B0 && NM >= 7, "every slot's work fits under the MFMAs");
     MXSTAMP(2, acc[NT - 1][0]);                     // the last MFMA's result is here
-    // the producer's lists / z image for later steps
-    if (PROD && HASX && !(MX_ABL & 1)) compact(fr[cur], cur);     // frame t + 2 -> the list buffer step t - 1 finished with
-    if (ZPROD && !(MX_ABL & 1)) stage_z(zr[cur], cur ^ 1);            // z_{t+1}
     MXSTAMP(3, acc[0][1]);
     // butterfly over the piece lanes: sums the pieces (and the note shares) and deals the tiles to the lanes
     float z[4];
@@ -441,17 +503,26 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
         *reinterpret_cast<unsigned short*>(at + off) = bf16_bits(mine);
       }
     }
-    if (!(MX_ABL & 2)) {
-      const unsigned tt = (MX_ABL & 16) ? 0u : (unsigned)t;
-      mx_store(gg * gate_grad<GATE>(z[0], ig), r_c, v_c, tt * (LG * 4));
-      mx_store(kf, r_c, v_c + LH * 4, tt * (LG * 4));
-      mx_store(ig * (1.f - gg * gg), r_c, v_c + 2 * LH * 4, tt * (LG * 4));
-      mx_store(tc * gate_grad<GATE>(z[3], og), r_c, v_c + 3 * LH * 4, tt * (LG * 4));
-      mx_store(fg, r_a, v_a, tt * (2 * LH * 4));
-      mx_store(og * (1.f - tc * tc), r_a, v_a + LH * 4, tt * (2 * LH * 4));
-      mx_store(h, r_h, v_h, tt * (LH * 4));
+    // this step's outputs: stored under the next step's MFMAs
+    pend[0] = gg * gate_grad<GATE>(z[0], ig);
+    pend[1] = kf;
+    pend[2] = ig * (1.f - gg * gg);
+    pend[3] = tc * gate_grad<GATE>(z[3], og);
+    pend[4] = fg;
+    pend[5] = og * (1.f - tc * tc);
+    pend[6] = h;
+    if (!(MX_ABL & 4)) {           // denser frames (rare for piano-rolls): the notes beyond the eighth; a row walks its own count
+      const MxItem* Lr = lists + ((cur ^ 1) * MX_R + r) * MX_CAP;
+      for (int j = MX_FAST; j < g.cnt; j += 4) {
+        const MxItem it = Lr[j + p];
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+          const float4 kr = *reinterpret_cast<const float4*>(Kimg + it.koff + ucol0 + 16 * tl);
+          xin[cur ^ 1][tl][0] = fmaf(it.v, kr.x, xin[cur ^ 1][tl][0]); xin[cur ^ 1][tl][1] = fmaf(it.v, kr.y, xin[cur ^ 1][tl][1]);
+          xin[cur ^ 1][tl][2] = fmaf(it.v, kr.z, xin[cur ^ 1][tl][2]); xin[cur ^ 1][tl][3] = fmaf(it.v, kr.w, xin[cur ^ 1][tl][3]);
+        }
+      }
     }
-    if (!(MX_ABL & 4)) gather_finish(cur ^ 1, g);
     // the producer's requests for two steps ahead, BEHIND the last use of the register set they land in (issued ahead of
     // it they need fresh registers, and the copies back at the loop's end wait for the loads just issued: every step
     // then costs a trip to HBM -- lstm_pair.hip)
@@ -464,8 +535,8 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
 #pragma unroll
       for (int k = 0; k < 7; ++k) g_mx_stamps[t - 64][wv][k] = mst[k];
       if (PROD) {
-        g_mx_pstamps[t - 64][0] = pst[0] - mst[2]; g_mx_pstamps[t - 64][1] = pst[1] - pst[0];
-        g_mx_pstamps[t - 64][2] = pst[2] - pst[1]; g_mx_pstamps[t - 64][3] = mst[3] - pst[2];
+        g_mx_pstamps[t - 64][0] = pst[0] - mst[0]; g_mx_pstamps[t - 64][1] = pst[1] - pst[0];
+        g_mx_pstamps[t - 64][2] = pst[2] - pst[1]; g_mx_pstamps[t - 64][3] = mst[1] - pst[2];
       }
     }
 #endif
@@ -480,6 +551,8 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     step(t + 1, P1{});
   }
   if (t < T) step(t, P0{});
+#pragma unroll
+  for (int k = 0; k < 7; ++k) store_pending(k, (unsigned)(T - 1));       // the last step's outputs
 }
 
 constexpr size_t mx_fwd_lds(int nx) {
@@ -505,12 +578,10 @@ __global__ __launch_bounds__(512) void lstm_mx_fwd_kernel(MxFwdArgs a) {
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // encoder (no z): the note lists in wave 0 (first served on its SIMD, done 1300 cycles before the step ends); decoder:
-  // both jobs in the one-tile wave 7 -- a three-tile wave that also holds K_z has no registers left for values in
-  // flight (the z job in wave 1 spilled two registers per step, the frames in wave 0 eight)
-  if (wave == 0) mx_fwd_body<GATE, HASZ, HASX, 3, HASZ ? 0 : 1>(a, mx_lds, 0);
-  else if (wave < 7) mx_fwd_body<GATE, HASZ, HASX, 3, 0>(a, mx_lds, 12 * wave);
-  else mx_fwd_body<GATE, HASZ, HASX, 1, HASZ ? 3 : 0>(a, mx_lds, 84);
+  // both producer jobs ride in the one-tile wave 7: a three-tile wave has no registers left for two sets of frame values in
+  // flight (encoder wave 0: eight spilled registers; with ONE set in wave 3 or 0 the launch took 390-400 us against 320)
+  if (wave < 7) mx_fwd_body<GATE, HASZ, HASX, 3, 0>(a, mx_lds, 12 * wave);
+  else mx_fwd_body<GATE, HASZ, HASX, 1, 3>(a, mx_lds, 84);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -562,8 +633,12 @@ __device__ __forceinline__ void mx_split4(const float (&x)[4], uint2 (&piece)[3]
   }
 }
 
-// dz_{t+1} (image `buf`) . the tile's rows; the butterfly leaves lane (ul, r, p) with row 4 ul + p of the tile
-__device__ __forceinline__ float mx_bwd_matvec(const char* dzB, int buf, const bf16x8 (&Ar)[11][3]) {
+// dz_{t+1} (image `buf`) . the tile's rows; the butterfly leaves lane (ul, r, p) with row 4 ul + p of the tile.
+// slot(m) runs behind MFMA m (0..32): vector work that does not depend on this product (the unit waves store the previous
+// step's dz there)
+struct MxNoSlot { __device__ __forceinline__ void operator()(int) const {} };
+template <class Slot = MxNoSlot>
+__device__ __forceinline__ float mx_bwd_matvec(const char* dzB, int buf, const bf16x8 (&Ar)[11][3], Slot slot = Slot()) {
   const int lane = threadIdx.x & 63, n = lane & 15, p = n & 3, kg = lane >> 4;
   const bool even = !(p & 1), lo = !(p & 2);
   const char* bp = dzB + buf * MX_DC * MX_CHUNK + kg * MX_CHUNK + mx_slot_q(n >> 2, p, kg) * 16;
@@ -574,8 +649,10 @@ __device__ __forceinline__ float mx_bwd_matvec(const char* dzB, int buf, const b
 #pragma unroll
   for (int s = 0; s < 11; ++s)
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < 3; ++q) {
       if (!(MX_ABL & 128) || (s == 0 && q == 0)) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ar[s][q], b[s], acc, 0, 0, 0);
+      slot(3 * s + q);
+    }
   const float kA = even ? acc[0] : acc[1], sA = even ? acc[1] : acc[0];
   const float kB = even ? acc[2] : acc[3], sB = even ? acc[3] : acc[2];
   const float wA = kA + dpp_mov<0xB1>(sA);
@@ -626,6 +703,7 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
   load_set(SB, T - 2);
   float dc = 0.f;
   float zs[4] = {0.f, 0.f, 0.f, 0.f};
+  float pend[4] = {0.f, 0.f, 0.f, 0.f};         // the previous step's dz: stored (and summed) under this step's MFMAs
   __builtin_amdgcn_s_waitcnt(0x0F70);          // the prologue's loads have landed (see the forward kernel)
   __syncthreads();
 
@@ -637,7 +715,16 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
     mst[4] = mst[5] = mst[6] = mst[7] = 0;
 #endif
     MXSTAMP(0, dc);
-    const float x = mx_bwd_matvec(dzB, par ^ 1, Ar);
+    // the previous step's (t + 1) dz goes out behind the first MFMAs; at i == 0 there is none (row T of a batch row would be
+    // the next row's step 0: beyond num_records instead)
+    const unsigned soff_prev = i > 0 ? (unsigned)(t + 1) * (LG * 4) : MX_OOB;
+    const float x = mx_bwd_matvec(dzB, par ^ 1, Ar, [&](int m) {
+      if (m < 4) {
+        if (!(MX_ABL & 64)) mx_store(pend[m], r_c, v_c + m * LH * 4, soff_prev);
+        zs[m] += pend[m];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
     MXSTAMP(1, x);                                   // MFMAs + butterfly done
     const float dh = k.dh + x;
     dc = fmaf(dh, k.kc, dc);
@@ -651,10 +738,7 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
     for (int q = 0; q < 3; ++q)
       if (!(MX_ABL & 256)) *reinterpret_cast<uint2*>(at + dzl_off[q]) = pc[q];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      zs[g] += dz[g];
-      if (!(MX_ABL & 64)) mx_store(dz[g], r_c, v_c + g * LH * 4, (unsigned)t * (LG * 4));
-    }
+    for (int g = 0; g < 4; ++g) pend[g] = dz[g];
     MXSTAMP(2, zs[3]);                               // cell math, dz pieces written, stores issued
     if (!(MX_ABL & 32)) load_set(k, t - 2);
 #ifdef MX_STAMPS
@@ -671,6 +755,15 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
   for (int i = 0; i < T; i += 2) {
     step(i, P0{}, SA);
     step(i + 1, P1{}, SB);
+  }
+  // the last executed step's dz (step 0, or the padded step -1 of an odd T whose dz is 0 and whose address lies beyond num_records)
+  {
+    const int tl = (T & 1) ? -1 : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (!(MX_ABL & 64)) mx_store(pend[g], r_c, v_c + g * LH * 4, (unsigned)tl * (LG * 4));
+      zs[g] += pend[g];
+    }
   }
   if (valid) {
     const size_t rowc = (size_t)row0 + rloc;

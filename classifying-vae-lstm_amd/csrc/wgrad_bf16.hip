@@ -99,6 +99,20 @@ __device__ __forceinline__ bf16x8 frag(const char* img, int pitch, int col0, int
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// -DWB_STAMPS: every wave of workgroup (0, 0) records the shader clock at the top of each stage and at its arrival at the
+// stage barrier (tools/wgrad_stamps.py)
+#ifdef WB_STAMPS
+__device__ unsigned long long g_wb_stamps[64][8][2];
+#define WBSTAMP(slot, s_)                                                                              \
+  do {                                                                                                  \
+    unsigned long long t__;                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__));                                   \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (s_) < 64) g_wb_stamps[s_][threadIdx.x >> 6][slot] = t__; \
+  } while (0)
+#else
+#define WBSTAMP(slot, s_)
+#endif
+
 // Stage barrier: this wave's LDS traffic is done, its global loads are NOT waited for (__syncthreads() would add
 // s_waitcnt vmcnt(0) and drain the producers' prefetch at every stage).
 __device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -261,12 +275,16 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
     // during stage s (consumers on buffer s & 1): convert stage s + 1 into the other buffer (last read in stage s - 1,
     // i.e. before the barrier every wave has passed), then request stage s + 3 into the registers that just emptied
     for (int s = 0; s < nstage; s += 2) {
+      WBSTAMP(0, s);
       if (s + 1 < nstage) store_stage(rb, s + 1);
       if (s + 3 < nstage) load_stage(rb, s + 3);
+      WBSTAMP(1, s);
       stage_barrier();
       if (s + 1 < nstage) {
+        WBSTAMP(0, s + 1);
         if (s + 2 < nstage) store_stage(ra, s + 2);
         if (s + 4 < nstage) load_stage(ra, s + 4);
+        WBSTAMP(1, s + 1);
         stage_barrier();
       }
     }
@@ -286,6 +304,7 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
   const int fo_dz = frag_lane_offset(WB_DZP, lane), fo_h = frag_lane_offset(HPB, lane), fo_x = frag_lane_offset(WB_AP, lane);
   stage_barrier();
   for (int s = 0; s < nstage; ++s) {
+    WBSTAMP(0, s);
     const char* dzi = lds + (s & 1) * BUF;
     const char* hi = dzi + G::DZ_BYTES;
     const char* xi = hi + G::H_BYTES;
@@ -318,6 +337,10 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
           for (int pb = 0; pb < (WB_ABLATE == 2 ? 1 : 3); ++pb)
             acch[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m][pa], b[pb], acch[m][n], 0, 0, 0);
     }
+#ifdef WB_STAMPS
+    asm volatile("" :: "v"(acch[HT - 1][NTW - 1][0]));       // the stage's last MFMA has delivered
+#endif
+    WBSTAMP(1, s);
     stage_barrier();
   }
 
@@ -354,6 +377,12 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
 // The producers' slot tables cover 32 rows x 96 columns of h and of x (A_L = 3 float4 slots per thread) and 32 x 8 z
 // scalars in the 6-row-tile kernel, 32 x 32 in the 8-row-tile one: the wide kernel is taken when [h | z] needs more
 // than 96 image columns OR more than 8 latent columns.
+#ifdef WB_STAMPS
+extern "C" int clv_debug_wb_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_wb_stamps), sizeof(unsigned long long) * 64 * 8 * 2);
+}
+#endif
+
 static bool wgrad_wide(int nh, int nz) { return nh + nz > 96 || nz > 8; }
 
 extern "C" int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16) {
