@@ -13,21 +13,19 @@
 // v_mfma_f32_16x16x4_f32 with dl handed from the C/D layout to the A and B layouts through LDS; dl and hs are read
 // from HBM once and dl never has to exist there.  dWo/dbo accumulate in registers across a workgroup's row blocks and
 // leave as one [89,88] slab per workgroup, summed by the deferred split-K reduce (fixed order: bit-reproducible).
-#include "common.h"
+#include "out_head_args.h"
 #include "reduce_job.h"
 
 namespace clv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int OH = 88;             // hidden units == output notes
 constexpr int OH_T = 6;            // 16-wide tiles covering 88 (96)
 constexpr int OH_KS = OH / 4;      // k-steps of a K = 88 product
 constexpr int OH_LD = 116;         // LDS row stride: 116 % 64 = 52 -> the [row][k] operand reads (r*52 + q) hit 64 different banks
 constexpr int OH_NW = 8;           // waves per workgroup, one 16-row tile each
-constexpr int OH_RB = 16 * OH_NW;  // rows per block
+static_assert(OH_RB == 16 * OH_NW, "rows per block");
 constexpr int OH_TILE = 16 * OH_LD;
-constexpr int OH_SLAB_ROWS = OH + 1;      // dWo rows + the dbo row
 constexpr int OH_P3 = 5;           // weight-gradient tiles per wave (36 tiles over 8 waves: 4 x 5 + 4 x 4)
 
 // -DOH_STAMPS: wave 0 of workgroup 0 records the shader clock at the phase boundaries of its first block
@@ -43,19 +41,6 @@ __device__ unsigned long long g_oh_stamps[16];
 #define OHS(k) do { } while (0)
 #endif
 
-struct OutHeadArgs {
-  int R, ldy;
-  float scale;
-  const float* hs;        // [R,88]
-  const float* Wo;        // [88,88]
-  const float* bo;        // [88]
-  const float* Y;         // [R,ldy] targets
-  float* logits;          // [R,88] or null
-  float* rownll;          // [R]
-  float* dlogits;         // [R,88] or null
-  float* dhs;             // [R,88]
-  float* partial;         // [gridDim.x][89][88]
-};
 
 __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float oh_lds[];
@@ -330,7 +315,11 @@ extern "C" int clv_out_head_train(int R, int H, int D, const float* hs, const fl
   if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(out_head_train_kernel), (int)lds)) return e;
   const int wgs = out_head_wgs(R);
   OutHeadArgs a{R, ldy, scale, hs, Wo, bo, Y, logits, rownll, dlogits, dhs, (float*)ws};
-  {
+  // CLV_OUT_HEAD_F32=1 keeps the f32-MFMA kernel of this file (A/B runs; it also serves rows that are not 16-byte aligned)
+  static const bool f32_only = [] { const char* e = getenv("CLV_OUT_HEAD_F32"); return e && e[0] == '1'; }();
+  if (!f32_only && out_head_bf16_ok(a)) {
+    if (int e = launch_out_head_bf16(a, wgs, s)) return e;
+  } else {
     ProfScope p("out_head_train", s);
     hipLaunchKernelGGL(out_head_train_kernel, dim3(wgs), dim3(64 * OH_NW), lds, s, a);
   }
