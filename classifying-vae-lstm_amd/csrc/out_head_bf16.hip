@@ -44,13 +44,16 @@ constexpr int OB_IMG = 3 * 6 * 3 * OB_FRAG;        // pieces x tiles x k-steps
 constexpr int OB_DLT = 96 * 16;                    // floats of a wave's dl tile
 constexpr int OB_LDS = 2 * OB_IMG + OB_NW * OB_DLT * 4;
 static_assert(OB_LDS <= 160 * 1024, "LDS");
-static_assert(3 * OB_NW * 16 * 64 * 4 <= OB_LDS, "the final reduction's rounds fit");
+static_assert(OB_NW * 18 * 64 * 16 <= OB_LDS, "the final reduction's rounds fit");
 
 // -DOB_STAMPS: wave 0 of workgroup 0 records the shader clock at the phase boundaries of its first block
 #ifdef OB_STAMPS
 __device__ unsigned long long g_ob_stamps[16];
+__device__ unsigned long long g_ob_wg[256][4];     // per workgroup: start, loop entered, loop left (wave 0), end -- 100 MHz clock
+#define OBW(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_ob_wg[blockIdx.x][k] = t_; } } while (0)
 #define OBS(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ob_stamps[k] = __builtin_readcyclecounter(); } while (0)
 #else
+#define OBW(k) do { } while (0)
 #define OBS(k) do { } while (0)
 #endif
 
@@ -59,15 +62,30 @@ __device__ __forceinline__ unsigned ob_pack2(float lo, float hi) {
   const bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(unsigned, v);
 }
-// 8 floats -> their three bf16 pieces as MFMA fragments (element e of the fragment = v[e])
+// x - bf16(x) in ONE instruction: v_dot2c_f32_bf16 computes d += a.lo * b.lo + a.hi * b.hi on bf16 pairs, so with
+// b = (-1, 0) or (0, -1) and d = x it subtracts one half of the packed pair from x.  The result is exactly representable,
+// so the instruction's rounding does not matter (tools/probes/dot2_split.hip: bitwise equal to shift + subtract on 2M random
+// pairs, denormals included).  The constants are handed over in scalar registers: written as literals the compiler turns
+// (-1, 0) into the inline constant -1.0, which the instruction reads as something else (same probe: every low half wrong).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ob_sconst(unsigned v) {
+  unsigned r;
+  asm("s_mov_b32 %0, %1" : "=s"(r) : "i"(v));
+  return r;
+}
+__device__ __forceinline__ float ob_minus_half(float x, unsigned pair, unsigned k) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, k), x, false);
+}
+// 8 floats -> their three bf16 pieces as MFMA fragments (element e of the fragment = v[e]): 7 instructions per pair
 __device__ __forceinline__ void ob_split8(const float (&v)[8], u32x4 (&f)[3]) {
+  const unsigned klo = ob_sconst(0x0000BF80u), khi = ob_sconst(0xBF800000u);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = v[2 * i], b = v[2 * i + 1];
     const unsigned p0 = ob_pack2(a, b);
-    const float ra = a - __builtin_bit_cast(float, p0 << 16), rb = b - __builtin_bit_cast(float, p0 & 0xffff0000u);
+    const float ra = ob_minus_half(a, p0, klo), rb = ob_minus_half(b, p0, khi);
     const unsigned p1 = ob_pack2(ra, rb);
-    const unsigned p2 = ob_pack2(ra - __builtin_bit_cast(float, p1 << 16), rb - __builtin_bit_cast(float, p1 & 0xffff0000u));
+    const unsigned p2 = ob_pack2(ob_minus_half(ra, p1, klo), ob_minus_half(rb, p1, khi));
     f[0][i] = p0; f[1][i] = p1; f[2][i] = p2;
   }
 }
@@ -130,47 +148,7 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
   const int r = lane & 15, q = lane >> 4, n32 = lane & 31, kh = lane >> 5;
   float* dlT = reinterpret_cast<float*>(ob_lds + 2 * OB_IMG) + wave * OB_DLT;
   OBS(0);
-
-  // ---- the two images of Wo (and bo): 2 x 18 fragments x 64 lanes, 8 values each
-  for (int idx = tid; idx < 2 * 18 * 64; idx += 64 * OB_NW) {
-    const int img = idx / (18 * 64), rem = idx - img * (18 * 64);
-    const int fr = rem >> 6, l = rem & 63, m = l & 15, qq = l >> 4;
-    const int j = fr / 3, s = fr - 3 * j;
-    float v[8];
-    if (img == 0) {
-      const int note = 16 * j + m;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int hid = 32 * s + 8 * qq + e;
-        const float w = a.Wo[min(hid, OH - 1) * OH + min(note, OH - 1)];
-        const float b = a.bo[min(note, OH - 1)];
-        v[e] = note < OH ? (hid < OH ? w : (hid == OH ? b : 0.f)) : 0.f;
-      }
-    } else {
-      const int hid = 16 * j + m;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int note = 16 * (2 * s + (e >> 2)) + 4 * qq + (e & 3);
-        const float w = a.Wo[min(hid, OH - 1) * OH + min(note, OH - 1)];
-        v[e] = (hid < OH && note < OH) ? w : 0.f;
-      }
-    }
-    u32x4 f[3];
-    ob_split8(v, f);
-    char* base = (img ? A2 : A1) + (j * 3 + s) * OB_FRAG + l * 16;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(base + p * 18 * OB_FRAG) = f[p];
-  }
-
-  f32x16 acc3[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc3[i][j][e] = 0.f;
-  __syncthreads();
-  OBS(1);
+  OBW(0);
 
   // Every global access of the row loop is a buffer instruction: rows beyond R fall outside the descriptor (loads return 0,
   // stores are dropped), a lane that has nothing to move gets an out-of-range offset, an absent output a descriptor of 0
@@ -182,6 +160,75 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
   const unsigned c_off = (16 * 0 + 4 * q) * 4u;           // byte offset of this lane's 4 outputs inside tile 0 of a row
   const bool c5 = q < 2;                                   // tile 5: notes / hidden units 88..95 do not exist
 
+  // this lane's part of the wave's hs rows as P1's B operand: hidden 32s + 8q + e of row r (hidden 88..95: nothing to load;
+  // element 0 of that group becomes the ones column where it is used).  The first block's rows are touched here, while the
+  // images are built, so that the loop's own loads find them in L2 (keeping them in registers across the loop's back edge
+  // would cost 24 registers through the whole body).
+  float hv[3][8];
+  auto load_hv = [&](int row0) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      ob_load8(r_hs, (s == 2 && q == 3) ? OB_OOB : (unsigned)(row0 + r) * (OH * 4u) + (32 * s + 8 * q) * 4u, hv[s]);
+  };
+  load_hv(blockIdx.x * OH_RB + wave * 16);
+
+  // ---- the two images of Wo (and bo): 36 fragments of 64 lanes x 8 values, fragment F = 8 it + wave.  Which fragment is a
+  // wave-uniform (scalar) matter, the lane supplies one offset per image, and values that do not exist come from offsets
+  // outside the descriptor: ~60 vector instructions per fragment, nearly all of them the split.  (First version: per-thread
+  // index arithmetic on 40 scalar loads, 2.5 us of instruction issue before the last load was even requested.)
+  {
+    const ob_rsrc_t r_wo = ob_rsrc(a.Wo, (size_t)OH * OH * 4), r_bo = ob_rsrc(a.bo, (size_t)OH * 4);
+    const int m = r, qq = q;
+    const unsigned l0 = (8 * qq * OH + m) * 4u;          // image 0: Wo[32s + 8qq + e][16j + m]
+    const unsigned l1 = (m * OH + 4 * qq) * 4u;          // image 1: Wo[16j + m][32s + 16(e >> 2) + 4qq + (e & 3)]
+    float wv[5][8];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int F = min(8 * it + wave, 35);
+      const int img = F >= 18, fr = F - 18 * img, j = fr / 3, s = fr - 3 * j;
+      if (!img) {
+        // (the whole offset goes through the vector operand: the range check does not see a scalar offset)
+        const unsigned vo = (16 * j + m < OH) ? l0 + (32 * s * OH + 16 * j) * 4u : OB_OOB;              // notes 88..95: zeros
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[it][e] = ob_u2f(__builtin_amdgcn_raw_buffer_load_b32(r_wo, (int)vo + e * OH * 4, 0, 0));
+        // hidden 88 (s = 2, qq = 3, e = 0) is the bias row; hidden 89..95 fall behind the array: zeros
+        const float bias = ob_u2f(__builtin_amdgcn_raw_buffer_load_b32(r_bo, (s == 2 && qq == 3) ? (16 * j + m) * 4 : (int)OB_OOB, 0, 0));
+        wv[it][0] = (s == 2 && qq == 3) ? bias : wv[it][0];
+      } else {
+        const unsigned vo = l1 + (16 * j * OH + 32 * s) * 4u;             // hidden 88..95 fall behind the array
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r_wo, (int)vo, 0, 0);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(r_wo, (s == 2 && qq >= 2) ? (int)OB_OOB : (int)vo + 64, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wv[it][e] = ob_u2f(lo[e]); wv[it][4 + e] = ob_u2f(hi[e]); }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int F = 8 * it + wave;
+      if (F < 36) {
+        u32x4 f[3];
+        ob_split8(wv[it], f);
+        char* base = (F >= 18 ? A2 + (F - 18) * OB_FRAG : A1 + F * OB_FRAG) + lane * 16;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(base + p * 18 * OB_FRAG) = f[p];
+      }
+    }
+  }
+
+  f32x16 acc3[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc3[i][j][e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) asm volatile("" :: "v"(hv[s][0]), "v"(hv[s][4]));
+  OBS(10);
+  __syncthreads();
+  OBS(1);
+  OBW(1);
+
   for (int blk = blockIdx.x; blk * OH_RB < a.R; blk += gridDim.x) {
     const int row0 = blk * OH_RB + wave * 16;
     if (row0 >= a.R) continue;                           // (wave-uniform; no barrier inside this loop)
@@ -190,14 +237,7 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
     const unsigned o_row = row * (OH * 4u) + c_off;        // + 64 j: this lane's float4 of tile j in an [R,88] array
     const unsigned o5 = c5 ? o_row + 5 * 64 : OB_OOB;
 
-    // this lane's part of the wave's hs rows as P1's B operand: hidden 32s + 8q + e of row r; hidden 88 is the ones column
-    float hv[3][8];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const unsigned o = (s == 2 && q == 3) ? OB_OOB : row * (OH * 4u) + (32 * s + 8 * q) * 4u;
-      ob_load8(r_hs, o, hv[s]);
-    }
-    hv[2][0] = q == 3 ? 1.f : hv[2][0];
+    load_hv(row0);                                       // (the first block's rows: out of L2, see above)
     OBS(2);
 
     // ---- P1: logits^T = Wo^T.hs^T (+ bias through the ones column)
@@ -207,6 +247,7 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
     for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
+      if (s == 2) hv[2][0] = q == 3 ? 1.f : hv[2][0];      // hidden 88: the ones column
       u32x4 B[3];
       ob_split8(hv[s], B);
       if (s == 2) {            // the targets are requested here, when two thirds of hv are dead
@@ -263,6 +304,11 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
       ob_store4(lg4, r_lg, o);
       ob_store4(dl4, r_dl, o);
     }
+    // the next block's hs and target rows -> L2 (one dword per 128 bytes of a row; rows behind the arrays request nothing):
+    // the row loop has no register to spare for a real prefetch, and its loads otherwise wait for HBM once per block
+    const unsigned nrow = row + gridDim.x * OH_RB;
+    const float pf0 = ob_load1(r_hs, q < 3 ? nrow * (OH * 4u) + q * 128u : OB_OOB, 0);
+    const float pf1 = ob_load1(r_y, q < 3 ? nrow * (a.ldy * 4u) + q * 128u : OB_OOB, 0);
     ssum += __shfl_xor(ssum, 16, 64);
     ssum += __shfl_xor(ssum, 32, 64);
     ob_store1(ssum, r_nl, q == 0 ? row * 4u : OB_OOB);
@@ -322,39 +368,57 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
         ob_store4(d4, r_dh, j < 5 ? o_row + 64 * j : o5);
       }
     }
+    asm volatile("" :: "v"(pf0), "v"(pf1));
     OBS(6);
   }
 
-  // ---- the eight waves' gradients meet in LDS, one row of tiles (jm) per round, and leave summed in wave order
+  // ---- the eight waves' gradients meet in LDS, half of the 36 float4 per lane per round (8 x 18 KB), and leave summed in
+  // wave order: float4 f = (3jm + jn) * 4 + i4 holds registers 4 i4 .. + 3 of tile (jm, jn) = 4 consecutive rows h of one note
+  OBW(2);
   float* slab = a.partial + (size_t)blockIdx.x * OH_SLAB_ROWS * OH;
-  float* red = reinterpret_cast<float*>(ob_lds);         // [wave][jn][reg][lane]
+  float4* red = reinterpret_cast<float4*>(ob_lds);       // [wave][18][lane]
   __syncthreads();
 #pragma unroll
-  for (int jm = 0; jm < 3; ++jm) {
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int jn = 0; jn < 3; ++jn)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) red[((wave * 3 + jn) * 16 + i) * 64 + lane] = acc3[jm][jn][i];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int v = tid + 64 * OB_NW * k;                // (jn, reg, lane) of one output
-      const int jn = v >> 10, i = (v >> 6) & 15, l = v & 63;
-      float sum = 0.f;
-#pragma unroll
-      for (int w = 0; w < OB_NW; ++w) sum += red[((w * 3 + jn) * 16 + i) * 64 + l];
-      const int h = 32 * jm + 8 * (i >> 2) + 4 * (l >> 5) + (i & 3), note = 32 * jn + (l & 31);
-      if (h < OH_SLAB_ROWS && note < OH) slab[h * OH + note] = sum;
+    for (int ff = 0; ff < 18; ++ff) {
+      const int f = 18 * half + ff, jm = f / 12, jn = (f >> 2) % 3, i4 = f & 3;
+      red[(wave * 18 + ff) * 64 + lane] = make_float4(acc3[jm][jn][4 * i4], acc3[jm][jn][4 * i4 + 1], acc3[jm][jn][4 * i4 + 2],
+                                                      acc3[jm][jn][4 * i4 + 3]);
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int v = tid + 64 * OB_NW * k;                // (ff, lane) of four outputs
+      if (v < 18 * 64) {
+        const int ff = v >> 6, l = v & 63;
+        float4 sum = red[ff * 64 + l];
+#pragma unroll
+        for (int w = 1; w < OB_NW; ++w) {
+          const float4 x = red[(w * 18 + ff) * 64 + l];
+          sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+        }
+        const int f = 18 * half + ff, jm = f / 12, jn = (f >> 2) % 3, i4 = f & 3;
+        const int h = 32 * jm + 8 * i4 + 4 * (l >> 5), note = 32 * jn + (l & 31);
+        const float o4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (h + i < OH_SLAB_ROWS && note < OH) slab[(h + i) * OH + note] = o4[i];
+      }
+    }
+    if (half == 0) __syncthreads();
   }
   OBS(7);
+  OBW(3);
 }
 
 #ifdef OB_STAMPS
 }
 extern "C" int clv_debug_out_head_bf16_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_ob_stamps), sizeof(unsigned long long) * 16);
+}
+extern "C" int clv_debug_out_head_bf16_wg(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_ob_wg), sizeof(unsigned long long) * 1024);
 }
 namespace clv {
 #endif

@@ -571,6 +571,9 @@ class VrnnEngine(_EngineBase):
         self.fuse_head = bool(cfg.get('fuse_head', os.environ.get('CLV_FUSE_HEAD', '1') != '0')) \
             and ops.out_head_train_supported(H, D)
         self._head_done = False
+        # the fused head also stores the logits (tests and callers of loss_and_grads read them); a replayed training step has
+        # no reader for them, so TrainStep(use_graph=True) turns the store off: 11.5 MB per step at configuration 3, 92 MB at 5
+        self.keep_logits = bool(cfg.get('keep_logits', True))
         # LSTM kernel gradients as split-bf16 exact products (csrc/wgrad_bf16.hip) instead of the f32 MFMA GEMM;
         # frames_exact_bf16: every staged frame value is exactly a bf16 number (TrainStep sets it when the data set is
         # kept as uint8), which lets the frame rows use one bf16 piece instead of three
@@ -760,7 +763,7 @@ class VrnnEngine(_EngineBase):
                 # the weight-gradient slabs are summed with the other pending reductions in grads_tail()
                 ops.out_head_train(BT, H, D, self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale,
                                    self.rownll, self.dhs, P.g('X_decoded_mean/kernel'), P.g('X_decoded_mean/bias'),
-                                   self.ws, logits=self.logits, defer=self._rq())
+                                   self.ws, logits=self.logits if self.keep_logits else None, defer=self._rq())
                 self._head_done = True
             else:
                 ops.gemm_bce(self.hs_dec, P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), X, scale, self.logits,

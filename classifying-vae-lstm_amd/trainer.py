@@ -38,6 +38,8 @@ class TrainStep:
         self.b2 = 0.9 if optimizer == 'rmsprop' else 0.999                       # rmsprop: rho
         self.lr = lr
         self.use_graph = use_graph
+        if use_graph and hasattr(engine, 'keep_logits') and 'keep_logits' not in engine.cfg:
+            engine.keep_logits = False       # nothing reads the logits of a replayed training step (VrnnEngine.keep_logits)
         self.fast_adam = bool(fast_adam) and os.environ.get('CLV_FAST_ADAM', '1') != '0'      # see _update()
         cfg, B, d = engine.cfg, engine.B, engine.device
         self.is_vrnn = 'T' in cfg

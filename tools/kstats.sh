@@ -9,7 +9,7 @@ python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$G/kernel_stats.csv")))
 # profiled steps = the launch count of a once-per-step kernel (bench.py also runs set-up steps; "$@" may change --steps)
-once=[int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("lstm_pair_fwd", "vae_fused_kernel", "vrnn_label_fwd", "out_head_train"))]
+once=[int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("lstm_pair_fwd", "vae_fused_kernel", "vrnn_label_fwd", "out_head_"))]
 steps=min(once) if once else 223
 print("profiled steps: %d" % steps)
 tot=0
