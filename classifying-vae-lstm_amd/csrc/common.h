@@ -77,6 +77,47 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return fast_rcp(1.0f + __expf(-xc));
 }
 
+// ---- fp32 = three bf16 pieces, exactly (wgrad_bf16.hip, out_head_bf16.hip, lstm_mx.hip) -----------------------------
+// x = p0 + p1 + p2: v_cvt_pk_bf16_f32 rounds a pair to nearest even and packs it (the 4 bytes an MFMA fragment wants), a
+// piece as a float is its 16 bits shifted up, and the residual x - bf16(x) is exact in fp32: 11 instructions per pair.
+typedef __bf16 clv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack2(float lo, float hi) {
+  const clv_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void bf16_split_pair(float a, float b, unsigned (&piece)[3]) {
+  piece[0] = bf16_pack2(a, b);
+  const float ra = a - __builtin_bit_cast(float, piece[0] << 16), rb = b - __builtin_bit_cast(float, piece[0] & 0xffff0000u);
+  piece[1] = bf16_pack2(ra, rb);
+  piece[2] = bf16_pack2(ra - __builtin_bit_cast(float, piece[1] << 16), rb - __builtin_bit_cast(float, piece[1] & 0xffff0000u));
+}
+// The residual in ONE instruction: v_dot2c_f32_bf16 computes d += a.lo * b.lo + a.hi * b.hi on bf16 pairs, so with
+// b = (-1, 0) or (0, -1) and d = x it subtracts one half of the packed pair from x; the result is exactly representable, so
+// the instruction's own rounding cannot matter (tools/probes/dot2_split.hip: bitwise equal to shift + subtract on 2M random
+// pairs, denormals included; an Inf / NaN in one half reaches its partner as 0 * Inf).  The constants sit in scalar
+// registers: as literals the compiler encodes (-1, 0) as the inline constant -1.0, which the instruction does not read as
+// that pair (same probe: every low half wrong).  7 instructions per pair -- but the dot product is NOT a 4-cycle vector
+// instruction next to MFMAs: in wgrad_bf16's producers (which split while the other waves of the SIMD issue MFMAs) it made
+// the kernel 10-18 % slower (35.9 -> 39.6 us at 32768 rows, 225 -> 266 us at 262144; profiles/r04_out_head_log.txt), so only
+// code that splits outside MFMA phases uses it.
+__device__ __forceinline__ unsigned sreg_const(unsigned v) {
+  unsigned r;
+  asm("s_mov_b32 %0, %1" : "=s"(r) : "i"(v));
+  return r;
+}
+__device__ __forceinline__ float minus_bf16_lo(float x, unsigned pair) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(clv_bf16x2, pair), __builtin_bit_cast(clv_bf16x2, sreg_const(0x0000BF80u)), x, false);
+}
+__device__ __forceinline__ float minus_bf16_hi(float x, unsigned pair) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(clv_bf16x2, pair), __builtin_bit_cast(clv_bf16x2, sreg_const(0xBF800000u)), x, false);
+}
+__device__ __forceinline__ void bf16_split_pair_dot2(float a, float b, unsigned (&piece)[3]) {
+  piece[0] = bf16_pack2(a, b);
+  const float ra = minus_bf16_lo(a, piece[0]), rb = minus_bf16_hi(b, piece[0]);
+  piece[1] = bf16_pack2(ra, rb);
+  piece[2] = bf16_pack2(minus_bf16_lo(ra, piece[1]), minus_bf16_hi(rb, piece[1]));
+}
+
 // Keras 2.0.0 hard_sigmoid: clip(0.2*x + 0.5, 0, 1)
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.0f), 1.0f); }
 // derivative; TF's clip passes the gradient at ties

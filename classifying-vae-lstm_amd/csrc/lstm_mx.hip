@@ -614,23 +614,14 @@ __device__ __forceinline__ void mx_bwd_weights(const float* W, int first, int li
     split8(v, Ar[s]);
   }
 }
-// four floats -> three piece images of four bf16 each (v_cvt_pk_bf16_f32 rounds and packs a pair)
-__device__ __forceinline__ unsigned mx_pack2(float lo, float hi) {
-  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-  const bf16x2v v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, v);
-}
+// four floats -> three piece images of four bf16 each (common.h: bf16_split_pair, 7 instructions per pair)
+__device__ __forceinline__ unsigned mx_pack2(float lo, float hi) { return bf16_pack2(lo, hi); }
 __device__ __forceinline__ void mx_split4(const float (&x)[4], uint2 (&piece)[3]) {
-  float a0 = x[0], a1 = x[1], a2 = x[2], a3 = x[3];
+  unsigned lo[3], hi[3];
+  bf16_split_pair(x[0], x[1], lo);
+  bf16_split_pair(x[2], x[3], hi);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const unsigned lo = mx_pack2(a0, a1), hi = mx_pack2(a2, a3);
-    piece[q] = make_uint2(lo, hi);
-    if (q < 2) {
-      a0 -= __builtin_bit_cast(float, lo << 16); a1 -= __builtin_bit_cast(float, lo & 0xffff0000u);
-      a2 -= __builtin_bit_cast(float, hi << 16); a3 -= __builtin_bit_cast(float, hi & 0xffff0000u);
-    }
-  }
+  for (int q = 0; q < 3; ++q) piece[q] = make_uint2(lo[q], hi[q]);
 }
 
 // dz_{t+1} (image `buf`) . the tile's rows; the butterfly leaves lane (ul, r, p) with row 4 ul + p of the tile.

@@ -57,36 +57,17 @@ __device__ unsigned long long g_ob_wg[256][4];     // per workgroup: start, loop
 #define OBS(k) do { } while (0)
 #endif
 
-__device__ __forceinline__ unsigned ob_pack2(float lo, float hi) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, v);
-}
-// x - bf16(x) in ONE instruction: v_dot2c_f32_bf16 computes d += a.lo * b.lo + a.hi * b.hi on bf16 pairs, so with
-// b = (-1, 0) or (0, -1) and d = x it subtracts one half of the packed pair from x.  The result is exactly representable,
-// so the instruction's rounding does not matter (tools/probes/dot2_split.hip: bitwise equal to shift + subtract on 2M random
-// pairs, denormals included).  The constants are handed over in scalar registers: written as literals the compiler turns
-// (-1, 0) into the inline constant -1.0, which the instruction reads as something else (same probe: every low half wrong).
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned ob_sconst(unsigned v) {
-  unsigned r;
-  asm("s_mov_b32 %0, %1" : "=s"(r) : "i"(v));
-  return r;
-}
-__device__ __forceinline__ float ob_minus_half(float x, unsigned pair, unsigned k) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, k), x, false);
-}
-// 8 floats -> their three bf16 pieces as MFMA fragments (element e of the fragment = v[e]): 7 instructions per pair
+// 8 floats -> their three bf16 pieces as MFMA fragments (element e of the fragment = v[e]); common.h: bf16_split_pair_dot2
 __device__ __forceinline__ void ob_split8(const float (&v)[8], u32x4 (&f)[3]) {
-  const unsigned klo = ob_sconst(0x0000BF80u), khi = ob_sconst(0xBF800000u);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a = v[2 * i], b = v[2 * i + 1];
-    const unsigned p0 = ob_pack2(a, b);
-    const float ra = ob_minus_half(a, p0, klo), rb = ob_minus_half(b, p0, khi);
-    const unsigned p1 = ob_pack2(ra, rb);
-    const unsigned p2 = ob_pack2(ob_minus_half(ra, p1, klo), ob_minus_half(rb, p1, khi));
-    f[0][i] = p0; f[1][i] = p1; f[2][i] = p2;
+    unsigned pc[3];
+#ifdef OB_SHIFT_SPLIT
+    bf16_split_pair(v[2 * i], v[2 * i + 1], pc);
+#else
+    bf16_split_pair_dot2(v[2 * i], v[2 * i + 1], pc);       // (-9 us per launch at 262144 rows against the shift form)
+#endif
+    f[0][i] = pc[0]; f[1][i] = pc[1]; f[2][i] = pc[2];
   }
 }
 __device__ __forceinline__ bf16x8 ob_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }

@@ -58,19 +58,9 @@ struct WgradArgs {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// x = p0 + p1 + p2 exactly, two values at a time: v_cvt_pk_bf16_f32 rounds a pair to nearest even and packs it (the
-// 4 bytes an image wants), a piece as a float is its 16 bits shifted up, and the residuals are exact in fp32
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[3]) {
-  piece[0] = pack2(a, b);
-  const float ra = a - __builtin_bit_cast(float, piece[0] << 16), rb = b - __builtin_bit_cast(float, piece[0] & 0xffff0000u);
-  piece[1] = pack2(ra, rb);
-  piece[2] = pack2(ra - __builtin_bit_cast(float, piece[1] << 16), rb - __builtin_bit_cast(float, piece[1] & 0xffff0000u));
-}
+// x = p0 + p1 + p2 exactly, two values at a time: common.h (bf16_split_pair: 7 vector instructions per pair)
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return bf16_pack2(lo, hi); }
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[3]) { bf16_split_pair(a, b, piece); }
 // 4 consecutive columns of one image row: one 8-byte LDS store per piece image
 #ifndef WB_ABLATE
 #define WB_ABLATE 0      // measurement builds (tools/build_variant.sh): 1 = no piece splitting, 2 = one MFMA term of nine,
