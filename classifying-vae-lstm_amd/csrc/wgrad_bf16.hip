@@ -1,4 +1,4 @@
-// wgrad_bf16.hip -- every kernel gradient of one LSTM in one pass over dz, on the bf16 matrix cores with EXACT
+// wgrad_bf16.hip -- every kernel gradient of one LSTM in one pass over dz, on the bf16 matrix cores from exact piece
 // products (gfx950).
 //
 //   dK_x [nx,4H] = X^T . dz      (input frames; binary piano-roll, or any values)
@@ -9,10 +9,13 @@
 //
 // Why not the f32 MFMA (gemm.hip): v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate.  An fp32 number is the exact
 // sum of three bf16 numbers (8 + 8 + 8 mantissa bits, same exponent range), and a product of two bf16 numbers is exact
-// in fp32, so  a.b = sum_{i,j} a_i.b_j  over the 3 x 3 piece pairs has EXACT partial products; the nine partial GEMMs
-// accumulate in fp32 like any other summation order of the same products.  9 bf16 MFMAs (144 cycles per 16x16 tile and
-// 32 k) replace 8 f32 MFMAs (256 cycles).  Frames that are exactly representable in bf16 (0/1 piano-roll, any uint8)
-// need one piece: 3 MFMAs.  The kernel is then bound by streaming dz / X / H once, not by the matrix pipe.
+// in fp32, so  a.b = sum_{i,j} a_i.b_j  over the 3 x 3 piece pairs has EXACT partial products that accumulate in fp32 like
+// any other summation order of the same products.  The three pairs with i + j >= 3 (a1.b2, a2.b1, a2.b2) together are below
+// 2^-25 |a.b| -- less than the ONE rounding an fp32 multiply of a and b makes -- and are left out (round 4): 6 bf16 MFMAs
+// (96 cycles per 16x16 tile and 32 k) replace 8 f32 MFMAs (256 cycles).  -DWB_PRODUCTS=9 keeps all nine (measured, us per
+// launch: 36.0 -> 33.8 at K = 32768, 218 -> 196 at K = 262144 with six; profiles/r04_out_head_log.txt).  Frames that are
+// exactly representable in bf16 (0/1 piano-roll, any uint8) need one piece: their 3 MFMAs are all kept, those products
+// stay exact.  The kernel is then bound by its data-moving waves (profiles/r04_mx_log.txt section 13), not by the matrix pipe.
 //
 // Decomposition: a workgroup (4 waves, one per SIMD) owns ALL output rows x half of the 4H columns (176 = 11 column
 // tiles, padded to 12) for K / splits rows; accumulators stay in registers (up to 168 per lane).  Per 32-row stage the
@@ -62,6 +65,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return bf16_pack2(lo, hi); }
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[3]) { bf16_split_pair(a, b, piece); }
 // 4 consecutive columns of one image row: one 8-byte LDS store per piece image
+#ifndef WB_PRODUCTS
+#define WB_PRODUCTS 6    // piece pairs of an h . dz product: 6 = those with pa + pb <= 2 (default), 9 = all (-DWB_PRODUCTS=9)
+#endif
 #ifndef WB_ABLATE
 #define WB_ABLATE 0      // measurement builds (tools/build_variant.sh): 1 = no piece splitting, 2 = one MFMA term of nine,
 #endif                   // 3 = no global loads after the first stages.  Results are wrong by design.
@@ -325,7 +331,8 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
         for (int pa = 0; pa < (WB_ABLATE == 2 ? 1 : 3); ++pa)
 #pragma unroll
           for (int pb = 0; pb < (WB_ABLATE == 2 ? 1 : 3); ++pb)
-            acch[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m][pa], b[pb], acch[m][n], 0, 0, 0);
+            if (WB_PRODUCTS == 9 || pa + pb <= 2)
+              acch[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m][pa], b[pb], acch[m][n], 0, 0, 0);
     }
 #ifdef WB_STAMPS
     asm volatile("" :: "v"(acch[HT - 1][NTW - 1][0]));       // the stage's last MFMA has delivered

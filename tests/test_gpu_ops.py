@@ -728,7 +728,9 @@ def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer, nh):
         ref = f8(A).T @ f8(dz)
         mag = np.abs(f8(A)).T @ np.abs(f8(dz)) + 1e-30
         err = np.abs(got.cpu().numpy() - ref) / mag
-        assert err.max() < 2e-6, err.max()          # fp32 accumulation of exact products over K terms
+        # fp32 accumulation over K terms of piece products that are exact; an h / z row's product leaves out the piece pairs
+        # below 2^-25 of it (csrc/wgrad_bf16.hip, WB_PRODUCTS): less than the rounding of one fp32 multiply
+        assert err.max() < 2e-6, err.max()
 
 
 @pytest.mark.parametrize("K,N,R,with_jobs", [(256, 352, 5, True), (1, 352, 5, False), (300, 100, 15, False),
