@@ -51,6 +51,20 @@ class BatchCursor(C.Structure):
     _fields_ = [("step_dev", _p), ("step0", C.c_int32), ("period", C.c_int32), ("stride", _i64), ("offset", _i64)]
 
 
+class WgradProblem(C.Structure):
+    """clv_wgrad_problem (include/clvae.h)."""
+    _fields_ = [("K", C.c_int32), ("N", C.c_int32),
+                ("X", _p), ("ldx", C.c_int32), ("nx", C.c_int32), ("x_exact_bf16", C.c_int32),
+                ("H", _p), ("ldh", C.c_int32), ("nh", C.c_int32), ("h_shift", C.c_int32), ("h_zero_period", C.c_int32),
+                ("Z", _p), ("ldz", C.c_int32), ("nz", C.c_int32),
+                ("dz", _p), ("lddz", C.c_int32),
+                ("dKx", _p), ("ld_kx", C.c_int32),
+                ("dU", _p), ("ld_u", C.c_int32),
+                ("dKz", _p), ("ld_kz", C.c_int32),
+                ("beta", C.c_float),
+                ("ws", _p), ("ws_bytes", C.c_size_t)]
+
+
 class ParamDesc(C.Structure):
     _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("col_offset", C.c_int64), ("is_matrix", C.c_int32), ("pad_", C.c_int32)]
@@ -103,6 +117,9 @@ SIGNATURES = {
     "clv_lstm_wgrad": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,
                             _p, _sz, _p, _p]),
     "clv_lstm_wgrad_workspace_bytes_ex": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "clv_lstm_wgrad_pair_supported": (_i, [_p, _p]),
+    "clv_lstm_wgrad_pair_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "clv_lstm_wgrad_pair": (_i, [_p, _p, _i, _p, _p, _p]),
     "clv_lstm_wgrad_ex": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,
                                _i, _p, _sz, _p, _p]),
     "clv_gemm_grouped_tn_small2": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _p]),

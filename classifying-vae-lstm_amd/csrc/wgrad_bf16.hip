@@ -114,7 +114,7 @@ __device__ unsigned long long g_wb_stamps[64][8][2];
 __device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int HM, int XP>
-__global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   using G = WbGeo<HM>;
   constexpr int HPB = G::HPB, BUF = G::template buf_bytes<XP>(), LDS_ALL = G::template lds_bytes<XP>();
   constexpr int HT = HM / 2;                     // h row tiles per consumer wave
@@ -369,6 +369,20 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) {
   flush(acch, HT, mh * HT * 16, a.nh + a.nz, a.nx);
 }
 
+template <int HM, int XP>
+__global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) { wgrad_body<HM, XP>(a); }
+
+// Two LSTMs in one launch (grid z): the encoder's and the decoder's gradients of a cl_vrnn step, whose dz both exist
+// once the backward pass is through.  Launched one after the other at K = 32768 (configuration 3), each grid is one
+// workgroup per CU with 8 stages -- 17 us of stages inside a 34 us launch (LDS clear and first loads in front, a 124 KB
+// slab store behind, launch and drain around).  Together, with row ranges twice as long, the same 256 workgroups run 16
+// stages each: the fixed part is paid once, and the split-K reduction reads half as many slabs.
+template <int HM, int XP>
+__global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_pair_kernel(WgradArgs a0, WgradArgs a1) {
+  const WgradArgs a = blockIdx.z ? a1 : a0;        // (scalar selects: one copy of the body)
+  wgrad_body<HM, XP>(a);
+}
+
 }  // namespace clv
 
 // The producers' slot tables cover 32 rows x 96 columns of h and of x (A_L = 3 float4 slots per thread) and 32 x 8 z
@@ -392,13 +406,13 @@ extern "C" int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exa
 // rows per split: one workgroup per CU (2 column halves x 128 row ranges of whole 32-row stages); split_scale s: s times
 // as many, shorter ranges (a grid of exactly one workgroup per CU needs a whole second round as soon as something else
 // -- the gradient all-reduce's kernel -- holds a few CUs; 2 x 256 half-length workgroups lose only the share that is taken)
-static int wgrad_kc(int K, int split_scale) {
-  const int ranges = 128 * (split_scale < 1 ? 1 : split_scale);
+static int wgrad_kc(int K, int split_scale, int base_ranges = 128) {
+  const int ranges = base_ranges * (split_scale < 1 ? 1 : split_scale);
   int kc = (K + ranges - 1) / ranges;
   return (kc + 31) / 32 * 32;
 }
-static int wgrad_splits(int K, int split_scale) {
-  const int kc = wgrad_kc(K, split_scale);
+static int wgrad_splits(int K, int split_scale, int base_ranges = 128) {
+  const int kc = wgrad_kc(K, split_scale, base_ranges);
   return (K + kc - 1) / kc;
 }
 
@@ -463,5 +477,77 @@ extern "C" int clv_lstm_wgrad_ex(int K, int N, const float* X, int ldx, int nx, 
   // deferred queue skips jobs without a split
   if (job && splits > 1) memcpy(job, &j, sizeof(j));
   else st = launch_reduce(j, s);
+  return st;
+}
+
+// ---- both LSTMs of a step in one launch -------------------------------------------------------------------------------
+static bool wgrad_problem_ok(const clv_wgrad_problem& p) {
+  if (!clv_lstm_wgrad_supported(p.N, p.nx, p.nh, p.nz, p.x_exact_bf16) || p.K <= 0 || !p.X || !p.H || !p.dz || !p.dKx || !p.dU ||
+      (p.nz > 0 && (!p.Z || !p.dKz)))
+    return false;
+  return !(p.ldx % 4 || p.ldh % 4 || p.lddz % 4 || ((uintptr_t)p.X | (uintptr_t)p.H | (uintptr_t)p.dz) % 16);
+}
+
+extern "C" int clv_lstm_wgrad_pair_supported(const clv_wgrad_problem* p, const clv_wgrad_problem* q) {
+  if (!p || !q || !wgrad_problem_ok(*p) || !wgrad_problem_ok(*q)) return 0;
+  // one kernel instance, one grid: the same row count, the same tile geometry, the same number of frame pieces
+  return p->K == q->K && p->N == q->N && wgrad_wide(p->nh, p->nz) == wgrad_wide(q->nh, q->nz) &&
+         (p->x_exact_bf16 != 0) == (q->x_exact_bf16 != 0);
+}
+
+extern "C" size_t clv_lstm_wgrad_pair_workspace_bytes(int K, int N, int nx, int nh, int nz, int split_scale) {
+  return (size_t)wgrad_splits(K, split_scale, 64) * (nx + nh + nz) * N * sizeof(float);
+}
+
+extern "C" int clv_lstm_wgrad_pair(const clv_wgrad_problem* p, const clv_wgrad_problem* q, int split_scale,
+                                   clv_reduce_job* job_p, clv_reduce_job* job_q, void* stream) {
+  using namespace clv;
+  if (split_scale < 1 || split_scale > 8) return CLV_EINVAL;
+  if (job_p) memset(job_p, 0, sizeof(*job_p));
+  if (job_q) memset(job_q, 0, sizeof(*job_q));
+  if (!clv_lstm_wgrad_pair_supported(p, q)) return CLV_EINVAL;
+  const clv_wgrad_problem* pr[2] = {p, q};
+  for (int i = 0; i < 2; ++i)
+    if (clv_lstm_wgrad_pair_workspace_bytes(pr[i]->K, pr[i]->N, pr[i]->nx, pr[i]->nh, pr[i]->nz, split_scale) > pr[i]->ws_bytes ||
+        !pr[i]->ws || ((uintptr_t)pr[i]->ws) % 16)
+      return CLV_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int K = p->K, N = p->N;
+  const int splits = wgrad_splits(K, split_scale, 64), kc = wgrad_kc(K, split_scale, 64);
+  WgradArgs a[2];
+  for (int i = 0; i < 2; ++i)
+    a[i] = WgradArgs{K, N, kc, pr[i]->X, pr[i]->ldx, pr[i]->nx, pr[i]->H, pr[i]->ldh, pr[i]->nh, pr[i]->h_shift, pr[i]->h_zero_period,
+                     pr[i]->Z, pr[i]->ldz, pr[i]->nz, pr[i]->dz, pr[i]->lddz, (float*)pr[i]->ws};
+  {
+    ProfScope ps("lstm_wgrad_bf16_pair", s);
+    dim3 grid(splits, N / WB_NC, 2);
+#define WB_LAUNCH2(HM, XP)                                                                                  \
+  do {                                                                                                      \
+    auto kern = lstm_wgrad_bf16_pair_kernel<HM, XP>;                                                        \
+    const int lds = WbGeo<HM>::template lds_bytes<XP>();                                                    \
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;                      \
+    hipLaunchKernelGGL(kern, grid, dim3(WB_NT), lds, s, a[0], a[1]);                                        \
+  } while (0)
+    const bool wide = wgrad_wide(p->nh, p->nz);
+    if (wide) { if (p->x_exact_bf16) WB_LAUNCH2(8, 1); else WB_LAUNCH2(8, 3); }
+    else { if (p->x_exact_bf16) WB_LAUNCH2(6, 1); else WB_LAUNCH2(6, 3); }
+#undef WB_LAUNCH2
+  }
+  int st = launch_status();
+  if (st) return st;
+  clv_reduce_job* jobs[2] = {job_p, job_q};
+  for (int i = 0; i < 2 && !st; ++i) {
+    const clv_wgrad_problem& w = *pr[i];
+    ReduceJob j;
+    memset(&j, 0, sizeof(j));
+    j.partial = (const float*)w.ws;
+    j.M = w.nx + w.nh + w.nz; j.N = N; j.splits = splits; j.nprob = w.nz > 0 ? 3 : 2;
+    j.alpha = 1.f; j.beta = w.beta; j.act = CLV_ACT_NONE;
+    j.prob[0] = ReduceProb{w.dKx, w.ld_kx, 0};
+    j.prob[1] = ReduceProb{w.dU, w.ld_u, w.nx};
+    if (w.nz > 0) j.prob[2] = ReduceProb{w.dKz, w.ld_kz, w.nx + w.nh};
+    if (jobs[i] && splits > 1) memcpy(jobs[i], &j, sizeof(j));
+    else st = launch_reduce(j, s);
+  }
   return st;
 }

@@ -579,6 +579,9 @@ class VrnnEngine(_EngineBase):
         # kept as uint8), which lets the frame rows use one bf16 piece instead of three
         self.bf16_wgrad = bool(cfg.get('bf16_wgrad', os.environ.get('CLV_BF16_WGRAD', '1') != '0'))
         self.frames_exact_bf16 = bool(cfg.get('frames_exact_bf16', False))
+        # ... and both LSTMs' in one launch where they take the same form of the kernel (grads_tail)
+        self.wgrad_pair = bool(cfg.get('wgrad_pair', os.environ.get('CLV_WGRAD_PAIR', '1') != '0'))
+        self.ws_b = None
         # Note lists (opt-in: cfg['fuse_notes'] / CLV_FUSE_NOTES=1): when the batch was staged from BINARY uint8 frames,
         # the staging launch also writes each frame's list of notes (ops.gather_rows_multi(notes=...)) and the pair
         # forward kernel gathers the LSTM input projections itself -- no projection launch, no [B*T,352] round trip per
@@ -933,26 +936,35 @@ class VrnnEngine(_EngineBase):
                 Xs[:, t - S].copy_(x_next)
         return Xs
 
-    def _lstm_wgrads(self, name, X_in, x_ld, x_rows, hs, dz, dzsum, w_row, ws):
-        """Every weight gradient of one LSTM in two grouped launches.
-        Over dz [B*T,4H] (K = B*T): kernel rows of the per-step inputs (x_t, or [x_{t-1} | z_t] for the
-        decoder) and the recurrent kernel (h_{t-1}: shift 1, zero at t == 0).
-        Over dzsum [B,4H] (K = B): kernel rows of the repeated label W, and the bias."""
-        cfg, P, B = self.cfg, self.P, self.B
-        H, T, Cn, L = cfg['H'], cfg['T'], cfg['C'], cfg['L']
-        BT, G4 = B * T, 4 * H
-        rq = self._rq()
+    def _wgrad_args(self, name, X_in, x_ld, x_rows, hs, dz):
+        """The argument tuple of ops.lstm_wgrad (up to dKz) for one LSTM's kernel gradients on the bf16 matrix cores
+        (csrc/wgrad_bf16.hip: x rows, h rows and z rows at once), or None where that kernel does not apply."""
+        cfg, P = self.cfg, self.P
+        H, T, L = cfg['H'], cfg['T'], cfg['L']
         nz = L if name == 'decoder_h' else 0          # the decoder's per-step inputs are [x_{t-1} | z_t]
         nx = x_rows - nz                              # 0: a decoder without history frames
-        if self.bf16_wgrad and nx > 0 and ops.lstm_wgrad_supported(G4, nx, H, nz, self.frames_exact_bf16):
-            # split-bf16 exact products on the bf16 matrix cores (csrc/wgrad_bf16.hip): x rows, h rows and z rows at once
-            gk = P.g(name + '/kernel')
-            ops.lstm_wgrad(BT, G4, X_in, x_ld, nx, self.frames_exact_bf16, hs, H, H, T,
-                           X_in[:, nx:] if nz else None, x_ld, nz, dz, gk, P.g(name + '/recurrent_kernel'),
-                           P.rows(P.grads, name + '/kernel', nx) if nz else None, ws, defer=rq,
-                           split_scale=2 if self.fine_grid else 1)
-        else:
-            self._lstm_wgrads_f32(name, X_in, x_ld, x_rows, hs, dz, ws, rq)
+        if not (self.bf16_wgrad and nx > 0 and ops.lstm_wgrad_supported(4 * H, nx, H, nz, self.frames_exact_bf16)):
+            return None
+        return (self.B * T, 4 * H, X_in, x_ld, nx, self.frames_exact_bf16, hs, H, H, T, X_in[:, nx:] if nz else None, x_ld, nz,
+                dz, P.g(name + '/kernel'), P.g(name + '/recurrent_kernel'),
+                P.rows(P.grads, name + '/kernel', nx) if nz else None)
+
+    def _lstm_wgrads(self, name, X_in, x_ld, x_rows, hs, dz, dzsum, w_row, ws, products=True):
+        """Every weight gradient of one LSTM in two grouped launches.
+        Over dz [B*T,4H] (K = B*T): kernel rows of the per-step inputs (x_t, or [x_{t-1} | z_t] for the
+        decoder) and the recurrent kernel (h_{t-1}: shift 1, zero at t == 0); products=False: already formed
+        (grads_tail: both LSTMs in one launch).
+        Over dzsum [B,4H] (K = B): kernel rows of the repeated label W, and the bias."""
+        cfg, P, B = self.cfg, self.P, self.B
+        H, Cn = cfg['H'], cfg['C']
+        G4 = 4 * H
+        rq = self._rq()
+        if products:
+            args = self._wgrad_args(name, X_in, x_ld, x_rows, hs, dz)
+            if args is not None:
+                ops.lstm_wgrad(*args, ws, defer=rq, split_scale=2 if self.fine_grid else 1)
+            else:
+                self._lstm_wgrads_f32(name, X_in, x_ld, x_rows, hs, dz, ws, rq)
         if not (Cn + 1 <= 16 and B <= 4096):      # else: both LSTMs' label rows + biases in one launch (grads_tail)
             ops.gemm_grouped_tn([dict(A=self.W, lda=Cn, M=Cn, C=P.rows(P.grads, name + '/kernel', w_row)),
                                  dict(A=None, M=1, C=P.g(name + '/bias'), ones=1)], G4, B, dzsum, ws, defer=rq)
@@ -1092,12 +1104,23 @@ class VrnnEngine(_EngineBase):
         # output head: kernel and bias gradient in one pass over dlogits (bias = an implicit row of ones)
         if not self._head_done:
             self._dense_wgrad('X_decoded_mean', self.hs_dec, H, H, D, BT, self.dlogits, ws, rq)
-        self._lstm_wgrads('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec, self.dzsum_dec,
-                          off + L, ws)
+        # both LSTMs' kernel gradients in ONE launch where they take the same form of the kernel (configuration 3: 256
+        # workgroups of 16 stages instead of twice 256 of 8; half as many slabs to reduce)
+        dec = ('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec)
+        enc = ('encoder_h', X, D, D, self.hs_enc, self.gates_enc)
+        paired = False
+        if self.wgrad_pair:
+            pd, pe = self._wgrad_args(*dec), self._wgrad_args(*enc)
+            if pd is not None and pe is not None and ops.lstm_wgrad_pair_supported(pd, pe):
+                if rq is None and self.ws_b is None:
+                    self.ws_b = ops.Workspace(self.device)
+                ops.lstm_wgrad_pair(pd, pe, (ws, self.ws_b), defer=rq, split_scale=2 if self.fine_grid else 1)
+                paired = True
+        self._lstm_wgrads(*dec, self.dzsum_dec, off + L, ws, products=not paired)
         if not getattr(self, '_head_grad_done', False):
             self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)
         self._head_grad_done = False
-        self._lstm_wgrads('encoder_h', X, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc, D, ws)
+        self._lstm_wgrads(*enc, self.dzsum_enc, D, ws, products=not paired)
         skinny = None
         if Cn + 1 <= 16 and B <= 4096:
             # label rows + bias of both LSTMs' input-kernel gradients (K = batch rows of sum_t dz)

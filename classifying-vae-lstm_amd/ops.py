@@ -152,6 +152,41 @@ def lstm_wgrad(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dK
                               int(split_scale), _ptr(buf), buf.numel(), job, _stream()), "clv_lstm_wgrad_ex")
 
 
+def _wgrad_problem(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dKx, dU, dKz, beta=0.0):
+    w = _lib.WgradProblem()
+    w.K, w.N = K, N
+    w.X, w.ldx, w.nx, w.x_exact_bf16 = _ptr(X), ldx, nx, int(bool(x_exact_bf16))
+    w.H, w.ldh, w.nh, w.h_shift, w.h_zero_period = _ptr(H), ldh, nh, 1, T
+    w.Z, w.ldz, w.nz = _ptr(Z), ldz, nz
+    w.dz, w.lddz = _ptr(dz), N
+    w.dKx, w.ld_kx, w.dU, w.ld_u, w.dKz, w.ld_kz = _ptr(dKx), N, _ptr(dU), N, _ptr(dKz), N
+    w.beta = float(beta)
+    return w
+
+
+def lstm_wgrad_pair_supported(p, q):
+    """p, q: the argument tuples of lstm_wgrad up to dKz (K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dKx,
+    dU, dKz): can both products run as ONE launch (clv_lstm_wgrad_pair)?"""
+    a, b = _wgrad_problem(*p), _wgrad_problem(*q)
+    return bool(_lib.lib().clv_lstm_wgrad_pair_supported(C.byref(a), C.byref(b)))
+
+
+def lstm_wgrad_pair(p, q, ws, defer=None, split_scale=1):
+    """Both LSTMs' kernel gradients of a step in one launch (csrc/wgrad_bf16.hip: row ranges twice as long, half as many
+    slabs); p, q as in lstm_wgrad_pair_supported.  ws: a pair of Workspaces when the reductions are not deferred."""
+    L = _lib.lib()
+    probs, jobs = [], []
+    for i, t in enumerate((p, q)):
+        w = _wgrad_problem(*t)
+        need = L.clv_lstm_wgrad_pair_workspace_bytes(w.K, w.N, w.nx, w.nh, w.nz, int(split_scale))
+        buf = defer.scratch(need) if defer is not None else ws[i].ensure(need)
+        jobs.append(defer.next_job() if defer is not None else None)
+        w.ws, w.ws_bytes = _ptr(buf), buf.numel()
+        probs.append(w)
+    check(L.clv_lstm_wgrad_pair(C.byref(probs[0]), C.byref(probs[1]), int(split_scale), jobs[0], jobs[1], _stream()),
+          "clv_lstm_wgrad_pair")
+
+
 def gemm_bce(A, B, bias, Y, scale, logits, dlogits, rownll, M, N, K, lda=None, ldb=None, ldy=None, ldc=None):
     """Output head + Bernoulli NLL in one launch: logits = A.B + bias, rownll, dlogits = scale*(sigmoid - Y)."""
     check(_lib.lib().clv_gemm_bce_f32(M, N, K, _ptr(A), lda if lda is not None else K, _ptr(B),

@@ -68,7 +68,7 @@ typedef struct clv_noise_draw {
  *   100  rounds 1-2
  *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
  *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
- *   400  round 4: + clv_lstm_mx_* (additions only) */
+ *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair (additions only) */
 #define CLV_ABI_VERSION 400
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
@@ -159,11 +159,12 @@ int clv_splitk_reduce_multi_ex(const clv_reduce_job* jobs, int njobs, const floa
  *   dKx [nx,N] = X^T . dz            X [K,ldx]: the input frames (first nx columns)
  *   dU  [nh,N] = H'^T . dz           H'_k = H[k - h_shift] (h of the previous step), zero where k % h_zero_period == 0
  *   dKz [nz,N] = Z^T . dz            Z [K,ldz]: the latent columns of the decoder input; nz = 0: absent
- * computed on the bf16 matrix cores with EXACT products: every fp32 operand is split into three bf16 pieces
- * (x = p0 + p1 + p2 exactly), the 3 x 3 partial products are exact in fp32 and accumulate in fp32, so the result is a
- * re-ordered fp32 summation of the same products the f32 path forms (9 bf16 MFMAs instead of 8 f32 MFMAs at 1/16 of the
- * rate).  x_exact_bf16 != 0 promises that every X value is exactly representable in bf16 (0/1 piano-roll frames, any
- * uint8): those rows then need one piece.  The products leave as split-K slabs: ws >= clv_lstm_wgrad_workspace_bytes,
+ * computed on the bf16 matrix cores from exact piece products: every fp32 operand is split into three bf16 pieces
+ * (x = p0 + p1 + p2 exactly), a product of two pieces is exact in fp32 and the partial products accumulate in fp32.  Of the
+ * 3 x 3 piece pairs of an H or Z value and a dz value, the three below 2^-25 of the product (less than the rounding of one
+ * fp32 multiply) are left out since round 4: 6 bf16 MFMAs instead of 8 f32 MFMAs at 1/16 of the rate.  x_exact_bf16 != 0
+ * promises that every X value is exactly representable in bf16 (0/1 piano-roll frames, any uint8): those rows then need
+ * one piece, and their products with all three dz pieces are exact.  The products leave as split-K slabs: ws >= clv_lstm_wgrad_workspace_bytes,
  * and like the *_deferred GEMMs the final sums (C = beta*C + sum) are formed by the reduction, now (job == NULL) or by
  * clv_splitk_reduce_multi.  Limits (clv_lstm_wgrad_supported): N == 352; nx <= 96, nh <= 96, nz <= 32; nx, nh,
  * ldx, ldh, lddz multiples of 4, 16-byte aligned bases; more than 96 rows of H and Z together, or more than 8 rows
@@ -184,6 +185,27 @@ int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf
                    const float* Z, int ldz, int nz, const float* dz, int lddz,
                    float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
                    void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
+/* Two such products in ONE launch (the encoder's and the decoder's of a cl_vrnn step, cl_vrnn/model.py:196-199 and
+ * 225-228, whose dz both exist once the backward pass is through): the arguments of clv_lstm_wgrad_ex per problem, each
+ * with its own slab workspace (>= clv_lstm_wgrad_pair_workspace_bytes: row ranges are twice as long as in the single
+ * launch, so there are half as many slabs) and its own reduction job (NULL: reduced at once).  The two problems must have
+ * the same K, N and x_exact_bf16 and take the same form of the kernel (clv_lstm_wgrad_pair_supported). */
+typedef struct clv_wgrad_problem {
+  int32_t K, N;
+  const float* X; int32_t ldx, nx, x_exact_bf16;
+  const float* H; int32_t ldh, nh, h_shift, h_zero_period;
+  const float* Z; int32_t ldz, nz;
+  const float* dz; int32_t lddz;
+  float* dKx; int32_t ld_kx;
+  float* dU; int32_t ld_u;
+  float* dKz; int32_t ld_kz;
+  float beta;
+  void* ws; size_t ws_bytes;
+} clv_wgrad_problem;
+int clv_lstm_wgrad_pair_supported(const clv_wgrad_problem* p, const clv_wgrad_problem* q);
+size_t clv_lstm_wgrad_pair_workspace_bytes(int K, int N, int nx, int nh, int nz, int split_scale);
+int clv_lstm_wgrad_pair(const clv_wgrad_problem* p, const clv_wgrad_problem* q, int split_scale,
+                        clv_reduce_job* job_p, clv_reduce_job* job_q, void* stream);
 
 
 /* column sums: out[N] = (beta ? out : 0) + sum_m X[m, n]   (bias gradients) */

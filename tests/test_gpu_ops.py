@@ -733,6 +733,55 @@ def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer, nh):
         assert err.max() < 2e-6, err.max()
 
 
+@pytest.mark.parametrize("K,Tn,nz,exact,defer,scale", [(32768, 128, 2, True, True, 1),      # configuration 3: 16 stages per workgroup
+                                                       (4096, 16, 2, True, False, 1), (1000, 8, 8, False, True, 2),
+                                                       (96, 96, 0, False, False, 1)])
+def test_lstm_wgrad_pair_matches_fp64(dev, K, Tn, nz, exact, defer, scale):
+    """clv_lstm_wgrad_pair: the encoder's (no latent rows) and the decoder's (nz latent rows) kernel gradients of a step in
+    ONE launch, against fp64 numpy with the single launch's bar; deferred and immediate reductions; bit-reproducible."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(K + nz + 1)
+    N, nx, nh = 352, 88, 88
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+    probs, refs = [], []
+    for z in (0, nz):                                   # "encoder", "decoder"
+        ldx = nx + (4 if 0 < z <= 4 else z)
+        XZ = np.zeros((K, ldx), np.float32)
+        XZ[:, :nx] = (rng.random((K, nx)) < 0.0443) if exact else rng.standard_normal((K, nx))
+        XZ[:, nx:nx + z] = rng.standard_normal((K, z))
+        hs = np.tanh(rng.standard_normal((K, nh))).astype(np.float32)
+        dz = (rng.standard_normal((K, N)) * np.exp(rng.standard_normal((K, 1)) * 2)).astype(np.float32)
+        Hs = np.zeros_like(hs)
+        Hs[1:] = hs[:-1]
+        Hs[::Tn] = 0
+        tXZ = d(XZ)
+        g = [torch.full((nx, N), 7.0, device=dev), torch.full((nh, N), 7.0, device=dev), torch.full((max(z, 1), N), 7.0, device=dev)]
+        probs.append((K, N, tXZ, ldx, nx, exact, d(hs), nh, nh, Tn, tXZ[:, nx:] if z else None, ldx, z, d(dz), g[0], g[1],
+                      g[2] if z else None))
+        refs.append([(g[0], XZ[:, :nx], dz), (g[1], Hs, dz)] + ([(g[2], XZ[:, nx:nx + z], dz)] if z else []))
+    if not ops.lstm_wgrad_pair_supported(*probs):
+        assert nz > 8 or (nz and not exact and nh + nz > 96)       # different forms of the kernel: two launches instead
+        pytest.skip("the two problems take different kernels")
+    outs = []
+    for rep in range(2):
+        rq = ops.ReduceQueue(dev) if defer else None
+        ops.lstm_wgrad_pair(probs[0], probs[1], (ops.Workspace(dev), ops.Workspace(dev)), defer=rq, split_scale=scale)
+        if rq is not None:
+            assert rq.n == 2
+            rq.flush()
+        torch.cuda.synchronize()
+        outs.append([t[0].clone() for r in refs for t in r])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    f8 = lambda a: a.astype(np.float64)
+    for r in refs:
+        for got, A, dz in r:
+            ref = f8(A).T @ f8(dz)
+            mag = np.abs(f8(A)).T @ np.abs(f8(dz)) + 1e-30
+            err = np.abs(got.cpu().numpy() - ref) / mag
+            assert err.max() < 2e-6, err.max()
+
+
 @pytest.mark.parametrize("K,N,R,with_jobs", [(256, 352, 5, True), (1, 352, 5, False), (300, 100, 15, False),
                                               (1000, 64, 1, True), (37, 353, 9, False)])
 def test_reduce_launch_skinny_riders(dev, K, N, R, with_jobs):
