@@ -65,6 +65,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return bf16_pack2(lo, hi); }
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[3]) { bf16_split_pair(a, b, piece); }
 // 4 consecutive columns of one image row: one 8-byte LDS store per piece image
+#ifndef WB_PRODUCER_PRIO
+#define WB_PRODUCER_PRIO 1
+#endif
 #ifndef WB_PRODUCTS
 #define WB_PRODUCTS 6    // piece pairs of an h . dz product: 6 = those with pa + pb <= 2 (default), 9 = all (-DWB_PRODUCTS=9)
 #endif
@@ -99,6 +102,17 @@ __device__ __forceinline__ bf16x8 frag(const char* img, int pitch, int col0, int
 // stage barrier (tools/wgrad_stamps.py)
 #ifdef WB_STAMPS
 __device__ unsigned long long g_wb_stamps[64][8][2];
+// ... and every workgroup's wave 0 (a consumer) the 100 MHz clock at: entry, LDS cleared, first stage ready, stages done, slab stored
+__device__ unsigned long long g_wb_wg[1024][5];
+#define WBWG(k)                                                                                                      \
+  do {                                                                                                               \
+    if (threadIdx.x == 0) {                                                                                          \
+      unsigned long long t__;                                                                                        \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__));                                          \
+      const unsigned w__ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                            \
+      if (w__ < 1024) g_wb_wg[w__][k] = t__;                                                                          \
+    }                                                                                                                \
+  } while (0)
 #define WBSTAMP(slot, s_)                                                                              \
   do {                                                                                                  \
     unsigned long long t__;                                                                             \
@@ -107,6 +121,7 @@ __device__ unsigned long long g_wb_stamps[64][8][2];
   } while (0)
 #else
 #define WBSTAMP(slot, s_)
+#define WBWG(k)
 #endif
 
 // Stage barrier: this wave's LDS traffic is done, its global loads are NOT waited for (__syncthreads() would add
@@ -135,12 +150,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   const int k_begin = split * a.kc, k_end = min(a.K, k_begin + a.kc);
   const int nstage = (k_end - k_begin + WB_KS - 1) / WB_KS;
 
+  WBWG(0);
   // The images' padding (x columns nx..95, h columns nh+nz.., dz columns 176..207) only reaches output rows / columns
   // that are never stored; everything is zeroed once so that every MFMA input is a finite number.
   for (int i = tid; i < LDS_ALL / 16; i += WB_NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
+  WBWG(1);
 
   if (producer) {
+    // the data movers go first when both waves of a SIMD have an instruction ready: the MFMA wave fills the gaps, and it
+    // has slack (34.1 -> 32.8 us per launch at K = 32768, 216 -> 209 us at K = 262144; -DWB_PRODUCER_PRIO=0 to compare)
+    __builtin_amdgcn_s_setprio(WB_PRODUCER_PRIO);
     // ---- which elements of a stage this thread moves (the same for every stage) ------------------------------------
     // dz: 32 rows x 44 float4 = 1408 slots;  h, x: 32 x (n/4);  z: 32 x nz scalars; 256 producer threads take slot
     // pt + 256 i.  Per slot: the byte offset from the stage's first row in global memory and the byte offset in the
@@ -299,6 +319,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   }
   const int fo_dz = frag_lane_offset(WB_DZP, lane), fo_h = frag_lane_offset(HPB, lane), fo_x = frag_lane_offset(WB_AP, lane);
   stage_barrier();
+  WBWG(2);
   for (int s = 0; s < nstage; ++s) {
     WBSTAMP(0, s);
     const char* dzi = lds + (s & 1) * BUF;
@@ -341,6 +362,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     stage_barrier();
   }
 
+  WBWG(3);
   // ---- slabs: accumulators -> LDS (row-major) -> 16-byte row pieces to the partial buffer ---------------------------
   // C/D layout of the MFMA: column = lane & 15, row = 4 (lane >> 4) + register.  (The producers are gone; the four
   // consumer waves stage in disjoint regions, no barrier needed: LDS operations of one wave execute in order.)
@@ -367,6 +389,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   };
   flush(accx, XT, mh * XT * 16, a.nx, 0);
   flush(acch, HT, mh * HT * 16, a.nh + a.nz, a.nx);
+  WBWG(4);
 }
 
 template <int HM, int XP>
@@ -391,6 +414,9 @@ __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_pair_kernel(WgradArgs a
 #ifdef WB_STAMPS
 extern "C" int clv_debug_wb_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_wb_stamps), sizeof(unsigned long long) * 64 * 8 * 2);
+}
+extern "C" int clv_debug_wb_wg(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_wb_wg), sizeof(unsigned long long) * 1024 * 5);
 }
 #endif
 
