@@ -440,12 +440,13 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
                 lstm_pair_bwd_with_it_us=round(1e3 * by['lstm_pair_bwd'][2] / by['lstm_pair_bwd'][1] - event_pair_us, 2),
                 lstm_pair_bwd_without_it_us=us(alt, 'lstm_pair_bwd'), label_bwd_own_launch_us=us(alt, 'vrnn_label_bwd'),
                 measured="this run: a second pass of %d eager steps with CLV_LABEL_IN_PAIR off" % max(reps // 2, 4))
-    if 'lstm_wgrad_bf16' in by:
+    wkeys = [k for k in by if k.startswith('lstm_wgrad_bf16')]      # one launch per LSTM, or both in one (..._pair)
+    if wkeys:
         # the batched gate GEMM of the north star: every kernel gradient of an LSTM, [x | h | z]^T . dz over B*T rows
         # (csrc/wgrad_bf16.hip), formed on the BF16 matrix cores from exact pieces.  Reported against the pipe it
         # runs on: (a) issued bf16 MFMA flops / 2.5 PFLOP/s, (b) the MFMA-busy counter of the committed SQ pass;
         # the algorithmic fp32-equivalent rate is given by name, never as a fraction of a peak it does not use.
-        gn, gms = by['lstm_wgrad_bf16'][1], by['lstm_wgrad_bf16'][2]
+        gn, gms = sum(by[k][1] for k in wkeys), sum(by[k][2] for k in wkeys)
         gms -= gn * event_pair_us * 1e-3
         rows = (88 + 88) + (88 + w['L'] + 88)
         alg = 2.0 * rows * 352 * B * w['T'] * reps                     # algorithmic flops of the products, both LSTMs
@@ -454,7 +455,7 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
         for nz in (0, w['L']):                                         # encoder, decoder
             wide = 88 + nz > 96 or nz > 8
             h_tiles, x_tiles, col_tiles = (8 if wide else 6), 6, 24   # 16-row tiles of [h | z] and x; 2 x 12 column tiles
-            mfmas = (x_tiles * (1 if exact else 3) * 3 + h_tiles * 9) * col_tiles * (B * w['T'] // 32)
+            mfmas = (x_tiles * (1 if exact else 3) * 3 + h_tiles * 6) * col_tiles * (B * w['T'] // 32)
             issued += mfmas * 2.0 * 16 * 16 * 32
         issued *= reps
         sq = None
@@ -468,13 +469,14 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
             except Exception:
                 continue
         roofline['gate_gemm'] = dict(
-            kernel='lstm_wgrad_bf16', avg_launch_us=round(gms / gn * 1e3, 2), bound="mfma", pipe="bf16 MFMA (v_mfma_f32_16x16x32_bf16)",
+            kernel='+'.join(sorted(wkeys)), avg_launch_us=round(gms / gn * 1e3, 2), launches_per_step=round(gn / reps, 2),
+            us_per_step=round(gms / reps * 1e3, 2), bound="mfma", pipe="bf16 MFMA (v_mfma_f32_16x16x32_bf16)",
             peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
             achieved=round(issued / (gms * 1e-3) / 1e12, 1), frac=round(issued / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            achieved_is="issued bf16 MFMA flops (padded tiles, 9 piece pairs per fp32 product, 3 for byte-valued frames) / launch time",
+            achieved_is="issued bf16 MFMA flops (padded tiles, 6 piece pairs per fp32 product, 3 for byte-valued frames) / launch time",
             mfma_busy_counter=sq,
             fp32_equivalent_tflops=round(alg / (gms * 1e-3) / 1e12, 2),
-            arithmetic="exact fp32 products from 3 bf16 pieces per operand, fp32 accumulate")
+            arithmetic="fp32 operands as 3 bf16 pieces each, the piece pairs above 2^-25 of the product (6 of 9; exact), fp32 accumulate")
     return roofline
 
 
