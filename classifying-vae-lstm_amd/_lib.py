@@ -154,6 +154,8 @@ SIGNATURES = {
     "clv_sparse_dense": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p]),
     "clv_sparse_outer_ex": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
+    "clv_dense_outer_bf16_supported": (_i, [_i, _i, _i, _i, _i]),
+    "clv_dense_outer_bf16": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "clv_gemm_bce_f32": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _i, _p, _p]),
     "clv_out_head_train_supported": (_i, [_i, _i]),
     "clv_out_head_train_workspace_bytes": (_sz, [_i]),

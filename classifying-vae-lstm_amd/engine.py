@@ -581,6 +581,8 @@ class VrnnEngine(_EngineBase):
         self.frames_exact_bf16 = bool(cfg.get('frames_exact_bf16', False))
         # ... and both LSTMs' in one launch where they take the same form of the kernel (grads_tail)
         self.wgrad_pair = bool(cfg.get('wgrad_pair', os.environ.get('CLV_WGRAD_PAIR', '1') != '0'))
+        # the hW layer's kernel gradient dense on the bf16 matrix cores when the frames are exact there (loss_and_grads)
+        self.dense_hw_grad = bool(cfg.get('dense_hw_grad', os.environ.get('CLV_DENSE_HW_GRAD', '1') != '0'))
         self.ws_b = None
         # Note lists (opt-in: cfg['fuse_notes'] / CLV_FUSE_NOTES=1): when the batch was staged from BINARY uint8 frames,
         # the staging launch also writes each frame's list of notes (ops.gather_rows_multi(notes=...)) and the pair
@@ -1085,8 +1087,12 @@ class VrnnEngine(_EngineBase):
                                defer=self._rq())
         if self.sparse_inputs and ops.sparse_dense_supported(D):      # kernel gradient and bias gradient (column sums of dhW)
             # ... and sum_j K dK per column for the optimizer's two-launch form (the batch sum of pre-activation x gradient)
-            ops.sparse_outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'),
-                             gdot=(self.hW, D, P.p('hW/bias'), self.gdot))
+            # frames that are exactly bf16 numbers (kept as bytes): the dense product on the bf16 matrix cores, one pass
+            # over X (csrc/outer_bf16.hip); else the kernel that walks the notes
+            outer = ops.dense_outer_bf16 if (self.dense_hw_grad and self.frames_exact_bf16 and
+                                             ops.dense_outer_bf16_supported(B, T * D, D, T * D, D)) else ops.sparse_outer
+            outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'),
+                  gdot=(self.hW, D, P.p('hW/bias'), self.gdot))
             self.gdot_fresh = True
         else:
             g(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)

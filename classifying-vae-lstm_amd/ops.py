@@ -356,6 +356,18 @@ def sparse_outer(Bn, nx, N, X, ldx, G, ldg, out, ldo=None, colsum=None, gdot=Non
                                          _ptr(colsum), _ptr(h), int(ldh), _ptr(hb), _ptr(go), _stream()), "clv_sparse_outer")
 
 
+def dense_outer_bf16_supported(Bn, nx, N, ldx, ldg):
+    return bool(_lib.lib().clv_dense_outer_bf16_supported(Bn, nx, N, ldx, ldg))
+
+
+def dense_outer_bf16(Bn, nx, N, X, ldx, G, ldg, out, ldo=None, colsum=None, gdot=None):
+    """sparse_outer's product for inputs that are exactly bf16 numbers (frames kept as bytes), dense on the bf16 matrix cores
+    (csrc/outer_bf16.hip); same arguments."""
+    h, ldh, hb, go = gdot if gdot is not None else (None, 0, None, None)
+    check(_lib.lib().clv_dense_outer_bf16(Bn, nx, N, _ptr(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
+                                          _ptr(colsum), _ptr(h), int(ldh), _ptr(hb), _ptr(go), _stream()), "clv_dense_outer_bf16")
+
+
 def vrnn_generate_supported(D, H, L, Cn):
     return bool(_lib.lib().clv_vrnn_generate_supported(D, H, L, Cn))
 

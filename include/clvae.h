@@ -68,7 +68,7 @@ typedef struct clv_noise_draw {
  *   100  rounds 1-2
  *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
  *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
- *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair (additions only) */
+ *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair, clv_dense_outer_bf16 (additions only) */
 #define CLV_ABI_VERSION 400
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
@@ -597,6 +597,16 @@ int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float
  * without a pass over K and dK (clv_adam_wn_step_ex). */
 int clv_sparse_outer_ex(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
                         float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream);
+
+/* The same kernel gradient, dK[j,:N] = sum_b X[b,j] G[b,:] (+ colsum, gdot as in clv_sparse_outer_ex), DENSE on the bf16
+ * matrix cores for inputs that are exactly representable in bf16 -- the caller's promise: 0/1 piano-roll frames, any uint8
+ * value.  X is then one bf16 piece, G three (an fp32 number is exactly the sum of three bf16 numbers), the piece products are
+ * exact and accumulate in fp32: the products of the fp32 path in another summation order.  The kernel streams X once
+ * (csrc/outer_bf16.hip); it replaces the note-walking kernel from a few hundred batch rows on (cl_vrnn/model.py:174-176, the
+ * hW layer's kernel gradient).  N <= 96, N, nx, ldx, ldg multiples of 4, 16-byte aligned X and G, arrays below 2 GiB. */
+int clv_dense_outer_bf16_supported(int Bn, int nx, int N, int ldx, int ldg);
+int clv_dense_outer_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+                         float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream);
 
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
  * HBM-resident data set; replaces the host-side slicing of Model.fit, cl_vae/train.py:66-71).

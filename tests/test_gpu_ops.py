@@ -539,6 +539,40 @@ def test_sparse_outer_matches_dense(dev, Bn, nx, Nn, dense):
     np.testing.assert_allclose(cs.cpu().numpy(), G.astype(np.float64).sum(0), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("Bn,nx,Nn,kind", [(256, 11264, 88, 'notes'),                # config 3
+                                           (1024, 22528, 88, 'notes'),               # config 5: T = 256 windows
+                                           (100, 132, 88, 'bytes'),                  # any uint8 value is exact in bf16
+                                           (37, 96, 20, 'notes'), (1, 4, 4, 'bytes'), (33, 200, 96, 'bytes')])
+def test_dense_outer_bf16_matches_fp64(dev, Bn, nx, Nn, kind):
+    """clv_dense_outer_bf16: dK = X^T G for byte-valued X on the bf16 matrix cores (X one exact piece, G three), the column
+    sums of G and gdot = sum_b (H - hb) G, against fp64 numpy; ragged batch / input / column counts; and against the
+    note-walking kernel it replaces (same bars)."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(Bn + nx + Nn)
+    X = (rng.random((Bn, nx)) < 0.0443).astype(np.float32) if kind == 'notes' else rng.integers(0, 256, (Bn, nx)).astype(np.float32)
+    G = (rng.standard_normal((Bn, Nn)) * np.exp(rng.standard_normal((Bn, 1)))).astype(np.float32)
+    H = np.maximum(rng.standard_normal((Bn, Nn)), 0).astype(np.float32)
+    hb = rng.standard_normal(Nn).astype(np.float32)
+    assert ops.dense_outer_bf16_supported(Bn, nx, Nn, nx, Nn)
+    assert not ops.dense_outer_bf16_supported(Bn, nx, 100, nx, 100)              # more than 96 columns
+    out = torch.full((nx, Nn), -3.0, dtype=torch.float32, device=dev)
+    cs, gd = torch.full((Nn,), -3.0, device=dev), torch.full((Nn,), -3.0, device=dev)
+    ops.dense_outer_bf16(Bn, nx, Nn, T(X, dev), nx, T(G, dev), Nn, out, colsum=cs, gdot=(T(H, dev), Nn, T(hb, dev), gd))
+    torch.cuda.synchronize()
+    f8 = lambda a: a.astype(np.float64)
+    ref = f8(X).T @ f8(G)
+    mag = np.abs(f8(X)).T @ np.abs(f8(G)) + 1e-30
+    err = np.abs(out.cpu().numpy() - ref) / mag
+    assert err.max() < 2e-6, err.max()                 # an fp32 accumulation of exact products over Bn terms
+    np.testing.assert_allclose(cs.cpu().numpy(), f8(G).sum(0), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gd.cpu().numpy(), ((f8(H) - f8(hb)) * f8(G)).sum(0), rtol=2e-5, atol=1e-4)
+    out2 = torch.full((nx, Nn), -3.0, dtype=torch.float32, device=dev)
+    if Nn % 2 == 0 and Nn <= 128:
+        ops.sparse_outer(Bn, nx, Nn, T(X, dev), nx, T(G, dev), Nn, out2)
+        torch.cuda.synchronize()
+        assert (np.abs(out2.cpu().numpy() - out.cpu().numpy()) / mag).max() < 4e-6
+
+
 @pytest.mark.parametrize("M,Nn,K", [(100, 88, 88), (37, 18, 40), (70, 130, 24)])
 def test_gemm_bce_matches_separate_kernels(dev, M, Nn, K):
     """Output head with the NLL fused into the GEMM epilogue == GEMM followed by clv_bernoulli_nll."""
