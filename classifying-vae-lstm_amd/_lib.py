@@ -179,6 +179,12 @@ SIGNATURES = {
     "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _p, _p]),
+    "clv_vrnn_label_fwd_parts": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                  _p, _p, _p]),
+    "clv_dense_window_fwd_bf16_supported": (_i, [_i, _i, _i, _i, _i]),
+    "clv_dense_window_fwd_bf16_splits": (_i, [_i, _i]),
+    "clv_dense_window_fwd_bf16_workspace_bytes": (_sz, [_i, _i, _i]),
+    "clv_dense_window_fwd_bf16": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _sz, _p]),
     "clv_vrnn_label_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "clv_vrnn_label_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_vrnn_label_bwd_ex": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, _p, _sz,

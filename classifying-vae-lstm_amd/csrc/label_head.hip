@@ -161,6 +161,9 @@ struct LabelFwdXArgs {
   const float* bh;         // [D]
   int nx, ldx;
   PairPackArgs pack;       // out != null: also write the pair kernels' weight pack
+  // part != null: X . Kh arrives as split-K partial sums [splits][B][D] (dense_window_fwd_bf16_kernel, outer_bf16.hip: the
+  // dense product on the bf16 matrix cores for byte-valued frames); the workgroup sums its row's, X / Kh are not read
+  const float* part; int splits;
 };
 __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax) {
   __shared__ float2 part[16][64];
@@ -186,32 +189,48 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   // wave pays one L2 round trip per PAIR of chunks (a window row has 176 chunks, 11 per wave).  (Four chunks per iteration,
   // 16 rows in flight per lane: 74 registers instead of 62, i.e. one workgroup per CU instead of two, and slower -- 24.9 us
   // against 22.8 at configuration 3, 131 against 119 at configuration 5.)
-  auto xload = [&](int ch) { return ch < nchunk ? xr[min(ch * 64 + lane, ax.nx - 1)] : 0.f; };
-  float xa = xload(wave), xb = xload(wave + 16);
-  for (int ch = wave; ch < nchunk; ch += 32) {
-    const float x0 = xa, x1 = xb;
-    const int j0 = ch * 64, j1 = (ch + 16) * 64;
-    xa = xload(ch + 32); xb = xload(ch + 48);
-    unsigned long long m0 = __ballot(j0 + lane < ax.nx && x0 != 0.f);
-    unsigned long long m1 = __ballot(ch + 16 < nchunk && j1 + lane < ax.nx && x1 != 0.f);
-    while (m0 | m1) {
-      int kk[8];
-      float vv[8];
+  if (ax.part) {
+    // wave w sums the chunks w, w + 16, ..: up to 8 loads of a lane in flight
+    const float2* pp = reinterpret_cast<const float2*>(ax.part + (size_t)b * a.D) + lc;
+    const size_t cs = (size_t)a.B * a.D / 2;               // float2 per chunk
+    for (int c0 = wave; c0 < ax.splits; c0 += 8 * 16) {
+      float2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)min(c0 + 16 * q, ax.splits - 1) * cs];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        unsigned long long& m = q < 4 ? m0 : m1;
-        const bool on = m != 0;
-        const int bit = on ? __builtin_ctzll(m) : 0;
-        m = on ? (m & (m - 1)) : 0;
-        kk[q] = (q < 4 ? j0 : j1) + bit;
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q < 4 ? x0 : x1), bit));
-        vv[q] = on ? v : 0.f;
+        const float mk = c0 + 16 * q < ax.splits ? 1.f : 0.f;
+        acc.x = fmaf(v[q].x, mk, acc.x); acc.y = fmaf(v[q].y, mk, acc.y);
       }
-      float2 kr[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) kr[q] = K2[(size_t)min(kk[q], ax.nx - 1) * n2 + lc];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
+    }
+  } else {
+    auto xload = [&](int ch) { return ch < nchunk ? xr[min(ch * 64 + lane, ax.nx - 1)] : 0.f; };
+    float xa = xload(wave), xb = xload(wave + 16);
+    for (int ch = wave; ch < nchunk; ch += 32) {
+      const float x0 = xa, x1 = xb;
+      const int j0 = ch * 64, j1 = (ch + 16) * 64;
+      xa = xload(ch + 32); xb = xload(ch + 48);
+      unsigned long long m0 = __ballot(j0 + lane < ax.nx && x0 != 0.f);
+      unsigned long long m1 = __ballot(ch + 16 < nchunk && j1 + lane < ax.nx && x1 != 0.f);
+      while (m0 | m1) {
+        int kk[8];
+        float vv[8];
+  #pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          unsigned long long& m = q < 4 ? m0 : m1;
+          const bool on = m != 0;
+          const int bit = on ? __builtin_ctzll(m) : 0;
+          m = on ? (m & (m - 1)) : 0;
+          kk[q] = (q < 4 ? j0 : j1) + bit;
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q < 4 ? x0 : x1), bit));
+          vv[q] = on ? v : 0.f;
+        }
+        float2 kr[8];
+  #pragma unroll
+        for (int q = 0; q < 8; ++q) kr[q] = K2[(size_t)min(kk[q], ax.nx - 1) * n2 + lc];
+  #pragma unroll
+        for (int q = 0; q < 8; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
+      }
     }
   }
   part[wave][lane] = acc;
@@ -302,22 +321,22 @@ extern "C" int clv_vrnn_label_bwd_ex(int B, int D, int C, int G4, const float* d
   return st;
 }
 
-extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
-                                    const float* bh, float* hW_out, const float* Ka, const float* ba,
-                                    float* eps, const float* onehot, float prior_logvar,
-                                    const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
-                                    float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                                    const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh, const float* part,
+                              int splits, const float* bh, float* hW_out, const float* Ka, const float* ba,
+                              float* eps, const float* onehot, float prior_logvar,
+                              const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                              float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                              const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
   if (pack && (pack->H != LH || !clv_lstm_pair_supported(pack->H, pack->L) || !pack->U_enc || !pack->U_dec || !pack->Kz ||
                !pack->Wz || !pack->pack || ((uintptr_t)pack->pack) % 16))
     return CLV_EINVAL;
-  if (B <= 0 || D <= 0 || D > 128 || D % 2 != 0 || C < 2 || C > LH_MAXC || G4 <= 0 || nx <= 0 || ldx < nx) return CLV_EINVAL;
-  if (!X || !Kh || !bh || !hW_out || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss ||
+  if (B <= 0 || D <= 0 || D > 128 || D % 2 != 0 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
+  if (part ? (splits <= 0 || ((uintptr_t)part) % 8 != 0) : (nx <= 0 || ldx < nx || !X || !Kh || ((uintptr_t)Kh) % 8 != 0)) return CLV_EINVAL;
+  if (!bh || !hW_out || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss ||
       !rb_enc || !rb_dec)
     return CLV_EINVAL;
-  if (((uintptr_t)Kh) % 8 != 0) return CLV_EINVAL;
   LabelFwdXArgs a{{B, D, C, G4, hW_out, Ka, ba, eps, {0, 0, 0, 0, 0, 0, nullptr}, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec,
-                   wargs, W, rowloss, rb_enc, rb_dec}, X, Kh, bh, nx, ldx, {0, nullptr, nullptr, nullptr, nullptr, nullptr}};
+                   wargs, W, rowloss, rb_enc, rb_dec}, X, Kh, bh, nx, ldx, {0, nullptr, nullptr, nullptr, nullptr, nullptr}, part, splits};
   if (pack) a.pack = PairPackArgs{pack->L, pack->U_enc, pack->U_dec, pack->Kz, pack->Wz, reinterpret_cast<float4*>(pack->pack)};
   if (noise) {
     a.l.noise.on = 1; a.l.noise.k0 = (uint32_t)noise->seed; a.l.noise.k1 = (uint32_t)(noise->seed >> 32);
@@ -328,4 +347,25 @@ extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X,
   ProfScope p("vrnn_label_fwd", s);
   hipLaunchKernelGGL(vrnn_label_fwd_x_kernel, dim3(B), dim3(1024), 0, s, a);
   return launch_status();
+}
+
+extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
+                                    const float* bh, float* hW_out, const float* Ka, const float* ba,
+                                    float* eps, const float* onehot, float prior_logvar,
+                                    const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                                    float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                                    const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+  return label_fwd_x_launch(B, D, C, G4, X, ldx, nx, Kh, nullptr, 0, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc,
+                            Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
+}
+
+extern "C" int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float* part, int splits,
+                                        const float* bh, float* hW_out, const float* Ka, const float* ba,
+                                        float* eps, const float* onehot, float prior_logvar,
+                                        const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                                        float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                                        const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+  if (!part) return CLV_EINVAL;
+  return label_fwd_x_launch(B, D, C, G4, nullptr, 0, 0, nullptr, part, splits, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w,
+                            benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
 }

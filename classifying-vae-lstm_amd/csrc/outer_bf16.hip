@@ -1,5 +1,6 @@
-// outer_bf16.hip -- the kernel gradient of a Dense layer over a whole flattened window, dK[j,:] = sum_b X[b,j] G[b,:],
-// on the bf16 matrix cores when X is exactly representable in bf16 (piano-roll frames kept as bytes)   (gfx950)
+// outer_bf16.hip -- a Dense layer over a whole flattened window on the bf16 matrix cores when its input X is exactly
+// representable in bf16 (piano-roll frames kept as bytes): the kernel gradient dK[j,:] = sum_b X[b,j] G[b,:], and the forward
+// product X.K as split-K partial sums (dense_window_fwd_bf16_kernel, at the end of the file)   (gfx950)
 //
 // Reference: h_w = Dense(relu)(flat(X)) of cl_vrnn (cl_vrnn/model.py:174-176): 88 * seq_length inputs, 88 outputs; this is
 // what K.gradients forms for its kernel.  sparse_outer_kernel (sparse_proj.hip) walks the ~4 % of notes that are on: each
@@ -187,6 +188,113 @@ __global__ __launch_bounds__(64 * OD_NW) void dense_outer_bf16_kernel(OuterBf16A
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Forward: part[c][b][:] = sum over the inputs i of chunk c of X[b,i] K[i,:]   (h_w = relu(sum_c part + bias) is formed by the
+// consumer: vrnn_label_fwd_x_kernel sums the chunks of its batch row, label_head.hip).
+// The note-walking form gathers ~4 % of K's rows PER BATCH ROW from L2 (config 5: 1000 row gathers of 352 bytes per batch row,
+// 360 MB through L2, 114 us): every row of K is fetched by ~45 batch rows.  Dense, K is one bf16-piece product per 32 inputs:
+// a workgroup owns 16 NW batch rows (a wave's A operand is its 16 rows x 32 inputs straight from HBM: X is row-major, the k
+// index is contiguous, one piece, exact) and a chunk of the inputs; K's 32 x N slab of a stage goes through LDS as three
+// piece images shared by the waves.  Split-K because the output is tiny (B x 88): chunks = 256 / row blocks.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct WindowFwdArgs {
+  int Bn, nx, N, ldx, ldk, chunk;     // chunk: inputs per workgroup (a multiple of 32)
+  const float* X;
+  const float* K;
+  float* part;                        // [chunks][Bn][N]
+};
+constexpr int WF_NW = 4, WF_NT = 64 * WF_NW;
+constexpr int WF_BUF = 3 * OD_IMG, WF_LDS = 2 * WF_BUF;
+
+__global__ __launch_bounds__(WF_NT) void dense_window_fwd_bf16_kernel(WindowFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char od_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < WF_LDS / 16; i += WF_NT) reinterpret_cast<float4*>(od_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int b0 = (blockIdx.x * WF_NW + wave) * 16;
+  const int i0 = blockIdx.y * a.chunk, i1 = min(a.nx, i0 + a.chunk);
+  const int nst = (i1 - i0 + OD_KS - 1) / OD_KS;
+  const int n4 = a.N / 4;
+  const od_rsrc_t r_x = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)(unsigned)((size_t)a.Bn * a.ldx * 4), 0x00020000);
+  // K's descriptor ends with the chunk: the slab rows of the last stage that belong to the next chunk read as zeros
+  const od_rsrc_t r_k = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.K), 0, (int)(unsigned)((size_t)i1 * a.ldk * 4), 0x00020000);
+  // A operand of this lane: row b0 + (lane & 15), inputs i0 + 32 s + 8 (lane >> 4) .. + 7.  An 8-group beyond the chunk is
+  // multiplied by zero rows of K, one beyond nx must not be read (it would be the next row's data): nx % 8 == 0, so a group is
+  // whole; rows beyond the batch fall outside the descriptor.
+  const unsigned xa = 4u * (unsigned)((b0 + (lane & 15)) * a.ldx + i0 + 8 * (lane >> 4));
+  constexpr int KS_ = (OD_KS * 24 + WF_NT - 1) / WF_NT;       // float4 slots of K's slab per thread (3)
+  unsigned kg[KS_];
+  int kl[KS_];
+  bool kok[KS_];
+#pragma unroll
+  for (int i = 0; i < KS_; ++i) {
+    const int e = tid + WF_NT * i;
+    kok[i] = e < OD_KS * n4;
+    const int ek = kok[i] ? e : 0, rk = ek / n4, ck = ek - n4 * rk;
+    kg[i] = kok[i] ? 4u * (unsigned)((i0 + rk) * a.ldk + 4 * ck) : OD_OOB;
+    kl[i] = rk * OD_P + 8 * ck;
+  }
+  constexpr int DEPTH = 4;
+  float4 xr[DEPTH][2], kr[DEPTH][KS_];
+  auto load_stage = [&](float4 (&xq)[2], float4 (&kq)[KS_], int s) {
+    const bool in = i0 + OD_KS * s + 8 * (lane >> 4) < a.nx;
+    const unsigned xo = in ? xa + 4u * (unsigned)(OD_KS * s) : OD_OOB;
+    xq[0] = od_load4(r_x, xo);
+    xq[1] = od_load4(r_x, in ? xo + 16u : OD_OOB);
+    const unsigned ko = 4u * (unsigned)(OD_KS * s * a.ldk);
+#pragma unroll
+    for (int i = 0; i < KS_; ++i) kq[i] = od_load4(r_k, kg[i] == OD_OOB ? OD_OOB : kg[i] + ko);
+  };
+  auto store_stage = [&](const float4 (&kq)[KS_], int s) {
+    char* buf = od_lds + (s & 1) * WF_BUF;
+#pragma unroll
+    for (int i = 0; i < KS_; ++i)
+      if (kok[i]) img_put4<3>(buf + kl[i], OD_IMG, kq[i]);
+  };
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_stage(xr[d], kr[d], d);
+  store_stage(kr[0], 0);
+  od_f32x4 acc[6];
+#pragma unroll
+  for (int n = 0; n < 6; ++n) acc[n] = od_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fo = img_frag_lane_offset(OD_P, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // stage s: its A operand sits in set s % 4 (xs), its K images in buffer s & 1; K of stage s + 1 (set xn / kn) goes to the
+  // other buffer; then the request for stage s + 4 into the set that held stage s
+  auto stage = [&](int s, float4 (&xs)[2], float4 (&ks)[KS_], const float4 (&kn)[KS_]) {
+    const char* buf = od_lds + (s & 1) * WF_BUF;
+    const od_u32x4 au = {bf16_pack2(xs[0].x, xs[0].y), bf16_pack2(xs[0].z, xs[0].w), bf16_pack2(xs[1].x, xs[1].y), bf16_pack2(xs[1].z, xs[1].w)};
+    const img_bf16x8 ax = __builtin_bit_cast(img_bf16x8, au);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      img_bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = img_frag(buf + p * OD_IMG, OD_P, 16 * n, fo);
+#pragma unroll
+      for (int p = 2; p >= 0; --p) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, b[p], acc[n], 0, 0, 0);
+    }
+    store_stage(kn, s + 1);
+    load_stage(xs, ks, s + DEPTH);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int s = 0; s < nst; s += DEPTH) {         // (stages beyond the chunk: K reads as zeros, the accumulators do not move)
+    stage(s, xr[0], kr[0], kr[1]);
+    stage(s + 1, xr[1], kr[1], kr[2]);
+    stage(s + 2, xr[2], kr[2], kr[3]);
+    stage(s + 3, xr[3], kr[3], kr[0]);
+  }
+  float* out = a.part + (size_t)blockIdx.y * a.Bn * a.N;
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + 4 * (lane >> 4) + r, c = 16 * n + (lane & 15);
+      if (b < a.Bn && c < a.N) out[(size_t)b * a.N + c] = acc[n][r];
+    }
+}
+
 }  // namespace clv
 
 extern "C" int clv_dense_outer_bf16_supported(int Bn, int nx, int N, int ldx, int ldg) {
@@ -211,5 +319,41 @@ extern "C" int clv_dense_outer_bf16(int Bn, int nx, int N, const float* X, int l
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(dense_outer_bf16_kernel<3>), OD_LDS)) return e;
     hipLaunchKernelGGL(dense_outer_bf16_kernel<3>, dim3((nx + 47) / 48 + extra), dim3(192), OD_LDS, s, a);
   }
+  return launch_status();
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------------------
+static int window_fwd_chunk(int Bn, int nx) {
+  const int rb = (Bn + 16 * clv::WF_NW - 1) / (16 * clv::WF_NW);
+  int chunks = (256 + rb - 1) / rb;                       // one workgroup per CU
+  if (chunks > nx / 64) chunks = nx / 64;                 // ... of at least two stages
+  if (chunks < 1) chunks = 1;
+  const int chunk = ((nx + chunks - 1) / chunks + 31) / 32 * 32;
+  return chunk;
+}
+extern "C" int clv_dense_window_fwd_bf16_supported(int Bn, int nx, int N, int ldx, int ldk) {
+  return Bn > 0 && nx >= 8 && nx % 8 == 0 && N >= 4 && N <= 96 && N % 4 == 0 && ldx % 4 == 0 && ldk % 4 == 0 && ldx >= nx && ldk >= N &&
+         (size_t)Bn * (size_t)ldx * 4 < 0x80000000ull && (size_t)nx * (size_t)ldk * 4 < 0x80000000ull;
+}
+extern "C" int clv_dense_window_fwd_bf16_splits(int Bn, int nx) {
+  const int chunk = window_fwd_chunk(Bn, nx);
+  return (nx + chunk - 1) / chunk;
+}
+extern "C" size_t clv_dense_window_fwd_bf16_workspace_bytes(int Bn, int nx, int N) {
+  return (size_t)clv_dense_window_fwd_bf16_splits(Bn, nx) * Bn * N * sizeof(float);
+}
+extern "C" int clv_dense_window_fwd_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* K, int ldk, float* part,
+                                         size_t part_bytes, void* stream) {
+  using namespace clv;
+  if (!clv_dense_window_fwd_bf16_supported(Bn, nx, N, ldx, ldk) || !X || !K) return CLV_EINVAL;
+  if (((uintptr_t)X) % 16 != 0 || ((uintptr_t)K) % 16 != 0) return CLV_EINVAL;
+  if (!part || part_bytes < clv_dense_window_fwd_bf16_workspace_bytes(Bn, nx, N)) return CLV_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(dense_window_fwd_bf16_kernel), WF_LDS)) return e;
+  const int chunk = window_fwd_chunk(Bn, nx);
+  WindowFwdArgs a{Bn, nx, N, ldx, ldk, chunk, X, K, part};
+  ProfScope p("dense_window_fwd_bf16", s);
+  hipLaunchKernelGGL(dense_window_fwd_bf16_kernel, dim3((Bn + 16 * WF_NW - 1) / (16 * WF_NW), (nx + chunk - 1) / chunk), dim3(WF_NT),
+                     WF_LDS, s, a);
   return launch_status();
 }

@@ -493,19 +493,36 @@ def _noise_ref(noise):
 
 
 def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, onehot, prior, Kenc_w, benc, Kdec_w, bdec, wargs,
-                     W, rowloss, rb_enc, rb_dec, noise=None, pack=None):
+                     W, rowloss, rb_enc, rb_dec, noise=None, pack=None, parts=None):
     """hW = relu(X . Kh + bh) over the nonzero inputs of each row, then vrnn_label_fwd, one workgroup per row.
     noise: a noise_draw(): eps is drawn in the kernel (and written to `eps`) instead of read.
-    pack = (L, U_enc, U_dec, Kz, Wz, out): the launch also writes the pair LSTM kernels' weight pack (lstm_pair_pack)."""
+    pack = (L, U_enc, U_dec, Kz, Wz, out): the launch also writes the pair LSTM kernels' weight pack (lstm_pair_pack).
+    parts = (buffer, splits): X . Kh was formed by dense_window_fwd_bf16 as split-K partial sums; X / Kh are not read."""
     ps = None
     if pack is not None:
         L_, ue, ud, kz, wz, out = pack
         ps = _lib.PairPackSrc(88, int(L_), _ptr(ue), _ptr(ud), _ptr(kz), _ptr(wz), _ptr(out))
-    check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), _ptr(bh), _ptr(hW_out), _ptr(Ka),
-                                          _ptr(ba), _ptr(eps), _ptr(onehot), float(prior), _ptr(Kenc_w), _ptr(benc),
-                                          _ptr(Kdec_w), _ptr(bdec), _ptr(wargs), _ptr(W), _ptr(rowloss), _ptr(rb_enc),
-                                          _ptr(rb_dec), _noise_ref(noise), C.byref(ps) if ps is not None else None, _stream()),
-          "clv_vrnn_label_fwd_x")
+    tail = (_ptr(bh), _ptr(hW_out), _ptr(Ka), _ptr(ba), _ptr(eps), _ptr(onehot), float(prior), _ptr(Kenc_w), _ptr(benc),
+            _ptr(Kdec_w), _ptr(bdec), _ptr(wargs), _ptr(W), _ptr(rowloss), _ptr(rb_enc), _ptr(rb_dec), _noise_ref(noise),
+            C.byref(ps) if ps is not None else None, _stream())
+    if parts is not None:
+        check(_lib.lib().clv_vrnn_label_fwd_parts(B, D, Cn, G4, _ptr(parts[0]), int(parts[1]), *tail), "clv_vrnn_label_fwd_parts")
+    else:
+        check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), *tail), "clv_vrnn_label_fwd_x")
+
+
+def dense_window_fwd_bf16_supported(Bn, nx, N, ldx, ldk):
+    return bool(_lib.lib().clv_dense_window_fwd_bf16_supported(Bn, nx, N, ldx, ldk))
+
+
+def dense_window_fwd_bf16(Bn, nx, N, X, ldx, K, ldk, ws):
+    """X . K for byte-valued X as split-K partial sums on the bf16 matrix cores (csrc/outer_bf16.hip); returns (buffer, splits)
+    for vrnn_label_fwd_x(parts=...).  ws: a Workspace that keeps the buffer."""
+    L = _lib.lib()
+    buf = ws.ensure(L.clv_dense_window_fwd_bf16_workspace_bytes(Bn, nx, N))
+    check(L.clv_dense_window_fwd_bf16(Bn, nx, N, _ptr(X), ldx, _ptr(K), ldk, _ptr(buf), buf.numel(), _stream()),
+          "clv_dense_window_fwd_bf16")
+    return buf, L.clv_dense_window_fwd_bf16_splits(Bn, nx)
 
 
 def vrnn_label_bwd(B, D, Cn, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior,

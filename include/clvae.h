@@ -68,7 +68,8 @@ typedef struct clv_noise_draw {
  *   100  rounds 1-2
  *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
  *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
- *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair, clv_dense_outer_bf16 (additions only) */
+ *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair, clv_dense_outer_bf16,
+ *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts (additions only) */
 #define CLV_ABI_VERSION 400
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
@@ -493,6 +494,25 @@ int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, i
                          const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                          float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
                          const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
+/* The hW layer's product as a DENSE one on the bf16 matrix cores, for inputs that are exactly representable in bf16 (the
+ * caller's promise: 0/1 piano-roll frames, any uint8 value): part[c][b][:N] = sum over the inputs i of chunk c of
+ * X[b,i] K[i,:], c < clv_dense_window_fwd_bf16_splits(Bn, nx) (split-K: the output is only [Bn,N]); X is one bf16 piece, K
+ * three, the piece products are exact and accumulate in fp32.  clv_vrnn_label_fwd_parts is clv_vrnn_label_fwd_x with that
+ * product handed in: the workgroup of a batch row sums its row of the chunks, adds bh, applies the relu and goes on with the
+ * label path.  From a few hundred batch rows on this replaces the note-walking gather (every kernel row is then fetched
+ * once per workgroup instead of once per batch row that has the note).  N <= 96; N, ldx, ldk multiples of 4, nx of 8;
+ * 16-byte aligned X and K; arrays below 2 GiB.  cl_vrnn/model.py:174-176. */
+int clv_dense_window_fwd_bf16_supported(int Bn, int nx, int N, int ldx, int ldk);
+int clv_dense_window_fwd_bf16_splits(int Bn, int nx);
+size_t clv_dense_window_fwd_bf16_workspace_bytes(int Bn, int nx, int N);
+int clv_dense_window_fwd_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* K, int ldk, float* part,
+                              size_t part_bytes, void* stream);
+int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float* part, int splits,
+                             const float* bh, float* hW_out, const float* Ka, const float* ba,
+                             float* eps, const float* onehot, float prior_logvar,
+                             const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                             float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                             const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
 int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
                        const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
                        const float* onehot, const float* W, const float* hW, const float* Ka,

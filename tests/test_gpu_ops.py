@@ -573,6 +573,35 @@ def test_dense_outer_bf16_matches_fp64(dev, Bn, nx, Nn, kind):
         assert (np.abs(out2.cpu().numpy() - out.cpu().numpy()) / mag).max() < 4e-6
 
 
+@pytest.mark.parametrize("Bn,nx,Nn,kind", [(256, 11264, 88, 'notes'), (1024, 22528, 88, 'notes'), (100, 136, 88, 'bytes'),
+                                           (37, 96, 20, 'notes'), (1, 8, 4, 'bytes'), (70, 2000, 96, 'bytes')])
+def test_dense_window_fwd_bf16_matches_fp64(dev, Bn, nx, Nn, kind):
+    """clv_dense_window_fwd_bf16: the split-K partial sums of X . K for byte-valued X on the bf16 matrix cores (X one exact
+    piece, K three); their sum against fp64 numpy; ragged row / input / column counts, chunk borders inside a stage."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(Bn + nx + Nn + 1)
+    X = (rng.random((Bn, nx)) < 0.0443).astype(np.float32) if kind == 'notes' else rng.integers(0, 256, (Bn, nx)).astype(np.float32)
+    K = (rng.standard_normal((nx, Nn)) * np.exp(rng.standard_normal((nx, 1)))).astype(np.float32)
+    assert ops.dense_window_fwd_bf16_supported(Bn, nx, Nn, nx, Nn)
+    assert not ops.dense_window_fwd_bf16_supported(Bn, nx + 4, Nn, nx + 4, Nn)        # inputs in whole groups of 8
+    ws = ops.Workspace(dev)
+    buf, splits = ops.dense_window_fwd_bf16(Bn, nx, Nn, T(X, dev), nx, T(K, dev), Nn, ws)
+    torch.cuda.synchronize()
+    parts = buf.view(torch.float32)[:splits * Bn * Nn].reshape(splits, Bn, Nn).cpu().numpy().astype(np.float64)
+    f8 = lambda a: a.astype(np.float64)
+    ref = f8(X) @ f8(K)
+    mag = np.abs(f8(X)) @ np.abs(f8(K)) + 1e-30
+    err = np.abs(parts.sum(0) - ref) / mag
+    assert err.max() < 2e-6, err.max()
+    # every chunk holds the sum over ITS inputs only
+    chunk = -(-nx // splits)
+    chunk = (chunk + 31) // 32 * 32
+    for c in (0, splits - 1):
+        sl = slice(c * chunk, min(nx, (c + 1) * chunk))
+        e = np.abs(parts[c] - f8(X[:, sl]) @ f8(K[sl])) / mag
+        assert e.max() < 2e-6, (c, e.max())
+
+
 @pytest.mark.parametrize("M,Nn,K", [(100, 88, 88), (37, 18, 40), (70, 130, 24)])
 def test_gemm_bce_matches_separate_kernels(dev, M, Nn, K):
     """Output head with the NLL fused into the GEMM epilogue == GEMM followed by clv_bernoulli_nll."""
