@@ -189,48 +189,32 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   // wave pays one L2 round trip per PAIR of chunks (a window row has 176 chunks, 11 per wave).  (Four chunks per iteration,
   // 16 rows in flight per lane: 74 registers instead of 62, i.e. one workgroup per CU instead of two, and slower -- 24.9 us
   // against 22.8 at configuration 3, 131 against 119 at configuration 5.)
-  if (ax.part) {
-    // wave w sums the chunks w, w + 16, ..: up to 8 loads of a lane in flight
-    const float2* pp = reinterpret_cast<const float2*>(ax.part + (size_t)b * a.D) + lc;
-    const size_t cs = (size_t)a.B * a.D / 2;               // float2 per chunk
-    for (int c0 = wave; c0 < ax.splits; c0 += 8 * 16) {
-      float2 v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)min(c0 + 16 * q, ax.splits - 1) * cs];
+  auto xload = [&](int ch) { return ch < nchunk ? xr[min(ch * 64 + lane, ax.nx - 1)] : 0.f; };
+  float xa = xload(wave), xb = xload(wave + 16);
+  for (int ch = wave; ch < nchunk; ch += 32) {
+    const float x0 = xa, x1 = xb;
+    const int j0 = ch * 64, j1 = (ch + 16) * 64;
+    xa = xload(ch + 32); xb = xload(ch + 48);
+    unsigned long long m0 = __ballot(j0 + lane < ax.nx && x0 != 0.f);
+    unsigned long long m1 = __ballot(ch + 16 < nchunk && j1 + lane < ax.nx && x1 != 0.f);
+    while (m0 | m1) {
+      int kk[8];
+      float vv[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float mk = c0 + 16 * q < ax.splits ? 1.f : 0.f;
-        acc.x = fmaf(v[q].x, mk, acc.x); acc.y = fmaf(v[q].y, mk, acc.y);
+        unsigned long long& m = q < 4 ? m0 : m1;
+        const bool on = m != 0;
+        const int bit = on ? __builtin_ctzll(m) : 0;
+        m = on ? (m & (m - 1)) : 0;
+        kk[q] = (q < 4 ? j0 : j1) + bit;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q < 4 ? x0 : x1), bit));
+        vv[q] = on ? v : 0.f;
       }
-    }
-  } else {
-    auto xload = [&](int ch) { return ch < nchunk ? xr[min(ch * 64 + lane, ax.nx - 1)] : 0.f; };
-    float xa = xload(wave), xb = xload(wave + 16);
-    for (int ch = wave; ch < nchunk; ch += 32) {
-      const float x0 = xa, x1 = xb;
-      const int j0 = ch * 64, j1 = (ch + 16) * 64;
-      xa = xload(ch + 32); xb = xload(ch + 48);
-      unsigned long long m0 = __ballot(j0 + lane < ax.nx && x0 != 0.f);
-      unsigned long long m1 = __ballot(ch + 16 < nchunk && j1 + lane < ax.nx && x1 != 0.f);
-      while (m0 | m1) {
-        int kk[8];
-        float vv[8];
-  #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          unsigned long long& m = q < 4 ? m0 : m1;
-          const bool on = m != 0;
-          const int bit = on ? __builtin_ctzll(m) : 0;
-          m = on ? (m & (m - 1)) : 0;
-          kk[q] = (q < 4 ? j0 : j1) + bit;
-          const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q < 4 ? x0 : x1), bit));
-          vv[q] = on ? v : 0.f;
-        }
-        float2 kr[8];
-  #pragma unroll
-        for (int q = 0; q < 8; ++q) kr[q] = K2[(size_t)min(kk[q], ax.nx - 1) * n2 + lc];
-  #pragma unroll
-        for (int q = 0; q < 8; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
-      }
+      float2 kr[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kr[q] = K2[(size_t)min(kk[q], ax.nx - 1) * n2 + lc];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { acc.x = fmaf(vv[q], kr[q].x, acc.x); acc.y = fmaf(vv[q], kr[q].y, acc.y); }
     }
   }
   part[wave][lane] = acc;
@@ -246,6 +230,52 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   }
   __syncthreads();
   label_fwd_row<1024>(a, b, tid, s_h, s_wargs, s_w);
+}
+
+// The same with X . Kh handed in as split-K partial sums (ax.part: dense_window_fwd_bf16_kernel, outer_bf16.hip).  Summing a
+// row's chunks is a few loads per lane, so this workgroup is the label path's size (LH_T threads: five fit a CU, and the
+// 1024 rows of configuration 5 are resident at once; as a mode of the 1024-thread kernel above they took two rounds, 32 us).
+__global__ __launch_bounds__(LH_T) void vrnn_label_fwd_parts_kernel(LabelFwdXArgs ax) {
+  constexpr int NWV = LH_T / 64;
+  __shared__ float2 part[NWV][64];
+  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
+  const LabelFwdArgs& a = ax.l;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (ax.pack.out) {
+    for (int i = blockIdx.x * LH_T + tid; i < PK_TOTAL; i += gridDim.x * LH_T)
+      ax.pack.out[i] = pair_pack_element(i, ax.pack.L, ax.pack.U_e, ax.pack.U_d, ax.pack.Kz, ax.pack.Wz,
+                                         [](const float* p) { return *p; });
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int n2 = a.D / 2;
+  const int lc = min(lane, n2 - 1);
+  float2 acc = make_float2(0.f, 0.f);
+  const float2* pp = reinterpret_cast<const float2*>(ax.part + (size_t)b * a.D) + lc;
+  const size_t cs = (size_t)a.B * a.D / 2;                 // float2 per chunk
+  for (int c0 = wave; c0 < ax.splits; c0 += 8 * NWV) {     // wave w sums the chunks w, w + 6, ..: 8 loads of a lane in flight
+    float2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)min(c0 + NWV * q, ax.splits - 1) * cs];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float mk = c0 + NWV * q < ax.splits ? 1.f : 0.f;
+      acc.x = fmaf(v[q].x, mk, acc.x); acc.y = fmaf(v[q].y, mk, acc.y);
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < n2) {
+    float2 t = make_float2(ax.bh[2 * lane], ax.bh[2 * lane + 1]);
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) { t.x += part[w][lane].x; t.y += part[w][lane].y; }
+    t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f);
+    s_h[2 * lane] = t.x; s_h[2 * lane + 1] = t.y;
+    float* op = a.hW_out() + (size_t)b * a.D + 2 * lane;
+    op[0] = t.x; op[1] = t.y;
+  }
+  __syncthreads();
+  label_fwd_row<LH_T>(a, b, tid, s_h, s_wargs, s_w);
 }
 
 __global__ __launch_bounds__(LH_T) void vrnn_label_bwd_kernel(LabelBwdArgs a) {
@@ -345,7 +375,8 @@ static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int l
   }
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("vrnn_label_fwd", s);
-  hipLaunchKernelGGL(vrnn_label_fwd_x_kernel, dim3(B), dim3(1024), 0, s, a);
+  if (part) hipLaunchKernelGGL(vrnn_label_fwd_parts_kernel, dim3(B), dim3(LH_T), 0, s, a);
+  else hipLaunchKernelGGL(vrnn_label_fwd_x_kernel, dim3(B), dim3(1024), 0, s, a);
   return launch_status();
 }
 
