@@ -38,11 +38,20 @@ constexpr int WB_XT = 6;             // row tiles of the x block (nx <= 96)
 // 32-lane half are 8 rows apart: with a pitch of 8 banks more than a multiple of 64 (dz: 416 B = 104 banks) or 48 banks
 // (192 B) the 4 rows of a group fall on different banks; the second group lands on the first one's (2-way, unavoidable
 // with a linear pitch: 8 rows x 8 banks would have to tile all 64 banks AND repeat after 8 rows).
-constexpr int WB_DZP = 416;          // dz image: 192 columns + 16 pad
+// WB_SWZ (round 4): the 32-byte segments of image rows 8..15 and 24..31 swapped pairwise (address bit 5 XORed), so that the
+// two 16-lane groups of a transposed read that are 8 rows apart fall on different banks too; needs an even number of
+// 32-byte segments per row (pitches 448 / 320 instead of 416 / 288).  Measured (tools/sessions/r04_wbswz.sh): bank-conflict
+// cycles per LDS-active cycle 0.37 -> 0.16, LDS-active cycles -24 % -- and the launch time does not move (32.5 against
+// 32.6 us at K = 32768, 193 against 193 at 262144): the LDS was never what a stage waited for.  Kept on (-DWB_SWZ=0: linear).
+#ifndef WB_SWZ
+#define WB_SWZ 1
+#endif
+#define WB_SWZ_OF(r) (WB_SWZ ? ((((r) >> 3) & 1) << 5) : 0)
+constexpr int WB_DZP = WB_SWZ ? 448 : 416;          // dz image: 192 columns + 16 pad
 constexpr int WB_AP = 192;           // x image: 96 columns;  h image: 16 * HM columns, pitch below
 
 template <int HM> struct WbGeo {
-  static constexpr int HPB = HM == 6 ? 192 : 288;            // h image pitch (bytes): 96 columns, or 128 + 16 pad (72 banks)
+  static constexpr int HPB = HM == 6 ? 192 : (WB_SWZ ? 320 : 288);            // h image pitch (bytes): 96 columns, or 128 + 16 pad (72 banks)
   static constexpr int DZ_BYTES = 3 * WB_KS * WB_DZP;
   static constexpr int H_BYTES = 3 * WB_KS * HPB;
   template <int XP> static constexpr int x_bytes() { return XP * WB_KS * WB_AP; }
@@ -90,8 +99,8 @@ __device__ __forceinline__ int frag_lane_offset(int pitch, int lane) {
   const int g = lane >> 4, i = lane & 15;
   return (8 * g + (i >> 2)) * pitch + 8 * (i & 3);
 }
-__device__ __forceinline__ bf16x8 frag(const char* img, int pitch, int col0, int lane_off) {
-  const char* p = img + lane_off + 2 * col0;
+__device__ __forceinline__ bf16x8 frag(const char* img, int pitch, int col0, int lane_off, int swz = 0) {
+  const char* p = img + ((lane_off + 2 * col0) ^ swz);
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * pitch));
@@ -177,7 +186,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     for (int i = 0; i < DZ_L; ++i) {
       const int e = pt + i * NP_T, ok = e < WB_KS * 44, ec = ok ? e : 0, r = ec / 44, c4 = ec % 44;
       dz_g[i] = 4u * (unsigned)(r * a.lddz + n0 + 4 * c4);
-      dz_l[i] = (r * WB_DZP + 8 * c4) | (ok ? 0 : IDLE);
+      dz_l[i] = ((r * WB_DZP + 8 * c4) ^ WB_SWZ_OF(r)) | (ok ? 0 : IDLE);
     }
 #pragma unroll
     for (int i = 0; i < A_L; ++i) {
@@ -185,15 +194,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       const int okh = e < WB_KS * nh4, eh = okh ? e : 0, rh = eh / nh4, ch = eh % nh4;
       const int okx = e < WB_KS * nx4, ex = okx ? e : 0, rx = ex / nx4, cx = ex % nx4;
       h_g[i] = 4u * (unsigned)(rh * a.ldh + 4 * ch);
-      h_l[i] = (rh * HPB + 8 * ch) | (rh == 0 ? ROW0 : 0) | (rh == 16 ? ROW16 : 0) | (okh ? 0 : IDLE);
+      h_l[i] = ((rh * HPB + 8 * ch) ^ WB_SWZ_OF(rh)) | (rh == 0 ? ROW0 : 0) | (rh == 16 ? ROW16 : 0) | (okh ? 0 : IDLE);
       x_g[i] = 4u * (unsigned)(rx * a.ldx + 4 * cx);
-      x_l[i] = (rx * WB_AP + 8 * cx) | (okx ? 0 : IDLE);
+      x_l[i] = ((rx * WB_AP + 8 * cx) ^ WB_SWZ_OF(rx)) | (okx ? 0 : IDLE);
     }
 #pragma unroll
     for (int i = 0; i < Z_L; ++i) {
       const int e = pt + i * NP_T, nz1 = max(a.nz, 1), ok = a.nz > 0 && e < WB_KS * a.nz, ez = ok ? e : 0;
       z_g[i] = 4u * (unsigned)((ez / nz1) * a.ldz + ez % nz1);
-      z_l[i] = ((ez / nz1) * HPB + 2 * (a.nh + ez % nz1)) | (ok ? 0 : IDLE);
+      z_l[i] = (((ez / nz1) * HPB + 2 * (a.nh + ez % nz1)) ^ WB_SWZ_OF(ez / nz1)) | (ok ? 0 : IDLE);
     }
     // A stage is "interior" when all of its 32 rows exist, the shifted H rows exist, and a window start can only be its
     // first row or its 17th (h_zero_period a multiple of 16 -- the reference's default seq_length is 16; k_begin is a
@@ -318,6 +327,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     for (int m = 0; m < HT; ++m) acch[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int fo_dz = frag_lane_offset(WB_DZP, lane), fo_h = frag_lane_offset(HPB, lane), fo_x = frag_lane_offset(WB_AP, lane);
+  const int swz = WB_SWZ_OF(lane >> 1);        // lane group g = lane >> 4 reads rows 8g ..: (g & 1) << 5
   stage_barrier();
   WBWG(2);
   for (int s = 0; s < nstage; ++s) {
@@ -329,16 +339,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #pragma unroll
     for (int m = 0; m < XT; ++m)
 #pragma unroll
-      for (int p = 0; p < XP; ++p) ax[m][p] = frag(xi + p * WB_KS * WB_AP, WB_AP, 16 * (mh * XT + m), fo_x);
+      for (int p = 0; p < XP; ++p) ax[m][p] = frag(xi + p * WB_KS * WB_AP, WB_AP, 16 * (mh * XT + m), fo_x, swz);
 #pragma unroll
     for (int m = 0; m < HT; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ah[m][p] = frag(hi + p * WB_KS * HPB, HPB, 16 * (mh * HT + m), fo_h);
+      for (int p = 0; p < 3; ++p) ah[m][p] = frag(hi + p * WB_KS * HPB, HPB, 16 * (mh * HT + m), fo_h, swz);
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
       bf16x8 b[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[p] = frag(dzi + p * WB_KS * WB_DZP, WB_DZP, 16 * (nh2 * NTW + n), fo_dz);
+      for (int p = 0; p < 3; ++p) b[p] = frag(dzi + p * WB_KS * WB_DZP, WB_DZP, 16 * (nh2 * NTW + n), fo_dz, swz);
 #pragma unroll
       for (int m = 0; m < XT; ++m)
 #pragma unroll
