@@ -51,6 +51,16 @@ class BatchCursor(C.Structure):
     _fields_ = [("step_dev", _p), ("step0", C.c_int32), ("period", C.c_int32), ("stride", _i64), ("offset", _i64)]
 
 
+class LabelStage(C.Structure):
+    """clv_label_stage (include/clvae.h)."""
+    _fields_ = [("cur", _p), ("hist", _p),
+                ("cur_stride", _i64), ("cur_offset", _i64), ("hist_stride", _i64), ("hist_offset", _i64), ("row0", _i64),
+                ("cur_table", _p), ("hist_table", _p), ("idx", _p),
+                ("cursor", BatchCursor),
+                ("X", _p), ("Xh", _p), ("hist_chunk", C.c_int32), ("hist_ld", _i64),
+                ("w_src", _p), ("w_out", _p)]
+
+
 class WgradProblem(C.Structure):
     """clv_wgrad_problem (include/clvae.h)."""
     _fields_ = [("K", C.c_int32), ("N", C.c_int32),
@@ -181,6 +191,7 @@ SIGNATURES = {
                                   _p, _p, _p]),
     "clv_vrnn_label_fwd_parts": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _p, _p]),
+    "clv_vrnn_label_fwd_x_staged": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_dense_window_fwd_bf16_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_dense_window_fwd_bf16_splits": (_i, [_i, _i]),
     "clv_dense_window_fwd_bf16_workspace_bytes": (_sz, [_i, _i, _i]),

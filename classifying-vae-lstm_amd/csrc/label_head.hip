@@ -38,7 +38,8 @@ struct LabelFwdArgs {
 
 // label path of row b from its hW activations in s_h (LDS); NT threads take part
 template <int NT>
-__device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int tid, const float* s_h, float* s_wargs, float* s_w) {
+__device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int tid, const float* s_h, float* s_wargs, float* s_w,
+                                              long long oh_row = -1) {      // row of a.onehot that belongs to batch row b (-1: b)
   const int C1 = a.C - 1, NA = 2 * C1;
   // the row's small vectors go to LDS in one round trip: the serial part below (thread 0) would otherwise pay an L2
   // round trip per element
@@ -56,7 +57,7 @@ __device__ __forceinline__ void label_fwd_row(const LabelFwdArgs& a, int b, int 
       }
     }
     s_eps[j] = e;
-    s_oh[j] = a.onehot ? a.onehot[(size_t)b * a.C + j] : 0.f;
+    s_oh[j] = a.onehot ? a.onehot[(size_t)(oh_row < 0 ? b : oh_row) * a.C + j] : 0.f;
   }
   {
     // Wargs = hW . K_a + b_a: [D] x [D, NA] with NA <= 62.  All NT threads take part: thread = (column, k-slice), every
@@ -164,6 +165,19 @@ struct LabelFwdXArgs {
   // part != null: X . Kh arrives as split-K partial sums [splits][B][D] (dense_window_fwd_bf16_kernel, outer_bf16.hip: the
   // dense product on the bf16 matrix cores for byte-valued frames); the workgroup sums its row's, X / Kh are not read
   const float* part; int splits;
+  // stage.on: the workgroup of batch row b ASSEMBLES the row first (clv_label_stage: what the batch gather launch does for
+  // the training step -- byte frames of the data set -> float rows of X and of the history buffer, the label row), reads the
+  // bytes for its own scan, and X / the history frames / the labels are there for every later launch of the step.  The
+  // mini-batch assembly then is no launch of its own.
+  struct Stage {
+    int on;
+    const unsigned char* cur; const unsigned char* hist;       // byte stores (hist may be null)
+    long long cur_stride, cur_offset, hist_stride, hist_offset, row0;
+    const long long* cur_table; const long long* hist_table; const long long* idx;
+    const int* step_dev; int step0, period; long long cur_s, cur_o;      // clv_batch_cursor
+    float* X; float* Xh; int hist_chunk; long long hist_ld;    // history frame p of row b at Xh + (b * pieces + p) * hist_ld
+    const float* w_src; float* w_out;
+  } stage;
 };
 __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax) {
   __shared__ float2 part[16][64];
@@ -183,13 +197,49 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   const int lc = min(lane, n2 - 1);
   const float2* K2 = reinterpret_cast<const float2*>(ax.Kh);
   const float* xr = ax.X + (size_t)b * ax.ldx;
+  const unsigned char* xbytes = nullptr;         // stage.on: the row's current frames as bytes
+  long long oh_row = -1;
+  if (ax.stage.on) {
+    const LabelFwdXArgs::Stage& g = ax.stage;
+    long long base = 0;
+    if (g.step_dev) {
+      int j = (*g.step_dev - g.step0) % g.period;
+      j = j < 0 ? j + g.period : j;
+      base = (long long)j * g.cur_s + g.cur_o;
+    }
+    const long long sr = g.idx ? g.idx[base + b] : g.row0 + base + b;
+    oh_row = sr;
+    xbytes = g.cur + (g.cur_table ? g.cur_table[sr] : sr) * g.cur_stride + g.cur_offset;
+    // bytes -> floats, 4 at a time (nx and the frame length are multiples of 4; the stores are 4-byte aligned: checked by the
+    // launcher); requested before the scan, nothing below waits for the stores
+    float* xo = g.X + (size_t)b * ax.ldx;
+    for (int c = 4 * tid; c < ax.nx; c += 4 * 1024) {
+      const unsigned v = *reinterpret_cast<const unsigned*>(xbytes + c);
+      *reinterpret_cast<float4*>(xo + c) = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+    }
+    if (g.hist) {
+      const unsigned char* hb = g.hist + (g.hist_table ? g.hist_table[sr] : sr) * g.hist_stride + g.hist_offset;
+      const int pieces = ax.nx / g.hist_chunk;
+      for (int c = 4 * tid; c < ax.nx; c += 4 * 1024) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(hb + c);
+        const int p = c / g.hist_chunk, w = c - p * g.hist_chunk;
+        *reinterpret_cast<float4*>(g.Xh + ((size_t)b * pieces + p) * g.hist_ld + w) =
+            make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+      }
+    }
+    if (g.w_out && tid < a.C) g.w_out[(size_t)b * a.C + tid] = g.w_src[(size_t)sr * a.C + tid];
+  }
   float2 acc = make_float2(0.f, 0.f);
   const int nchunk = (ax.nx + 63) / 64;
   // Two chunks of 64 inputs per iteration: their kernel rows (up to 4 each per round) are requested together, so a
   // wave pays one L2 round trip per PAIR of chunks (a window row has 176 chunks, 11 per wave).  (Four chunks per iteration,
   // 16 rows in flight per lane: 74 registers instead of 62, i.e. one workgroup per CU instead of two, and slower -- 24.9 us
   // against 22.8 at configuration 3, 131 against 119 at configuration 5.)
-  auto xload = [&](int ch) { return ch < nchunk ? xr[min(ch * 64 + lane, ax.nx - 1)] : 0.f; };
+  auto xload = [&](int ch) {
+    if (ch >= nchunk) return 0.f;
+    const int i = min(ch * 64 + lane, ax.nx - 1);
+    return xbytes ? (float)xbytes[i] : xr[i];
+  };
   float xa = xload(wave), xb = xload(wave + 16);
   for (int ch = wave; ch < nchunk; ch += 32) {
     const float x0 = xa, x1 = xb;
@@ -229,7 +279,7 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
     op[0] = t.x; op[1] = t.y;
   }
   __syncthreads();
-  label_fwd_row<1024>(a, b, tid, s_h, s_wargs, s_w);
+  label_fwd_row<1024>(a, b, tid, s_h, s_wargs, s_w, oh_row);
 }
 
 // The same with X . Kh handed in as split-K partial sums (ax.part: dense_window_fwd_bf16_kernel, outer_bf16.hip).  Summing a
@@ -352,7 +402,7 @@ extern "C" int clv_vrnn_label_bwd_ex(int B, int D, int C, int G4, const float* d
 }
 
 static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh, const float* part,
-                              int splits, const float* bh, float* hW_out, const float* Ka, const float* ba,
+                              int splits, const clv_label_stage* stage, const float* bh, float* hW_out, const float* Ka, const float* ba,
                               float* eps, const float* onehot, float prior_logvar,
                               const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                               float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
@@ -362,11 +412,31 @@ static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int l
     return CLV_EINVAL;
   if (B <= 0 || D <= 0 || D > 128 || D % 2 != 0 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
   if (part ? (splits <= 0 || ((uintptr_t)part) % 8 != 0) : (nx <= 0 || ldx < nx || !X || !Kh || ((uintptr_t)Kh) % 8 != 0)) return CLV_EINVAL;
+  if (stage) {        // the batch assembly inside the launch: byte stores, 4 bytes / 4 floats at a time
+    const clv_label_stage& g = *stage;
+    if (part || !g.cur || g.X != X || nx % 4 || ldx % 4 || ((uintptr_t)g.cur) % 4 || g.cur_stride % 4 || g.cur_offset % 4 ||
+        ((uintptr_t)X) % 16)
+      return CLV_EINVAL;
+    if (g.hist && (!g.Xh || g.hist_chunk <= 0 || g.hist_chunk % 4 || nx % g.hist_chunk || g.hist_ld % 4 || g.hist_ld < g.hist_chunk ||
+                   ((uintptr_t)g.hist) % 4 || g.hist_stride % 4 || g.hist_offset % 4 || ((uintptr_t)g.Xh) % 16))
+      return CLV_EINVAL;
+    if ((g.w_out != nullptr) != (g.w_src != nullptr)) return CLV_EINVAL;
+    if (g.cursor.step_dev && g.cursor.period < 1) return CLV_EINVAL;
+  }
   if (!bh || !hW_out || !Ka || !ba || !eps || !Kenc_w || !benc || !Kdec_w || !bdec || !wargs || !W || !rowloss ||
       !rb_enc || !rb_dec)
     return CLV_EINVAL;
   LabelFwdXArgs a{{B, D, C, G4, hW_out, Ka, ba, eps, {0, 0, 0, 0, 0, 0, nullptr}, onehot, prior_logvar, Kenc_w, benc, Kdec_w, bdec,
-                   wargs, W, rowloss, rb_enc, rb_dec}, X, Kh, bh, nx, ldx, {0, nullptr, nullptr, nullptr, nullptr, nullptr}, part, splits};
+                   wargs, W, rowloss, rb_enc, rb_dec}, X, Kh, bh, nx, ldx, {0, nullptr, nullptr, nullptr, nullptr, nullptr}, part, splits, {}};
+  if (stage) {
+    const clv_label_stage& g = *stage;
+    a.stage = LabelFwdXArgs::Stage{1, g.cur, g.hist, (long long)g.cur_stride, (long long)g.cur_offset, (long long)g.hist_stride,
+                                   (long long)g.hist_offset, (long long)g.row0, (const long long*)g.cur_table,
+                                   (const long long*)g.hist_table, (const long long*)g.idx, g.cursor.step_dev, g.cursor.step0,
+                                   g.cursor.period, (long long)g.cursor.stride, (long long)g.cursor.offset, g.X, g.Xh, g.hist_chunk,
+                                   (long long)g.hist_ld, g.w_src, g.w_out};
+    if (g.w_src) a.l.onehot = g.w_src;           // the label path reads the row's labels where they come from
+  }
   if (pack) a.pack = PairPackArgs{pack->L, pack->U_enc, pack->U_dec, pack->Kz, pack->Wz, reinterpret_cast<float4*>(pack->pack)};
   if (noise) {
     a.l.noise.on = 1; a.l.noise.k0 = (uint32_t)noise->seed; a.l.noise.k1 = (uint32_t)(noise->seed >> 32);
@@ -386,7 +456,7 @@ extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X,
                                     const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                                     float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
                                     const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
-  return label_fwd_x_launch(B, D, C, G4, X, ldx, nx, Kh, nullptr, 0, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc,
+  return label_fwd_x_launch(B, D, C, G4, X, ldx, nx, Kh, nullptr, 0, nullptr, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc,
                             Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
 }
 
@@ -397,6 +467,17 @@ extern "C" int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float
                                         float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
                                         const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
   if (!part) return CLV_EINVAL;
-  return label_fwd_x_launch(B, D, C, G4, nullptr, 0, 0, nullptr, part, splits, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w,
+  return label_fwd_x_launch(B, D, C, G4, nullptr, 0, 0, nullptr, part, splits, nullptr, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w,
                             benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
+}
+
+extern "C" int clv_vrnn_label_fwd_x_staged(int B, int D, int C, int G4, const clv_label_stage* stage, int ldx, int nx, const float* Kh,
+                                           const float* bh, float* hW_out, const float* Ka, const float* ba,
+                                           float* eps, float prior_logvar,
+                                           const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                                           float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                                           const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+  if (!stage) return CLV_EINVAL;
+  return label_fwd_x_launch(B, D, C, G4, stage->X, ldx, nx, Kh, nullptr, 0, stage, bh, hW_out, Ka, ba, eps, stage->w_src,
+                            prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
 }

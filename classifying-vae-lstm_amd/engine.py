@@ -587,6 +587,7 @@ class VrnnEngine(_EngineBase):
         self.dense_hw_fwd = bool(cfg.get('dense_hw_fwd', os.environ.get('CLV_DENSE_HW_FWD', '1') != '0')) and \
             B >= int(os.environ.get('CLV_DENSE_HW_FWD_ROWS', '512'))
         self.ws_hw = None
+        self.stage_spec = None       # set by TrainStep for one forward pass: see _forward_pair
         self.ws_b = None
         # Note lists (opt-in: cfg['fuse_notes'] / CLV_FUSE_NOTES=1): when the batch was staged from BINARY uint8 frames,
         # the staging launch also writes each frame's list of notes (ops.gather_rows_multi(notes=...)) and the pair
@@ -742,7 +743,20 @@ class VrnnEngine(_EngineBase):
                         P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.gates_dec, self.cs_dec, gate_act=self.gate_act)
         self._output_head(target, nll)
 
-    def _label_forward(self, X, eps_W, w_true, pack=None):
+    def _dense_hw_fwd_now(self):
+        cfg = self.cfg
+        return self.dense_hw_fwd and self.frames_exact_bf16 and \
+            ops.dense_window_fwd_bf16_supported(self.B, cfg['T'] * cfg['D'], cfg['D'], cfg['T'] * cfg['D'], cfg['D'])
+
+    def can_stage_in_label(self):
+        """Can the label forward launch assemble the step's mini-batch itself (ops.label_stage; TrainStep decides per bound
+        batch source)?  The fused pair path with the note-walking label kernel: its workgroup per batch row reads the row's
+        byte frames for its scan anyway."""
+        return self.fuse_pair and self.sparse_inputs and self.cfg['D'] % 2 == 0 and not self.fuse_notes and \
+            not (self.dense_hw_fwd and ops.dense_window_fwd_bf16_supported(self.B, self.cfg['T'] * self.cfg['D'], self.cfg['D'],
+                                                                         self.cfg['T'] * self.cfg['D'], self.cfg['D']))
+
+    def _label_forward(self, X, eps_W, w_true, pack=None, stage=None):
         """Label path (:174-191): hW Dense layer over the flattened window, Wargs head, logistic-normal sample, label
         losses and both per-row LSTM biases (W.K_w + b).  One launch when the window is handled sparsely."""
         cfg, P, B = self.cfg, self.P, self.B
@@ -755,14 +769,14 @@ class VrnnEngine(_EngineBase):
         if self.sparse_inputs and D % 2 == 0:
             nz = getattr(self, '_noise', None)
             parts = None
-            if self.dense_hw_fwd and self.frames_exact_bf16 and ops.dense_window_fwd_bf16_supported(B, T * D, D, T * D, D):
+            if stage is None and self._dense_hw_fwd_now():
                 # byte-valued frames: the product dense on the bf16 matrix cores (split-K partial sums, summed by the label
                 # launch) instead of the note-walking gather
                 if self.ws_hw is None:
                     self.ws_hw = ops.Workspace(self.device)
                 parts = ops.dense_window_fwd_bf16(B, T * D, D, X, T * D, P.p('hW/kernel'), D, self.ws_hw)
             ops.vrnn_label_fwd_x(B, D, Cn, G4, X, T * D, T * D, P.p('hW/kernel'), P.p('hW/bias'), self.hW, *tail,
-                                 noise=nz[0] if nz else None, pack=pack, parts=parts)
+                                 noise=nz[0] if nz else None, pack=pack, parts=parts, stage=stage)
         else:
             ops.gemm(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=self.ws)
             ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, *tail)
@@ -802,6 +816,12 @@ class VrnnEngine(_EngineBase):
         pack_in_label = self.sparse_inputs and D % 2 == 0
         if not pack_in_label:
             ops.lstm_pair_pack(*pack)
+        # TrainStep handed over the mini-batch assembly (stage_spec: ops.label_stage): the label launch goes FIRST and fills X,
+        # the history frames and the labels for everything behind it
+        stage = self.stage_spec if pack_in_label else None
+        self.stage_spec = None
+        if stage is not None:
+            self._label_forward(X, eps_W, w_true, pack=pack, stage=stage)
         notes = None
         if self.fuse_notes and self.notes_valid:      # the projections are gathered inside the pair kernel
             notes = (self.notes_enc, P.p('encoder_h/kernel'), self.notes_dec if off else None,
@@ -816,7 +836,8 @@ class VrnnEngine(_EngineBase):
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel
                 g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off, lda=self.xz_ld, ws=ws)
-        self._label_forward(X, eps_W, w_true, pack=pack if pack_in_label else None)
+        if stage is None:
+            self._label_forward(X, eps_W, w_true, pack=pack if pack_in_label else None)
         nz = getattr(self, '_noise', None)
         ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, self.gates_dec, off > 0, self.wk_dec, self.pair_pack,
                           P.p('Zargs/bias'), eps_Z, self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z,

@@ -492,8 +492,23 @@ def _noise_ref(noise):
     return C.byref(noise) if noise is not None else None
 
 
+def label_stage(cur, hist, idx, row0, cursor, X, Xh, hist_chunk, hist_ld, w_src, w_out):
+    """clv_label_stage for vrnn_label_fwd_x(stage=...): cur / hist = (uint8 store, stride, offset, table or None) of the
+    current / history frames (hist None: no history frames), cursor = (step_dev, step0, period, stride, offset) or None."""
+    g = _lib.LabelStage()
+    g.cur, g.cur_stride, g.cur_offset, g.cur_table = _ptr(cur[0]), int(cur[1]), int(cur[2]), _ptr(cur[3])
+    if hist is not None:
+        g.hist, g.hist_stride, g.hist_offset, g.hist_table = _ptr(hist[0]), int(hist[1]), int(hist[2]), _ptr(hist[3])
+    g.idx, g.row0 = _ptr(idx), int(row0)
+    if cursor is not None:
+        g.cursor = _lib.BatchCursor(_ptr(cursor[0]), int(cursor[1]), int(cursor[2]), int(cursor[3]), int(cursor[4]))
+    g.X, g.Xh, g.hist_chunk, g.hist_ld = _ptr(X), _ptr(Xh), int(hist_chunk), int(hist_ld)
+    g.w_src, g.w_out = _ptr(w_src), _ptr(w_out)
+    return g
+
+
 def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, onehot, prior, Kenc_w, benc, Kdec_w, bdec, wargs,
-                     W, rowloss, rb_enc, rb_dec, noise=None, pack=None, parts=None):
+                     W, rowloss, rb_enc, rb_dec, noise=None, pack=None, parts=None, stage=None):
     """hW = relu(X . Kh + bh) over the nonzero inputs of each row, then vrnn_label_fwd, one workgroup per row.
     noise: a noise_draw(): eps is drawn in the kernel (and written to `eps`) instead of read.
     pack = (L, U_enc, U_dec, Kz, Wz, out): the launch also writes the pair LSTM kernels' weight pack (lstm_pair_pack).
@@ -505,7 +520,11 @@ def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, oneh
     tail = (_ptr(bh), _ptr(hW_out), _ptr(Ka), _ptr(ba), _ptr(eps), _ptr(onehot), float(prior), _ptr(Kenc_w), _ptr(benc),
             _ptr(Kdec_w), _ptr(bdec), _ptr(wargs), _ptr(W), _ptr(rowloss), _ptr(rb_enc), _ptr(rb_dec), _noise_ref(noise),
             C.byref(ps) if ps is not None else None, _stream())
-    if parts is not None:
+    if stage is not None:      # a label_stage(): the launch assembles the mini-batch rows itself (X, history frames, labels)
+        t = tail[:5] + tail[6:]           # (no `onehot`: the labels come from stage.w_src)
+        check(_lib.lib().clv_vrnn_label_fwd_x_staged(B, D, Cn, G4, C.byref(stage), ldx, nx, _ptr(Kh), *t),
+              "clv_vrnn_label_fwd_x_staged")
+    elif parts is not None:
         check(_lib.lib().clv_vrnn_label_fwd_parts(B, D, Cn, G4, _ptr(parts[0]), int(parts[1]), *tail), "clv_vrnn_label_fwd_parts")
     else:
         check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), *tail), "clv_vrnn_label_fwd_x")

@@ -163,9 +163,44 @@ class TrainStep:
         ops.gather_rows_multi(self.eng.B, b['idx'], segs, notes=self._note_outputs(b['cur'], b['hist'], len(segs)),
                               cursor=(self.eng.P.iterations, b['step0'], b['period'], b['stride'], b['offset']))
 
+    def _label_stage(self):
+        """ops.label_stage of the bound batches when the label forward launch can assemble them (VrnnEngine.can_stage_in_label:
+        the mini-batch assembly then is no launch of its own), else None.  Byte frames only, no separate target, no note
+        lists; CLV_STAGE_IN_LABEL=0 keeps the gather launch."""
+        b, eng = self._bound, self.eng
+        if not self.is_vrnn or os.environ.get('CLV_STAGE_IN_LABEL', '1') == '0' or b['target'] is not None:
+            return None
+        if not getattr(eng, 'can_stage_in_label', lambda: False)():
+            return None
+        need_hist = eng.off > 0
+        if need_hist != (b['hist'] is not None):
+            return None
+        D, row = eng.cfg['D'], int(self.X[0].numel())
+
+        def src(x):
+            if isinstance(x, DevWindows):
+                return (x.store, D, x.t0 * D, x.starts)
+            return (x, row, 0, None)
+        cur = src(b['cur'])
+        hist = src(b['hist']) if need_hist else None
+        if any(t is not None and (t[0].dtype != torch.uint8 or not t[0].is_contiguous()) for t in (cur, hist)):
+            return None
+        if b['w'].dtype != torch.float32 or not b['w'].is_contiguous():
+            return None
+        if not eng.frames_exact_bf16:             # byte frames (what _segments() notes for the gather launch)
+            eng.frames_exact_bf16 = True
+            self.recapture()
+        hist_chunk, hist_ld = (D, self.xp_ld) if self.xp_ld else (row, row)
+        return ops.label_stage(cur, hist, b['idx'], 0, (eng.P.iterations, b['step0'], b['period'], b['stride'], b['offset']),
+                               self.X, self.Xp if need_hist else None, hist_chunk, hist_ld, b['w'], self.w_true)
+
     def _main(self):
         if self._bound is not None:
-            self._stage_bound()
+            st = self._label_stage()
+            if st is None:
+                self._stage_bound()
+            elif hasattr(self.eng, 'stage_spec'):
+                self.eng.stage_spec = st
         if self._folded():
             self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y,
                                     noise=self.noise_spec(), bump=True)

@@ -62,6 +62,14 @@ typedef struct clv_noise_draw {
   const int32_t* step_dev;
 } clv_noise_draw;
 
+/* Which mini-batch a staging launch assembles, chosen by a DEVICE step counter (clv_gather_rows_multi_cursor,
+ * clv_vrnn_label_fwd_x_staged): batch j = (*step_dev - step0) mod period, rows idx[j * stride + offset + r]. */
+typedef struct clv_batch_cursor {
+  const int32_t* step_dev;
+  int32_t step0, period;
+  int64_t stride, offset;
+} clv_batch_cursor;
+
 /* ABI version = CLV_ABI_VERSION of the header the library was built from.  It changes whenever an existing entry point
  * changes its argument list or the size / meaning of a buffer (a caller built against an older header would still resolve
  * the symbol): the binding compares it at load time and refuses a mismatch.
@@ -69,7 +77,7 @@ typedef struct clv_noise_draw {
  *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
  *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
  *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair, clv_dense_outer_bf16,
- *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts (additions only) */
+ *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts, clv_vrnn_label_fwd_x_staged (additions only) */
 #define CLV_ABI_VERSION 400
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
@@ -513,6 +521,30 @@ int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float* part, int
                              const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                              float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
                              const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
+/* clv_vrnn_label_fwd_x with the step's MINI-BATCH ASSEMBLY inside (cl_vae/train.py:66-71, the host-side slicing of
+ * Model.fit; what clv_gather_rows_multi_cursor does as a launch of its own): the workgroup of batch row b resolves its source
+ * row sr = idx[base + b] (idx NULL: row0 + base + b; base from the batch cursor), converts the row's byte frames into the float
+ * rows every later launch of the step reads --
+ *   X[b, :nx]                         = cur  + (cur_table  ? cur_table[sr]  : sr) * cur_stride  + cur_offset   (bytes)
+ *   Xh + (b * nx / hist_chunk + p) * hist_ld, hist_chunk floats per frame p
+ *                                     = hist + (hist_table ? hist_table[sr] : sr) * hist_stride + hist_offset  (hist NULL: none)
+ *   w_out[b, :C] = w_src[sr, :C]      (both NULL: none; the label path reads w_src[sr] either way)
+ * -- and scans the bytes itself.  nx, hist_chunk, hist_ld, the strides and offsets are multiples of 4; stores 4-byte, X / Xh
+ * 16-byte aligned.  The assembly then costs no launch (configuration 3: 8.8 us). */
+typedef struct clv_label_stage {
+  const uint8_t* cur; const uint8_t* hist;
+  int64_t cur_stride, cur_offset, hist_stride, hist_offset, row0;
+  const int64_t* cur_table; const int64_t* hist_table; const int64_t* idx;
+  clv_batch_cursor cursor;                 /* step_dev NULL: no cursor */
+  float* X; float* Xh; int32_t hist_chunk; int64_t hist_ld;
+  const float* w_src; float* w_out;
+} clv_label_stage;
+int clv_vrnn_label_fwd_x_staged(int B, int D, int C, int G4, const clv_label_stage* stage, int ldx, int nx, const float* Kh,
+                                const float* bh, float* hW_out, const float* Ka, const float* ba,
+                                float* eps, float prior_logvar,
+                                const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
+                                float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
+                                const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
 int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
                        const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
                        const float* onehot, const float* W, const float* hW, const float* Ka,
@@ -659,11 +691,7 @@ int clv_gather_rows_multi_notes(int64_t rows, const int64_t* idx, int64_t row0, 
  * `iterations` counter (clv_adam_wn_step advances it at the end of a step), so the mini-batch assembly of
  * Model.fit (cl_vae/train.py:66-71: one contiguous slice of the shuffled index per step) becomes a node of the step's
  * hipGraph: a step is ONE graph launch, nothing is staged from the host.  cursor == NULL: clv_gather_rows_multi_notes. */
-typedef struct clv_batch_cursor {
-  const int32_t* step_dev;
-  int32_t step0, period;
-  int64_t stride, offset;
-} clv_batch_cursor;
+/* (clv_batch_cursor is declared near the top of this header, next to clv_noise_draw) */
 int clv_gather_rows_multi_cursor(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                                  const void* const* src, const int32_t* src_u8, float* const* out,
                                  const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,

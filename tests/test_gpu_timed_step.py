@@ -143,3 +143,48 @@ def test_cl_vae_timed_step_tracks_the_oracle(dev, bf16):
         check_params(eng.P.get_weights(), p, steps, rtol=5e-2, atol=5e-4, frac=2e-2, what="cl_vae bf16")
     else:
         check_params(eng.P.get_weights(), p, steps, what="cl_vae fp32")
+
+
+@pytest.mark.parametrize("source", ["rows", "windows"])
+def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, monkeypatch, source):
+    """TrainStep.bind_batches: the label forward launch assembles the mini-batch itself (clv_vrnn_label_fwd_x_staged) where it
+    can -- byte frames, the fused pair path.  Against the same steps with the gather launch (CLV_STAGE_IN_LABEL=0): the staged
+    X / history frames / labels, every loss and every parameter after three replayed steps, bit for bit.  `rows`: whole
+    rows in two byte tensors (bench.py); `windows`: overlapping windows of one frame store through a start table
+    (Model.fit: utils.pianoroll.Windows), shuffled by a row list."""
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep, DevWindows
+    B, Tn, L, Cn, nb = 16, 12, 2, 10, 3
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(31)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=6).items()}
+    n = nb * B
+    keys = ft(np.eye(Cn)[rng.integers(0, Cn, n)], dev)
+    if source == "rows":
+        win = (rng.random((n, Tn + 1, 88)) < 0.05)
+        cur, hist, idx = u8(win[:, 1:].reshape(n, -1), dev), u8(win[:, :-1].reshape(n, -1), dev), None
+    else:
+        store = u8(rng.random((n + Tn + 40, 88)) < 0.05, dev)
+        starts = torch.as_tensor(rng.permutation(n + 30)[:n].astype(np.int64), device=dev)
+        cur, hist = DevWindows(store, starts, 1), DevWindows(store, starts, 0)
+        idx = torch.as_tensor(rng.permutation(n).astype(np.int64), device=dev)
+    runs = {}
+    for staged in ("1", "0"):
+        monkeypatch.setenv("CLV_STAGE_IN_LABEL", staged)
+        eng = VrnnEngine(cfg, B, dev)
+        eng.P.set_weights(p)
+        ts = TrainStep(eng, seed=77)
+        ts.bind_batches(cur, hist, keys, idx=idx, period=nb, stride=B)
+        assert (ts._label_stage() is not None) == (staged == "1")
+        out = []
+        for it in range(3):
+            ts.step()
+            torch.cuda.synchronize()
+            out.append((dict(eng.losses()), ts.X.clone(), ts.Xp.clone(), ts.w_true.clone()))
+        runs[staged] = (out, eng.P.get_weights())
+    for a, b in zip(runs["1"][0], runs["0"][0]):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y)
+    for k, v in runs["1"][1].items():
+        assert np.array_equal(v, runs["0"][1][k]), k
