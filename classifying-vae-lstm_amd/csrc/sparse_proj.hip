@@ -341,7 +341,11 @@ static int sparse_proj_launch(int R, int N, int ldo, int nset, const clv::Sparse
   SparseProjArgs a;
   memset(&a, 0, sizeof(a));
   a.R = R; a.N = N; a.ldo = ldo;
-  a.wgs = R < 256 * SP_NW ? (R + SP_NW - 1) / SP_NW : 256;     // one persistent workgroup per CU and projection
+  // one persistent workgroup per CU IN ALL: 256 / nset per projection.  (Round 4: with 256 per projection every CU staged its
+  // 124 KB of kernel twice, once per projection, for 8 frames per wave each: 26.2 us at configuration 3 against 23.6; 192: 29.7,
+  // 64: 36.3)
+  const int cap = 256 / (nset > 0 ? nset : 1);
+  a.wgs = R < cap * SP_NW ? (R + SP_NW - 1) / SP_NW : cap;
   for (int i = 0; i < nset; ++i) a.set[i] = sets[i];
   ProfScope p("sparse_proj", s);
   hipLaunchKernelGGL(sparse_proj_kernel, dim3(nset * a.wgs), dim3(SP_NT), clv_sparse_proj_lds_bytes(nxmax, N), s, a);
