@@ -405,7 +405,11 @@ __global__ void adam_bump_kernel(int32_t* iterations) { *iterations += 1; }
 // 16.2 + 5.8 (too few CUs stream), 64-row blocks of 256 threads: 17.2 + 11.3.
 // The classic chain needs five launches (stats, columns, update, columns, rescale).
 // ---------------------------------------------------------------------------
-constexpr int FAST_ROWS = 64;       // rows per workgroup: 176 workgroups for hW/kernel, i.e. 176 partial rows for the second launch
+#ifndef CLV_FAST_ROWS
+#define CLV_FAST_ROWS 64
+#endif
+constexpr int FAST_ROWS = CLV_FAST_ROWS;       // rows per workgroup: 176 workgroups for hW/kernel, i.e. 176 partial rows for the second launch
+                                               // (round 4, -DCLV_FAST_ROWS: 48 rows = 235 workgroups 15.5 + 6.8 us, 32 = 352: 15.4 + 8.9, against 12.6 + 6.0)
 constexpr int FAST_NT = 1024;       // 64 column-pair lanes x 16 row lanes
 struct AdamFast {
   int64_t offset, col_offset;
