@@ -186,6 +186,8 @@ SIGNATURES = {
                                 _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vae_fused_step_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i,
                                    _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_vae_fused_step_staged": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i,
+                                       _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _p, _p]),

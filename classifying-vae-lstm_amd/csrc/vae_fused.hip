@@ -83,6 +83,18 @@ struct VaeArgs {
   float* slab; long slab_stride;                           // [n_wg][slab_stride] partial gradients
   float* logits; float* w_out; float* wargs_out; float* zargs_out;   // [B,D] [B,C] [B,2(C-1)] [B,2L] (for predict/tests)
   float* rownll; float* rowkl; float* rowloss;             // [B] [B] [B,3]
+  // stage.on: the kernel assembles its own mini-batch rows (clv_label_stage: byte frames of the data set chosen by the device
+  // step counter / row list / window table) instead of reading x / xp / onehot; x_out / xp_out / w_out (may be null) receive
+  // the rows as the gather launch would have left them
+  struct Stage {
+    int on;
+    const unsigned char* cur; const unsigned char* hist;
+    long long cur_stride, cur_offset, hist_stride, hist_offset, row0;
+    const long long* cur_table; const long long* hist_table; const long long* idx;
+    const int* step_dev; int step0, period; long long cur_s, cur_o;
+    const float* w_src;
+    float* x_out; float* xp_out; float* w_out;
+  } stage;
   VStage st[VNSTAGE];
 };
 
@@ -300,13 +312,46 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
   // requested first so that the zero fill runs under their latency -------------------------------------------------
   constexpr int FPT = (VRB * 96 + VNT - 1) / VNT;          // frame elements per thread
   float fx[FPT], fp[FPT], fy[FPT];
+  __shared__ long long s_cur[VRB], s_hist[VRB], s_sr[VRB];
+  if (a.stage.on) {
+    // the workgroup's rows of the mini-batch: source row (step counter -> row list), byte offsets of its frames
+    if (tid < VRB) {
+      const VaeArgs::Stage& g = a.stage;
+      long long base = 0;
+      if (g.step_dev) {
+        int j = (*g.step_dev - g.step0) % g.period;
+        j = j < 0 ? j + g.period : j;
+        base = (long long)j * g.cur_s + g.cur_o;
+      }
+      const int b = row0 + min(tid, nvalid - 1);
+      const long long sr = g.idx ? g.idx[base + b] : g.row0 + base + b;
+      s_sr[tid] = sr;
+      s_cur[tid] = (g.cur_table ? g.cur_table[sr] : sr) * g.cur_stride + g.cur_offset;
+      s_hist[tid] = g.hist ? (g.hist_table ? g.hist_table[sr] : sr) * g.hist_stride + g.hist_offset : 0;
+    }
+    __syncthreads();
 #pragma unroll
-  for (int u = 0; u < FPT; ++u) {
-    const int i = min(tid + u * VNT, nvalid * D - 1);
-    const size_t g = (size_t)row0 * D + i;
-    fx[u] = a.x[g];
-    fp[u] = a.use_xp ? a.xp[g] : 0.f;
-    fy[u] = a.y ? a.y[g] : 0.f;
+    for (int u = 0; u < FPT; ++u) {
+      const int i = min(tid + u * VNT, nvalid * D - 1);
+      const int r = i / D, c = i - r * D;
+      fx[u] = (float)a.stage.cur[s_cur[r] + c];
+      fp[u] = (a.use_xp && a.stage.hist) ? (float)a.stage.hist[s_hist[r] + c] : 0.f;
+      fy[u] = 0.f;
+      if (tid + u * VNT < nvalid * D) {
+        const size_t g = (size_t)row0 * D + i;
+        if (a.stage.x_out) a.stage.x_out[g] = fx[u];
+        if (a.stage.xp_out && a.use_xp) a.stage.xp_out[g] = fp[u];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < FPT; ++u) {
+      const int i = min(tid + u * VNT, nvalid * D - 1);
+      const size_t g = (size_t)row0 * D + i;
+      fx[u] = a.x[g];
+      fp[u] = a.use_xp ? a.xp[g] : 0.f;
+      fy[u] = a.y ? a.y[g] : 0.f;
+    }
   }
   for (int i = tid; i < M.total / 4; i += VNT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   lds_barrier();
@@ -320,7 +365,14 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
       if (a.y) lds[M.G2 + r * VL + c] = fy[u];            // the target waits in G2 (free until the backward pass)
     }
   }
-  if (a.onehot)
+  if (a.stage.on) {
+    for (int i = tid; i < nvalid * C; i += VNT) {
+      const int r = i / C, c = i - r * C;
+      const float v = a.stage.w_src[(size_t)s_sr[r] * C + c];
+      lds[M.OH + r * VL + c] = v;
+      if (a.stage.w_out) a.stage.w_out[(size_t)(row0 + r) * C + c] = v;
+    }
+  } else if (a.onehot)
     for (int i = tid; i < nvalid * C; i += VNT) {
       const int r = i / C, c = i - r * C;
       lds[M.OH + r * VL + c] = a.onehot[(size_t)(row0 + r) * C + c];
@@ -407,12 +459,12 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
         }
         if (r < nvalid) {
           float wrec = 0.f;
-          if (a.onehot)
+          if (a.onehot || a.stage.on)
             for (int j = 0; j < C; ++j)
               wrec -= oh[j] * logf(fminf(fmaxf((wv[j] + VW2) / qs, VEPS_K), 1.f - VEPS_K));
           a.rowloss[(size_t)(row0 + r) * 3 + 0] = -0.5f * klw;
           a.rowloss[(size_t)(row0 + r) * 3 + 1] = (float)C1 * wrec;
-          a.rowloss[(size_t)(row0 + r) * 3 + 2] = (a.onehot && amax == tmax) ? 1.f : 0.f;
+          a.rowloss[(size_t)(row0 + r) * 3 + 2] = ((a.onehot || a.stage.on) && amax == tmax) ? 1.f : 0.f;
           for (int j = 0; j < C; ++j) a.w_out[(size_t)(row0 + r) * C + j] = wv[j];
           for (int j = 0; j < NA; ++j) a.wargs_out[(size_t)(row0 + r) * NA + j] = wargs[j];
         }
@@ -652,9 +704,9 @@ static void vae_build_stages(VStage* st, int D, int H, int Hc, int C, int L, int
   st[11] = bwd(M.G1, Hc, M.XC, D, sm.slab_off[0], sm.slab_off[1]);                           // h_w backward (no product)
 }
 
-extern "C" int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
+static int vae_step_impl(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
                                      const float* x, const float* xp, const float* target, const float* onehot,
-                                     float* eps_w, float* eps_z,
+                                     const clv_label_stage* stage, float* eps_w, float* eps_z,
                                      const float* params, const int64_t* host_offsets12, long n_params,
                                      float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
                                      int need_grads, float* grads, void* ws, size_t ws_bytes,
@@ -662,16 +714,29 @@ extern "C" int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, 
                                      float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts,
                                      void* stream) {
   if (!clv_vae_fused_supported(D, H, Hc, C, L) || B <= 0 || n_params <= 0 || n_params > 0x7fffffffL) return CLV_EINVAL;
-  if (!x || !eps_w || !eps_z || !params || !host_offsets12 || !w_out || !wargs_out || !zargs_out || !rownll || !rowkl || !rowloss)
+  if (!eps_w || !eps_z || !params || !host_offsets12 || !w_out || !wargs_out || !zargs_out || !rownll || !rowkl || !rowloss)
     return CLV_EINVAL;
-  if (use_x_prev && !xp) return CLV_EINVAL;
-  if (need_grads && (!grads || !onehot)) return CLV_EINVAL;
+  if (stage) {
+    if (!stage->cur || !stage->w_src || (use_x_prev && !stage->hist) || (stage->cursor.step_dev && stage->cursor.period < 1))
+      return CLV_EINVAL;
+  } else {
+    if (!x || (use_x_prev && !xp) || (need_grads && !onehot)) return CLV_EINVAL;
+  }
+  if (need_grads && !grads) return CLV_EINVAL;
   const int nwg = (B + VRB - 1) / VRB;
   const VSlabMap sm = vae_slab_map(D, H, Hc, C, L, use_x_prev, host_offsets12);
   if (need_grads && (!ws || ws_bytes < (size_t)nwg * sm.stride * sizeof(float))) return CLV_EWORKSPACE;
   VaeArgs a{};
   a.B = B; a.D = D; a.H = H; a.Hc = Hc; a.C = C; a.L = L; a.use_xp = use_x_prev;
   a.x = x; a.xp = xp; a.onehot = onehot; a.y = target == x ? nullptr : target;
+  if (stage) {
+    const clv_label_stage& g = *stage;
+    a.y = nullptr;
+    a.stage = VaeArgs::Stage{1, g.cur, g.hist, (long long)g.cur_stride, (long long)g.cur_offset, (long long)g.hist_stride,
+                             (long long)g.hist_offset, (long long)g.row0, (const long long*)g.cur_table, (const long long*)g.hist_table,
+                             (const long long*)g.idx, g.cursor.step_dev, g.cursor.step0, g.cursor.period, (long long)g.cursor.stride,
+                             (long long)g.cursor.offset, g.w_src, g.X, g.Xh, g.w_out};
+  }
   a.eps_w = eps_w; a.eps_z = eps_z; a.P = params;
   a.prior = prior_logvar; a.class_weight = class_weight; a.kl_weight = kl_weight; a.w_kl_weight = w_kl_weight;
   a.need_grads = need_grads;
@@ -706,6 +771,34 @@ extern "C" int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, 
     hipLaunchKernelGGL(slab_sum_kernel, dim3(t.nblk_grads + (means ? 5u : 0u)), dim3(256), 0, s, t);
   }
   return launch_status();
+}
+
+extern "C" int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
+                                     const float* x, const float* xp, const float* target, const float* onehot,
+                                     float* eps_w, float* eps_z,
+                                     const float* params, const int64_t* host_offsets12, long n_params,
+                                     float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
+                                     int need_grads, float* grads, void* ws, size_t ws_bytes,
+                                     float* logits, float* w_out, float* wargs_out, float* zargs_out,
+                                     float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts,
+                                     void* stream) {
+  return vae_step_impl(B, D, H, Hc, C, L, use_x_prev, x, xp, target, onehot, nullptr, eps_w, eps_z, params, host_offsets12, n_params,
+                       prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out, wargs_out,
+                       zargs_out, rownll, rowkl, rowloss, opts, stream);
+}
+
+extern "C" int clv_vae_fused_step_staged(int B, int D, int H, int Hc, int C, int L, int use_x_prev, const clv_label_stage* stage,
+                                         float* eps_w, float* eps_z,
+                                         const float* params, const int64_t* host_offsets12, long n_params,
+                                         float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
+                                         int need_grads, float* grads, void* ws, size_t ws_bytes,
+                                         float* logits, float* w_out, float* wargs_out, float* zargs_out,
+                                         float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts,
+                                         void* stream) {
+  if (!stage) return CLV_EINVAL;
+  return vae_step_impl(B, D, H, Hc, C, L, use_x_prev, nullptr, nullptr, nullptr, nullptr, stage, eps_w, eps_z, params, host_offsets12,
+                       n_params, prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out,
+                       wargs_out, zargs_out, rownll, rowkl, rowloss, opts, stream);
 }
 
 extern "C" int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,

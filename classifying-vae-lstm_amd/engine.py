@@ -286,6 +286,7 @@ class VaeEngine(_EngineBase):
         self.xoff = D if cfg['use_x_prev'] else 0      # decoder_h kernel rows: [w | xp | z]
         L_ = _lib.lib()
         self.fused = H > 0 and bool(cfg.get('fused_step', True)) and bool(L_.clv_vae_fused_supported(D, H, Hc, Cn, L))
+        self.stage_spec = None       # set by TrainStep for one fused step: see _fused_step
         names = ['h_w', 'wargs', 'h', 'zargs', 'decoder_h', 'x_decoded_mean']
         self._offs = (C.c_int64 * 12)(*[self.P.offsets.get('%s/%s' % (n, w), 0) for n in names for w in ('kernel', 'bias')])
         ws_bytes = L_.clv_vae_fused_workspace_bytes(B, D, H, Hc, Cn, L, int(cfg['use_x_prev'])) if self.fused else 0
@@ -444,13 +445,24 @@ class VaeEngine(_EngineBase):
             opts.draw, opts.step_dev = 1, p_(step_dev)
         if bump and need_grads:
             opts.bump_iterations = p_(P.iterations)
+        tail = (p_(eps_w), p_(eps_z), p_(P.params), self._offs, P.n, float(cfg['w_log_var_prior']), self.class_weight,
+                self.kl_weight, self.w_kl_weight, int(need_grads), p_(P.grads), p_(self._fused_ws), self._fused_ws.numel(),
+                p_(self.logits), p_(self.w), p_(self.wargs), p_(self.zargs), p_(self.rownll), p_(self.rowkl),
+                p_(self.rowloss), C.byref(opts), ops._stream())
+        stage, self.stage_spec = self.stage_spec, None
+        if stage is not None and target is None:
+            # TrainStep handed over the mini-batch assembly (ops.label_stage): the kernel reads its rows' byte frames itself
+            _lib.check(_lib.lib().clv_vae_fused_step_staged(
+                B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), C.byref(stage), *tail),
+                "clv_vae_fused_step_staged")
+            return
         _lib.check(_lib.lib().clv_vae_fused_step_ex(
             B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), p_(x), p_(xp), p_(target),
-            p_(w_true),
-            p_(eps_w), p_(eps_z), p_(P.params), self._offs, P.n, float(cfg['w_log_var_prior']), self.class_weight,
-            self.kl_weight, self.w_kl_weight, int(need_grads), p_(P.grads), p_(self._fused_ws), self._fused_ws.numel(),
-            p_(self.logits), p_(self.w), p_(self.wargs), p_(self.zargs), p_(self.rownll), p_(self.rowkl),
-            p_(self.rowloss), C.byref(opts), ops._stream()), "clv_vae_fused_step_ex")
+            p_(w_true), *tail), "clv_vae_fused_step_ex")
+
+    def can_stage_in_label(self):
+        """Can the step's own launch assemble its mini-batch (ops.label_stage)?  The fused kernel reads its rows itself."""
+        return bool(self.fused)
 
     def folds_step(self, w_true):
         """True when loss_and_grads(noise=..., bump=True) draws the noise and advances `iterations` inside the step's

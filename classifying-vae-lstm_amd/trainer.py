@@ -164,15 +164,18 @@ class TrainStep:
                               cursor=(self.eng.P.iterations, b['step0'], b['period'], b['stride'], b['offset']))
 
     def _label_stage(self):
-        """ops.label_stage of the bound batches when the label forward launch can assemble them (VrnnEngine.can_stage_in_label:
-        the mini-batch assembly then is no launch of its own), else None.  Byte frames only, no separate target, no note
-        lists; CLV_STAGE_IN_LABEL=0 keeps the gather launch."""
+        """ops.label_stage of the bound batches when the step's first launch can assemble them itself -- cl_vrnn: the label
+        forward launch (VrnnEngine.can_stage_in_label), cl_vae: the fused step kernel -- so that the mini-batch assembly is no
+        launch of its own; else None.  Byte frames only, no separate target, no note lists; CLV_STAGE_IN_LABEL=0 keeps the
+        gather launch."""
         b, eng = self._bound, self.eng
-        if not self.is_vrnn or os.environ.get('CLV_STAGE_IN_LABEL', '1') == '0' or b['target'] is not None:
+        if os.environ.get('CLV_STAGE_IN_LABEL', '1') == '0' or b['target'] is not None:
             return None
         if not getattr(eng, 'can_stage_in_label', lambda: False)():
             return None
-        need_hist = eng.off > 0
+        if not self.is_vrnn and not (self._folded() and b['w'] is not None):
+            return None
+        need_hist = (eng.off > 0) if self.is_vrnn else bool(eng.cfg['use_x_prev'])
         if need_hist != (b['hist'] is not None):
             return None
         D, row = eng.cfg['D'], int(self.X[0].numel())
@@ -187,7 +190,7 @@ class TrainStep:
             return None
         if b['w'].dtype != torch.float32 or not b['w'].is_contiguous():
             return None
-        if not eng.frames_exact_bf16:             # byte frames (what _segments() notes for the gather launch)
+        if hasattr(eng, 'frames_exact_bf16') and not eng.frames_exact_bf16:      # byte frames (what _segments() notes for the gather)
             eng.frames_exact_bf16 = True
             self.recapture()
         hist_chunk, hist_ld = (D, self.xp_ld) if self.xp_ld else (row, row)

@@ -77,7 +77,7 @@ typedef struct clv_batch_cursor {
  *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
  *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
  *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair, clv_dense_outer_bf16,
- *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts, clv_vrnn_label_fwd_x_staged (additions only) */
+ *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts, clv_vrnn_label_fwd_x_staged, clv_vae_fused_step_staged (additions only) */
 #define CLV_ABI_VERSION 400
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
@@ -539,6 +539,17 @@ typedef struct clv_label_stage {
   float* X; float* Xh; int32_t hist_chunk; int64_t hist_ld;
   const float* w_src; float* w_out;
 } clv_label_stage;
+/* clv_vae_fused_step_ex with the mini-batch assembly inside (cl_vae/train.py:66-71): every workgroup resolves its 16 batch rows
+ * (clv_label_stage with rows of D bytes: cur = the frames x, hist = the previous frames x_prev, w_src = the labels) and reads
+ * their bytes itself; stage->X / Xh / w_out (each may be NULL) receive the rows as a gather launch would have left them.  No
+ * separate target (the auto-encoder).  The cl_vae training step is then three launches: this one, the slab sum, Adam. */
+int clv_vae_fused_step_staged(int B, int D, int H, int Hc, int C, int L, int use_x_prev, const clv_label_stage* stage,
+                              float* eps_w, float* eps_z,
+                              const float* params, const int64_t* host_offsets12, long n_params,
+                              float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
+                              int need_grads, float* grads, void* ws, size_t ws_bytes,
+                              float* logits, float* w_out, float* wargs_out, float* zargs_out,
+                              float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts, void* stream);
 int clv_vrnn_label_fwd_x_staged(int B, int D, int C, int G4, const clv_label_stage* stage, int ldx, int nx, const float* Kh,
                                 const float* bh, float* hW_out, const float* Ka, const float* ba,
                                 float* eps, float prior_logvar,

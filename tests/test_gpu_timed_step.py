@@ -188,3 +188,47 @@ def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, mo
             assert torch.equal(x, y)
     for k, v in runs["1"][1].items():
         assert np.array_equal(v, runs["0"][1][k]), k
+
+
+@pytest.mark.parametrize("source", ["rows", "windows"])
+def test_cl_vae_batch_assembly_inside_the_fused_step_equals_the_gather_launch(dev, monkeypatch, source):
+    """cl_vae: the fused step kernel assembles its own mini-batch rows (clv_vae_fused_step_staged) -- three launches per
+    step.  Against the same steps with the gather launch (CLV_STAGE_IN_LABEL=0): the staged frames and labels, every loss and
+    every parameter after three replayed steps, bit for bit; a batch that does not fill its last workgroup's 16 rows."""
+    from clvae_amd.engine import VaeEngine
+    from clvae_amd.trainer import TrainStep, DevWindows
+    B, L, Cn, nb = 40, 4, 2, 3
+    cfg = O.vae_config(latent_dim=L, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(32)
+    p = {k: f32(v) for k, v in O.vae_init_params(cfg, seed=3).items()}
+    n = nb * B
+    keys = ft(np.eye(Cn)[rng.integers(0, Cn, n)], dev)
+    if source == "rows":
+        fr = (rng.random((n, 2, 88)) < 0.05)
+        cur, hist, idx = u8(fr[:, 1], dev), u8(fr[:, 0], dev), None
+    else:
+        store = u8(rng.random((n + 50, 88)) < 0.05, dev)
+        starts = torch.as_tensor(rng.permutation(n + 40)[:n].astype(np.int64), device=dev)
+        cur, hist = DevWindows(store, starts, 1), DevWindows(store, starts, 0)
+        idx = torch.as_tensor(rng.permutation(n).astype(np.int64), device=dev)
+    runs = {}
+    for staged in ("1", "0"):
+        monkeypatch.setenv("CLV_STAGE_IN_LABEL", staged)
+        eng = VaeEngine(cfg, B, dev)
+        assert eng.fused
+        eng.P.set_weights(p)
+        ts = TrainStep(eng, seed=78)
+        ts.bind_batches(cur, hist, keys, idx=idx, period=nb, stride=B)
+        assert (ts._label_stage() is not None) == (staged == "1")
+        out = []
+        for it in range(3):
+            ts.step()
+            torch.cuda.synchronize()
+            out.append((dict(eng.losses()), ts.X.clone(), ts.Xp.clone(), ts.w_true.clone()))
+        runs[staged] = (out, eng.P.get_weights())
+    for a, b in zip(runs["1"][0], runs["0"][0]):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y)
+    for k, v in runs["1"][1].items():
+        assert np.array_equal(v, runs["0"][1][k]), k
