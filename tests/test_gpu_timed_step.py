@@ -145,7 +145,7 @@ def test_cl_vae_timed_step_tracks_the_oracle(dev, bf16):
         check_params(eng.P.get_weights(), p, steps, what="cl_vae fp32")
 
 
-@pytest.mark.parametrize("source", ["rows", "windows"])
+@pytest.mark.parametrize("source", ["rows", "windows", "windows-no-history"])
 def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, monkeypatch, source):
     """TrainStep.bind_batches: the label forward launch assembles the mini-batch itself (clv_vrnn_label_fwd_x_staged) where it
     can -- byte frames, the fused pair path.  Against the same steps with the gather launch (CLV_STAGE_IN_LABEL=0): the staged
@@ -155,7 +155,8 @@ def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, mo
     from clvae_amd.engine import VrnnEngine
     from clvae_amd.trainer import TrainStep, DevWindows
     B, Tn, L, Cn, nb = 16, 12, 2, 10, 3
-    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    hist_on = source != "windows-no-history"         # a decoder without history frames (--no use_x_prev)
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=hist_on)
     rng = np.random.default_rng(31)
     p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=6).items()}
     n = nb * B
@@ -166,7 +167,7 @@ def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, mo
     else:
         store = u8(rng.random((n + Tn + 40, 88)) < 0.05, dev)
         starts = torch.as_tensor(rng.permutation(n + 30)[:n].astype(np.int64), device=dev)
-        cur, hist = DevWindows(store, starts, 1), DevWindows(store, starts, 0)
+        cur, hist = DevWindows(store, starts, 1), (DevWindows(store, starts, 0) if hist_on else None)
         idx = torch.as_tensor(rng.permutation(n).astype(np.int64), device=dev)
     runs = {}
     for staged in ("1", "0"):
