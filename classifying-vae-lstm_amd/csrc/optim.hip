@@ -486,6 +486,87 @@ __device__ __forceinline__ void wn_fast_update_body(const AdamFast& f, int unit,
   }
 }
 
+#ifndef CLV_ADAM_FLAT
+#define CLV_ADAM_FLAT 1      // 0: the float2 / row-lane form (round 3) for A/B runs
+#endif
+// The same pass with the tile taken as what it is in memory -- 64 rows x cols floats, CONTIGUOUS in each of the four arrays --
+// and walked 16 bytes per lane (round 4: 12.6 -> 11.0 us at configuration 3; 3 / 4 float4 per thread on fewer threads: 11.8 / 12.6): thread t owns the float4s t and t + 1024 of the tile (cols % 4 == 0: a float4 never crosses a
+// row, its columns are (4 t) % cols ..+3).  The per-column sums of V'^2 go through an LDS copy of the tile's squares.
+__device__ __forceinline__ void wn_fast_update_body_flat(const AdamFast& f, int unit, float* params, const float* grads, float* m,
+                                                         float* v, float* mg, float* vg, const float* s, const AdamHyper& h) {
+  __shared__ float cs[3][128];
+  __shared__ float sq[FAST_ROWS * 128];          // V'^2 of the tile, [row][col]; then [8][cols] partial column sums at its front
+  const int tid = threadIdx.x;
+  const float lr_t = adam_lr_t(h);
+  for (int c = tid; c < f.cols; c += FAST_NT) {
+    const size_t cg = f.col_offset + c;
+    const float sc = s[cg], a = f.vn2[cg];
+    const float Vn = sqrtf(a), inv_s = 1.f / sc;
+    const float grad_g = f.gdot[c] * inv_s / Vn;
+    cs[0][c] = inv_s; cs[1][c] = grad_g / Vn; cs[2][c] = sc;
+    if (unit == 0) {
+      const float mgn = h.b1 * mg[cg] + (1.f - h.b1) * grad_g;
+      const float vgn = h.b2 * vg[cg] + (1.f - h.b2) * grad_g * grad_g;
+      mg[cg] = mgn; vg[cg] = vgn;
+      f.gnew[c] = sc * Vn - lr_t * mgn / (sqrtf(vgn) + h.eps);
+    }
+  }
+  const int row0 = unit * FAST_ROWS, nrows = min(FAST_ROWS, f.rows - row0);
+  const int n4 = nrows * f.cols / 4;
+  const size_t o0 = f.offset + (size_t)row0 * f.cols;
+#ifndef CLV_ADAM_FLAT_PT
+#define CLV_ADAM_FLAT_PT 2
+#endif
+  constexpr int PT = CLV_ADAM_FLAT_PT;                    // float4s per thread
+  constexpr int NTA = (FAST_ROWS * 128 / 4 + PT - 1) / PT < FAST_NT ? (FAST_ROWS * 128 / 4 + PT - 1) / PT : FAST_NT;      // threads that move data
+  float4 pv[PT], gv[PT], mv[PT], vv[PT];
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {                 // all loads of the thread in flight (clamped; masked below)
+    const size_t o = o0 + 4 * (size_t)min(tid + NTA * k, n4 - 1);
+    pv[k] = *reinterpret_cast<const float4*>(params + o); gv[k] = *reinterpret_cast<const float4*>(grads + o);
+    mv[k] = *reinterpret_cast<const float4*>(m + o); vv[k] = *reinterpret_cast<const float4*>(v + o);
+  }
+  __syncthreads();                               // the column scalars are in LDS
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {
+    const int i = tid + NTA * k;
+    if (tid < NTA && i < n4) {
+      const int c0 = (4 * i) % f.cols;
+      const float pin[4] = {pv[k].x, pv[k].y, pv[k].z, pv[k].w}, gin[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+      const float min_[4] = {mv[k].x, mv[k].y, mv[k].z, mv[k].w}, vin[4] = {vv[k].x, vv[k].y, vv[k].z, vv[k].w};
+      float po[4], mo[4], vo[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float V = pin[c] * cs[0][c0 + c];
+        const float gV = cs[2][c0 + c] * (gin[c] - cs[1][c0 + c] * V);
+        mo[c] = h.b1 * min_[c] + (1.f - h.b1) * gV;
+        vo[c] = h.b2 * vin[c] + (1.f - h.b2) * gV * gV;
+        po[c] = V - lr_t * mo[c] / (sqrtf(vo[c]) + h.eps);
+      }
+      const size_t o = o0 + 4 * (size_t)i;
+      *reinterpret_cast<float4*>(m + o) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+      *reinterpret_cast<float4*>(v + o) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+      *reinterpret_cast<float4*>(params + o) = make_float4(po[0], po[1], po[2], po[3]);
+      *reinterpret_cast<float4*>(sq + 4 * i) = make_float4(po[0] * po[0], po[1] * po[1], po[2] * po[2], po[3] * po[3]);
+    }
+  }
+  __syncthreads();
+  // column sums of the squares: 8 row lanes x cols column lanes, then the 8 partials
+  const int cx = tid % f.cols, rl = tid / f.cols;
+  float part = 0.f;
+  if (rl < 8)
+    for (int r = rl; r < nrows; r += 8) part += sq[r * f.cols + cx];
+  __syncthreads();
+  if (rl < 8) sq[rl * f.cols + cx] = part;
+  __syncthreads();
+  if (tid < f.cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += sq[w * f.cols + tid];
+    f.partC[(size_t)unit * f.cols + tid] = t;
+  }
+}
+
 __global__ __launch_bounds__(FAST_NT) void wn_fast_update_kernel(AdamFast f, const SmallItem* items, float* params,
                                                                  const float* grads, float* m, float* v, float* mg, float* vg,
                                                                  float* s, AdamHyper h) {
@@ -494,6 +575,12 @@ __global__ __launch_bounds__(FAST_NT) void wn_fast_update_kernel(AdamFast f, con
     wn_small_body(items[blockIdx.x - f.nunits], params, grads, m, v, mg, vg, s, h);
     return;
   }
+#if CLV_ADAM_FLAT
+  if (f.cols % 4 == 0 && f.offset % 4 == 0 && 8 * f.cols <= FAST_NT) {
+    wn_fast_update_body_flat(f, (int)blockIdx.x, params, grads, m, v, mg, vg, s, h);
+    return;
+  }
+#endif
   wn_fast_update_body(f, (int)blockIdx.x, params, grads, m, v, mg, vg, s, h);
 }
 
@@ -501,6 +588,17 @@ __global__ __launch_bounds__(FAST_NT) void wn_fast_rescale_kernel(AdamFast f, fl
   __shared__ float2 red[16][64], snew[64];
   const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6, unit = blockIdx.x, n2 = f.cols / 2;
   if (unit == 0 && tid == 0 && iterations) *iterations += 1;
+#if CLV_ADAM_FLAT
+  // the tile's rows (contiguous: see wn_fast_update_body_flat) are requested first: they do not depend on the column sums
+  const bool flat = f.cols % 4 == 0 && f.offset % 4 == 0;
+  const int frow0 = unit * FAST_ROWS, fn4 = min(FAST_ROWS, f.rows - frow0) * f.cols / 4;
+  float* ftile = params + f.offset + (size_t)frow0 * f.cols;
+  float4 fpv[2];
+  if (flat) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) fpv[k] = *reinterpret_cast<const float4*>(ftile + 4 * (size_t)min(tid + FAST_NT * k, fn4 - 1));
+  }
+#endif
   float2 a = make_float2(0.f, 0.f);
   if (cx < n2)
     for (int k = ry; k < f.nunits; k += 16) {
@@ -521,6 +619,21 @@ __global__ __launch_bounds__(FAST_NT) void wn_fast_rescale_kernel(AdamFast f, fl
     }
   }
   __syncthreads();
+#if CLV_ADAM_FLAT
+  if (flat) {
+    const float* sf = reinterpret_cast<const float*>(snew);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + FAST_NT * k;
+      if (i < fn4) {
+        const int c0 = (4 * i) % f.cols;
+        *reinterpret_cast<float4*>(ftile + 4 * (size_t)i) =
+            make_float4(fpv[k].x * sf[c0], fpv[k].y * sf[c0 + 1], fpv[k].z * sf[c0 + 2], fpv[k].w * sf[c0 + 3]);
+      }
+    }
+    return;
+  }
+#endif
   const int row0 = unit * FAST_ROWS, nrows = min(FAST_ROWS, f.rows - row0);
   if (cx < n2) {
     const float2 sn = snew[cx];
