@@ -46,7 +46,7 @@ WORKLOADS = {
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (never the 2:1-sparsity figure)
-PROFILE_TAGS = ('r04_e', 'r04_d', 'r04_c', 'r04_b', 'r04_a', 'r03_f')      # committed profile sets (profiles/<tag>_*), newest first
+PROFILE_TAGS = ('r04_f', 'r04_e', 'r04_d', 'r04_c', 'r04_b', 'r04_a', 'r03_f')      # committed profile sets (profiles/<tag>_*), newest first
 NOTE_DENSITY = 0.0443        # measured JSB note density
 
 
