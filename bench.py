@@ -15,8 +15,11 @@ The timed region is exactly K steps between a barrier + torch.cuda.synchronize()
 than 50 ms (the driver's K = 20 at 0.4 ms is 8 ms: one clock-state hiccup of the device moves it by 5-10 %), the region is
 repeated as 5..9 such blocks and the line carries the MEDIAN block (`timed_blocks`: every block, its min and max).
 A default single-GPU run (`python bench.py`, workload cfg3) appends `also`: the other BASELINE workloads -- cfg5, cfg2
-fp32 / bf16, generation of 1 and 1024 sequences -- measured in the same process right after the headline (a few seconds
-each: value, ms per step, dominant-kernel fraction), so that those numbers are witnessed by whoever runs the line.
+fp32 / bf16, generation of 1 and 1024 sequences -- measured right after the headline by a child process (`bench.py
+--also-only`; a few seconds each: value, ms per step, dominant-kernel fraction), so that those numbers are witnessed by
+whoever runs the line and nothing an extra does can cost the headline (it is on stderr before the child starts).
+CLV_BENCH_SHARE_GPU=1 puts every rank of `--gpus N` on cuda:0 with gloo between them: the whole world > 1 code path on a
+one-GPU box (tests/test_gpu_bench_dp.py), never a scaling measurement (the line says `shared_device`).
 """
 import argparse
 import json
@@ -201,7 +204,8 @@ def allreduce_microbench(ts, dev, iters=50):
         ar.reduce_tail(); ar.reduce_main(); ar.wait()
     torch.cuda.synchronize()
     us = 1e6 * (time.perf_counter() - t0) / iters
-    tt = torch.tensor([us], dtype=torch.float64, device=dev)
+    from clvae_amd.parallel import meta_device
+    tt = torch.tensor([us], dtype=torch.float64, device=meta_device(dev))
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     ar.flat.copy_(keep)
     return dict(tail_bucket_bytes=tail_b, main_bucket_bytes=main_b, both_buckets_us=round(float(tt.item()), 2),
@@ -296,6 +300,8 @@ def timed_blocks(run, barrier, steps, world, dev):
     Returns (seconds of the median block, [ms per step of every block], per-rank ms per step of the median block)."""
     import torch
     import torch.distributed as dist
+    from clvae_amd.parallel import meta_device
+    mdev = meta_device(dev)
 
     def one():
         barrier()
@@ -304,7 +310,7 @@ def timed_blocks(run, barrier, steps, world, dev):
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+            mine = torch.tensor([dt], dtype=torch.float64, device=mdev)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
             return [float(t.item()) for t in every]
@@ -315,7 +321,7 @@ def timed_blocks(run, barrier, steps, world, dev):
     if first < 0.05:
         n = int(min(9, max(5, np.ceil(0.05 / max(first, 1e-6)))))
         if world > 1:                      # every rank must run the same number of blocks
-            t = torch.tensor([n], dtype=torch.int32, device=dev)
+            t = torch.tensor([n], dtype=torch.int32, device=mdev)
             dist.broadcast(t, src=0)
             n = int(t.item())
         blocks += [one() for _ in range(n - 1)]
@@ -526,6 +532,8 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
             recs_nolabel = kernel_time_pass(eng, dict(seed=1234, rank=rank, world=1), batch, max(reps // 2, 4), label_off=True)
     barrier()
     run(warmup)
+    if os.environ.get('CLV_BENCH_FAULT_RANK') == str(rank):        # tests: one rank dies between warm-up and the timed region
+        raise RuntimeError("CLV_BENCH_FAULT_RANK: injected failure of rank %d" % rank)
     dt, block_ms, rank_ms = timed_blocks(run, barrier, steps, world, dev)
     allreduce = allreduce_microbench(ts, dev) if world > 1 else None
     # what the host spends per step issuing it (staging launch + graph replays / plain launches / collectives), device idle
@@ -545,8 +553,39 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
                 roofline=roofline, host_us=round(host_us, 1))
 
 
+def also_in_child(timeout_s=600):
+    """The `also` list from a FRESH child process (`bench.py --also-only`), so that nothing an extra workload does -- a GPU
+    fault, an abort inside a C-ABI call, an out-of-memory kill, a hang -- can cost the headline this process has already
+    measured (and printed to stderr).  The child is started, never exec'd over this process; on a timeout exactly the
+    process group started here is killed."""
+    import signal
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--also-only']
+    try:
+        pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    except OSError as ex:
+        return [{"error": "could not start the child: %r" % (ex,)}]
+    try:
+        so, se = pr.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        pr.communicate()
+        return [{"error": "the child process of the extra workloads passed %d s and was killed" % timeout_s}]
+    for line in reversed(so.splitlines()):
+        if line.startswith('['):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return [{"error": "child exit code %s, no list on stdout; stderr tail: %s" % (pr.returncode, se[-300:])}]
+
+
 def also_list(args, dev):
-    """The other BASELINE workloads, measured in this process right after the headline (single GPU, default run only)."""
+    """The other BASELINE workloads on one GPU.  Runs inside `bench.py --also-only`: the child process a default run starts
+    right after its headline (also_in_child)."""
     import copy
     import gc
     import torch
@@ -602,6 +641,7 @@ def main():
     ap.add_argument('--no-also', action='store_true', help='skip the `also` list (the other workloads after a default cfg3 run)')
     ap.add_argument('--kernel-times', action='store_true', help='print per-kernel event times to stderr')
     ap.add_argument('--selftest-launch', action='store_true', help='launcher / rendezvous check on CPU (gloo), no timing')
+    ap.add_argument('--also-only', action='store_true', help='print only the `also` list (what a default run starts as its child)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
@@ -613,7 +653,7 @@ def main():
     import torch.distributed as dist
     import clvae_amd  # noqa: F401
     from clvae_amd import _lib
-    from clvae_amd.parallel import init_from_env
+    from clvae_amd.parallel import init_from_env, shared_gpu
 
     rank, local, world = init_from_env()
     if world != args.gpus:
@@ -626,6 +666,9 @@ def main():
     w = WORKLOADS[args.workload]
     B, T = w['B'], w['T']
 
+    if args.also_only:
+        print(json.dumps(also_list(args, dev)))
+        return
     if w.get('generate'):
         g = bench_generate(args, w, dev, rank, world)
         if rank == 0:
@@ -675,10 +718,20 @@ def main():
                 "optimizer": "hW kernel updated (two launches, its sum g.V averaged with its gradient bucket) under the "
                              "main bucket's all-reduce, the rest after it"},
         }
+        if shared_gpu():
+            out["shared_device"] = ("CLV_BENCH_SHARE_GPU=1: all %d ranks on cuda:0, gloo carries the gradient buckets through "
+                                    "the host -- a run of the world > 1 code path on a one-GPU box, NOT a scaling measurement"
+                                    % world)
+            out["backend"] = dist.get_backend() if world > 1 else None
         if world == 1 and args.workload == 'cfg3' and not args.bf16 and not args.no_also and not args.no_graph:
+            # the headline is out (stderr, flushed) before any extra workload runs, and the extras run in a child process
+            print("headline (repeated on stdout with `also`): " + json.dumps(out), file=sys.stderr, flush=True)
             del m, eng, ts
-            out["also"] = also_list(args, dev)
-        print(json.dumps(out))
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["also"] = also_in_child()
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -17,11 +17,16 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* if world > 1."""
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* if world > 1.
+    CLV_BENCH_SHARE_GPU=1: every rank on cuda:0 with gloo carrying the gradient buckets through the host (RCCL cannot put
+    two ranks on one device) -- how a one-GPU box runs the whole world > 1 schedule; returns local = 0."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if shared_gpu():
+        local = 0
+        backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -31,6 +36,18 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def shared_gpu():
+    import os
+    return os.environ.get("CLV_BENCH_SHARE_GPU") == "1"
+
+
+def meta_device(dev):
+    """Where the small bookkeeping tensors of a collective (times, counts) live: the device under RCCL, the host under gloo."""
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return dev
 
 
 def shard_rows(global_batch, rank, world):

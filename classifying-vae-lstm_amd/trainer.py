@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .parallel import GradAllReduce, eps_first_index
+from .parallel import GradAllReduce, eps_first_index, meta_device
 
 
 class DevWindows:
@@ -384,7 +384,7 @@ class TrainStep:
             for _ in range(steps):
                 self.step()
             torch.cuda.synchronize()
-            ms = torch.tensor([1e3 * (time.perf_counter() - t0) / steps], dtype=torch.float64, device=eng.device)
+            ms = torch.tensor([1e3 * (time.perf_counter() - t0) / steps], dtype=torch.float64, device=meta_device(eng.device))
             if self.ar.world > 1:
                 dist.all_reduce(ms, op=dist.ReduceOp.MAX)
             res[name] = round(float(ms.item()), 4)
