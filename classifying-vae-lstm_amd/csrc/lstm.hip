@@ -649,8 +649,11 @@ extern "C" int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
                                 float* hs, float* cs, float* gates, float* hT, float* cT,
                                 void* stream) {
   using namespace clv;
-  if (H != LH || B <= 0 || T < 0 || !xproj || !U || !hs || (gates && !cs)) return CLV_EINVAL;
+  if (H <= 0 || B <= 0 || T < 0 || !xproj || !U || !hs || (gates && !cs)) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  // any other --intermediate_dim (cl_vrnn/train.py:90): csrc/lstm_any.hip (CLV_LSTM_ANY=1, read per call: also at 88 units -- tests)
+  if (H != LH || env_int("CLV_LSTM_ANY", 0))
+    return launch_lstm_any_fwd(B, T, H, gate_act, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT, (hipStream_t)stream);
   LstmFwdArgs a{B, T, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT, nullptr, nullptr, 0, 0};
   return lstm_fwd_dispatch(a, gate_act, (hipStream_t)stream);
 }
@@ -692,8 +695,9 @@ extern "C" int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
                                 const float* U, const float* dhs, const float* cs, const float* c0,
                                 float* gates_inout_dz, float* dzsum, void* stream) {
   using namespace clv;
-  if (H != LH || B <= 0 || T < 0 || !U || !dhs || !cs || !gates_inout_dz || !dzsum) return CLV_EINVAL;
+  if (H <= 0 || B <= 0 || T < 0 || !U || !dhs || !cs || !gates_inout_dz || !dzsum) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  if (H != LH || env_int("CLV_LSTM_ANY", 0)) return launch_lstm_any_bwd(B, T, H, gate_act, U, dhs, cs, c0, gates_inout_dz, dzsum, (hipStream_t)stream);
   LstmBwdArgs a{B, T, U, dhs, cs, c0, gates_inout_dz, dzsum, nullptr, nullptr, 0, 0};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_seq_bwd", s);

@@ -15,6 +15,13 @@ int launch_lstm_fwd_mfma(int B, int T, int gate_act, const float* xproj, const f
                          const float* zin, int ldz, int nz, const float* Kz, hipStream_t s);
 bool lstm_fwd_mfma_wanted(int B);      // the batch sizes at which lstm.hip hands a training forward to lstm_mfma.hip
 
+// lstm_any.hip: the same contract for any number of hidden units (1..1024); clv_lstm_seq_fwd / _bwd dispatch here for H != 88
+int launch_lstm_any_fwd(int B, int T, int H, int gate_act, const float* xproj, const float* rowbias, const float* U,
+                        const float* h0, const float* c0, float* hs, float* cs, float* gates, float* hT, float* cT,
+                        hipStream_t s);
+int launch_lstm_any_bwd(int B, int T, int H, int gate_act, const float* U, const float* dhs, const float* cs,
+                        const float* c0, float* gates_inout_dz, float* dzsum, hipStream_t s);
+
 typedef float f2 __attribute__((ext_vector_type(2)));   // register pair: v_pk_fma_f32 does two fp32 FMAs per issue slot
 
 template <int CTRL>
@@ -61,20 +68,31 @@ __device__ __forceinline__ void step_barrier() {
   else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// A lane mask (ballot of a per-lane condition) kept in an SGPR pair, opaque to the optimiser: the empty asm holds no
+// instruction, it only hides that the mask is `cond` per lane (see Sel4).
+__device__ __forceinline__ unsigned long long lane_mask(bool cond) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(cond);
+  asm volatile("" : "+s"(m));
+  return m;
+}
+
 // v[i] for a per-lane i in 0..3 as three v_cndmask_b32 on lane masks kept in SGPR pairs.  Written as a chain of selects
 // on `i == const` the compiler recognises a dynamic index into a 4-element array and puts the array in LDS
-// (ds_write_b128 + ds_read_b32 and a full lgkmcnt wait on the critical path of every step); the asm form costs no VGPR.
+// (ds_write_b128 + ds_read_b32 and a full lgkmcnt wait on the critical path of every step); selects on opaque masks cost
+// no VGPR and no LDS.
+// pick() is the compiler's own select on inverse_ballot(mask) -- since round 5; until then it was an inline-asm
+// v_cndmask_b32_e64, and that was a BUG on gfx940/gfx950: a VALU instruction that reads the result of a transcendental
+// one (v_rcp_f32, v_exp_f32) needs one wait state in between (LLVM's "trans forwarding hazard"); the compiler inserts
+// the s_nop for instructions it emits but does not look inside an asm statement.  With SLP vectorisation on, the sigmoid
+// instance of the pair forward kernel scheduled `v_rcp_f32 v97` directly in front of the asm select that reads v97 and
+// the select saw the stale register (wrong states, logits off by 0.1: round 4's "-fno-slp-vectorize is a correctness
+// requirement"); without SLP a v_fma happened to sit in between.  tools/probes/trans_hazard_asm.hip reproduces the
+// pattern in 20 lines; tests/test_host_logic.py checks that no VALU inline asm is left in csrc/.
 struct Sel4 {
   unsigned long long m1, m2, m3;
-  __device__ __forceinline__ explicit Sel4(int i) {
-    m1 = __builtin_amdgcn_ballot_w64(i == 1);
-    m2 = __builtin_amdgcn_ballot_w64(i == 2);
-    m3 = __builtin_amdgcn_ballot_w64(i == 3);
-  }
+  __device__ __forceinline__ explicit Sel4(int i) : m1(lane_mask(i == 1)), m2(lane_mask(i == 2)), m3(lane_mask(i == 3)) {}
   __device__ __forceinline__ static float pick(unsigned long long m, float a, float b) {     // m ? a : b
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
-    return r;
+    return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b;
   }
   __device__ __forceinline__ float operator()(float v0, float v1, float v2, float v3) const {
     return pick(m3, v3, pick(m2, v2, pick(m1, v1, v0)));

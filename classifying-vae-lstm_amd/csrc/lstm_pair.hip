@@ -120,9 +120,9 @@ struct PairFwdArgs {
 struct SliceMasks {
   unsigned long long m1, m2, odd;
   __device__ __forceinline__ explicit SliceMasks(int s) {
-    m1 = __builtin_amdgcn_ballot_w64(s == 1);
-    m2 = __builtin_amdgcn_ballot_w64(s == 2);
-    odd = __builtin_amdgcn_ballot_w64(s & 1);
+    m1 = lane_mask(s == 1);
+    m2 = lane_mask(s == 2);
+    odd = lane_mask(s & 1);
   }
 };
 
@@ -327,7 +327,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   // head column this lane ends with after the reduce-scatter: (mean_2j, mean_2j+1, log_var_2j, log_var_2j+1)[s]
   const int zcol = (s >> 1) * L + lat;
   const SliceMasks sm(s);
-  const unsigned long long m_lo = __builtin_amdgcn_ballot_w64(s < 2);
+  const unsigned long long m_lo = lane_mask(s < 2);
 
   f2 Up[PKK / 2][4];     // [k pair][acc] = (U[2j][g], U[2j+1][g]), g = acc ^ s
   {
@@ -355,7 +355,7 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   const int cg = lane >> 4, cj = lane & 15, cu_raw = wave * 16 + cj, cu = min(cu_raw, LH - 1);
   const bool c_is_z = LATW && cu_raw >= LH && 2 * (cu_raw - LH) < L;          // the slot of a latent group
   const int paddr_inv = XProj<XL>::perm_addr_inv(lane);
-  const unsigned vo_g = PAIR_CONTIG ? (c_is_z ? BUF_OOB : (unsigned)(cg * LH + cu) * 4u) : (is_z ? BUF_OOB : loff * 4);
+  unsigned vo_g = PAIR_CONTIG ? (c_is_z ? BUF_OOB : (unsigned)(cg * LH + cu) * 4u) : (is_z ? BUF_OOB : loff * 4);
   XProj<XL> xp;
   xp.r_kx = XL ? make_rsrc(a.Kx_e, CLV_NOTE_NONE * LG * 4) : r_g;
   // contiguous lane order for the loads (latent lanes mask what arrives: xmask)
@@ -364,15 +364,15 @@ __device__ __forceinline__ void pair_fwd_encoder(const PairFwdArgs& a, int wave,
   xp.nrow = XProj<XL>::as_notes(a.notes_e + (XL ? bt0 * CLV_NOTE_ROW : 0));
   xp.r_n = XL ? make_rsrc(a.notes_e + bt0 * CLV_NOTE_ROW, T * CLV_NOTE_ROW) : r_g;
   xp.T = T;
-  const unsigned vo_h = PAIR_CONTIG ? ((!c_is_z && cg == 0) ? cu * 4 : BUF_OOB) : ((!is_z && s == 0) ? u * 4 : BUF_OOB);
-  const unsigned vo_a = PAIR_CONTIG ? ((!c_is_z && (cg == 1 || cg == 2)) ? ((cg - 1) * LH + cu) * 4 : BUF_OOB)
+  unsigned vo_h = PAIR_CONTIG ? ((!c_is_z && cg == 0) ? cu * 4 : BUF_OOB) : ((!is_z && s == 0) ? u * 4 : BUF_OOB);
+  unsigned vo_a = PAIR_CONTIG ? ((!c_is_z && (cg == 1 || cg == 2)) ? ((cg - 1) * LH + cu) * 4 : BUF_OOB)
                                     : ((!is_z && (s == 1 || s == 2)) ? ((s - 1) * LH + u) * 4 : BUF_OOB);
   const unsigned vo_e = (lat_ok ? lat : 0) * 4;
   const unsigned vo_za = lat_ok ? zcol * 4 : BUF_OOB;
   if (PAIR_ABL == 6) {      // timing ablation: lane-contiguous addresses (wrong layout, same instruction count)
-    const_cast<unsigned&>(vo_g) = is_z ? BUF_OOB : (wave * 64 + lane) * 4;
-    const_cast<unsigned&>(vo_h) = (!is_z && lane < 16) ? (wave * 16 + lane) * 4 : BUF_OOB;
-    const_cast<unsigned&>(vo_a) = (!is_z && lane >= 16 && lane < 48) ? (wave * 32 + lane - 16) * 4 : BUF_OOB;
+    vo_g = is_z ? BUF_OOB : (wave * 64 + lane) * 4;
+    vo_h = (!is_z && lane < 16) ? (wave * 16 + lane) * 4 : BUF_OOB;
+    vo_a = (!is_z && lane >= 16 && lane < 48) ? (wave * 32 + lane - 16) * 4 : BUF_OOB;
     xp.vo = (wave * 64 + lane) * 4;
   }
   const unsigned vo_z = (lat_ok && s < 2) ? lat * 4 : BUF_OOB;
@@ -507,9 +507,9 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   const rsrc_t r_a = make_rsrc(a.aux_d + bt0 * 2 * LH, T * 2 * LH * 4);
   const int cg = lane >> 4, cu = min(wave * 16 + (lane & 15), LH - 1);        // contiguous order: see the encoder
   const int paddr_inv = XProj<XL>::perm_addr_inv(lane);
-  const unsigned vo_g = PAIR_CONTIG ? (unsigned)(cg * LH + cu) * 4u : loff * 4;
-  const unsigned vo_h = PAIR_CONTIG ? (cg == 0 ? cu * 4 : BUF_OOB) : (s == 0 ? u * 4 : BUF_OOB);
-  const unsigned vo_a = PAIR_CONTIG ? ((cg == 1 || cg == 2) ? ((cg - 1) * LH + cu) * 4 : BUF_OOB)
+  unsigned vo_g = PAIR_CONTIG ? (unsigned)(cg * LH + cu) * 4u : loff * 4;
+  unsigned vo_h = PAIR_CONTIG ? (cg == 0 ? cu * 4 : BUF_OOB) : (s == 0 ? u * 4 : BUF_OOB);
+  unsigned vo_a = PAIR_CONTIG ? ((cg == 1 || cg == 2) ? ((cg - 1) * LH + cu) * 4 : BUF_OOB)
                                     : ((s == 1 || s == 2) ? ((s - 1) * LH + u) * 4 : BUF_OOB);
   XProj<XL> xp;
   xp.r_kx = XL ? make_rsrc(a.Kx_d, CLV_NOTE_NONE * LG * 4) : r_g;
@@ -521,9 +521,9 @@ __device__ __forceinline__ void pair_fwd_decoder(const PairFwdArgs& a, int wave,
   const float rb = a.rb_d[(size_t)b * LG + loff];
   const int hslot = pair_hslot(u);
   if (PAIR_ABL == 6) {
-    const_cast<unsigned&>(vo_g) = min(wave * 64 + lane, LG - 1) * 4;
-    const_cast<unsigned&>(vo_h) = lane < 16 ? min(wave * 16 + lane, LH - 1) * 4 : BUF_OOB;
-    const_cast<unsigned&>(vo_a) = (lane >= 16 && lane < 48) ? min(wave * 32 + lane - 16, 2 * LH - 1) * 4 : BUF_OOB;
+    vo_g = min(wave * 64 + lane, LG - 1) * 4;
+    vo_h = lane < 16 ? min(wave * 16 + lane, LH - 1) * 4 : BUF_OOB;
+    vo_a = (lane >= 16 && lane < 48) ? min(wave * 32 + lane - 16, 2 * LH - 1) * 4 : BUF_OOB;
     xp.vo = min(wave * 64 + lane, LG - 1) * 4;
   }
   float c = 0.f;
@@ -680,8 +680,8 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
   const int lat = zg0 + (cs & 3);                    // latent this lane finishes after the reduce-scatter
   const bool zlane = zgroup && lat < L;
   const bool zlive = zlane && q < 2;                 // replica 0: the mean column of dzargs, replica 1: the log_var column
-  const unsigned long long m_q3 = __builtin_amdgcn_ballot_w64(q == 3);
-  const unsigned long long m_q0 = __builtin_amdgcn_ballot_w64(q == 0);
+  const unsigned long long m_q3 = lane_mask(q == 3);
+  const unsigned long long m_q0 = lane_mask(q == 0);
   float* gates = DEC ? a.gates_d : a.gates_e;
   const float* aux = DEC ? a.aux_d : a.aux_e;
   float* dzsum = DEC ? a.dzsum_d : a.dzsum_e;

@@ -561,14 +561,15 @@ class VrnnEngine(_EngineBase):
         super().__init__(cfg, batch_size, vrnn_param_shapes(cfg), device,
                          head_pairs=[('Z_mean', 'Z_log_var', 'Zargs')], grads_pre=cfg['D'])
         B, D, H, L, T, Cn = self.B, cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
-        if H != 88:
-            raise ValueError("the LSTM sequence kernels are built for intermediate_dim == 88")
+        # H = --intermediate_dim (cl_vrnn/train.py:90).  The fused and the matrix-core paths below are laid out for the
+        # reference's default of 88 units and say so through their *_supported() predicates; any other width takes the
+        # generic chain: GEMM (or row-gather) input projections + csrc/lstm_any.hip + the GEMM heads.
         d = self.device
         BT = B * T
         self.gate_act = _lib.GATE_HARD_SIGMOID if cfg.get('gate_act', 'hard_sigmoid') == 'hard_sigmoid' \
             else _lib.GATE_SIGMOID
         self.off = D if cfg['use_x_prev'] else 0     # decoder kernel rows: [Xp | Z | W]
-        self.fuse_xproj = bool(cfg.get('fuse_xproj', False))   # break-even vs the projection GEMM at config 3
+        self.fuse_xproj = bool(cfg.get('fuse_xproj', False)) and H == 88   # break-even vs the projection GEMM at config 3
         # encoder + latent head + decoder as one launch (csrc/lstm_pair.hip); latent_dim <= 16
         self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj
         # Twice the workgroups, half the K each, for the LSTM weight-gradient products.  They run one 1024-thread
@@ -617,7 +618,7 @@ class VrnnEngine(_EngineBase):
         # on the bf16 matrix cores with the frame rows of their input kernels gathered inside the kernel (csrc/lstm_mx.hip):
         # no projection launch, no [B*T,4H] projection buffer; gates_* / cs_* then hold the coefficient format
         self.use_mx = bool(cfg.get('lstm_mx', os.environ.get('CLV_USE_MX', '1') != '0')) and not self.fuse_pair \
-            and self.sparse_inputs and not self.fuse_xproj and ops.lstm_mx_supported(B, D, L)
+            and self.sparse_inputs and not self.fuse_xproj and ops.lstm_mx_supported(B, D, L, H)
         self.fuse_notes = bool(cfg.get('fuse_notes', os.environ.get('CLV_FUSE_NOTES', '0') == '1')) and self.fuse_pair \
             and self.sparse_inputs and D == ops.NOTE_NONE
         self.notes_valid = False
@@ -707,7 +708,7 @@ class VrnnEngine(_EngineBase):
                                self.hs_enc, self.cs_enc, self.gates_enc, gate_act=self.gate_act)
         else:
             ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
-                             self.cs_enc, self.gates_enc, gate_act=self.gate_act)
+                             self.cs_enc, self.gates_enc, gate_act=self.gate_act, H=H)
         # latent heads + sample (:200-216)
         if self.fuse_latent:       # one launch on the matrix cores (csrc/latent_head.hip)
             ops.latent_head_fwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z, self.zargs, self.Z,
@@ -721,7 +722,7 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_fwd_x(B, T, self.XZ, self.xz_ld, off + L, P.p('decoder_h/kernel'), self.wk_dec,
                                P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.cs_dec, self.gates_dec,
                                gate_act=self.gate_act)
-        elif off and self.sparse_inputs and ops.lstm_seq_fwd_z_supported(B, L):
+        elif off and self.sparse_inputs and ops.lstm_seq_fwd_z_supported(B, L, H):
             # large batches: the history frames' projection as a row gather, z_t . K_z inside the MFMA sequence kernel
             # (no dense [B*T, 120] x [120, 352] product, no second trip of the gate buffer through HBM)
             ops.sparse_proj(BT, off, G4, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec)
@@ -731,7 +732,7 @@ class VrnnEngine(_EngineBase):
         else:
             g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
             ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
-                             self.cs_dec, self.gates_dec, gate_act=self.gate_act)
+                             self.cs_dec, self.gates_dec, gate_act=self.gate_act, H=H)
         # output head (:229-234), with the NLL fused into its epilogue when the caller wants the loss
         self._output_head(target, nll)
 
@@ -884,7 +885,7 @@ class VrnnEngine(_EngineBase):
 
     def _lstm_step(self, name, st, hkey, ckey):
         ops.lstm_seq_fwd(st['B'], 1, st['gates'], None, self.P.p(name + '/recurrent_kernel'), st['hs'], None, None,
-                         h0=st[hkey], c0=st[ckey], hT=st[hkey], cT=st[ckey], gate_act=self.gate_act)
+                         h0=st[hkey], c0=st[ckey], hT=st[hkey], cT=st[ckey], gate_act=self.gate_act, H=self.cfg['H'])
 
     def enc_step(self, x, w, st, rec_name='encoder_h'):
         """one encoder-LSTM step on [x_t, w] + the Z heads -> st['zargs'] = [z_mean | z_log_var]"""
@@ -1055,13 +1056,13 @@ class VrnnEngine(_EngineBase):
         if self.use_mx:      # the backward pass of csrc/lstm_mx.hip, dZ = dz_dec . Kz^T as its latent tiles
             ops.lstm_mx_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec, self.dzsum_dec,
                             Kz=P.rows(P.params, 'decoder_h/kernel', off), nz=L, dZ=self.dZ, lddz=L)
-        elif L <= 40 and os.environ.get('CLV_BWD_Z', '1') != '0':      # dZ = dz_dec . Kz^T by two more waves of the decoder's backward kernel
+        elif H == 88 and L <= 40 and os.environ.get('CLV_BWD_Z', '1') != '0':      # dZ = dz_dec . Kz^T by two more waves of the decoder's backward kernel
             ops.lstm_seq_bwd_z(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
                                self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off), L, self.dZ, L,
                                gate_act=self.gate_act)
         else:
             ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
-                             self.dzsum_dec, gate_act=self.gate_act)
+                             self.dzsum_dec, gate_act=self.gate_act, H=H)
             g(self.gates_dec, P.rows(P.params, 'decoder_h/kernel', off), self.dZ, BT, L, G4, tb=True, ws=ws)
         if self.fuse_latent:       # dzargs, dh_enc and the head's own kernel / bias gradient in one launch; dzargs stays on chip
             ops.latent_head_bwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), self.zargs, eps_Z, self.dZ, L,
@@ -1074,7 +1075,7 @@ class VrnnEngine(_EngineBase):
             ops.lstm_mx_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc, self.dzsum_enc)
         else:
             ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
-                             self.dzsum_enc, gate_act=self.gate_act)
+                             self.dzsum_enc, gate_act=self.gate_act, H=H)
 
     def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True, target=None, noise=None):
         """target: the frames the decoder output is scored against (default X; the next frames under --predict_next).

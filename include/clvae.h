@@ -223,8 +223,10 @@ int clv_colsum_f32(int M, int N, const float* X, int ldx, float beta, float* out
                    void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ LSTM --
- * Persistent sequence kernels, one workgroup per batch row, recurrent kernel
- * U [H,4H] resident in registers for all T steps (H must be 88).
+ * Persistent sequence kernels, one workgroup per batch row.  H == 88 (the reference's default --intermediate_dim,
+ * cl_vrnn/train.py:90): recurrent kernel U [H,4H] resident in registers for all T steps (csrc/lstm.hip).  Any other
+ * 1 <= H <= 1024 (clv_lstm_seq_fwd and clv_lstm_seq_bwd only): the same contract with U streamed from L2 every step
+ * (csrc/lstm_any.hip) -- correct for whatever LSTM(intermediate_dim) cl_vrnn/model.py:196-199,225-228 builds, not fast.
  *   z_t = xproj[b,t,:] + rowbias[b,:] + h_{t-1} . U
  *   i,f,o = gate_act(z_i,z_f,z_o); g = tanh(z_c); c_t = f*c_{t-1} + i*g; h_t = o*tanh(c_t)
  * fwd writes hs[B,T,H], cs[B,T,H] and gates[B,T,4H] = (z_i, z_f, tanh(z_c), z_o)

@@ -242,6 +242,60 @@ def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate, pair):
         np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("H,B,Tn,L,Cn,use_x_prev,gate", [
+    (32, 6, 5, 2, 10, True, 'hard_sigmoid'),     # 8 k-slices per unit
+    (64, 5, 9, 3, 4, True, 'sigmoid'),           # 4 slices
+    (128, 4, 16, 2, 10, True, 'hard_sigmoid'),   # 2 slices; the CLI's default window (cl_vrnn/train.py:92)
+    (128, 3, 7, 32, 10, False, 'hard_sigmoid'),  # no history frames, config-5 latent size
+    (50, 4, 6, 2, 3, True, 'hard_sigmoid'),      # not a multiple of 4, ragged last slice
+    (300, 2, 4, 2, 10, True, 'sigmoid'),         # more units than threads: two units per owner thread, one slice
+    (88, 4, 6, 2, 10, True, 'hard_sigmoid'),     # the default width through the SAME generic chain (fuse_pair off, lstm_any forced)
+])
+def test_cl_vrnn_step_matches_oracle_at_any_intermediate_dim(dev, monkeypatch, H, B, Tn, L, Cn, use_x_prev, gate):
+    """--intermediate_dim != 88 (cl_vrnn/train.py:90; LSTM(intermediate_dim) at cl_vrnn/model.py:196-199, 225-228): the
+    step through the generic chain -- GEMM / row-gather input projections, csrc/lstm_any.hip for both recurrences, GEMM
+    heads -- against the fp64 oracle: ELBO and every loss term, per-note logits, both LSTMs' states, every gradient
+    tensor, and two Adam-WN steps."""
+    from clvae_amd.engine import VrnnEngine
+    cfg = O.vrnn_config(intermediate_dim=H, latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=use_x_prev,
+                        class_weight=0.8, kl_weight=0.6, w_kl_weight=0.9, w_log_var_prior=0.2, gate_act=gate)
+    rng = np.random.default_rng(H * 1000 + Tn)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=2).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    eW, eZ = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, Tn, L)))
+    ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
+    if H == 88:
+        cfg['fuse_pair'] = False
+        monkeypatch.setenv("CLV_LSTM_ANY", "1")
+    eng = VrnnEngine(cfg, B, dev)
+    assert not eng.fuse_pair and not eng.use_mx
+    eng.P.set_weights(p)
+    args = (T(X, dev), T(Xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev))
+    eng.loss_and_grads(*args)
+    torch.cuda.synchronize()
+    got = eng.losses()
+    logit_err = np.abs(N(eng.logits).reshape(B, Tn, 88) - ref['cache']['logits']).max()
+    print("cl_vrnn H=%d B=%d T=%d L=%d: ELBO gpu %.6f oracle %.6f |d|=%.2e  logits max-abs err %.2e"
+          % (H, B, Tn, L, got['elbo'], ref['elbo'], abs(got['elbo'] - ref['elbo']), logit_err))
+    for k in ('elbo', 'vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, k
+    assert logit_err < LOGIT_TOL
+    np.testing.assert_allclose(N(eng.hs_enc).reshape(B, Tn, H), ref['cache']['enc_h'], atol=2e-5)
+    np.testing.assert_allclose(N(eng.hs_dec).reshape(B, Tn, H), ref['cache']['dec_h'], atol=2e-5)
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'], tol=2e-4)
+    st = O.adam_wn_init(p)
+    for _ in range(2):
+        r = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ)
+        O.adam_wn_step(p, r['grads'], st)
+        eng.loss_and_grads(*args)
+        eng.P.adam_step()
+    w = eng.P.get_weights()
+    for k in p:
+        np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
+
+
 @pytest.mark.parametrize("exact_frames", [False, True])
 @pytest.mark.parametrize("B,Tn,L", [(256, 128, 2),         # BASELINE config 3 (and 4 per GPU): what bench.py times
                                     (1024, 256, 32)])      # config 5 per GPU

@@ -51,6 +51,25 @@ def test_no_gpu_fails_loudly():
         get_model(4, 88, (88, 2), (88, 2), 'adam-wn')          # no CPU fallback: building a model needs the device
 
 
+def test_no_valu_instruction_hides_inside_inline_asm():
+    """gfx940/gfx950: a VALU instruction that reads a transcendental instruction's result needs a wait state the compiler
+    only inserts around instructions it emits itself; an asm statement holding a v_* instruction once put wrong states
+    into the sigmoid-gate pair kernel (csrc/lstm_common.h, Sel4::pick; tools/probes/trans_hazard_asm.hip).  csrc/ keeps
+    its asm statements to waits, barriers, clocks, empty register pins and one VMEM load."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = []
+    for path in sorted(glob.glob(os.path.join(root, "classifying-vae-lstm_amd", "csrc", "*.h*"))):
+        src = re.sub(r"//[^\n]*", "", open(path).read())
+        for m in re.finditer(r"\basm\s*(?:volatile)?\s*\(\s*((?:\"(?:[^\"\\]|\\.)*\"\s*)+)", src):
+            text = "".join(re.findall(r"\"((?:[^\"\\]|\\.)*)\"", m.group(1)))
+            for ins in re.split(r"\\n|\\t|;", text):
+                if re.match(r"\s*(v_|ds_)\w+", ins):
+                    found.append((os.path.basename(path), ins.strip()))
+    assert not found, found
+
+
 def test_adam_plan_layout_on_host():
     L = _lib.lib()
     tab = (_lib.ParamDesc * 3)(_lib.ParamDesc(0, 200, 88, 0, 1, 0), _lib.ParamDesc(17600, 1, 88, 0, 0, 0),
