@@ -307,6 +307,55 @@ def test_cl_vrnn_cli_train_then_sample(dev, tmp_path):
     assert len(dout) == 3 and dout[0].shape == (8, 88) and set(np.unique(dout[0])) <= {0.0, 1.0}
 
 
+def test_cl_vrnn_cli_with_another_intermediate_dim(dev, tmp_path):
+    """`--intermediate_dim 64` (cl_vrnn/train.py:90) end to end: train CLI (Model.fit on the generic LSTM chain, graph
+    replay), the .json / .h5 it writes, load_model + the three stateful sub-models of sample.py (host loop) and the
+    device-side frame loop; then the trained weights' loss through the engine equals the oracle's on the same batch."""
+    from clvae_amd.cl_vrnn import sample as S, train as TR
+    from clvae_amd.cl_vrnn.model import load_model
+    data = make_synthetic_pickle(str(tmp_path / "jsb_syn.pickle"), n_songs=(10, 4, 4), seed=2)
+    mdir, sdir = str(tmp_path / "models"), str(tmp_path / "samples")
+    os.makedirs(mdir); os.makedirs(sdir)
+    args = _ns(TR.build_parser(), ['r64', '--use_x_prev', '--seq_length', '8', '--batch_size', '20', '--num_epochs', '3',
+                                   '--intermediate_dim', '64', '--train_file', data, '--model_dir', mdir, '--patience', '0'])
+    np.random.seed(1)
+    model, best = TR.train(args)
+    h = model.history.history
+    assert model.engine.cfg['H'] == 64 and not model.engine.fuse_pair
+    assert len(h['loss']) == 3 and h['loss'][-1] < h['loss'][0]
+    assert json.load(open(os.path.join(mdir, 'r64.json')))['intermediate_dim'] == 64
+    w = model.engine.P.get_weights()
+    assert w['encoder_h/recurrent_kernel'].shape == (64, 256) and w['X_decoded_mean/kernel'].shape == (64, 88)
+    # the step's numbers at the trained weights against the oracle
+    cfg = O.vrnn_config(intermediate_dim=64, latent_dim=2, seq_length=8, n_classes=model.engine.cfg['C'], use_x_prev=True)
+    rng = np.random.default_rng(9)
+    B, Cn = model.engine.B, cfg['C']
+    win = (rng.random((B, 9, 88)) < 0.05).astype(np.float64)
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    eW, eZ = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, 8, 2)))
+    p = {k: f32(v) for k, v in w.items()}
+    ref = O.vrnn_loss_and_grads(p, cfg, win[:, 1:], win[:, :-1], wt, eW, eZ)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+    model.engine.loss_and_grads(t(win[:, 1:]), t(win[:, :-1]), t(wt), t(eW), t(eZ), need_grads=False)
+    got = model.engine.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= 1e-3, (k, got[k], ref[k])
+    # sampling: host loop over the stateful sub-models, then the device-side loop
+    m2, _, margs = load_model(os.path.join(mdir, 'r64.h5'))
+    assert margs['intermediate_dim'] == 64 and m2.engine.cfg['H'] == 64 and m2.engine.P.get_weights()['decoder_h/recurrent_kernel'].shape == (64, 256)
+    sargs = _ns(S.build_parser(), ['g', '-n', '2', '-t', '8', '-i', os.path.join(mdir, 'r64.h5'), '--train_file', data,
+                                   '--sample_dir', sdir])
+    np.random.seed(2)
+    out = S.sample(sargs)
+    assert len(out) == 2 and out[0].shape == (8, 88) and set(np.unique(out[0])) <= {0.0, 1.0}
+    from clvae_amd.cli import DEVICE_LOOP_FLAGS, parser_for
+    dargs = _ns(parser_for('cl_vrnn.sample', DEVICE_LOOP_FLAGS), ['d', '-n', '3', '-t', '8', '--device_loop', '-i',
+                                                                    os.path.join(mdir, 'r64.h5'), '--train_file', data,
+                                                                    '--sample_dir', sdir])
+    dout = S.sample(dargs)
+    assert len(dout) == 3 and dout[0].shape == (8, 88) and set(np.unique(dout[0])) <= {0.0, 1.0}
+
+
 def test_device_generation_matches_stepwise_oracle(dev):
     """generate_samples_device: the frame loop on the device (hipGraph replays, Philox noise) vs an oracle
     loop that redraws the same Philox numbers on the host."""
