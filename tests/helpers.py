@@ -68,11 +68,12 @@ class StubModel:
         return (1 / (1 + np.exp(-3 * base[:D]))).reshape((1,) * lead + (D,))
 
 
-def write_jsb_cs_pickle(path):
-    """The real `JSB Chorales_Cs` data set (tests/golden/g7_jsb_cs_notes.npz, made from the reference's pickle in the build
-    container) as a pickle of the reference's schema: {'train' | 'valid' | 'test': list[song], song: list[frame], frame:
-    list[int MIDI]; '<split>_key': list[str]; '<split>_mode': list[bool]}."""
-    G = golden("g7_jsb_cs_notes.npz")
+def write_jsb_pickle(which, path):
+    """A real JSB data set of the reference -- which = 'Cs' (`JSB Chorales_Cs`, tests/golden/g7_jsb_cs_notes.npz) or 'all'
+    (`JSB Chorales_all`, g8_jsb_all_notes.npz), both made from the reference's pickles in the build container -- as a
+    pickle of the reference's schema: {'train' | 'valid' | 'test': list[song], song: list[frame], frame: list[int MIDI];
+    '<split>_key': list[str]; '<split>_mode': list[bool]}."""
+    G = golden({'Cs': "g7_jsb_cs_notes.npz", 'all': "g8_jsb_all_notes.npz"}[which])
     D = {}
     for split in ('train', 'valid', 'test'):
         notes, per_frame, frames = G[split + '/notes'], G[split + '/per_frame'], G[split + '/frames']
@@ -85,3 +86,7 @@ def write_jsb_cs_pickle(path):
     with open(path, 'wb') as f:
         pickle.dump(D, f, protocol=2)
     return path
+
+
+def write_jsb_cs_pickle(path):
+    return write_jsb_pickle('Cs', path)

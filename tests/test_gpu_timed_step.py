@@ -61,9 +61,13 @@ def check_params(got, want, steps, rtol=1e-4, atol=2e-5, frac=1e-4, what=""):
     return worst
 
 
+@pytest.mark.parametrize("feed", ["stage_batch", "cursor"])
 @pytest.mark.parametrize("B,Tn,L,steps", [(256, 128, 2, 3),        # BASELINE config 3 (config 4 per GPU): bench.py's default
                                           (1024, 256, 32, 2)])     # config 5 per GPU
-def test_cl_vrnn_timed_step_tracks_the_oracle(dev, B, Tn, L, steps):
+def test_cl_vrnn_timed_step_tracks_the_oracle(dev, B, Tn, L, steps, feed):
+    """feed = "cursor": what bench.py and Model.fit do -- TrainStep.bind_batches, the mini-batch assembled INSIDE the
+    captured step from the device-resident data set by the device step counter (at 256 x 128: inside the label forward
+    launch), nothing staged from the host; "stage_batch": one staging launch per step in front of the graph."""
     from clvae_amd.engine import VrnnEngine
     from clvae_amd.trainer import TrainStep
     Cn, seed = 10, 4321
@@ -78,9 +82,13 @@ def test_cl_vrnn_timed_step_tracks_the_oracle(dev, B, Tn, L, steps):
     assert ts.use_graph and ts.fast_adam and ts.ar is None
     Xd, Xpd, wd = u8(win[:, 1:], dev), u8(win[:, :-1], dev), ft(keys, dev)
     st = O.adam_wn_init(p)
+    if feed == "cursor":
+        ts.bind_batches(Xd.reshape(steps * B, -1), Xpd.reshape(steps * B, -1), wd, idx=None, period=steps, stride=B)
+        assert (ts._label_stage() is not None) == (L <= 8)        # the pair path's label launch assembles the batch itself
     for it in range(steps):
         sl = slice(it * B, (it + 1) * B)
-        ts.stage_batch(Xd[sl], Xpd[sl], wd[sl])
+        if feed == "stage_batch":
+            ts.stage_batch(Xd[sl], Xpd[sl], wd[sl])
         ts.step()
         torch.cuda.synchronize()
         got = eng.losses()
@@ -88,8 +96,8 @@ def test_cl_vrnn_timed_step_tracks_the_oracle(dev, B, Tn, L, steps):
         eZ = f32(OP.normal(B * Tn * L, seed, step=it, stream_id=1).reshape(B, Tn, L))
         ref = O.vrnn_loss_and_grads(p, cfg, win[sl, 1:].astype(np.float64), win[sl, :-1].astype(np.float64), keys[sl], eW, eZ)
         O.adam_wn_step(p, ref['grads'], st)
-        print("cl_vrnn %dx%d L=%d step %d (%s): total gpu %.6f oracle %.6f |d| %.2e" %
-              (B, Tn, L, it, "eager" if it == 0 else "graph replay", got['total'], ref['total'], abs(got['total'] - ref['total'])))
+        print("cl_vrnn %dx%d L=%d %s step %d (%s): total gpu %.6f oracle %.6f |d| %.2e" %
+              (B, Tn, L, feed, it, "eager" if it == 0 else "graph replay", got['total'], ref['total'], abs(got['total'] - ref['total'])))
         for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total', 'elbo'):
             assert abs(got[k] - ref[k]) <= LOSS_TOL, (it, k, got[k], ref[k])
     # the path that ran is the one bench.py times

@@ -7,7 +7,7 @@ import pytest
 
 import clvae_amd  # noqa: F401
 from clvae_amd.utils import pianoroll as PR
-from helpers import REF_DATA, golden, make_synthetic_pickle, write_jsb_cs_pickle
+from helpers import REF_DATA, golden, make_synthetic_pickle, write_jsb_pickle
 
 G1 = golden("g1_pianodata.npz")
 CASES = [('Cs', 100, 1, dict(return_y_next=True, squeeze_x=True, squeeze_y=True)),
@@ -26,14 +26,9 @@ def sha(a):
 
 @pytest.mark.parametrize("name,bs,T,kw", CASES)
 def test_pianodata_matches_reference_golden(name, bs, T, kw, tmp_path):
-    """JSB_Cs: rebuilt from the committed note fixture G7 (runs anywhere, so the fixture itself is held to the checksums
-    the reference's loader produced on the reference's file); JSB_all: the reference checkout's file (build container)."""
-    if name == 'Cs':
-        path = write_jsb_cs_pickle(str(tmp_path / 'JSB Chorales_Cs.pickle'))
-    else:
-        if not os.path.isdir(REF_DATA):
-            pytest.skip("JSB Chorales_all.pickle lives in the reference checkout (build container only)")
-        path = os.path.join(REF_DATA, 'JSB Chorales_%s.pickle' % name)
+    """Both data sets are rebuilt from the committed note fixtures (G7: JSB_Cs, G8: JSB_all), so this runs anywhere and
+    the fixtures themselves are held to the checksums the reference's loader produced on the reference's files."""
+    path = write_jsb_pickle(name, str(tmp_path / ('JSB Chorales_%s.pickle' % name)))
     P = PR.PianoData(path, batch_size=bs, seq_length=T, step_length=1, **kw)
     tag = '%s_b%s_t%d' % (name, bs, T)
     for split in ('train', 'valid', 'test'):
