@@ -342,6 +342,7 @@ def kernel_time_pass(eng, ts_args, batch, reps, label_off=False):
     if label_off:
         eng.label_in_pair = False
     ts_e = TrainStep(eng, use_graph=False, **ts_args)
+    ts_e._drop_logits = hasattr(eng, 'keep_logits')      # the launches of the REPLAYED step: it stores no logits (TrainStep._main)
     ts_e.stage_batch(*batch)
     ts_e.step(); torch.cuda.synchronize()
     ops.prof_enable(True)
@@ -449,7 +450,7 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
     wkeys = [k for k in by if k.startswith('lstm_wgrad_bf16')]      # one launch per LSTM, or both in one (..._pair)
     if wkeys:
         # the batched gate GEMM of the north star: every kernel gradient of an LSTM, [x | h | z]^T . dz over B*T rows
-        # (csrc/wgrad_bf16.hip), formed on the BF16 matrix cores from exact pieces.  Reported against the pipe it
+        # (csrc/wgrad_bf16.hip), formed on the BF16 matrix cores from bf16 pieces (6 of 9 piece pairs).  Reported against the pipe it
         # runs on: (a) issued bf16 MFMA flops / 2.5 PFLOP/s, (b) the MFMA-busy counter of the committed SQ pass;
         # the algorithmic fp32-equivalent rate is given by name, never as a fraction of a peak it does not use.
         gn, gms = sum(by[k][1] for k in wkeys), sum(by[k][2] for k in wkeys)
@@ -482,7 +483,9 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
             achieved_is="issued bf16 MFMA flops (padded tiles, 6 piece pairs per fp32 product, 3 for byte-valued frames) / launch time",
             mfma_busy_counter=sq,
             fp32_equivalent_tflops=round(alg / (gms * 1e-3) / 1e12, 2),
-            arithmetic="fp32 operands as 3 bf16 pieces each, the piece pairs above 2^-25 of the product (6 of 9; exact), fp32 accumulate")
+            arithmetic="fp32 operands as 3 bf16 pieces each; 6 of the 9 piece pairs are multiplied (the 3 dropped ones are below "
+                       "2^-25 of the product: fp32-rounding accuracy, not exact; byte-valued frame rows: 1 piece, all pairs), fp32 "
+                       "accumulate; tests/test_gpu_ops.py bounds the error against float64 on cancelling inputs")
     return roofline
 
 

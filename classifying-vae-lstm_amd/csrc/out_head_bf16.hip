@@ -1,4 +1,5 @@
-// out_head_bf16.hip -- the output head of cl_vrnn in training on the bf16 matrix cores with exact products (gfx950):
+// out_head_bf16.hip -- the output head of cl_vrnn in training on the bf16 matrix cores, fp32 operands as bf16 pieces with 6 of
+// the 9 piece pairs per product (relative error <= 2^-24 of a product: fp32-rounding accuracy, not exact) (gfx950):
 // forward, loss and all three backward products of out_head.hip, every wave on its own 16 rows from start to end.
 //
 // Reference: X_decoded_mean = TimeDistributed(Dense(88, sigmoid)) on the decoder LSTM states (cl_vrnn/model.py:229-234),

@@ -587,7 +587,7 @@ class VrnnEngine(_EngineBase):
         # the fused head also stores the logits (tests and callers of loss_and_grads read them); a replayed training step has
         # no reader for them, so TrainStep(use_graph=True) turns the store off: 11.5 MB per step at configuration 3, 92 MB at 5
         self.keep_logits = bool(cfg.get('keep_logits', True))
-        # LSTM kernel gradients as split-bf16 exact products (csrc/wgrad_bf16.hip) instead of the f32 MFMA GEMM;
+        # LSTM kernel gradients as split-bf16 products (6 of 9 piece pairs, <= 2^-25 per product: csrc/wgrad_bf16.hip) instead of the f32 MFMA GEMM;
         # frames_exact_bf16: every staged frame value is exactly a bf16 number (TrainStep sets it when the data set is
         # kept as uint8), which lets the frame rows use one bf16 piece instead of three
         self.bf16_wgrad = bool(cfg.get('bf16_wgrad', os.environ.get('CLV_BF16_WGRAD', '1') != '0'))

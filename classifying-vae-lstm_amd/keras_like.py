@@ -289,40 +289,48 @@ class Model:
         for c in cbs:
             c.on_train_begin({})
         idx_dev = torch.zeros(n, dtype=torch.int64, device=dev)
-        for epoch in range(initial_epoch, epochs):
-            for c in cbs:
-                c.on_epoch_begin(epoch, {})
-            ts = self._train_step()
-            index = np.arange(n)
-            if shuffle:
-                np.random.shuffle(index)                        # global np.random state, like Keras (A.4)
-            idx_dev.copy_(torch.from_numpy(index))
-            if world > 1:
-                dist.broadcast(idx_dev, src=0)                  # every rank walks rank 0's permutation
-            self._acc.zero_()
-            if ts._bound is None or ts._bound['cur'] is not d_cur:
-                # the epoch's batches are assembled by the step itself, from the device step counter: batch j of an epoch
-                # = rows idx_dev[j * GB + rank * B ..] (the permutation is rewritten in place per epoch)
-                ts.bind_batches(d_cur, d_hist, d_w, idx=idx_dev, period=n // GB, stride=GB, offset=rank * B, d_target=d_tgt)
-                ts.loss_acc = self._acc
-            if world > 1 and ts.dp_trials is None and ts.ar is not None:
-                # once per fit: which weight-gradient grid is faster next to the real all-reduce on this node (timed on
-                # the first batch; parameters, optimizer state and the epoch's loss sums are restored)
-                ts.dp_trials = ts.tune_dp_schedule() or {}
+        try:
+            for epoch in range(initial_epoch, epochs):
+                for c in cbs:
+                    c.on_epoch_begin(epoch, {})
+                ts = self._train_step()
+                index = np.arange(n)
+                if shuffle:
+                    np.random.shuffle(index)                        # global np.random state, like Keras (A.4)
+                idx_dev.copy_(torch.from_numpy(index))
+                if world > 1:
+                    dist.broadcast(idx_dev, src=0)                  # every rank walks rank 0's permutation
                 self._acc.zero_()
-            for b0 in range(0, n, GB):
-                ts.step()
-            if world > 1:
-                dist.all_reduce(self._acc)                      # once per epoch (sum over ranks of per-batch means)
-            logs = self._logs_from(self._acc, (n // GB) * world)
-            if val is not None:
-                logs.update(self.evaluate_device(*val, prefix='val_'))
-            if verbose and rank == 0:
-                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
-            for c in cbs:
-                c.on_epoch_end(epoch, logs)
-            if self.stop_training:
-                break
+                if ts._bound is None or ts._bound['cur'] is not d_cur:
+                    # the epoch's batches are assembled by the step itself, from the device step counter: batch j of an epoch
+                    # = rows idx_dev[j * GB + rank * B ..] (the permutation is rewritten in place per epoch)
+                    ts.bind_batches(d_cur, d_hist, d_w, idx=idx_dev, period=n // GB, stride=GB, offset=rank * B, d_target=d_tgt)
+                    ts.loss_acc = self._acc
+                if world > 1 and ts.dp_trials is None and ts.ar is not None:
+                    # once per fit: which weight-gradient grid is faster next to the real all-reduce on this node (timed on
+                    # the first batch; parameters, optimizer state and the epoch's loss sums are restored)
+                    ts.dp_trials = ts.tune_dp_schedule() or {}
+                    self._acc.zero_()
+                for b0 in range(0, n, GB):
+                    ts.step()
+                if world > 1:
+                    dist.all_reduce(self._acc)                      # once per epoch (sum over ranks of per-batch means)
+                logs = self._logs_from(self._acc, (n // GB) * world)
+                if val is not None:
+                    logs.update(self.evaluate_device(*val, prefix='val_'))
+                if verbose and rank == 0:
+                    print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+                for c in cbs:
+                    c.on_epoch_end(epoch, logs)
+                if self.stop_training:
+                    break
+        finally:
+            # the step stays bound to THIS data set only while fit() runs: a later stage_batch() / gather_batch() + step()
+            # must train on what it staged (not on the bound cursor), the epoch sums must not collect other callers' steps,
+            # and the device copies of the data set are released with fit()'s locals instead of living on in the step
+            if self._step is not None:
+                self._step.unbind_batches()
+                self._step.loss_acc = None
         for c in cbs:
             c.on_train_end({})
         return self.history

@@ -140,7 +140,8 @@ def lstm_wgrad_supported(N, nx, nh, nz, x_exact_bf16):
 
 def lstm_wgrad(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dKx, dU, dKz, ws, defer=None, beta=0.0,
                split_scale=1):
-    """All kernel gradients of one LSTM in one pass over dz (split-bf16 exact products, csrc/wgrad_bf16.hip):
+    """All kernel gradients of one LSTM in one pass over dz (split-bf16 products, 6 of the 9 piece pairs: fp32-rounding
+    accuracy; csrc/wgrad_bf16.hip):
     dKx = X^T dz, dU = H'^T dz (H' = hs shifted by one step, zero at window starts: period T), dKz = Z^T dz.
     split_scale: that many times as many, shorter row ranges (2 under the data-parallel step: see include/clvae.h)."""
     L = _lib.lib()

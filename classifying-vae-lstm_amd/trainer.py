@@ -38,8 +38,10 @@ class TrainStep:
         self.b2 = 0.9 if optimizer == 'rmsprop' else 0.999                       # rmsprop: rho
         self.lr = lr
         self.use_graph = use_graph
-        if use_graph and hasattr(engine, 'keep_logits') and 'keep_logits' not in engine.cfg:
-            engine.keep_logits = False       # nothing reads the logits of a replayed training step (VrnnEngine.keep_logits)
+        # nothing reads the logits of a replayed training step (VrnnEngine.keep_logits): the store is switched off AROUND this
+        # step's own passes (_main), never on the shared engine for good -- a direct loss_and_grads() call, a tool or a second
+        # TrainStep(use_graph=False) on the same engine keep finding fresh logits
+        self._drop_logits = bool(use_graph and hasattr(engine, 'keep_logits') and 'keep_logits' not in engine.cfg)
         self.fast_adam = bool(fast_adam) and os.environ.get('CLV_FAST_ADAM', '1') != '0'      # see _update()
         cfg, B, d = engine.cfg, engine.B, engine.device
         self.is_vrnn = 'T' in cfg
@@ -198,6 +200,15 @@ class TrainStep:
                                self.X, self.Xp if need_hist else None, hist_chunk, hist_ld, b['w'], self.w_true)
 
     def _main(self):
+        if not self._drop_logits:
+            return self._main_pass()
+        keep, self.eng.keep_logits = self.eng.keep_logits, False
+        try:
+            return self._main_pass()
+        finally:
+            self.eng.keep_logits = keep
+
+    def _main_pass(self):
         if self._bound is not None:
             st = self._label_stage()
             if st is None:

@@ -57,7 +57,7 @@ def test_cl_vrnn_train_cli_on_jsb_all_tracks_an_oracle_loop(tmp_path, capsys):
     nb, nvb = 10400 // B, 3000 // B
     assert eng.fuse_pair and eng.label_in_pair and int(eng.P.iterations.item()) == E * nb
     ts = model._step
-    assert ts.use_graph and ts._graphs is not None and eng.frames_exact_bf16      # graph replay on byte frames
+    assert ts.use_graph and ts._bound is None and eng.frames_exact_bf16      # graph replay on byte frames; fit() left the step unbound
 
     # ---- the same run on the oracle ------------------------------------------------------------------------------------
     P = PianoData(path, batch_size=B, seq_length=T, step_length=1, return_y_next=True, return_y_hist=True, squeeze_x=False,

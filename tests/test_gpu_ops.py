@@ -719,6 +719,16 @@ def test_out_head_train_matches_numpy(dev, R, defer, store):
     np.testing.assert_allclose(N(dhs), dlr @ Wo.astype(np.float64).T, rtol=1e-4, atol=3e-5 * scale * 100)
     np.testing.assert_allclose(N(dWo), hs.astype(np.float64).T @ dlr, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(N(dbo), dlr.sum(0), rtol=1e-4, atol=2e-5)
+    if store:
+        # The weight-gradient PRODUCT alone: hs^T . dl with the device's own dl (fp32; sigmoid(l) - y cancels in fp32 where it
+        # must, like in Keras) taken as exact input -- 6 of 9 bf16 piece pairs per product (csrc/out_head_bf16.hip: what is
+        # dropped is <= 2^-24 of a product) plus the fp32 accumulation over the R rows, per entry against the sum of the
+        # magnitudes of its products.  A single bf16 piece would be off by 2^-9.
+        dl_dev = N(dl)
+        ref = hs.astype(np.float64).T @ dl_dev
+        mag = np.abs(hs.astype(np.float64)).T @ np.abs(dl_dev) + 1e-300
+        err = (np.abs(N(dWo) - ref) / mag).max()
+        assert err <= 2.0 ** -23 + np.sqrt(R) * 2.0 ** -24, (err, R)
 
 
 def test_sparse_proj2_matches_two_single_launches(dev):
@@ -794,6 +804,38 @@ def test_lstm_wgrad_split_bf16_matches_fp64(dev, K, Tn, nz, exact, defer, nh):
         # fp32 accumulation over K terms of piece products that are exact; an h / z row's product leaves out the piece pairs
         # below 2^-25 of it (csrc/wgrad_bf16.hip, WB_PRODUCTS): less than the rounding of one fp32 multiply
         assert err.max() < 2e-6, err.max()
+
+
+@pytest.mark.parametrize("K", [64, 4096])
+def test_six_of_nine_piece_pairs_stay_within_fp32_rounding_on_cancelling_inputs(dev, K):
+    """The h / z / non-byte x rows of clv_lstm_wgrad multiply 6 of the 9 bf16 piece pairs of an fp32 x fp32 product
+    (csrc/wgrad_bf16.hip: what is dropped is <= 2^-25 |a.b| per product).  Inputs that CANCEL -- consecutive rows of dz are
+    (v, -v (1 + 2^-12)), every value with a full 24-bit mantissa, so the exact sums are ~2^-12 of the sum of magnitudes --
+    against float64: the error stays below an explicit multiple of the sum of |a.b| (truncation 2^-25 + fp32 accumulation),
+    i.e. it is an fp32 GEMM's error, not a bf16 one (one bf16 piece alone would be off by 2^-9)."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(K)
+    N, nx, nh, Tn = 352, 88, 88, K                       # one window: H' is hs shifted by one row
+    X = rng.standard_normal((K, nx)).astype(np.float32)  # not byte-valued: three pieces, 6 pairs
+    hs = np.repeat(np.tanh(rng.standard_normal((K // 2, nh))), 2, axis=0).astype(np.float32)
+    X[1::2] = X[0::2]                                    # pairs of equal rows on the A side ...
+    v = rng.standard_normal((K // 2, N))
+    dz = np.empty((K, N), np.float32)
+    dz[0::2], dz[1::2] = v, -v * (1 + 2.0 ** -12)        # ... times (v, -v(1 + 2^-12)) on the B side
+    Hs = np.zeros_like(hs)
+    Hs[1:] = hs[:-1]
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    gx, gu = torch.zeros(nx, N, device=dev), torch.zeros(nh, N, device=dev)
+    ops.lstm_wgrad(K, N, d(X), nx, nx, False, d(hs), nh, nh, Tn, None, 0, 0, d(dz), gx, gu, None, ops.Workspace(dev))
+    torch.cuda.synchronize()
+    f8 = lambda a: a.astype(np.float64)
+    bound = 2.0 ** -25 + np.sqrt(K) * 2.0 ** -24         # dropped pairs + a random-walk fp32 accumulation over K terms
+    for name, got, A in (("dKx", gx, X), ("dU", gu, Hs)):
+        ref, mag = f8(A).T @ f8(dz), np.abs(f8(A)).T @ np.abs(f8(dz))
+        err = (np.abs(got.cpu().numpy() - ref) / mag).max()
+        print("K=%d %s: max |err| / sum|a.b| = %.2e (bound %.2e; cancellation: |sum| / sum|a.b| = %.1e)"
+              % (K, name, err, bound, np.abs(ref).max() / mag.max()))
+        assert err <= bound, (name, err, bound)
 
 
 @pytest.mark.parametrize("K,Tn,nz,exact,defer,scale", [(32768, 128, 2, True, True, 1),      # configuration 3: 16 stages per workgroup
