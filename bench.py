@@ -49,7 +49,7 @@ WORKLOADS = {
 }
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (never the 2:1-sparsity figure)
-PROFILE_TAGS = ('r04_f', 'r04_e', 'r04_d', 'r04_c', 'r04_b', 'r04_a', 'r03_f')      # committed profile sets (profiles/<tag>_*), newest first
+PROFILE_TAGS = ('r05_f', 'r05_e', 'r05_d', 'r05_c', 'r05_b', 'r05_a', 'r04_f', 'r04_e', 'r04_d', 'r04_c', 'r04_b', 'r04_a', 'r03_f')      # committed profile sets (profiles/<tag>_*), newest first
 NOTE_DENSITY = 0.0443        # measured JSB note density
 
 
@@ -137,6 +137,109 @@ def cpu_baseline(w, seconds=20.0):
                        "(Keras-equivalent math, torch-CPU fp32, per-timestep LSTM loop), not Keras; %s, os.cpu_count() "
                        "= %d, torch.get_num_threads() = %d"
                        % (r['steps'], B, T, cpu_model_name(), os.cpu_count(), torch.get_num_threads()))
+
+
+# ---- HBM traffic of the step, measured: rocprofv3 PMC passes over a short eager run of this script -----------------------
+DOMINANT_RE = r'lstm_(pair_|mx_)?(fwd|bwd)(_mfma)?_kernel|vae_fused'      # the kernels the roofline object times
+
+
+def aggregate_pmc(workload, fetch_csv, write_csv, steps_fallback=9):
+    """Two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> HBM bytes per kernel launch and per step, with the gfx950
+    corrections of MI355X_MICROARCH.md: both counters are in KB (x 1024); FETCH_SIZE reports half of the bytes read (x 2)."""
+    import collections
+    import csv
+    import re
+
+    def per_kernel(path, counter):
+        disp, name = collections.defaultdict(float), {}
+        for r in csv.DictReader(open(path)):
+            if r['Counter_Name'] != counter:
+                continue
+            disp[r['Dispatch_Id']] += float(r['Counter_Value'])
+            name[r['Dispatch_Id']] = r['Kernel_Name']
+        agg = collections.defaultdict(list)
+        for d, v in disp.items():
+            agg[name[d]].append(v)
+        return agg
+
+    f, w = per_kernel(fetch_csv, 'FETCH_SIZE'), per_kernel(write_csv, 'WRITE_SIZE')
+    rows = []
+    for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) * 2 + sum(w.get(k, [0])))):
+        fk, wk = f.get(k, [0.0]), w.get(k, [0.0])
+        short = re.sub(r'^void ', '', k).replace('clv::', '')
+        rows.append(dict(kernel=short[:120], launches=len(fk), fetch_size_kb_avg=sum(fk) / len(fk),
+                         write_size_kb_avg=sum(wk) / len(wk), hbm_read_bytes_corrected=2 * 1024 * sum(fk) / len(fk),
+                         hbm_write_bytes=1024 * sum(wk) / len(wk)))
+    dom = [r for r in rows if re.match(DOMINANT_RE, r['kernel'])]
+    per_launch = sum(r['hbm_read_bytes_corrected'] + r['hbm_write_bytes'] for r in dom) / max(len(dom), 1)
+    # steps the profiled run executed (set-up + warm-up + timed): the launch count of a kernel that runs once per LSTM pass
+    per_step = {'lstm_pair_fwd_kernel': 1, 'lstm_mx_fwd_kernel': 2, 'lstm_fwd_mfma_kernel': 2, 'vae_fused_kernel': 1}
+    steps = None
+    for r in rows:
+        for key, n in per_step.items():
+            if steps is None and r['kernel'].startswith(key):
+                steps = sum(x['launches'] for x in rows if x['kernel'].startswith(key)) // n
+    steps = steps or steps_fallback
+    step_bytes = sum((r['hbm_read_bytes_corrected'] + r['hbm_write_bytes']) * r['launches'] for r in rows) / steps
+    return dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --no-graph); FETCH_SIZE x2 "
+                     "(gfx950 reports half of the bytes read), both KB -> bytes x1024 (MI355X_MICROARCH.md)",
+                workload=workload, dominant_kernels=[r['kernel'] for r in dom], dominant_bytes_per_launch=per_launch,
+                step_bytes=step_bytes, steps_profiled=steps, kernels=rows)
+
+
+def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
+    """The two PMC passes as CHILD processes of this one -- `rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py
+    --workload W --steps 6 --warmup 3 --no-graph ...` -- started before this process has touched the GPU (nothing is exec'd
+    over a GPU-initialised process; the program after `--` is python3 itself; a PMC pass carries no other trace domain).
+    Returns aggregate_pmc()'s dict, or {'error': ...}: the caller then falls back to the committed summary."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rp):
+        return dict(error="rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix='clv_pmc_')
+    try:
+        csvs = {}
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, '--pmc', counter, '--kernel-trace', '-d', out, '-o', 't', '--output-format', 'csv', '--',
+                   sys.executable, os.path.abspath(__file__), '--workload', workload, '--steps', '6', '--warmup', '3',
+                   '--no-cpu-baseline', '--no-roofline', '--no-graph', '--no-also', '--no-pmc-traffic'] + (['--bf16'] if bf16 else [])
+            env = dict(os.environ, TMPDIR='/tmp')
+            pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  start_new_session=True)
+            try:
+                so, se = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.communicate()
+                return dict(error="the %s pass passed %d s and was killed" % (counter, timeout_s))
+            found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('counter_collection.csv')]
+            if pr.returncode != 0 or not found:
+                return dict(error="the %s pass ended with code %s; stderr tail: %s" % (counter, pr.returncode, se[-200:]))
+            csvs[counter] = found[0]
+        return aggregate_pmc(workload, csvs['FETCH_SIZE'], csvs['WRITE_SIZE'])
+    except Exception as ex:      # noqa: BLE001 -- a measurement extra must never cost the run
+        return dict(error=repr(ex)[:200])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def sources_sha16():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/clvae.h) of THIS tree: a committed PMC summary carries the
+    value of the tree it was measured on (tools/round_profile.sh), so a stale one shows."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'classifying-vae-lstm_amd', 'csrc', '*.h*')) + [os.path.join(ROOT, 'include', 'clvae.h')]):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def bench_generate(args, w, dev, rank, world):
@@ -359,7 +462,7 @@ def kernel_time_pass(eng, ts_args, batch, reps, label_off=False):
     return recs
 
 
-def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_gpu, bf16, kernel_times=False):
+def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_gpu, bf16, kernel_times=False, pmc=None):
     B = w['B']
     pair_ms = [r[2] / max(r[1], 1) for r in recs if r[0] == 'event_pair']
     event_pair_us = 1e3 * pair_ms[0] if pair_ms else 0.0
@@ -397,23 +500,41 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
         ms = ms_raw - n * event_pair_us * 1e-3
         avg_s = ms / n * 1e-3
         achieved = (flop_per_timestep(w) * B / (n / reps)) / avg_s / 1e12
-    # HBM bytes: NOT measured in this run -- read from the newest committed PMC summary of the SAME workload
-    # (tools/round_profile.sh -> profiles/<tag>_pmc_traffic_<workload>.json; separate --pmc passes, the guide's gfx950
-    # corrections); the JSON names the file, and carries null when none matches
-    traffic = step_traffic = traffic_source = None
+    # HBM bytes per launch of the dominant kernels and per step: MEASURED in this run when main() made the two PMC passes
+    # (measure_pmc_traffic: the default single-GPU run does), else read from the newest committed PMC summary of the SAME
+    # workload (tools/round_profile.sh -> profiles/<tag>_pmc_traffic_<workload>.json).  Either way the summary's dominant
+    # kernels must be the kernels this run just timed (same names, as many instances), or `traffic` stays null; a
+    # committed summary also says whether it was measured on this tree's kernel sources (`traffic_sources_match`).
+    import re
+    traffic = step_traffic = traffic_source = traffic_match = traffic_problem = None
+    measured = bool(pmc is not None and 'error' not in pmc)
     wl_tag = wl_name + ('_bf16' if bf16 else '')
+
+    def names_agree(pm):
+        timed = sorted(kname.split('+'))                                         # e.g. lstm_pair_bwd, lstm_pair_fwd
+        prof = sorted(set(re.sub(r'_kernel.*', '', k) for k in pm.get('dominant_kernels', [])))
+        if w['model'] != 'cl_vrnn':
+            return any(k.startswith('vae_fused') for k in pm.get('dominant_kernels', [])) == (kname == 'vae_fused_step')
+        return timed == prof
+
+    cands = [('measured in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child passes of bench.py --no-graph)', pmc)] if measured else []
     for tag in PROFILE_TAGS:
         path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (tag, wl_tag))
         try:
-            pm = json.load(open(path))
+            cands.append((os.path.relpath(path, ROOT), json.load(open(path))))
         except Exception:
             continue
+    for src, pm in cands:
         if pm.get('workload') != wl_name:
+            continue
+        if not names_agree(pm):
+            traffic_problem = "%s: its dominant kernels %s are not the kernels timed here (%s)" % (src, pm.get('dominant_kernels'), kname)
             continue
         if w['model'] == 'cl_vrnn':
             traffic = round(pm.get('dominant_bytes_per_launch', pm.get('lstm_seq_bytes_per_launch')))
         step_traffic = pm.get('step_bytes')
-        traffic_source = os.path.relpath(path, ROOT)
+        traffic_source = src
+        traffic_match = True if pm is pmc else (pm.get('sources_sha16') == sources_sha16() if 'sources_sha16' in pm else None)
         break
     roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=kname,
@@ -426,7 +547,9 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
                     algorithmic_step_frac_is="whole-step ALGORITHMIC flop rate (SURVEY.md 8d: dense-equivalent GEMM flops, which the "
                                              "sparse input kernels never execute) / the fp32 peak: a throughput figure, not a utilisation",
                     step_traffic=step_traffic, traffic_source=traffic_source,
-                    traffic_measured_in_this_run=False,
+                    traffic_measured_in_this_run=bool(measured and traffic_source is not None and traffic_source.startswith('measured')),
+                    traffic_sources_match=traffic_match, traffic_rejected=traffic_problem,
+                    traffic_pass_error=(pmc or {}).get('error') if pmc is not None else None,
                     kernel_time_pass="%d eager steps with HIP events around every launch, after the graph capture and before the warm-up" % reps)
     if w['model'] == 'cl_vrnn':
         if getattr(eng, 'use_mx', False):
@@ -489,7 +612,7 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
     return roofline
 
 
-def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, reps=40, want_roofline=True):
+def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, reps=40, want_roofline=True, pmc=None):
     """One training workload: engine, synthetic windows resident in HBM, set-up (graph capture + the kernel-time pass),
     warm-up, the timed blocks.  Returns the pieces of the JSON line."""
     import torch
@@ -551,7 +674,7 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
     roofline = None
     if recs is not None:
         roofline = roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value / world, bf16,
-                                   kernel_times=args.kernel_times)
+                                   kernel_times=args.kernel_times, pmc=pmc)
     return dict(w=w, eng=eng, ts=ts, value=value, dt=dt, block_ms=block_ms, rank_ms=rank_ms, allreduce=allreduce, loss=loss,
                 roofline=roofline, host_us=round(host_us, 1))
 
@@ -644,6 +767,9 @@ def main():
     ap.add_argument('--no-also', action='store_true', help='skip the `also` list (the other workloads after a default cfg3 run)')
     ap.add_argument('--kernel-times', action='store_true', help='print per-kernel event times to stderr')
     ap.add_argument('--selftest-launch', action='store_true', help='launcher / rendezvous check on CPU (gloo), no timing')
+    ap.add_argument('--no-pmc-traffic', action='store_true',
+                    help='do not measure roofline.traffic with two rocprofv3 PMC child passes (a default single-GPU training run does); '
+                         'the committed summary under profiles/ is read instead')
     ap.add_argument('--also-only', action='store_true', help='print only the `also` list (what a default run starts as its child)')
     args = ap.parse_args()
 
@@ -651,6 +777,16 @@ def main():
         sys.exit(self_launch(args.gpus))
     if args.selftest_launch:
         return launch_selftest(args)
+
+    # roofline.traffic, measured: two PMC passes over a short eager run, as child processes, BEFORE this process touches the GPU
+    pmc = None
+    w0 = WORKLOADS[args.workload]
+    profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith('ROCPROF') for k in os.environ)
+    if (args.gpus == 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_pmc_traffic and not args.no_roofline
+            and not args.also_only and not w0.get('generate') and not args.no_graph and not profiled):
+        t0 = time.perf_counter()
+        pmc = measure_pmc_traffic(args.workload, bf16=args.bf16)
+        print("pmc traffic passes: %.1f s%s" % (time.perf_counter() - t0, "; " + pmc['error'] if 'error' in pmc else ""), file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -678,7 +814,7 @@ def main():
             print(json.dumps(g))
         return
     m = measure_train(args, args.workload, dev, rank, world, args.steps, args.warmup, bf16=args.bf16,
-                      want_roofline=not args.no_roofline)
+                      want_roofline=not args.no_roofline, pmc=pmc)
     eng, ts = m['eng'], m['ts']
 
     cpu = None
