@@ -569,7 +569,7 @@ class VrnnEngine(_EngineBase):
         self.gate_act = _lib.GATE_HARD_SIGMOID if cfg.get('gate_act', 'hard_sigmoid') == 'hard_sigmoid' \
             else _lib.GATE_SIGMOID
         self.off = D if cfg['use_x_prev'] else 0     # decoder kernel rows: [Xp | Z | W]
-        self.fuse_xproj = bool(cfg.get('fuse_xproj', False)) and H == 88   # break-even vs the projection GEMM at config 3
+        self.fuse_xproj = bool(cfg.get('fuse_xproj', False)) and H == 88   # break-even vs the projection GEMM at config 3 (PERFLOG.md 8)
         # encoder + latent head + decoder as one launch (csrc/lstm_pair.hip); latent_dim <= 16
         self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj
         # Twice the workgroups, half the K each, for the LSTM weight-gradient products.  They run one 1024-thread
