@@ -823,6 +823,16 @@ __device__ __forceinline__ void pair_bwd_chain(const PairBwdArgs& a, int wave, i
     zsum += val;
     if (!zgroup) dzb[cur ^ 1][lpos] = val;
     buf_store(val, r_g, vo_g, (unsigned)t * (unsigned)(LG * 4));
+    if (PAIR_ABL == 10) {             // timing ablation: what writing dz as three bf16 pieces (for the kernel-gradient product) would add --
+      const __bf16 p0 = (__bf16)val;  // the split and three 2-byte stores (into the aux rows of this step: already consumed)
+      const float r1 = val - (float)p0;
+      const __bf16 p1 = (__bf16)r1;
+      const __bf16 p2 = (__bf16)(r1 - (float)p1);
+      const unsigned vo_p = zgroup ? BUF_OOB : col * 2;
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, p0), r_a, (int)vo_p, (int)((unsigned)t * (unsigned)(2 * LH * 4)), 0);
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, p1), r_a, (int)vo_p, (int)((unsigned)t * (unsigned)(2 * LH * 4)), 0);
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, p2), r_a, (int)vo_p, (int)((unsigned)t * (unsigned)(2 * LH * 4)), 0);
+    }
     if (LATW) {                       // latent lanes turn dZ_{t+1} into dzargs_{t+1}
       const float zv = latent_dz(k, dhrec);
       if (zlive) dza[cur][lpos] = zv;
