@@ -494,8 +494,8 @@ __device__ __forceinline__ void wn_fast_update_body(const AdamFast& f, int unit,
 // row, its columns are (4 t) % cols ..+3).  The per-column sums of V'^2 go through an LDS copy of the tile's squares.
 __device__ __forceinline__ void wn_fast_update_body_flat(const AdamFast& f, int unit, float* params, const float* grads, float* m,
                                                          float* v, float* mg, float* vg, const float* s, const AdamHyper& h) {
-  __shared__ float cs[3][128];
-  __shared__ float sq[FAST_ROWS * 128];          // V'^2 of the tile, [row][col]; then [8][cols] partial column sums at its front
+  __shared__ __attribute__((aligned(16))) float cs[3][128];
+  __shared__ __attribute__((aligned(16))) float sq[FAST_ROWS * 128];          // V'^2 of the tile, [row][col]; then [8][cols] partial column sums at its front
   const int tid = threadIdx.x;
   const float lr_t = adam_lr_t(h);
   for (int c = tid; c < f.cols; c += FAST_NT) {
@@ -534,11 +534,16 @@ __device__ __forceinline__ void wn_fast_update_body_flat(const AdamFast& f, int 
       const int c0 = (4 * i) % f.cols;
       const float pin[4] = {pv[k].x, pv[k].y, pv[k].z, pv[k].w}, gin[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
       const float min_[4] = {mv[k].x, mv[k].y, mv[k].z, mv[k].w}, vin[4] = {vv[k].x, vv[k].y, vv[k].z, vv[k].w};
+      // the four columns' scalars as three 16-byte LDS reads (c0 is a multiple of 4): twelve 4-byte reads at a lane stride of
+      // 4 floats put lanes l and l + 16 on one bank (SQ counters, round 4: half of this kernel's LDS cycles were conflicts)
+      const float4 c_is = *reinterpret_cast<const float4*>(&cs[0][c0]), c_gg = *reinterpret_cast<const float4*>(&cs[1][c0]),
+                   c_sc = *reinterpret_cast<const float4*>(&cs[2][c0]);
+      const float is4[4] = {c_is.x, c_is.y, c_is.z, c_is.w}, gg4[4] = {c_gg.x, c_gg.y, c_gg.z, c_gg.w}, sc4[4] = {c_sc.x, c_sc.y, c_sc.z, c_sc.w};
       float po[4], mo[4], vo[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float V = pin[c] * cs[0][c0 + c];
-        const float gV = cs[2][c0 + c] * (gin[c] - cs[1][c0 + c] * V);
+        const float V = pin[c] * is4[c];
+        const float gV = sc4[c] * (gin[c] - gg4[c] * V);
         mo[c] = h.b1 * min_[c] + (1.f - h.b1) * gV;
         vo[c] = h.b2 * vin[c] + (1.f - h.b2) * gV * gV;
         po[c] = V - lr_t * mo[c] / (sqrtf(vo[c]) + h.eps);
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(FAST_NT) void wn_fast_update_kernel(AdamFast f, con
 }
 
 __global__ __launch_bounds__(FAST_NT) void wn_fast_rescale_kernel(AdamFast f, float* params, float* s, int32_t* iterations) {
-  __shared__ float2 red[16][64], snew[64];
+  __shared__ __attribute__((aligned(16))) float2 red[16][64], snew[64];
   const int tid = threadIdx.x, cx = tid & 63, ry = tid >> 6, unit = blockIdx.x, n2 = f.cols / 2;
   if (unit == 0 && tid == 0 && iterations) *iterations += 1;
 #if CLV_ADAM_FLAT
@@ -627,8 +632,8 @@ __global__ __launch_bounds__(FAST_NT) void wn_fast_rescale_kernel(AdamFast f, fl
       const int i = tid + FAST_NT * k;
       if (i < fn4) {
         const int c0 = (4 * i) % f.cols;
-        *reinterpret_cast<float4*>(ftile + 4 * (size_t)i) =
-            make_float4(fpv[k].x * sf[c0], fpv[k].y * sf[c0 + 1], fpv[k].z * sf[c0 + 2], fpv[k].w * sf[c0 + 3]);
+        const float4 sn4 = *reinterpret_cast<const float4*>(sf + c0);      // one 16-byte read (see wn_fast_update_body_flat)
+        *reinterpret_cast<float4*>(ftile + 4 * (size_t)i) = make_float4(fpv[k].x * sn4.x, fpv[k].y * sn4.y, fpv[k].z * sn4.z, fpv[k].w * sn4.w);
       }
     }
     return;
