@@ -155,6 +155,59 @@ def test_lstm_seq_fwd_bwd(dev, B, Tn, gate):
     np.testing.assert_allclose(N(dzsum), dz.sum(1), atol=1e-4)
 
 
+@pytest.mark.parametrize("H,B,Tn,gate", [(1, 3, 4, 0), (7, 2, 5, 1), (32, 5, 9, 0), (50, 4, 3, 1), (64, 3, 16, 0), (100, 2, 6, 0),
+                                         (128, 3, 8, 1), (257, 2, 3, 0), (600, 1, 2, 0), (1024, 1, 2, 1), (88, 4, 6, 0)])
+def test_lstm_seq_fwd_bwd_at_any_width(dev, monkeypatch, H, B, Tn, gate):
+    """clv_lstm_seq_fwd / _bwd for H != 88 (csrc/lstm_any.hip; H == 88: the same kernels forced by CLV_LSTM_ANY=1): states,
+    stored gates, final state, dz and its column sums against the oracle's LSTM (cl_vrnn/model.py:196-199 under K.rnn /
+    K.gradients); 1, 2, 4, 8 k-slices per unit, widths beyond the 256 threads (two and four units per owner thread), an
+    initial state; then the stateful single-step form of sampling (T = 1, no cell / gate buffers, state in and out)."""
+    from clvae_amd import ops
+    if H == 88:
+        monkeypatch.setenv("CLV_LSTM_ANY", "1")
+    rng = np.random.default_rng(H * 31 + Tn)
+    U = (O.orthogonal(rng, (H, 4 * H), np.float64) if H > 1 else rng.standard_normal((1, 4))) * 1.5
+    xproj = rng.standard_normal((B, Tn, 4 * H)) * 1.5
+    rb = rng.standard_normal((B, 4 * H)) * 0.3
+    h0, c0 = rng.standard_normal((B, H)) * 0.5, rng.standard_normal((B, H)) * 0.5
+    act = 'hard_sigmoid' if gate == 0 else 'sigmoid'
+    hs_ref, cache = O.lstm_forward(xproj + rb[:, None, :], np.eye(4 * H), U, np.zeros(4 * H), h0=h0, c0=c0, gate_act=act)
+    dHs = rng.standard_normal((B, Tn, H))
+    _, _, _, _, dZ_ref = O.lstm_backward(dHs, cache, np.eye(4 * H), U)
+    gates = T(xproj, dev)
+    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
+    hT = torch.empty(B, H, device=dev); cT = torch.empty(B, H, device=dev)
+    Ud = T(U, dev)
+    ops.lstm_seq_fwd(B, Tn, gates, T(rb, dev), Ud, hs, cs, gates, h0=T(h0, dev), c0=T(c0, dev), hT=hT, cT=cT,
+                     gate_act=gate, H=H)
+    torch.cuda.synchronize()
+    tol = 3e-6 * max(1.0, np.sqrt(H / 88))
+    np.testing.assert_allclose(N(hs), hs_ref, atol=tol)
+    np.testing.assert_allclose(N(cs), cache['C'], atol=2 * tol)
+    np.testing.assert_allclose(N(hT), hs_ref[:, -1], atol=tol)
+    np.testing.assert_allclose(N(cT), cache['C'][:, -1], atol=2 * tol)
+    g = N(gates).reshape(B, Tn, 4, H)
+    Zr = cache['Z'].reshape(B, Tn, 4, H)
+    for k in (0, 1, 3):
+        np.testing.assert_allclose(g[:, :, k], Zr[:, :, k], atol=4 * tol)
+    np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=tol)
+    dzsum = torch.empty(B, 4 * H, device=dev)
+    ops.lstm_seq_bwd(B, Tn, Ud, T(dHs, dev), cs, gates, dzsum, c0=T(c0, dev), gate_act=gate, H=H)
+    torch.cuda.synchronize()
+    dz = N(gates).reshape(B, Tn, 4 * H)
+    bad = np.abs(dz - dZ_ref) > 2e-5 * (1 + np.abs(dZ_ref)) * max(1.0, np.sqrt(H / 88))     # hard-sigmoid kinks: see above
+    assert bad.mean() < 2e-4, bad.mean()
+    np.testing.assert_allclose(N(dzsum), dz.sum(1), atol=1e-4)
+    # one stateful step (cl_vrnn/model.py:122-125: the batch-1 step models of sample.py): h, c in and out, nothing else stored
+    st_h, st_c = T(h0, dev), T(c0, dev)
+    out = torch.empty(B, H, device=dev)
+    ops.lstm_seq_fwd(B, 1, T(xproj[:, 0] + rb, dev), None, Ud, out, None, None, h0=st_h, c0=st_c, hT=st_h, cT=st_c, gate_act=gate, H=H)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(N(out), hs_ref[:, 0], atol=tol)
+    np.testing.assert_allclose(N(st_h), hs_ref[:, 0], atol=tol)
+    np.testing.assert_allclose(N(st_c), cache['C'][:, 0], atol=2 * tol)
+
+
 @pytest.mark.parametrize("B,Tn,gate", [(1027, 7, 0), (768, 3, 1), (2050, 2, 0), (769, 1, 0)])
 def test_lstm_seq_fwd_large_batch_runs_on_the_matrix_cores(dev, B, Tn, gate):
     """From 768 rows on, a training forward from zero state takes csrc/lstm_mfma.hip (four rows per workgroup, the
