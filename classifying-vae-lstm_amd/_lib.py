@@ -223,6 +223,7 @@ SIGNATURES = {
     "clv_philox_uniform": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
     "clv_i32_add": (_i, [_p, C.c_int32, _p]),
     "clv_bernoulli_sample": (_i, [_i64, _p, _p, _p, _p]),
+    "clv_dropout_rows": (_i, [_i, _i, _i, _p, _i, _p, _i, _f, _f, _p, _i, _p]),
     "clv_graph_begin_capture": (_i, [_p]),
     "clv_graph_end_capture": (_i, [_p, C.POINTER(_p)]),
     "clv_graph_launch": (_i, [_p, _p]),

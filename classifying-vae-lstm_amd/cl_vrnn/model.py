@@ -268,12 +268,13 @@ def make_decoder(model, original_dim, intermediate_dim, latent_dim, n_classes, u
 def get_model(batch_size, original_dim, intermediate_dim, latent_dim, seq_length, n_classes, use_x_prev, optimizer,
               class_weight=1.0, kl_weight=1.0, dropout=0.0, w_kl_weight=1.0, w_log_var_prior=0.0, seed=None,
               device='cuda:0', gate_act='hard_sigmoid'):
-    """-> (model, encoder).  dropout is 0 at every call site of the reference (cl_vrnn/train.py:46)."""
-    if dropout != 0.0:
-        raise ValueError("dropout is never enabled by the reference scripts and is not supported")
+    """-> (model, encoder).  dropout (cl_vrnn/model.py:164,198,227: `LSTM(..., dropout=dropout)` for both LSTMs; 0 at every
+    call site of the reference, cl_vrnn/train.py:46): input dropout in the training steps of fit(), none in validation,
+    predict() and generation (Keras' learning phase); > 0 takes the engine's generic kernel chain (VrnnEngine._forward_dropout)."""
     cfg = dict(D=int(original_dim), H=int(intermediate_dim), L=int(latent_dim), T=int(seq_length), C=int(n_classes),
                use_x_prev=bool(use_x_prev), class_weight=get_value(class_weight), kl_weight=get_value(kl_weight),
-               w_kl_weight=get_value(w_kl_weight), w_log_var_prior=float(w_log_var_prior), gate_act=gate_act)
+               w_kl_weight=get_value(w_kl_weight), w_log_var_prior=float(w_log_var_prior), gate_act=gate_act,
+               dropout=float(dropout))
     eng = VrnnEngine(cfg, batch_size, device)
     eng.P.set_weights(init_weights(eng.P.logical, cfg, seed=seed))
     model = ClVrnnModel(eng, optimizer, kl_weight, w_kl_weight, class_weight, bool(use_x_prev), seed=seed)

@@ -92,7 +92,10 @@ struct TileLoader {
         if (KC) {
           const int mn = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
           const int gm = mn0 + mn, gk = k0 + k4;
-          const float* src = p + (size_t)min(gm, dim_mn - 1) * ld + min(gk, ld - 4);
+          // (the clamp stays inside the operand's OWN k range, rounded up to a float4: an operand may be a column block of a
+          // wider matrix -- pointer offset, ld = the parent's -- whose last row ends the allocation: round 5, a fault at
+          // M = 4, K = 88, lda = 352 on the fourth gate block)
+          const float* src = p + (size_t)min(gm, dim_mn - 1) * ld + min(gk, min(ld - 4, (k_end - 1) & ~3));
           v = *reinterpret_cast<const float4*>(src);
           const bool row = gm < dim_mn;
           ok0 = row && gk + 0 < k_end; ok1 = row && gk + 1 < k_end; ok2 = row && gk + 2 < k_end; ok3 = row && gk + 3 < k_end;
@@ -102,7 +105,7 @@ struct TileLoader {
           const int gk = k0 + k, gm = mn0 + c4;
           const bool row = gk < k_end && !(zperiod > 0 && gk % zperiod == 0);
           const int rk = max(min(gk, k_end - 1) - shift, 0);
-          const float* src = p + (size_t)rk * ld + min(gm, ld - 4);
+          const float* src = p + (size_t)rk * ld + min(gm, min(ld - 4, (dim_mn - 1) & ~3));
           v = *reinterpret_cast<const float4*>(src);
           const int nreal = ones == 2 ? dim_mn - 1 : dim_mn;     // ones == 2: the last row of op(A)^T is implicit ones
           ok0 = row && gm + 0 < nreal; ok1 = row && gm + 1 < nreal; ok2 = row && gm + 2 < nreal; ok3 = row && gm + 3 < nreal;
@@ -188,7 +191,7 @@ struct TileLoader {
       } else {
         constexpr int RV = BMN / 4;
         const int k = idx / RV, c4 = (idx % RV) * 4;
-        it.p[i] = base + (size_t)(k0 + k - shift) * ld + min(mn0 + c4, ld - 4);
+        it.p[i] = base + (size_t)(k0 + k - shift) * ld + min(mn0 + c4, min(ld - 4, (dim_mn - 1) & ~3));
         it.lofs[i] = k * LD + c4;
         it.zr[i] = zperiod > 0 ? (k0 + k) % zperiod : 1;
         const int oc = dim_mn - 1 - (mn0 + c4);

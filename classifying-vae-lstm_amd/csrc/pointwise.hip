@@ -520,6 +520,33 @@ extern "C" int clv_bernoulli_sample(int64_t n, const float* p, const float* u, f
   return launch_status();
 }
 
+namespace clv {
+// out[r, c] = beta * out[r, c] + X[r, c] * m(U[r / T, c]),  m(u) = (u >= rate) / (1 - rate): see clv_dropout_rows
+__global__ __launch_bounds__(256) void dropout_rows_kernel(int64_t total, int T, int n, const float* X, int ldx, const float* U,
+                                                           int ldu, float rate, float inv_keep, float beta, float* out, int ldo) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int64_t r = e / n;
+  const int c = (int)(e - r * n);
+  const float m = U[(r / T) * ldu + c] >= rate ? inv_keep : 0.f;
+  const float v = X[r * ldx + c] * m;
+  float* o = out + r * ldo + c;
+  *o = beta != 0.f ? fmaf(beta, *o, v) : v;
+}
+}  // namespace clv
+
+extern "C" int clv_dropout_rows(int R, int T, int n, const float* X, int ldx, const float* U, int ldu, float rate, float beta,
+                                float* out, int ldo, void* stream) {
+  using namespace clv;
+  if (R <= 0 || T <= 0 || n <= 0 || !X || !U || !out || ldx < n || ldu < n || ldo < n || !(rate >= 0.f && rate < 1.f)) return CLV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope pr("dropout_rows", s);
+  const int64_t total = (int64_t)R * n;
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, T, n, X, ldx, U, ldu, rate,
+                     1.f / (1.f - rate), beta, out, ldo);
+  return launch_status();
+}
+
 extern "C" int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream) {
   if (n <= 0 || !x || !y) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;

@@ -653,6 +653,12 @@ def i32_add(counter, v=1):
     check(_lib.lib().clv_i32_add(_ptr(counter), int(v), _stream()), "clv_i32_add")
 
 
+def dropout_rows(R, T, n, X, ldx, U, ldu, rate, out, ldo, beta=0.0):
+    """out[r, :n] = beta * out + X[r, :n] * mask(U[r // T, :n]), mask(u) = (u >= rate) / (1 - rate) (clv_dropout_rows)."""
+    check(_lib.lib().clv_dropout_rows(R, T, n, _ptr(X), ldx, _ptr(U), ldu, float(rate), float(beta), _ptr(out), ldo, _stream()),
+          "clv_dropout_rows")
+
+
 def bernoulli_sample(n, p, u, x):
     check(_lib.lib().clv_bernoulli_sample(n, _ptr(p), _ptr(u), _ptr(x), _stream()), "clv_bernoulli_sample")
 

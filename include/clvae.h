@@ -808,6 +808,13 @@ int clv_philox_normal2(float* out0, int64_t n0, uint32_t stream_id0, uint64_t fi
 int clv_i32_add(int32_t* counter, int32_t v, void* stream);
 /* x[i] = (u[i] <= p[i]) ? 1 : 0   -- sample_x */
 int clv_bernoulli_sample(int64_t n, const float* p, const float* u, float* x, void* stream);
+/* Input dropout of an LSTM in the training phase (get_model(dropout=p): cl_vrnn/model.py:164,198,227; Keras 2.0.0
+ * recurrent.py, implementation 0: one mask per gate and sample, constant over the time steps, K.dropout(ones, p) =
+ * floor(1 - p + u) / (1 - p)):   out[r, c] = beta * out[r, c] + X[r, c] * m(U[r / T, c]),   m(u) = (u >= rate) / (1 - rate),
+ * r < R, c < n.  U holds UNIFORMS (clv_philox_uniform), one row per sample; T = rows of X per sample.  Forward: X = the
+ * inputs of a gate's projection; backward: X = that gate's share of dL/d(input), beta = 1 sums the four gates. */
+int clv_dropout_rows(int R, int T, int n, const float* X, int ldx, const float* U, int ldu, float rate, float beta,
+                     float* out, int ldo, void* stream);
 
 /* ----------------------------------------------------------------- graphs --
  * thin wrappers so a host without HIP bindings can capture a step once and

@@ -288,18 +288,31 @@ def vae_loss_and_grads(p, cfg, x, xp, w_true, eps_w, eps_z, need_grads=True, tar
 # --------------------------------------------------------------------------- #
 # LSTM (Keras 2.0.0 semantics, Appendix A.2)
 # --------------------------------------------------------------------------- #
-def lstm_forward(xs, kernel, rec, bias, h0=None, c0=None, gate_act='hard_sigmoid'):
+def dropout_masks(u, rate):
+    """Keras' input-dropout masks from uniforms u in [0,1): K.dropout(ones, rate) = tf.nn.dropout(ones, keep) =
+    ones / keep * floor(keep + u), i.e. 1/keep where u >= rate, else 0  [K]."""
+    keep = 1.0 - rate
+    return np.floor(keep + u) / keep
+
+
+def lstm_forward(xs, kernel, rec, bias, h0=None, c0=None, gate_act='hard_sigmoid', in_masks=None):
     """xs [B,T,In] -> hs [B,T,H]; also returns what BPTT needs.
 
     z = x_t.kernel + bias + h_{t-1}.recurrent ; i,f,o = hs(z_*), g = tanh(z_c)
     c_t = f*c_{t-1} + i*g ; h_t = o*tanh(c_t)    (cl_vrnn/model.py:196-199,225-228 + [K] A.2)
+    in_masks [4,B,In] (LSTM(dropout=p) in the training phase, cl_vrnn/model.py:198,227; [K] Keras 2.0.0 recurrent.py,
+    implementation 0: `_time_distributed_dense(x, kernel_g, bias_g, dropout)` draws ONE mask per gate and sample, constant
+    over the time steps, and multiplies the inputs of that gate's projection with it): z_g = (x_t * m_g).kernel_g + ...
     """
     B, T, _ = xs.shape
     H = rec.shape[0]
     act = hard_sigmoid if gate_act == 'hard_sigmoid' else sigmoid
     h = np.zeros((B, H), xs.dtype) if h0 is None else h0
     c = np.zeros((B, H), xs.dtype) if c0 is None else c0
-    xproj = xs @ kernel + bias                       # implementation=0 precompute [K]
+    if in_masks is None:
+        xproj = xs @ kernel + bias                   # implementation=0 precompute [K]
+    else:
+        xproj = np.concatenate([(xs * in_masks[g][:, None, :]) @ kernel[:, g * H:(g + 1) * H] for g in range(4)], axis=-1) + bias
     Z = np.empty((B, T, 4 * H), xs.dtype)
     Cs = np.empty((B, T, H), xs.dtype)
     Hs = np.empty((B, T, H), xs.dtype)
@@ -309,7 +322,7 @@ def lstm_forward(xs, kernel, rec, bias, h0=None, c0=None, gate_act='hard_sigmoid
         c = f * c + i * g
         h = o * np.tanh(c)
         Z[:, t] = z; Cs[:, t] = c; Hs[:, t] = h
-    return Hs, dict(Z=Z, C=Cs, H=Hs, xs=xs, h0=h0, c0=c0, gate_act=gate_act)
+    return Hs, dict(Z=Z, C=Cs, H=Hs, xs=xs, h0=h0, c0=c0, gate_act=gate_act, in_masks=in_masks)
 
 
 def lstm_backward(dHs, cache, kernel, rec):
@@ -340,10 +353,17 @@ def lstm_backward(dHs, cache, kernel, rec):
     h_prev = np.concatenate([np.zeros((B, 1, H), Z.dtype) if cache['h0'] is None else cache['h0'][:, None],
                              Hs[:, :-1]], axis=1)
     dZ2 = dZ.reshape(B * T, 4 * H)
-    dkernel = xs.reshape(B * T, -1).T @ dZ2
     drec = h_prev.reshape(B * T, H).T @ dZ2
     dbias = dZ2.sum(0)
-    dxs = (dZ2 @ kernel.T).reshape(B, T, -1)
+    masks = cache.get('in_masks')
+    if masks is None:
+        dkernel = xs.reshape(B * T, -1).T @ dZ2
+        dxs = (dZ2 @ kernel.T).reshape(B, T, -1)
+    else:                                            # per gate: the masked inputs' products
+        dkernel = np.concatenate([(xs * masks[g][:, None, :]).reshape(B * T, -1).T @ dZ2[:, g * H:(g + 1) * H]
+                                  for g in range(4)], axis=-1)
+        dxs = sum((dZ2[:, g * H:(g + 1) * H] @ kernel[:, g * H:(g + 1) * H].T).reshape(B, T, -1) * masks[g][:, None, :]
+                  for g in range(4))
     return dxs, dkernel, drec, dbias, dZ
 
 
@@ -394,8 +414,10 @@ def vrnn_init_params(cfg, seed=0, dtype=np.float64):
     return p
 
 
-def vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z):
-    """X, Xp [B,T,D]; eps_W [B,C-1]; eps_Z [B,T,L]  (SURVEY.md 3.3)."""
+def vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z, masks=None):
+    """X, Xp [B,T,D]; eps_W [B,C-1]; eps_Z [B,T,L]  (SURVEY.md 3.3).
+    masks = (enc [4,B,D+C], dec [4,B,(D)+L+C]): the input-dropout masks of the two LSTMs (training phase of
+    get_model(dropout=p), cl_vrnn/model.py:164,198,227); None: no dropout (the reference's scripts, and every inference)."""
     B, T, D = X.shape
     C, L = cfg['C'], cfg['L']
     c = {}
@@ -410,7 +432,7 @@ def vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z):
     c['XW'] = np.concatenate([X, Wrep], axis=-1)                            # :193
     c['enc_h'], c['enc_cache'] = lstm_forward(c['XW'], p['encoder_h/kernel'],
                                               p['encoder_h/recurrent_kernel'], p['encoder_h/bias'],
-                                              gate_act=cfg['gate_act'])     # :196-199
+                                              gate_act=cfg['gate_act'], in_masks=None if masks is None else masks[0])     # :196-199
     c['Z_mean'] = c['enc_h'] @ p['Z_mean/kernel'] + p['Z_mean/bias']        # :200-209
     c['Z_log_var'] = c['enc_h'] @ p['Z_log_var/kernel'] + p['Z_log_var/bias']
     c['Z'] = c['Z_mean'] + np.exp(c['Z_log_var'] / 2) * eps_Z               # :212-216
@@ -420,16 +442,16 @@ def vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z):
         c['XpZ'] = np.concatenate([c['Z'], Wrep], axis=-1)
     c['dec_h'], c['dec_cache'] = lstm_forward(c['XpZ'], p['decoder_h/kernel'],
                                               p['decoder_h/recurrent_kernel'], p['decoder_h/bias'],
-                                              gate_act=cfg['gate_act'])     # :225-228
+                                              gate_act=cfg['gate_act'], in_masks=None if masks is None else masks[1])     # :225-228
     c['logits'] = c['dec_h'] @ p['X_decoded_mean/kernel'] + p['X_decoded_mean/bias']  # :229-234
     c['X_hat'] = sigmoid(c['logits'])
     return c
 
 
-def vrnn_loss_and_grads(p, cfg, X, Xp, w_true, eps_W, eps_Z, need_grads=True, target=None):
+def vrnn_loss_and_grads(p, cfg, X, Xp, w_true, eps_W, eps_Z, need_grads=True, target=None, masks=None):
     B, T, D = X.shape
     C, L, H = cfg['C'], cfg['L'], cfg['H']
-    c = vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z)
+    c = vrnn_forward(p, cfg, X, Xp, eps_W, eps_Z, masks=masks)
     # scored against y[0] of fit() (cl_vrnn/train.py:15,59-66): X, or the next frames under --predict_next
     vae_bt, dlogits = bce_from_logits_keras(c['logits'], X if target is None else target)                # [B,T]
     klz_bt, dzm_kl, dzlv_kl = kl_gauss(c['Z_mean'], c['Z_log_var'])

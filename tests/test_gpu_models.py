@@ -296,6 +296,104 @@ def test_cl_vrnn_step_matches_oracle_at_any_intermediate_dim(dev, monkeypatch, H
         np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("H,B,Tn,L,Cn,use_x_prev,gate,rate", [
+    (88, 5, 7, 2, 10, True, 'hard_sigmoid', 0.25),     # the default width: the generic chain instead of the pair kernels
+    (88, 4, 16, 3, 4, False, 'sigmoid', 0.5),          # no history frames: the decoder's inputs are [z, W]
+    (48, 3, 6, 2, 3, True, 'hard_sigmoid', 0.1),       # another width (csrc/lstm_any.hip)
+])
+def test_cl_vrnn_step_with_lstm_input_dropout_matches_oracle(dev, H, B, Tn, L, Cn, use_x_prev, gate, rate):
+    """get_model(dropout=p) -> LSTM(..., dropout=p) for both LSTMs (cl_vrnn/model.py:164,198,227; Keras 2.0.0, implementation
+    0: one input mask per gate and sample, constant over the time steps).  A training pass with INJECTED mask uniforms against
+    the oracle with the same masks: every loss term, per-note logits, both LSTMs' states, every gradient tensor (incl. dZ and
+    dW through the masks), two Adam-WN steps; a pass without gradients (validation / predict) takes no dropout."""
+    from clvae_amd.engine import VrnnEngine
+    cfg = O.vrnn_config(intermediate_dim=H, latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=use_x_prev,
+                        class_weight=0.8, kl_weight=0.6, w_kl_weight=0.9, w_log_var_prior=0.2, gate_act=gate)
+    rng = np.random.default_rng(H + Tn)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=4).items()}
+    win = frames(rng, B, Tn + 1, 88)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(Cn)[rng.integers(0, Cn, B)]
+    eW, eZ = f32(rng.standard_normal((B, Cn - 1))), f32(rng.standard_normal((B, Tn, L)))
+    in_e, in_d = 88 + Cn, (88 if use_x_prev else 0) + L + Cn
+    ue, ud = f32(rng.random((B, 4, in_e))), f32(rng.random((B, 4, in_d)))          # device layout [row][gate][input]
+    masks = (O.dropout_masks(ue.transpose(1, 0, 2), rate), O.dropout_masks(ud.transpose(1, 0, 2), rate))
+    assert 0.3 * rate < (masks[0] == 0).mean() < 3 * rate
+    ref = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ, masks=masks)
+    plain = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ, need_grads=False)
+    assert abs(ref['vae'] - plain['vae']) > 1e-2                                    # the masks matter
+
+    eng = VrnnEngine(dict(cfg, dropout=rate), B, dev)
+    assert eng.dropout == rate and not eng.fuse_pair and not eng.use_mx
+    eng.P.set_weights(p)
+    eng.u_enc.copy_(T(ue, dev)); eng.u_dec.copy_(T(ud, dev))
+    args = (T(X, dev), T(Xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev))
+    eng.loss_and_grads(*args)
+    torch.cuda.synchronize()
+    got = eng.losses()
+    logit_err = np.abs(N(eng.logits).reshape(B, Tn, 88) - ref['cache']['logits']).max()
+    print("cl_vrnn dropout %.2f H=%d: ELBO gpu %.6f oracle %.6f |d|=%.2e  logits max-abs err %.2e"
+          % (rate, H, got['elbo'], ref['elbo'], abs(got['elbo'] - ref['elbo']), logit_err))
+    for k in ('elbo', 'vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - ref[k]) <= ELBO_TOL, k
+    assert logit_err < LOGIT_TOL
+    np.testing.assert_allclose(N(eng.hs_enc).reshape(B, Tn, H), ref['cache']['enc_h'], atol=2e-5)
+    np.testing.assert_allclose(N(eng.hs_dec).reshape(B, Tn, H), ref['cache']['dec_h'], atol=2e-5)
+    check_grads(eng.P.get_weights(eng.P.grads), ref['grads'], tol=2e-4)
+    # an inference pass: no dropout
+    eng.loss_and_grads(*args, need_grads=False)
+    torch.cuda.synchronize()
+    got = eng.losses()
+    for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+        assert abs(got[k] - plain[k]) <= ELBO_TOL, k
+    st = O.adam_wn_init(p)
+    for _ in range(2):
+        r = O.vrnn_loss_and_grads(p, cfg, X, Xp, wt, eW, eZ, masks=masks)
+        O.adam_wn_step(p, r['grads'], st)
+        eng.loss_and_grads(*args)
+        eng.P.adam_step()
+    w = eng.P.get_weights()
+    for k in p:
+        np.testing.assert_allclose(w[k], p[k], rtol=5e-3, atol=5e-5, err_msg=k)
+
+
+def test_cl_vrnn_fit_with_dropout_draws_its_masks_from_philox(dev):
+    """Model.fit on get_model(dropout=0.2): the captured step draws the masks' uniforms itself (Philox streams 2 / 3 at the
+    step's counter, by global row) -- an oracle loop with oracle/philox.py's uniforms follows the epoch losses; validation
+    takes no dropout."""
+    from clvae_amd.cl_vrnn.model import get_model
+    B, Tn, L, C, n, rate, seed = 4, 6, 2, 3, 12, 0.2, 91
+    rng = np.random.default_rng(5)
+    win = (rng.random((n, Tn + 1, 88)) < 0.05).astype(np.float64)
+    X, Xp = win[:, 1:].copy(), win[:, :-1].copy()
+    wt = np.eye(C)[rng.integers(0, C, n)]
+    model, _ = get_model(B, 88, 88, L, Tn, C, True, 'adam-wn', dropout=rate, seed=seed)
+    p = {k: f32(v) for k, v in model.engine.P.get_weights().items()}
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=C, use_x_prev=True)
+    hist = model.fit([X, Xp], [X, wt, wt, X], shuffle=False, epochs=2, batch_size=B, verbose=0,
+                     validation_data=([X[:B], Xp[:B]], [X[:B], wt[:B], wt[:B], X[:B]]))
+    in_e, in_d = 88 + C, 88 + L + C
+    st, it, ref_epoch, ref_val = O.adam_wn_init(p), 0, [], []
+    for ep in range(2):
+        tot = 0.0
+        for b0 in range(0, n, B):
+            eW = OP.normal(B * (C - 1), seed, step=it, stream_id=0).reshape(B, C - 1).astype(np.float64)
+            eZ = OP.normal(B * Tn * L, seed, step=it, stream_id=1).reshape(B, Tn, L).astype(np.float64)
+            ue = OP.uniform(B * 4 * in_e, seed, step=it, stream_id=2).reshape(B, 4, in_e).astype(np.float64)
+            ud = OP.uniform(B * 4 * in_d, seed, step=it, stream_id=3).reshape(B, 4, in_d).astype(np.float64)
+            masks = (O.dropout_masks(ue.transpose(1, 0, 2), rate), O.dropout_masks(ud.transpose(1, 0, 2), rate))
+            r = O.vrnn_loss_and_grads(p, cfg, X[b0:b0 + B], Xp[b0:b0 + B], wt[b0:b0 + B], eW, eZ, masks=masks)
+            O.adam_wn_step(p, r['grads'], st)
+            tot += r['total']
+            it += 1
+        ref_epoch.append(tot / (n // B))
+        eW = OP.normal(B * (C - 1), seed, step=it, stream_id=4).reshape(B, C - 1).astype(np.float64)
+        eZ = OP.normal(B * Tn * L, seed, step=it, stream_id=5).reshape(B, Tn, L).astype(np.float64)
+        ref_val.append(O.vrnn_loss_and_grads(p, cfg, X[:B], Xp[:B], wt[:B], eW, eZ, need_grads=False)['total'])
+    np.testing.assert_allclose(hist.history['loss'], ref_epoch, rtol=2e-4)
+    np.testing.assert_allclose(hist.history['val_loss'], ref_val, rtol=2e-4)
+
+
 @pytest.mark.parametrize("exact_frames", [False, True])
 @pytest.mark.parametrize("B,Tn,L", [(256, 128, 2),         # BASELINE config 3 (and 4 per GPU): what bench.py times
                                     (1024, 256, 32)])      # config 5 per GPU
