@@ -16,7 +16,8 @@ from oracle import clvae_oracle as O  # noqa: E402
 
 def main():
     rank, world, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
-    use_graph = sys.argv[2] == "graph"
+    use_graph = sys.argv[2].startswith("graph")
+    dropout = 0.3 if sys.argv[2].endswith("dropout") else 0.0      # LSTM(dropout=p): masks by GLOBAL row, like the noise
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     B, T, L, C = 4, 6, 2, 3
@@ -25,7 +26,7 @@ def main():
     rng = np.random.default_rng(0)
     win = (rng.random((world * B, T + 1, 88)) < 0.05).astype(np.float32)
     wt = np.eye(C, dtype=np.float32)[rng.integers(0, C, world * B)]
-    eng = VrnnEngine(cfg, B, dev)
+    eng = VrnnEngine(dict(cfg, dropout=dropout), B, dev)
     eng.P.set_weights(p)
     ts = TrainStep(eng, seed=5, rank=rank, world=world, use_graph=use_graph)
     assert ts.ar is not None and ts.split_update

@@ -459,7 +459,7 @@ def test_persistent_generation_matches_frame_steps(dev, N, L, use_x_prev, gate, 
 
 
 # ------------------------------------------------------------------ data parallel, two ranks on one GPU
-@pytest.mark.parametrize("mode", ["eager", "graph"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "graph-dropout"])
 def test_two_rank_dp_step_matches_single_process(dev, tmp_path, mode):
     """Two data-parallel ranks (4 rows each, gloo carrying the CUDA gradient buckets, both on this GPU) end every step
     with identical weights, equal to one process training on the 8 rows: bucketed all-reduce on the side stream, the
@@ -490,7 +490,7 @@ def test_two_rank_dp_step_matches_single_process(dev, tmp_path, mode):
     rng = np.random.default_rng(0)
     win = (rng.random((B, Tn + 1, 88)) < 0.05).astype(np.float32)
     wt = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
-    eng = VrnnEngine(cfg, B, dev)
+    eng = VrnnEngine(dict(cfg, dropout=0.3 if mode.endswith("dropout") else 0.0), B, dev)      # (masks by global row: the same on 1 and 2 ranks)
     eng.P.set_weights(p)
     ts = TrainStep(eng, seed=5, use_graph=False)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
