@@ -92,3 +92,45 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in (r.stderr + r.stdout)
+
+
+def test_bench_shared_gpu_mode_puts_every_rank_on_device_0():
+    """CLV_BENCH_SHARE_GPU=1 (the one-GPU box's way to run `bench.py --gpus N`, tests/test_gpu_bench_dp.py): every rank gets
+    local device 0 and the group is gloo; here through the CPU self-test path."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CLV_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and sorted(tuple(x) for x in d["ranks"]) == [(0, 0), (1, 0)] and d["backend"] == "gloo"
+
+
+def test_pmc_passes_become_bytes_per_launch_and_per_step(tmp_path):
+    """bench.aggregate_pmc: two rocprofv3 counter CSVs (FETCH_SIZE, WRITE_SIZE; one row per dispatch and counter instance) ->
+    HBM bytes with the gfx950 corrections (KB -> bytes, FETCH_SIZE x 2), the dominant kernels' average per launch, the step's
+    total from the launch count of the once-per-step kernel."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    head = "Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+    fwd, bwd, red = ("void clv::lstm_pair_fwd_kernel<0, true, 1, false>(clv::PairFwdArgs)",
+                     "void clv::lstm_pair_bwd_kernel<0, 4, true>(clv::PairBwdArgs)", "clv::splitk_reduce_multi_kernel(clv::ReduceTable)")
+    rows_f, rows_w = [], []
+    for step in range(3):
+        for j, (k, fkb, wkb) in enumerate(((fwd, 100.0, 400.0), (bwd, 300.0, 200.0), (red, 50.0, 1.0))):
+            d = 10 * step + j
+            rows_f += ['%d,"%s",FETCH_SIZE,%g' % (d, k, fkb / 2)] * 2          # two counter instances per dispatch: summed
+            rows_w += ['%d,"%s",WRITE_SIZE,%g' % (d, k, wkb)]
+    (tmp_path / "f.csv").write_text(head + "\n".join(rows_f) + "\n")
+    (tmp_path / "w.csv").write_text(head + "\n".join(rows_w) + "\n")
+    d = bench.aggregate_pmc("cfg3", str(tmp_path / "f.csv"), str(tmp_path / "w.csv"))
+    assert d["steps_profiled"] == 3 and len(d["dominant_kernels"]) == 2
+    per = {k["kernel"].split("_kernel")[0]: k for k in d["kernels"]}
+    assert per["lstm_pair_fwd"]["hbm_read_bytes_corrected"] == 2 * 1024 * 100.0 and per["lstm_pair_fwd"]["hbm_write_bytes"] == 1024 * 400.0
+    assert d["dominant_bytes_per_launch"] == ((200 + 400) + (600 + 200)) * 1024 / 2
+    assert d["step_bytes"] == ((200 + 400) + (600 + 200) + (100 + 1)) * 1024
