@@ -626,6 +626,8 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
             dist.broadcast(t_, src=0)
     X_all, Xp_all, w_all = synthetic_windows(w, 4 * B, 1234 + rank, dev)
     ts = TrainStep(eng, seed=1234, rank=rank, world=world, use_graph=not args.no_graph)
+    if args.no_graph:      # (profiling passes run eagerly: the same launches as the replayed step, which stores no logits)
+        ts._drop_logits = hasattr(eng, 'keep_logits') and 'keep_logits' not in eng.cfg
     nb = X_all.shape[0] // B
 
     # the step assembles its own batch from the HBM-resident windows (batch = device step counter mod nb), inside its graph:

@@ -129,12 +129,13 @@ class _LstmSeqFn(Function):
 
 class ClvLSTMSeq(nn.Module):
     """keras.layers.LSTM(H, return_sequences=True) with zero initial state: the whole window in one persistent
-    sequence kernel per pass (csrc/lstm.hip).  H is 88 (the kernels keep the recurrent weights in registers)."""
+    sequence kernel per pass.  hidden = 88 (the reference's default, cl_vrnn/train.py:90): csrc/lstm.hip, recurrent weights in
+    registers; any other width 1..1024: csrc/lstm_any.hip (same contract, recurrent weights streamed from L2)."""
 
     def __init__(self, input_dim, hidden=88, recurrent_activation='hard_sigmoid'):
         super().__init__()
-        if hidden != 88:
-            raise ValueError("the sequence kernels are built for 88 hidden units")
+        if not 1 <= int(hidden) <= 1024:
+            raise ValueError("hidden must be in 1..1024")
         self.gate_act = {'hard_sigmoid': _lib.GATE_HARD_SIGMOID, 'sigmoid': _lib.GATE_SIGMOID}[recurrent_activation]
         lim = math.sqrt(6.0 / (input_dim + 4 * hidden))
         self.kernel = nn.Parameter(torch.empty(input_dim, 4 * hidden).uniform_(-lim, lim))

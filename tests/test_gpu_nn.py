@@ -65,13 +65,13 @@ def _lstm_ref(x, k, r, b, gate):
 
 
 @pytest.mark.parametrize("gate", ['hard_sigmoid', 'sigmoid'])
-@pytest.mark.parametrize("B,T,Din", [(3, 5, 98), (16, 32, 100), (2, 1, 120)])
-def test_lstm_seq(dev, gate, B, T, Din):
+@pytest.mark.parametrize("B,T,Din,H", [(3, 5, 98, 88), (16, 32, 100, 88), (2, 1, 120, 88), (4, 6, 98, 40), (3, 4, 100, 128)])
+def test_lstm_seq(dev, gate, B, T, Din, H):
     from clvae_amd.nn import ClvLSTMSeq
     torch.manual_seed(B * 100 + T)
-    layer = ClvLSTMSeq(Din, 88, recurrent_activation=gate).to(dev)
+    layer = ClvLSTMSeq(Din, H, recurrent_activation=gate).to(dev)
     x = (0.5 * torch.randn(B, T, Din, device=dev)).requires_grad_(True)
-    g = torch.randn(B, T, 88, device=dev)
+    g = torch.randn(B, T, H, device=dev)
     y = layer(x)
     y.backward(g)
     ps = [p.detach().cpu().double().requires_grad_(True) for p in (layer.kernel, layer.recurrent_kernel, layer.bias)]
