@@ -187,6 +187,34 @@ def aggregate_pmc(workload, fetch_csv, write_csv, steps_fallback=9):
                 step_bytes=step_bytes, steps_profiled=steps, kernels=rows)
 
 
+def aggregate_sq(sq_csv):
+    """One rocprofv3 SQ pass -> per kernel (average over its dispatches): mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4
+    (four matrix pipes per CU), valu_issue = 2 SQ_INSTS_VALU / (4 SQ_BUSY_CU_CYCLES) (a wave64 vector instruction holds a SIMD-32 for
+    two cycles), waves_parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES (tools/pmc_sq.py, MI355X_MICROARCH.md units)."""
+    import collections
+    import csv
+    import re
+    per, name = collections.defaultdict(lambda: collections.defaultdict(float)), {}
+    for r in csv.DictReader(open(sq_csv)):
+        per[r['Dispatch_Id']][r['Counter_Name']] += float(r['Counter_Value'])
+        name[r['Dispatch_Id']] = r['Kernel_Name']
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d_, cs in per.items():
+        k = re.sub(r'\(.*', '', re.sub(r'^void ', '', name[d_]).replace('clv::', ''))[:80]
+        for c, v in cs.items():
+            acc[k][c].append(v)
+    out = {}
+    for k, cs in acc.items():
+        m = {c: sum(v) / len(v) for c, v in cs.items()}
+        busy = m.get('SQ_BUSY_CU_CYCLES')
+        if not busy:
+            continue
+        out[k] = dict(mfma_busy=round(m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / busy / 4, 4),
+                      valu_issue=round(2 * m.get('SQ_INSTS_VALU', 0.0) / (4 * busy), 4),
+                      waves_parked=round(m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES'], 4) if m.get('SQ_WAVE_CYCLES') else None)
+    return out
+
+
 def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
     """The two PMC passes as CHILD processes of this one -- `rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py
     --workload W --steps 6 --warmup 3 --no-graph ...` -- started before this process has touched the GPU (nothing is exec'd
@@ -202,9 +230,11 @@ def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
     tmp = tempfile.mkdtemp(prefix='clv_pmc_')
     try:
         csvs = {}
-        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        # three passes: the two traffic counters each alone (the guide's rule), then the SQ counters of the busy fractions
+        for counter, pmc_list in (('FETCH_SIZE', ['FETCH_SIZE']), ('WRITE_SIZE', ['WRITE_SIZE']),
+                                  ('SQ', ['SQ_BUSY_CU_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY'])):
             out = os.path.join(tmp, counter)
-            cmd = [rp, '--pmc', counter, '--kernel-trace', '-d', out, '-o', 't', '--output-format', 'csv', '--',
+            cmd = [rp, '--pmc'] + pmc_list + ['--kernel-trace', '-d', out, '-o', 't', '--output-format', 'csv', '--',
                    sys.executable, os.path.abspath(__file__), '--workload', workload, '--steps', '6', '--warmup', '3',
                    '--no-cpu-baseline', '--no-roofline', '--no-graph', '--no-also', '--no-pmc-traffic'] + (['--bf16'] if bf16 else [])
             env = dict(os.environ, TMPDIR='/tmp')
@@ -218,12 +248,19 @@ def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
                 except OSError:
                     pass
                 pr.communicate()
+                if counter == 'SQ':
+                    break
                 return dict(error="the %s pass passed %d s and was killed" % (counter, timeout_s))
             found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('counter_collection.csv')]
             if pr.returncode != 0 or not found:
+                if counter == 'SQ':      # the busy fractions are an extra: the traffic stands without them
+                    break
                 return dict(error="the %s pass ended with code %s; stderr tail: %s" % (counter, pr.returncode, se[-200:]))
             csvs[counter] = found[0]
-        return aggregate_pmc(workload, csvs['FETCH_SIZE'], csvs['WRITE_SIZE'])
+        d = aggregate_pmc(workload, csvs['FETCH_SIZE'], csvs['WRITE_SIZE'])
+        if 'SQ' in csvs:
+            d['sq'] = aggregate_sq(csvs['SQ'])
+        return d
     except Exception as ex:      # noqa: BLE001 -- a measurement extra must never cost the run
         return dict(error=repr(ex)[:200])
     finally:
@@ -550,6 +587,10 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
                     traffic_measured_in_this_run=bool(measured and traffic_source is not None and traffic_source.startswith('measured')),
                     traffic_sources_match=traffic_match, traffic_rejected=traffic_problem,
                     traffic_pass_error=(pmc or {}).get('error') if pmc is not None else None,
+                    counters=({kk: v for kk, v in pmc['sq'].items() if re.match(DOMINANT_RE + '|lstm_wgrad_bf16|out_head|vrnn_label_fwd|sparse_proj', kk)}
+                              if (measured and pmc.get('sq')) else None),
+                    counters_are="SQ counters of the same child passes, per kernel: mfma_busy (of the four matrix pipes), valu_issue "
+                                 "(of the SIMDs' vector issue cycles), waves_parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES)",
                     kernel_time_pass="%d eager steps with HIP events around every launch, after the graph capture and before the warm-up" % reps)
     if w['model'] == 'cl_vrnn':
         if getattr(eng, 'use_mx', False):
@@ -589,7 +630,12 @@ def roofline_object(args, w, wl_name, eng, recs, recs_nolabel, reps, value_per_g
             issued += mfmas * 2.0 * 16 * 16 * 32
         issued *= reps
         sq = None
-        for tag in PROFILE_TAGS:
+        sq_run = (pmc or {}).get('sq') if (pmc is not None and 'error' not in pmc) else None
+        if sq_run:        # measured in this run (the third PMC child pass)
+            k = [v for kk, v in sq_run.items() if 'lstm_wgrad_bf16' in kk]
+            if k:
+                sq = dict(mfma_busy=k[0]['mfma_busy'], source='measured in this run (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ...)')
+        for tag in PROFILE_TAGS if sq is None else ():
             try:
                 sj = json.load(open(os.path.join(ROOT, 'profiles', '%s_sq_%s.json' % (tag, wl_name))))
                 k = [k for k in sj['kernels'] if 'lstm_wgrad_bf16' in k['kernel']]
