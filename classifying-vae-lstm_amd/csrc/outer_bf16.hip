@@ -336,10 +336,12 @@ extern "C" int clv_dense_window_fwd_bf16_supported(int Bn, int nx, int N, int ld
          (size_t)Bn * (size_t)ldx * 4 < 0x80000000ull && (size_t)nx * (size_t)ldk * 4 < 0x80000000ull;
 }
 extern "C" int clv_dense_window_fwd_bf16_splits(int Bn, int nx) {
+  if (Bn <= 0 || nx <= 0) return 0;                       // (a size query never divides by zero: tests/test_host_logic.py)
   const int chunk = window_fwd_chunk(Bn, nx);
   return (nx + chunk - 1) / chunk;
 }
 extern "C" size_t clv_dense_window_fwd_bf16_workspace_bytes(int Bn, int nx, int N) {
+  if (Bn <= 0 || nx <= 0 || N <= 0) return 0;
   return (size_t)clv_dense_window_fwd_bf16_splits(Bn, nx) * Bn * N * sizeof(float);
 }
 extern "C" int clv_dense_window_fwd_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* K, int ldk, float* part,

@@ -528,6 +528,7 @@ static int wgrad_kc(int K, int split_scale, int base_ranges = 128) {
   return (kc + 31) / 32 * 32;
 }
 static int wgrad_splits(int K, int split_scale, int base_ranges = 128) {
+  if (K <= 0) return 0;                                   // (size queries with no rows: 0 bytes, never a division by zero)
   const int kc = wgrad_kc(K, split_scale, base_ranges);
   return (K + kc - 1) / kc;
 }

@@ -70,6 +70,47 @@ def test_no_valu_instruction_hides_inside_inline_asm():
     assert not found, found
 
 
+def test_every_entry_point_survives_null_and_zero_arguments():
+    """Error behaviour of the C ABI (include/clvae.h: "return 0 / negative CLV_E* / positive hipError_t", nothing crashes):
+    every exported function called with NULL pointers, zero sizes and zero-filled structs, each in a process of its own --
+    a compute entry point answers with an error code before it touches its arguments or the device, a size query with a
+    number.  (Round 5 found five size queries that divided by zero here.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import sys, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "import clvae_amd\n"
+        "from clvae_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "for n in sorted(_lib.SIGNATURES):\n"
+        "    res, args = _lib.SIGNATURES[n]\n"
+        "    vals = []\n"
+        "    for a in args:\n"
+        "        if a in (C.c_void_p, C.c_char_p): vals.append(None)\n"
+        "        elif a in (C.c_float, C.c_double): vals.append(0.0)\n"
+        "        elif isinstance(a, type) and issubclass(a, C.Structure): vals.append(a())\n"
+        "        elif hasattr(a, '_type_') and isinstance(getattr(a, '_type_'), type): vals.append(None)\n"
+        "        else: vals.append(0)\n"
+        "    print('CALL', n, flush=True)\n"
+        "    r = getattr(L, n)(*vals)\n"
+        "    print('RET', n, r if not isinstance(r, bytes) else 0, flush=True)\n" % root)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    calls = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("CALL")]
+    rets = {l.split()[1]: int(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("RET")}
+    assert r.returncode == 0, "crashed in %s (exit code %d)" % (calls[-1] if calls else "?", r.returncode)
+    assert set(rets) == set(_lib.SIGNATURES)
+    compute = [n for n in rets if not n.endswith(("_bytes", "_bytes_ex", "_supported", "_splits", "_floats", "_split", "_version", "_count",
+                                                  "_string", "_enable", "_collect", "_scope", "_destroy"))
+               and not n.startswith(("clv_splitk_reduce_multi", "clv_graph_", "clv_prof_"))]
+    for n in compute:
+        assert rets[n] != 0, n             # an error code, not "ok"
+    for n in rets:
+        if n.endswith(("_bytes", "_bytes_ex", "_splits")):
+            assert rets[n] >= 0, n
+
+
 def test_adam_plan_layout_on_host():
     L = _lib.lib()
     tab = (_lib.ParamDesc * 3)(_lib.ParamDesc(0, 200, 88, 0, 1, 0), _lib.ParamDesc(17600, 1, 88, 0, 0, 0),
