@@ -21,6 +21,7 @@ namespace clv {
 constexpr int LA_NT = 256;
 constexpr int LA_MAXH = 1024;                 // units (4 per thread at most)
 constexpr int LA_UPT = LA_MAXH / LA_NT;       // units per owner thread
+constexpr int LA_KB = 8;                      // rows of U a thread keeps in flight (forward), rows of U per wave round (backward)
 
 struct LstmAnyFwdArgs {
   int B, T, H;
@@ -77,7 +78,25 @@ __global__ __launch_bounds__(LA_NT) void lstm_any_fwd_kernel(LstmAnyFwdArgs a) {
         if (u >= H) break;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const float* Up = a.U + u;
-        for (int k = k0; k < k1; ++k) {
+        // LA_KB rows of U in flight per round (4 LA_KB loads requested before the first FMA): a k loop that waits for every
+        // row's four loads pays one L2 round trip per k (17 us per step at 128 units: tools/any_width_bench.py)
+        int k = k0;
+        for (; k + LA_KB <= k1; k += LA_KB) {
+          float uv[LA_KB][4];
+#pragma unroll
+          for (int j = 0; j < LA_KB; ++j) {
+            const float* row = Up + (size_t)(k + j) * G4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) uv[j][g] = row[g * H];
+          }
+#pragma unroll
+          for (int j = 0; j < LA_KB; ++j) {
+            const float hk = hv[k + j];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = fmaf(hk, uv[j][g], acc[g]);
+          }
+        }
+        for (; k < k1; ++k) {
           const float hk = hv[k];
           const float* row = Up + (size_t)k * G4;
 #pragma unroll
@@ -172,12 +191,27 @@ __global__ __launch_bounds__(LA_NT) void lstm_any_bwd_kernel(LstmAnyBwdArgs a) {
     }
     __syncthreads();
     if (t > 0) {                               // dh_{t-1}[k] += sum_j dz_t[j] U[k][j]: a wave per row of U
-      for (int k = wave; k < H; k += LA_NT / 64) {
-        const float* row = a.U + (size_t)k * G4;
-        float s = 0.f;
-        for (int j = lane; j < G4; j += 64) s = fmaf(dzb[j], row[j], s);
-        s = wave_sum(s);
-        if (lane == 0) dhr[k] = s;
+      // LA_KB / 2 rows of U per round, their loads requested together, their wave reductions interleaved
+      constexpr int RB = LA_KB / 2, NWV = LA_NT / 64;
+      for (int kb = wave * RB; kb < H; kb += NWV * RB) {
+        float s[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) s[r] = 0.f;
+        for (int j = lane; j < G4; j += 64) {
+          const float dv = dzb[j];
+          float uv[RB];
+#pragma unroll
+          for (int r = 0; r < RB; ++r) uv[r] = a.U[(size_t)min(kb + r, H - 1) * G4 + j];
+#pragma unroll
+          for (int r = 0; r < RB; ++r) s[r] = fmaf(dv, uv[r], s[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) s[r] = wave_sum(s[r]);
+        if (lane == 0) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            if (kb + r < H) dhr[kb + r] = s[r];
+        }
       }
     }
     __syncthreads();
