@@ -702,6 +702,15 @@ def measure_train(args, wl_name, dev, rank, world, steps, warmup, bf16=False, re
     if rank == 0 and want_roofline:
         batch = (X_all[:B], Xp_all[:B], w_all[:B])
         recs = kernel_time_pass(eng, dict(seed=1234, rank=rank, world=1), batch, reps)
+        if w['model'] == 'cl_vae':
+            # a launch-bound step (three launches of 5-40 us, issued eagerly here): when the host falls behind, the interval
+            # between a bracket's two events contains the wait for the launch itself (seen once: 70.8 us where rocprofv3 and every
+            # other pass say 40-42).  Three passes, the one with the shortest fused-step bracket counts.
+            tot = lambda rs: sum(r[2] for r in rs if r[0] in ('vae_fused_step', 'gemm_f32'))
+            for _ in range(2):
+                again = kernel_time_pass(eng, dict(seed=1234, rank=rank, world=1), batch, reps)
+                if tot(again) < tot(recs):
+                    recs = again
         if getattr(eng, 'fuse_pair', False) and getattr(eng, 'label_in_pair', False):
             recs_nolabel = kernel_time_pass(eng, dict(seed=1234, rank=rank, world=1), batch, max(reps // 2, 4), label_off=True)
     barrier()
