@@ -199,6 +199,8 @@ def test_cl_vae_without_hidden_layers_matches_oracle(dev, use_x_prev):
     (4, 9, 2, 10, True, 'sigmoid'),
     (4, 128, 2, 10, True, 'hard_sigmoid'),      # BASELINE config 3/4 shape at reduced batch
     (4, 32, 32, 10, True, 'hard_sigmoid'),      # config 5 latent size
+    (1, 3, 1, 2, True, 'hard_sigmoid'),         # the smallest of everything: one sample, one latent, two classes
+    (1, 1, 1, 2, False, 'sigmoid'),
 ])
 def test_cl_vrnn_step_matches_oracle(dev, B, Tn, L, Cn, use_x_prev, gate, pair):
     """pair=True: both LSTMs + latent head in one persistent launch (csrc/lstm_pair.hip) where supported."""
