@@ -19,9 +19,14 @@
 //  * the input projection is gathered INSIDE the kernel: K_x (124 KB) stays in LDS as [k][unit][gate], one wave turns
 //    the frames into note lists two steps ahead, and because the piece lanes are summed anyway, lane p adds the notes
 //    p, p+4, ... of its row: no [B*T,352] projection buffer, no projection launch (2 x 110 us at configuration 5);
-//  * the forward pass stores what the backward pass needs in the coefficient format of lstm_pair.hip:
-//    coef [B*T,4H] = (ki, kf, kg, ko) = (g i', c_{t-1} f', i g', tanh(c) o'), aux [B*T,2,H] = (kcarry, kc) =
-//    (f, o (1 - tanh(c)^2)), so a backward step is dc += dh kc; dz = (dc ki, dc kf, dc kg, dh ko); dc *= kcarry.
+//  * the forward pass stores what the backward pass needs, the coefficients of lstm_pair.hip, as unit-major records:
+//    coef [B*T,H,4] = (ki, kf, kg, ko) = (g i', c_{t-1} f', i g', tanh(c) o'), aux [B*T,H,2] = (kcarry, kc) =
+//    (f, o (1 - tanh(c)^2)), so a backward step is dc += dh kc; dz = (dc ki, dc kf, dc kg, dh ko); dc *= kcarry, and a
+//    lane moves its unit's record with one 16-byte and one 8-byte access (round 5: seven 4-byte stores / loads per lane
+//    and step cost 22-33 us more per forward launch and 10-14 per backward launch at configuration 5).  The backward
+//    pass writes dz over the record's row in the GATE-major order the kernel-gradient product reads: other lanes' records
+//    are overwritten, which is safe because a step's dz goes out one step late -- behind the barrier every wave reaches
+//    only after it has used its own record of that row.
 // Backward: dh_rec = dz_{t+1} . U^T with M = 16 units per tile, N = (row, piece) of dz, K = 352 gate columns (11 k-steps);
 // the same butterfly leaves lane (unit quad, row, p) with unit 4 ul + p: 64 distinct (row, unit) cells per wave.  The
 // decoder's dZ_t = dz_t . K_z^T is two more tiles whose "units" are latents.
@@ -121,6 +126,25 @@ __device__ __forceinline__ float mx_load(mx_rsrc_t r, unsigned voff, unsigned so
 __device__ __forceinline__ void mx_store(float v, mx_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
+typedef unsigned mx_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned mx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mx_store2(float a, float b, mx_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64((mx_u32x2){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)}, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void mx_store4(float a, float b, float c, float d, mx_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128((mx_u32x4){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                    __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)}, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void mx_load2(float& a, float& b, mx_rsrc_t r, unsigned voff, unsigned soff) {
+  const mx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  const unsigned x = v.x, y = v.y;      // (not __builtin_bit_cast(float, v.y): on a vector ELEMENT this clang reads element 0)
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ void mx_load4(float& a, float& b, float& c, float& d, mx_rsrc_t r, unsigned voff, unsigned soff) {
+  const mx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  const unsigned x = v.x, y = v.y, z = v.z, w = v.w;
+  a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y); c = __builtin_bit_cast(float, z); d = __builtin_bit_cast(float, w);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward.  8 waves; wave w < 7 owns three tiles = the units 12w .. 12w+11 (tile tl: units 12w + 3 j + tl, j = 0..3, so
@@ -210,7 +234,7 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   const mx_rsrc_t r_c = mx_rsrc(a.coef + (size_t)row0 * T * LG, (size_t)nrows * T * LG * 4);
   const mx_rsrc_t r_a = mx_rsrc(a.aux + (size_t)row0 * T * 2 * LH, (size_t)nrows * T * 2 * LH * 4);
   const mx_rsrc_t r_h = mx_rsrc(a.hs + (size_t)row0 * T * LH, (size_t)nrows * T * LH * 4);
-  const unsigned v_c = (rloc * T * LG + unit) * 4u, v_a = (rloc * T * 2 * LH + unit) * 4u, v_h = (rloc * T * LH + unit) * 4u;
+  const unsigned v_c = (rloc * T * LG + 4 * unit) * 4u, v_a = (rloc * T * 2 * LH + 2 * unit) * 4u, v_h = (rloc * T * LH + unit) * 4u;
   // h pieces -> B-operand image: chunk unit / 8, slot of column 4 r + q, element unit % 8
   int hw_off[3];
 #pragma unroll
@@ -375,14 +399,11 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   auto store_pending = [&](int k, unsigned tt) {        // tt = the step the values belong to; (unsigned)-1: beyond num_records
     if (MX_ABL & 2) return;
     if (MX_ABL & 16) tt = tt == 0xffffffffu ? tt : 0u;
-    switch (k) {
-      case 0: mx_store(pend[0], r_c, v_c, tt * (LG * 4)); break;
-      case 1: mx_store(pend[1], r_c, v_c + LH * 4, tt * (LG * 4)); break;
-      case 2: mx_store(pend[2], r_c, v_c + 2 * LH * 4, tt * (LG * 4)); break;
-      case 3: mx_store(pend[3], r_c, v_c + 3 * LH * 4, tt * (LG * 4)); break;
-      case 4: mx_store(pend[4], r_a, v_a, tt * (2 * LH * 4)); break;
-      case 5: mx_store(pend[5], r_a, v_a + LH * 4, tt * (2 * LH * 4)); break;
-      default: mx_store(pend[6], r_h, v_h, tt * (LH * 4)); break;
+    switch (k) {        // one 16-byte, one 8-byte and one 4-byte store per lane and step (seven 4-byte ones: +9-27 us per launch)
+      case 0: mx_store4(pend[0], pend[1], pend[2], pend[3], r_c, v_c, tt * (LG * 4)); break;
+      case 1: mx_store2(pend[4], pend[5], r_a, v_a, tt * (2 * LH * 4)); break;
+      case 2: mx_store(pend[6], r_h, v_h, tt * (LH * 4)); break;
+      default: break;
     }
   };
   float xin[2][NT][4];        // input contribution of the step of parity [.]: written during the previous step's MFMAs
@@ -419,12 +440,12 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     f32x4v acc[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) acc[tl] = f32x4v{xin[cur][tl][0], xin[cur][tl][1], xin[cur][tl][2], xin[cur][tl][3]};
-    // vector work of MFMA slot m: stores of the previous step in slots 0..6, two gather FMAs per slot from slot F0 on
-    // slots 0..6: the previous step's stores; A0 .. A0+2NT-1: round-0 FMAs (two per slot); slot A0+2NT: the round-1 rows are
+    // vector work of MFMA slot m -- slots 0..2: the previous step's three stores; A0 .. A0+2NT-1: round-0 FMAs (two per slot); slot A0+2NT: the round-1 rows are
     // requested into the same registers; B0 .. B0+2NT-1: round-1 FMAs
+    // (the FMAs three slots earlier, right behind the stores: no change, profiles/r05_mx_wide_records_ab.txt)
     constexpr int NM = 9 * NT, A0 = NT == 3 ? 7 : 1, B0 = NT == 3 ? 20 : 6;
     auto slot = [&](int m) {
-      if (m < 7) store_pending(m, (unsigned)(t - 1));
+      if (m < 3) store_pending(m, (unsigned)(t - 1));
       if (!(MX_ABL & 4)) {
         if (m >= A0 && m < A0 + 2 * NT) {
 #pragma unroll
@@ -552,7 +573,7 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   }
   if (t < T) step(t, P0{});
 #pragma unroll
-  for (int k = 0; k < 7; ++k) store_pending(k, (unsigned)(T - 1));       // the last step's outputs
+  for (int k = 0; k < 3; ++k) store_pending(k, (unsigned)(T - 1));       // the last step's outputs
 }
 
 constexpr size_t mx_fwd_lds(int nx) {
@@ -668,8 +689,9 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
   const mx_rsrc_t r_c = mx_rsrc(a.coef + (size_t)row0 * T * LG, (size_t)nrows * T * LG * 4);
   const mx_rsrc_t r_a = mx_rsrc(a.aux + (size_t)row0 * T * 2 * LH, (size_t)nrows * T * 2 * LH * 4);
   const mx_rsrc_t r_d = mx_rsrc(a.dhs + (size_t)row0 * T * LH, (size_t)nrows * T * LH * 4);
-  const unsigned v_c = valid ? (rloc * T * LG + u) * 4u : MX_OOB;
-  const unsigned v_a = valid ? (rloc * T * 2 * LH + u) * 4u : MX_OOB;
+  const unsigned v_c = valid ? (rloc * T * LG + u) * 4u : MX_OOB;              // dz, written in place: [gate][unit]
+  const unsigned v_ci = valid ? (rloc * T * LG + 4 * u) * 4u : MX_OOB;         // the forward pass's record: [unit][4]
+  const unsigned v_a = valid ? (rloc * T * 2 * LH + 2 * u) * 4u : MX_OOB;      // ... and [unit][2]
   const unsigned v_d = valid ? (rloc * T * LH + u) * 4u : MX_OOB;
   // dz pieces: k = 4 u + gate: chunk u / 2, the lane's four gates are 8 contiguous bytes; a lane without a unit writes to
   // its own dump slot behind the images
@@ -684,9 +706,8 @@ __device__ __forceinline__ void mx_bwd_units(const MxBwdArgs& a, char* dzB, int 
   struct Coef { float ki, kf, kg, ko, kcarry, kc, dh; };
   auto load_set = [&](Coef& k, int t) {
     const unsigned tc = (unsigned)t;
-    k.ki = mx_load(r_c, v_c, tc * (LG * 4)); k.kf = mx_load(r_c, v_c + LH * 4, tc * (LG * 4));
-    k.kg = mx_load(r_c, v_c + 2 * LH * 4, tc * (LG * 4)); k.ko = mx_load(r_c, v_c + 3 * LH * 4, tc * (LG * 4));
-    k.kcarry = mx_load(r_a, v_a, tc * (2 * LH * 4)); k.kc = mx_load(r_a, v_a + LH * 4, tc * (2 * LH * 4));
+    mx_load4(k.ki, k.kf, k.kg, k.ko, r_c, v_ci, tc * (LG * 4));
+    mx_load2(k.kcarry, k.kc, r_a, v_a, tc * (2 * LH * 4));
     k.dh = mx_load(r_d, v_d, tc * (LH * 4));
   };
   Coef SA, SB;
@@ -832,6 +853,7 @@ extern "C" int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,
   if (H != LH || B <= 0 || T < 1 || nx < 0 || nx > MX_NXMAX || nz < 0 || nz > 32) return CLV_EINVAL;
   if ((nx > 0 && (!X || !Kx || ldx < nx)) || (nz > 0 && (!Z || !Kz || ldz < nz)) || !U || !hs || !coef || !aux) return CLV_EINVAL;
   if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
+  if (((uintptr_t)coef) % 16 != 0 || ((uintptr_t)aux) % 8 != 0) return CLV_EINVAL;      // the records move as 16- and 8-byte accesses
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_mx_fwd", s);
   MxFwdArgs a{B, T, X, ldx, nx, Kx, Z, ldz, nz, Kz, rowbias, U, hs, coef, aux};
@@ -861,6 +883,7 @@ extern "C" int clv_lstm_mx_bwd(int B, int T, int H, const float* U, const float*
   using namespace clv;
   if (H != LH || B <= 0 || T < 1 || !U || !dhs || !aux || !coef_inout_dz || !dzsum) return CLV_EINVAL;
   if (nz < 0 || nz > 32 || (nz > 0 && (!Kz || !dZ || lddz < nz))) return CLV_EINVAL;
+  if (((uintptr_t)coef_inout_dz) % 16 != 0 || ((uintptr_t)aux) % 8 != 0) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ProfScope p("lstm_mx_bwd", s);
   MxBwdArgs a{B, T, U, dhs, aux, coef_inout_dz, dzsum, Kz, nz, dZ, lddz};

@@ -282,10 +282,12 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  * frame: Kx [nx,4H] stays in LDS and only the rows of the notes that are on are added), nx <= 96, nx == 0: no frames;
  * Z: B*T rows of stride ldz, nz <= 32 latent inputs times Kz [nz,4H] as one more MFMA k-step, nz == 0: none.
  * No [B*T,4H] projection buffer exists (clv_sparse_proj + clv_lstm_seq_fwd read and write one).  Zero initial state.
- * Outputs: hs [B*T,H] and the backward pass's coefficients in the format of clv_lstm_pair_fwd:
- *   coef [B*T,4H] = (ki, kf, kg, ko) = (g i', c_{t-1} f', i g', tanh(c) o'),  aux [B*T,2,H] = (kcarry, kc) = (f, o (1 - tanh(c)^2)).
+ * Outputs: hs [B*T,H] and the backward pass's coefficients (the quantities of clv_lstm_pair_fwd) as UNIT-MAJOR records,
+ * one 16-byte and one 8-byte access per unit and step (private to this pair of entry points; 16-byte aligned buffers):
+ *   coef [B*T,H,4] = (ki, kf, kg, ko) = (g i', c_{t-1} f', i g', tanh(c) o'),  aux [B*T,H,2] = (kcarry, kc) = (f, o (1 - tanh(c)^2)).
  * clv_lstm_mx_bwd: BPTT from dhs [B*T,H]: dc += dh kc; dz = (dc ki, dc kf, dc kg, dh ko); dc *= kcarry, with
- * dh = dhs_t + dz_{t+1} . U^T on the same matrix cores; coef is overwritten in place with dz [B*T,4H], dzsum [B,4H] =
+ * dh = dhs_t + dz_{t+1} . U^T on the same matrix cores; coef is overwritten in place with dz [B*T,4H] (gate-major, the
+ * layout of the LSTM's kernel columns: what clv_lstm_wgrad_bf16 reads), dzsum [B,4H] =
  * sum_t dz.  nz > 0: dZ_t = dz_t . Kz^T as well (dZ: B*T rows of stride lddz), by one or two more waves.
  * clv_lstm_mx_supported: H == 88, nx <= 96, nz <= 32 and a batch the engine hands to these kernels (>= 768 rows;
  * CLV_LSTM_MX=1 / 0 forces / forbids them for measurements and tests). */

@@ -1092,11 +1092,11 @@ def test_lstm_mx_fwd_bwd_match_the_oracle(dev, B, Tn, nx, nz, density, gate):
     cprev = np.concatenate([np.zeros((B, 1, H)), Cs[:, :-1]], 1)
     tc = np.tanh(Cs)
     want = np.stack([g * da(Zr[:, :, 0]), cprev * da(Zr[:, :, 1]), i * (1 - g * g), tc * da(Zr[:, :, 3])], 2)
-    got = N(coef).reshape(B, Tn, 4, H)
+    got = N(coef).reshape(B, Tn, H, 4).transpose(0, 1, 3, 2)       # the record is unit-major: [unit][ki, kf, kg, ko]
     # a hard-sigmoid pre-activation within fp32 noise of a kink may fall on its other side
     bad = np.abs(got - want) > 2e-5 * (1 + np.abs(want))
     assert bad.mean() < 2e-4, bad.mean()
-    ga = N(aux).reshape(B, Tn, 2, H)
+    ga = N(aux).reshape(B, Tn, H, 2).transpose(0, 1, 3, 2)         # ... and [unit][kcarry, kc]
     np.testing.assert_allclose(ga[:, :, 0], f, atol=5e-6)
     np.testing.assert_allclose(ga[:, :, 1], o * (1 - tc * tc), atol=1e-5)
 

@@ -70,6 +70,21 @@ def test_no_valu_instruction_hides_inside_inline_asm():
     assert not found, found
 
 
+def test_no_bit_cast_of_a_vector_element():
+    """`__builtin_bit_cast(float, v.y)` on an ELEMENT of an ext_vector_type value reads element 0 with this clang (the
+    front end takes the vector's address for the cast: every lane got ki for kf, kg and ko in round 5's first build of the
+    wide record loads of csrc/lstm_mx.hip).  Elements are copied to scalars first."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = []
+    for path in sorted(glob.glob(os.path.join(root, "classifying-vae-lstm_amd", "csrc", "*.h*"))):
+        src = re.sub(r"//[^\n]*", "", open(path).read())
+        for m in re.finditer(r"__builtin_bit_cast\(\s*[\w ]+,\s*[\w\]\[]+\.[xyzw]\s*\)", src):
+            found.append((os.path.basename(path), m.group(0)))
+    assert not found, found
+
+
 def test_every_entry_point_survives_null_and_zero_arguments():
     """Error behaviour of the C ABI (include/clvae.h: "return 0 / negative CLV_E* / positive hipError_t", nothing crashes):
     every exported function called with NULL pointers, zero sizes and zero-filled structs, each in a process of its own --
