@@ -980,12 +980,15 @@ def test_reduce_launch_skinny_riders(dev, K, N, R, with_jobs):
         np.testing.assert_allclose(out[0].item(), Bs[0].astype(np.float64).mean(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("pads", [(3, 1), (4, 8)])
 @pytest.mark.parametrize("R,L,defer", [(1, 2, False), (37, 9, False), (128, 16, True), (1000, 17, True), (4096, 32, True),
-                                       (128 * 300 + 5, 32, True), (300, 1, False)])
-def test_latent_head_matches_numpy(dev, R, L, defer):
+                                       (128 * 300 + 5, 32, True), (300, 1, False), (5, 4, False), (77, 20, True), (130, 12, False)])
+def test_latent_head_matches_numpy(dev, R, L, defer, pads):
     """clv_latent_head_fwd / _bwd (cl_vrnn/model.py:200-216, 243 and their gradients) against fp64 numpy: zargs, the
     sample, the rows' KL; dzargs, dh_enc, dWz, dbz -- ragged row counts, one block per workgroup and the persistent
-    multi-block case, both padded widths (latent_dim <= 16 / <= 32), immediate and deferred reduction, Z and dZ strided."""
+    multi-block case, both padded widths (latent_dim <= 16 / <= 32), immediate and deferred reduction, Z and dZ strided.
+    pads: the strides of Z and dZ beyond latent_dim -- (4, 8) with latent_dim a multiple of 4 is what configuration 5 runs
+    (every row 16-byte aligned), (3, 1) never is."""
     from clvae_amd import ops
     rng = np.random.default_rng(R + L)
     H = 88
@@ -993,7 +996,7 @@ def test_latent_head_matches_numpy(dev, R, L, defer):
     Wz = (rng.standard_normal((H, 2 * L)) * 0.2).astype(np.float32)
     bz = (rng.standard_normal(2 * L) * 0.3).astype(np.float32)
     eps = rng.standard_normal((R, L)).astype(np.float32)
-    ldz, lddz = L + 3, L + 1
+    ldz, lddz = L + pads[0], L + pads[1]
     z = lambda *sh: torch.full(sh, -7.0, dtype=torch.float32, device=dev)
     zargs, Z, rowkl = z(R, 2 * L), z(R, ldz), z(R)
     hs_d, Wz_d, eps_d = T(hs, dev), T(Wz, dev), T(eps, dev)
