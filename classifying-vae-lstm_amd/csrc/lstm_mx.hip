@@ -115,6 +115,20 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[3]) {
 // workgroup's rows, the lane's byte offset in one VGPR, the step's row offset in an SGPR; a lane (or a step) without an
 // element gets an offset beyond num_records -- the load returns 0, the store is dropped -- so no access sits under a
 // divergent branch and the compiler's vmcnt waits stay counted.
+// Cache policy of the per-step stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  The forward pass's records are a write-once
+// stream of 550 MB per launch that nothing reads for the next ~1 ms: stored non-temporal they do not push the step's other
+// arrays out of the L2 / MALL (config 5: 1.855-1.861 -> 1.818-1.827 ms per step; all stores nt: 1.823-1.832; h is read again
+// by the next launches and keeps the default policy).  The backward pass's dz is read by the kernel-gradient product right
+// after: nt there costs 4-10 us per launch (profiles/r05_mx_store_policy_ab.txt).
+#ifndef MX_FWD_AUX
+#define MX_FWD_AUX 2
+#endif
+#ifndef MX_FWD_HAUX
+#define MX_FWD_HAUX 0
+#endif
+#ifndef MX_BWD_AUX
+#define MX_BWD_AUX 0
+#endif
 typedef __amdgpu_buffer_rsrc_t mx_rsrc_t;
 constexpr unsigned MX_OOB = 0x80000000u;
 __device__ __forceinline__ mx_rsrc_t mx_rsrc(const void* p, size_t bytes) {
@@ -123,25 +137,32 @@ __device__ __forceinline__ mx_rsrc_t mx_rsrc(const void* p, size_t bytes) {
 __device__ __forceinline__ float mx_load(mx_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+template <int AUX = MX_BWD_AUX>
 __device__ __forceinline__ void mx_store(float v, mx_rsrc_t r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, AUX);
 }
 typedef unsigned mx_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned mx_u32x4 __attribute__((ext_vector_type(4)));
+template <int AUX = MX_BWD_AUX>
 __device__ __forceinline__ void mx_store2(float a, float b, mx_rsrc_t r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b64((mx_u32x2){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)}, r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64((mx_u32x2){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)}, r, (int)voff, (int)soff, AUX);
 }
+template <int AUX = MX_BWD_AUX>
 __device__ __forceinline__ void mx_store4(float a, float b, float c, float d, mx_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b128((mx_u32x4){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
-                                                    __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)}, r, (int)voff, (int)soff, 0);
+                                                    __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)}, r, (int)voff, (int)soff, AUX);
 }
+// (the backward pass reads each record once: loaded nt, -8 to -10 us per config-5 step, same file)
+#ifndef MX_BWD_LAUX
+#define MX_BWD_LAUX 2
+#endif
 __device__ __forceinline__ void mx_load2(float& a, float& b, mx_rsrc_t r, unsigned voff, unsigned soff) {
-  const mx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  const mx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, MX_BWD_LAUX);
   const unsigned x = v.x, y = v.y;      // (not __builtin_bit_cast(float, v.y): on a vector ELEMENT this clang reads element 0)
   a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
 }
 __device__ __forceinline__ void mx_load4(float& a, float& b, float& c, float& d, mx_rsrc_t r, unsigned voff, unsigned soff) {
-  const mx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  const mx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, MX_BWD_LAUX);
   const unsigned x = v.x, y = v.y, z = v.z, w = v.w;
   a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y); c = __builtin_bit_cast(float, z); d = __builtin_bit_cast(float, w);
 }
@@ -400,9 +421,9 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     if (MX_ABL & 2) return;
     if (MX_ABL & 16) tt = tt == 0xffffffffu ? tt : 0u;
     switch (k) {        // one 16-byte, one 8-byte and one 4-byte store per lane and step (seven 4-byte ones: +9-27 us per launch)
-      case 0: mx_store4(pend[0], pend[1], pend[2], pend[3], r_c, v_c, tt * (LG * 4)); break;
-      case 1: mx_store2(pend[4], pend[5], r_a, v_a, tt * (2 * LH * 4)); break;
-      case 2: mx_store(pend[6], r_h, v_h, tt * (LH * 4)); break;
+      case 0: mx_store4<MX_FWD_AUX>(pend[0], pend[1], pend[2], pend[3], r_c, v_c, tt * (LG * 4)); break;
+      case 1: mx_store2<MX_FWD_AUX>(pend[4], pend[5], r_a, v_a, tt * (2 * LH * 4)); break;
+      case 2: mx_store<MX_FWD_HAUX>(pend[6], r_h, v_h, tt * (LH * 4)); break;
       default: break;
     }
   };
