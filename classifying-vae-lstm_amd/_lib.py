@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CLV_LIB: another build of the same ABI (A/B measurements inside one GPU session; tools/build_variant.sh)
 LIB_PATH = os.environ.get("CLV_LIB") or os.path.join(_HERE, "libclvae_hip.so")
 
-ABI_VERSION = 400      # CLV_ABI_VERSION of include/clvae.h
+ABI_VERSION = 500      # CLV_ABI_VERSION of include/clvae.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_MASKPOS = 0, 1, 2, 3
 GATE_HARD_SIGMOID, GATE_SIGMOID = 0, 1
 

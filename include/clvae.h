@@ -77,8 +77,10 @@ typedef struct clv_batch_cursor {
  *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
  *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
  *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair, clv_dense_outer_bf16,
- *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts, clv_vrnn_label_fwd_x_staged, clv_vae_fused_step_staged (additions only) */
-#define CLV_ABI_VERSION 400
+ *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts, clv_vrnn_label_fwd_x_staged, clv_vae_fused_step_staged (additions only)
+ *   500  round 5: the coef / aux buffers between clv_lstm_mx_fwd and clv_lstm_mx_bwd are unit-major records ([B*T,H,4] and
+ *        [B*T,H,2]; same sizes); clv_lstm_seq_fwd / _bwd take any H <= 1024; + clv_dropout_rows */
+#define CLV_ABI_VERSION 500
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
 int clv_device_count(void);
