@@ -101,3 +101,41 @@ def test_lazy_windows_equal_the_materialised_arrays(tmp_path, kw):
         np.testing.assert_array_equal(getattr(E, '%s_song_keys' % split), getattr(Lz, '%s_song_keys' % split))
     assert isinstance(Lz.x_train, PR.Windows)
     assert Lz.x_train.store.dtype == np.uint8 and Lz.x_train.store.nbytes * T // 2 < E.x_train.nbytes // 8
+
+
+@pytest.mark.parametrize("T,bs", [(2, 100), (3, 64)])
+def test_flatten_windows_matches_the_reference_lines(T, bs, tmp_path):
+    """G9: `cl_vae/train.py --seq_length T` (T > 1).  The reference's own lines cl_vae/train.py:21-30, run on windows from
+    the reference's own loader on the real JSB_Cs, against this build's `flatten_windows` on the G7-rebuilt pickle: the
+    note mask, `original_dim` and all six flattened arrays."""
+    import types
+    from clvae_amd.cl_vae.train import SPLITS, flatten_windows
+    G9 = golden("g9_flatten_windows.npz")
+    path = write_jsb_pickle('Cs', str(tmp_path / 'JSB Chorales_Cs.pickle'))
+    P = PR.PianoData(path, batch_size=bs, seq_length=T, step_length=1, return_y_next=False, squeeze_x=True, squeeze_y=True)
+    args = types.SimpleNamespace(seq_length=T, original_dim=88)
+    flatten_windows(P, args)
+    tag = 'Cs_b%d_t%d' % (bs, T)
+    assert args.original_dim == int(G9[tag + '/original_dim']) == int(G9[tag + '/mask'].sum()) * T
+    assert isinstance(args.original_dim, int)           # it goes into <run>.json
+    for nm in SPLITS:
+        a = getattr(P, nm)
+        assert tuple(G9['%s/%s/shape' % (tag, nm)]) == a.shape and a.shape[1] == args.original_dim
+        assert float(G9['%s/%s/sum' % (tag, nm)]) == a.sum()
+        assert int(G9['%s/%s/sha' % (tag, nm)]) == int(sha(a.astype(np.uint8)))
+        np.testing.assert_array_equal(G9['%s/%s/head' % (tag, nm)], a[:3])
+        np.testing.assert_array_equal(G9['%s/%s/tail' % (tag, nm)], a[-3:])
+
+
+def test_flatten_windows_refuses_single_frame_targets_like_the_reference(tmp_path):
+    """`--seq_length 2 --use_x_prev` (or --predict_next): the targets are single frames [n, 88] next to windows [n, 2, 88]
+    and the reference's np.vstack (cl_vae/train.py:22) raises ValueError (recorded in G9); so does this build."""
+    import types
+    from clvae_amd.cl_vae.train import flatten_windows
+    G9 = golden("g9_flatten_windows.npz")
+    assert str(G9['Cs_b100_t2_y_next/raises']) == 'ValueError'
+    path = write_jsb_pickle('Cs', str(tmp_path / 'JSB Chorales_Cs.pickle'))
+    P = PR.PianoData(path, batch_size=100, seq_length=2, step_length=1, return_y_next=True, squeeze_x=True, squeeze_y=True)
+    assert P.x_train.shape == tuple(G9['Cs_b100_t2_y_next/x_shape']) and P.y_train.shape == tuple(G9['Cs_b100_t2_y_next/y_shape'])
+    with pytest.raises(ValueError):
+        flatten_windows(P, types.SimpleNamespace(seq_length=2, original_dim=88))
