@@ -215,11 +215,13 @@ def aggregate_sq(sq_csv):
     return out
 
 
-def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
+def measure_pmc_traffic(workload, bf16=False, timeout_s=(150, 60, 60)):
     """The two PMC passes as CHILD processes of this one -- `rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py
     --workload W --steps 6 --warmup 3 --no-graph ...` -- started before this process has touched the GPU (nothing is exec'd
     over a GPU-initialised process; the program after `--` is python3 itself; a PMC pass carries no other trace domain).
-    Returns aggregate_pmc()'s dict, or {'error': ...}: the caller then falls back to the committed summary."""
+    Returns aggregate_pmc()'s dict, or {'error': ...}: the caller then falls back to the committed summary.
+    timeout_s: per pass; the first one may be the box's first `import torch` (1-2 minutes on a fresh image), the others take
+    seconds -- a hung profiler costs the headline at most 4.5 minutes, and the first failure ends the passes."""
     import shutil
     import signal
     import subprocess
@@ -231,8 +233,9 @@ def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
     try:
         csvs = {}
         # three passes: the two traffic counters each alone (the guide's rule), then the SQ counters of the busy fractions
-        for counter, pmc_list in (('FETCH_SIZE', ['FETCH_SIZE']), ('WRITE_SIZE', ['WRITE_SIZE']),
-                                  ('SQ', ['SQ_BUSY_CU_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY'])):
+        for ipass, (counter, pmc_list) in enumerate((('FETCH_SIZE', ['FETCH_SIZE']), ('WRITE_SIZE', ['WRITE_SIZE']),
+                                                     ('SQ', ['SQ_BUSY_CU_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY']))):
+            limit = timeout_s[ipass]
             out = os.path.join(tmp, counter)
             cmd = [rp, '--pmc'] + pmc_list + ['--kernel-trace', '-d', out, '-o', 't', '--output-format', 'csv', '--',
                    sys.executable, os.path.abspath(__file__), '--workload', workload, '--steps', '6', '--warmup', '3',
@@ -241,7 +244,7 @@ def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
             pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                   start_new_session=True)
             try:
-                so, se = pr.communicate(timeout=timeout_s)
+                so, se = pr.communicate(timeout=limit)
             except subprocess.TimeoutExpired:
                 try:
                     os.killpg(pr.pid, signal.SIGKILL)
@@ -250,7 +253,7 @@ def measure_pmc_traffic(workload, bf16=False, timeout_s=240):
                 pr.communicate()
                 if counter == 'SQ':
                     break
-                return dict(error="the %s pass passed %d s and was killed" % (counter, timeout_s))
+                return dict(error="the %s pass passed %d s and was killed" % (counter, limit))
             found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('counter_collection.csv')]
             if pr.returncode != 0 or not found:
                 if counter == 'SQ':      # the busy fractions are an extra: the traffic stands without them
@@ -749,7 +752,7 @@ def also_in_child(timeout_s=600):
     except OSError as ex:
         return [{"error": "could not start the child: %r" % (ex,)}]
     try:
-        so, se = pr.communicate(timeout=timeout_s)
+        so, se = pr.communicate(timeout=limit)
     except subprocess.TimeoutExpired:
         try:
             os.killpg(pr.pid, signal.SIGKILL)

@@ -81,13 +81,9 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&piece)[3
 #ifndef WB_PRODUCTS
 #define WB_PRODUCTS 6    // piece pairs of an h . dz product: 6 = those with pa + pb <= 2 (default), 9 = all (-DWB_PRODUCTS=9)
 #endif
-// WB_SHARE (round 5): who turns the h and x rows of a stage into bf16 pieces.  0: the four data-moving waves do everything
-// (round 4).  1 (default): the four MFMA waves take the h and x rows -- a third of the conversion work -- in the issue
-// slots their MFMAs leave free, the data movers keep dz (and z).  The stamps of round 4 (profiles/r04_mx_log.txt, 13) had
-// the data movers at 4900-6150 cycles per stage against an MFMA floor of 2592 (162 MFMAs x 16): the stage waited for them.
-#ifndef WB_SHARE
-#define WB_SHARE 1
-#endif
+// (round 5 tried the MFMA waves converting the h and x rows themselves: spills or no gain; the patch is
+// tools/experiments/r05_wgrad_symmetric_waves.patch, the numbers profiles/r05_wgrad_symmetric_ab.txt.  The shipped schedule is
+// round 4's: waves 0-3 issue MFMAs, waves 4-7 move and convert every operand.)
 #ifndef WB_ABLATE
 #define WB_ABLATE 0      // measurement builds (tools/build_variant.sh): 1 = no piece splitting, 2 = one MFMA term of nine,
 #endif                   // 3 = no global loads after the first stages.  Results are wrong by design.
@@ -144,78 +140,6 @@ __device__ unsigned long long g_wb_wg[1024][5];
 // Stage barrier: this wave's LDS traffic is done, its global loads are NOT waited for (__syncthreads() would add
 // s_waitcnt vmcnt(0) and drain the producers' prefetch at every stage).
 __device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// The h and x rows of a stage: global -> registers (two stages in flight) -> bf16 pieces -> LDS images.  Used by the data
-// movers (WB_SHARE == 0) or by the MFMA waves (WB_SHARE == 1); `pt` = this thread's index among the 256 of its role.
-constexpr int WB_ROW0 = 1 << 30, WB_ROW16 = 1 << 29, WB_IDLE = 1 << 31, WB_OFFM = WB_ROW16 - 1;
-template <int HM, int XP>
-struct HxStager {
-  using G = WbGeo<HM>;
-  static constexpr int A_L = 3, HPB = G::HPB, NP_T = WB_NT / 2;
-  static_assert(A_L * NP_T >= WB_KS * (96 / 4), "h / x slots: 32 rows x 96 columns (clv_lstm_wgrad_supported: nh, nx <= 96)");
-  struct Regs { float4 h[A_L], x[A_L]; };
-  const WgradArgs& a;
-  int k_begin, k_end;
-  bool aligned;
-  unsigned h_g[A_L], x_g[A_L];
-  int h_l[A_L], x_l[A_L];          // LDS offsets; bit 30: row 0 of the stage (h), bit 29: row 16, bit 31: idle slot
-  __device__ __forceinline__ HxStager(const WgradArgs& a_, int pt, int kb, int ke) : a(a_), k_begin(kb), k_end(ke) {
-    const int nh4 = a.nh / 4, nx4 = a.nx / 4;
-    aligned = a.h_zero_period == 0 || a.h_zero_period % (WB_KS / 2) == 0;
-#pragma unroll
-    for (int i = 0; i < A_L; ++i) {
-      const int e = pt + i * NP_T;
-      const int okh = e < WB_KS * nh4, eh = okh ? e : 0, rh = eh / nh4, ch = eh % nh4;
-      const int okx = e < WB_KS * nx4, ex = okx ? e : 0, rx = ex / nx4, cx = ex % nx4;
-      h_g[i] = 4u * (unsigned)(rh * a.ldh + 4 * ch);
-      h_l[i] = ((rh * HPB + 8 * ch) ^ WB_SWZ_OF(rh)) | (rh == 0 ? WB_ROW0 : 0) | (rh == 16 ? WB_ROW16 : 0) | (okh ? 0 : WB_IDLE);
-      x_g[i] = 4u * (unsigned)(rx * a.ldx + 4 * cx);
-      x_l[i] = ((rx * WB_AP + 8 * cx) ^ WB_SWZ_OF(rx)) | (okx ? 0 : WB_IDLE);
-    }
-  }
-  __device__ __forceinline__ bool interior(int s) const {
-    const int k0 = k_begin + s * WB_KS;
-    return aligned && k0 + WB_KS <= k_end && k0 >= a.h_shift;
-  }
-  __device__ __forceinline__ void load(Regs& q, int s) const {        // nothing uses the values until store()
-    if (WB_ABLATE == 3 && s > 2) return;
-    const int k0 = k_begin + s * WB_KS;
-    if (interior(s)) {
-      const char* hb = reinterpret_cast<const char*>(a.H + (size_t)(k0 - a.h_shift) * a.ldh);
-      const char* xb = reinterpret_cast<const char*>(a.X + (size_t)k0 * a.ldx);
-#pragma unroll
-      for (int i = 0; i < A_L; ++i) {
-        q.h[i] = *reinterpret_cast<const float4*>(hb + h_g[i]);
-        q.x[i] = *reinterpret_cast<const float4*>(xb + x_g[i]);
-      }
-      return;
-    }
-    auto row = [&](unsigned g, int ld, int shift) { const int r = (int)(g / 4u) / ld; return min(max(k0 + r - shift, 0), a.K - 1) - r; };
-#pragma unroll
-    for (int i = 0; i < A_L; ++i) {
-      q.h[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.H + (size_t)row(h_g[i], a.ldh, a.h_shift) * a.ldh) + h_g[i]);
-      q.x[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.X + (size_t)row(x_g[i], a.ldx, 0) * a.ldx) + x_g[i]);
-    }
-  }
-  __device__ __forceinline__ static float4 keep(const float4& v, bool live) { return live ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
-  // slot i of stage s -> the h and x images `hi` / `xi` (of buffer s & 1)
-  __device__ __forceinline__ void store_slot(const Regs& q, int s, int i, char* hi, char* xi) const {
-    const int k0 = k_begin + s * WB_KS;
-    const bool fast = interior(s);
-    const bool wstart = a.h_zero_period != 0 && k0 % a.h_zero_period == 0;     // row 0 of the stage starts a window
-    const bool wstart16 = a.h_zero_period != 0 && (k0 + WB_KS / 2) % a.h_zero_period == 0;      // ... row 16 does
-    const int rh = (h_l[i] & WB_OFFM) / HPB, rx = (x_l[i] & WB_OFFM) / WB_AP, k = k0 + rh;
-    // H'_k = h of the previous step; zero at the start of a window
-    const bool live = fast ? !((wstart && (h_l[i] & WB_ROW0)) || (wstart16 && (h_l[i] & WB_ROW16)))
-                           : (k < k_end && k >= a.h_shift && (a.h_zero_period == 0 || k % a.h_zero_period != 0));
-    if (i + 1 < A_L || !(h_l[i] & WB_IDLE)) put4<3>(hi + (h_l[i] & WB_OFFM), WB_KS * HPB, keep(q.h[i], live));
-    if (i + 1 < A_L || !(x_l[i] & WB_IDLE)) put4<XP>(xi + (x_l[i] & WB_OFFM), WB_KS * WB_AP, fast ? q.x[i] : keep(q.x[i], k0 + rx < k_end));
-  }
-  __device__ __forceinline__ void store(const Regs& q, int s, char* hi, char* xi) const {
-#pragma unroll
-    for (int i = 0; i < A_L; ++i) store_slot(q, s, i, hi, xi);
-  }
-};
 
 template <int HM, int XP>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {

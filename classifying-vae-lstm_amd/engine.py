@@ -14,6 +14,7 @@ buffer; gradients, Adam m/v use the same layout; the weight-norm column state
 import contextlib
 import ctypes as C
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -566,6 +567,9 @@ class VrnnEngine(_EngineBase):
         # generic chain: GEMM (or row-gather) input projections + csrc/lstm_any.hip + the GEMM heads.
         d = self.device
         BT = B * T
+        if H != 88:       # once per width (the warnings filter's default): a user of --intermediate_dim should know what runs
+            warnings.warn("cl_vrnn with %d LSTM units runs on the generic kernels (csrc/lstm_any.hip, GEMM heads): several times "
+                          "slower per step than the default 88 units, which the fused kernels are laid out for" % H, stacklevel=2)
         self.gate_act = _lib.GATE_HARD_SIGMOID if cfg.get('gate_act', 'hard_sigmoid') == 'hard_sigmoid' \
             else _lib.GATE_SIGMOID
         self.off = D if cfg['use_x_prev'] else 0     # decoder kernel rows: [Xp | Z | W]
@@ -672,9 +676,16 @@ class VrnnEngine(_EngineBase):
         if self.dropout:
             in_e, in_d = D + Cn, self.off + L + Cn
             self.u_enc, self.u_dec = _f(d, B, 4, in_e), _f(d, B, 4, in_d)          # the masks uniforms [row][gate][input] (clv_dropout_rows)
+            self._masks_given = False      # u_enc / u_dec hold nothing until a pass draws them (noise=...) or set_dropout_uniforms()
             self.xm_e, self.xm_d = _f(d, 4, BT, D), _f(d, 4, BT, self.xz_ld)       # a gate's masked per-step inputs
             self.wm_e, self.wm_d = _f(d, 4, B, Cn), _f(d, 4, B, Cn)                # ... and masked label rows
             self.dxg, self.dwg = _f(d, BT, self.xz_ld), _f(d, B, Cn)               # a gate's share of dL/d[Xp | Z], dL/dW
+
+    def set_dropout_uniforms(self, u_enc, u_dec):
+        """The uniforms behind the two LSTMs' input-dropout masks ([B, 4, D + C] and [B, 4, (D) + L + C], m = (u >= p) / (1 - p)) as
+        explicit inputs, like eps_W / eps_Z: a training pass without `noise=` uses them."""
+        self.u_enc.copy_(u_enc.view_as(self.u_enc)); self.u_dec.copy_(u_dec.view_as(self.u_dec))
+        self._masks_given = True
 
     def folds_noise(self):
         """True when forward(noise=...) draws eps_W / eps_Z inside the label and pair kernels (no Philox launch)."""
@@ -711,6 +722,10 @@ class VrnnEngine(_EngineBase):
                 for u, sid in ((self.u_enc, 2), (self.u_dec, 3)):
                     per_row = u.shape[1] * u.shape[2]
                     ops.philox_uniform(u, B * per_row, noise[0], noise[5], sid, row0 * per_row, step_dev=noise[6])
+                self._masks_given = True
+            elif not self._masks_given:
+                raise RuntimeError("training pass with dropout=%g and neither noise=... nor set_dropout_uniforms(): the masks "
+                                   "would come from uninitialised memory" % self.dropout)
             return self._forward_dropout(X, eps_W, eps_Z, w_true, nll, target)
         fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
         fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)

@@ -328,8 +328,10 @@ def test_cl_vrnn_step_with_lstm_input_dropout_matches_oracle(dev, H, B, Tn, L, C
     eng = VrnnEngine(dict(cfg, dropout=rate), B, dev)
     assert eng.dropout == rate and not eng.fuse_pair and not eng.use_mx
     eng.P.set_weights(p)
-    eng.u_enc.copy_(T(ue, dev)); eng.u_dec.copy_(T(ud, dev))
     args = (T(X, dev), T(Xp, dev), T(wt, dev), T(eW, dev), T(eZ, dev))
+    with pytest.raises(RuntimeError):          # no masks yet (neither noise=... nor injected uniforms): refuse, do not read junk
+        eng.loss_and_grads(*args)
+    eng.set_dropout_uniforms(T(ue, dev), T(ud, dev))
     eng.loss_and_grads(*args)
     torch.cuda.synchronize()
     got = eng.losses()
