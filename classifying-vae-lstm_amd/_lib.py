@@ -146,7 +146,7 @@ SIGNATURES = {
     "clv_lstm_seq_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_seq_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_mx_supported": (_i, [_i, _i, _i, _i]),
-    "clv_lstm_mx_fwd": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_lstm_mx_fwd": (_i, [_i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_mx_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p]),
     "clv_lstm_pair_supported": (_i, [_i, _i]),
     "clv_lstm_pair_pack_floats": (_sz, []),
@@ -165,14 +165,14 @@ SIGNATURES = {
     "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p]),
     "clv_sparse_outer_ex": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "clv_dense_outer_bf16_supported": (_i, [_i, _i, _i, _i, _i]),
-    "clv_dense_outer_bf16": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
+    "clv_dense_outer_bf16": (_i, [_i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "clv_gemm_bce_f32": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _i, _p, _p]),
     "clv_out_head_train_supported": (_i, [_i, _i]),
     "clv_out_head_train_workspace_bytes": (_sz, [_i]),
-    "clv_out_head_train": (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
+    "clv_out_head_train": (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "clv_latent_head_supported": (_i, [_i, _i]),
     "clv_latent_head_bwd_workspace_bytes": (_sz, [_i, _i]),
-    "clv_latent_head_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "clv_latent_head_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "clv_latent_head_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "clv_vrnn_generate_supported": (_i, [_i, _i, _i, _i]),
     "clv_vrnn_generate": (_i, [_i] * 9 + [_u64] + [_p] * 18),
@@ -197,7 +197,7 @@ SIGNATURES = {
     "clv_dense_window_fwd_bf16_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_dense_window_fwd_bf16_splits": (_i, [_i, _i]),
     "clv_dense_window_fwd_bf16_workspace_bytes": (_sz, [_i, _i, _i]),
-    "clv_dense_window_fwd_bf16": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _sz, _p]),
+    "clv_dense_window_fwd_bf16": (_i, [_i, _i, _i, _p, _i, _i, _p, _i, _p, _sz, _p]),
     "clv_vrnn_label_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "clv_vrnn_label_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_vrnn_label_bwd_ex": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, _p, _sz,

@@ -17,6 +17,7 @@
 // Head columns are PADDED per half to a multiple of 16 (LP16 tiles each): column c of the mean sits at c, of log_var at
 // 16*LP16 + c, so that a lane of the C/D layout holds both values of a latent.
 #include "common.h"
+#include "philox.h"
 #include "reduce_job.h"
 
 namespace clv {
@@ -39,11 +40,56 @@ struct LatentFwdArgs {
   const float* hs;        // [R,88]
   const float* Wz;        // [88,2L]
   const float* bz;        // [2L]
-  const float* eps;       // [R,L]
+  float* eps;             // [R,L]: read, or drawn here and written (noise.on; the backward pass reads it)
   float* zargs;           // [R,2L]
   float* Z;               // [R] rows of stride ldz
   float* rowkl;           // [R] or null
+  struct { int on; uint32_t k0, k1, stream, step; uint64_t first; const int32_t* step_dev; } noise;
 };
+
+// eps of a wave's 16-row tile drawn in the accumulators' C/D layout (lane (q, r), register reg: row 4 q + reg, column
+// 16 jm + r): element (row, c) is the clv_philox_normal value at index first + row * L + c, bit for bit.
+// A Philox counter yields the four normals of indices 4 k .. 4 k + 3: when L and `first` are multiples of 4 those are four
+// neighbouring columns of ONE row, i.e. what the four lanes of a DPP quad hold in one register -- so lane i of a quad draws
+// the counter of row 4 q + i (one Philox call instead of four per lane and column tile) and a 4 x 4 transpose inside the
+// quad (two DPP exchange rounds) hands every lane its four rows.  Any other L: one call per element.
+template <int CTRL>
+__device__ __forceinline__ float zh_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LP16>
+__device__ __forceinline__ void zh_draw_eps(const LatentFwdArgs& a, uint32_t stp, int row0, int q, int r, float (&ev)[LP16][4]) {
+  const int L = a.L;
+  if ((L & 3) == 0 && (a.noise.first & 3) == 0) {
+    const int i = r & 3;
+    const uint64_t rowi = (uint64_t)min(row0 + 4 * q + i, a.R - 1);
+#pragma unroll
+    for (int jm = 0; jm < LP16; ++jm) {
+      const int cg = min(16 * jm + (r & ~3), L - 4);
+      const uint64_t ctr = (a.noise.first + rowi * (uint64_t)L + (uint64_t)cg) >> 2;
+      uint32_t w[4];
+      philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), a.noise.stream, stp, a.noise.k0, a.noise.k1, w);
+      const float rad0 = sqrtf(-2.f * logf(u01(w[0]))), th0 = 6.283185307179586f * u01(w[1]);
+      const float rad1 = sqrtf(-2.f * logf(u01(w[2]))), th1 = 6.283185307179586f * u01(w[3]);
+      float n0 = rad0 * cosf(th0), n1 = rad0 * sinf(th0), n2 = rad1 * cosf(th1), n3 = rad1 * sinf(th1);
+      // transpose: lane i element k  <->  lane k element i
+      const bool o1 = i & 1, o2 = i & 2;
+      const float s01 = zh_dpp<0xB1>(o1 ? n0 : n1), s23 = zh_dpp<0xB1>(o1 ? n2 : n3);      // quad_perm [1,0,3,2]
+      if (o1) { n0 = s01; n2 = s23; } else { n1 = s01; n3 = s23; }
+      const float s02 = zh_dpp<0x4E>(o2 ? n0 : n2), s13 = zh_dpp<0x4E>(o2 ? n1 : n3);      // quad_perm [2,3,0,1]
+      if (o2) { n0 = s02; n1 = s13; } else { n2 = s02; n3 = s13; }
+      ev[jm][0] = n0; ev[jm][1] = n1; ev[jm][2] = n2; ev[jm][3] = n3;
+    }
+    return;
+  }
+#pragma unroll
+  for (int jm = 0; jm < LP16; ++jm)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const uint64_t e = (uint64_t)min(row0 + 4 * q + reg, a.R - 1) * (uint64_t)L + (uint64_t)min(16 * jm + r, L - 1);
+      ev[jm][reg] = philox_normal_at(a.noise.first + e, a.noise.k0, a.noise.k1, a.noise.stream, stp);
+    }
+}
 
 // this wave's 16 rows of hs: one contiguous 5.6 KB piece of HBM, 6 float4 per lane -> its LDS tile [16][ZH_LD]
 __device__ __forceinline__ void zh_load_hs(const float* hs, int row0, int R, int lane, float4 (&hv)[6]) {
@@ -100,9 +146,12 @@ __global__ __launch_bounds__(64 * ZH_NW) void latent_head_fwd_kernel(LatentFwdAr
   // loads at the top of each block the kernel was a chain of exposed HBM round trips: 72 us for 3 GFLOP)
   float4 hv[6];
   float ev[LP16][4];                                   // eps of this lane's outputs (C/D layout: rows 4q + reg, column 16 jm + r)
+  const bool draw = a.noise.on != 0;                   // (uniform)
+  const uint32_t stp = a.noise.step + ((draw && a.noise.step_dev) ? (uint32_t)*a.noise.step_dev : 0u);
   auto fetch = [&](int blk) {                          // (rows beyond R: clamped addresses, masked where they are used)
     const int row0 = blk * ZH_RB + wave * 16;
     zh_load_hs(a.hs, row0, a.R, lane, hv);
+    if (draw) return;
 #pragma unroll
     for (int jm = 0; jm < LP16; ++jm)
 #pragma unroll
@@ -114,11 +163,16 @@ __global__ __launch_bounds__(64 * ZH_NW) void latent_head_fwd_kernel(LatentFwdAr
     const int row0 = blk * ZH_RB + wave * 16;
     zh_store_hs(myhs, row0, a.R, lane, hv, false);
     float ec[LP16][4];
+    if (draw) {        // the next block's loads go out first: the draw's VALU work (two Philox calls per lane) runs under them
+      fetch(blk + gridDim.x);
+      zh_draw_eps<LP16>(a, stp, row0, q, r, ec);
+    } else {
 #pragma unroll
-    for (int jm = 0; jm < LP16; ++jm)
+      for (int jm = 0; jm < LP16; ++jm)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) ec[jm][reg] = ev[jm][reg];
-    fetch(blk + gridDim.x);
+        for (int reg = 0; reg < 4; ++reg) ec[jm][reg] = ev[jm][reg];
+      fetch(blk + gridDim.x);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is wave-private: no barrier
 
     f32x4 acc[NTZ];
@@ -165,6 +219,7 @@ __global__ __launch_bounds__(64 * ZH_NW) void latent_head_fwd_kernel(LatentFwdAr
           a.zargs[(size_t)row * 2 * L + c] = m;
           a.zargs[(size_t)row * 2 * L + L + c] = lv;
           a.Z[(size_t)row * a.ldz + c] = z;
+          if (draw) a.eps[(size_t)row * L + c] = ec[jm][reg];
         }
       }
       ssum += __shfl_xor(ssum, 8, 64);
@@ -356,13 +411,18 @@ extern "C" size_t clv_latent_head_bwd_workspace_bytes(int R, int L) {
   return (R > 0 && L > 0) ? (size_t)clv::latent_head_wgs(R) * clv::ZH_SLAB_ROWS * 2 * L * sizeof(float) : 0;
 }
 
-extern "C" int clv_latent_head_fwd(int R, int H, int L, const float* hs, const float* Wz, const float* bz, const float* eps,
-                                   float* zargs, float* Z, int ldz, float* rowkl, void* stream) {
+extern "C" int clv_latent_head_fwd(int R, int H, int L, const float* hs, const float* Wz, const float* bz, float* eps,
+                                   float* zargs, float* Z, int ldz, float* rowkl, const clv_noise_draw* noise, void* stream) {
   using namespace clv;
   if (!clv_latent_head_supported(H, L) || R <= 0 || ldz < L) return CLV_EINVAL;
   if (!hs || !Wz || !bz || !eps || !zargs || !Z || ((uintptr_t)hs) % 16 != 0) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  LatentFwdArgs a{R, L, ldz, hs, Wz, bz, eps, zargs, Z, rowkl};
+  LatentFwdArgs a{R, L, ldz, hs, Wz, bz, eps, zargs, Z, rowkl, {}};
+  if (noise) {
+    a.noise.on = 1; a.noise.k0 = (uint32_t)noise->seed; a.noise.k1 = (uint32_t)(noise->seed >> 32);
+    a.noise.stream = noise->stream; a.noise.step = noise->step; a.noise.first = noise->first;
+    a.noise.step_dev = noise->step_dev;
+  }
   const int wgs = latent_head_wgs(R);
   ProfScope p("latent_head_fwd", s);
   if (L <= 16) {

@@ -87,7 +87,7 @@ struct MxItem { int koff; float v; };       // byte offset of the K_x image row,
 
 struct MxFwdArgs {
   int B, T;
-  const float* X; int ldx, nx; const float* Kx;       // frames: B*T rows of stride ldx, nx columns; Kx [nx,352]
+  const void* X; int ldx, nx; const float* Kx;        // frames: B*T rows of stride ldx, nx columns (float, or bytes in the XU8 kernels); Kx [nx,352]
   const float* Z; int ldz, nz; const float* Kz;       // latent inputs (decoder): B*T rows of stride ldz; Kz [nz,352]
   const float* rowbias; const float* U;
   float* hs; float* coef; float* aux;
@@ -185,11 +185,14 @@ __device__ __forceinline__ void mx_load4(float& a, float& b, float& c, float& d,
 // wave (~5 cycles per instruction of a wave, whatever the instruction): with both jobs in the one-tile wave 7 that wave
 // ran ~400 instructions per step (2770 cycles) while waves 0-3 sat at the barrier after 1500; the jobs now ride in
 // waves 0 and 1, which are the first to be served on their SIMDs (decoder: lists in wave 7, z pieces in wave 1).
-template <int GATE, bool HASZ, bool HASX, int NT, int ROLE>
+template <int GATE, bool HASZ, int XMODE, int NT, int ROLE>
 __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int ubase) {
   // HASX is a template parameter, not `a.nx > 0`: requests under a run-time branch, even a uniform one, count as "maybe
   // not issued" in the compiler's vmcnt bookkeeping, and the wait for the frames requested two steps ago then also waited
   // for the stores of the previous step -- 980 cycles per step in the producer wave (tools/mx_stamps.py)
+  // XMODE: 0 no frames, 1 float frames, 2 frames as bytes (round 6: ldx in bytes; a requested byte travels raw, zero-extended, in
+  // the register a float would take and is widened where the list is built)
+  constexpr bool HASX = XMODE != 0, XU8 = XMODE == 2;
   constexpr bool PROD = (ROLE & 1) != 0, ZPROD = (ROLE & 2) != 0 && HASZ;
   const int lane = threadIdx.x & 63;
   const int ul = lane >> 4, n = lane & 15, r = n >> 2, p = n & 3;
@@ -280,10 +283,17 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
   float zr[2][2];            // ... and of z pairs
   const int zlat = 2 * pj;
   auto load_frames = [&](float (&f)[PC], int t) {
-    const float* fp = a.X + ((size_t)min(row0 + pr, a.B - 1) * T + min(t, T - 1)) * a.ldx;
+    const size_t frame = ((size_t)min(row0 + pr, a.B - 1) * T + min(t, T - 1)) * a.ldx;
+    if (XU8) {
+      const unsigned char* bp = static_cast<const unsigned char*>(a.X) + frame;
 #pragma unroll
-    for (int i = 0; i < PC; ++i) f[i] = fp[min(PC * pj + i, a.nx - 1)];      // raw: nothing touches a requested value before
-  };                                                                          // its consumer does
+      for (int i = 0; i < PC; ++i) f[i] = __builtin_bit_cast(float, (unsigned)bp[min(PC * pj + i, a.nx - 1)]);
+    } else {
+      const float* fp = static_cast<const float*>(a.X) + frame;
+#pragma unroll
+      for (int i = 0; i < PC; ++i) f[i] = fp[min(PC * pj + i, a.nx - 1)];    // raw: nothing touches a requested value before
+    }                                                                         // its consumer does
+  };
   auto load_z = [&](float (&z)[2], int t) {
     const float* zp = a.Z + ((size_t)min(row0 + pr, a.B - 1) * T + min(t, T - 1)) * a.ldz;
     z[0] = zp[min(zlat, a.nz - 1)];
@@ -297,7 +307,7 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < PC; ++i) {
-      on[i] = PC * pj + i < a.nx && f[i] != 0.f;
+      on[i] = PC * pj + i < a.nx && (XU8 ? __builtin_bit_cast(unsigned, f[i]) != 0u : f[i] != 0.f);
       cnt += on[i] ? 1 : 0;
     }
     MXPSTAMP(0, cnt);                                      // the frame values are here
@@ -313,7 +323,7 @@ __device__ __forceinline__ void mx_fwd_body(const MxFwdArgs& a, char* lds, int u
 #pragma unroll
     for (int i = 0; i < PC; ++i) {
       MxItem* at = on[i] ? L + pos : mine;
-      *at = MxItem{(PC * pj + i) * MX_KP, f[i]};
+      *at = MxItem{(PC * pj + i) * MX_KP, XU8 ? (float)__builtin_bit_cast(unsigned, f[i]) : f[i]};
       pos += on[i] ? 1 : 0;
     }
     // beyond 16 notes: pad up to the next round of four (a row's consumers walk its own count)
@@ -601,7 +611,7 @@ constexpr size_t mx_fwd_lds(int nx) {
   return (size_t)(nx + 1) * MX_KP + 2 * MX_HC * MX_CHUNK + 2 * MX_ZC * MX_CHUNK + (2 * MX_R * MX_CAP + 64) * sizeof(MxItem) + 2 * MX_R * 4;
 }
 
-template <int GATE, bool HASZ, bool HASX>
+template <int GATE, bool HASZ, int XMODE>
 __global__ __launch_bounds__(512) void lstm_mx_fwd_kernel(MxFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char mx_lds[];
   const int tid = threadIdx.x;
@@ -622,8 +632,8 @@ __global__ __launch_bounds__(512) void lstm_mx_fwd_kernel(MxFwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // both producer jobs ride in the one-tile wave 7: a three-tile wave has no registers left for two sets of frame values in
   // flight (encoder wave 0: eight spilled registers; with ONE set in wave 3 or 0 the launch took 390-400 us against 320)
-  if (wave < 7) mx_fwd_body<GATE, HASZ, HASX, 3, 0>(a, mx_lds, 12 * wave);
-  else mx_fwd_body<GATE, HASZ, HASX, 1, 3>(a, mx_lds, 84);
+  if (wave < 7) mx_fwd_body<GATE, HASZ, XMODE, 3, 0>(a, mx_lds, 12 * wave);
+  else mx_fwd_body<GATE, HASZ, XMODE, 1, 3>(a, mx_lds, 84);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -866,7 +876,7 @@ extern "C" int clv_lstm_mx_supported(int B, int H, int nx, int nz) {
 }
 
 extern "C" int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,
-                               const float* X, int ldx, int nx, const float* Kx,
+                               const void* X, int x_u8, int ldx, int nx, const float* Kx,
                                const float* Z, int ldz, int nz, const float* Kz,
                                const float* rowbias, const float* U,
                                float* hs, float* coef, float* aux, void* stream) {
@@ -889,8 +899,9 @@ extern "C" int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,
   } while (0)
 #define MX_LAUNCH_G(G)                                                                        \
   do {                                                                                        \
-    if (nz > 0) { if (nx > 0) MX_LAUNCH(G, true, true); else MX_LAUNCH(G, true, false); }     \
-    else { if (nx > 0) MX_LAUNCH(G, false, true); else MX_LAUNCH(G, false, false); }          \
+    const int xm = nx > 0 ? (x_u8 ? 2 : 1) : 0;                                               \
+    if (nz > 0) { if (xm == 2) MX_LAUNCH(G, true, 2); else if (xm) MX_LAUNCH(G, true, 1); else MX_LAUNCH(G, true, 0); }     \
+    else { if (xm == 2) MX_LAUNCH(G, false, 2); else if (xm) MX_LAUNCH(G, false, 1); else MX_LAUNCH(G, false, 0); }        \
   } while (0)
   if (hard) MX_LAUNCH_G(CLV_GATE_HARD_SIGMOID); else MX_LAUNCH_G(CLV_GATE_SIGMOID);
 #undef MX_LAUNCH_G

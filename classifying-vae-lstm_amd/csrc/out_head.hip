@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * OH_NW) void out_head_train_kernel(OutHeadArgs 
     for (int j = 0; j < OH_T; ++j)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
-        y[j][reg] = a.Y[(size_t)min(row0 + 4 * q + reg, a.R - 1) * a.ldy + min(16 * j + r, OH - 1)];
+        y[j][reg] = static_cast<const float*>(a.Y)[(size_t)min(row0 + 4 * q + reg, a.R - 1) * a.ldy + min(16 * j + r, OH - 1)];
   };
   load_hs(blockIdx.x * OH_RB + wave * 16);               // both in flight while Wo is staged
   load_y(blockIdx.x * OH_RB + wave * 16);
@@ -302,7 +302,7 @@ extern "C" size_t clv_out_head_train_workspace_bytes(int R) {
 }
 
 extern "C" int clv_out_head_train(int R, int H, int D, const float* hs, const float* Wo, const float* bo,
-                                  const float* Y, int ldy, float scale, float* logits, float* rownll, float* dlogits,
+                                  const void* Y, int y_u8, int ldy, float scale, float* logits, float* rownll, float* dlogits,
                                   float* dhs, float* dWo, float* dbo, void* ws, size_t ws_bytes, clv_reduce_job* job,
                                   void* stream) {
   using namespace clv;
@@ -314,12 +314,13 @@ extern "C" int clv_out_head_train(int R, int H, int D, const float* hs, const fl
   const size_t lds = (size_t)(OH * OH_LD + 2 * OH_NW * OH_TILE) * sizeof(float);
   if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(out_head_train_kernel), (int)lds)) return e;
   const int wgs = out_head_wgs(R);
-  OutHeadArgs a{R, ldy, scale, hs, Wo, bo, Y, logits, rownll, dlogits, dhs, (float*)ws};
+  OutHeadArgs a{R, ldy, scale, hs, Wo, bo, Y, y_u8 != 0, logits, rownll, dlogits, dhs, (float*)ws};
   // CLV_OUT_HEAD_F32=1 keeps the f32-MFMA kernel of this file (A/B runs; it also serves rows that are not 16-byte aligned)
   static const bool f32_only = [] { const char* e = getenv("CLV_OUT_HEAD_F32"); return e && e[0] == '1'; }();
-  if (!f32_only && out_head_bf16_ok(a)) {
+  if (!(f32_only && !y_u8) && out_head_bf16_ok(a)) {
     if (int e = launch_out_head_bf16(a, wgs, s)) return e;
   } else {
+    if (y_u8) return CLV_EINVAL;            // byte targets: the bf16-MFMA kernel only (rows 4-byte aligned, ldy a multiple of 4)
     ProfScope p("out_head_train", s);
     hipLaunchKernelGGL(out_head_train_kernel, dim3(wgs), dim3(64 * OH_NW), lds, s, a);
   }

@@ -14,7 +14,8 @@ struct OutHeadArgs {
   const float* hs;        // [R,88]
   const float* Wo;        // [88,88]
   const float* bo;        // [88]
-  const float* Y;         // [R,ldy] targets
+  const void* Y;          // [R,ldy] targets: float, or uint8 frames (y_u8: ldy in bytes; out_head_bf16.hip only)
+  int y_u8;
   float* logits;          // [R,88] or null
   float* rownll;          // [R]
   float* dlogits;         // [R,88] or null

@@ -121,6 +121,7 @@ __device__ __forceinline__ void ob_store1(float v, ob_rsrc_t r, unsigned voff) {
 // ds_read_b128) then finds the 4 lines that share a bank group at 4 different chunks.
 __device__ __forceinline__ int ob_dlt_line(int note) { return (((note >> 4) * 4 + (note & 3)) * 4 + ((note >> 2) & 3)) * 16; }
 
+template <bool YU8>
 __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ob_lds[];
   char* A1 = ob_lds;                                     // P1: Wo^T pieces, [piece][note tile][k-step][lane] x 16 B
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
   // Every global access of the row loop is a buffer instruction: rows beyond R fall outside the descriptor (loads return 0,
   // stores are dropped), a lane that has nothing to move gets an out-of-range offset, an absent output a descriptor of 0
   // bytes -- no divergent branch in the loop, which the register allocator (144 accumulators live) cannot afford.
-  const ob_rsrc_t r_hs = ob_rsrc(a.hs, (size_t)a.R * OH * 4), r_y = ob_rsrc(a.Y, (size_t)a.R * a.ldy * 4);
+  const ob_rsrc_t r_hs = ob_rsrc(a.hs, (size_t)a.R * OH * 4), r_y = ob_rsrc(a.Y, (size_t)a.R * a.ldy * (YU8 ? 1 : 4));
   const ob_rsrc_t r_lg = ob_rsrc(a.logits, a.logits ? (size_t)a.R * OH * 4 : 0);
   const ob_rsrc_t r_dl = ob_rsrc(a.dlogits, a.dlogits ? (size_t)a.R * OH * 4 : 0);
   const ob_rsrc_t r_dh = ob_rsrc(a.dhs, (size_t)a.R * OH * 4), r_nl = ob_rsrc(a.rownll, (size_t)a.R * 4);
@@ -235,7 +236,10 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
       if (s == 2) {            // the targets are requested here, when two thirds of hv are dead
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) ob_load4(r_y, row * (a.ldy * 4u) + c_off + 64 * j, y[j]);
+        for (int j = 0; j < 6; ++j) {
+          if (YU8) y[j][0] = ob_load1(r_y, row * (unsigned)a.ldy + 4 * q + 16 * j, 0);      // byte frames: this lane's four notes are one dword
+          else ob_load4(r_y, row * (a.ldy * 4u) + c_off + 64 * j, y[j]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -267,10 +271,11 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
       }
       const bool cok = j < 5 || c5;
       float lg4[4], dl4[4];
+      const unsigned yraw = __builtin_bit_cast(unsigned, y[j][0]);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const float lg = acc[j][reg];
-        const float t = y[j][reg];
+        const float t = YU8 ? (float)((yraw >> (8 * reg)) & 0xffu) : y[j][reg];
         const float l = fminf(fmaxf(lg, BCE_CLIP_LO), BCE_CLIP_HI);
         const float e = __expf(-fabsf(l));
         const float nl = fmaxf(l, 0.f) + __logf(1.f + e) - l * t;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(64 * OB_NW) void out_head_bf16_kernel(OutHeadArgs a
     // the row loop has no register to spare for a real prefetch, and its loads otherwise wait for HBM once per block
     const unsigned nrow = row + gridDim.x * OH_RB;
     const float pf0 = ob_load1(r_hs, q < 3 ? nrow * (OH * 4u) + q * 128u : OB_OOB, 0);
-    const float pf1 = ob_load1(r_y, q < 3 ? nrow * (a.ldy * 4u) + q * 128u : OB_OOB, 0);
+    const float pf1 = ob_load1(r_y, YU8 ? (q == 0 ? nrow * (unsigned)a.ldy : OB_OOB) : (q < 3 ? nrow * (a.ldy * 4u) + q * 128u : OB_OOB), 0);
     ssum += __shfl_xor(ssum, 16, 64);
     ssum += __shfl_xor(ssum, 32, 64);
     ob_store1(ssum, r_nl, q == 0 ? row * 4u : OB_OOB);
@@ -409,13 +414,19 @@ bool out_head_bf16_ok(const OutHeadArgs& a) {
   auto al = [](const void* p) { return ((uintptr_t)p) % 16 == 0; };
   // (buffer descriptors: every array below 2 GiB, so that offset 0x80000000 is out of range for all of them)
   const size_t widest = (size_t)a.R * (size_t)(a.ldy > OH ? a.ldy : OH) * 4;
-  return widest < 0x80000000ull && al(a.hs) && al(a.Y) && a.ldy % 4 == 0 && al(a.dhs) && al(a.logits) && al(a.dlogits);
+  const bool y_ok = a.y_u8 ? (((uintptr_t)a.Y) % 4 == 0) : al(a.Y);
+  return widest < 0x80000000ull && al(a.hs) && y_ok && a.ldy % 4 == 0 && al(a.dhs) && al(a.logits) && al(a.dlogits);
 }
 
 int launch_out_head_bf16(const OutHeadArgs& a, int wgs, hipStream_t s) {
-  if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(out_head_bf16_kernel), OB_LDS)) return e;
   ProfScope p("out_head_bf16", s);
-  hipLaunchKernelGGL(out_head_bf16_kernel, dim3(wgs), dim3(64 * OB_NW), OB_LDS, s, a);
+  if (a.y_u8) {
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(out_head_bf16_kernel<true>), OB_LDS)) return e;
+    hipLaunchKernelGGL(out_head_bf16_kernel<true>, dim3(wgs), dim3(64 * OB_NW), OB_LDS, s, a);
+  } else {
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(out_head_bf16_kernel<false>), OB_LDS)) return e;
+    hipLaunchKernelGGL(out_head_bf16_kernel<false>, dim3(wgs), dim3(64 * OB_NW), OB_LDS, s, a);
+  }
   return CLV_OK;
 }
 

@@ -32,7 +32,7 @@ constexpr int OD_LDS = 2 * OD_BUF;
 
 struct OuterBf16Args {
   int Bn, nx, N, ldx, ldg, ldo;
-  const float* X;
+  const void* X;       // float, or uint8 (XU8 kernels: ldx counts bytes)
   const float* G;
   float* out;          // [nx, ldo]
   float* colsum;       // [N] or null
@@ -46,8 +46,19 @@ __device__ __forceinline__ float4 od_load4(od_rsrc_t r, unsigned voff) {
   const od_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
   return make_float4(od_u2f(x[0]), od_u2f(x[1]), od_u2f(x[2]), od_u2f(x[3]));
 }
+// Frames kept as BYTES (round 6: the training step of the large-batch path never widens its piano-roll frames to float): four
+// consecutive inputs are one dword; it travels raw in the .x of the register slot a float4 would take and is widened where
+// the slot is consumed (every byte value is exactly a bf16 number).
+__device__ __forceinline__ float4 od_load_u8x4(od_rsrc_t r, unsigned voff) {
+  return make_float4(od_u2f((unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0)), 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float4 od_widen(const float4& raw) {
+  const float r0 = raw.x;                     // (a scalar copy first: bit_cast of a vector ELEMENT reads element 0, tests/test_host_logic.py)
+  const unsigned v = __builtin_bit_cast(unsigned, r0);
+  return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+}
 
-template <int OD_NW>
+template <int OD_NW, bool XU8>
 __global__ __launch_bounds__(64 * OD_NW) void dense_outer_bf16_kernel(OuterBf16Args a) {
   constexpr int OD_NT = 64 * OD_NW, OD_JT = 16 * OD_NW;
   extern __shared__ __attribute__((aligned(16))) char od_lds[];
@@ -100,7 +111,8 @@ __global__ __launch_bounds__(64 * OD_NW) void dense_outer_bf16_kernel(OuterBf16A
   const int n4 = a.N / 4;
   // which float4s of a stage this thread moves: X 32 rows x 24, G 32 rows x n4; slot e = tid + 384 i.  Rows beyond the
   // batch fall outside the descriptors (the loads return 0), inputs beyond nx and idle slots get an out-of-range offset.
-  const od_rsrc_t r_x = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)(unsigned)((size_t)a.Bn * a.ldx * 4), 0x00020000);
+  constexpr unsigned XE = XU8 ? 1u : 4u;                  // bytes per element of X
+  const od_rsrc_t r_x = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, (int)(unsigned)((size_t)a.Bn * a.ldx * XE), 0x00020000);
   const od_rsrc_t r_g = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G), 0, (int)(unsigned)((size_t)a.Bn * a.ldg * 4), 0x00020000);
   constexpr int XC4 = OD_JT / 4;                          // float4 columns of the X tile
   constexpr int XS = OD_KS * XC4 / OD_NT, GS = (OD_KS * 24 + OD_NT - 1) / OD_NT;      // float4 slots per thread: 2, and 2 or 4
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(64 * OD_NW) void dense_outer_bf16_kernel(OuterBf16A
   for (int i = 0; i < XS; ++i) {
     const int e = tid + OD_NT * i;
     const int rx = e / XC4, cx = e - XC4 * rx;
-    xg[i] = j0 + 4 * cx < a.nx ? 4u * (unsigned)(rx * a.ldx + j0 + 4 * cx) : OD_OOB;
+    xg[i] = j0 + 4 * cx < a.nx ? XE * (unsigned)(rx * a.ldx + j0 + 4 * cx) : OD_OOB;
     xl[i] = rx * OD_P + 8 * cx;
   }
 #pragma unroll
@@ -130,16 +142,19 @@ __global__ __launch_bounds__(64 * OD_NW) void dense_outer_bf16_kernel(OuterBf16A
   constexpr int DEPTH = 4;
   float4 xr[DEPTH][XS], gr[DEPTH][GS];
   auto load_stage = [&](float4 (&xq)[XS], float4 (&gq)[GS], int s) {
-    const unsigned kx = 4u * (unsigned)(s * OD_KS * a.ldx), kg = 4u * (unsigned)(s * OD_KS * a.ldg);
+    const unsigned kx = XE * (unsigned)(s * OD_KS * a.ldx), kg = 4u * (unsigned)(s * OD_KS * a.ldg);
 #pragma unroll
-    for (int i = 0; i < XS; ++i) xq[i] = od_load4(r_x, xg[i] == OD_OOB ? OD_OOB : xg[i] + kx);
+    for (int i = 0; i < XS; ++i) {
+      const unsigned xo = xg[i] == OD_OOB ? OD_OOB : xg[i] + kx;
+      xq[i] = XU8 ? od_load_u8x4(r_x, xo) : od_load4(r_x, xo);
+    }
 #pragma unroll
     for (int i = 0; i < GS; ++i) gq[i] = od_load4(r_g, gg[i] == OD_OOB ? OD_OOB : gg[i] + kg);
   };
   auto store_stage = [&](const float4 (&xq)[XS], const float4 (&gq)[GS], int s) {
     char* buf = od_lds + (s & 1) * OD_BUF;
 #pragma unroll
-    for (int i = 0; i < XS; ++i) img_put4<1>(buf + xl[i], 0, xq[i]);
+    for (int i = 0; i < XS; ++i) img_put4<1>(buf + xl[i], 0, XU8 ? od_widen(xq[i]) : xq[i]);
 #pragma unroll
     for (int i = 0; i < GS; ++i)
       if (gok[i]) img_put4<3>(buf + OD_IMG + gl[i], OD_IMG, gq[i]);
@@ -200,13 +215,14 @@ __global__ __launch_bounds__(64 * OD_NW) void dense_outer_bf16_kernel(OuterBf16A
 // ---------------------------------------------------------------------------------------------------------------------------
 struct WindowFwdArgs {
   int Bn, nx, N, ldx, ldk, chunk;     // chunk: inputs per workgroup (a multiple of 32)
-  const float* X;
+  const void* X;                      // float, or uint8 (XU8 kernel: ldx counts bytes)
   const float* K;
   float* part;                        // [chunks][Bn][N]
 };
 constexpr int WF_NW = 4, WF_NT = 64 * WF_NW;
 constexpr int WF_BUF = 3 * OD_IMG, WF_LDS = 2 * WF_BUF;
 
+template <bool XU8>
 __global__ __launch_bounds__(WF_NT) void dense_window_fwd_bf16_kernel(WindowFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char od_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -216,13 +232,14 @@ __global__ __launch_bounds__(WF_NT) void dense_window_fwd_bf16_kernel(WindowFwdA
   const int i0 = blockIdx.y * a.chunk, i1 = min(a.nx, i0 + a.chunk);
   const int nst = (i1 - i0 + OD_KS - 1) / OD_KS;
   const int n4 = a.N / 4;
-  const od_rsrc_t r_x = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)(unsigned)((size_t)a.Bn * a.ldx * 4), 0x00020000);
+  constexpr unsigned XE = XU8 ? 1u : 4u;
+  const od_rsrc_t r_x = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, (int)(unsigned)((size_t)a.Bn * a.ldx * XE), 0x00020000);
   // K's descriptor ends with the chunk: the slab rows of the last stage that belong to the next chunk read as zeros
   const od_rsrc_t r_k = (od_rsrc_t)__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.K), 0, (int)(unsigned)((size_t)i1 * a.ldk * 4), 0x00020000);
   // A operand of this lane: row b0 + (lane & 15), inputs i0 + 32 s + 8 (lane >> 4) .. + 7.  An 8-group beyond the chunk is
   // multiplied by zero rows of K, one beyond nx must not be read (it would be the next row's data): nx % 8 == 0, so a group is
   // whole; rows beyond the batch fall outside the descriptor.
-  const unsigned xa = 4u * (unsigned)((b0 + (lane & 15)) * a.ldx + i0 + 8 * (lane >> 4));
+  const unsigned xa = XE * (unsigned)((b0 + (lane & 15)) * a.ldx + i0 + 8 * (lane >> 4));
   constexpr int KS_ = (OD_KS * 24 + WF_NT - 1) / WF_NT;       // float4 slots of K's slab per thread (3)
   unsigned kg[KS_];
   int kl[KS_];
@@ -239,9 +256,14 @@ __global__ __launch_bounds__(WF_NT) void dense_window_fwd_bf16_kernel(WindowFwdA
   float4 xr[DEPTH][2], kr[DEPTH][KS_];
   auto load_stage = [&](float4 (&xq)[2], float4 (&kq)[KS_], int s) {
     const bool in = i0 + OD_KS * s + 8 * (lane >> 4) < a.nx;
-    const unsigned xo = in ? xa + 4u * (unsigned)(OD_KS * s) : OD_OOB;
-    xq[0] = od_load4(r_x, xo);
-    xq[1] = od_load4(r_x, in ? xo + 16u : OD_OOB);
+    const unsigned xo = in ? xa + XE * (unsigned)(OD_KS * s) : OD_OOB;
+    if (XU8) {       // eight inputs = two dwords, raw in the .x of the two slots
+      xq[0] = od_load_u8x4(r_x, xo);
+      xq[1] = od_load_u8x4(r_x, in ? xo + 4u : OD_OOB);
+    } else {
+      xq[0] = od_load4(r_x, xo);
+      xq[1] = od_load4(r_x, in ? xo + 16u : OD_OOB);
+    }
     const unsigned ko = 4u * (unsigned)(OD_KS * s * a.ldk);
 #pragma unroll
     for (int i = 0; i < KS_; ++i) kq[i] = od_load4(r_k, kg[i] == OD_OOB ? OD_OOB : kg[i] + ko);
@@ -265,7 +287,8 @@ __global__ __launch_bounds__(WF_NT) void dense_window_fwd_bf16_kernel(WindowFwdA
   // other buffer; then the request for stage s + 4 into the set that held stage s
   auto stage = [&](int s, float4 (&xs)[2], float4 (&ks)[KS_], const float4 (&kn)[KS_]) {
     const char* buf = od_lds + (s & 1) * WF_BUF;
-    const od_u32x4 au = {bf16_pack2(xs[0].x, xs[0].y), bf16_pack2(xs[0].z, xs[0].w), bf16_pack2(xs[1].x, xs[1].y), bf16_pack2(xs[1].z, xs[1].w)};
+    const float4 x0 = XU8 ? od_widen(xs[0]) : xs[0], x1 = XU8 ? od_widen(xs[1]) : xs[1];
+    const od_u32x4 au = {bf16_pack2(x0.x, x0.y), bf16_pack2(x0.z, x0.w), bf16_pack2(x1.x, x1.y), bf16_pack2(x1.z, x1.w)};
     const img_bf16x8 ax = __builtin_bit_cast(img_bf16x8, au);
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
@@ -302,24 +325,23 @@ extern "C" int clv_dense_outer_bf16_supported(int Bn, int nx, int N, int ldx, in
          (size_t)Bn * (size_t)ldx * 4 < 0x80000000ull && (size_t)Bn * (size_t)ldg * 4 < 0x80000000ull;
 }
 
-extern "C" int clv_dense_outer_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+extern "C" int clv_dense_outer_bf16(int Bn, int nx, int N, const void* X, int x_u8, int ldx, const float* G, int ldg, float* out, int ldo,
                                     float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream) {
   using namespace clv;
   if (!clv_dense_outer_bf16_supported(Bn, nx, N, ldx, ldg) || !X || !G || !out || ldo < N) return CLV_EINVAL;
-  if (((uintptr_t)X) % 16 != 0 || ((uintptr_t)G) % 16 != 0) return CLV_EINVAL;
+  if (((uintptr_t)X) % (x_u8 ? 4 : 16) != 0 || ((uintptr_t)G) % 16 != 0) return CLV_EINVAL;
   if (gdot && (!Hact || !hbias || ldh < N || ldh % 2 != 0 || ((uintptr_t)Hact) % 8 != 0)) return CLV_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   OuterBf16Args a{Bn, nx, N, ldx, ldg, ldo, X, G, out, colsum, Hact, hbias, gdot, ldh};
   const int extra = (colsum || gdot) ? 1 : 0;
   ProfScope p("dense_outer_bf16", s);
-  if ((nx + 95) / 96 >= 200) {
-    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(dense_outer_bf16_kernel<6>), OD_LDS)) return e;
-    hipLaunchKernelGGL(dense_outer_bf16_kernel<6>, dim3((nx + 95) / 96 + extra), dim3(384), OD_LDS, s, a);
-  } else {
-    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(dense_outer_bf16_kernel<3>), OD_LDS)) return e;
-    hipLaunchKernelGGL(dense_outer_bf16_kernel<3>, dim3((nx + 47) / 48 + extra), dim3(192), OD_LDS, s, a);
-  }
-  return launch_status();
+  auto go = [&](auto kern, int inputs, int threads) -> int {
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), OD_LDS)) return e;
+    hipLaunchKernelGGL(kern, dim3((nx + inputs - 1) / inputs + extra), dim3(threads), OD_LDS, s, a);
+    return launch_status();
+  };
+  if ((nx + 95) / 96 >= 200) return x_u8 ? go(dense_outer_bf16_kernel<6, true>, 96, 384) : go(dense_outer_bf16_kernel<6, false>, 96, 384);
+  return x_u8 ? go(dense_outer_bf16_kernel<3, true>, 48, 192) : go(dense_outer_bf16_kernel<3, false>, 48, 192);
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------------------
@@ -344,18 +366,23 @@ extern "C" size_t clv_dense_window_fwd_bf16_workspace_bytes(int Bn, int nx, int 
   if (Bn <= 0 || nx <= 0 || N <= 0) return 0;
   return (size_t)clv_dense_window_fwd_bf16_splits(Bn, nx) * Bn * N * sizeof(float);
 }
-extern "C" int clv_dense_window_fwd_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* K, int ldk, float* part,
+extern "C" int clv_dense_window_fwd_bf16(int Bn, int nx, int N, const void* X, int x_u8, int ldx, const float* K, int ldk, float* part,
                                          size_t part_bytes, void* stream) {
   using namespace clv;
   if (!clv_dense_window_fwd_bf16_supported(Bn, nx, N, ldx, ldk) || !X || !K) return CLV_EINVAL;
-  if (((uintptr_t)X) % 16 != 0 || ((uintptr_t)K) % 16 != 0) return CLV_EINVAL;
+  if (((uintptr_t)X) % (x_u8 ? 4 : 16) != 0 || ((uintptr_t)K) % 16 != 0) return CLV_EINVAL;
   if (!part || part_bytes < clv_dense_window_fwd_bf16_workspace_bytes(Bn, nx, N)) return CLV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(dense_window_fwd_bf16_kernel), WF_LDS)) return e;
   const int chunk = window_fwd_chunk(Bn, nx);
   WindowFwdArgs a{Bn, nx, N, ldx, ldk, chunk, X, K, part};
   ProfScope p("dense_window_fwd_bf16", s);
-  hipLaunchKernelGGL(dense_window_fwd_bf16_kernel, dim3((Bn + 16 * WF_NW - 1) / (16 * WF_NW), (nx + chunk - 1) / chunk), dim3(WF_NT),
-                     WF_LDS, s, a);
+  const dim3 grid((Bn + 16 * WF_NW - 1) / (16 * WF_NW), (nx + chunk - 1) / chunk);
+  if (x_u8) {
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(dense_window_fwd_bf16_kernel<true>), WF_LDS)) return e;
+    hipLaunchKernelGGL(dense_window_fwd_bf16_kernel<true>, grid, dim3(WF_NT), WF_LDS, s, a);
+  } else {
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(dense_window_fwd_bf16_kernel<false>), WF_LDS)) return e;
+    hipLaunchKernelGGL(dense_window_fwd_bf16_kernel<false>, grid, dim3(WF_NT), WF_LDS, s, a);
+  }
   return launch_status();
 }

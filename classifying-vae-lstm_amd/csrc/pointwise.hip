@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
     if (si == k) { src = a.seg[k].src; out = a.seg[k].out; table = a.seg[k].table; row_elems = a.seg[k].row_elems;
                    out_ld = a.seg[k].out_ld; stride = a.seg[k].stride; offset = a.seg[k].offset;
                    chunk = a.seg[k].chunk; pieces = a.seg[k].pieces; vec = a.seg[k].vec; u8 = a.seg[k].u8; }
-  const int W = vec ? 4 : 1;                       // work item = 4 elements (aligned segments) or one
+  const int W = vec == 2 ? 8 : (vec ? 4 : 1);      // work item = 4 elements (aligned segments) or one; 8 bytes of a byte copy
   // GATHER_IPT items per thread, 256 apart: the row's source offset is a chain of dependent loads (step counter -> row list
   // -> window table), paid once per block, and a thread's loads are issued together (round 4: one item per thread made the
   // launch 8448 blocks of one chain + one load each at configuration 3: 11.9 us for 30 MB)
@@ -379,6 +379,24 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
     int64_t sr = a.idx ? a.idx[base + r] : a.row0 + base + r;
     if (table) sr = table[sr];
     const int64_t s0 = sr * stride + offset;       // first element of the source row
+    if (vec == 2) {                                // bytes as they are, 8 per work item (a batch that stays uint8; out_ld in bytes)
+      uint2 v[GATHER_IPT];
+#pragma unroll
+      for (int k = 0; k < GATHER_IPT; ++k) {
+        const unsigned c = (int64_t)cs[k] < row_elems ? cs[k] : cs[0];
+        v[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(src) + s0 + c);
+      }
+#pragma unroll
+      for (int k = 0; k < GATHER_IPT; ++k) {
+        const unsigned c = cs[k];
+        if ((int64_t)c < row_elems) {
+          unsigned piece = 0, within = c;
+          if (pieces > 1) { piece = c / (unsigned)chunk; within = c - piece * (unsigned)chunk; }
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(out) + (r * pieces + piece) * out_ld + within) = v[k];
+        }
+      }
+      continue;
+    }
     if (u8 && vec) {                               // uint8 store (binary piano-roll frames): 4 bytes in, one float4 out
       unsigned int v[GATHER_IPT];
 #pragma unroll
@@ -392,6 +410,10 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs a) {
         if ((int64_t)c < row_elems) {
           unsigned piece = 0, within = c;
           if (pieces > 1) { piece = c / (unsigned)chunk; within = c - piece * (unsigned)chunk; }
+          if (u8 == 2) {                           // ... or the four bytes as they are (a batch that stays uint8; out_ld in bytes)
+            *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(out) + (r * pieces + piece) * out_ld + within) = v[k];
+            continue;
+          }
           *reinterpret_cast<float4*>(out + (r * pieces + piece) * out_ld + within) =
               make_float4((float)(v[k] & 255u), (float)((v[k] >> 8) & 255u), (float)((v[k] >> 16) & 255u), (float)(v[k] >> 24));
         }
@@ -619,15 +641,20 @@ extern "C" int clv_gather_rows_multi_cursor(int64_t rows, const int64_t* idx, in
     const int64_t ch = chunk[k] > 0 ? chunk[k] : row_elems[k];
     if (row_elems[k] % ch != 0) return CLV_EINVAL;
     const int64_t ld = chunk[k] > 0 ? out_ld[k] : row_elems[k];
-    const int u8 = src_u8 && src_u8[k];
+    const int u8 = src_u8 ? (src_u8[k] == 2 ? 2 : (src_u8[k] != 0)) : 0;      // 2: a uint8 source copied to a uint8 output
     const int64_t stride = (src_stride && src_stride[k] > 0) ? src_stride[k] : row_elems[k];
     const int64_t offset = src_offset ? src_offset[k] : 0;
     const int64_t salign = u8 ? 4 : 16, ealign = u8 ? 4 : 4;       // bytes / elements a vector access needs
     const int vec = row_elems[k] % 4 == 0 && ch % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src[k]) % salign == 0 &&
-                    stride % ealign == 0 && offset % ealign == 0 && ((uintptr_t)out[k]) % 16 == 0;
+                    stride % ealign == 0 && offset % ealign == 0 && ((uintptr_t)out[k]) % (u8 == 2 ? 4 : 16) == 0;
+    if (u8 == 2 && !vec) return CLV_EINVAL;                      // the byte copy moves dwords only
+    // ... or 8 bytes at a time where everything is 8-byte aligned (88-byte frames are): the launch is bound by the chain of
+    // dependent loads in front of every block (step counter -> row list -> window table), so fewer, fatter blocks
+    const int wide = u8 == 2 && row_elems[k] % 8 == 0 && ch % 8 == 0 && ld % 8 == 0 && stride % 8 == 0 && offset % 8 == 0 &&
+                     ((uintptr_t)src[k]) % 8 == 0 && ((uintptr_t)out[k]) % 8 == 0;
     a.seg[k] = GatherSeg{(const float*)src[k], out[k], src_table ? src_table[k] : nullptr, row_elems[k], ld, stride, offset,
-                         (int)ch, (int)(row_elems[k] / ch), vec, u8, notes_out ? notes_out[k] : nullptr};
-    int64_t w = row_elems[k] / (vec ? 4 : 1);
+                         (int)ch, (int)(row_elems[k] / ch), wide ? 2 : vec, u8, notes_out ? notes_out[k] : nullptr};
+    int64_t w = row_elems[k] / (wide ? 8 : (vec ? 4 : 1));
     if (a.seg[k].notes) {      // byte frames of at most 88 notes, read 4 bytes per lane
       if (!u8 || ch > CLV_NOTE_NONE || ch % 4 || stride % 4 || offset % 4 || ((uintptr_t)src[k]) % 4) return CLV_EINVAL;
       a.list_seg[a.nlist++] = k;

@@ -62,7 +62,7 @@ template <int HM> struct WbGeo {
 
 struct WgradArgs {
   int K, N, kc;                      // rows, columns (352), rows per split
-  const float* X; int ldx, nx;
+  const void* X; int ldx, nx, x_u8;      // frames: float rows, or (x_u8) the bytes themselves, ldx in bytes (one bf16 piece either way)
   const float* H; int ldh, nh, h_shift, h_zero_period;
   const float* Z; int ldz, nz;
   const float* dz; int lddz;
@@ -141,8 +141,15 @@ __device__ unsigned long long g_wb_wg[1024][5];
 // s_waitcnt vmcnt(0) and drain the producers' prefetch at every stage).
 __device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int HM, int XP>
+__device__ __forceinline__ float4 wb_widen(const float4& raw) {      // four byte frames that travelled as one dword in .x
+  const float r0 = raw.x;                     // (a scalar copy first: bit_cast of a vector ELEMENT reads element 0, tests/test_host_logic.py)
+  const unsigned v = __builtin_bit_cast(unsigned, r0);
+  return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+}
+
+template <int HM, int XP, bool XU8 = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
+  static_assert(!XU8 || XP == 1, "byte frames are one bf16 piece");
   using G = WbGeo<HM>;
   constexpr int HPB = G::HPB, BUF = G::template buf_bytes<XP>(), LDS_ALL = G::template lds_bytes<XP>();
   constexpr int HT = HM / 2;                     // h row tiles per consumer wave
@@ -199,7 +206,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       const int okx = e < WB_KS * nx4, ex = okx ? e : 0, rx = ex / nx4, cx = ex % nx4;
       h_g[i] = 4u * (unsigned)(rh * a.ldh + 4 * ch);
       h_l[i] = ((rh * HPB + 8 * ch) ^ WB_SWZ_OF(rh)) | (rh == 0 ? ROW0 : 0) | (rh == 16 ? ROW16 : 0) | (okh ? 0 : IDLE);
-      x_g[i] = 4u * (unsigned)(rx * a.ldx + 4 * cx);
+      x_g[i] = (XU8 ? 1u : 4u) * (unsigned)(rx * a.ldx + 4 * cx);
       x_l[i] = ((rx * WB_AP + 8 * cx) ^ WB_SWZ_OF(rx)) | (okx ? 0 : IDLE);
     }
 #pragma unroll
@@ -225,13 +232,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       if (interior(s)) {                           // uniform base + per-lane 32-bit offset
         const char* dzb = reinterpret_cast<const char*>(a.dz + (size_t)k0 * a.lddz);
         const char* hb = reinterpret_cast<const char*>(a.H + (size_t)(k0 - a.h_shift) * a.ldh);
-        const char* xb = reinterpret_cast<const char*>(a.X + (size_t)k0 * a.ldx);
+        const char* xb = static_cast<const char*>(a.X) + (size_t)k0 * a.ldx * (XU8 ? 1 : 4);
 #pragma unroll
         for (int i = 0; i < DZ_L; ++i) q.dz[i] = *reinterpret_cast<const float4*>(dzb + dz_g[i]);
 #pragma unroll
         for (int i = 0; i < A_L; ++i) {
           q.h[i] = *reinterpret_cast<const float4*>(hb + h_g[i]);
-          q.x[i] = *reinterpret_cast<const float4*>(xb + x_g[i]);
+          if (XU8) q.x[i].x = *reinterpret_cast<const float*>(xb + x_g[i]);       // (raw dword = four frames' bytes: widened in store_stage)
+          else q.x[i] = *reinterpret_cast<const float4*>(xb + x_g[i]);
         }
         if (a.nz > 0) {
           const char* zb = reinterpret_cast<const char*>(a.Z + (size_t)k0 * a.ldz);
@@ -241,14 +249,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
         return;
       }
       // first / last stage of the matrix: row indices clamped into it (the values of rows outside are masked later)
-      auto row = [&](unsigned g, int ld, int shift) { const int r = (int)(g / 4u) / ld; return min(max(k0 + r - shift, 0), a.K - 1) - r; };
+      auto row = [&](unsigned g, int ld, int shift, unsigned esz = 4u) { const int r = (int)(g / esz) / ld; return min(max(k0 + r - shift, 0), a.K - 1) - r; };
 #pragma unroll
       for (int i = 0; i < DZ_L; ++i)
         q.dz[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dz + (size_t)row(dz_g[i] - 4u * n0, a.lddz, 0) * a.lddz) + dz_g[i]);
 #pragma unroll
       for (int i = 0; i < A_L; ++i) {
         q.h[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.H + (size_t)row(h_g[i], a.ldh, a.h_shift) * a.ldh) + h_g[i]);
-        q.x[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.X + (size_t)row(x_g[i], a.ldx, 0) * a.ldx) + x_g[i]);
+        if (XU8) q.x[i].x = *reinterpret_cast<const float*>(static_cast<const char*>(a.X) + (size_t)row(x_g[i], a.ldx, 0, 1u) * a.ldx + x_g[i]);
+        else q.x[i] = *reinterpret_cast<const float4*>(static_cast<const char*>(a.X) + (size_t)row(x_g[i], a.ldx, 0) * a.ldx * 4 + x_g[i]);
       }
       if (a.nz > 0) {
 #pragma unroll
@@ -278,7 +287,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
         const bool live = fast ? !((wstart && (h_l[i] & ROW0)) || (wstart16 && (h_l[i] & ROW16)))
                                : (k < k_end && k >= a.h_shift && (a.h_zero_period == 0 || k % a.h_zero_period != 0));
         if (i + 1 < A_L || !(h_l[i] & IDLE)) put4<3>(hi + (h_l[i] & OFFM), WB_KS * HPB, keep(q.h[i], live));
-        if (i + 1 < A_L || !(x_l[i] & IDLE)) put4<XP>(xi + (x_l[i] & OFFM), WB_KS * WB_AP, fast ? q.x[i] : keep(q.x[i], k0 + rx < k_end));
+        const float4 xv = XU8 ? wb_widen(q.x[i]) : q.x[i];
+        if (i + 1 < A_L || !(x_l[i] & IDLE)) put4<XP>(xi + (x_l[i] & OFFM), WB_KS * WB_AP, fast ? xv : keep(xv, k0 + rx < k_end));
       }
       if (a.nz > 0) {
 #pragma unroll
@@ -406,18 +416,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   WBWG(4);
 }
 
-template <int HM, int XP>
-__global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) { wgrad_body<HM, XP>(a); }
+template <int HM, int XP, bool XU8 = false>
+__global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_kernel(WgradArgs a) { wgrad_body<HM, XP, XU8>(a); }
 
 // Two LSTMs in one launch (grid z): the encoder's and the decoder's gradients of a cl_vrnn step, whose dz both exist
 // once the backward pass is through.  Launched one after the other at K = 32768 (configuration 3), each grid is one
 // workgroup per CU with 8 stages -- 17 us of stages inside a 34 us launch (LDS clear and first loads in front, a 124 KB
 // slab store behind, launch and drain around).  Together, with row ranges twice as long, the same 256 workgroups run 16
 // stages each: the fixed part is paid once, and the split-K reduction reads half as many slabs.
-template <int HM, int XP>
+template <int HM, int XP, bool XU8 = false>
 __global__ __launch_bounds__(WB_NT) void lstm_wgrad_bf16_pair_kernel(WgradArgs a0, WgradArgs a1) {
   const WgradArgs a = blockIdx.z ? a1 : a0;        // (scalar selects: one copy of the body)
-  wgrad_body<HM, XP>(a);
+  wgrad_body<HM, XP, XU8>(a);
 }
 
 }  // namespace clv
@@ -464,7 +474,7 @@ extern "C" size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, i
   return clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, 1);
 }
 
-extern "C" int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+extern "C" int clv_lstm_wgrad(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
                               const float* H, int ldh, int nh, int h_shift, int h_zero_period,
                               const float* Z, int ldz, int nz, const float* dz, int lddz,
                               float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
@@ -473,7 +483,7 @@ extern "C" int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int
                            dU, ld_u, dKz, ld_kz, beta, 1, ws, ws_bytes, job, stream);
 }
 
-extern "C" int clv_lstm_wgrad_ex(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+extern "C" int clv_lstm_wgrad_ex(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
                                  const float* H, int ldh, int nh, int h_shift, int h_zero_period,
                                  const float* Z, int ldz, int nz, const float* dz, int lddz,
                                  float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
@@ -483,25 +493,26 @@ extern "C" int clv_lstm_wgrad_ex(int K, int N, const float* X, int ldx, int nx, 
   if (job) memset(job, 0, sizeof(*job));
   if (!clv_lstm_wgrad_supported(N, nx, nh, nz, x_exact_bf16) || K <= 0 || !X || !H || !dz || !dKx || !dU || (nz > 0 && (!Z || !dKz)))
     return CLV_EINVAL;
-  if (ldx % 4 || ldh % 4 || lddz % 4 || ((uintptr_t)X | (uintptr_t)H | (uintptr_t)dz) % 16) return CLV_EINVAL;
+  const bool xu8 = x_exact_bf16 == CLV_FRAMES_U8;           // the frames as bytes (ldx in bytes): 4-byte aligned rows
+  if (ldx % 4 || ldh % 4 || lddz % 4 || ((uintptr_t)H | (uintptr_t)dz) % 16 || ((uintptr_t)X) % (xu8 ? 4 : 16)) return CLV_EINVAL;
   if (clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, split_scale) > ws_bytes || !ws || ((uintptr_t)ws) % 16) return CLV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int splits = wgrad_splits(K, split_scale);
   const int kc = wgrad_kc(K, split_scale);
-  WgradArgs a{K, N, kc, X, ldx, nx, H, ldh, nh, h_shift, h_zero_period, Z, ldz, nz, dz, lddz, (float*)ws};
+  WgradArgs a{K, N, kc, X, ldx, nx, xu8, H, ldh, nh, h_shift, h_zero_period, Z, ldz, nz, dz, lddz, (float*)ws};
   const bool wide = wgrad_wide(nh, nz);
   {
     ProfScope p("lstm_wgrad_bf16", s);
     dim3 grid(splits, N / WB_NC);
-#define WB_LAUNCH(HM, XP)                                                                                   \
+#define WB_LAUNCH(HM, XP, ...)                                                                              \
   do {                                                                                                      \
-    auto kern = lstm_wgrad_bf16_kernel<HM, XP>;                                                             \
+    auto kern = lstm_wgrad_bf16_kernel<HM, XP, ##__VA_ARGS__>;                                              \
     const int lds = WbGeo<HM>::template lds_bytes<XP>();                                                    \
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;                      \
     hipLaunchKernelGGL(kern, grid, dim3(WB_NT), lds, s, a);                                                 \
   } while (0)
-    if (wide) { if (x_exact_bf16) WB_LAUNCH(8, 1); else WB_LAUNCH(8, 3); }
-    else { if (x_exact_bf16) WB_LAUNCH(6, 1); else WB_LAUNCH(6, 3); }
+    if (wide) { if (xu8) WB_LAUNCH(8, 1, true); else if (x_exact_bf16) WB_LAUNCH(8, 1); else WB_LAUNCH(8, 3); }
+    else { if (xu8) WB_LAUNCH(6, 1, true); else if (x_exact_bf16) WB_LAUNCH(6, 1); else WB_LAUNCH(6, 3); }
 #undef WB_LAUNCH
   }
   int st = launch_status();
@@ -526,14 +537,15 @@ static bool wgrad_problem_ok(const clv_wgrad_problem& p) {
   if (!clv_lstm_wgrad_supported(p.N, p.nx, p.nh, p.nz, p.x_exact_bf16) || p.K <= 0 || !p.X || !p.H || !p.dz || !p.dKx || !p.dU ||
       (p.nz > 0 && (!p.Z || !p.dKz)))
     return false;
-  return !(p.ldx % 4 || p.ldh % 4 || p.lddz % 4 || ((uintptr_t)p.X | (uintptr_t)p.H | (uintptr_t)p.dz) % 16);
+  return !(p.ldx % 4 || p.ldh % 4 || p.lddz % 4 || ((uintptr_t)p.H | (uintptr_t)p.dz) % 16 ||
+           ((uintptr_t)p.X) % (p.x_exact_bf16 == CLV_FRAMES_U8 ? 4 : 16));
 }
 
 extern "C" int clv_lstm_wgrad_pair_supported(const clv_wgrad_problem* p, const clv_wgrad_problem* q) {
   if (!p || !q || !wgrad_problem_ok(*p) || !wgrad_problem_ok(*q)) return 0;
   // one kernel instance, one grid: the same row count, the same tile geometry, the same number of frame pieces
   return p->K == q->K && p->N == q->N && wgrad_wide(p->nh, p->nz) == wgrad_wide(q->nh, q->nz) &&
-         (p->x_exact_bf16 != 0) == (q->x_exact_bf16 != 0);
+         p->x_exact_bf16 == q->x_exact_bf16;
 }
 
 extern "C" size_t clv_lstm_wgrad_pair_workspace_bytes(int K, int N, int nx, int nh, int nz, int split_scale) {
@@ -557,21 +569,22 @@ extern "C" int clv_lstm_wgrad_pair(const clv_wgrad_problem* p, const clv_wgrad_p
   const int splits = wgrad_splits(K, split_scale, 64), kc = wgrad_kc(K, split_scale, 64);
   WgradArgs a[2];
   for (int i = 0; i < 2; ++i)
-    a[i] = WgradArgs{K, N, kc, pr[i]->X, pr[i]->ldx, pr[i]->nx, pr[i]->H, pr[i]->ldh, pr[i]->nh, pr[i]->h_shift, pr[i]->h_zero_period,
+    a[i] = WgradArgs{K, N, kc, pr[i]->X, pr[i]->ldx, pr[i]->nx, pr[i]->x_exact_bf16 == CLV_FRAMES_U8, pr[i]->H, pr[i]->ldh, pr[i]->nh, pr[i]->h_shift, pr[i]->h_zero_period,
                      pr[i]->Z, pr[i]->ldz, pr[i]->nz, pr[i]->dz, pr[i]->lddz, (float*)pr[i]->ws};
   {
     ProfScope ps("lstm_wgrad_bf16_pair", s);
     dim3 grid(splits, N / WB_NC, 2);
-#define WB_LAUNCH2(HM, XP)                                                                                  \
+#define WB_LAUNCH2(HM, XP, ...)                                                                             \
   do {                                                                                                      \
-    auto kern = lstm_wgrad_bf16_pair_kernel<HM, XP>;                                                        \
+    auto kern = lstm_wgrad_bf16_pair_kernel<HM, XP, ##__VA_ARGS__>;                                         \
     const int lds = WbGeo<HM>::template lds_bytes<XP>();                                                    \
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;                      \
     hipLaunchKernelGGL(kern, grid, dim3(WB_NT), lds, s, a[0], a[1]);                                        \
   } while (0)
     const bool wide = wgrad_wide(p->nh, p->nz);
-    if (wide) { if (p->x_exact_bf16) WB_LAUNCH2(8, 1); else WB_LAUNCH2(8, 3); }
-    else { if (p->x_exact_bf16) WB_LAUNCH2(6, 1); else WB_LAUNCH2(6, 3); }
+    const bool xu8 = p->x_exact_bf16 == CLV_FRAMES_U8;
+    if (wide) { if (xu8) WB_LAUNCH2(8, 1, true); else if (p->x_exact_bf16) WB_LAUNCH2(8, 1); else WB_LAUNCH2(8, 3); }
+    else { if (xu8) WB_LAUNCH2(6, 1, true); else if (p->x_exact_bf16) WB_LAUNCH2(6, 1); else WB_LAUNCH2(6, 3); }
 #undef WB_LAUNCH2
   }
   int st = launch_status();

@@ -613,6 +613,7 @@ class VrnnEngine(_EngineBase):
             B >= int(os.environ.get('CLV_DENSE_HW_FWD_ROWS', '512'))
         self.ws_hw = None
         self.stage_spec = None       # set by TrainStep for one forward pass: see _forward_pair
+        self._f8 = None              # the pass's uint8 frames (forward(frames8=...))
         self.ws_b = None
         # Note lists (opt-in: cfg['fuse_notes'] / CLV_FUSE_NOTES=1): when the batch was staged from BINARY uint8 frames,
         # the staging launch also writes each frame's list of notes (ops.gather_rows_multi(notes=...)) and the pair
@@ -688,14 +689,36 @@ class VrnnEngine(_EngineBase):
         self._masks_given = True
 
     def folds_noise(self):
-        """True when forward(noise=...) draws eps_W / eps_Z inside the label and pair kernels (no Philox launch)."""
-        return bool(self.fuse_pair and self.sparse_inputs and self.cfg['D'] % 2 == 0)
+        """True when forward(noise=...) draws eps_W / eps_Z inside the label kernel and the pair kernels / the latent head of the
+        large-batch path (no Philox launch)."""
+        return bool((self.fuse_pair or (self.use_mx and self.fuse_latent)) and self.sparse_inputs and self.cfg['D'] % 2 == 0)
 
-    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None, target=None, noise=None):
+    def frames_u8_supported(self):
+        """Can a training pass read its frames as BYTES (frames8 of forward / loss_and_grads / grads_tail: the uint8 batch the
+        staging launch copied out of the frame store, never widened to float)?  The large-batch path with every consumer of
+        frames on its byte-reading kernel: csrc/lstm_mx.hip (note lists), wgrad_bf16.hip (x rows), out_head_bf16.hip (targets),
+        outer_bf16.hip (the hW layer's forward and kernel-gradient products)."""
+        cfg, B = self.cfg, self.B
+        D, H, L, T = cfg['D'], cfg['H'], cfg['L'], cfg['T']
+        if not (self.use_mx and self.fuse_head and self.bf16_wgrad and self.dense_hw_grad and self.dense_hw_fwd and D % 4 == 0
+                and os.environ.get('CLV_FRAMES_U8', '1') != '0'):
+            return False
+        return bool(ops.dense_window_fwd_bf16_supported(B, T * D, D, T * D, D) and ops.dense_outer_bf16_supported(B, T * D, D, T * D, D)
+                    and ops.sparse_dense_supported(D) and ops.lstm_wgrad_supported(4 * H, D, H, 0, 2)
+                    and (not self.off or ops.lstm_wgrad_supported(4 * H, D, H, L, 2)))
+
+    def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None, target=None, noise=None, frames8=None):
         """nll = (scale, need_grads): fuse the Bernoulli NLL of the output head into its GEMM; target = the frames the
         output is scored against (default X).
+        frames8 = (X8, Xp8): uint8 [B,T,D] copies of the batch's current / history frames (Xp8 None without history) -- the pass
+        then reads its frames from THEM, as bytes, and X / Xp are not read at all (frames_u8_supported(); training passes
+        whose target is X).
         noise = (seed, stream_w, stream_z, first_w, first_z, step, step_dev): draw eps_W / eps_Z (into the buffers passed)
         instead of reading them -- inside the label and pair kernels where they run, else with one Philox launch."""
+        if frames8 is not None and (target is not None or not self.frames_exact_bf16 or not self.frames_u8_supported()):
+            raise ValueError("frames8 needs the large-batch path (frames_u8_supported()), frames_exact_bf16 and the input frames as "
+                             "the target")
+        self._f8 = frames8
         target = X if target is None else target
         cfg, P, B = self.cfg, self.P, self.B
         self._nll_done = False
@@ -710,7 +733,7 @@ class VrnnEngine(_EngineBase):
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
         g, ws = ops.gemm, self.ws
-        if cfg['use_x_prev'] and Xp.data_ptr() != self.XZ.data_ptr():
+        if cfg['use_x_prev'] and frames8 is None and Xp.data_ptr() != self.XZ.data_ptr():
             self.XZ.view(B, T, self.xz_ld)[:, :, :D].copy_(Xp.view(B, T, D))     # staging copy only
         if self.fuse_pair:
             return self._forward_pair(X, eps_W, eps_Z, w_true, nll, target)
@@ -778,19 +801,24 @@ class VrnnEngine(_EngineBase):
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T = cfg['D'], cfg['H'], cfg['L'], cfg['T']
         BT, off = B * T, self.off
+        f8 = self._f8
+        if f8 is not None:       # the frames as bytes: the batch the staging launch copied out of the frame store
+            X = f8[0]
         self._label_forward(X, eps_W, w_true)
         ops.lstm_mx_fwd(B, T, X, D, D, P.p('encoder_h/kernel'), None, 0, 0, None, self.wk_enc,
                         P.p('encoder_h/recurrent_kernel'), self.hs_enc, self.gates_enc, self.cs_enc, gate_act=self.gate_act)
         if self.fuse_latent:
+            nz = getattr(self, '_noise', None)          # (set by forward(noise=...) when folds_noise(): eps_Z is drawn in the launch)
             ops.latent_head_fwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z, self.zargs, self.Z,
-                                self.xz_ld, self.rowkl)
+                                self.xz_ld, self.rowkl, noise=nz[1] if nz else None)
         else:
             ops.gemm(self.hs_enc, P.p('Zargs/kernel'), self.zargs, BT, 2 * L, H, bias=P.p('Zargs/bias'), ws=self.ws)
             ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
-        ops.lstm_mx_fwd(B, T, self.XZ if off else None, self.xz_ld, off, P.p('decoder_h/kernel') if off else None,
+        hist, hist_ld = (f8[1], D) if (f8 is not None and off) else (self.XZ if off else None, self.xz_ld)
+        ops.lstm_mx_fwd(B, T, hist, hist_ld, off, P.p('decoder_h/kernel') if off else None,
                         self.Z, self.xz_ld, L, P.rows(P.params, 'decoder_h/kernel', off), self.wk_dec,
                         P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.gates_dec, self.cs_dec, gate_act=self.gate_act)
-        self._output_head(target, nll)
+        self._output_head(X if f8 is not None else target, nll)
 
     # -- LSTM(dropout=p), training passes (cl_vrnn/model.py:164,198,227) ---------------------------------------------------
     # Keras 2.0.0 (implementation 0) multiplies the inputs of gate g's projection with a mask m_g [B, input_dim] drawn once per
@@ -1125,20 +1153,22 @@ class VrnnEngine(_EngineBase):
                 Xs[:, t - S].copy_(x_next)
         return Xs
 
-    def _wgrad_args(self, name, X_in, x_ld, x_rows, hs, dz):
+    def _wgrad_args(self, name, X_in, x_ld, x_rows, hs, dz, x8=None):
         """The argument tuple of ops.lstm_wgrad (up to dKz) for one LSTM's kernel gradients on the bf16 matrix cores
-        (csrc/wgrad_bf16.hip: x rows, h rows and z rows at once), or None where that kernel does not apply."""
+        (csrc/wgrad_bf16.hip: x rows, h rows and z rows at once), or None where that kernel does not apply.
+        x8: the frame rows as a uint8 [B*T, nx] batch instead of the first nx columns of X_in (the z rows stay in X_in)."""
         cfg, P = self.cfg, self.P
         H, T, L = cfg['H'], cfg['T'], cfg['L']
         nz = L if name == 'decoder_h' else 0          # the decoder's per-step inputs are [x_{t-1} | z_t]
         nx = x_rows - nz                              # 0: a decoder without history frames
         if not (self.bf16_wgrad and nx > 0 and ops.lstm_wgrad_supported(4 * H, nx, H, nz, self.frames_exact_bf16)):
             return None
-        return (self.B * T, 4 * H, X_in, x_ld, nx, self.frames_exact_bf16, hs, H, H, T, X_in[:, nx:] if nz else None, x_ld, nz,
+        xs, xs_ld = (X_in, x_ld) if (x8 is None or nx == 0) else (x8, nx)
+        return (self.B * T, 4 * H, xs, xs_ld, nx, self.frames_exact_bf16, hs, H, H, T, X_in[:, nx:] if nz else None, x_ld, nz,
                 dz, P.g(name + '/kernel'), P.g(name + '/recurrent_kernel'),
                 P.rows(P.grads, name + '/kernel', nx) if nz else None)
 
-    def _lstm_wgrads(self, name, X_in, x_ld, x_rows, hs, dz, dzsum, w_row, ws, products=True):
+    def _lstm_wgrads(self, name, X_in, x_ld, x_rows, hs, dz, dzsum, w_row, ws, products=True, x8=None):
         """Every weight gradient of one LSTM in two grouped launches.
         Over dz [B*T,4H] (K = B*T): kernel rows of the per-step inputs (x_t, or [x_{t-1} | z_t] for the
         decoder) and the recurrent kernel (h_{t-1}: shift 1, zero at t == 0); products=False: already formed
@@ -1149,7 +1179,9 @@ class VrnnEngine(_EngineBase):
         G4 = 4 * H
         rq = self._rq()
         if products:
-            args = self._wgrad_args(name, X_in, x_ld, x_rows, hs, dz)
+            args = self._wgrad_args(name, X_in, x_ld, x_rows, hs, dz, x8)
+            if args is None and x8 is not None:
+                raise RuntimeError("frames8: the %s kernel gradients have no byte-reading kernel at these shapes" % name)
             if args is not None:
                 ops.lstm_wgrad(*args, ws, defer=rq, split_scale=2 if self.fine_grid else 1)
             else:
@@ -1219,9 +1251,9 @@ class VrnnEngine(_EngineBase):
             ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc,
                              self.dzsum_enc, gate_act=self.gate_act, H=H)
 
-    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True, target=None, noise=None):
+    def loss_and_grads(self, X, Xp, w_true, eps_W, eps_Z, need_grads=True, do_tail=True, target=None, noise=None, frames8=None):
         """target: the frames the decoder output is scored against (default X; the next frames under --predict_next).
-        noise: see forward()."""
+        noise, frames8: see forward() (with frames8 and do_tail=False, hand the same frames8 to grads_tail())."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, G4 = Cn - 1, B * T, 4 * H
@@ -1229,7 +1261,7 @@ class VrnnEngine(_EngineBase):
         g, ws, off = ops.gemm, self.ws, self.off
         self._train_pass = bool(need_grads)      # LSTM(dropout=p) applies in training passes only
         try:
-            self.forward(X, Xp, eps_W, eps_Z, w_true, nll=(inv_bt, need_grads), target=target, noise=noise)
+            self.forward(X, Xp, eps_W, eps_Z, w_true, nll=(inv_bt, need_grads), target=target, noise=noise, frames8=frames8)
         finally:
             self._train_pass = False
         if not self._nll_done:
@@ -1285,18 +1317,18 @@ class VrnnEngine(_EngineBase):
             # over X (csrc/outer_bf16.hip); else the kernel that walks the notes
             outer = ops.dense_outer_bf16 if (self.dense_hw_grad and self.frames_exact_bf16 and
                                              ops.dense_outer_bf16_supported(B, T * D, D, T * D, D)) else ops.sparse_outer
-            outer(B, T * D, D, X, T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'),
+            outer(B, T * D, D, X if frames8 is None else frames8[0], T * D, self.dhW, D, P.g('hW/kernel'), colsum=P.g('hW/bias'),
                   gdot=(self.hW, D, P.p('hW/bias'), self.gdot))
             self.gdot_fresh = True
         else:
             g(X, self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)
             ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
         if do_tail:
-            self.grads_tail(X)
+            self.grads_tail(X, frames8=frames8)
 
-    def grads_tail(self, X):
+    def grads_tail(self, X, frames8=None):
         """Backward, late part: every other weight gradient (products over dz / dlogits / dzargs / dwargs that
-        nothing downstream waits for), their split-K reductions in one launch."""
+        nothing downstream waits for), their split-K reductions in one launch.  frames8: as the pass's loss_and_grads()."""
         cfg, P, B = self.cfg, self.P, self.B
         D, H, L, T, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C']
         C1, BT, off = Cn - 1, B * T, self.off
@@ -1310,6 +1342,8 @@ class VrnnEngine(_EngineBase):
         # workgroups of 16 stages instead of twice 256 of 8; half as many slabs to reduce)
         dec = ('decoder_h', self.XZ, self.xz_ld, off + L, self.hs_dec, self.gates_dec)
         enc = ('encoder_h', X, D, D, self.hs_enc, self.gates_enc)
+        if frames8 is not None:      # the frame rows of both products read the byte batch (the z rows stay in [Xp | Z])
+            dec, enc = dec + (frames8[1],), enc + (frames8[0],)
         paired = False
         if self.wgrad_pair:
             pd, pe = self._wgrad_args(*dec), self._wgrad_args(*enc)
@@ -1318,11 +1352,11 @@ class VrnnEngine(_EngineBase):
                     self.ws_b = ops.Workspace(self.device)
                 ops.lstm_wgrad_pair(pd, pe, (ws, self.ws_b), defer=rq, split_scale=2 if self.fine_grid else 1)
                 paired = True
-        self._lstm_wgrads(*dec, self.dzsum_dec, off + L, ws, products=not paired)
+        self._lstm_wgrads(*dec[:6], self.dzsum_dec, off + L, ws, products=not paired, x8=dec[6] if len(dec) > 6 else None)
         if not getattr(self, '_head_grad_done', False):
             self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, rq)
         self._head_grad_done = False
-        self._lstm_wgrads(*enc, self.dzsum_enc, D, ws, products=not paired)
+        self._lstm_wgrads(*enc[:6], self.dzsum_enc, D, ws, products=not paired, x8=enc[6] if len(enc) > 6 else None)
         skinny = None
         if Cn + 1 <= 16 and B <= 4096:
             # label rows + bias of both LSTMs' input-kernel gradients (K = batch rows of sum_t dz)

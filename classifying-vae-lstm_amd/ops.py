@@ -148,7 +148,7 @@ def lstm_wgrad(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dK
     need = L.clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, int(split_scale))
     buf = defer.scratch(need) if defer is not None else ws.ensure(need)
     job = defer.next_job() if defer is not None else None
-    check(L.clv_lstm_wgrad_ex(K, N, _ptr(X), ldx, nx, int(bool(x_exact_bf16)), _ptr(H), ldh, nh, 1, T,
+    check(L.clv_lstm_wgrad_ex(K, N, _ptr(X), ldx, nx, _frames_mode(X, x_exact_bf16), _ptr(H), ldh, nh, 1, T,
                               _ptr(Z), ldz, nz, _ptr(dz), N, _ptr(dKx), N, _ptr(dU), N, _ptr(dKz), N, float(beta),
                               int(split_scale), _ptr(buf), buf.numel(), job, _stream()), "clv_lstm_wgrad_ex")
 
@@ -156,7 +156,7 @@ def lstm_wgrad(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dK
 def _wgrad_problem(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dKx, dU, dKz, beta=0.0):
     w = _lib.WgradProblem()
     w.K, w.N = K, N
-    w.X, w.ldx, w.nx, w.x_exact_bf16 = _ptr(X), ldx, nx, int(bool(x_exact_bf16))
+    w.X, w.ldx, w.nx, w.x_exact_bf16 = _ptr(X), ldx, nx, _frames_mode(X, x_exact_bf16)
     w.H, w.ldh, w.nh, w.h_shift, w.h_zero_period = _ptr(H), ldh, nh, 1, T
     w.Z, w.ldz, w.nz = _ptr(Z), ldz, nz
     w.dz, w.lddz = _ptr(dz), N
@@ -202,13 +202,14 @@ def out_head_train_supported(H, D):
 
 def out_head_train(R, H, D, hs, Wo, bo, Y, scale, rownll, dhs, dWo, dbo, ws, logits=None, dlogits=None, ldy=None,
                    defer=None):
-    """Output head forward + Bernoulli NLL + dhs + dWo/dbo in one launch (see clv_out_head_train).
+    """Output head forward + Bernoulli NLL + dhs + dWo/dbo in one launch (see clv_out_head_train).  Y: the target frames,
+    float32 or the bytes themselves (uint8).
     defer: a ReduceQueue that takes the pending reduction of the weight-gradient slabs."""
     L = _lib.lib()
     need = L.clv_out_head_train_workspace_bytes(R)
     buf = defer.scratch(need) if defer is not None else ws.ensure(need)
     job = defer.next_job() if defer is not None else None
-    check(L.clv_out_head_train(R, H, D, _ptr(hs), _ptr(Wo), _ptr(bo), _ptr(Y), ldy if ldy is not None else D,
+    check(L.clv_out_head_train(R, H, D, _ptr(hs), _ptr(Wo), _ptr(bo), _ptr(Y), _is_u8(Y), ldy if ldy is not None else D,
                                float(scale), _ptr(logits), _ptr(rownll), _ptr(dlogits), _ptr(dhs), _ptr(dWo), _ptr(dbo),
                                _ptr(buf), buf.numel(), job, _stream()), "clv_out_head_train")
 
@@ -217,10 +218,11 @@ def latent_head_supported(H, L):
     return bool(_lib.lib().clv_latent_head_supported(H, L))
 
 
-def latent_head_fwd(R, H, L, hs, Wz, bz, eps, zargs, Z, ldz, rowkl=None):
-    """zargs = hs.Wz + bz, the reparametrised sample into Z (row stride ldz) and the rows' KL in one launch."""
+def latent_head_fwd(R, H, L, hs, Wz, bz, eps, zargs, Z, ldz, rowkl=None, noise=None):
+    """zargs = hs.Wz + bz, the reparametrised sample into Z (row stride ldz) and the rows' KL in one launch.
+    noise (noise_draw(...)): eps is drawn inside the kernel and written to `eps`, else read from it."""
     check(_lib.lib().clv_latent_head_fwd(R, H, L, _ptr(hs), _ptr(Wz), _ptr(bz), _ptr(eps), _ptr(zargs), _ptr(Z), ldz,
-                                         _ptr(rowkl), _stream()), "clv_latent_head_fwd")
+                                         _ptr(rowkl), _noise_ref(noise), _stream()), "clv_latent_head_fwd")
 
 
 def latent_head_bwd(R, H, L, hs, Wz, zargs, eps, dZ, lddz, kl_scale, dhs, dWz, dbz, ws, dzargs=None, defer=None):
@@ -312,8 +314,9 @@ def lstm_mx_supported(B, nx, nz, H=88):
 
 
 def lstm_mx_fwd(B, T, X, ldx, nx, Kx, Z, ldz, nz, Kz, rowbias, U, hs, coef, aux, gate_act=0, H=88):
-    """LSTM training forward with the input products inside the kernel: frames X (sparse rows of Kx) and latents Z."""
-    check(_lib.lib().clv_lstm_mx_fwd(B, T, H, gate_act, _ptr(X), ldx, nx, _ptr(Kx), _ptr(Z), ldz, nz, _ptr(Kz),
+    """LSTM training forward with the input products inside the kernel: frames X (sparse rows of Kx; float32 or the bytes
+    themselves, ldx in elements) and latents Z."""
+    check(_lib.lib().clv_lstm_mx_fwd(B, T, H, gate_act, _ptr(X), _is_u8(X) if X is not None else 0, ldx, nx, _ptr(Kx), _ptr(Z), ldz, nz, _ptr(Kz),
                                      _ptr(rowbias), _ptr(U), _ptr(hs), _ptr(coef), _ptr(aux), _stream()), "clv_lstm_mx_fwd")
 
 
@@ -363,9 +366,9 @@ def dense_outer_bf16_supported(Bn, nx, N, ldx, ldg):
 
 def dense_outer_bf16(Bn, nx, N, X, ldx, G, ldg, out, ldo=None, colsum=None, gdot=None):
     """sparse_outer's product for inputs that are exactly bf16 numbers (frames kept as bytes), dense on the bf16 matrix cores
-    (csrc/outer_bf16.hip); same arguments."""
+    (csrc/outer_bf16.hip); same arguments.  X: float32, or the bytes themselves (uint8; ldx in elements either way)."""
     h, ldh, hb, go = gdot if gdot is not None else (None, 0, None, None)
-    check(_lib.lib().clv_dense_outer_bf16(Bn, nx, N, _ptr(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
+    check(_lib.lib().clv_dense_outer_bf16(Bn, nx, N, _ptr(X), _is_u8(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
                                           _ptr(colsum), _ptr(h), int(ldh), _ptr(hb), _ptr(go), _stream()), "clv_dense_outer_bf16")
 
 
@@ -489,6 +492,20 @@ def noise_draw(seed, stream, first, step=0, step_dev=None):
     return _lib.NoiseDraw(int(seed), int(first), int(stream), int(step), _ptr(step_dev))
 
 
+def _is_u8(t):
+    """1 for a uint8 tensor (frames kept as bytes), 0 for float32: the x_u8 flag of the entry points that take either"""
+    if t.dtype == torch.uint8:
+        return 1
+    if t.dtype != torch.float32:
+        raise TypeError("frames must be float32 or uint8, got %s" % t.dtype)
+    return 0
+
+
+def _frames_mode(X, exact):
+    """CLV_FRAMES_* of include/clvae.h: 2 = X holds the frames as bytes, 1 = float values that are exactly bf16 numbers, 0 = any"""
+    return 2 if _is_u8(X) else int(bool(exact))
+
+
 def _noise_ref(noise):
     return C.byref(noise) if noise is not None else None
 
@@ -540,7 +557,7 @@ def dense_window_fwd_bf16(Bn, nx, N, X, ldx, K, ldk, ws):
     for vrnn_label_fwd_x(parts=...).  ws: a Workspace that keeps the buffer."""
     L = _lib.lib()
     buf = ws.ensure(L.clv_dense_window_fwd_bf16_workspace_bytes(Bn, nx, N))
-    check(L.clv_dense_window_fwd_bf16(Bn, nx, N, _ptr(X), ldx, _ptr(K), ldk, _ptr(buf), buf.numel(), _stream()),
+    check(L.clv_dense_window_fwd_bf16(Bn, nx, N, _ptr(X), _is_u8(X), ldx, _ptr(K), ldk, _ptr(buf), buf.numel(), _stream()),
           "clv_dense_window_fwd_bf16")
     return buf, L.clv_dense_window_fwd_bf16_splits(Bn, nx)
 
@@ -597,7 +614,8 @@ NOTE_ROW, NOTE_NONE = 96, 88       # CLV_NOTE_ROW / CLV_NOTE_NONE (include/clvae
 
 def gather_rows_multi(rows, idx, segs, row0=0, notes=None, cursor=None):
     """segs: up to 4 (src, out, row_elems, chunk, out_ld[, stride, offset, table]); one launch; idx None = rows
-    row0..row0+rows-1.  A uint8 src (binary frames kept as bytes) is converted to float on the way.  With (stride,
+    row0..row0+rows-1.  A uint8 src (binary frames kept as bytes) is converted to float on the way -- or copied as bytes when
+    `out` is a uint8 tensor too.  With (stride,
     offset, table) source row r starts at element table[idx[r]] * stride + offset: windows of a frame store.
     notes: per segment None or a uint8 tensor [rows * pieces, NOTE_ROW] that receives the frames' note lists (uint8
     sources of binary frames only): what lstm_pair_fwd gathers the input projections from.
@@ -606,7 +624,10 @@ def gather_rows_multi(rows, idx, segs, row0=0, notes=None, cursor=None):
     n = len(segs)
     P, I, U = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     src = P(*[s_[0].data_ptr() for s_ in segs])
-    u8 = U(*[1 if s_[0].dtype == torch.uint8 else 0 for s_ in segs])
+    if any(s_[1].dtype == torch.uint8 and s_[0].dtype != torch.uint8 for s_ in segs):
+        raise TypeError("a uint8 output takes a uint8 source")
+    # 2: bytes in, bytes out (a batch that stays uint8, out_ld in bytes); 1: bytes widened to float; 0: float
+    u8 = U(*[(2 if s_[1].dtype == torch.uint8 else 1) if s_[0].dtype == torch.uint8 else 0 for s_ in segs])
     out = P(*[s_[1].data_ptr() for s_ in segs])
     re = I(*[int(s_[2]) for s_ in segs])
     ch = I(*[int(s_[3]) for s_ in segs])

@@ -58,6 +58,11 @@ class TrainStep:
         else:
             self.Xp = torch.zeros(*shp, **f)
         self.Y = None        # reconstruction target when it is not the input itself (--predict_next): see set_target()
+        # The bound batches of the large-batch path stay BYTES (round 6): the staging launch copies the rows out of the uint8 frame
+        # store as they are (X8 / Xp8, a quarter of the float batch) and every kernel of the step reads frames from them
+        # (VrnnEngine.frames_u8_supported); X / Xp are then not written at all.  _f8: the captured step uses them.
+        self.X8 = self.Xp8 = None
+        self._f8 = None
         self.w_true = torch.zeros(B, cfg['C'], **f)
         self.eps_w = torch.zeros(B, C1, **f)
         self.eps_z = torch.zeros(B * T, L, **f)
@@ -159,9 +164,28 @@ class TrainStep:
             self._bound = None
             self.recapture()
 
+    def _bytes_batch(self, b):
+        """(X8, Xp8) when the bound batches can stay uint8 for the whole step, else None (see __init__)."""
+        eng = self.eng
+        if not (self.is_vrnn and b['target'] is None and getattr(eng, 'frames_u8_supported', lambda: False)()):
+            return None
+        need_hist = eng.off > 0
+        if need_hist != (b['hist'] is not None):
+            return None
+        for x in ((b['cur'], b['hist']) if need_hist else (b['cur'],)):
+            t = x.store if isinstance(x, DevWindows) else x
+            if t.dtype != torch.uint8 or not t.is_contiguous():
+                return None
+        if self.X8 is None:
+            shp = tuple(self.X.shape)
+            self.X8 = torch.zeros(*shp, dtype=torch.uint8, device=self.X.device)
+            self.Xp8 = torch.zeros(*shp, dtype=torch.uint8, device=self.X.device) if need_hist else None
+        return (self.X8, self.Xp8)
+
     def _stage_bound(self):
         b = self._bound
-        segs = self._segments(b['cur'], b['hist'], b['w'], b['target'])
+        self._f8 = self._bytes_batch(b)
+        segs = self._segments(b['cur'], b['hist'], b['w'], b['target'], bytes_out=self._f8)
         ops.gather_rows_multi(self.eng.B, b['idx'], segs, notes=self._note_outputs(b['cur'], b['hist'], len(segs)),
                               cursor=(self.eng.P.iterations, b['step0'], b['period'], b['stride'], b['offset']))
 
@@ -209,6 +233,7 @@ class TrainStep:
             self.eng.keep_logits = keep
 
     def _main_pass(self):
+        self._f8 = None
         if self._bound is not None:
             st = self._label_stage()
             if st is None:
@@ -221,14 +246,14 @@ class TrainStep:
             return
         if self.is_vrnn:     # eps is drawn inside the label / pair kernels where they run (else one Philox launch in forward())
             self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, do_tail=False, target=self.Y,
-                                    noise=self.noise_spec())
+                                    noise=self.noise_spec(), frames8=self._f8)
             return
         self.draw_noise()
         self.eng.loss_and_grads(self.X, self.Xp, self.w_true, self.eps_w, self.eps_z, target=self.Y)
 
     def _tail(self):
         if self.is_vrnn:
-            self.eng.grads_tail(self.X)
+            self.eng.grads_tail(self.X, frames8=self._f8)
 
     def _update(self):
         # single GPU, cl_vrnn: the backward pass left sum_j K dK of the hW kernel (VrnnEngine.gdot), so Adam-WN runs in two
@@ -256,10 +281,10 @@ class TrainStep:
                              advanced=self._folded())
 
     # -- public -----------------------------------------------------------
-    def _segments(self, cur, hist, w, target=None):
+    def _segments(self, cur, hist, w, target=None, bytes_out=None):
         """(src, out, row_elems, chunk, out_ld[, stride, offset, table]) of the current frames, history frames, labels and
         (optional) target frames of a batch.  cur / hist / target are device tensors of whole rows or DevWindows (windows
-        of a frame store)."""
+        of a frame store).  bytes_out = (X8, Xp8): the frames are copied as bytes into these uint8 buffers (_bytes_batch)."""
         row, D = int(self.X[0].numel()), self.eng.cfg['D']
 
         def src(x):
@@ -271,6 +296,13 @@ class TrainStep:
             self.eng.frames_exact_bf16 = exact
             self.recapture()
         c, cx = src(cur)
+        if bytes_out is not None:
+            segs = [(c, bytes_out[0], row, D, D) + cx]
+            if hist is not None:
+                h, hx = src(hist)
+                segs.append((h, bytes_out[1], row, D, D) + hx)
+            segs.append((w, self.w_true, int(self.w_true.shape[1]), 0, 0))
+            return segs
         segs = [(c, self.X, row, D, D) + cx]          # frame by frame (the same bytes as one piece; note lists are per frame)
         if hist is not None:
             h, hx = src(hist)

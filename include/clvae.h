@@ -179,19 +179,24 @@ int clv_splitk_reduce_multi_ex(const clv_reduce_job* jobs, int njobs, const floa
  * and like the *_deferred GEMMs the final sums (C = beta*C + sum) are formed by the reduction, now (job == NULL) or by
  * clv_splitk_reduce_multi.  Limits (clv_lstm_wgrad_supported): N == 352; nx <= 96, nh <= 96, nz <= 32; nx, nh,
  * ldx, ldh, lddz multiples of 4, 16-byte aligned bases; more than 96 rows of H and Z together, or more than 8 rows
- * of Z, need x_exact_bf16 (the wide form of the kernel has no room for three pieces of X). */
+ * of Z, need x_exact_bf16 (the wide form of the kernel has no room for three pieces of X).
+ * x_exact_bf16 == CLV_FRAMES_U8 (2): X IS the frames as bytes -- uint8 rows, ldx in bytes, 4-byte aligned -- i.e. the frame
+ * store's own format: the training step of the large-batch path never widens its frames to float (round 6). */
+#define CLV_FRAMES_F32       0   /* float rows, any values */
+#define CLV_FRAMES_F32_EXACT 1   /* float rows whose values are exactly bf16 numbers */
+#define CLV_FRAMES_U8        2   /* uint8 rows */
 int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16);
 size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz);
 /* split_scale (1..8): that many times as many, proportionally shorter row ranges (and slabs).  1 = one workgroup per CU,
  * the fastest grid on an idle GPU; 2 is what the data-parallel step uses: the gradient all-reduce's kernel holds a few
  * CUs while these products run, and a grid of exactly one workgroup per CU would then need a whole second round. */
 size_t clv_lstm_wgrad_workspace_bytes_ex(int K, int N, int nx, int nh, int nz, int split_scale);
-int clv_lstm_wgrad_ex(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+int clv_lstm_wgrad_ex(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
                       const float* H, int ldh, int nh, int h_shift, int h_zero_period,
                       const float* Z, int ldz, int nz, const float* dz, int lddz,
                       float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
                       int split_scale, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
-int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf16,
+int clv_lstm_wgrad(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
                    const float* H, int ldh, int nh, int h_shift, int h_zero_period,
                    const float* Z, int ldz, int nz, const float* dz, int lddz,
                    float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
@@ -203,7 +208,7 @@ int clv_lstm_wgrad(int K, int N, const float* X, int ldx, int nx, int x_exact_bf
  * the same K, N and x_exact_bf16 and take the same form of the kernel (clv_lstm_wgrad_pair_supported). */
 typedef struct clv_wgrad_problem {
   int32_t K, N;
-  const float* X; int32_t ldx, nx, x_exact_bf16;
+  const void* X; int32_t ldx, nx, x_exact_bf16;      /* x_exact_bf16 == CLV_FRAMES_U8: X holds bytes, ldx counts bytes */
   const float* H; int32_t ldh, nh, h_shift, h_zero_period;
   const float* Z; int32_t ldz, nz;
   const float* dz; int32_t lddz;
@@ -282,6 +287,7 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  *   z_t = X[b,t,:nx] . Kx + Z[b,t,:nz] . Kz + rowbias[b,:] + h_{t-1} . U
  * X: B*T rows of stride ldx (piano-roll frames; any float values are handled exactly, cost grows with the nonzeros of a
  * frame: Kx [nx,4H] stays in LDS and only the rows of the notes that are on are added), nx <= 96, nx == 0: no frames;
+ * x_u8 != 0: X holds the frames as BYTES (uint8 rows, ldx in bytes) -- the frame store's own format, no float copy of a batch;
  * Z: B*T rows of stride ldz, nz <= 32 latent inputs times Kz [nz,4H] as one more MFMA k-step, nz == 0: none.
  * No [B*T,4H] projection buffer exists (clv_sparse_proj + clv_lstm_seq_fwd read and write one).  Zero initial state.
  * Outputs: hs [B*T,H] and the backward pass's coefficients (the quantities of clv_lstm_pair_fwd) as UNIT-MAJOR records,
@@ -295,7 +301,7 @@ int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
  * CLV_LSTM_MX=1 / 0 forces / forbids them for measurements and tests). */
 int clv_lstm_mx_supported(int B, int H, int nx, int nz);
 int clv_lstm_mx_fwd(int B, int T, int H, int gate_act,
-                    const float* X, int ldx, int nx, const float* Kx,
+                    const void* X, int x_u8, int ldx, int nx, const float* Kx,
                     const float* Z, int ldz, int nz, const float* Kz,
                     const float* rowbias, const float* U,
                     float* hs, float* coef, float* aux, void* stream);
@@ -515,11 +521,12 @@ int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, i
  * product handed in: the workgroup of a batch row sums its row of the chunks, adds bh, applies the relu and goes on with the
  * label path.  From a few hundred batch rows on this replaces the note-walking gather (every kernel row is then fetched
  * once per workgroup instead of once per batch row that has the note).  N <= 96; N, ldx, ldk multiples of 4, nx of 8;
- * 16-byte aligned X and K; arrays below 2 GiB.  cl_vrnn/model.py:174-176. */
+ * 16-byte aligned X and K; arrays below 2 GiB.  x_u8 != 0: X holds the frames as BYTES (uint8, ldx in bytes, 4-byte
+ * aligned) -- the frame store's own format, widened inside the kernel (clv_frames_u8 below).  cl_vrnn/model.py:174-176. */
 int clv_dense_window_fwd_bf16_supported(int Bn, int nx, int N, int ldx, int ldk);
 int clv_dense_window_fwd_bf16_splits(int Bn, int nx);
 size_t clv_dense_window_fwd_bf16_workspace_bytes(int Bn, int nx, int N);
-int clv_dense_window_fwd_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* K, int ldk, float* part,
+int clv_dense_window_fwd_bf16(int Bn, int nx, int N, const void* X, int x_u8, int ldx, const float* K, int ldk, float* part,
                               size_t part_bytes, void* stream);
 int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float* part, int splits,
                              const float* bh, float* hW_out, const float* Ka, const float* ba,
@@ -607,18 +614,20 @@ int clv_gemm_bce_f32(int M, int N, int K, const float* A, int lda, const float* 
  * dWo = hs^T.dl, dbo = sum_r dl, with dl kept on chip (cl_vrnn/model.py:229-234, 241-242 and their K.gradients).
  * hs [R,88] and Wo 16-byte aligned; logits / dlogits may be NULL (not stored).  dWo/dbo leave as one partial slab per
  * workgroup in `ws`: with job == NULL they are reduced at once, otherwise *job receives the pending reduction for
- * clv_splitk_reduce_multi.  Replaces clv_gemm_bce_f32 + clv_gemm_f32 (NT) + clv_gemm_grouped_tn for this layer. */
+ * clv_splitk_reduce_multi.  Replaces clv_gemm_bce_f32 + clv_gemm_f32 (NT) + clv_gemm_grouped_tn for this layer.
+ * y_u8 != 0: the targets are the frames as BYTES (uint8, ldy in bytes and a multiple of 4, Y 4-byte aligned). */
 int clv_out_head_train_supported(int H, int D);
 size_t clv_out_head_train_workspace_bytes(int R);
 int clv_out_head_train(int R, int H, int D, const float* hs, const float* Wo, const float* bo,
-                       const float* Y, int ldy, float scale, float* logits, float* rownll, float* dlogits,
+                       const void* Y, int y_u8, int ldy, float scale, float* logits, float* rownll, float* dlogits,
                        float* dhs, float* dWo, float* dbo, void* ws, size_t ws_bytes, clv_reduce_job* job,
                        void* stream);
 
 /* The latent head of cl_vrnn outside the pair kernels (H == 88, latent_dim <= 32; cl_vrnn/model.py:200-216, 243 and their
  * K.gradients), one launch per pass (csrc/latent_head.hip):
  *   forward:  zargs = hs.Wz + bz [R,2L] = (mean | log_var), Z[r, :L] = mean + exp(log_var/2) * eps (row stride ldz),
- *             rowkl[r] = -0.5 sum_l (1 + log_var - mean^2 - exp(log_var)) (may be NULL)
+ *             rowkl[r] = -0.5 sum_l (1 + log_var - mean^2 - exp(log_var)) (may be NULL); noise != NULL: eps [R,L] is drawn in
+ *             the kernel (clv_noise_draw: element r * L + l) and written for the backward pass, no Philox launch
  *             -- replaces clv_gemm_f32 + clv_gauss_fwd;
  *   backward: dzargs = (dZ + kl_scale*mean | dZ*eps*sd/2 - kl_scale*(1 - sd^2)/2) (stored only when dzargs != NULL),
  *             dhs = dzargs.Wz^T [R,88], dWz = hs^T.dzargs, dbz = sum_r dzargs -- replaces clv_gauss_bwd + clv_gemm_f32 (NT)
@@ -627,8 +636,8 @@ int clv_out_head_train(int R, int H, int D, const float* hs, const float* Wo, co
  * hs 16-byte aligned. */
 int clv_latent_head_supported(int H, int L);
 size_t clv_latent_head_bwd_workspace_bytes(int R, int L);
-int clv_latent_head_fwd(int R, int H, int L, const float* hs, const float* Wz, const float* bz, const float* eps,
-                        float* zargs, float* Z, int ldz, float* rowkl, void* stream);
+int clv_latent_head_fwd(int R, int H, int L, const float* hs, const float* Wz, const float* bz, float* eps,
+                        float* zargs, float* Z, int ldz, float* rowkl, const clv_noise_draw* noise, void* stream);
 int clv_latent_head_bwd(int R, int H, int L, const float* hs, const float* Wz, const float* zargs, const float* eps,
                         const float* dZ, int lddz, float kl_scale, float* dzargs, float* dhs, float* dWz, float* dbz,
                         void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
@@ -672,9 +681,10 @@ int clv_sparse_outer_ex(int Bn, int nx, int N, const float* X, int ldx, const fl
  * value.  X is then one bf16 piece, G three (an fp32 number is exactly the sum of three bf16 numbers), the piece products are
  * exact and accumulate in fp32: the products of the fp32 path in another summation order.  The kernel streams X once
  * (csrc/outer_bf16.hip); it replaces the note-walking kernel from a few hundred batch rows on (cl_vrnn/model.py:174-176, the
- * hW layer's kernel gradient).  N <= 96, N, nx, ldx, ldg multiples of 4, 16-byte aligned X and G, arrays below 2 GiB. */
+ * hW layer's kernel gradient).  N <= 96, N, nx, ldx, ldg multiples of 4, 16-byte aligned X and G, arrays below 2 GiB.
+ * x_u8 != 0: X holds bytes (uint8, ldx in bytes, 4-byte aligned). */
 int clv_dense_outer_bf16_supported(int Bn, int nx, int N, int ldx, int ldg);
-int clv_dense_outer_bf16(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+int clv_dense_outer_bf16(int Bn, int nx, int N, const void* X, int x_u8, int ldx, const float* G, int ldg, float* out, int ldo,
                          float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream);
 
 /* out[r, :] = src[idx[r], :] for r < rows; idx is a device int64 array (mini-batch assembly from the
@@ -691,7 +701,10 @@ int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int
  * With stride = one frame the rows are overlapping windows of a frame store (songs are kept once, as
  * uint8, and the sliding windows of utils/pianoroll.py:49-71 are never materialised).
  * src_u8 (may be NULL): src_u8[k] != 0 marks a uint8 source (binary piano-roll frames kept as bytes in HBM,
- * a quarter of the footprint and of the gather's read traffic); the output is float either way. */
+ * a quarter of the footprint and of the gather's read traffic); the output is float -- unless
+ * src_u8[k] == 2: then out[k] is a uint8 buffer too (out_ld[k] in bytes) and the rows are copied as bytes: the batch of
+ * the large-batch training step, whose kernels read frames as bytes (x_u8 / CLV_FRAMES_U8).  Needs row_elems, chunk, out_ld,
+ * stride and offset multiples of 4 and 4-byte aligned bases. */
 /* clv_gather_rows_multi_notes: the same launch also writes NOTE LISTS for the segments whose notes_out[k] is not NULL
  * (uint8 sources of binary frames, chunk[k] <= 88 and a multiple of 4): frame p of output row r gets CLV_NOTE_ROW bytes
  * at notes_out[k] + (r * pieces + p) * CLV_NOTE_ROW -- the indices of its nonzero bytes (any order), then CLV_NOTE_NONE

@@ -1037,6 +1037,39 @@ def test_latent_head_matches_numpy(dev, R, L, defer, pads):
     assert torch.equal(dhs2, dhs) and torch.equal(dWz2, dWz) and torch.equal(dbz2, dbz)
 
 
+@pytest.mark.parametrize("R,L,first", [(4096, 32, 0), (128 * 9 + 5, 32, 4096 * 32), (77, 20, 40), (130, 12, 12 * 7), (37, 9, 0),
+                                       (300, 1, 5), (64, 8, 6), (1000, 17, 3), (5, 4, (1 << 33) + 8)])
+def test_latent_head_draws_its_own_noise(dev, R, L, first):
+    """clv_latent_head_fwd(noise=...): eps is drawn inside the launch -- element (r, l) = the Philox normal at index
+    first + r * L + l (oracle/philox.py), BIT FOR BIT what clv_philox_normal writes (quad-shared counters when L and first are multiples of 4, one
+    call per element otherwise; an index beyond 2^32) -- written for the backward pass, and zargs / Z / KL are those of the
+    same launch fed with that eps."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(R * L)
+    H, seed, stream, step = 88, 0x1234567890AB, 7, 3
+    hs = np.tanh(rng.standard_normal((R, H))).astype(np.float32)
+    Wz = (rng.standard_normal((H, 2 * L)) * 0.2).astype(np.float32)
+    bz = (rng.standard_normal(2 * L) * 0.3).astype(np.float32)
+    z = lambda *sh: torch.full(sh, -7.0, dtype=torch.float32, device=dev)
+    hs_d, Wz_d, bz_d = T(hs, dev), T(Wz, dev), T(bz, dev)
+    eps_d, zargs, Z, rowkl = z(R + 1, L), z(R, 2 * L), z(R, L + 4), z(R)
+    it = torch.tensor([2], dtype=torch.int32, device=dev)         # the device step counter is added to `step`
+    nz = ops.noise_draw(seed, stream, first, step - 2, it)
+    ops.latent_head_fwd(R, H, L, hs_d, Wz_d, bz_d, eps_d, zargs, Z, L + 4, rowkl, noise=nz)
+    torch.cuda.synchronize()
+    want = OP.normal(R * L, seed, step=step, stream_id=stream, first_index=first).reshape(R, L)
+    got = eps_d.cpu().numpy()
+    assert (got[R] == -7.0).all()
+    np.testing.assert_allclose(got[:R], want, atol=2e-5)           # (the oracle's libm differs from the device's in the last bits)
+    ref = torch.empty(R * L, dtype=torch.float32, device=dev)      # ... and what the stand-alone launch writes
+    ops.philox_normal(ref, R * L, seed, step, stream, first)
+    assert torch.equal(ref.view(R, L), eps_d[:R])
+    zargs2, Z2, rowkl2 = z(R, 2 * L), z(R, L + 4), z(R)
+    ops.latent_head_fwd(R, H, L, hs_d, Wz_d, bz_d, eps_d, zargs2, Z2, L + 4, rowkl2)
+    torch.cuda.synchronize()
+    assert torch.equal(zargs, zargs2) and torch.equal(Z, Z2) and torch.equal(rowkl, rowkl2)
+
+
 def _mx_case(rng, B, Tn, nx, nz, density, gate):
     """inputs of one clv_lstm_mx_fwd / _bwd call and the oracle's forward / backward for them"""
     H = 88
