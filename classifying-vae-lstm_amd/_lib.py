@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CLV_LIB: another build of the same ABI (A/B measurements inside one GPU session; tools/build_variant.sh)
 LIB_PATH = os.environ.get("CLV_LIB") or os.path.join(_HERE, "libclvae_hip.so")
 
-ABI_VERSION = 500      # CLV_ABI_VERSION of include/clvae.h
+ABI_VERSION = 600      # CLV_ABI_VERSION of include/clvae.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_MASKPOS = 0, 1, 2, 3
 GATE_HARD_SIGMOID, GATE_SIGMOID = 0, 1
 
@@ -119,18 +119,13 @@ SIGNATURES = {
     "clv_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p]),
     "clv_gemm_f32_deferred": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p, _p]),
     "clv_gemm_grouped_tn_deferred": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p, _p]),
-    "clv_splitk_reduce_multi": (_i, [_p, _i, _p]),
-    "clv_splitk_reduce_multi_means": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
-    "clv_splitk_reduce_multi_ex": (_i, [_p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
+    "clv_splitk_reduce_multi": (_i, [_p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
     "clv_lstm_wgrad_supported": (_i, [_i, _i, _i, _i, _i]),
-    "clv_lstm_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "clv_lstm_wgrad": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,
-                            _p, _sz, _p, _p]),
-    "clv_lstm_wgrad_workspace_bytes_ex": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "clv_lstm_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "clv_lstm_wgrad_pair_supported": (_i, [_p, _p]),
     "clv_lstm_wgrad_pair_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "clv_lstm_wgrad_pair": (_i, [_p, _p, _i, _p, _p, _p]),
-    "clv_lstm_wgrad_ex": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,
+    "clv_lstm_wgrad": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f,
                                _i, _p, _sz, _p, _p]),
     "clv_gemm_grouped_tn_small2": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _p]),
     "clv_gemm_grouped_auto_split": (_i, [_p, _i, _i, _i]),
@@ -140,10 +135,6 @@ SIGNATURES = {
     "clv_colsum_f32": (_i, [_i, _i, _p, _i, _f, _p, _p, _sz, _p]),
     "clv_lstm_seq_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_seq_bwd_z": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p]),
-    "clv_lstm_seq_fwd_z_supported": (_i, [_i, _i, _i]),
-    "clv_lstm_seq_fwd_z": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "clv_lstm_seq_fwd_x_lds_bytes": (_sz, [_i, _i]),
-    "clv_lstm_seq_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_seq_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_mx_supported": (_i, [_i, _i, _i, _i]),
     "clv_lstm_mx_fwd": (_i, [_i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
@@ -153,8 +144,7 @@ SIGNATURES = {
     "clv_lstm_pair_pack": (_i, [_i, _i, _p, _p, _p, _p, _p, _p]),
     "clv_lstm_pair_fwd": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p,
                                _p, _p]),
-    "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 12 + [_p, _p, _p, _p, _sz, _p, _p]),
-    "clv_lstm_pair_bwd_ex": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 12 + [_p, _p, _p, _p, _sz, _p, _p, _p]),
+    "clv_lstm_pair_bwd": (_i, [_i, _i, _i, _i, _i, _f] + [_p] * 12 + [_p, _p, _p, _p, _sz, _p, _p, _p]),
     "clv_lstm_pair_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_sparse_proj_supported": (_i, [_i, _i]),
     "clv_sparse_proj_lds_bytes": (_sz, [_i, _i]),
@@ -162,8 +152,7 @@ SIGNATURES = {
     "clv_sparse_proj2": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p]),
     "clv_sparse_dense_supported": (_i, [_i]),
     "clv_sparse_dense": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
-    "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p]),
-    "clv_sparse_outer_ex": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
+    "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "clv_dense_outer_bf16_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_dense_outer_bf16": (_i, [_i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "clv_gemm_bce_f32": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _f, _p, _p, _i, _p, _p]),
@@ -182,25 +171,19 @@ SIGNATURES = {
     "clv_label_bwd": (_i, [_i, _i, _p, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _i, _p]),
     "clv_vae_fused_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_vae_fused_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
-    "clv_vae_fused_step": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i, _p,
-                                _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "clv_vae_fused_step_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i,
-                                   _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "clv_vae_fused_step_staged": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i,
-                                       _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_vae_fused_step": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_long, _f, _f, _f, _f, _i,
+                                _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+    "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _p, _p]),
     "clv_vrnn_label_fwd_parts": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _p, _p]),
-    "clv_vrnn_label_fwd_x_staged": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_dense_window_fwd_bf16_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_dense_window_fwd_bf16_splits": (_i, [_i, _i]),
     "clv_dense_window_fwd_bf16_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_dense_window_fwd_bf16": (_i, [_i, _i, _i, _p, _i, _i, _p, _i, _p, _sz, _p]),
-    "clv_vrnn_label_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "clv_vrnn_label_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "clv_vrnn_label_bwd_ex": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, _p, _sz,
+    "clv_vrnn_label_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, _p, _sz,
                                    _p, _p]),
     "clv_gauss_fwd": (_i, [_i, _i, _p, _p, _p, _i, _p, _p]),
     "clv_gauss_bwd": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p]),
@@ -213,12 +196,9 @@ SIGNATURES = {
     "clv_adam_wn_plan_bytes": (_sz, [_p, _i]),
     "clv_adam_wn_plan_build": (_i, [_p, _i, _p]),
     "clv_adam_wn_workspace_bytes": (_sz, [_p, _i]),
-    "clv_adam_wn_step": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _p, _sz, _p]),
-    "clv_adam_wn_step_ex": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _p, _p, _sz, _p]),
+    "clv_adam_wn_step": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _p, _p, _sz, _p]),
     "clv_philox_normal2": (_i, [_p, _i64, _u32, _u64, _p, _i64, _u32, _u64, _u64, _u32, _p, _p]),
-    "clv_gather_rows_multi": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "clv_gather_rows_multi_notes": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "clv_gather_rows_multi_cursor": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "clv_gather_rows_multi": (_i, [_i64, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_philox_normal": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
     "clv_philox_uniform": (_i, [_p, _i64, _u64, _u32, _p, _u32, _u64, _p]),
     "clv_i32_add": (_i, [_p, C.c_int32, _p]),

@@ -705,7 +705,7 @@ __device__ __forceinline__ void mean_block(const MeanTerms& m, int k, float4 (*r
   __syncthreads();
   if (threadIdx.x == 0) m.out[k] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
 }
-// Few-row products over a short K riding in the same launch (clv_splitk_reduce_multi_ex): C[r, :] = sum_k A[k, r] B[k, :] for
+// Few-row products over a short K riding in the same launch (clv_splitk_reduce_multi): C[r, :] = sum_k A[k, r] B[k, :] for
 // r < R rows of A [K, lda] plus, with `ones`, the column sums of B as one more row -- the label rows and the bias of an
 // LSTM input-kernel gradient over K = batch rows of sum_t dz (cl_vrnn/model.py:194,223: the RepeatVector(W) columns).
 // A launch of their own was 8.6 us for 2 MFLOP.  A block owns 64 columns; 4 k-lanes stride through K with every row's
@@ -1045,16 +1045,7 @@ extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float a
                                ws_bytes, nullptr, stream);
 }
 
-extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream) {
-  return clv_splitk_reduce_multi_means(jobs, njobs, nullptr, nullptr, nullptr, 0, nullptr, stream);
-}
-
-extern "C" int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
-                                             const int* stride, int n_terms, float* means_out, void* stream) {
-  return clv_splitk_reduce_multi_ex(jobs, njobs, x, n, stride, n_terms, means_out, nullptr, 0, stream);
-}
-
-extern "C" int clv_splitk_reduce_multi_ex(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
+extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
                                           const int* stride, int n_terms, float* means_out,
                                           const clv_skinny_product* riders, int n_riders, void* stream) {
   using namespace clv;

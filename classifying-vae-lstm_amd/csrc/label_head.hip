@@ -351,23 +351,11 @@ extern "C" int clv_vrnn_label_fwd(int B, int D, int C, int G4, const float* hW, 
   return launch_status();
 }
 
-extern "C" int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
-                                  const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
-                                  const float* onehot, const float* W, const float* hW, const float* Ka,
-                                  float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
-                                  float* dwargs, float* dhW, void* stream) {
-  if (B <= 0 || D <= 0 || D > 128 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
-  if (!dzsum_enc || !dzsum_dec || !Kenc_w || !Kdec_w || !wargs || !eps || !onehot || !W || !hW || !Ka || !dwargs || !dhW)
-    return CLV_EINVAL;
-  return clv_vrnn_label_bwd_ex(B, D, C, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, eps, onehot, W, hW, Ka, prior_logvar,
-                               class_weight, w_kl_weight, inv_b, dwargs, dhW, nullptr, nullptr, nullptr, 0, nullptr, stream);
-}
-
 extern "C" size_t clv_vrnn_label_bwd_workspace_bytes(int B, int D, int C) {
   return (size_t)B * (D + 1) * 2 * (C - 1) * sizeof(float);
 }
 
-extern "C" int clv_vrnn_label_bwd_ex(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
+extern "C" int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
                                      const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
                                      const float* onehot, const float* W, const float* hW, const float* Ka,
                                      float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
@@ -451,11 +439,15 @@ static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int l
 }
 
 extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
+                                    const clv_label_stage* stage,
                                     const float* bh, float* hW_out, const float* Ka, const float* ba,
                                     float* eps, const float* onehot, float prior_logvar,
                                     const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                                     float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
                                     const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+  if (stage)      // the launch assembles its mini-batch rows itself: X = stage->X is an output, the labels come from stage->w_src
+    return label_fwd_x_launch(B, D, C, G4, stage->X, ldx, nx, Kh, nullptr, 0, stage, bh, hW_out, Ka, ba, eps, stage->w_src,
+                              prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
   return label_fwd_x_launch(B, D, C, G4, X, ldx, nx, Kh, nullptr, 0, nullptr, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc,
                             Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
 }
@@ -471,13 +463,3 @@ extern "C" int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float
                             benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
 }
 
-extern "C" int clv_vrnn_label_fwd_x_staged(int B, int D, int C, int G4, const clv_label_stage* stage, int ldx, int nx, const float* Kh,
-                                           const float* bh, float* hW_out, const float* Ka, const float* ba,
-                                           float* eps, float prior_logvar,
-                                           const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
-                                           float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                                           const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
-  if (!stage) return CLV_EINVAL;
-  return label_fwd_x_launch(B, D, C, G4, stage->X, ldx, nx, Kh, nullptr, 0, stage, bh, hW_out, Ka, ba, eps, stage->w_src,
-                            prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
-}

@@ -37,7 +37,7 @@ struct Geo {
 
 struct LstmFwdArgs {
   int B, T;
-  const float* xproj;    // [B,T,352] or null (then xin/Kin give the input projection)
+  const float* xproj;    // [B,T,352]
   const float* rowbias;  // [B,352] or null
   const float* U;        // [88,352]
   const float* h0;       // [B,88] or null
@@ -47,33 +47,19 @@ struct LstmFwdArgs {
   float* gates;          // [B,T,352] (z_i, z_f, tanh(z_c), z_o) or null (inference)
   float* hT;             // [B,88] or null
   float* cT;
-  // fused sparse input projection: z += sum_k x[b,t,k] * Kin[k,:] over the NONZERO x (piano-roll frames
-  // have ~4 of 88 notes on), Kin [nx,352] resident in LDS for the whole sequence
-  const float* xin;      // [B,T,ldx] or null
-  const float* Kin;      // [nx,352]
-  int ldx, nx;
 };
 
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
 // ABL != 0 builds exist only in tools/lstm_ablate.hip (phase-removal timing, results are wrong by design)
-constexpr int XMAX = 128;      // max input features of the fused projection (2 per lane of wave 0)
-constexpr int XFAST = 3;       // list entries per lane handled without a loop (KS*XFAST nonzeros per frame)
-struct XItem { int k; float v; };
-
-template <int KS, int R, int GATE, bool SAVE, int ABL = 0, bool XIN = false>
+template <int KS, int R, int GATE, bool SAVE, int ABL = 0>
 __global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
   using G = Geo<KS>;
   constexpr int KK = G::KK, KP = G::KP;
   constexpr int NC = KS / R;                 // lane copies per (row, unit)
   constexpr int NX = (4 * R + KS - 1) / KS;  // xproj loads per lane per step
   __shared__ __attribute__((aligned(16))) float hbuf[2][R][KS * KP];   // slice s at KP*s (KK used)
-  // XIN: dynamic LDS = Kin image [nx][88 units][4 gates] + per-row nonzero lists (double buffered)
-  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
-  float* Kimg = dyn_lds;
-  XItem* xlist = reinterpret_cast<XItem*>(dyn_lds + (XIN ? a.nx * LG : 0));      // [2][R][XMAX]
-  __shared__ __attribute__((aligned(16))) int xcount[2][4];   // 32 B: keeps the dynamic LDS base 16-byte aligned
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = lane % KS;
@@ -110,93 +96,7 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
   for (int i = 0; i < NX; ++i) xn[i] = (T > 0 && a.xproj) ? a.xproj[xoff[i]] : 0.f;
 
-  // fused projection state (wave 0 owns the frame prefetch + compaction)
-  float fx[R][2];
-  auto load_frame = [&](int t) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float* fp = a.xin + ((size_t)(row0 + r) * T + t) * a.ldx;
-      fx[r][0] = lane < a.nx ? fp[lane] : 0.f;
-      fx[r][1] = lane + 64 < a.nx ? fp[lane + 64] : 0.f;
-    }
-  };
-  auto compact = [&](int buf) {        // wave 0: nonzeros of the held frame(s) -> xlist[buf], xcount[buf]
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const unsigned long long m0 = __ballot(fx[r][0] != 0.f), m1 = __ballot(fx[r][1] != 0.f);
-      const unsigned long long lt = (1ull << lane) - 1ull;
-      const int n0 = __popcll(m0);
-      XItem* lp = xlist + (buf * R + r) * XMAX;
-      if (lane < KS * XFAST) lp[lane] = XItem{0, 0.f};      // zero padding: the straight-line part always reads KS*XFAST items
-      if (fx[r][0] != 0.f) lp[__popcll(m0 & lt)] = XItem{lane, fx[r][0]};
-      if (fx[r][1] != 0.f) lp[n0 + __popcll(m1 & lt)] = XItem{lane + 64, fx[r][1]};
-      if (lane == 0) xcount[buf][r] = n0 + __popcll(m1);
-    }
-  };
-  if (XIN) {
-    // Kin [nx,352] (gate-major columns) -> LDS image [k][unit][gate] so a thread fetches its 4 gates in one b128
-    // (float4 loads, 4 in flight per thread: a one-element-per-iteration loop would pay an L2 round trip per element)
-    const int nv = a.nx * (LG / 4);
-    const float4* src = reinterpret_cast<const float4*>(a.Kin);
-    for (int i0 = tid; i0 < nv; i0 += 4 * G::NT) {
-      float4 v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + q * G::NT;
-        v[q] = i < nv ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + q * G::NT;
-        if (i < nv) {
-          const int k = i / (LG / 4), col = (i % (LG / 4)) * 4;      // 4 consecutive units of one gate
-          float* dst = &Kimg[k * LG + (col % LH) * 4 + col / LH];
-          dst[0] = v[q].x; dst[4] = v[q].y; dst[8] = v[q].z; dst[12] = v[q].w;
-        }
-      }
-    }
-    if (wave == 0 && T > 0) {
-      load_frame(0);
-      compact(0);
-      load_frame(min(1, T - 1));
-      compact(1);
-      load_frame(min(2, T - 1));
-    }
-  }
   __syncthreads();
-  // x-contribution of a step: this lane takes the nonzero inputs s, s+KS, ... of its row(s); the slice
-  // reduction of the gate sums adds the lanes up.  It does not depend on the recurrence, so it is computed
-  // one step ahead (three dependent LDS round trips: count -> item -> kernel row) off the critical chain.
-  float xc_next[R][4];
-  auto xcontrib = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-      const int n = xcount[buf][r];
-      const XItem* lp = xlist + (buf * R + r) * XMAX;
-      // straight-line part (no loop => the scheduler can overlap its LDS latency with the recurrence):
-      // the first KS*XFAST list entries, zero-padded by compact()
-#pragma unroll
-      for (int m = 0; m < XFAST; ++m) {
-        const XItem it = lp[s + KS * m];
-        const float4 kr = *reinterpret_cast<const float4*>(&Kimg[it.k * LG + u * 4]);
-        c0 = fmaf(it.v, kr.x, c0); c1 = fmaf(it.v, kr.y, c1); c2 = fmaf(it.v, kr.z, c2); c3 = fmaf(it.v, kr.w, c3);
-      }
-      // denser frames: the remaining nonzeros (rare for piano-rolls)
-      for (int j = s + KS * XFAST; j < n; j += KS) {
-        const XItem it = lp[j];
-        const float4 kr = *reinterpret_cast<const float4*>(&Kimg[it.k * LG + u * 4]);
-        c0 = fmaf(it.v, kr.x, c0); c1 = fmaf(it.v, kr.y, c1); c2 = fmaf(it.v, kr.z, c2); c3 = fmaf(it.v, kr.w, c3);
-      }
-      xc_next[r][0] = c0; xc_next[r][1] = c1; xc_next[r][2] = c2; xc_next[r][3] = c3;
-    }
-  };
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) xc_next[r][g] = 0.f;
-  if (XIN && T > 0) xcontrib(0);
-
   // output slots of this lane (loop-invariant): slot 0 h, 1 c, 2..5 gates (z_i, z_f, g, z_o)
   constexpr int NS = (6 + NC - 1) / NC;
   float* optr[NS];
@@ -223,19 +123,7 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       xv[i] = xn[i] + rb[i];
-      if (ABL != 5 && !XIN) xn[i] = a.xproj[xoff[i] + (size_t)min(t + 1, T - 1) * LG];   // prefetch, unconditional (clamped)
-    }
-    float xc[R][4];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xc[r][g] = xc_next[r][g];
-    if (XIN) {
-      if (wave == 0) {               // frame t+2 (loaded one iteration ago) -> list buffer of step t (already consumed);
-        compact(cur);                // then start loading frame t+3
-        load_frame(min(t + 3, T - 1));
-      }
-      xcontrib(cur ^ 1);             // for step t+1, overlaps this step's recurrence
+      if (ABL != 5) xn[i] = a.xproj[xoff[i] + (size_t)min(t + 1, T - 1) * LG];   // prefetch, unconditional (clamped)
     }
     // acc[r][g] starts from the lane's xproj share, then KK FMAs per gate
     f2 acc2[R][2];
@@ -244,7 +132,7 @@ __global__ __launch_bounds__(Geo<KS>::NT) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int e = r * 4 + g;              // compile-time
-        acc2[r][g >> 1][g & 1] = ((s == (e % KS) && xok[e / KS]) ? xv[e / KS] : 0.f) + (XIN ? xc[r][g] : 0.f);
+        acc2[r][g >> 1][g & 1] = (s == (e % KS) && xok[e / KS]) ? xv[e / KS] : 0.f;
       }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -585,14 +473,7 @@ static int lstm_ks() {
 template <int KS, int R, int GATE, bool SAVE>
 static int launch_fwd_r(const LstmFwdArgs& a, hipStream_t s) {
   constexpr int NT = Geo<KS>::NT;
-  if (a.xin) {
-    const size_t dyn = (size_t)a.nx * LG * sizeof(float) + 2 * R * XMAX * sizeof(XItem);
-    auto kern = lstm_fwd_kernel<KS, R, GATE, SAVE, 0, true>;
-    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 4096)) return e;
-    hipLaunchKernelGGL(kern, dim3(a.B / R), dim3(NT), dyn, s, a);
-  } else {
-    hipLaunchKernelGGL((lstm_fwd_kernel<KS, R, GATE, SAVE, 0, false>), dim3(a.B / R), dim3(NT), 0, s, a);
-  }
+  hipLaunchKernelGGL((lstm_fwd_kernel<KS, R, GATE, SAVE, 0>), dim3(a.B / R), dim3(NT), 0, s, a);
   return launch_status();
 }
 template <int KS, int GATE, bool SAVE>
@@ -619,22 +500,11 @@ static int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
 
 }  // namespace clv
 
-bool clv::lstm_fwd_mfma_wanted(int B) {
-  static const int mfma_mode = env_int("CLV_LSTM_MFMA", -1);
-  return mfma_mode == 1 || (mfma_mode < 0 && B >= 768);
-}
-
 static int lstm_fwd_dispatch(clv::LstmFwdArgs a, int gate_act, hipStream_t s) {
   using namespace clv;
   ProfScope p("lstm_seq_fwd", s);
   const bool save = a.gates != nullptr;
   const bool hard = gate_act == CLV_GATE_HARD_SIGMOID;
-  // Large batches: four rows per workgroup on the 4x4x1 MFMA (lstm_mfma.hip) once that fills the chip better than one
-  // or two rows per workgroup on the VALU.  CLV_LSTM_MFMA=0 / 1 forces the choice (tests run both on the same inputs).
-  const bool eligible = save && !a.xin && !a.h0 && !a.c0 && a.T >= 1 && a.xproj;
-  if (eligible && lstm_fwd_mfma_wanted(a.B))
-    return launch_lstm_fwd_mfma(a.B, a.T, gate_act, a.xproj, a.rowbias, a.U, a.hs, a.cs, a.gates, a.hT, a.cT, nullptr, 0, 0,
-                                nullptr, s);
   if (lstm_ks() == 8) {
     if (hard) return save ? launch_fwd<8, CLV_GATE_HARD_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_HARD_SIGMOID, false>(a, s);
     return save ? launch_fwd<8, CLV_GATE_SIGMOID, true>(a, s) : launch_fwd<8, CLV_GATE_SIGMOID, false>(a, s);
@@ -654,40 +524,7 @@ extern "C" int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
   // any other --intermediate_dim (cl_vrnn/train.py:90): csrc/lstm_any.hip (CLV_LSTM_ANY=1, read per call: also at 88 units -- tests)
   if (H != LH || env_int("CLV_LSTM_ANY", 0))
     return launch_lstm_any_fwd(B, T, H, gate_act, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT, (hipStream_t)stream);
-  LstmFwdArgs a{B, T, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT, nullptr, nullptr, 0, 0};
-  return lstm_fwd_dispatch(a, gate_act, (hipStream_t)stream);
-}
-
-extern "C" int clv_lstm_seq_fwd_z_supported(int B, int H, int nz) {
-  return H == clv::LH && nz >= 1 && nz <= 32 && clv::lstm_fwd_mfma_wanted(B);
-}
-
-extern "C" int clv_lstm_seq_fwd_z(int B, int T, int H, int gate_act, const float* xproj, const float* rowbias,
-                                  const float* U, const float* zin, int ldz, int nz, const float* Kz,
-                                  float* hs, float* cs, float* gates, float* hT, float* cT, void* stream) {
-  using namespace clv;
-  if (!clv_lstm_seq_fwd_z_supported(B, H, nz) || T < 1 || !xproj || !U || !zin || !Kz || ldz < nz || !hs || !cs || !gates)
-    return CLV_EINVAL;
-  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope p("lstm_seq_fwd", s);
-  return launch_lstm_fwd_mfma(B, T, gate_act, xproj, rowbias, U, hs, cs, gates, hT, cT, zin, ldz, nz, Kz, s);
-}
-
-extern "C" size_t clv_lstm_seq_fwd_x_lds_bytes(int B, int nx) {
-  return (size_t)nx * clv::LG * sizeof(float) + 2 * clv::rows_per_wg(B) * clv::XMAX * sizeof(clv::XItem) + 2048;
-}
-
-extern "C" int clv_lstm_seq_fwd_x(int B, int T, int H, int gate_act,
-                                  const float* xin, int ldx, int nx, const float* Kin,
-                                  const float* rowbias, const float* U, const float* h0, const float* c0,
-                                  float* hs, float* cs, float* gates, float* hT, float* cT, void* stream) {
-  using namespace clv;
-  if (H != LH || B <= 0 || T < 0 || !xin || !Kin || nx <= 0 || nx > XMAX || ldx < nx || !U || !hs || (gates && !cs))
-    return CLV_EINVAL;
-  if (gate_act != CLV_GATE_HARD_SIGMOID && gate_act != CLV_GATE_SIGMOID) return CLV_EINVAL;
-  if (clv_lstm_seq_fwd_x_lds_bytes(B, nx) > 156 * 1024) return CLV_EINVAL;     // Kin must fit the 160 KB LDS
-  LstmFwdArgs a{B, T, nullptr, rowbias, U, h0, c0, hs, cs, gates, hT, cT, xin, Kin, ldx, nx};
+  LstmFwdArgs a{B, T, xproj, rowbias, U, h0, c0, hs, cs, gates, hT, cT};
   return lstm_fwd_dispatch(a, gate_act, (hipStream_t)stream);
 }
 

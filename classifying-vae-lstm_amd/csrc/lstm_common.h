@@ -7,14 +7,6 @@ namespace clv {
 constexpr int LH = 88;          // hidden units
 constexpr int LG = 4 * LH;      // gate columns
 
-// lstm_mfma.hip: the sequence forward with the recurrent product on the multi-block f32 MFMA, four rows per workgroup
-// (training passes from zero state; used from ~3 rows per CU on)
-// zin != null: + z_t . Kz inside the kernel (z_t: B*T rows of stride ldz, nz <= 32 columns; Kz [nz,352])
-int launch_lstm_fwd_mfma(int B, int T, int gate_act, const float* xproj, const float* rowbias, const float* U,
-                         float* hs, float* cs, float* gates, float* hT, float* cT,
-                         const float* zin, int ldz, int nz, const float* Kz, hipStream_t s);
-bool lstm_fwd_mfma_wanted(int B);      // the batch sizes at which lstm.hip hands a training forward to lstm_mfma.hip
-
 // lstm_any.hip: the same contract for any number of hidden units (1..1024); clv_lstm_seq_fwd / _bwd dispatch here for H != 88
 int launch_lstm_any_fwd(int B, int T, int H, int gate_act, const float* xproj, const float* rowbias, const float* U,
                         const float* h0, const float* c0, float* hs, float* cs, float* gates, float* hT, float* cT,

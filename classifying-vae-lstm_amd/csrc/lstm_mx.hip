@@ -4,7 +4,7 @@
 //   z_t = x_t . K_x + z^lat_t . K_z + rowbias + h_{t-1} . U;   i,f,o = gate_act(z_i,z_f,z_o), g = tanh(z_c)
 //   c_t = f c_{t-1} + i g;   h_t = o tanh(c_t)                          (cl_vrnn/model.py:196-199, 225-228; Keras LSTM)
 //
-// Why another pair of sequence kernels.  lstm.hip (VALU, U in registers) and lstm_mfma.hip (4x4x1 f32 MFMA) both take
+// Why another pair of sequence kernels.  lstm.hip (VALU, U in registers) and round 2's 4x4x1 f32-MFMA forward (removed in round 6) both took
 // ~1.45 us per step for the four rows a CU owns at 1024 rows: the f32 pipes need ~1000 cycles per step for the product
 // alone and the gate phase cannot overlap it.  Here:
 //  * an fp32 number is the exact sum of three bf16 numbers and a bf16 x bf16 product is exact in fp32 (wgrad_bf16.hip),

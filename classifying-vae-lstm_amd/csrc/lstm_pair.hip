@@ -962,19 +962,6 @@ extern "C" int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
 }
 
 extern "C" int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
-                                 const float* pack, const float* Wz,
-                                 const float* dhs_dec, const float* aux_dec, const float* aux_enc,
-                                 float* gates_dec_inout_dz, float* gates_enc_inout_dz,
-                                 float* dzsum_dec, float* dzsum_enc,
-                                 const float* zargs, const float* eps, float* dzargs,
-                                 const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
-                                 void* stream) {
-  return clv_lstm_pair_bwd_ex(B, T, H, L, gate_act, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_dec_inout_dz,
-                              gates_enc_inout_dz, dzsum_dec, dzsum_enc, zargs, eps, dzargs, hs_enc, dWz, dbz, ws, ws_bytes, job,
-                              nullptr, stream);
-}
-
-extern "C" int clv_lstm_pair_bwd_ex(int B, int T, int H, int L, int gate_act, float kl_scale,
                                     const float* pack, const float* Wz,
                                     const float* dhs_dec, const float* aux_dec, const float* aux_enc,
                                     float* gates_dec_inout_dz, float* gates_enc_inout_dz,
@@ -1022,7 +1009,7 @@ extern "C" int clv_lstm_pair_bwd_ex(int B, int T, int H, int L, int gate_act, fl
 #undef PAIR_BWD_W
   int st = launch_status();
   if (st) return st;
-  if (label && label->dKa) {       // the Wargs layer's per-row slabs, exactly as clv_vrnn_label_bwd_ex leaves them
+  if (label && label->dKa) {       // the Wargs layer's per-row slabs, exactly as clv_vrnn_label_bwd leaves them
     ReduceJob jl;
     memset(&jl, 0, sizeof(jl));
     const int NA = 2 * (label->C - 1);

@@ -22,7 +22,7 @@ namespace clv {
 constexpr int UNIT_ROWS = CLV_ADAM_UNIT_ROWS;
 // fused small-tensor kernel: 16 row lanes x 9 rows = matrices of <= 144 rows (round 3: 9, so that cl_vrnn's decoder input
 // kernel at latent_dim 32 -- 88 + 32 + 10 = 130 rows -- is a small tensor and the hW kernel stays the ONLY tall one: the
-// two-launch form of clv_adam_wn_step_ex then applies at configuration 5 as well)
+// two-launch form of clv_adam_wn_step then applies at configuration 5 as well)
 constexpr int SM_RL = 16, SM_RMAX = 9;
 constexpr int SM_ROWS = SM_RL * SM_RMAX;
 
@@ -392,7 +392,7 @@ __global__ void adam_bump_kernel(int32_t* iterations) { *iterations += 1; }
 
 // ---------------------------------------------------------------------------
 // Two-launch Adam-WN of ONE tall matrix (cl_vrnn's hW/kernel: 87 % of the parameters) when both column sums of the
-// first pass are known BEFORE the optimizer runs (clv_adam_wn_step_ex):
+// first pass are known BEFORE the optimizer runs (clv_adam_wn_step):
 //   sum_r V^2    = ||V||^2 of the previous step's result (kept per column in vn2: the rescale leaves W = s' V', so the
 //                  next step's V is this step's V');
 //   sum_r g.V    = (1/s) sum_r g[r,c] W[r,c], and with g = X^T dH (the layer's own gradient) that is
@@ -734,15 +734,6 @@ extern "C" size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, 
 }
 
 extern "C" int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
-                                float* params, const float* grads, float* m, float* v,
-                                float* mg, float* vg, float* s,
-                                int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
-                                int weightnorm, void* ws, size_t ws_bytes, void* stream) {
-  return clv_adam_wn_step_ex(host_table, n_tensors, plan_dev, params, grads, m, v, mg, vg, s, iterations_dev, step_t, lr, beta1,
-                             beta2, eps, weightnorm, nullptr, ws, ws_bytes, stream);
-}
-
-extern "C" int clv_adam_wn_step_ex(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
                                    float* params, const float* grads, float* m, float* v,
                                    float* mg, float* vg, float* s,
                                    int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,

@@ -13,7 +13,7 @@
 // stages of 32 rows: every thread moves 2 float4 of X and 2 of G per stage (requested one stage ahead), X goes to a bf16
 // [k][column] image as it is, G as three piece images, double buffered; fragments come out with ds_read_b64_tr_b16 (both
 // operands are k-major in memory: bf16_images.h).  Every output row is written once: no split-K slabs, no reduction.
-// One more workgroup forms the column sums of G (the bias gradient) and gdot (see clv_sparse_outer_ex).
+// One more workgroup forms the column sums of G (the bias gradient) and gdot (see clv_sparse_outer).
 #include "bf16_images.h"
 
 namespace clv {

@@ -305,7 +305,7 @@ __global__ void gather_rows_kernel(int64_t rows, int64_t row_elems, const float*
 struct GatherSeg { const float* src; float* out; const int64_t* table; int64_t row_elems, out_ld, stride, offset;
                    int chunk, pieces, vec, u8; unsigned char* notes; };
 struct GatherArgs { GatherSeg seg[4]; int nseg; int64_t rows; const int64_t* idx; int64_t row0; int nlist; int list_seg[4];
-                    // batch cursor (clv_gather_rows_multi_cursor): the launch reads the device step counter and takes batch
+                    // batch cursor (clv_gather_rows_multi): the launch reads the device step counter and takes batch
                     // j = (step - step0) mod period: rows j * cur_stride + cur_offset .. of the row list
                     const int32_t* step_dev; int32_t step0, period; int64_t cur_stride, cur_offset; };
 __device__ __forceinline__ int64_t gather_base(const GatherArgs& a) {
@@ -605,24 +605,6 @@ extern "C" int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src
 }
 
 extern "C" int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
-                                     const void* const* src, const int32_t* src_u8, float* const* out,
-                                     const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
-                                     const int64_t* src_stride, const int64_t* src_offset,
-                                     const int64_t* const* src_table, void* stream) {
-  return clv_gather_rows_multi_notes(rows, idx, row0, nseg, src, src_u8, out, row_elems, chunk, out_ld, src_stride,
-                                     src_offset, src_table, nullptr, stream);
-}
-
-extern "C" int clv_gather_rows_multi_notes(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
-                                           const void* const* src, const int32_t* src_u8, float* const* out,
-                                           const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
-                                           const int64_t* src_stride, const int64_t* src_offset,
-                                           const int64_t* const* src_table, unsigned char* const* notes_out, void* stream) {
-  return clv_gather_rows_multi_cursor(rows, idx, row0, nseg, src, src_u8, out, row_elems, chunk, out_ld, src_stride, src_offset,
-                                      src_table, notes_out, nullptr, stream);
-}
-
-extern "C" int clv_gather_rows_multi_cursor(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                                             const void* const* src, const int32_t* src_u8, float* const* out,
                                             const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
                                             const int64_t* src_stride, const int64_t* src_offset,

@@ -184,7 +184,7 @@ struct SparseOuterArgs {
   float* colsum;       // [N] = sum_b G[b,:] (the layer's bias gradient) or null; written by workgroup 0
   // gdot [N] = sum_b (Hact[b,c] - hbias[c]) G[b,c] (or null): Hact = relu(X.K + hbias) is the layer's output and G its
   // relu-masked upstream gradient, so this is sum_b (X.K)[b,c] G[b,c] = sum_j K[j,c] dK[j,c]: the weight-norm optimizer's
-  // sum g.W per column without a pass over K and dK (clv_adam_wn_step_ex).  Formed by one extra workgroup of the launch.
+  // sum g.W per column without a pass over K and dK (clv_adam_wn_step).  Formed by one extra workgroup of the launch.
   const float* Hact; const float* hbias; float* gdot; int ldh;
 };
 
@@ -380,11 +380,6 @@ extern "C" int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, c
 }
 
 extern "C" int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
-                                float* colsum, void* stream) {
-  return clv_sparse_outer_ex(Bn, nx, N, X, ldx, G, ldg, out, ldo, colsum, nullptr, 0, nullptr, nullptr, stream);
-}
-
-extern "C" int clv_sparse_outer_ex(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
                                    float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream) {
   using namespace clv;
   if (gdot && (!Hact || !hbias || ldh < N || ldh % 2 != 0 || ((uintptr_t)Hact) % 8 != 0)) return CLV_EINVAL;

@@ -773,44 +773,20 @@ static int vae_step_impl(int B, int D, int H, int Hc, int C, int L, int use_x_pr
   return launch_status();
 }
 
-extern "C" int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
-                                     const float* x, const float* xp, const float* target, const float* onehot,
-                                     float* eps_w, float* eps_z,
-                                     const float* params, const int64_t* host_offsets12, long n_params,
-                                     float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
-                                     int need_grads, float* grads, void* ws, size_t ws_bytes,
-                                     float* logits, float* w_out, float* wargs_out, float* zargs_out,
-                                     float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts,
-                                     void* stream) {
-  return vae_step_impl(B, D, H, Hc, C, L, use_x_prev, x, xp, target, onehot, nullptr, eps_w, eps_z, params, host_offsets12, n_params,
-                       prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out, wargs_out,
-                       zargs_out, rownll, rowkl, rowloss, opts, stream);
-}
-
-extern "C" int clv_vae_fused_step_staged(int B, int D, int H, int Hc, int C, int L, int use_x_prev, const clv_label_stage* stage,
-                                         float* eps_w, float* eps_z,
-                                         const float* params, const int64_t* host_offsets12, long n_params,
-                                         float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
-                                         int need_grads, float* grads, void* ws, size_t ws_bytes,
-                                         float* logits, float* w_out, float* wargs_out, float* zargs_out,
-                                         float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts,
-                                         void* stream) {
-  if (!stage) return CLV_EINVAL;
-  return vae_step_impl(B, D, H, Hc, C, L, use_x_prev, nullptr, nullptr, nullptr, nullptr, stage, eps_w, eps_z, params, host_offsets12,
-                       n_params, prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out,
-                       wargs_out, zargs_out, rownll, rowkl, rowloss, opts, stream);
-}
-
 extern "C" int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
                                   const float* x, const float* xp, const float* target, const float* onehot,
-                                  const float* eps_w, const float* eps_z,
+                                  const clv_label_stage* stage, float* eps_w, float* eps_z,
                                   const float* params, const int64_t* host_offsets12, long n_params,
                                   float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
                                   int need_grads, float* grads, void* ws, size_t ws_bytes,
                                   float* logits, float* w_out, float* wargs_out, float* zargs_out,
-                                  float* rownll, float* rowkl, float* rowloss, void* stream) {
-  return clv_vae_fused_step_ex(B, D, H, Hc, C, L, use_x_prev, x, xp, target, onehot, const_cast<float*>(eps_w),
-                               const_cast<float*>(eps_z), params, host_offsets12, n_params, prior_logvar, class_weight,
-                               kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out, wargs_out,
-                               zargs_out, rownll, rowkl, rowloss, nullptr, stream);
+                                  float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts,
+                                  void* stream) {
+  if (stage)      // the workgroups assemble their own rows: x / xp / target / onehot are not read
+    return vae_step_impl(B, D, H, Hc, C, L, use_x_prev, nullptr, nullptr, nullptr, nullptr, stage, eps_w, eps_z, params, host_offsets12,
+                         n_params, prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out,
+                         wargs_out, zargs_out, rownll, rowkl, rowloss, opts, stream);
+  return vae_step_impl(B, D, H, Hc, C, L, use_x_prev, x, xp, target, onehot, nullptr, eps_w, eps_z, params, host_offsets12, n_params,
+                       prior_logvar, class_weight, kl_weight, w_kl_weight, need_grads, grads, ws, ws_bytes, logits, w_out, wargs_out,
+                       zargs_out, rownll, rowkl, rowloss, opts, stream);
 }

@@ -467,23 +467,10 @@ static int wgrad_splits(int K, int split_scale, int base_ranges = 128) {
   return (K + kc - 1) / kc;
 }
 
-extern "C" size_t clv_lstm_wgrad_workspace_bytes_ex(int K, int N, int nx, int nh, int nz, int split_scale) {
+extern "C" size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz, int split_scale) {
   return (size_t)wgrad_splits(K, split_scale) * (nx + nh + nz) * N * sizeof(float);
 }
-extern "C" size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz) {
-  return clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, 1);
-}
-
 extern "C" int clv_lstm_wgrad(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
-                              const float* H, int ldh, int nh, int h_shift, int h_zero_period,
-                              const float* Z, int ldz, int nz, const float* dz, int lddz,
-                              float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
-                              void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream) {
-  return clv_lstm_wgrad_ex(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, h_shift, h_zero_period, Z, ldz, nz, dz, lddz, dKx, ld_kx,
-                           dU, ld_u, dKz, ld_kz, beta, 1, ws, ws_bytes, job, stream);
-}
-
-extern "C" int clv_lstm_wgrad_ex(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
                                  const float* H, int ldh, int nh, int h_shift, int h_zero_period,
                                  const float* Z, int ldz, int nz, const float* dz, int lddz,
                                  float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
@@ -495,7 +482,7 @@ extern "C" int clv_lstm_wgrad_ex(int K, int N, const void* X, int ldx, int nx, i
     return CLV_EINVAL;
   const bool xu8 = x_exact_bf16 == CLV_FRAMES_U8;           // the frames as bytes (ldx in bytes): 4-byte aligned rows
   if (ldx % 4 || ldh % 4 || lddz % 4 || ((uintptr_t)H | (uintptr_t)dz) % 16 || ((uintptr_t)X) % (xu8 ? 4 : 16)) return CLV_EINVAL;
-  if (clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, split_scale) > ws_bytes || !ws || ((uintptr_t)ws) % 16) return CLV_EWORKSPACE;
+  if (clv_lstm_wgrad_workspace_bytes(K, N, nx, nh, nz, split_scale) > ws_bytes || !ws || ((uintptr_t)ws) % 16) return CLV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int splits = wgrad_splits(K, split_scale);
   const int kc = wgrad_kc(K, split_scale);

@@ -20,7 +20,10 @@ import numpy as np
 import torch
 
 from . import _lib, ops
+from .engine_dropout import VrnnDropout
+from .engine_generate import VaeGenerate, VrnnGenerate
 from .ops import ACT_MASKPOS, ACT_NONE, ACT_RELU, ACT_SIGMOID
+from .params import FlatParams, fuse_heads  # noqa: F401  (engine.FlatParams stays importable)
 
 
 def vae_param_shapes(cfg):
@@ -57,168 +60,38 @@ def vrnn_param_shapes(cfg):
             ('X_decoded_mean/kernel', (H, D)), ('X_decoded_mean/bias', (D,))]
 
 
-def fuse_heads(shapes, pairs):
-    """Physical layout where each (a, b, fused) pair of same-input Dense heads is ONE [in, na+nb] kernel and
-    one [na+nb] bias: a single GEMM serves both heads (forward, dX and dW).  Columns are independent under
-    weight normalisation and Adam, so the update is identical to two separate tensors.
-    Returns (physical shapes, aliases: logical name -> (physical name, col0, ncols))."""
-    d = dict(shapes)
-    phys, aliases, done = [], {}, set()
-    for name, shp in shapes:
-        layer, w = name.split('/')
-        hit = [pr for pr in pairs if layer in pr[:2]]
-        if not hit:
-            phys.append((name, shp))
-            continue
-        a, b, fused = hit[0]
-        na, nb = d[a + '/kernel'][1], d[b + '/kernel'][1]
-        for wn in ('kernel', 'bias'):
-            aliases[a + '/' + wn] = (fused + '/' + wn, 0, na)
-            aliases[b + '/' + wn] = (fused + '/' + wn, na, nb)
-        if fused not in done:
-            done.add(fused)
-            phys.append((fused + '/kernel', (d[a + '/kernel'][0], na + nb)))
-            phys.append((fused + '/bias', (na + nb,)))
-    return phys, aliases
+# Which kernels a VrnnEngine's chains take.  Every entry is an engine cfg key (tests, A/B sessions: cfg[key] = True / False), an
+# environment variable of the same meaning for runs that build their engines elsewhere (bench.py, the CLIs), and the default --
+# the product configuration, what every number in DESIGN.md was measured with.  Each is narrowed by what the shapes support
+# (the *_supported() predicates of include/clvae.h); tests/test_gpu_switches.py walks every one of them through a two-step
+# oracle check in its non-default position.
+SWITCHES = {
+    # key:            (env variable,           default, what the non-default position selects)
+    'fuse_pair':      (None,                   True,  "the separate sequence kernels (csrc/lstm.hip) instead of encoder + latent head + decoder as one launch"),
+    'sparse_inputs':  (None,                   True,  "dense GEMM input projections instead of row gathers of the notes that are on"),
+    'keep_logits':    (None,                   True,  "the fused output head does not store its logits (what a replayed training step does: 11.5 / 92 MB per step)"),
+    'fuse_head':      ('CLV_FUSE_HEAD',        True,  "output head as GEMM + NLL + three backward GEMMs instead of one launch"),
+    'bf16_wgrad':     ('CLV_BF16_WGRAD',       True,  "the LSTM kernel gradients on the f32 MFMA GEMM instead of split-bf16 products"),
+    'wgrad_pair':     ('CLV_WGRAD_PAIR',       True,  "one kernel-gradient launch per LSTM instead of both in one"),
+    'dense_hw_grad':  ('CLV_DENSE_HW_GRAD',    True,  "the hW kernel gradient by walking the notes instead of dense on the bf16 matrix cores"),
+    'dense_hw_fwd':   ('CLV_DENSE_HW_FWD',     True,  "the hW forward product by walking the notes at every batch size"),
+    'label_in_pair':  ('CLV_LABEL_IN_PAIR',    True,  "the label path's backward as a launch of its own instead of the pair backward kernel's epilogue"),
+    'fuse_latent':    ('CLV_FUSE_LATENT',      True,  "the latent head as GEMM + pointwise launches instead of csrc/latent_head.hip"),
+    'lstm_mx':        ('CLV_USE_MX',           True,  "large batches on the generic chain instead of csrc/lstm_mx.hip"),
+    'frames_u8':      ('CLV_FRAMES_U8',        True,  "the large-batch step widens its byte batch to float (rounds 4-5) instead of reading bytes"),
+    'fine_grid':      ('CLV_FINE_GRID',        False, "twice the workgroups, half the rows each, for the LSTM kernel gradients (what tune_dp_schedule may pick next to an all-reduce)"),
+    'fuse_notes':     ('CLV_FUSE_NOTES',       False, "input projections gathered inside the pair forward from note lists (+48 us on MI355X: profiles/r03_notes_fusion_ab.txt)"),
+}
 
 
-class FlatParams:
-    """Flat fp32 parameter / gradient / optimizer-state buffers plus the Adam-WN plan.
-
-    `shapes` are the logical (Keras) tensors; `aliases` maps some of them onto column slices of fused
-    physical tensors (see fuse_heads)."""
-
-    def __init__(self, shapes, device, phys=None, aliases=None, pre=0):
-        """pre: floats of scratch IN FRONT of the gradient buffer, contiguous with it (`grads_pre`): what lives there is
-        averaged across ranks together with the first gradient bucket (cl_vrnn: the optimizer's sum g.V of the hW kernel,
-        which is linear in the gradient like the gradient itself)."""
-        self.logical = list(shapes)
-        self.aliases = dict(aliases or {})
-        self.shapes = list(phys) if phys is not None else list(shapes)
-        self.device = device
-        self.offsets, self.col_offsets = {}, {}
-        off = col = 0
-        table = (_lib.ParamDesc * len(self.shapes))()
-        for i, (name, shp) in enumerate(self.shapes):
-            n = int(np.prod(shp))
-            self.offsets[name] = off
-            is_mat = len(shp) > 1
-            rows = int(np.prod(shp[:-1])) if is_mat else 1
-            table[i] = _lib.ParamDesc(off, rows, int(shp[-1]), col if is_mat else 0, int(is_mat), 0)
-            if is_mat:
-                self.col_offsets[name] = col
-                col += (int(shp[-1]) + 3) // 4 * 4
-            off += (n + 3) // 4 * 4
-        self.n, self.n_cols, self.table = off, max(col, 4), table
-        self._subplans = {}
-        f = dict(dtype=torch.float32, device=device)
-        self.params = torch.zeros(self.n, **f)
-        pre = (int(pre) + 3) // 4 * 4
-        self.grads_store = torch.zeros(pre + self.n, **f)
-        self.grads_pre, self.grads = self.grads_store[:pre], self.grads_store[pre:]
-        self.m = torch.zeros(self.n, **f)
-        self.v = torch.zeros(self.n, **f)
-        self.mg = torch.zeros(self.n_cols, **f)
-        self.vg = torch.zeros(self.n_cols, **f)
-        self.s = torch.ones(self.n_cols, **f)
-        # ||V||^2 per column of the tall matrices, kept by every Adam-WN step (clv_adam_wn_step_ex): the next step's first
-        # column sum.  norms_valid: it describes the parameters as they are now (cleared by anything else that writes them)
-        self.vn2 = torch.zeros(self.n_cols, **f)
-        self.norms_valid = False
-        self.iterations = torch.zeros(1, dtype=torch.int32, device=device)
-        L = _lib.lib()
-        nb = L.clv_adam_wn_plan_bytes(table, len(self.shapes))
-        blob = (C.c_uint8 * nb)()
-        _lib.check(L.clv_adam_wn_plan_build(table, len(self.shapes), blob), "adam plan")
-        self.plan = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(device)
-        self.adam_ws = torch.empty(L.clv_adam_wn_workspace_bytes(table, len(self.shapes)), dtype=torch.uint8,
-                                   device=device)
-
-    # views ---------------------------------------------------------------
-    def view(self, buf, name):
-        if name in self.aliases:
-            phys, c0, nc = self.aliases[name]
-            return self.view(buf, phys)[..., c0:c0 + nc]
-        shp = dict(self.shapes)[name]
-        o = self.offsets[name]
-        return buf[o:o + int(np.prod(shp))].view(*shp)
-
-    def p(self, name):
-        return self.view(self.params, name)
-
-    def g(self, name):
-        return self.view(self.grads, name)
-
-    def rows(self, buf, name, r0):
-        """1-D view of tensor `name` starting at row r0 (for sub-blocks of a kernel)."""
-        shp = dict(self.shapes)[name]
-        o = self.offsets[name] + r0 * int(shp[-1])
-        return buf[o:]
-
-    # host <-> device -------------------------------------------------------
-    def set_weights(self, weights):
-        for name, _ in self.logical:
-            self.p(name).copy_(torch.as_tensor(np.asarray(weights[name], dtype=np.float32)))
-        self.norms_valid = False
-
-    def get_weights(self, buf=None):
-        buf = self.params if buf is None else buf
-        return {name: self.view(buf, name).detach().cpu().numpy().copy() for name, _ in self.logical}
-
-    def state_tensors(self):
-        """Everything a replica must share to step identically: parameters, Adam moments, the weight-norm column state
-        and the step counter (which also keys the Philox noise stream)."""
-        return [self.params, self.m, self.v, self.mg, self.vg, self.s, self.vn2, self.iterations]
-
-    def reset_optimizer(self):
-        for t in (self.m, self.v, self.mg, self.vg):
-            t.zero_()
-        self.s.fill_(1.0)
-        self.iterations.zero_()
-        self.norms_valid = False
-
-    def _subplan(self, names):
-        """(table, n, device plan) of the update restricted to the tensors in `names` (same flat buffers)."""
-        key = tuple(names)
-        if key not in self._subplans:
-            idx = [i for i, (name, _) in enumerate(self.shapes) if name in names]
-            table = (_lib.ParamDesc * len(idx))(*[self.table[i] for i in idx])
-            L = _lib.lib()
-            blob = (C.c_uint8 * L.clv_adam_wn_plan_bytes(table, len(idx)))()
-            _lib.check(L.clv_adam_wn_plan_build(table, len(idx), blob), "adam plan")
-            plan = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(self.device)
-            self._subplans[key] = (table, len(idx), plan)
-        return self._subplans[key]
-
-    def tall_tensor(self):
-        """Index and name of the one matrix of more than 144 rows (csrc/optim.hip SM_ROWS; cl_vrnn's hW/kernel), or None."""
-        tall = [(i, name) for i, (name, shp) in enumerate(self.shapes) if len(shp) > 1 and int(np.prod(shp[:-1])) > 144]
-        return tall[0] if len(tall) == 1 else None
-
-    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weightnorm=True, only=None, advance=True, advanced=False,
-                  gdot=None):
-        """utils/weightnorm.py:75-143; t comes from the device `iterations` counter.
-        only: names of the tensors to update (default all); advance=False leaves `iterations` alone, so one optimizer step
-        can be issued in pieces (the multi-GPU schedule updates a bucket as soon as its all-reduce has landed).
-        advanced=True: the counter was already advanced by the launch that produced the gradients (the fused cl_vae
-        step) and holds t.
-        gdot [cols]: sum_j K[j,c] dK[j,c] of the tall matrix (ops.sparse_outer(gdot=...)), for gradients that were not
-        averaged across ranks afterwards: with norms_valid the step takes the two-launch form (clv_adam_wn_step_ex)."""
-        table, n, plan = (self.table, len(self.shapes), self.plan) if only is None else self._subplan(only)
-        known, tall = None, self.tall_tensor()
-        if int(weightnorm) == 1 and tall is not None and (only is None or tall[1] in only):
-            use = gdot is not None and self.norms_valid
-            pos = tall[0] if only is None else [name for name, _ in self.shapes if name in only].index(tall[1])
-            known = _lib.AdamKnownSums(pos, int(use), ops._ptr(gdot) if use else None, ops._ptr(self.vn2))
-        _lib.check(_lib.lib().clv_adam_wn_step_ex(
-            table, n, ops._ptr(plan), ops._ptr(self.params), ops._ptr(self.grads),
-            ops._ptr(self.m), ops._ptr(self.v), ops._ptr(self.mg), ops._ptr(self.vg), ops._ptr(self.s),
-            ops._ptr(self.iterations), -2 if advanced else (0 if advance else -1), lr, b1, b2, eps, int(weightnorm),
-            C.byref(known) if known is not None else None, ops._ptr(self.adam_ws),
-            self.adam_ws.numel(), ops._stream()), "clv_adam_wn_step")
-        # vn2 follows the parameters through whole Adam-WN steps only
-        self.norms_valid = known is not None or (self.norms_valid and tall is not None and only is not None
-                                                 and tall[1] not in only)
+def switch(cfg, key):
+    """cfg[key] if given, else the switch's environment variable ('0' / '1'), else its default"""
+    env, default, _ = SWITCHES[key]
+    if key in cfg:
+        return bool(cfg[key])
+    if env is not None and env in os.environ:
+        return os.environ[env] != '0'
+    return default
 
 
 def _f(device, *shape):
@@ -273,7 +146,7 @@ class _EngineBase:
 
 
 # --------------------------------------------------------------------------- #
-class VaeEngine(_EngineBase):
+class VaeEngine(VaeGenerate, _EngineBase):
     """cl_vae: Dense encoder/decoder VAE with a logistic-normal label (cl_vae/model.py:130-224).
 
     Concatenations ([x,w], [w,xp,z]) are never materialised: a Dense over a concatenation is
@@ -381,58 +254,6 @@ class VaeEngine(_EngineBase):
         ops.gauss_fwd(B, L, self.zargs, eps_z, self.z, L, self.rowkl)
         self.decode(self.w, self.z, xp)
 
-    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False, persistent=True, xhat_out=None):
-        """N independent sequences of `nsteps` frames on the device: the frame loop of cl_vae/model.py:28-41
-        (z-encoder on the last frame, z ~ N(mean, exp(lv)) or N(0, 1), decoder on (w, z, frame before last),
-        x ~ Bernoulli); eps and u come from the Philox streams 0 / 1 at step = frame index.  x_seed [N,D], w [N,C] device
-        tensors.  persistent=True (default where the shapes allow): the whole loop is ONE kernel, a workgroup per
-        sequence (csrc/vae_generate.hip; any N); otherwise the layer chain captured once as a hipGraph and replayed per
-        frame (N <= batch size).  Same noise, same samples either way."""
-        cfg, d = self.cfg, self.device
-        N, D, L = int(x_seed.shape[0]), cfg['D'], cfg['L']
-        if persistent and cfg['H'] > 0 and ops.vae_generate_supported(D, cfg['H'], L, cfg['C']):
-            P = self.P
-            f = dict(dtype=torch.float32, device=d)
-            Xs = torch.zeros(N, nsteps, D, **f)
-            ops.vae_generate(N, nsteps, D, cfg['H'], L, cfg['C'], cfg['use_x_prev'], z_prior, seed,
-                             x_seed.to(**f).contiguous(), w.to(**f).contiguous(), P.p('h/kernel'), P.p('h/bias'),
-                             P.p('zargs/kernel'), P.p('zargs/bias'), P.p('decoder_h/kernel'), P.p('decoder_h/bias'),
-                             P.p('x_decoded_mean/kernel'), P.p('x_decoded_mean/bias'), Xs, xhat_out)
-            return Xs
-        if N > self.B:
-            raise ValueError("%d sequences exceed the engine's batch size %d" % (N, self.B))
-        f = dict(dtype=torch.float32, device=d)
-        x_in, hist, x_next = x_seed.to(**f).clone(), x_seed.to(**f).clone(), torch.zeros(N, D, **f)
-        eps, u = torch.zeros(N, L, **f), torch.zeros(N, D, **f)
-        counter = torch.zeros(1, dtype=torch.int32, device=d)
-        Xs = torch.zeros(N, nsteps, D, **f)
-        w = w.to(**f).contiguous()
-
-        def frame():
-            self.encode_z(x_in, w, N)
-            ops.philox_normal(eps, N * L, seed, 0, 0, 0, step_dev=counter)
-            if z_prior:
-                self.zargs[:N].zero_()
-            ops.gauss_fwd(N, L, self.zargs, eps, self.z, L, None)
-            self.decode(w, self.z, hist if cfg['use_x_prev'] else None, N, act=ACT_SIGMOID)
-            ops.philox_uniform(u, N * D, seed, 0, 1, 0, step_dev=counter)
-            ops.bernoulli_sample(N * D, self.logits, u, x_next)
-            ops.i32_add(counter, 1)
-            hist.copy_(x_in)            # the decoder's history lags the encoder input by one frame
-            x_in.copy_(x_next)
-
-        graph = None
-        for t in range(nsteps):
-            if use_graph and t == 1:
-                with ops.Graph() as graph:       # frame 0 ran eagerly and sized every workspace
-                    frame()
-            if graph is not None:
-                graph.launch()
-            else:
-                frame()
-            Xs[:, t].copy_(x_next)
-        return Xs
-
     def _fused_step(self, x, xp, w_true, eps_w, eps_z, need_grads, target=None, noise=None, bump=False):
         """The whole step as ONE kernel (csrc/vae_fused.hip) + one launch that sums the gradient slabs, takes the loss
         means and (bump) advances the step counter."""
@@ -451,15 +272,11 @@ class VaeEngine(_EngineBase):
                 p_(self.logits), p_(self.w), p_(self.wargs), p_(self.zargs), p_(self.rownll), p_(self.rowkl),
                 p_(self.rowloss), C.byref(opts), ops._stream())
         stage, self.stage_spec = self.stage_spec, None
-        if stage is not None and target is None:
-            # TrainStep handed over the mini-batch assembly (ops.label_stage): the kernel reads its rows' byte frames itself
-            _lib.check(_lib.lib().clv_vae_fused_step_staged(
-                B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), C.byref(stage), *tail),
-                "clv_vae_fused_step_staged")
-            return
-        _lib.check(_lib.lib().clv_vae_fused_step_ex(
-            B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), p_(x), p_(xp), p_(target),
-            p_(w_true), *tail), "clv_vae_fused_step_ex")
+        # stage: TrainStep handed over the mini-batch assembly (ops.label_stage): the kernel reads its rows' byte frames itself
+        staged = stage is not None and target is None
+        _lib.check(_lib.lib().clv_vae_fused_step(
+            B, cfg['D'], cfg['H'], cfg['Hc'], cfg['C'], cfg['L'], int(cfg['use_x_prev']), p_(x), p_(xp), p_(target), p_(w_true),
+            C.byref(stage) if staged else None, *tail), "clv_vae_fused_step")
 
     def can_stage_in_label(self):
         """Can the step's own launch assemble its mini-batch (ops.label_stage)?  The fused kernel reads its rows itself."""
@@ -555,7 +372,7 @@ class VaeEngine(_EngineBase):
 
 
 # --------------------------------------------------------------------------- #
-class VrnnEngine(_EngineBase):
+class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
     """cl_vrnn: classifying VAE + two LSTMs (cl_vrnn/model.py:164-267)."""
 
     def __init__(self, cfg, batch_size, device='cuda:0'):
@@ -580,60 +397,34 @@ class VrnnEngine(_EngineBase):
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout must be in [0, 1)")
         self._train_pass = False
-        self.fuse_xproj = bool(cfg.get('fuse_xproj', False)) and H == 88 and not self.dropout   # break-even vs the projection GEMM at config 3 (PERFLOG.md 8)
-        # encoder + latent head + decoder as one launch (csrc/lstm_pair.hip); latent_dim <= 16
-        self.fuse_pair = bool(cfg.get('fuse_pair', True)) and ops.lstm_pair_supported(L, H) and not self.fuse_xproj \
-            and not self.dropout
-        # Twice the workgroups, half the K each, for the LSTM weight-gradient products.  They run one 1024-thread
-        # workgroup per CU with the register file full: alone on the GPU a grid of exactly 256 is best, but when the
-        # gradient all-reduce holds a few CUs a 256-workgroup grid needs a whole second round; 512 shorter ones lose
-        # only the share of the CUs that is taken.  TrainStep turns it on for world > 1.
-        self.fine_grid = bool(cfg.get('fine_grid', os.environ.get('CLV_FINE_GRID', '0') == '1'))
+        # which kernels the chains take: SWITCHES (cfg key -> what it selects), each narrowed by what the shapes support
+        sw = lambda key: switch(cfg, key)
+        self.fuse_pair = sw('fuse_pair') and ops.lstm_pair_supported(L, H) and not self.dropout
+        self.fine_grid = sw('fine_grid')
         self.pair_pack = _f(d, ops.lstm_pair_pack_floats()) if self.fuse_pair else None
-        # input projections by sparse row gathering (exact for any input; pays off for piano-roll frames)
-        self.sparse_inputs = bool(cfg.get('sparse_inputs', True)) and ops.sparse_proj_supported(D, 4 * H)
-        # output head: forward + loss + all three backward products in one launch
-        self.fuse_head = bool(cfg.get('fuse_head', os.environ.get('CLV_FUSE_HEAD', '1') != '0')) \
-            and ops.out_head_train_supported(H, D)
+        self.sparse_inputs = sw('sparse_inputs') and ops.sparse_proj_supported(D, 4 * H)
+        self.fuse_head = sw('fuse_head') and ops.out_head_train_supported(H, D)
         self._head_done = False
-        # the fused head also stores the logits (tests and callers of loss_and_grads read them); a replayed training step has
-        # no reader for them, so TrainStep(use_graph=True) turns the store off: 11.5 MB per step at configuration 3, 92 MB at 5
-        self.keep_logits = bool(cfg.get('keep_logits', True))
-        # LSTM kernel gradients as split-bf16 products (6 of 9 piece pairs, <= 2^-25 per product: csrc/wgrad_bf16.hip) instead of the f32 MFMA GEMM;
-        # frames_exact_bf16: every staged frame value is exactly a bf16 number (TrainStep sets it when the data set is
-        # kept as uint8), which lets the frame rows use one bf16 piece instead of three
-        self.bf16_wgrad = bool(cfg.get('bf16_wgrad', os.environ.get('CLV_BF16_WGRAD', '1') != '0'))
+        self.keep_logits = sw('keep_logits')
+        self.bf16_wgrad = sw('bf16_wgrad')
+        # every staged frame value is exactly a bf16 number (TrainStep sets it when the data set is kept as uint8): the frame
+        # rows of the kernel-gradient products then use one bf16 piece instead of three
         self.frames_exact_bf16 = bool(cfg.get('frames_exact_bf16', False))
-        # ... and both LSTMs' in one launch where they take the same form of the kernel (grads_tail)
-        self.wgrad_pair = bool(cfg.get('wgrad_pair', os.environ.get('CLV_WGRAD_PAIR', '1') != '0'))
-        # the hW layer's kernel gradient dense on the bf16 matrix cores when the frames are exact there (loss_and_grads)
-        self.dense_hw_grad = bool(cfg.get('dense_hw_grad', os.environ.get('CLV_DENSE_HW_GRAD', '1') != '0'))
-        # ... and its forward product (label forward): from CLV_DENSE_HW_FWD_ROWS batch rows on (default 512: at 256 rows the note-walking gather is as fast, 20.5 against 12.5 + 11.7 us)
-        self.dense_hw_fwd = bool(cfg.get('dense_hw_fwd', os.environ.get('CLV_DENSE_HW_FWD', '1') != '0')) and \
-            B >= int(os.environ.get('CLV_DENSE_HW_FWD_ROWS', '512'))
+        self.wgrad_pair = sw('wgrad_pair')
+        self.dense_hw_grad = sw('dense_hw_grad')
+        # (from 512 batch rows on: at 256 rows the note-walking gather is as fast, 20.5 against 12.5 + 11.7 us)
+        self.dense_hw_fwd = sw('dense_hw_fwd') and B >= int(os.environ.get('CLV_DENSE_HW_FWD_ROWS', '512'))
         self.ws_hw = None
         self.stage_spec = None       # set by TrainStep for one forward pass: see _forward_pair
         self._f8 = None              # the pass's uint8 frames (forward(frames8=...))
         self.ws_b = None
-        # Note lists (opt-in: cfg['fuse_notes'] / CLV_FUSE_NOTES=1): when the batch was staged from BINARY uint8 frames,
-        # the staging launch also writes each frame's list of notes (ops.gather_rows_multi(notes=...)) and the pair
-        # forward kernel gathers the LSTM input projections itself -- no projection launch, no [B*T,352] round trip per
-        # LSTM.  Measured (profiles/r03_notes_fusion_ab.txt): it LOSES on MI355X -- every CU re-gathers ~11 KB of kernel
-        # rows per step through its L1 miss path (~10 B/cycle per CU), +48 us on the pair kernel for the 26 us launch it
-        # removes -- so the default stays the projection launch, whose workgroups keep K_x in LDS.
-        # notes_valid: the lists describe the frames now in X / XZ (TrainStep sets it per staged batch).
-        # the label path's backward as the pair backward kernel's epilogue (CLV_LABEL_IN_PAIR=0: its own launch)
-        self.label_in_pair = bool(cfg.get('label_in_pair', os.environ.get('CLV_LABEL_IN_PAIR', '1') != '0')) and self.fuse_pair
-        # outside the pair kernels: the latent head's forward / backward as one MFMA launch each (csrc/latent_head.hip)
-        self.fuse_latent = bool(cfg.get('fuse_latent', os.environ.get('CLV_FUSE_LATENT', '1') != '0')) \
-            and ops.latent_head_supported(H, L)
-        # large batches (>= 768 rows per GPU: BASELINE configuration 5) outside the pair kernels: both LSTMs' training passes
-        # on the bf16 matrix cores with the frame rows of their input kernels gathered inside the kernel (csrc/lstm_mx.hip):
-        # no projection launch, no [B*T,4H] projection buffer; gates_* / cs_* then hold the coefficient format
-        self.use_mx = bool(cfg.get('lstm_mx', os.environ.get('CLV_USE_MX', '1') != '0')) and not self.fuse_pair \
-            and not self.dropout and self.sparse_inputs and not self.fuse_xproj and ops.lstm_mx_supported(B, D, L, H)
-        self.fuse_notes = bool(cfg.get('fuse_notes', os.environ.get('CLV_FUSE_NOTES', '0') == '1')) and self.fuse_pair \
-            and self.sparse_inputs and D == ops.NOTE_NONE
+        self.label_in_pair = sw('label_in_pair') and self.fuse_pair
+        self.fuse_latent = sw('fuse_latent') and ops.latent_head_supported(H, L)
+        self.use_mx = sw('lstm_mx') and not self.fuse_pair and not self.dropout and self.sparse_inputs \
+            and ops.lstm_mx_supported(B, D, L, H)
+        self.frames_u8 = sw('frames_u8')
+        # notes_valid: the note lists describe the frames now in X / XZ (TrainStep sets it per staged batch)
+        self.fuse_notes = sw('fuse_notes') and self.fuse_pair and self.sparse_inputs and D == ops.NOTE_NONE
         self.notes_valid = False
         if self.fuse_notes:
             self.notes_enc = torch.full((BT, ops.NOTE_ROW), ops.NOTE_NONE, dtype=torch.uint8, device=d)
@@ -682,12 +473,6 @@ class VrnnEngine(_EngineBase):
             self.wm_e, self.wm_d = _f(d, 4, B, Cn), _f(d, 4, B, Cn)                # ... and masked label rows
             self.dxg, self.dwg = _f(d, BT, self.xz_ld), _f(d, B, Cn)               # a gate's share of dL/d[Xp | Z], dL/dW
 
-    def set_dropout_uniforms(self, u_enc, u_dec):
-        """The uniforms behind the two LSTMs' input-dropout masks ([B, 4, D + C] and [B, 4, (D) + L + C], m = (u >= p) / (1 - p)) as
-        explicit inputs, like eps_W / eps_Z: a training pass without `noise=` uses them."""
-        self.u_enc.copy_(u_enc.view_as(self.u_enc)); self.u_dec.copy_(u_dec.view_as(self.u_dec))
-        self._masks_given = True
-
     def folds_noise(self):
         """True when forward(noise=...) draws eps_W / eps_Z inside the label kernel and the pair kernels / the latent head of the
         large-batch path (no Philox launch)."""
@@ -700,8 +485,8 @@ class VrnnEngine(_EngineBase):
         outer_bf16.hip (the hW layer's forward and kernel-gradient products)."""
         cfg, B = self.cfg, self.B
         D, H, L, T = cfg['D'], cfg['H'], cfg['L'], cfg['T']
-        if not (self.use_mx and self.fuse_head and self.bf16_wgrad and self.dense_hw_grad and self.dense_hw_fwd and D % 4 == 0
-                and os.environ.get('CLV_FRAMES_U8', '1') != '0'):
+        if not (self.frames_u8 and self.use_mx and self.fuse_head and self.bf16_wgrad and self.dense_hw_grad and self.dense_hw_fwd
+                and D % 4 == 0):
             return False
         return bool(ops.dense_window_fwd_bf16_supported(B, T * D, D, T * D, D) and ops.dense_outer_bf16_supported(B, T * D, D, T * D, D)
                     and ops.sparse_dense_supported(D) and ops.lstm_wgrad_supported(4 * H, D, H, 0, 2)
@@ -750,24 +535,17 @@ class VrnnEngine(_EngineBase):
                 raise RuntimeError("training pass with dropout=%g and neither noise=... nor set_dropout_uniforms(): the masks "
                                    "would come from uninitialised memory" % self.dropout)
             return self._forward_dropout(X, eps_W, eps_Z, w_true, nll, target)
-        fuse_enc = self.fuse_xproj and ops.lstm_fused_input_fits(B, D)
-        fuse_dec = self.fuse_xproj and ops.lstm_fused_input_fits(B, self.off + L)
-        if not fuse_enc:
-            if self.sparse_inputs:     # add the kernel rows of the notes that are on (csrc/sparse_proj.hip)
-                ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
-            else:
-                with self._side():
-                    g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
+        if self.sparse_inputs:     # add the kernel rows of the notes that are on (csrc/sparse_proj.hip)
+            ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
+        else:
+            with self._side():
+                g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=self.ws2)
         # label path (:174-191)
         off = self.off
         self._label_forward(X, eps_W, w_true)
         self._join()
-        if fuse_enc:          # x_t.K gathered from the LDS-resident kernel inside the sequence kernel
-            ops.lstm_seq_fwd_x(B, T, X, D, D, P.p('encoder_h/kernel'), self.wk_enc, P.p('encoder_h/recurrent_kernel'),
-                               self.hs_enc, self.cs_enc, self.gates_enc, gate_act=self.gate_act)
-        else:
-            ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
-                             self.cs_enc, self.gates_enc, gate_act=self.gate_act, H=H)
+        ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc,
+                         self.cs_enc, self.gates_enc, gate_act=self.gate_act, H=H)
         # latent heads + sample (:200-216)
         if self.fuse_latent:       # one launch on the matrix cores (csrc/latent_head.hip)
             ops.latent_head_fwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z, self.zargs, self.Z,
@@ -777,21 +555,9 @@ class VrnnEngine(_EngineBase):
             ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
         # decoder LSTM on [Xp, Z, repeat(W)] (:218-228): one projection of the [Xp | Z] rows
         self._join()
-        if fuse_dec:
-            ops.lstm_seq_fwd_x(B, T, self.XZ, self.xz_ld, off + L, P.p('decoder_h/kernel'), self.wk_dec,
-                               P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.cs_dec, self.gates_dec,
-                               gate_act=self.gate_act)
-        elif off and self.sparse_inputs and ops.lstm_seq_fwd_z_supported(B, L, H):
-            # large batches: the history frames' projection as a row gather, z_t . K_z inside the MFMA sequence kernel
-            # (no dense [B*T, 120] x [120, 352] product, no second trip of the gate buffer through HBM)
-            ops.sparse_proj(BT, off, G4, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec)
-            ops.lstm_seq_fwd_z(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.Z, self.xz_ld, L,
-                               P.rows(P.params, 'decoder_h/kernel', off), self.hs_dec, self.cs_dec, self.gates_dec,
-                               gate_act=self.gate_act)
-        else:
-            g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
-            ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
-                             self.cs_dec, self.gates_dec, gate_act=self.gate_act, H=H)
+        g(self.XZ, P.p('decoder_h/kernel'), self.gates_dec, BT, G4, off + L, lda=self.xz_ld, ws=ws)
+        ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec,
+                         self.cs_dec, self.gates_dec, gate_act=self.gate_act, H=H)
         # output head (:229-234), with the NLL fused into its epilogue when the caller wants the loss
         self._output_head(target, nll)
 
@@ -819,112 +585,6 @@ class VrnnEngine(_EngineBase):
                         self.Z, self.xz_ld, L, P.rows(P.params, 'decoder_h/kernel', off), self.wk_dec,
                         P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.gates_dec, self.cs_dec, gate_act=self.gate_act)
         self._output_head(X if f8 is not None else target, nll)
-
-    # -- LSTM(dropout=p), training passes (cl_vrnn/model.py:164,198,227) ---------------------------------------------------
-    # Keras 2.0.0 (implementation 0) multiplies the inputs of gate g's projection with a mask m_g [B, input_dim] drawn once per
-    # batch -- the same for every time step -- and different for the four gates: z_g = ([x_t, z_t, W] * m_g) . K[:, g] + b_g +
-    # h_{t-1} . U[:, g].  u_enc / u_dec [B, 4, input_dim] hold the masks' UNIFORMS (m = (u >= p) / (1 - p), applied by
-    # clv_dropout_rows); the per-step rows and the label row of a gate are masked into xm_* / wm_* and multiplied as GEMMs
-    # over that gate's column block (ldb = ldc = 4H).  Inference passes (validation, predict, generation) take no dropout.
-    def _gate_cols(self, t, gi):
-        """1-D / 2-D view of buffer t starting at gate gi's column block (pointer offset; the leading dimension stays 4H)"""
-        H = self.cfg['H']
-        return t[gi * H:] if t.dim() == 1 else t[:, gi * H:]
-
-    def _forward_dropout(self, X, eps_W, eps_Z, w_true, nll, target):
-        cfg, P, B = self.cfg, self.P, self.B
-        D, H, L, T, Cn, off = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C'], self.off
-        BT, G4, rate = B * T, 4 * H, self.dropout
-        g, ws, gc = ops.gemm, self.ws, self._gate_cols
-        self._label_forward(X, eps_W, w_true)              # hW, Wargs, W, the label losses (its unmasked row biases are replaced)
-        in_e, in_d = D + Cn, off + L + Cn
-        ue, ud = self.u_enc.view(B, 4 * in_e), self.u_dec.view(B, 4 * in_d)
-        X2 = X.reshape(BT, D)
-        for gi in range(4):
-            ops.dropout_rows(BT, T, D, X2, D, ue[:, gi * in_e:], 4 * in_e, rate, self.xm_e[gi], D)
-            g(self.xm_e[gi], gc(P.p('encoder_h/kernel'), gi), gc(self.gates_enc, gi), BT, H, D, ldb=G4, ldc=G4, ws=ws)
-            ops.dropout_rows(B, 1, Cn, self.W, Cn, ue[:, gi * in_e + D:], 4 * in_e, rate, self.wm_e[gi], Cn)
-            g(self.wm_e[gi], gc(P.rows(P.params, 'encoder_h/kernel', D), gi), gc(self.wk_enc, gi), B, H, Cn, ldb=G4, ldc=G4,
-              bias=gc(P.p('encoder_h/bias'), gi), ws=ws)
-        ops.lstm_seq_fwd(B, T, self.gates_enc, self.wk_enc, P.p('encoder_h/recurrent_kernel'), self.hs_enc, self.cs_enc,
-                         self.gates_enc, gate_act=self.gate_act, H=H)
-        if self.fuse_latent:
-            ops.latent_head_fwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), P.p('Zargs/bias'), eps_Z, self.zargs, self.Z,
-                                self.xz_ld, self.rowkl)
-        else:
-            g(self.hs_enc, P.p('Zargs/kernel'), self.zargs, BT, 2 * L, H, bias=P.p('Zargs/bias'), ws=ws)
-            ops.gauss_fwd(BT, L, self.zargs, eps_Z, self.Z, self.xz_ld, self.rowkl)
-        for gi in range(4):
-            ops.dropout_rows(BT, T, off + L, self.XZ, self.xz_ld, ud[:, gi * in_d:], 4 * in_d, rate, self.xm_d[gi], self.xz_ld)
-            g(self.xm_d[gi], gc(P.p('decoder_h/kernel'), gi), gc(self.gates_dec, gi), BT, H, off + L, lda=self.xz_ld, ldb=G4,
-              ldc=G4, ws=ws)
-            ops.dropout_rows(B, 1, Cn, self.W, Cn, ud[:, gi * in_d + off + L:], 4 * in_d, rate, self.wm_d[gi], Cn)
-            g(self.wm_d[gi], gc(P.rows(P.params, 'decoder_h/kernel', off + L), gi), gc(self.wk_dec, gi), B, H, Cn, ldb=G4,
-              ldc=G4, bias=gc(P.p('decoder_h/bias'), gi), ws=ws)
-        ops.lstm_seq_fwd(B, T, self.gates_dec, self.wk_dec, P.p('decoder_h/recurrent_kernel'), self.hs_dec, self.cs_dec,
-                         self.gates_dec, gate_act=self.gate_act, H=H)
-        self._output_head(target, nll)
-
-    def _backward_dropout(self, X, w_true, eps_W, eps_Z):
-        """Everything behind dL/dh_dec (self.dhs) of a training pass with input dropout: both BPTTs, dZ and dW through the
-        gates' masks, the latent head, the label path from an explicit dL/dW, every weight gradient.  Plain launches (no
-        deferred reductions): this chain is the rarely used one."""
-        cfg, P, B = self.cfg, self.P, self.B
-        D, H, L, T, Cn, off = cfg['D'], cfg['H'], cfg['L'], cfg['T'], cfg['C'], self.off
-        C1, BT, G4, rate = Cn - 1, B * T, 4 * H, self.dropout
-        g, ws, gc = ops.gemm, self.ws, self._gate_cols
-        in_e, in_d = D + Cn, off + L + Cn
-        ue, ud = self.u_enc.view(B, 4 * in_e), self.u_dec.view(B, 4 * in_d)
-        Kd, Ke = P.p('decoder_h/kernel'), P.p('encoder_h/kernel')
-        # decoder BPTT; dZ = sum_g m_g[z cols] * (dz_g . K_z[:, g]^T); dW (decoder share) likewise from sum_t dz
-        ops.lstm_seq_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec, self.dzsum_dec,
-                         gate_act=self.gate_act, H=H)
-        for gi in range(4):
-            g(gc(self.gates_dec, gi), gc(P.rows(P.params, 'decoder_h/kernel', off), gi), self.dxg, BT, L, H, tb=True, lda=G4,
-              ldb=G4, ldc=self.xz_ld, ws=ws)
-            ops.dropout_rows(BT, T, L, self.dxg, self.xz_ld, ud[:, gi * in_d + off:], 4 * in_d, rate, self.dZ, L, beta=float(gi > 0))
-            g(gc(self.dzsum_dec, gi), gc(P.rows(P.params, 'decoder_h/kernel', off + L), gi), self.dwg, B, Cn, H, tb=True, lda=G4,
-              ldb=G4, ws=ws)
-            ops.dropout_rows(B, 1, Cn, self.dwg, Cn, ud[:, gi * in_d + off + L:], 4 * in_d, rate, self.dW, Cn, beta=float(gi > 0))
-        # latent head backward -> dL/dh_enc
-        if self.fuse_latent:
-            ops.latent_head_bwd(BT, H, L, self.hs_enc, P.p('Zargs/kernel'), self.zargs, eps_Z, self.dZ, L,
-                                self.kl_weight / BT, self.dhs, P.g('Zargs/kernel'), P.g('Zargs/bias'), ws, defer=None)
-        else:
-            ops.gauss_bwd(BT, L, self.zargs, eps_Z, self.dZ, L, self.kl_weight / BT, self.dzargs)
-            g(self.dzargs, P.p('Zargs/kernel'), self.dhs, BT, H, 2 * L, tb=True, ws=ws)
-            self._dense_wgrad('Zargs', self.hs_enc, H, H, 2 * L, BT, self.dzargs, ws, None)
-        ops.lstm_seq_bwd(B, T, P.p('encoder_h/recurrent_kernel'), self.dhs, self.cs_enc, self.gates_enc, self.dzsum_enc,
-                         gate_act=self.gate_act, H=H)
-        for gi in range(4):
-            g(gc(self.dzsum_enc, gi), gc(P.rows(P.params, 'encoder_h/kernel', D), gi), self.dwg, B, Cn, H, tb=True, lda=G4,
-              ldb=G4, ws=ws)
-            ops.dropout_rows(B, 1, Cn, self.dwg, Cn, ue[:, gi * in_e + D:], 4 * in_e, rate, self.dW, Cn, beta=1.0)
-        # label path from dL/dW (the LSTMs' share so far; clv_label_bwd adds the label losses' own terms)
-        ops.label_bwd(B, Cn, self.wargs, self.wargs[:, C1:], 2 * C1, eps_W, w_true, self.W, self.dW,
-                      cfg['w_log_var_prior'], self.class_weight, self.w_kl_weight, 1.0 / B,
-                      self.dwargs, self.dwargs[:, C1:], 2 * C1)
-        g(self.hW, self.dwargs, P.g('Wargs/kernel'), D, 2 * C1, B, ta=True, ws=ws)
-        ops.colsum(self.dwargs, B, 2 * C1, P.g('Wargs/bias'), ws)
-        g(self.dwargs, P.p('Wargs/kernel'), self.dhW, B, D, 2 * C1, tb=True, act=ACT_MASKPOS, aux=self.hW, ws=ws)
-        g(X.reshape(B, T * D), self.dhW, P.g('hW/kernel'), T * D, D, B, ta=True, ws=ws)
-        ops.colsum(self.dhW, B, D, P.g('hW/bias'), ws)
-        self.gdot_fresh = False
-        # weight gradients of the two LSTMs: per gate the masked inputs' products, the recurrent kernel as usual
-        for name, xm, wm, nin, ldx, hs, dz, dzsum in (('encoder_h', self.xm_e, self.wm_e, D, D, self.hs_enc, self.gates_enc, self.dzsum_enc),
-                                                      ('decoder_h', self.xm_d, self.wm_d, off + L, self.xz_ld, self.hs_dec, self.gates_dec,
-                                                       self.dzsum_dec)):
-            for gi in range(4):
-                g(xm[gi], gc(dz, gi), gc(P.g(name + '/kernel'), gi), nin, H, BT, ta=True, lda=ldx, ldb=G4, ldc=G4, ws=ws)
-                g(wm[gi], gc(dzsum, gi), gc(P.rows(P.grads, name + '/kernel', nin), gi), Cn, H, B, ta=True, ldb=G4, ldc=G4, ws=ws)
-            ops.gemm_grouped_tn([dict(A=hs, lda=H, M=H, C=P.g(name + '/recurrent_kernel'), shift=1, zero_period=T)], G4, BT, dz, ws)
-            ops.colsum(dzsum, B, G4, P.g(name + '/bias'), ws)
-        if not self._head_done:
-            self._dense_wgrad('X_decoded_mean', self.hs_dec, H, H, D, BT, self.dlogits, ws, None)
-        rq = self._rq()
-        if rq is not None:       # (the fused output head may have left its slabs pending; the loss means ride along)
-            rq.flush(means=getattr(self, '_loss_terms', None), out=self.scal, skinny=None)
-            self._loss_terms = None
 
     def _dense_hw_fwd_now(self):
         cfg = self.cfg
@@ -1038,121 +698,6 @@ class VrnnEngine(_EngineBase):
                  bias=P.p('X_decoded_mean/bias'), act=ACT_SIGMOID, ws=self.ws)
         return self.dlogits
 
-    # -- stateful single-step inference (the reference's stateful batch-1 sub-models,
-    #    cl_vrnn/model.py:116-162; here for any batch of independent sequences) -------------
-    def new_state(self, B):
-        d, H = self.device, self.cfg['H']
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=d)
-        return dict(B=B, h_enc=z(B, H), c_enc=z(B, H), h_dec=z(B, H), c_dec=z(B, H), gates=z(B, 4 * H),
-                    hs=z(B, H), zargs=z(B, 2 * self.cfg['L']), xhat=z(B, self.cfg['D']))
-
-    def encode_w(self, X, B):
-        """hW -> Wargs for B windows [B, T*D] (:174-181) -> self.wargs[:B]"""
-        cfg, P = self.cfg, self.P
-        D, T, C1 = cfg['D'], cfg['T'], cfg['C'] - 1
-        ops.gemm(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=self.ws)
-        ops.gemm(self.hW, P.p('Wargs/kernel'), self.wargs, B, 2 * C1, D, bias=P.p('Wargs/bias'), ws=self.ws)
-
-    def _lstm_step(self, name, st, hkey, ckey):
-        ops.lstm_seq_fwd(st['B'], 1, st['gates'], None, self.P.p(name + '/recurrent_kernel'), st['hs'], None, None,
-                         h0=st[hkey], c0=st[ckey], hT=st[hkey], cT=st[ckey], gate_act=self.gate_act, H=self.cfg['H'])
-
-    def enc_step(self, x, w, st, rec_name='encoder_h'):
-        """one encoder-LSTM step on [x_t, w] + the Z heads -> st['zargs'] = [z_mean | z_log_var]"""
-        cfg, P, B = self.cfg, self.P, st['B']
-        D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
-        g, ws = ops.gemm, self.ws
-        g(x, P.p(rec_name + '/kernel'), st['gates'], B, 4 * H, D, ws=ws)
-        g(w, P.rows(P.params, rec_name + '/kernel', D), st['gates'], B, 4 * H, Cn, beta=1.0, bias=P.p(rec_name + '/bias'),
-          ws=ws)
-        self._lstm_step(rec_name, st, 'h_enc', 'c_enc')
-        g(st['hs'], P.p('Zargs/kernel'), st['zargs'], B, 2 * L, H, bias=P.p('Zargs/bias'), ws=ws)
-
-    def dec_step(self, z, xp, w, st):
-        """one decoder-LSTM step on [x_{t-1}, z_t, w] + sigmoid head -> st['xhat']"""
-        cfg, P, B = self.cfg, self.P, st['B']
-        D, H, L, Cn = cfg['D'], cfg['H'], cfg['L'], cfg['C']
-        g, ws, off = ops.gemm, self.ws, self.off
-        if cfg['use_x_prev']:
-            g(xp, P.p('decoder_h/kernel'), st['gates'], B, 4 * H, D, ws=ws)
-        g(z, P.rows(P.params, 'decoder_h/kernel', off), st['gates'], B, 4 * H, L,
-          beta=1.0 if cfg['use_x_prev'] else 0.0, ws=ws)
-        g(w, P.rows(P.params, 'decoder_h/kernel', off + L), st['gates'], B, 4 * H, Cn, beta=1.0,
-          bias=P.p('decoder_h/bias'), ws=ws)     # three tiny GEMMs: batch-1 sampling is launch-bound, not flop-bound
-        self._lstm_step('decoder_h', st, 'h_dec', 'c_dec')
-        g(st['hs'], P.p('X_decoded_mean/kernel'), st['xhat'], B, D, H, bias=P.p('X_decoded_mean/bias'),
-          act=ACT_SIGMOID, ws=ws)
-
-    def generate(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False, persistent=True, xhat_out=None):
-        """Autoregressive generation of N independent sequences on the device.  persistent=True (default where the
-        shapes allow): the whole frame loop is ONE kernel, a workgroup per sequence (csrc/generate.hip); otherwise the
-        per-frame chain below, captured once and replayed per frame.  Same Philox noise either way.
-        xhat_out [N,S+nsteps,D] (persistent path only) receives every frame's note probabilities."""
-        cfg = self.cfg
-        if persistent and ops.vrnn_generate_supported(cfg['D'], cfg['H'], cfg['L'], cfg['C']):
-            return self._generate_persistent(x_seed, w, nsteps, seed, z_prior, xhat_out)
-        return self._generate_frames(x_seed, w, nsteps, seed, use_graph, z_prior)
-
-    def _generate_persistent(self, x_seed, w, nsteps, seed, z_prior, xhat_out):
-        cfg, P, d = self.cfg, self.P, self.device
-        D, H, L, Cn, off = cfg['D'], cfg['H'], cfg['L'], cfg['C'], self.off
-        N, S = int(x_seed.shape[0]), int(x_seed.shape[1])
-        Xs = torch.zeros(N, nsteps, D, dtype=torch.float32, device=d)
-        rows = lambda name, r: P.rows(P.params, name, r)
-        ops.vrnn_generate(N, S, nsteps, D, H, L, Cn, self.gate_act, z_prior, seed, x_seed.contiguous() if S else None,
-                          w.contiguous(), P.p('encoder_h/kernel'), rows('encoder_h/kernel', D), P.p('encoder_h/bias'),
-                          P.p('encoder_h/recurrent_kernel'), P.p('Zargs/kernel'), P.p('Zargs/bias'),
-                          P.p('decoder_h/kernel') if cfg['use_x_prev'] else None, rows('decoder_h/kernel', off),
-                          rows('decoder_h/kernel', off + L), P.p('decoder_h/bias'), P.p('decoder_h/recurrent_kernel'),
-                          P.p('X_decoded_mean/kernel'), P.p('X_decoded_mean/bias'), Xs, xhat_out)
-        return Xs
-
-    def _generate_frames(self, x_seed, w, nsteps, seed=0, use_graph=True, z_prior=False):
-        """Batched autoregressive generation on the device (the hot loop of cl_vrnn/model.py:47-59 for N
-        independent sequences at once, noise from Philox instead of np.random).
-        x_seed [N,S,D] device tensor (teacher-forced frames, S may be 0), w [N,C]; returns Xs [N,nsteps,D].
-        One frame = encoder step -> z ~ N(mean, exp(lv)) -> decoder step -> x ~ Bernoulli(x_hat); the chain
-        is captured once and replayed per frame with no host synchronisation."""
-        cfg, d = self.cfg, self.device
-        N, S = int(x_seed.shape[0]), int(x_seed.shape[1])
-        D, L = cfg['D'], cfg['L']
-        f = dict(dtype=torch.float32, device=d)
-        st = self.new_state(N)
-        x_prev, x_next = torch.zeros(N, D, **f), torch.zeros(N, D, **f)
-        eps, u, z = torch.zeros(N, L, **f), torch.zeros(N, D, **f), torch.zeros(N, L, **f)
-        counter = torch.zeros(1, dtype=torch.int32, device=d)
-        Xs = torch.zeros(N, nsteps, D, **f)
-        w = w.contiguous()
-
-        def frame():
-            self.enc_step(x_prev, w, st)
-            ops.philox_normal(eps, N * L, seed, 0, 0, 0, step_dev=counter)
-            if z_prior:
-                st['zargs'].zero_()
-            ops.gauss_fwd(N, L, st['zargs'], eps, z, L, None)
-            self.dec_step(z, x_prev if cfg['use_x_prev'] else None, w, st)
-            ops.philox_uniform(u, N * D, seed, 0, 1, 0, step_dev=counter)
-            ops.bernoulli_sample(N * D, st['xhat'], u, x_next)
-            ops.i32_add(counter, 1)
-            x_prev.copy_(x_next)
-
-        if S == 0:
-            x_prev.zero_()
-        graph = None
-        for t in range(S + nsteps):
-            if t < S:
-                x_prev.copy_(x_seed[:, t])
-            if use_graph and t == 1:
-                with ops.Graph() as graph:       # step 0 ran eagerly and sized every workspace
-                    frame()
-            if graph is not None:
-                graph.launch()
-            else:
-                frame()
-            if t >= S:
-                Xs[:, t - S].copy_(x_next)
-        return Xs
-
     def _wgrad_args(self, name, X_in, x_ld, x_rows, hs, dz, x8=None):
         """The argument tuple of ops.lstm_wgrad (up to dKz) for one LSTM's kernel gradients on the bf16 matrix cores
         (csrc/wgrad_bf16.hip: x rows, h rows and z rows at once), or None where that kernel does not apply.
@@ -1230,7 +775,7 @@ class VrnnEngine(_EngineBase):
         if self.use_mx:      # the backward pass of csrc/lstm_mx.hip, dZ = dz_dec . Kz^T as its latent tiles
             ops.lstm_mx_bwd(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec, self.dzsum_dec,
                             Kz=P.rows(P.params, 'decoder_h/kernel', off), nz=L, dZ=self.dZ, lddz=L)
-        elif H == 88 and L <= 40 and os.environ.get('CLV_BWD_Z', '1') != '0':      # dZ = dz_dec . Kz^T by two more waves of the decoder's backward kernel
+        elif H == 88 and L <= 40:      # dZ = dz_dec . Kz^T by two more waves of the decoder's backward kernel
             ops.lstm_seq_bwd_z(B, T, P.p('decoder_h/recurrent_kernel'), self.dhs, self.cs_dec, self.gates_dec,
                                self.dzsum_dec, P.rows(P.params, 'decoder_h/kernel', off), L, self.dZ, L,
                                gate_act=self.gate_act)

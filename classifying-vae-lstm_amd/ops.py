@@ -69,7 +69,7 @@ class ReduceQueue:
         """Run the pending reductions in one launch.  means: up to five (tensor, n, stride) terms whose means go to
         out[k] from extra blocks of the same launch (a step's loss terms: no launch of their own).  skinny: up to two
         dict(A, lda, rows, B, ldb, N, K, C, ldc, bias_row) few-row products A[:, :rows]^T B riding along as well."""
-        if means or skinny:
+        if means or skinny or self.n:
             means = means or []
             k = len(means)
             xs = (C.c_void_p * max(k, 1))(*[_ptr(t) for t, _, _ in means])
@@ -80,10 +80,9 @@ class ReduceQueue:
             for i, p in enumerate(skinny):
                 riders[i] = _lib.SkinnyProduct(_ptr(p['A']), p['lda'], p['rows'], _ptr(p['B']), p['ldb'], p['N'], p['K'],
                                                _ptr(p['C']), p['ldc'], _ptr(p.get('bias_row')))
-            check(_lib.lib().clv_splitk_reduce_multi_ex(self.jobs, self.n, xs, ns, st, k, _ptr(out), riders, len(skinny),
-                                                        _stream()), "clv_splitk_reduce_multi_ex")
-        elif self.n:
-            check(_lib.lib().clv_splitk_reduce_multi(self.jobs, self.n, _stream()), "clv_splitk_reduce_multi")
+            check(_lib.lib().clv_splitk_reduce_multi(self.jobs, self.n, xs if k else None, ns if k else None, st if k else None, k,
+                                                     _ptr(out) if k else None, riders if skinny else None, len(skinny), _stream()),
+                  "clv_splitk_reduce_multi")
         self.n = 0
 
 
@@ -145,12 +144,12 @@ def lstm_wgrad(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dK
     dKx = X^T dz, dU = H'^T dz (H' = hs shifted by one step, zero at window starts: period T), dKz = Z^T dz.
     split_scale: that many times as many, shorter row ranges (2 under the data-parallel step: see include/clvae.h)."""
     L = _lib.lib()
-    need = L.clv_lstm_wgrad_workspace_bytes_ex(K, N, nx, nh, nz, int(split_scale))
+    need = L.clv_lstm_wgrad_workspace_bytes(K, N, nx, nh, nz, int(split_scale))
     buf = defer.scratch(need) if defer is not None else ws.ensure(need)
     job = defer.next_job() if defer is not None else None
-    check(L.clv_lstm_wgrad_ex(K, N, _ptr(X), ldx, nx, _frames_mode(X, x_exact_bf16), _ptr(H), ldh, nh, 1, T,
+    check(L.clv_lstm_wgrad(K, N, _ptr(X), ldx, nx, _frames_mode(X, x_exact_bf16), _ptr(H), ldh, nh, 1, T,
                               _ptr(Z), ldz, nz, _ptr(dz), N, _ptr(dKx), N, _ptr(dU), N, _ptr(dKz), N, float(beta),
-                              int(split_scale), _ptr(buf), buf.numel(), job, _stream()), "clv_lstm_wgrad_ex")
+                              int(split_scale), _ptr(buf), buf.numel(), job, _stream()), "clv_lstm_wgrad")
 
 
 def _wgrad_problem(K, N, X, ldx, nx, x_exact_bf16, H, ldh, nh, T, Z, ldz, nz, dz, dKx, dU, dKz, beta=0.0):
@@ -281,28 +280,6 @@ def lstm_seq_bwd_z(B, T, U, dhs, cs, gates_inout, dzsum, Kz, nz, dZ, lddz, c0=No
                                         _ptr(dzsum), _ptr(Kz), nz, _ptr(dZ), lddz, _stream()), "clv_lstm_seq_bwd_z")
 
 
-def lstm_seq_fwd_z_supported(B, nz, H=88):
-    return bool(_lib.lib().clv_lstm_seq_fwd_z_supported(B, H, nz))
-
-
-def lstm_seq_fwd_z(B, T, xproj, rowbias, U, zin, ldz, nz, Kz, hs, cs, gates, hT=None, cT=None, gate_act=0, H=88):
-    """clv_lstm_seq_fwd + z_t . Kz inside the kernel (large batches, csrc/lstm_mfma.hip)."""
-    check(_lib.lib().clv_lstm_seq_fwd_z(B, T, H, gate_act, _ptr(xproj), _ptr(rowbias), _ptr(U), _ptr(zin), ldz, nz,
-                                        _ptr(Kz), _ptr(hs), _ptr(cs), _ptr(gates), _ptr(hT), _ptr(cT), _stream()),
-          "clv_lstm_seq_fwd_z")
-
-
-def lstm_fused_input_fits(B, nx):
-    return nx <= 128 and _lib.lib().clv_lstm_seq_fwd_x_lds_bytes(B, nx) <= 156 * 1024
-
-
-def lstm_seq_fwd_x(B, T, xin, ldx, nx, Kin, rowbias, U, hs, cs, gates, h0=None, c0=None, hT=None, cT=None, gate_act=0,
-                   H=88):
-    check(_lib.lib().clv_lstm_seq_fwd_x(B, T, H, gate_act, _ptr(xin), ldx, nx, _ptr(Kin), _ptr(rowbias), _ptr(U),
-                                        _ptr(h0), _ptr(c0), _ptr(hs), _ptr(cs), _ptr(gates), _ptr(hT), _ptr(cT),
-                                        _stream()), "clv_lstm_seq_fwd_x")
-
-
 def lstm_seq_bwd(B, T, U, dhs, cs, gates_inout, dzsum, c0=None, gate_act=0, H=88):
     check(_lib.lib().clv_lstm_seq_bwd(B, T, H, gate_act, _ptr(U), _ptr(dhs), _ptr(cs), _ptr(c0), _ptr(gates_inout),
                                       _ptr(dzsum), _stream()), "clv_lstm_seq_bwd")
@@ -356,7 +333,7 @@ def sparse_outer(Bn, nx, N, X, ldx, G, ldg, out, ldo=None, colsum=None, gdot=Non
     """out[j,:N] = sum_b X[b,j] G[b,:] (kernel gradient of a Dense layer with sparse inputs); colsum[N] = sum_b G[b,:].
     gdot = (Hact, ldh, hbias, out[N]): also sum_b (Hact - hbias)[b,c] G[b,c] = sum_j K[j,c] dK[j,c] (see adam_wn_step_ex)."""
     h, ldh, hb, go = gdot if gdot is not None else (None, 0, None, None)
-    check(_lib.lib().clv_sparse_outer_ex(Bn, nx, N, _ptr(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
+    check(_lib.lib().clv_sparse_outer(Bn, nx, N, _ptr(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
                                          _ptr(colsum), _ptr(h), int(ldh), _ptr(hb), _ptr(go), _stream()), "clv_sparse_outer")
 
 
@@ -457,12 +434,12 @@ def lstm_pair_bwd(B, T, L, kl_scale, pack, Wz, dhs_dec, aux_dec, aux_enc, gates_
                                    float(label['w_kl_weight']), float(label['inv_b']), _ptr(label['dwargs']),
                                    _ptr(label['dhW']), _ptr(lg[0]) if lg else None, _ptr(lg[1]) if lg else None,
                                    lbuf_ptr, need_l, ljob)
-    check(Lb.clv_lstm_pair_bwd_ex(B, T, H, L, gate_act, float(kl_scale), _ptr(pack), _ptr(Wz),
+    check(Lb.clv_lstm_pair_bwd(B, T, H, L, gate_act, float(kl_scale), _ptr(pack), _ptr(Wz),
                                   _ptr(dhs_dec), _ptr(aux_dec), _ptr(aux_enc), _ptr(gates_dec), _ptr(gates_enc),
                                   _ptr(dzsum_dec), _ptr(dzsum_enc), _ptr(zargs), _ptr(eps), _ptr(dzargs),
                                   _ptr(hs), _ptr(dWz), _ptr(dbz), _ptr(buf), nbytes, job,
                                   C.byref(rider) if rider is not None else None, _stream()),
-          "clv_lstm_pair_bwd_ex")
+          "clv_lstm_pair_bwd")
 
 
 def label_fwd(B, Cn, mean, logvar, ld_in, eps, onehot, prior, w, rowloss):
@@ -538,14 +515,11 @@ def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, oneh
     tail = (_ptr(bh), _ptr(hW_out), _ptr(Ka), _ptr(ba), _ptr(eps), _ptr(onehot), float(prior), _ptr(Kenc_w), _ptr(benc),
             _ptr(Kdec_w), _ptr(bdec), _ptr(wargs), _ptr(W), _ptr(rowloss), _ptr(rb_enc), _ptr(rb_dec), _noise_ref(noise),
             C.byref(ps) if ps is not None else None, _stream())
-    if stage is not None:      # a label_stage(): the launch assembles the mini-batch rows itself (X, history frames, labels)
-        t = tail[:5] + tail[6:]           # (no `onehot`: the labels come from stage.w_src)
-        check(_lib.lib().clv_vrnn_label_fwd_x_staged(B, D, Cn, G4, C.byref(stage), ldx, nx, _ptr(Kh), *t),
-              "clv_vrnn_label_fwd_x_staged")
-    elif parts is not None:
+    if parts is not None and stage is None:
         check(_lib.lib().clv_vrnn_label_fwd_parts(B, D, Cn, G4, _ptr(parts[0]), int(parts[1]), *tail), "clv_vrnn_label_fwd_parts")
-    else:
-        check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), *tail), "clv_vrnn_label_fwd_x")
+    else:      # stage = a label_stage(): the launch assembles the mini-batch rows itself (X, history frames, labels)
+        check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), C.byref(stage) if stage is not None else None,
+                                              *tail), "clv_vrnn_label_fwd_x")
 
 
 def dense_window_fwd_bf16_supported(Bn, nx, N, ldx, ldk):
@@ -574,11 +548,11 @@ def vrnn_label_bwd(B, D, Cn, G4, dzsum_enc, dzsum_dec, Kenc_w, Kdec_w, wargs, ep
         buf = defer.scratch(need) if defer is not None else ws.ensure(need)
         nbytes = buf.numel()
         job = defer.next_job() if defer is not None else None
-    check(Lb.clv_vrnn_label_bwd_ex(B, D, Cn, G4, _ptr(dzsum_enc), _ptr(dzsum_dec), _ptr(Kenc_w), _ptr(Kdec_w),
+    check(Lb.clv_vrnn_label_bwd(B, D, Cn, G4, _ptr(dzsum_enc), _ptr(dzsum_dec), _ptr(Kenc_w), _ptr(Kdec_w),
                                    _ptr(wargs), _ptr(eps), _ptr(onehot), _ptr(W), _ptr(hW), _ptr(Ka),
                                    float(prior), float(class_weight), float(w_kl_weight), float(inv_b),
                                    _ptr(dwargs), _ptr(dhW), _ptr(dKa), _ptr(dba), _ptr(buf), nbytes, job, _stream()),
-          "clv_vrnn_label_bwd_ex")
+          "clv_vrnn_label_bwd")
 
 
 def gauss_fwd(R, Ld, zargs, eps, z, ldz, rowkl):
@@ -636,18 +610,11 @@ def gather_rows_multi(rows, idx, segs, row0=0, notes=None, cursor=None):
     st = I(*[int(e[0]) for e in ext])
     of = I(*[int(e[1]) for e in ext])
     tb = P(*[(e[2].data_ptr() if e[2] is not None else None) for e in ext])
-    if cursor is not None:      # (step_dev int32 tensor, step0, period, stride, offset): the batch is chosen on the device
-        nt = P(*[(t.data_ptr() if t is not None else None) for t in (notes or [None] * n)])
-        cur = _lib.BatchCursor(cursor[0].data_ptr(), int(cursor[1]), int(cursor[2]), int(cursor[3]), int(cursor[4]))
-        check(_lib.lib().clv_gather_rows_multi_cursor(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, nt,
-                                                      C.byref(cur), _stream()), "clv_gather_rows_multi_cursor")
-        return
-    if notes is not None and any(t is not None for t in notes):
-        nt = P(*[(t.data_ptr() if t is not None else None) for t in notes])
-        check(_lib.lib().clv_gather_rows_multi_notes(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, nt,
-                                                     _stream()), "clv_gather_rows_multi_notes")
-        return
-    check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, _stream()),
+    nt = P(*[(t.data_ptr() if t is not None else None) for t in (notes or [None] * n)])
+    cur = None      # (step_dev int32 tensor, step0, period, stride, offset): the batch is chosen on the device
+    if cursor is not None:
+        cur = C.byref(_lib.BatchCursor(cursor[0].data_ptr(), int(cursor[1]), int(cursor[2]), int(cursor[3]), int(cursor[4])))
+    check(_lib.lib().clv_gather_rows_multi(rows, _ptr(idx), int(row0), n, src, u8, out, re, ch, ld, st, of, tb, nt, cur, _stream()),
           "clv_gather_rows_multi")
 
 

@@ -94,22 +94,14 @@ class TrainStep:
         # all-reduce, so it is no longer assumed: tune_dp_schedule() times both on the hardware at hand and keeps the
         # faster (bench.py and Model.fit call it before their first step).  Until then: the coarse grid.
         self.dp_trials = None
-        # One graph for the whole data-parallel step, collectives included, when RCCL can be captured (tried once, at the
+        # One graph for the whole data-parallel step, collectives included, when RCCL lets itself be captured (tried once, at the
         # first capture; `capture_note` says what happened); else two graphs + plain launches around eager collectives.
-        # OPT-IN (CLV_CAPTURE_COLLECTIVES=1): on the one-rank RCCL group a one-GPU box can build, the capture works or fails
-        # cleanly (tests/test_gpu_api.py records which); nobody has run it across GPUs, and a capture that wedges RCCL on a
-        # real node would cost the whole run, so the default stays the split schedule.
-        self.capture_collectives = os.environ.get('CLV_CAPTURE_COLLECTIVES', '0') == '1'
+        # DEFAULT since round 6 (CLV_CAPTURE_COLLECTIVES=0 keeps the split schedule): on the MI355X box's RCCL 2.26 the capture
+        # works (one-rank group, the only group a one-GPU box can build) and the captured step takes 0.385 ms against 0.407 for
+        # the split schedule around the same two real RCCL calls (0.353: the single-GPU step; profiles/r06_dp_schedule_one_gpu.txt).
+        # A capture that raises falls back to the split schedule and says so; nobody has run either across GPUs yet.
+        self.capture_collectives = os.environ.get('CLV_CAPTURE_COLLECTIVES', '1') != '0'
         self.capture_note = None
-        # CLV_OVERLAP_UPDATE=1 (measurement option, single GPU): the optimizer step of the hW kernel (87 % of the parameters;
-        # a chain of five small, latency-bound launches) on a side stream NEXT TO the weight-gradient products of the
-        # backward pass's late part -- its gradient is final before they start and nothing they read is touched -- as a
-        # fork / join inside the step's one graph.  Measured on MI355X (three alternating pairs, 200 steps): 0.4346 /
-        # 0.4385 / 0.4321 ms with the fork against 0.4299 / 0.4274 / 0.4273 serial: the branches do not overlap to any
-        # gain (the same finding as round 1's two-stream backward), so the default is the serial order.
-        self.overlap_update = (self.ar is None and self.is_vrnn and len(self.tail_names) == 1
-                               and optimizer == 'adam-wn' and os.environ.get('CLV_OVERLAP_UPDATE', '0') == '1')
-        self._upd_stream = torch.cuda.Stream(device=d) if self.overlap_update else None
         self._graphs = None
         self._warm = False
         self._bound = None          # bind_batches(): the mini-batch assembly as the first node of the captured step
@@ -367,18 +359,8 @@ class TrainStep:
     def _single(self):
         """The whole step on one GPU (eager or under capture)."""
         self._main()
-        if not self.overlap_update:
-            self._tail()
-            self._update()
-            self._accumulate()
-            return
-        cur = torch.cuda.current_stream()
-        self._upd_stream.wait_stream(cur)
-        with torch.cuda.stream(self._upd_stream):
-            self._update_tail()
         self._tail()
-        cur.wait_stream(self._upd_stream)
-        self._update_rest()
+        self._update()
         self._accumulate()
 
     def _eager(self):
@@ -506,7 +488,7 @@ class TrainStep:
         if not (self.capture_collectives and rccl):
             if self.capture_note is None:
                 self.capture_note = "not tried: " + ("the collectives of this process are not RCCL calls on device buffers"
-                                                     if not rccl else "off by default (CLV_CAPTURE_COLLECTIVES=1 tries it)")
+                                                     if not rccl else "switched off (CLV_CAPTURE_COLLECTIVES=0)")
             return False
         if self.capture_note is not None and not self.capture_note.startswith('captured'):
             return False                     # failed before: do not try again

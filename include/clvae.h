@@ -62,13 +62,33 @@ typedef struct clv_noise_draw {
   const int32_t* step_dev;
 } clv_noise_draw;
 
-/* Which mini-batch a staging launch assembles, chosen by a DEVICE step counter (clv_gather_rows_multi_cursor,
- * clv_vrnn_label_fwd_x_staged): batch j = (*step_dev - step0) mod period, rows idx[j * stride + offset + r]. */
+/* Which mini-batch a staging launch assembles, chosen by a DEVICE step counter (clv_gather_rows_multi,
+ * clv_vrnn_label_fwd_x): batch j = (*step_dev - step0) mod period, rows idx[j * stride + offset + r]. */
 typedef struct clv_batch_cursor {
   const int32_t* step_dev;
   int32_t step0, period;
   int64_t stride, offset;
 } clv_batch_cursor;
+
+/* clv_vrnn_label_fwd_x(stage != NULL): the step's MINI-BATCH ASSEMBLY inside the launch (cl_vae/train.py:66-71, the host-side slicing of
+ * Model.fit; what clv_gather_rows_multi does as a launch of its own): the workgroup of batch row b resolves its source
+ * row sr = idx[base + b] (idx NULL: row0 + base + b; base from the batch cursor), converts the row's byte frames into the float
+ * rows every later launch of the step reads --
+ *   X[b, :nx]                         = cur  + (cur_table  ? cur_table[sr]  : sr) * cur_stride  + cur_offset   (bytes)
+ *   Xh + (b * nx / hist_chunk + p) * hist_ld, hist_chunk floats per frame p
+ *                                     = hist + (hist_table ? hist_table[sr] : sr) * hist_stride + hist_offset  (hist NULL: none)
+ *   w_out[b, :C] = w_src[sr, :C]      (both NULL: none; the label path reads w_src[sr] either way)
+ * -- and scans the bytes itself.  nx, hist_chunk, hist_ld, the strides and offsets are multiples of 4; stores 4-byte, X / Xh
+ * 16-byte aligned; X and onehot of the call are then not read (the labels are w_src).  The assembly then costs no launch
+ * (configuration 3: 8.8 us). */
+typedef struct clv_label_stage {
+  const uint8_t* cur; const uint8_t* hist;
+  int64_t cur_stride, cur_offset, hist_stride, hist_offset, row0;
+  const int64_t* cur_table; const int64_t* hist_table; const int64_t* idx;
+  clv_batch_cursor cursor;                 /* step_dev NULL: no cursor */
+  float* X; float* Xh; int32_t hist_chunk; int64_t hist_ld;
+  const float* w_src; float* w_out;
+} clv_label_stage;
 
 /* ABI version = CLV_ABI_VERSION of the header the library was built from.  It changes whenever an existing entry point
  * changes its argument list or the size / meaning of a buffer (a caller built against an older header would still resolve
@@ -76,11 +96,17 @@ typedef struct clv_batch_cursor {
  *   100  rounds 1-2
  *   300  round 3: clv_lstm_pair_fwd / _bwd / clv_vrnn_label_fwd_x took new trailing pointers; the pair kernels' aux_* buffers
  *        are [B*T, 2, H] (kcarry, kc), no longer [B*T, H] cell states
- *   400  round 4: + clv_lstm_mx_*, clv_gather_rows_multi_cursor, clv_lstm_wgrad_pair, clv_dense_outer_bf16,
- *        clv_dense_window_fwd_bf16, clv_vrnn_label_fwd_parts, clv_vrnn_label_fwd_x_staged, clv_vae_fused_step_staged (additions only)
+ *   400  round 4: additions only (the large-batch sequence kernels, the batch cursor, the paired kernel-gradient launch, the
+ *        dense bf16 products of the hW layer, mini-batch assembly inside the label / cl_vae launches)
  *   500  round 5: the coef / aux buffers between clv_lstm_mx_fwd and clv_lstm_mx_bwd are unit-major records ([B*T,H,4] and
- *        [B*T,H,2]; same sizes); clv_lstm_seq_fwd / _bwd take any H <= 1024; + clv_dropout_rows */
-#define CLV_ABI_VERSION 500
+ *        [B*T,H,2]; same sizes); clv_lstm_seq_fwd / _bwd take any H <= 1024; + clv_dropout_rows
+ *   600  round 6: ONE entry point per operation -- the *_ex / *_staged / *_means / *_notes / *_cursor variants took over the base
+ *        names (their argument lists) and the thin wrappers are gone; frames may be passed as BYTES (x_u8 / y_u8 /
+ *        CLV_FRAMES_U8 of lstm_mx_fwd, lstm_wgrad, out_head_train, dense_window_fwd_bf16, dense_outer_bf16; src_u8 == 2 of the
+ *        gather); clv_latent_head_fwd draws its own eps (noise); removed: the 4x4x1 f32-MFMA sequence forward
+ *        (lstm_seq_fwd_z) and the in-kernel input gather of the single-LSTM forward (lstm_seq_fwd_x), which no shipped path
+ *        launched */
+#define CLV_ABI_VERSION 600
 int clv_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product must fail loudly) */
 int clv_device_count(void);
@@ -146,12 +172,9 @@ int clv_gemm_f32_deferred(int transa, int transb, int M, int N, int K, float alp
 int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int nprob, int N, int K,
                                  const float* B, int ldb, float beta,
                                  int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
-int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, void* stream);
 /* The same launch with up to five strided means computed by extra blocks (means_out[i] = mean of the n[i] elements
  * x[i][k * stride[i]]): a training step takes its loss terms here instead of in a clv_loss_sums launch of its own.
  * x / n / stride are host arrays of n_terms entries (device pointers in x). */
-int clv_splitk_reduce_multi_means(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
-                                  const int* stride, int n_terms, float* means_out, void* stream);
 /* ... and with up to two few-row products riding in the launch as well: C[r, :N] = sum_k A[k, r] B[k, :N] for r < rows
  * (rows + (bias_row != NULL) <= 16), bias_row[:N] = column sums of B -- the label rows and the bias of an LSTM
  * input-kernel gradient over K = batch rows of sum_t dz; both products must have the same N. */
@@ -161,7 +184,7 @@ typedef struct clv_skinny_product {
   float* C; int ldc;
   float* bias_row;                    /* may be NULL */
 } clv_skinny_product;
-int clv_splitk_reduce_multi_ex(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
+int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
                                const int* stride, int n_terms, float* means_out,
                                const clv_skinny_product* riders, int n_riders, void* stream);
 
@@ -186,23 +209,17 @@ int clv_splitk_reduce_multi_ex(const clv_reduce_job* jobs, int njobs, const floa
 #define CLV_FRAMES_F32_EXACT 1   /* float rows whose values are exactly bf16 numbers */
 #define CLV_FRAMES_U8        2   /* uint8 rows */
 int clv_lstm_wgrad_supported(int N, int nx, int nh, int nz, int x_exact_bf16);
-size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz);
 /* split_scale (1..8): that many times as many, proportionally shorter row ranges (and slabs).  1 = one workgroup per CU,
  * the fastest grid on an idle GPU; 2 is what the data-parallel step uses: the gradient all-reduce's kernel holds a few
  * CUs while these products run, and a grid of exactly one workgroup per CU would then need a whole second round. */
-size_t clv_lstm_wgrad_workspace_bytes_ex(int K, int N, int nx, int nh, int nz, int split_scale);
-int clv_lstm_wgrad_ex(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
+size_t clv_lstm_wgrad_workspace_bytes(int K, int N, int nx, int nh, int nz, int split_scale);
+int clv_lstm_wgrad(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
                       const float* H, int ldh, int nh, int h_shift, int h_zero_period,
                       const float* Z, int ldz, int nz, const float* dz, int lddz,
                       float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
                       int split_scale, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
-int clv_lstm_wgrad(int K, int N, const void* X, int ldx, int nx, int x_exact_bf16,
-                   const float* H, int ldh, int nh, int h_shift, int h_zero_period,
-                   const float* Z, int ldz, int nz, const float* dz, int lddz,
-                   float* dKx, int ld_kx, float* dU, int ld_u, float* dKz, int ld_kz, float beta,
-                   void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
 /* Two such products in ONE launch (the encoder's and the decoder's of a cl_vrnn step, cl_vrnn/model.py:196-199 and
- * 225-228, whose dz both exist once the backward pass is through): the arguments of clv_lstm_wgrad_ex per problem, each
+ * 225-228, whose dz both exist once the backward pass is through): the arguments of clv_lstm_wgrad per problem, each
  * with its own slab workspace (>= clv_lstm_wgrad_pair_workspace_bytes: row ranges are twice as long as in the single
  * launch, so there are half as many slabs) and its own reduction job (NULL: reduced at once).  The two problems must have
  * the same K, N and x_exact_bf16 and take the same form of the kernel (clv_lstm_wgrad_pair_supported). */
@@ -247,11 +264,6 @@ int clv_lstm_seq_fwd(int B, int T, int H, int gate_act,
                      const float* h0, const float* c0,
                      float* hs, float* cs, float* gates, float* hT, float* cT,
                      void* stream);
-/* Same recurrence with the input projection fused in: z_t = sum_k xin[b,t,k] * Kin[k,:] + rowbias[b,:] + h.U.
- * Kin [nx,4H] (the kernel rows of the per-step inputs) stays in LDS for the whole sequence and only the
- * NONZERO inputs of a frame are visited (a piano-roll frame has ~4 of 88 notes on; any float input is
- * handled exactly, cost grows with its nonzeros), so no [B,T,4H] projection is ever written to HBM.
- * nx <= 128 and clv_lstm_seq_fwd_x_lds_bytes(B, nx) <= 156 KB (else CLV_EINVAL: use the xproj form). */
 /* clv_lstm_seq_bwd + dZ_t = dz_t . Kz^T (Kz [nz,4H]: the z rows of decoder_h/kernel; dZ: B*T rows of stride lddz;
  * nz <= 40) inside the same launch: two more waves whose "units" are latents.  The decoder's backward pass without the
  * [B*T,4H] x [4H,nz] product as a launch of its own and without reading dz a second time
@@ -260,20 +272,6 @@ int clv_lstm_seq_bwd_z(int B, int T, int H, int gate_act,
                        const float* U, const float* dhs, const float* cs, const float* c0,
                        float* gates_inout_dz, float* dzsum, const float* Kz, int nz, float* dZ, int lddz, void* stream);
 
-/* Large batches (clv_lstm_seq_fwd_z_supported: H == 88, 1 <= nz <= 32 and a batch the MFMA sequence kernel is used
- * for, >= 768 rows): the decoder's forward with the latent part of its input projection inside the kernel --
- * z_t . Kz (z_t: B*T rows of stride ldz, nz columns; Kz [nz,4H] = the z rows of decoder_h/kernel,
- * cl_vrnn/model.py:218-228) joins the recurrent product as nz/4 more k-steps of the 4x4x1 MFMA; xproj then only
- * carries x_{t-1} . K_x (the sparse projection).  Zero initial state, gates/cs required (a training forward). */
-int clv_lstm_seq_fwd_z_supported(int B, int H, int nz);
-int clv_lstm_seq_fwd_z(int B, int T, int H, int gate_act, const float* xproj, const float* rowbias,
-                       const float* U, const float* zin, int ldz, int nz, const float* Kz,
-                       float* hs, float* cs, float* gates, float* hT, float* cT, void* stream);
-size_t clv_lstm_seq_fwd_x_lds_bytes(int B, int nx);
-int clv_lstm_seq_fwd_x(int B, int T, int H, int gate_act,
-                       const float* xin, int ldx, int nx, const float* Kin,
-                       const float* rowbias, const float* U, const float* h0, const float* c0,
-                       float* hs, float* cs, float* gates, float* hT, float* cT, void* stream);
 int clv_lstm_seq_bwd(int B, int T, int H, int gate_act,
                      const float* U, const float* dhs, const float* cs, const float* c0,
                      float* gates_inout_dz, float* dzsum, void* stream);
@@ -357,19 +355,11 @@ int clv_lstm_pair_fwd(int B, int T, int H, int L, int gate_act,
                       const unsigned char* notes_enc, const float* Kx_enc,
                       const unsigned char* notes_dec, const float* Kx_dec,
                       const clv_noise_draw* noise, void* stream);
-int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
-                      const float* pack, const float* Wz,
-                      const float* dhs_dec, const float* aux_dec, const float* aux_enc,
-                      float* gates_dec_inout_dz, float* gates_enc_inout_dz,
-                      float* dzsum_dec, float* dzsum_enc,
-                      const float* zargs, const float* eps, float* dzargs,
-                      const float* hs_enc, float* dWz, float* dbz, void* ws, size_t ws_bytes, clv_reduce_job* job,
-                      void* stream);
 size_t clv_lstm_pair_bwd_workspace_bytes(int B, int H, int L);
-/* ... with the label path's backward (clv_vrnn_label_bwd_ex: same arithmetic, same outputs) as the epilogue of every
+/* ... with the label path's backward (clv_vrnn_label_bwd: same arithmetic, same outputs) as the epilogue of every
  * workgroup: row b's sum_t dz of both LSTMs is what the label backward of row b reads, so it needs no launch of its own
  * (cl_vrnn/model.py:174-191, 244-252 under K.gradients).  label == NULL: clv_lstm_pair_bwd.  dKa / dba / ws / job as in
- * clv_vrnn_label_bwd_ex (dKa == NULL: no layer gradient). */
+ * clv_vrnn_label_bwd (dKa == NULL: no layer gradient). */
 typedef struct clv_label_bwd_rider {
   int D, C;
   const float *Kenc_w, *Kdec_w;         /* [C,352] the kernel rows that multiply W */
@@ -380,7 +370,7 @@ typedef struct clv_label_bwd_rider {
   void* ws; size_t ws_bytes;
   clv_reduce_job* job;
 } clv_label_bwd_rider;
-int clv_lstm_pair_bwd_ex(int B, int T, int H, int L, int gate_act, float kl_scale,
+int clv_lstm_pair_bwd(int B, int T, int H, int L, int gate_act, float kl_scale,
                          const float* pack, const float* Wz,
                          const float* dhs_dec, const float* aux_dec, const float* aux_enc,
                          float* gates_dec_inout_dz, float* gates_enc_inout_dz,
@@ -454,16 +444,8 @@ int clv_label_bwd(int B, int C, const float* mean, const float* logvar, int ld_i
  * scored against: NULL or x for the auto-encoder, the next frame under --predict_next (cl_vae/train.py:15,66). */
 int clv_vae_fused_supported(int D, int H, int Hc, int C, int L);
 size_t clv_vae_fused_workspace_bytes(int B, int D, int H, int Hc, int C, int L, int use_x_prev);
-int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
-                       const float* x, const float* xp, const float* target, const float* onehot,
-                       const float* eps_w, const float* eps_z,
-                       const float* params, const int64_t* host_offsets12, long n_params,
-                       float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
-                       int need_grads, float* grads, void* ws, size_t ws_bytes,
-                       float* logits, float* w_out, float* wargs_out, float* zargs_out,
-                       float* rownll, float* rowkl, float* rowloss, void* stream);
 
-/* The same step with the three small launches around it folded in (a cl_vae training step is launch-bound):
+/* opts (may be NULL): the three small launches around the step folded in (a cl_vae training step is launch-bound):
  *   draw != 0        the kernel draws eps_w / eps_z itself -- the values clv_philox_normal2(eps_w, B*(C-1), noise_seed,
  *                    step, step_dev, stream_w, first_w, eps_z, B*L, ..., stream_z, first_z) would have written -- and stores
  *                    them into eps_w / eps_z (which are outputs then);
@@ -475,7 +457,7 @@ int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev
  *                    fp32 on the bf16 matrix cores (BASELINE configuration 2: "bf16 ... encoder/decoder MFMA kernels
  *                    only"); sampling, losses and the optimizer stay fp32.  Measured against the fp64 oracle in
  *                    tests/test_gpu_models.py::test_cl_vae_bf16_step_tolerance.
- * opts == NULL is clv_vae_fused_step. */
+ * opts == NULL: eps is read, no loss means, no counter bump, fp32 products. */
 typedef struct clv_vae_step_opts {
   int draw;
   uint32_t stream_w, stream_z, step;
@@ -485,14 +467,6 @@ typedef struct clv_vae_step_opts {
   int32_t* bump_iterations;
   int bf16;
 } clv_vae_step_opts;
-int clv_vae_fused_step_ex(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
-                          const float* x, const float* xp, const float* target, const float* onehot,
-                          float* eps_w, float* eps_z,
-                          const float* params, const int64_t* host_offsets12, long n_params,
-                          float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
-                          int need_grads, float* grads, void* ws, size_t ws_bytes,
-                          float* logits, float* w_out, float* wargs_out, float* zargs_out,
-                          float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts, void* stream);
 
 /* The whole cl_vrnn label path of a batch row in one launch (one workgroup per row):
  * fwd: Wargs = hW.K_a + b_a; W = logistic-normal sample; (kl_w, w_rec, hit) -> rowloss[B,3];
@@ -509,6 +483,7 @@ int clv_vrnn_label_fwd(int B, int D, int C, int G4, const float* hW, const float
  * the nonzero inputs of the row (cl_vrnn/model.py:174-176; X = the flattened window, ~4 % notes), written to hW_out
  * [B,D] for the backward pass, then the label path as above.  D even. */
 int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
+                         const clv_label_stage* stage,      /* NULL, or the mini-batch assembly inside the launch: clv_label_stage */
                          const float* bh, float* hW_out, const float* Ka, const float* ba,
                          float* eps, const float* onehot, float prior_logvar,
                          const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
@@ -534,51 +509,24 @@ int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float* part, int
                              const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                              float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
                              const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
-/* clv_vrnn_label_fwd_x with the step's MINI-BATCH ASSEMBLY inside (cl_vae/train.py:66-71, the host-side slicing of
- * Model.fit; what clv_gather_rows_multi_cursor does as a launch of its own): the workgroup of batch row b resolves its source
- * row sr = idx[base + b] (idx NULL: row0 + base + b; base from the batch cursor), converts the row's byte frames into the float
- * rows every later launch of the step reads --
- *   X[b, :nx]                         = cur  + (cur_table  ? cur_table[sr]  : sr) * cur_stride  + cur_offset   (bytes)
- *   Xh + (b * nx / hist_chunk + p) * hist_ld, hist_chunk floats per frame p
- *                                     = hist + (hist_table ? hist_table[sr] : sr) * hist_stride + hist_offset  (hist NULL: none)
- *   w_out[b, :C] = w_src[sr, :C]      (both NULL: none; the label path reads w_src[sr] either way)
- * -- and scans the bytes itself.  nx, hist_chunk, hist_ld, the strides and offsets are multiples of 4; stores 4-byte, X / Xh
- * 16-byte aligned.  The assembly then costs no launch (configuration 3: 8.8 us). */
-typedef struct clv_label_stage {
-  const uint8_t* cur; const uint8_t* hist;
-  int64_t cur_stride, cur_offset, hist_stride, hist_offset, row0;
-  const int64_t* cur_table; const int64_t* hist_table; const int64_t* idx;
-  clv_batch_cursor cursor;                 /* step_dev NULL: no cursor */
-  float* X; float* Xh; int32_t hist_chunk; int64_t hist_ld;
-  const float* w_src; float* w_out;
-} clv_label_stage;
-/* clv_vae_fused_step_ex with the mini-batch assembly inside (cl_vae/train.py:66-71): every workgroup resolves its 16 batch rows
+/* stage != NULL: the mini-batch assembly inside the step (cl_vae/train.py:66-71): every workgroup resolves its 16 batch rows
  * (clv_label_stage with rows of D bytes: cur = the frames x, hist = the previous frames x_prev, w_src = the labels) and reads
- * their bytes itself; stage->X / Xh / w_out (each may be NULL) receive the rows as a gather launch would have left them.  No
- * separate target (the auto-encoder).  The cl_vae training step is then three launches: this one, the slab sum, Adam. */
-int clv_vae_fused_step_staged(int B, int D, int H, int Hc, int C, int L, int use_x_prev, const clv_label_stage* stage,
-                              float* eps_w, float* eps_z,
-                              const float* params, const int64_t* host_offsets12, long n_params,
-                              float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
-                              int need_grads, float* grads, void* ws, size_t ws_bytes,
-                              float* logits, float* w_out, float* wargs_out, float* zargs_out,
-                              float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts, void* stream);
-int clv_vrnn_label_fwd_x_staged(int B, int D, int C, int G4, const clv_label_stage* stage, int ldx, int nx, const float* Kh,
-                                const float* bh, float* hW_out, const float* Ka, const float* ba,
-                                float* eps, float prior_logvar,
-                                const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
-                                float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                                const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
-int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
-                       const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
-                       const float* onehot, const float* W, const float* hW, const float* Ka,
-                       float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
-                       float* dwargs, float* dhW, void* stream);
+ * their bytes itself -- x / xp / target / onehot are not read (no separate target: the auto-encoder); stage->X / Xh / w_out (each
+ * may be NULL) receive the rows as a gather launch would have left them.  The cl_vae training step is then three launches:
+ * this one, the slab sum, Adam. */
+int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev,
+                       const float* x, const float* xp, const float* target, const float* onehot,
+                       const clv_label_stage* stage, float* eps_w, float* eps_z,
+                       const float* params, const int64_t* host_offsets12, long n_params,
+                       float prior_logvar, float class_weight, float kl_weight, float w_kl_weight,
+                       int need_grads, float* grads, void* ws, size_t ws_bytes,
+                       float* logits, float* w_out, float* wargs_out, float* zargs_out,
+                       float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts, void* stream);
 /* ..._ex: dKa != NULL -- the Wargs layer's own gradient rides along: dKa [D,2(C-1)] = hW^T . dwargs, dba = column sums of
  * dwargs, as per-row outer products in ws (>= clv_vrnn_label_bwd_workspace_bytes) summed by the pending reduction `job`
  * (NULL: at once), like a split-K product's slabs: no GEMM launch over K = batch. */
 size_t clv_vrnn_label_bwd_workspace_bytes(int B, int D, int C);
-int clv_vrnn_label_bwd_ex(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
+int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsum_enc, const float* dzsum_dec,
                           const float* Kenc_w, const float* Kdec_w, const float* wargs, const float* eps,
                           const float* onehot, const float* W, const float* hW, const float* Ka,
                           float prior_logvar, float class_weight, float w_kl_weight, float inv_b,
@@ -668,15 +616,13 @@ int clv_sparse_proj2(int R, int N, int ldo, int nx0, const float* X0, int ldx0, 
 int clv_sparse_dense_supported(int N);
 int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, const float* K, const float* bias, int act,
                      float* out, int ldo, void* stream);
-int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
-                     float* colsum /* [N] = sum_b G[b,:], the layer's bias gradient; may be NULL */, void* stream);
 /* ..._ex: gdot != NULL also returns gdot[c] = sum_b (Hact[b,c] - hbias[c]) G[b,c], Hact [Bn,ldh] = the layer's relu output
  * and G its (relu-masked) upstream gradient: = sum_j K[j,c] dK[j,c], the weight-norm optimizer's sum g.W per column
- * without a pass over K and dK (clv_adam_wn_step_ex). */
-int clv_sparse_outer_ex(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
+ * without a pass over K and dK (clv_adam_wn_step). */
+int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
                         float* colsum, const float* Hact, int ldh, const float* hbias, float* gdot, void* stream);
 
-/* The same kernel gradient, dK[j,:N] = sum_b X[b,j] G[b,:] (+ colsum, gdot as in clv_sparse_outer_ex), DENSE on the bf16
+/* The same kernel gradient, dK[j,:N] = sum_b X[b,j] G[b,:] (+ colsum, gdot as in clv_sparse_outer), DENSE on the bf16
  * matrix cores for inputs that are exactly representable in bf16 -- the caller's promise: 0/1 piano-roll frames, any uint8
  * value.  X is then one bf16 piece, G three (an fp32 number is exactly the sum of three bf16 numbers), the piece products are
  * exact and accumulate in fp32: the products of the fp32 path in another summation order.  The kernel streams X once
@@ -711,28 +657,18 @@ int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int
  * up to the end of the row.  clv_lstm_pair_fwd gathers the LSTM input projections x_t . K_x from such lists. */
 #define CLV_NOTE_ROW 96
 #define CLV_NOTE_NONE 88
-int clv_gather_rows_multi_notes(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
-                                const void* const* src, const int32_t* src_u8, float* const* out,
-                                const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
-                                const int64_t* src_stride, const int64_t* src_offset,
-                                const int64_t* const* src_table, unsigned char* const* notes_out, void* stream);
 /* ... with a BATCH CURSOR read on the device: the launch takes batch j = (*step_dev - step0) mod period, i.e. the rows
  * i = (idx ? idx[base + r] : row0 + base + r), base = j * stride + offset, r < rows.  step_dev is the optimizer's
  * `iterations` counter (clv_adam_wn_step advances it at the end of a step), so the mini-batch assembly of
  * Model.fit (cl_vae/train.py:66-71: one contiguous slice of the shuffled index per step) becomes a node of the step's
  * hipGraph: a step is ONE graph launch, nothing is staged from the host.  cursor == NULL: clv_gather_rows_multi_notes. */
 /* (clv_batch_cursor is declared near the top of this header, next to clv_noise_draw) */
-int clv_gather_rows_multi_cursor(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
+int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                                  const void* const* src, const int32_t* src_u8, float* const* out,
                                  const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
                                  const int64_t* src_stride, const int64_t* src_offset,
                                  const int64_t* const* src_table, unsigned char* const* notes_out,
                                  const clv_batch_cursor* cursor, void* stream);
-int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
-                          const void* const* src, const int32_t* src_u8, float* const* out,
-                          const int64_t* row_elems, const int64_t* chunk, const int64_t* out_ld,
-                          const int64_t* src_stride, const int64_t* src_offset, const int64_t* const* src_table,
-                          void* stream);
 
 /* the five loss scalars of a step in one launch: out[k] = scale[k] * sum_{i<n[k]} x[k][i*stride[k]], k < 5
  * (vae, kl_z, kl_w, w_rec, acc means; fixed summation order => deterministic). */
@@ -770,14 +706,14 @@ size_t clv_adam_wn_workspace_bytes(const clv_param_desc* host_table, int n_tenso
  * counter is read but NOT advanced -- a step may be split over several calls on disjoint tensor subsets (each with its
  * own table and plan over the same flat buffers), of which only the last one advances the counter.
  * iterations_dev with step_t == CLV_STEP_ADVANCED: the counter already holds t (it was advanced by the launch that
- * produced the gradients, clv_vae_fused_step_ex's bump_iterations) and is left alone. */
+ * produced the gradients, clv_vae_fused_step's bump_iterations) and is left alone. */
 #define CLV_STEP_ADVANCED (-2)
 /* `weightnorm` selects the update rule: */
 #define CLV_OPT_ADAM     0   /* plain Keras Adam on every tensor                                                   */
 #define CLV_OPT_ADAM_WN  1   /* utils/weightnorm.py:75-143: matrices per output column as g V/||V||, biases plain   */
 #define CLV_OPT_RMSPROP  2   /* Keras RMSprop (the 'rmsprop' optimizer string, cl_vae/train.py:83): a = rho a +     */
                              /* (1 - rho) g^2, p -= lr g / (sqrt(a) + eps); rho = beta2, `v` holds a, `m` is unused  */
-/* clv_adam_wn_step_ex: `known` (may be NULL = clv_adam_wn_step) concerns the ONE tall matrix of the table (more than 144
+/* clv_adam_wn_step: `known` (may be NULL = clv_adam_wn_step) concerns the ONE tall matrix of the table (more than 144
  * rows: cl_vrnn's hW/kernel) under CLV_OPT_ADAM_WN:
  *   vnorm2 [n columns, laid out like s]: every call keeps ||V||^2 per column of the tall matrix there (the rescale leaves
  *     W = s' V', so the next step's sum V^2 is this step's ||V'||^2);
@@ -792,16 +728,11 @@ typedef struct clv_adam_known_sums {
   const float* gdot;     /* [cols] */
   float* vnorm2;
 } clv_adam_known_sums;
-int clv_adam_wn_step_ex(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
+int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
                         float* params, const float* grads, float* m, float* v,
                         float* mg, float* vg, float* s,
                         int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
                         int weightnorm, const clv_adam_known_sums* known, void* ws, size_t ws_bytes, void* stream);
-int clv_adam_wn_step(const clv_param_desc* host_table, int n_tensors, const void* plan_dev,
-                     float* params, const float* grads, float* m, float* v,
-                     float* mg, float* vg, float* s,
-                     int32_t* iterations_dev, int step_t, float lr, float beta1, float beta2, float eps,
-                     int weightnorm, void* ws, size_t ws_bytes, void* stream);
 
 /* -------------------------------------------------------------------- RNG --
  * Counter-based Philox4x32-10, key = (seed_lo, seed_hi), counter =

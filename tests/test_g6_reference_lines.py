@@ -78,7 +78,7 @@ def _t(a, dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fast", [False, True])
 def test_hip_adam_wn_matches_the_reference_lines(dev, fast):
-    """clv_adam_wn_step (five launches) and clv_adam_wn_step_ex with known column sums (two launches: the form the timed
+    """clv_adam_wn_step (five launches) and clv_adam_wn_step with known column sums (two launches: the form the timed
     step uses) against the parameters the reference's optimizer lines produced.  fp32 on the device: rtol 2e-5."""
     import torch
     from clvae_amd.engine import FlatParams

@@ -209,9 +209,9 @@ def test_lstm_seq_fwd_bwd_at_any_width(dev, monkeypatch, H, B, Tn, gate):
 
 
 @pytest.mark.parametrize("B,Tn,gate", [(1027, 7, 0), (768, 3, 1), (2050, 2, 0), (769, 1, 0)])
-def test_lstm_seq_fwd_large_batch_runs_on_the_matrix_cores(dev, B, Tn, gate):
-    """From 768 rows on, a training forward from zero state takes csrc/lstm_mfma.hip (four rows per workgroup, the
-    recurrent product on v_mfma_f32_4x4x1_16B_f32); batch sizes that are not multiples of 4 included."""
+def test_lstm_seq_fwd_at_large_batches(dev, B, Tn, gate):
+    """clv_lstm_seq_fwd at batches far beyond one row per CU (the generic chain's forward: dropout, CLV_USE_MX=0): 1, 2 or 4
+    rows per workgroup by what divides the batch."""
     from clvae_amd import ops
     H = 88
     rng = np.random.default_rng(B + Tn)
@@ -234,36 +234,6 @@ def test_lstm_seq_fwd_large_batch_runs_on_the_matrix_cores(dev, B, Tn, gate):
     for k in (0, 1, 3):
         np.testing.assert_allclose(g[:, :, k], Zr[:, :, k], atol=1e-5)
     np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=3e-6)
-
-
-@pytest.mark.parametrize("B,Tn,nz,ldz,gate", [(1027, 5, 32, 120, 0), (770, 3, 5, 9, 1), (1024, 2, 8, 8, 0), (771, 1, 1, 3, 0)])
-def test_lstm_seq_fwd_z_multiplies_the_latent_rows_in_the_kernel(dev, B, Tn, nz, ldz, gate):
-    """clv_lstm_seq_fwd_z: xproj + rowbias + z_t . Kz + h_{t-1} . U, the z product as extra k-steps of the MFMA."""
-    from clvae_amd import ops
-    H = 88
-    assert ops.lstm_seq_fwd_z_supported(B, nz)
-    rng = np.random.default_rng(B + nz)
-    U = O.orthogonal(rng, (H, 4 * H), np.float64) * 1.5
-    Kz = rng.standard_normal((nz, 4 * H)) * 0.4
-    xproj = rng.standard_normal((B, Tn, 4 * H))
-    rb = rng.standard_normal((B, 4 * H)) * 0.3
-    zbuf = rng.standard_normal((B * Tn, ldz))
-    act = 'hard_sigmoid' if gate == 0 else 'sigmoid'
-    xs = xproj + rb[:, None, :] + (f32(zbuf[:, :nz]) @ f32(Kz)).reshape(B, Tn, 4 * H)
-    hs_ref, cache = O.lstm_forward(xs, np.eye(4 * H), U, np.zeros(4 * H), gate_act=act)
-    gates = T(xproj, dev)
-    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
-    hT = torch.empty(B, H, device=dev)
-    ops.lstm_seq_fwd_z(B, Tn, gates, T(rb, dev), T(U, dev), T(zbuf, dev), ldz, nz, T(Kz, dev), hs, cs, gates, hT=hT,
-                       gate_act=gate)
-    torch.cuda.synchronize()
-    np.testing.assert_allclose(N(hs), hs_ref, atol=5e-6)
-    np.testing.assert_allclose(N(cs), cache['C'], atol=8e-6)
-    np.testing.assert_allclose(N(hT), hs_ref[:, -1], atol=5e-6)
-    g = N(gates).reshape(B, Tn, 4, H)
-    Zr = cache['Z'].reshape(B, Tn, 4, H)
-    np.testing.assert_allclose(g[:, :, 0], Zr[:, :, 0], atol=2e-5)
-    np.testing.assert_allclose(g[:, :, 2], np.tanh(Zr[:, :, 2]), atol=5e-6)
 
 
 @pytest.mark.parametrize("B,Tn,nz,gate", [(6, 9, 32, 0), (1028, 3, 32, 0), (514, 4, 5, 1), (3, 1, 40, 0)])
@@ -503,34 +473,6 @@ def test_loss_sums(dev):
     ops.loss_sums([(T(a, dev), 5000, 1), (T(b, dev), 37, 1), (cd, 29, 3), (cd[:, 1:], 29, 3), (cd[:, 2:], 29, 3)], out)
     ref = [a.astype(np.float32).mean(), b.astype(np.float32).mean()] + [c[:, j].astype(np.float32).mean() for j in range(3)]
     np.testing.assert_allclose(N(out)[:5], ref, atol=1e-5)
-
-
-@pytest.mark.parametrize("B,Tn,nx,ldx,dense", [(3, 9, 88, 88, False), (4, 6, 90, 92, False), (2, 5, 98, 100, True),
-                                                (1024, 3, 88, 88, False)])
-def test_lstm_fused_input_projection(dev, B, Tn, nx, ldx, dense):
-    """clv_lstm_seq_fwd_x (K resident in LDS, nonzero gather) == GEMM projection + clv_lstm_seq_fwd."""
-    from clvae_amd import ops
-    H = 88
-    rng = np.random.default_rng(B * 7 + nx)
-    U = O.orthogonal(rng, (H, 4 * H), np.float64)
-    K = rng.standard_normal((nx, 4 * H)) * 0.4
-    X = rng.standard_normal((B, Tn, ldx)) if dense else (rng.random((B, Tn, ldx)) < 0.06).astype(np.float64)
-    if not dense:
-        X[:, :, nx - 2:nx] = rng.standard_normal((B, Tn, 2))         # latent columns are dense floats
-    X[:, 0, :] = 0 if not dense else X[:, 0, :]                       # an all-zero frame (empty nonzero list)
-    rb = rng.standard_normal((B, 4 * H)) * 0.3
-    f = lambda a: a.astype(np.float32).astype(np.float64)
-    hs_ref, cache = O.lstm_forward(f(X[:, :, :nx]), f(K), f(U), np.zeros(4 * H), gate_act='hard_sigmoid')
-    hs_ref, cache = O.lstm_forward(f(X[:, :, :nx]) @ f(K) + f(rb)[:, None, :], np.eye(4 * H), f(U), np.zeros(4 * H))
-    assert ops.lstm_fused_input_fits(B, nx)
-    hs = torch.empty(B, Tn, H, device=dev); cs = torch.empty(B, Tn, H, device=dev)
-    gates = torch.empty(B, Tn, 4 * H, device=dev)
-    ops.lstm_seq_fwd_x(B, Tn, T(X, dev), ldx, nx, T(K, dev), T(rb, dev), T(U, dev), hs, cs, gates)
-    torch.cuda.synchronize()
-    np.testing.assert_allclose(N(hs), hs_ref, atol=1e-5)
-    np.testing.assert_allclose(N(cs), cache['C'], atol=2e-5)
-    np.testing.assert_allclose(N(gates).reshape(B, Tn, 4, H)[:, :, 0], cache['Z'].reshape(B, Tn, 4, H)[:, :, 0], atol=3e-5)
-    assert not ops.lstm_fused_input_fits(B, 120)                      # 120 x 352 floats do not fit the LDS
 
 
 @pytest.mark.parametrize("R,nx,Nn,ldx,dense", [(1, 88, 352, 88, False), (7, 88, 352, 92, False), (1000, 88, 352, 88, False),
@@ -943,7 +885,7 @@ def test_lstm_wgrad_pair_matches_fp64(dev, K, Tn, nz, exact, defer, scale):
 @pytest.mark.parametrize("K,N,R,with_jobs", [(256, 352, 5, True), (1, 352, 5, False), (300, 100, 15, False),
                                               (1000, 64, 1, True), (37, 353, 9, False)])
 def test_reduce_launch_skinny_riders(dev, K, N, R, with_jobs):
-    """clv_splitk_reduce_multi_ex: two few-row products A[:, :R]^T B (+ the column sums of B) from rider blocks of the
+    """clv_splitk_reduce_multi: two few-row products A[:, :R]^T B (+ the column sums of B) from rider blocks of the
     reduction launch -- the label rows and biases of both LSTM input-kernel gradients (cl_vrnn/model.py:194,223) --
     with and without pending reductions and loss means in the same launch, ragged N / K and one chunk and several."""
     from clvae_amd import ops

@@ -1,4 +1,4 @@
-"""Time clv_lstm_seq_fwd / _bwd at one batch size (rows per workgroup forced by CLV_LSTM_ROWS, MFMA forward by CLV_LSTM_MFMA).
+"""Time clv_lstm_seq_fwd / _bwd at one batch size (rows per workgroup forced by CLV_LSTM_ROWS).
   CLV_LSTM_ROWS=2 python tools/lstm_rows_bench.py 512 256"""
 import os
 import sys
@@ -33,5 +33,4 @@ def timeit(fn, n=6):
 gates = g.clone()
 tf = timeit(lambda: ops.lstm_seq_fwd(B, T, gates, rb, U, hs, cs, gates))
 tb = timeit(lambda: ops.lstm_seq_bwd(B, T, U, dhs, cs, gates, dzsum))
-print("B %5d T %4d rows/wg %s mfma %s: fwd %8.1f us  bwd %8.1f us" % (B, T, os.environ.get('CLV_LSTM_ROWS', 'auto'),
-                                                                   os.environ.get('CLV_LSTM_MFMA', 'auto'), tf, tb))
+print("B %5d T %4d rows/wg %s: fwd %8.1f us  bwd %8.1f us" % (B, T, os.environ.get('CLV_LSTM_ROWS', 'auto'), tf, tb))

@@ -48,10 +48,9 @@ def timeit(fn, n=10):
 
 def old_fwd(z):
     ops.sparse_proj(B * T, D, 4 * H, XZd, ld, K, gates)
-    if z:
-        ops.lstm_seq_fwd_z(B, T, gates, rb, U, XZd[:, D:], ld, L, Kz, hs, cs, gates)
-    else:
-        ops.lstm_seq_fwd(B, T, gates, rb, U, hs, cs, gates)
+    if z:      # (until round 6 the 4x4x1 f32-MFMA forward added z_t . Kz in the kernel; now: one more row gather / GEMM)
+        ops.gemm(XZd[:, D:], Kz, gates, B * T, 4 * H, L, lda=ld, beta=1.0, ws=ops.Workspace(dev))
+    ops.lstm_seq_fwd(B, T, gates, rb, U, hs, cs, gates)
 
 
 def new_fwd(z):
