@@ -58,7 +58,7 @@ class LabelStage(C.Structure):
                 ("cur_table", _p), ("hist_table", _p), ("idx", _p),
                 ("cursor", BatchCursor),
                 ("X", _p), ("Xh", _p), ("hist_chunk", C.c_int32), ("hist_ld", _i64),
-                ("w_src", _p), ("w_out", _p)]
+                ("w_src", _p), ("w_out", _p), ("X8", _p), ("Xh8", _p)]
 
 
 class WgradProblem(C.Structure):
@@ -116,9 +116,8 @@ SIGNATURES = {
     "clv_error_string": (C.c_char_p, [_i]),
     "clv_gemm_auto_split": (_i, [_i, _i, _i]),
     "clv_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
-    "clv_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p]),
-    "clv_gemm_f32_deferred": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p, _p]),
-    "clv_gemm_grouped_tn_deferred": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p, _p]),
+    "clv_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _f, _p, _i, _p, _i, _p, _i, _p, _sz, _p, _p]),
+    "clv_gemm_grouped_tn": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p, _p]),
     "clv_splitk_reduce_multi": (_i, [_p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
     "clv_lstm_wgrad_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_lstm_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -130,7 +129,6 @@ SIGNATURES = {
     "clv_gemm_grouped_tn_small2": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _p]),
     "clv_gemm_grouped_auto_split": (_i, [_p, _i, _i, _i]),
     "clv_gemm_grouped_workspace_bytes": (_sz, [_p, _i, _i, _i]),
-    "clv_gemm_grouped_tn": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _p, _sz, _p]),
     "clv_colsum_workspace_bytes": (_sz, [_i, _i]),
     "clv_colsum_f32": (_i, [_i, _i, _p, _i, _f, _p, _p, _sz, _p]),
     "clv_lstm_seq_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -148,8 +146,8 @@ SIGNATURES = {
     "clv_lstm_pair_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "clv_sparse_proj_supported": (_i, [_i, _i]),
     "clv_sparse_proj_lds_bytes": (_sz, [_i, _i]),
-    "clv_sparse_proj": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p]),
-    "clv_sparse_proj2": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p]),
+    "clv_sparse_proj": (_i, [_i, _i, _i, _p, _i, _i, _p, _p, _i, _p]),
+    "clv_sparse_proj2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p]),
     "clv_sparse_dense_supported": (_i, [_i]),
     "clv_sparse_dense": (_i, [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "clv_sparse_outer": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),

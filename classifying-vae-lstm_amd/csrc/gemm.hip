@@ -987,7 +987,7 @@ extern "C" size_t clv_gemm_workspace_bytes(int M, int N, int split_k) {
   return (size_t)split_k * M * N * sizeof(float);
 }
 
-extern "C" int clv_gemm_f32_deferred(int transa, int transb, int M, int N, int K, float alpha,
+extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
                                      const float* A, int lda, const float* B, int ldb,
                                      float beta, float* C, int ldc,
                                      const float* bias, int act, const float* aux,
@@ -1034,15 +1034,6 @@ extern "C" int clv_gemm_f32_deferred(int transa, int transb, int M, int N, int K
     else st = launch_reduce(j, s);
   }
   return st;
-}
-
-extern "C" int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
-                            const float* A, int lda, const float* B, int ldb,
-                            float beta, float* C, int ldc,
-                            const float* bias, int act, const float* aux,
-                            int split_k, void* ws, size_t ws_bytes, void* stream) {
-  return clv_gemm_f32_deferred(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, act, aux, split_k, ws,
-                               ws_bytes, nullptr, stream);
 }
 
 extern "C" int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, const float* const* x, const int* n,
@@ -1133,7 +1124,7 @@ extern "C" size_t clv_gemm_grouped_workspace_bytes(const clv_gemm_prob* probs, i
   return (size_t)split_k * m * N * sizeof(float);
 }
 
-extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int nprob, int N, int K,
+extern "C" int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N, int K,
                                             const float* B, int ldb, float beta,
                                             int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream) {
   using namespace clv;
@@ -1220,12 +1211,6 @@ extern "C" int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int npro
     else st = launch_reduce(j, s);
   }
   return st;
-}
-
-extern "C" int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N, int K,
-                                   const float* B, int ldb, float beta,
-                                   int split_k, void* ws, size_t ws_bytes, void* stream) {
-  return clv_gemm_grouped_tn_deferred(probs, nprob, N, K, B, ldb, beta, split_k, ws, ws_bytes, nullptr, stream);
 }
 
 // Output head with the loss fused into the epilogue: logits = A.B + bias (C, optional), row NLL and

@@ -177,6 +177,7 @@ struct LabelFwdXArgs {
     const int* step_dev; int step0, period; long long cur_s, cur_o;      // clv_batch_cursor
     float* X; float* Xh; int hist_chunk; long long hist_ld;    // history frame p of row b at Xh + (b * pieces + p) * hist_ld
     const float* w_src; float* w_out;
+    unsigned char* X8; unsigned char* Xh8;      // not null: the rows are copied as BYTES ([B, nx] each) instead of widened into X / Xh
   } stage;
 };
 __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax) {
@@ -211,20 +212,30 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
     oh_row = sr;
     xbytes = g.cur + (g.cur_table ? g.cur_table[sr] : sr) * g.cur_stride + g.cur_offset;
     // bytes -> floats, 4 at a time (nx and the frame length are multiples of 4; the stores are 4-byte aligned: checked by the
-    // launcher); requested before the scan, nothing below waits for the stores
-    float* xo = g.X + (size_t)b * ax.ldx;
-    for (int c = 4 * tid; c < ax.nx; c += 4 * 1024) {
-      const unsigned v = *reinterpret_cast<const unsigned*>(xbytes + c);
-      *reinterpret_cast<float4*>(xo + c) = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
-    }
-    if (g.hist) {
-      const unsigned char* hb = g.hist + (g.hist_table ? g.hist_table[sr] : sr) * g.hist_stride + g.hist_offset;
-      const int pieces = ax.nx / g.hist_chunk;
+    // launcher); requested before the scan, nothing below waits for the stores.  X8: the bytes as they are (round 6: every
+    // later launch of the step reads frames as bytes) -- a quarter of the stores
+    const unsigned char* hb = g.hist ? g.hist + (g.hist_table ? g.hist_table[sr] : sr) * g.hist_stride + g.hist_offset : nullptr;
+    if (g.X8) {
+      unsigned* xo8 = reinterpret_cast<unsigned*>(g.X8 + (size_t)b * ax.nx);
+      unsigned* ho8 = reinterpret_cast<unsigned*>(g.Xh8 + (size_t)b * ax.nx);
       for (int c = 4 * tid; c < ax.nx; c += 4 * 1024) {
-        const unsigned v = *reinterpret_cast<const unsigned*>(hb + c);
-        const int p = c / g.hist_chunk, w = c - p * g.hist_chunk;
-        *reinterpret_cast<float4*>(g.Xh + ((size_t)b * pieces + p) * g.hist_ld + w) =
-            make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+        xo8[c >> 2] = *reinterpret_cast<const unsigned*>(xbytes + c);
+        if (hb) ho8[c >> 2] = *reinterpret_cast<const unsigned*>(hb + c);
+      }
+    } else {
+      float* xo = g.X + (size_t)b * ax.ldx;
+      for (int c = 4 * tid; c < ax.nx; c += 4 * 1024) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(xbytes + c);
+        *reinterpret_cast<float4*>(xo + c) = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+      }
+      if (hb) {
+        const int pieces = ax.nx / g.hist_chunk;
+        for (int c = 4 * tid; c < ax.nx; c += 4 * 1024) {
+          const unsigned v = *reinterpret_cast<const unsigned*>(hb + c);
+          const int p = c / g.hist_chunk, w = c - p * g.hist_chunk;
+          *reinterpret_cast<float4*>(g.Xh + ((size_t)b * pieces + p) * g.hist_ld + w) =
+              make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+        }
       }
     }
     if (g.w_out && tid < a.C) g.w_out[(size_t)b * a.C + tid] = g.w_src[(size_t)sr * a.C + tid];
@@ -399,15 +410,20 @@ static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int l
                !pack->Wz || !pack->pack || ((uintptr_t)pack->pack) % 16))
     return CLV_EINVAL;
   if (B <= 0 || D <= 0 || D > 128 || D % 2 != 0 || C < 2 || C > LH_MAXC || G4 <= 0) return CLV_EINVAL;
-  if (part ? (splits <= 0 || ((uintptr_t)part) % 8 != 0) : (nx <= 0 || ldx < nx || !X || !Kh || ((uintptr_t)Kh) % 8 != 0)) return CLV_EINVAL;
+  if (part ? (splits <= 0 || ((uintptr_t)part) % 8 != 0)
+           : (nx <= 0 || ldx < nx || (!X && !(stage && stage->X8)) || !Kh || ((uintptr_t)Kh) % 8 != 0)) return CLV_EINVAL;
   if (stage) {        // the batch assembly inside the launch: byte stores, 4 bytes / 4 floats at a time
     const clv_label_stage& g = *stage;
-    if (part || !g.cur || g.X != X || nx % 4 || ldx % 4 || ((uintptr_t)g.cur) % 4 || g.cur_stride % 4 || g.cur_offset % 4 ||
-        ((uintptr_t)X) % 16)
-      return CLV_EINVAL;
-    if (g.hist && (!g.Xh || g.hist_chunk <= 0 || g.hist_chunk % 4 || nx % g.hist_chunk || g.hist_ld % 4 || g.hist_ld < g.hist_chunk ||
-                   ((uintptr_t)g.hist) % 4 || g.hist_stride % 4 || g.hist_offset % 4 || ((uintptr_t)g.Xh) % 16))
-      return CLV_EINVAL;
+    if (part || !g.cur || nx % 4 || ldx % 4 || ((uintptr_t)g.cur) % 4 || g.cur_stride % 4 || g.cur_offset % 4) return CLV_EINVAL;
+    if (g.hist && (((uintptr_t)g.hist) % 4 || g.hist_stride % 4 || g.hist_offset % 4)) return CLV_EINVAL;
+    if (g.X8) {       // the byte batch: [B, nx] rows of the current and (with hist) of the history frames
+      if (((uintptr_t)g.X8) % 4 || (g.hist && (!g.Xh8 || ((uintptr_t)g.Xh8) % 4))) return CLV_EINVAL;
+    } else {
+      if (!g.X || ((uintptr_t)g.X) % 16) return CLV_EINVAL;
+      if (g.hist && (!g.Xh || g.hist_chunk <= 0 || g.hist_chunk % 4 || nx % g.hist_chunk || g.hist_ld % 4 || g.hist_ld < g.hist_chunk ||
+                     ((uintptr_t)g.Xh) % 16))
+        return CLV_EINVAL;
+    }
     if ((g.w_out != nullptr) != (g.w_src != nullptr)) return CLV_EINVAL;
     if (g.cursor.step_dev && g.cursor.period < 1) return CLV_EINVAL;
   }
@@ -422,7 +438,7 @@ static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int l
                                    (long long)g.hist_offset, (long long)g.row0, (const long long*)g.cur_table,
                                    (const long long*)g.hist_table, (const long long*)g.idx, g.cursor.step_dev, g.cursor.step0,
                                    g.cursor.period, (long long)g.cursor.stride, (long long)g.cursor.offset, g.X, g.Xh, g.hist_chunk,
-                                   (long long)g.hist_ld, g.w_src, g.w_out};
+                                   (long long)g.hist_ld, g.w_src, g.w_out, g.X8, g.Xh8};
     if (g.w_src) a.l.onehot = g.w_src;           // the label path reads the row's labels where they come from
   }
   if (pack) a.pack = PairPackArgs{pack->L, pack->U_enc, pack->U_dec, pack->Kz, pack->Wz, reinterpret_cast<float4*>(pack->pack)};

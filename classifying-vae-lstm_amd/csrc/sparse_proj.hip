@@ -17,7 +17,7 @@ constexpr int SP_NC = 6;           // output columns per lane (N <= 384)
 
 struct SparseProjSet {
   int nx, ldx;
-  const float* X;      // [R, ldx]
+  const void* X;       // [R, ldx] float, or uint8 (XU8 kernel: ldx in bytes)
   const float* K;      // [nx, N]
   float* out;          // [R, ldo]
 };
@@ -32,13 +32,14 @@ struct SparseProjArgs {
 // (Round 3, tried: four consecutive columns per lane -- 2 ds_read_b128 per note and 2 float4 stores per frame instead of 6
 // + 6 dword accesses: 34.3 us against 32.6 at configuration 3 (HIP events), 202 against 196 at configuration 5.  The dword
 // form's 256-byte wave stores are what the write path likes.)
+template <bool XU8>
 __global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs g) {
   extern __shared__ __attribute__((aligned(16))) float Kl[];            // [nx][N]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // second projection of the launch: its workgroups start as the first one's retire, so the two tails overlap
   const bool second = (int)blockIdx.x >= g.wgs;
-  struct { int R, nx, N, ldx, ldo; const float* X; const float* K; float* out; } a;
+  struct { int R, nx, N, ldx, ldo; const void* X; const float* K; float* out; } a;
   a.R = g.R; a.N = g.N; a.ldo = g.ldo;
   a.nx = second ? g.set[1].nx : g.set[0].nx; a.ldx = second ? g.set[1].ldx : g.set[0].ldx;
   a.X = second ? g.set[1].X : g.set[0].X; a.K = second ? g.set[1].K : g.set[0].K;
@@ -65,17 +66,17 @@ __global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs g) {
   for (int c = 0; c < SP_NC; ++c) colo[c] = min(lane + 64 * c, a.N - 1);
   const int k0 = min(lane, a.nx - 1), k1 = min(lane + 64, a.nx - 1);
   const bool v0 = lane < a.nx, v1 = lane + 64 < a.nx;
+  // a frame's two inputs of this lane (byte frames: widened here; a byte IS its float value)
+  auto frame = [&](int f, float& x0, float& x1) {
+    const size_t o = (size_t)min(f, a.R - 1) * a.ldx;
+    if (XU8) { const unsigned char* bp = static_cast<const unsigned char*>(a.X) + o; x0 = (float)bp[k0]; x1 = (float)bp[k1]; }
+    else { const float* fp = static_cast<const float*>(a.X) + o; x0 = fp[k0]; x1 = fp[k1]; }
+  };
   float nx0, nx1;
-  {
-    const float* fp = a.X + (size_t)min(first + wave, a.R - 1) * a.ldx;
-    nx0 = fp[k0]; nx1 = fp[k1];
-  }
+  frame(first + wave, nx0, nx1);
   for (int f = first + wave; f < last; f += SP_NW) {
     const float fx0 = nx0, fx1 = nx1;
-    {                                                     // next frame of this wave (clamped, unconditional)
-      const float* fp = a.X + (size_t)min(f + SP_NW, a.R - 1) * a.ldx;
-      nx0 = fp[k0]; nx1 = fp[k1];
-    }
+    frame(f + SP_NW, nx0, nx1);                           // next frame of this wave (clamped, unconditional)
     unsigned long long m0 = __ballot(v0 && fx0 != 0.f), m1 = __ballot(v1 && fx1 != 0.f);
     float acc[SP_NC];
 #pragma unroll
@@ -327,7 +328,7 @@ extern "C" int clv_sparse_proj_supported(int nx, int N) {
          clv_sparse_proj_lds_bytes(nx, N) <= 150 * 1024;
 }
 
-static int sparse_proj_launch(int R, int N, int ldo, int nset, const clv::SparseProjSet* sets, hipStream_t s) {
+static int sparse_proj_launch(int R, int N, int ldo, int nset, const clv::SparseProjSet* sets, bool x_u8, hipStream_t s) {
   using namespace clv;
   int nxmax = 0;
   for (int i = 0; i < nset; ++i) {
@@ -337,7 +338,8 @@ static int sparse_proj_launch(int R, int N, int ldo, int nset, const clv::Sparse
     nxmax = p.nx > nxmax ? p.nx : nxmax;
   }
   if (R <= 0 || ldo < N) return CLV_EINVAL;
-  if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(sparse_proj_kernel), 150 * 1024)) return e;
+  const void* kern = x_u8 ? reinterpret_cast<const void*>(sparse_proj_kernel<true>) : reinterpret_cast<const void*>(sparse_proj_kernel<false>);
+  if (int e = clv::allow_dynamic_lds(kern, 150 * 1024)) return e;
   SparseProjArgs a;
   memset(&a, 0, sizeof(a));
   a.R = R; a.N = N; a.ldo = ldo;
@@ -348,20 +350,21 @@ static int sparse_proj_launch(int R, int N, int ldo, int nset, const clv::Sparse
   a.wgs = R < cap * SP_NW ? (R + SP_NW - 1) / SP_NW : cap;
   for (int i = 0; i < nset; ++i) a.set[i] = sets[i];
   ProfScope p("sparse_proj", s);
-  hipLaunchKernelGGL(sparse_proj_kernel, dim3(nset * a.wgs), dim3(SP_NT), clv_sparse_proj_lds_bytes(nxmax, N), s, a);
+  if (x_u8) hipLaunchKernelGGL(sparse_proj_kernel<true>, dim3(nset * a.wgs), dim3(SP_NT), clv_sparse_proj_lds_bytes(nxmax, N), s, a);
+  else hipLaunchKernelGGL(sparse_proj_kernel<false>, dim3(nset * a.wgs), dim3(SP_NT), clv_sparse_proj_lds_bytes(nxmax, N), s, a);
   return launch_status();
 }
 
-extern "C" int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, const float* K, float* out, int ldo,
+extern "C" int clv_sparse_proj(int R, int nx, int N, const void* X, int x_u8, int ldx, const float* K, float* out, int ldo,
                                void* stream) {
   const clv::SparseProjSet set{nx, ldx, X, K, out};
-  return sparse_proj_launch(R, N, ldo, 1, &set, (hipStream_t)stream);
+  return sparse_proj_launch(R, N, ldo, 1, &set, x_u8 != 0, (hipStream_t)stream);
 }
 
-extern "C" int clv_sparse_proj2(int R, int N, int ldo, int nx0, const float* X0, int ldx0, const float* K0, float* out0,
-                                int nx1, const float* X1, int ldx1, const float* K1, float* out1, void* stream) {
+extern "C" int clv_sparse_proj2(int R, int N, int ldo, int x_u8, int nx0, const void* X0, int ldx0, const float* K0, float* out0,
+                                int nx1, const void* X1, int ldx1, const float* K1, float* out1, void* stream) {
   const clv::SparseProjSet sets[2] = {{nx0, ldx0, X0, K0, out0}, {nx1, ldx1, X1, K1, out1}};
-  return sparse_proj_launch(R, N, ldo, 2, sets, (hipStream_t)stream);
+  return sparse_proj_launch(R, N, ldo, 2, sets, x_u8 != 0, (hipStream_t)stream);
 }
 
 extern "C" int clv_sparse_dense_supported(int N) { return N >= 2 && N <= 128 && N % 2 == 0; }

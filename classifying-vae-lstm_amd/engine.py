@@ -478,19 +478,28 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
         large-batch path (no Philox launch)."""
         return bool((self.fuse_pair or (self.use_mx and self.fuse_latent)) and self.sparse_inputs and self.cfg['D'] % 2 == 0)
 
-    def frames_u8_supported(self):
-        """Can a training pass read its frames as BYTES (frames8 of forward / loss_and_grads / grads_tail: the uint8 batch the
-        staging launch copied out of the frame store, never widened to float)?  The large-batch path with every consumer of
-        frames on its byte-reading kernel: csrc/lstm_mx.hip (note lists), wgrad_bf16.hip (x rows), out_head_bf16.hip (targets),
-        outer_bf16.hip (the hW layer's forward and kernel-gradient products)."""
+    def frames_u8_route(self):
+        """How a training pass can get its frames as BYTES (frames8 of forward / loss_and_grads / grads_tail: a uint8 batch copied out
+        of the frame store, never widened to float), or None.  Every consumer of frames must be on its byte-reading kernel:
+        csrc/lstm_mx.hip (note lists) or sparse_proj.hip (row gathers), wgrad_bf16.hip (x rows), out_head_bf16.hip (targets),
+        outer_bf16.hip (the hW layer's products).
+          'gather': the large-batch path -- the staging launch copies the bytes (TrainStep._stage_bound);
+          'label':  the pair path -- the label forward launch, which assembles the mini-batch anyway (ops.label_stage), leaves
+                    the byte batch instead of the float one (its own note walk reads the frame store)."""
         cfg, B = self.cfg, self.B
         D, H, L, T = cfg['D'], cfg['H'], cfg['L'], cfg['T']
-        if not (self.frames_u8 and self.use_mx and self.fuse_head and self.bf16_wgrad and self.dense_hw_grad and self.dense_hw_fwd
-                and D % 4 == 0):
-            return False
-        return bool(ops.dense_window_fwd_bf16_supported(B, T * D, D, T * D, D) and ops.dense_outer_bf16_supported(B, T * D, D, T * D, D)
-                    and ops.sparse_dense_supported(D) and ops.lstm_wgrad_supported(4 * H, D, H, 0, 2)
-                    and (not self.off or ops.lstm_wgrad_supported(4 * H, D, H, L, 2)))
+        if not (self.frames_u8 and self.fuse_head and self.bf16_wgrad and self.dense_hw_grad and D % 4 == 0 and self.sparse_inputs
+                and ops.dense_outer_bf16_supported(B, T * D, D, T * D, D) and ops.sparse_dense_supported(D)
+                and ops.lstm_wgrad_supported(4 * H, D, H, 0, 2) and (not self.off or ops.lstm_wgrad_supported(4 * H, D, H, L, 2))):
+            return None
+        if self.use_mx:
+            return 'gather' if (self.dense_hw_fwd and ops.dense_window_fwd_bf16_supported(B, T * D, D, T * D, D)) else None
+        if self.fuse_pair and self.can_stage_in_label():
+            return 'label'
+        return None
+
+    def frames_u8_supported(self):
+        return self.frames_u8_route() is not None
 
     def forward(self, X, Xp, eps_W, eps_Z, w_true=None, keep_gates=True, nll=None, target=None, noise=None, frames8=None):
         """nll = (scale, need_grads): fuse the Bernoulli NLL of the output head into its GEMM; target = the frames the
@@ -663,6 +672,9 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
         # the history frames and the labels for everything behind it
         stage = self.stage_spec if pack_in_label else None
         self.stage_spec = None
+        f8 = self._f8
+        if f8 is not None and stage is None:
+            raise ValueError("frames8 on the pair path: the byte batch is what the label launch's own stage leaves (ops.label_stage)")
         if stage is not None:
             self._label_forward(X, eps_W, w_true, pack=pack, stage=stage)
         notes = None
@@ -670,11 +682,12 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
             notes = (self.notes_enc, P.p('encoder_h/kernel'), self.notes_dec if off else None,
                      P.p('decoder_h/kernel') if off else None)
         elif self.sparse_inputs:     # piano-roll frames are ~4 % nonzero: add the kernel rows of the notes that are on
+            cur, hist, hist_ld = (X, self.XZ, self.xz_ld) if f8 is None else (f8[0], f8[1], D)
             if off:        # both LSTMs in one launch
-                ops.sparse_proj2(BT, G4, (D, X, D, P.p('encoder_h/kernel'), self.gates_enc),
-                                 (off, self.XZ, self.xz_ld, P.p('decoder_h/kernel'), self.gates_dec))
+                ops.sparse_proj2(BT, G4, (D, cur, D, P.p('encoder_h/kernel'), self.gates_enc),
+                                 (off, hist, hist_ld, P.p('decoder_h/kernel'), self.gates_dec))
             else:
-                ops.sparse_proj(BT, D, G4, X, D, P.p('encoder_h/kernel'), self.gates_enc)
+                ops.sparse_proj(BT, D, G4, cur, D, P.p('encoder_h/kernel'), self.gates_enc)
         else:
             g(X, P.p('encoder_h/kernel'), self.gates_enc, BT, G4, D, ws=ws)
             if off:        # history frames only: z_t . K_z is added inside the sequence kernel
@@ -685,7 +698,7 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
         ops.lstm_pair_fwd(B, T, L, self.gates_enc, self.wk_enc, self.gates_dec, off > 0, self.wk_dec, self.pair_pack,
                           P.p('Zargs/bias'), eps_Z, self.hs_enc, self.cs_enc, self.hs_dec, self.cs_dec, self.zargs, self.Z,
                           self.xz_ld, self.klterm, gate_act=self.gate_act, noise=nz[1] if nz else None, notes=notes)
-        self._output_head(X if target is None else target, nll)
+        self._output_head(f8[0] if f8 is not None else (X if target is None else target), nll)
 
     def xp_view(self):
         """[B,T,D] strided view of the history columns of the [Xp | Z] buffer (stage batches straight into it)."""

@@ -34,7 +34,7 @@ class Workspace:
 
 
 class ReduceQueue:
-    """Pending split-K reductions of one backward pass (clv_*_deferred + clv_splitk_reduce_multi).
+    """Pending split-K reductions of one backward pass (the `job` argument of the products + clv_splitk_reduce_multi).
     Every queued product keeps its partial slabs in its own scratch buffer until flush(); the buffers are
     kept per queue slot, so a step that queues the same products in the same order reuses the same memory
     (and a captured hipGraph sees fixed pointers)."""
@@ -102,7 +102,7 @@ def gemm(A, B, C_out, M, N, K, ta=False, tb=False, lda=None, ldb=None, ldc=None,
         buf = defer.scratch(need) if defer is not None else ws.ensure(need)
         wsp, wsb = _ptr(buf), buf.numel()
         job = defer.next_job() if defer is not None else None
-    check(L.clv_gemm_f32_deferred(int(ta), int(tb), M, N, K, float(alpha), _ptr(A), lda, _ptr(B), ldb, float(beta),
+    check(L.clv_gemm_f32(int(ta), int(tb), M, N, K, float(alpha), _ptr(A), lda, _ptr(B), ldb, float(beta),
                                   _ptr(C_out), ldc, _ptr(bias), act, _ptr(aux), split_k, wsp, wsb, job, _stream()),
           "clv_gemm_f32")
 
@@ -129,7 +129,7 @@ def gemm_grouped_tn(probs, N, K, B, ws, ldb=None, beta=0.0, split_k=None, defer=
         buf = defer.scratch(need) if defer is not None else ws.ensure(need)
         wsp, wsb = _ptr(buf), buf.numel()
         job = defer.next_job() if defer is not None else None
-    check(L.clv_gemm_grouped_tn_deferred(arr, n, N, K, _ptr(B), ldb if ldb is not None else N, float(beta), split_k,
+    check(L.clv_gemm_grouped_tn(arr, n, N, K, _ptr(B), ldb if ldb is not None else N, float(beta), split_k,
                                          wsp, wsb, job, _stream()), "clv_gemm_grouped_tn")
 
 
@@ -308,14 +308,16 @@ def sparse_proj_supported(nx, N):
 
 
 def sparse_proj2(R, N, a, b, ldo=None):
-    """Two projections over the same R frames in one launch; a, b = (nx, X, ldx, K, out)."""
-    check(_lib.lib().clv_sparse_proj2(R, N, ldo if ldo is not None else N, a[0], _ptr(a[1]), a[2], _ptr(a[3]), _ptr(a[4]),
+    """Two projections over the same R frames in one launch; a, b = (nx, X, ldx, K, out); X float32, or both the bytes themselves."""
+    if _is_u8(a[1]) != _is_u8(b[1]):
+        raise TypeError("both projections read float frames or both read bytes")
+    check(_lib.lib().clv_sparse_proj2(R, N, ldo if ldo is not None else N, _is_u8(a[1]), a[0], _ptr(a[1]), a[2], _ptr(a[3]), _ptr(a[4]),
                                       b[0], _ptr(b[1]), b[2], _ptr(b[3]), _ptr(b[4]), _stream()), "clv_sparse_proj2")
 
 
 def sparse_proj(R, nx, N, X, ldx, K, out, ldo=None):
     """out[r,:N] = sum_k X[r,k] K[k,:] visiting only the nonzero inputs of a frame (K resident in LDS)."""
-    check(_lib.lib().clv_sparse_proj(R, nx, N, _ptr(X), ldx, _ptr(K), _ptr(out), ldo if ldo is not None else N,
+    check(_lib.lib().clv_sparse_proj(R, nx, N, _ptr(X), _is_u8(X), ldx, _ptr(K), _ptr(out), ldo if ldo is not None else N,
                                      _stream()), "clv_sparse_proj")
 
 
@@ -487,9 +489,10 @@ def _noise_ref(noise):
     return C.byref(noise) if noise is not None else None
 
 
-def label_stage(cur, hist, idx, row0, cursor, X, Xh, hist_chunk, hist_ld, w_src, w_out):
+def label_stage(cur, hist, idx, row0, cursor, X, Xh, hist_chunk, hist_ld, w_src, w_out, bytes_out=None):
     """clv_label_stage for vrnn_label_fwd_x(stage=...): cur / hist = (uint8 store, stride, offset, table or None) of the
-    current / history frames (hist None: no history frames), cursor = (step_dev, step0, period, stride, offset) or None."""
+    current / history frames (hist None: no history frames), cursor = (step_dev, step0, period, stride, offset) or None.
+    bytes_out = (X8, Xh8): the rows are copied as bytes into these uint8 [B, nx] buffers instead of widened into X / Xh."""
     g = _lib.LabelStage()
     g.cur, g.cur_stride, g.cur_offset, g.cur_table = _ptr(cur[0]), int(cur[1]), int(cur[2]), _ptr(cur[3])
     if hist is not None:
@@ -499,6 +502,8 @@ def label_stage(cur, hist, idx, row0, cursor, X, Xh, hist_chunk, hist_ld, w_src,
         g.cursor = _lib.BatchCursor(_ptr(cursor[0]), int(cursor[1]), int(cursor[2]), int(cursor[3]), int(cursor[4]))
     g.X, g.Xh, g.hist_chunk, g.hist_ld = _ptr(X), _ptr(Xh), int(hist_chunk), int(hist_ld)
     g.w_src, g.w_out = _ptr(w_src), _ptr(w_out)
+    if bytes_out is not None:
+        g.X8, g.Xh8 = _ptr(bytes_out[0]), _ptr(bytes_out[1])
     return g
 
 

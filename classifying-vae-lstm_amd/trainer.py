@@ -159,7 +159,7 @@ class TrainStep:
     def _bytes_batch(self, b):
         """(X8, Xp8) when the bound batches can stay uint8 for the whole step, else None (see __init__)."""
         eng = self.eng
-        if not (self.is_vrnn and b['target'] is None and getattr(eng, 'frames_u8_supported', lambda: False)()):
+        if not (self.is_vrnn and b['target'] is None and getattr(eng, 'frames_u8_route', lambda: None)() == 'gather'):
             return None
         need_hist = eng.off > 0
         if need_hist != (b['hist'] is not None):
@@ -212,8 +212,16 @@ class TrainStep:
             eng.frames_exact_bf16 = True
             self.recapture()
         hist_chunk, hist_ld = (D, self.xp_ld) if self.xp_ld else (row, row)
+        f8 = None
+        if self.is_vrnn and getattr(eng, 'frames_u8_route', lambda: None)() == 'label':
+            # the label launch leaves the batch as BYTES (a quarter of its stores) and every later launch of the step reads bytes
+            if self.X8 is None:
+                self.X8 = torch.zeros(tuple(self.X.shape), dtype=torch.uint8, device=self.X.device)
+                self.Xp8 = torch.zeros(tuple(self.X.shape), dtype=torch.uint8, device=self.X.device) if need_hist else None
+            f8 = (self.X8, self.Xp8)
+        self._f8 = f8
         return ops.label_stage(cur, hist, b['idx'], 0, (eng.P.iterations, b['step0'], b['period'], b['stride'], b['offset']),
-                               self.X, self.Xp if need_hist else None, hist_chunk, hist_ld, b['w'], self.w_true)
+                               self.X, self.Xp if need_hist else None, hist_chunk, hist_ld, b['w'], self.w_true, bytes_out=f8)
 
     def _main(self):
         if not self._drop_logits:

@@ -88,6 +88,9 @@ typedef struct clv_label_stage {
   clv_batch_cursor cursor;                 /* step_dev NULL: no cursor */
   float* X; float* Xh; int32_t hist_chunk; int64_t hist_ld;
   const float* w_src; float* w_out;
+  uint8_t* X8; uint8_t* Xh8;               /* clv_vrnn_label_fwd_x only; not NULL: the rows are copied as BYTES into X8 / Xh8 ([B, nx]
+                                            * each) INSTEAD of widened into X / Xh (which may then be NULL): the batch of a step whose
+                                            * later launches read frames as bytes (x_u8 / y_u8 / CLV_FRAMES_U8) */
 } clv_label_stage;
 
 /* ABI version = CLV_ABI_VERSION of the header the library was built from.  It changes whenever an existing entry point
@@ -125,11 +128,6 @@ const char* clv_error_string(int code);
  * clv_gemm_workspace_bytes(M, N, clv_gemm_auto_split(M, N, K)). */
 int clv_gemm_auto_split(int M, int N, int K);
 size_t clv_gemm_workspace_bytes(int M, int N, int split_k);
-int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
-                 const float* A, int lda, const float* B, int ldb,
-                 float beta, float* C, int ldc,
-                 const float* bias, int act, const float* aux,
-                 int split_k, void* ws, size_t ws_bytes, void* stream);
 
 /* Grouped weight-gradient GEMM: C_p[M_p,N] = (beta ? beta*C_p : 0) + op(A_p)^T . B for up to 4 problems
  * that share B [K,N] -- one pass over dz yields every kernel gradient of an LSTM
@@ -147,9 +145,6 @@ typedef struct clv_gemm_prob {
 } clv_gemm_prob;
 int clv_gemm_grouped_auto_split(const clv_gemm_prob* host_probs, int nprob, int N, int K);
 size_t clv_gemm_grouped_workspace_bytes(const clv_gemm_prob* host_probs, int nprob, int N, int split_k);
-int clv_gemm_grouped_tn(const clv_gemm_prob* host_probs, int nprob, int N, int K,
-                        const float* B, int ldb, float beta,
-                        int split_k, void* ws, size_t ws_bytes, void* stream);
 /* Two such grouped products with few output rows (<= 16 in total each) over a short K (<= 4096) and DIFFERENT B
  * operands in one launch: the label rows and the bias of both LSTM input-kernel gradients of cl_vrnn
  * (B = sum_t dz [batch,4H] of the encoder / of the decoder, K = batch).  ones in {0, 1}; beta = 0. */
@@ -157,25 +152,25 @@ int clv_gemm_grouped_tn_small2(const clv_gemm_prob* probs0, int nprob0, const fl
                                const clv_gemm_prob* probs1, int nprob1, const float* B1,
                                int N, int K, int ldb, void* stream);
 
-/* Deferred split-K reduction.  The *_deferred forms behave like the plain ones, but when `job` is not
- * NULL and the product was split, they leave the partial slabs in `ws` and describe the pending
- * reduction (+ epilogue) in *job instead of launching it; `ws` must then stay untouched until
- * clv_splitk_reduce_multi has run.  A backward pass queues all of its weight-gradient products this
- * way and finishes them with ONE reduce launch (up to 16 pending jobs; jobs that needed no split are
- * skipped).  Summation order per output is fixed, so results are bit-identical to the plain forms. */
+/* clv_gemm_f32 (the plain product documented at the top of this section) and clv_gemm_grouped_tn.  Deferred split-K
+ * reduction: job == NULL: the product is finished by the call.  job != NULL and the product was split: the partial slabs stay
+ * in `ws` and *job describes the pending reduction (+ epilogue) instead of launching it; `ws` must then stay untouched until
+ * clv_splitk_reduce_multi has run.  A backward pass queues all of its weight-gradient products this way and finishes them
+ * with ONE reduce launch (up to 16 pending jobs; jobs that needed no split are skipped).  Summation order per output is fixed,
+ * so results are bit-identical either way. */
 typedef struct { unsigned char opaque[160]; } clv_reduce_job;
-int clv_gemm_f32_deferred(int transa, int transb, int M, int N, int K, float alpha,
+int clv_gemm_f32(int transa, int transb, int M, int N, int K, float alpha,
                           const float* A, int lda, const float* B, int ldb,
                           float beta, float* C, int ldc,
                           const float* bias, int act, const float* aux,
                           int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
-int clv_gemm_grouped_tn_deferred(const clv_gemm_prob* probs, int nprob, int N, int K,
+int clv_gemm_grouped_tn(const clv_gemm_prob* probs, int nprob, int N, int K,
                                  const float* B, int ldb, float beta,
                                  int split_k, void* ws, size_t ws_bytes, clv_reduce_job* job, void* stream);
-/* The same launch with up to five strided means computed by extra blocks (means_out[i] = mean of the n[i] elements
- * x[i][k * stride[i]]): a training step takes its loss terms here instead of in a clv_loss_sums launch of its own.
- * x / n / stride are host arrays of n_terms entries (device pointers in x). */
-/* ... and with up to two few-row products riding in the launch as well: C[r, :N] = sum_k A[k, r] B[k, :N] for r < rows
+/* clv_splitk_reduce_multi: the pending reductions in one launch, with up to five strided means computed by extra blocks
+ * (means_out[i] = mean of the n[i] elements x[i][k * stride[i]]; x / n / stride: host arrays of n_terms entries, device pointers
+ * in x): a training step takes its loss terms here instead of in a clv_loss_sums launch of its own -- and with up to two
+ * few-row products riding in the launch as well: C[r, :N] = sum_k A[k, r] B[k, :N] for r < rows
  * (rows + (bias_row != NULL) <= 16), bias_row[:N] = column sums of B -- the label rows and the bias of an LSTM
  * input-kernel gradient over K = batch rows of sum_t dz; both products must have the same N. */
 typedef struct clv_skinny_product {
@@ -199,7 +194,7 @@ int clv_splitk_reduce_multi(const clv_reduce_job* jobs, int njobs, const float* 
  * fp32 multiply) are left out since round 4: 6 bf16 MFMAs instead of 8 f32 MFMAs at 1/16 of the rate.  x_exact_bf16 != 0
  * promises that every X value is exactly representable in bf16 (0/1 piano-roll frames, any uint8): those rows then need
  * one piece, and their products with all three dz pieces are exact.  The products leave as split-K slabs: ws >= clv_lstm_wgrad_workspace_bytes,
- * and like the *_deferred GEMMs the final sums (C = beta*C + sum) are formed by the reduction, now (job == NULL) or by
+ * and like the GEMMs' deferred form (job) the final sums (C = beta*C + sum) are formed by the reduction, now (job == NULL) or by
  * clv_splitk_reduce_multi.  Limits (clv_lstm_wgrad_supported): N == 352; nx <= 96, nh <= 96, nz <= 32; nx, nh,
  * ldx, ldh, lddz multiples of 4, 16-byte aligned bases; more than 96 rows of H and Z together, or more than 8 rows
  * of Z, need x_exact_bf16 (the wide form of the kernel has no room for three pieces of X).
@@ -601,13 +596,14 @@ int clv_axpy(int64_t n, float alpha, const float* x, float* y, void* stream);
  * columns), K [nx,N] (16-byte aligned), out rows of stride ldo.  The LSTM input projections of cl_vrnn
  * (cl_vrnn/model.py:193-196, 218-226) multiply piano-roll frames that are ~4 % nonzero; this keeps K in LDS
  * and adds only the kernel rows of a frame's nonzero inputs.  Exact for any float input (cost grows with
- * the number of nonzeros); clv_sparse_proj_supported: nx <= 128, N <= 384, nx*N*4 <= 150 KB. */
+ * the number of nonzeros); clv_sparse_proj_supported: nx <= 128, N <= 384, nx*N*4 <= 150 KB.  x_u8 != 0: X holds the frames
+ * as bytes (uint8 rows, ldx in bytes). */
 int clv_sparse_proj_supported(int nx, int N);
 size_t clv_sparse_proj_lds_bytes(int nx, int N);
-int clv_sparse_proj(int R, int nx, int N, const float* X, int ldx, const float* K, float* out, int ldo, void* stream);
+int clv_sparse_proj(int R, int nx, int N, const void* X, int x_u8, int ldx, const float* K, float* out, int ldo, void* stream);
 /* two such projections over the same R frames (the two LSTMs of cl_vrnn) in one launch */
-int clv_sparse_proj2(int R, int N, int ldo, int nx0, const float* X0, int ldx0, const float* K0, float* out0,
-                     int nx1, const float* X1, int ldx1, const float* K1, float* out1, void* stream);
+int clv_sparse_proj2(int R, int N, int ldo, int x_u8, int nx0, const void* X0, int ldx0, const float* K0, float* out0,
+                     int nx1, const void* X1, int ldx1, const float* K1, float* out1, void* stream);
 
 /* The same idea for a Dense layer over a whole flattened window (cl_vrnn's hW layer, model.py:174-176;
  * nx = seq_length*88 inputs, ~4 % nonzero): out[r,:N] = act(sum_j X[r,j] K[j,:] + bias), act in {none, relu};

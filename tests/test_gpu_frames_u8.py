@@ -194,11 +194,12 @@ def test_gather_copies_bytes(dev, rows, n, row, chunk, ld, use_idx):
         ops.gather_rows_multi(rows, idx, [(F(St, dev), out, row, chunk, ld)], row0=row0)      # float source, uint8 output
 
 
-@pytest.mark.parametrize("B,Tn,L,Cn", [(1024, 6, 32, 10), (768, 5, 12, 3)])
+@pytest.mark.parametrize("B,Tn,L,Cn", [(1024, 6, 32, 10), (768, 5, 12, 3), (64, 16, 2, 10), (256, 128, 2, 10), (7, 3, 8, 4)])
 def test_step_on_byte_batch_equals_step_on_float_batch(dev, B, Tn, L, Cn):
-    """One captured training step of the large-batch path fed by the bound-batch cursor from a uint8 data set: with the
-    byte batch (default) and with CLV_FRAMES_U8=0 (the float staging of rounds 4-5) -- the same losses, the same
-    parameters after three steps, bit for bit (tests/test_gpu_timed_step.py holds the same step to the oracle)."""
+    """One captured training step fed by the bound-batch cursor from a uint8 data set: with the byte batch (default) and with
+    CLV_FRAMES_U8=0 (the float staging of rounds 4-5) -- the same losses, the same parameters after three steps, bit for bit
+    (tests/test_gpu_timed_step.py holds the same step to the oracle).  The large-batch path (768+ rows: the staging launch
+    copies the bytes) and the pair path (the label launch leaves the byte batch; BASELINE configuration 3 is the 256 x 128 case)."""
     import os
     from clvae_amd.engine import VrnnEngine
     from clvae_amd.trainer import TrainStep
@@ -215,7 +216,8 @@ def test_step_on_byte_batch_equals_step_on_float_batch(dev, B, Tn, L, Cn):
         os.environ['CLV_FRAMES_U8'] = flag
         try:
             eng = VrnnEngine(cfg, B, dev)
-            assert eng.use_mx and eng.frames_u8_supported() == (flag == '1')
+            assert (eng.use_mx or eng.fuse_pair) and eng.frames_u8_supported() == (flag == '1')
+            assert eng.frames_u8_route() == ((('gather' if eng.use_mx else 'label')) if flag == '1' else None)
             eng.P.set_weights(p0)
             ts = TrainStep(eng, seed=5, use_graph=True)
             ts.bind_batches(cur, hist, F(wl, dev), idx=perm, period=2, stride=B)
@@ -232,3 +234,26 @@ def test_step_on_byte_batch_equals_step_on_float_batch(dev, B, Tn, L, Cn):
         assert la == lb, (la, lb)
     for k in runs[0][1]:
         np.testing.assert_array_equal(runs[0][1][k], runs[1][1][k], err_msg=k)
+
+
+@pytest.mark.parametrize("R,nx,ldx,two", [(1, 88, 88, False), (1000, 88, 92, True), (33, 96, 96, True), (515, 16, 16, False)])
+def test_sparse_proj_reads_byte_frames(dev, R, nx, ldx, two):
+    """clv_sparse_proj / clv_sparse_proj2 with x_u8: the row gathers of byte frames (any value, padded rows) bit for bit those of
+    the float frames."""
+    from clvae_amd import ops
+    rng = np.random.default_rng(R + nx)
+    Nn = 352
+    X = np.full((R, ldx), 7, np.uint8)
+    X[:, :nx] = frames(rng, (R, nx), 'notes' if two else 'bytes')
+    Ka, Kb = rng.standard_normal((nx, Nn)).astype(np.float32), rng.standard_normal((nx, Nn)).astype(np.float32)
+    res = []
+    for Xd in (F(X, dev), U8(X, dev)):
+        oa, ob = torch.full((R, Nn), -1.0, device=dev), torch.full((R, Nn), -1.0, device=dev)
+        if two:
+            ops.sparse_proj2(R, Nn, (nx, Xd, ldx, F(Ka, dev), oa), (nx, Xd, ldx, F(Kb, dev), ob))
+        else:
+            ops.sparse_proj(R, nx, Nn, Xd, ldx, F(Ka, dev), oa)
+        torch.cuda.synchronize()
+        res.append((oa, ob))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), X[:, :nx].astype(np.float64) @ Ka.astype(np.float64), rtol=1e-5, atol=1e-3)

@@ -155,7 +155,7 @@ def test_cl_vae_timed_step_tracks_the_oracle(dev, bf16):
 
 @pytest.mark.parametrize("source", ["rows", "windows", "windows-no-history"])
 def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, monkeypatch, source):
-    """TrainStep.bind_batches: the label forward launch assembles the mini-batch itself (clv_vrnn_label_fwd_x_staged) where it
+    """TrainStep.bind_batches: the label forward launch assembles the mini-batch itself (clv_vrnn_label_fwd_x(stage)) where it
     can -- byte frames, the fused pair path.  Against the same steps with the gather launch (CLV_STAGE_IN_LABEL=0): the staged
     X / history frames / labels, every loss and every parameter after three replayed steps, bit for bit.  `rows`: whole
     rows in two byte tensors (bench.py); `windows`: overlapping windows of one frame store through a start table
@@ -189,7 +189,12 @@ def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, mo
         for it in range(3):
             ts.step()
             torch.cuda.synchronize()
-            out.append((dict(eng.losses()), ts.X.clone(), ts.Xp.clone(), ts.w_true.clone()))
+            # what the step was fed: the float batch, or (round 6, the label launch's own stage) the byte batch the later launches read
+            f8 = ts._f8
+            assert (f8 is not None) == (staged == "1")
+            fx = f8[0].float() if f8 is not None else ts.X.clone()
+            fh = (f8[1].float() if f8 is not None else ts.Xp.clone().view(B, Tn, 88)) if hist_on else ts.w_true.clone()
+            out.append((dict(eng.losses()), fx.view(B, Tn, 88), fh, ts.w_true.clone()))
         runs[staged] = (out, eng.P.get_weights())
     for a, b in zip(runs["1"][0], runs["0"][0]):
         assert a[0] == b[0]
@@ -201,7 +206,7 @@ def test_batch_assembly_inside_the_label_launch_equals_the_gather_launch(dev, mo
 
 @pytest.mark.parametrize("source", ["rows", "windows"])
 def test_cl_vae_batch_assembly_inside_the_fused_step_equals_the_gather_launch(dev, monkeypatch, source):
-    """cl_vae: the fused step kernel assembles its own mini-batch rows (clv_vae_fused_step_staged) -- three launches per
+    """cl_vae: the fused step kernel assembles its own mini-batch rows (clv_vae_fused_step(stage)) -- three launches per
     step.  Against the same steps with the gather launch (CLV_STAGE_IN_LABEL=0): the staged frames and labels, every loss and
     every parameter after three replayed steps, bit for bit; a batch that does not fill its last workgroup's 16 rows."""
     from clvae_amd.engine import VaeEngine

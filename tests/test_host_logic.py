@@ -137,7 +137,7 @@ def test_adam_plan_layout_on_host():
     assert L.clv_adam_wn_workspace_bytes(tab, 3) > 0
     assert L.clv_gemm_auto_split(88, 352, 32768) > 1 and L.clv_gemm_auto_split(32768, 352, 88) == 1
     assert L.clv_gemm_f32(0, 0, 0, 4, 4, ctypes.c_float(1), None, 4, None, 4, ctypes.c_float(0), None, 4, None, 0, None,
-                          1, None, 0, None) == -1       # CLV_EINVAL before any device work
+                          1, None, 0, None, None) == -1       # CLV_EINVAL before any device work
     assert L.clv_lstm_seq_fwd(4, 4, 64, 0, None, None, None, None, None, None, None, None, None, None, None) == -1
 
 
