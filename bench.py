@@ -486,7 +486,9 @@ def kernel_time_pass(eng, ts_args, batch, reps, label_off=False):
         eng.label_in_pair = False
     ts_e = TrainStep(eng, use_graph=False, **ts_args)
     ts_e._drop_logits = hasattr(eng, 'keep_logits')      # the launches of the REPLAYED step: it stores no logits (TrainStep._main)
-    ts_e.stage_batch(*batch)
+    # fed like the timed step (the bound-batch cursor): the launches -- mini-batch assembly inside the label / fused launch, frames
+    # read as bytes -- are then those of the replayed graph, not those of a float batch staged once
+    ts_e.bind_batches(batch[0], batch[1], batch[2], idx=None, period=1, stride=int(batch[0].shape[0]))
     ts_e.step(); torch.cuda.synchronize()
     ops.prof_enable(True)
     for _ in range(reps):
@@ -752,7 +754,7 @@ def also_in_child(timeout_s=600):
     except OSError as ex:
         return [{"error": "could not start the child: %r" % (ex,)}]
     try:
-        so, se = pr.communicate(timeout=limit)
+        so, se = pr.communicate(timeout=timeout_s)
     except subprocess.TimeoutExpired:
         try:
             os.killpg(pr.pid, signal.SIGKILL)
