@@ -104,7 +104,7 @@ struct PairFwdArgs {
   const float* rb_d;
   const float* pack;      // weights in lane order (clv_lstm_pair_pack)
   const float* bz;        // [2L]
-  // note lists (clv_gather_rows_multi_notes) of the frames x_t / x_{t-1} and the kernels' frame rows [88,352]: when
+  // note lists (clv_gather_rows_multi, notes_out) of the frames x_t / x_{t-1} and the kernels' frame rows [88,352]: when
   // given, the input projections are gathered in this kernel and the gate buffers are not read
   const unsigned char* notes_e; const float* Kx_e;
   const unsigned char* notes_d; const float* Kx_d;

@@ -315,7 +315,7 @@ __device__ __forceinline__ int64_t gather_base(const GatherArgs& a) {
   return (int64_t)j * a.cur_stride + a.cur_offset;
 }
 
-// Note lists (clv_gather_rows_multi_notes): frame p of output row r -> notes[(r * pieces + p) * CLV_NOTE_ROW ..]: the
+// Note lists (clv_gather_rows_multi, notes_out): frame p of output row r -> notes[(r * pieces + p) * CLV_NOTE_ROW ..]: the
 // indices of the bytes that are not zero, then CLV_NOTE_NONE up to the end of the row (at least 8 of them: a reader that
 // walks the row 4 bytes at a time always meets the terminator).  One wave per frame: lanes 0..21 take 4 bytes each, the
 // position of a note in the list is a prefix count over four ballots (the order of a list is byte-major, not

@@ -333,7 +333,7 @@ def sparse_dense(R, nx, N, X, ldx, K, bias, act, out, ldo=None):
 
 def sparse_outer(Bn, nx, N, X, ldx, G, ldg, out, ldo=None, colsum=None, gdot=None):
     """out[j,:N] = sum_b X[b,j] G[b,:] (kernel gradient of a Dense layer with sparse inputs); colsum[N] = sum_b G[b,:].
-    gdot = (Hact, ldh, hbias, out[N]): also sum_b (Hact - hbias)[b,c] G[b,c] = sum_j K[j,c] dK[j,c] (see adam_wn_step_ex)."""
+    gdot = (Hact, ldh, hbias, out[N]): also sum_b (Hact - hbias)[b,c] G[b,c] = sum_j K[j,c] dK[j,c] (the `known` sums of clv_adam_wn_step)."""
     h, ldh, hb, go = gdot if gdot is not None else (None, 0, None, None)
     check(_lib.lib().clv_sparse_outer(Bn, nx, N, _ptr(X), ldx, _ptr(G), ldg, _ptr(out), ldo if ldo is not None else N,
                                          _ptr(colsum), _ptr(h), int(ldh), _ptr(hb), _ptr(go), _stream()), "clv_sparse_outer")

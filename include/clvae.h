@@ -316,7 +316,7 @@ int clv_lstm_mx_bwd(int B, int T, int H, const float* U, const float* dhs, const
  *   rowbias_* : [B,4H] per-row bias (W.K_w + b)
  *   zargs [B*T,2L], Z: B*T rows of stride ldz, klterm [B*T,L] = L * KL_l (the mean over ALL entries is
  *   the per-frame KL, which is what clv_loss_sums computes).
- * notes_enc != NULL: the input projections are formed INSIDE the kernel from note lists (clv_gather_rows_multi_notes:
+ * notes_enc != NULL: the input projections are formed INSIDE the kernel from note lists (clv_gather_rows_multi, notes_out:
  *   notes_enc [B*T, CLV_NOTE_ROW] of the frames x_t, notes_dec of x_{t-1}) and the kernels' frame rows Kx_enc / Kx_dec
  *   [88,4H] (rows 0..87 of encoder_h/kernel, decoder_h/kernel); gates_* are then outputs only and no projection launch
  *   (clv_sparse_proj / GEMM) is needed.  Binary frames only (a list says which notes are on, not how loud).
@@ -517,7 +517,7 @@ int clv_vae_fused_step(int B, int D, int H, int Hc, int C, int L, int use_x_prev
                        int need_grads, float* grads, void* ws, size_t ws_bytes,
                        float* logits, float* w_out, float* wargs_out, float* zargs_out,
                        float* rownll, float* rowkl, float* rowloss, const clv_vae_step_opts* opts, void* stream);
-/* ..._ex: dKa != NULL -- the Wargs layer's own gradient rides along: dKa [D,2(C-1)] = hW^T . dwargs, dba = column sums of
+/* dKa != NULL -- the Wargs layer's own gradient rides along: dKa [D,2(C-1)] = hW^T . dwargs, dba = column sums of
  * dwargs, as per-row outer products in ws (>= clv_vrnn_label_bwd_workspace_bytes) summed by the pending reduction `job`
  * (NULL: at once), like a split-K product's slabs: no GEMM launch over K = batch. */
 size_t clv_vrnn_label_bwd_workspace_bytes(int B, int D, int C);
@@ -612,7 +612,7 @@ int clv_sparse_proj2(int R, int N, int ldo, int x_u8, int nx0, const void* X0, i
 int clv_sparse_dense_supported(int N);
 int clv_sparse_dense(int R, int nx, int N, const float* X, int ldx, const float* K, const float* bias, int act,
                      float* out, int ldo, void* stream);
-/* ..._ex: gdot != NULL also returns gdot[c] = sum_b (Hact[b,c] - hbias[c]) G[b,c], Hact [Bn,ldh] = the layer's relu output
+/* gdot != NULL also returns gdot[c] = sum_b (Hact[b,c] - hbias[c]) G[b,c], Hact [Bn,ldh] = the layer's relu output
  * and G its (relu-masked) upstream gradient: = sum_j K[j,c] dK[j,c], the weight-norm optimizer's sum g.W per column
  * without a pass over K and dK (clv_adam_wn_step). */
 int clv_sparse_outer(int Bn, int nx, int N, const float* X, int ldx, const float* G, int ldg, float* out, int ldo,
@@ -647,7 +647,7 @@ int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int
  * src_u8[k] == 2: then out[k] is a uint8 buffer too (out_ld[k] in bytes) and the rows are copied as bytes: the batch of
  * the large-batch training step, whose kernels read frames as bytes (x_u8 / CLV_FRAMES_U8).  Needs row_elems, chunk, out_ld,
  * stride and offset multiples of 4 and 4-byte aligned bases. */
-/* clv_gather_rows_multi_notes: the same launch also writes NOTE LISTS for the segments whose notes_out[k] is not NULL
+/* notes_out != NULL: the same launch also writes NOTE LISTS for the segments whose notes_out[k] is not NULL
  * (uint8 sources of binary frames, chunk[k] <= 88 and a multiple of 4): frame p of output row r gets CLV_NOTE_ROW bytes
  * at notes_out[k] + (r * pieces + p) * CLV_NOTE_ROW -- the indices of its nonzero bytes (any order), then CLV_NOTE_NONE
  * up to the end of the row.  clv_lstm_pair_fwd gathers the LSTM input projections x_t . K_x from such lists. */
@@ -657,7 +657,7 @@ int clv_gather_rows(int64_t rows, int64_t row_elems, const float* src, const int
  * i = (idx ? idx[base + r] : row0 + base + r), base = j * stride + offset, r < rows.  step_dev is the optimizer's
  * `iterations` counter (clv_adam_wn_step advances it at the end of a step), so the mini-batch assembly of
  * Model.fit (cl_vae/train.py:66-71: one contiguous slice of the shuffled index per step) becomes a node of the step's
- * hipGraph: a step is ONE graph launch, nothing is staged from the host.  cursor == NULL: clv_gather_rows_multi_notes. */
+ * hipGraph: a step is ONE graph launch, nothing is staged from the host.  cursor == NULL: the rows idx[r] / row0 + r. */
 /* (clv_batch_cursor is declared near the top of this header, next to clv_noise_draw) */
 int clv_gather_rows_multi(int64_t rows, const int64_t* idx, int64_t row0, int nseg,
                                  const void* const* src, const int32_t* src_u8, float* const* out,

@@ -638,7 +638,7 @@ def test_adam_step_in_two_pieces_is_bitwise_the_whole_step(dev):
 
 @pytest.mark.parametrize("B,L,Cn", [(100, 4, 2), (37, 16, 16), (1, 3, 5), (17, 1, 2)])
 def test_cl_vae_fused_step_draws_its_own_noise_and_advances_the_counter(dev, B, L, Cn):
-    """clv_vae_fused_step_ex: the in-kernel Philox draw writes the values clv_philox_normal2 writes (bit for bit), the
+    """clv_vae_fused_step(opts): the in-kernel Philox draw writes the values clv_philox_normal2 writes (bit for bit), the
     folded loss means equal clv_loss_sums', and bump + adam_step(advanced=True) is adam_step()."""
     from clvae_amd import ops
     from clvae_amd.engine import VaeEngine
@@ -802,7 +802,7 @@ def test_cl_vae_bf16_step_tolerance(dev):
 
 
 def test_cl_vae_fused_loss_only_pass_takes_its_means_in_one_launch(dev):
-    """need_grads=False through clv_vae_fused_step_ex: no gradients, no counter bump, the five loss means from the tail
+    """need_grads=False through clv_vae_fused_step(opts): no gradients, no counter bump, the five loss means from the tail
     launch alone -- equal to the training pass's on the same inputs."""
     from clvae_amd.engine import VaeEngine
     B, L, Cn = 50, 4, 2

@@ -650,7 +650,7 @@ def test_gather_rows_multi_uint8_store(dev, rows, n, row, chunk, ld, use_idx):
 
 @pytest.mark.parametrize("rows,pieces,use_idx,dense", [(5, 7, False, 0.05), (33, 16, True, 0.05), (4, 128, True, 0.3), (3, 2, False, 1.0)])
 def test_gather_note_lists(dev, rows, pieces, use_idx, dense):
-    """clv_gather_rows_multi_notes: next to the float copy of the frames, every frame's NOTE LIST -- the indices of its
+    """clv_gather_rows_multi(notes_out): next to the float copy of the frames, every frame's NOTE LIST -- the indices of its
     nonzero bytes (any order), then CLV_NOTE_NONE up to the end of the 96-byte row; frames with no note, more than 8 notes
     and all 88 notes; windows of a frame store through a start table."""
     from clvae_amd import ops

@@ -116,13 +116,13 @@ def test_every_entry_point_survives_null_and_zero_arguments():
     rets = {l.split()[1]: int(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("RET")}
     assert r.returncode == 0, "crashed in %s (exit code %d)" % (calls[-1] if calls else "?", r.returncode)
     assert set(rets) == set(_lib.SIGNATURES)
-    compute = [n for n in rets if not n.endswith(("_bytes", "_bytes_ex", "_supported", "_splits", "_floats", "_split", "_version", "_count",
+    compute = [n for n in rets if not n.endswith(("_bytes", "_supported", "_splits", "_floats", "_split", "_version", "_count",
                                                   "_string", "_enable", "_collect", "_scope", "_destroy"))
                and not n.startswith(("clv_splitk_reduce_multi", "clv_graph_", "clv_prof_"))]
     for n in compute:
         assert rets[n] != 0, n             # an error code, not "ok"
     for n in rets:
-        if n.endswith(("_bytes", "_bytes_ex", "_splits")):
+        if n.endswith(("_bytes", "_splits")):
             assert rets[n] >= 0, n
 
 
