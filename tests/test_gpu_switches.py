@@ -78,3 +78,53 @@ def test_switch_in_its_other_position_still_follows_the_oracle(dev, key):
     for k in p:      # (an entry whose gradient is within rounding of zero moves by +-lr per step whatever its size: tests/test_gpu_timed_step.py)
         d = np.abs(w[k] - p[k])
         assert float((d > 2e-3 * np.abs(p[k]) + 5e-5).mean()) <= 2e-2 and d.max() <= 4.1e-3, (key, k, d.max())
+
+
+# TrainStep's own run-time switches (environment variables read when the step object is built): each in its non-default
+# position, three captured steps fed by the bound-batch cursor against an oracle loop with the Philox noise of the same keys.
+TRAIN_SWITCHES = [
+    {'CLV_STAGE_IN_LABEL': '0'},                                   # the gather launch instead of the assembly inside the label launch
+    {'CLV_FAST_ADAM': '0'},                                        # the five-launch Adam-WN chain instead of the two-launch form
+    {'CLV_FORCE_DP_GRAPHS': '1'},                                  # the data-parallel schedule (no-op collectives) on one GPU
+    {'CLV_FORCE_DP_GRAPHS': '1', 'CLV_DP_EAGER_UPDATE': '0'},      # ... with the optimizer pieces as graphs of their own
+    {'CLV_FORCE_DP_GRAPHS': '1', 'CLV_FINE_GRID': '1'},            # ... with the finer weight-gradient grid
+    {'CLV_CAPTURE_COLLECTIVES': '0', 'CLV_FORCE_DP_GRAPHS': '1'},  # the split schedule asked for by name
+]
+
+
+@pytest.mark.parametrize("env", TRAIN_SWITCHES, ids=lambda e: "+".join("%s=%s" % kv for kv in sorted(e.items())))
+def test_trainstep_switch_in_its_other_position_still_follows_the_oracle(dev, monkeypatch, env):
+    from oracle import philox as OP
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B, Tn, L, Cn, steps, seed = 16, 10, 2, 10, 3, 808
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(3)
+    p = {k: f32(v) for k, v in O.vrnn_init_params(cfg, seed=9).items()}
+    win = (rng.random((steps * B, Tn + 1, 88)) < 0.05)
+    keys = np.eye(Cn)[rng.integers(0, Cn, steps * B)]
+    eng = VrnnEngine(cfg, B, dev)
+    eng.P.set_weights(p)
+    ts = TrainStep(eng, seed=seed)
+    u8 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.uint8), device=dev)
+    ts.bind_batches(u8(win[:, 1:].reshape(steps * B, -1)), u8(win[:, :-1].reshape(steps * B, -1)),
+                    torch.as_tensor(keys.astype(np.float32), device=dev), idx=None, period=steps, stride=B)
+    st = O.adam_wn_init(p)
+    for it in range(steps):
+        ts.step()
+        torch.cuda.synchronize()
+        got = eng.losses()
+        sl = slice(it * B, (it + 1) * B)
+        eW = f32(OP.normal(B * (Cn - 1), seed, step=it, stream_id=0).reshape(B, Cn - 1))
+        eZ = f32(OP.normal(B * Tn * L, seed, step=it, stream_id=1).reshape(B, Tn, L))
+        ref = O.vrnn_loss_and_grads(p, cfg, win[sl, 1:].astype(np.float64), win[sl, :-1].astype(np.float64), keys[sl], eW, eZ)
+        O.adam_wn_step(p, ref['grads'], st)
+        for k in ('vae', 'kl_z', 'kl_w', 'w_rec', 'total'):
+            assert abs(got[k] - ref[k]) <= 1e-3, (env, it, k, got[k], ref[k])
+    assert int(eng.P.iterations.item()) == steps
+    w = eng.P.get_weights()
+    for k in p:
+        d = np.abs(w[k] - p[k])
+        assert float((d > 1e-4 * np.abs(p[k]) + 2e-5).mean()) <= 1e-2 and d.max() <= 2e-3 * steps, (env, k, d.max())
