@@ -340,10 +340,11 @@ extern "C" int clv_dense_outer_bf16(int Bn, int nx, int N, const void* X, int x_
     hipLaunchKernelGGL(kern, dim3((nx + inputs - 1) / inputs + extra), dim3(threads), OD_LDS, s, a);
     return launch_status();
   };
-  // 96 inputs per workgroup (6 waves) or 48 (3): float frames take the wide form once it fills the chip (configuration 5); BYTE
-  // frames from 100 workgroups on -- a row's piece of a stage is then 96 bytes instead of 48 (configuration 3, 118 workgroups:
-  // 13.1 -> 11.1 us, profiles/r06_small_ab.txt)
-  if ((nx + 95) / 96 >= (x_u8 ? 100 : 200)) return x_u8 ? go(dense_outer_bf16_kernel<6, true>, 96, 384) : go(dense_outer_bf16_kernel<6, false>, 96, 384);
+  // 96 inputs per workgroup (6 waves) from 100 workgroups on, else 48 (3).  Round 6: 100, not 200 -- with byte frames a row's piece
+  // of a stage is then 96 bytes instead of 48 (configuration 3, 118 workgroups: 13.1 -> 11.1 us, profiles/r06_small_ab.txt).
+  // ONE rule for float and byte frames: the two forms sum the column sums / gdot over the batch in different orders, and the
+  // byte kernels promise the float kernels' results bit for bit.
+  if ((nx + 95) / 96 >= 100) return x_u8 ? go(dense_outer_bf16_kernel<6, true>, 96, 384) : go(dense_outer_bf16_kernel<6, false>, 96, 384);
   return x_u8 ? go(dense_outer_bf16_kernel<3, true>, 48, 192) : go(dense_outer_bf16_kernel<3, false>, 48, 192);
 }
 

@@ -469,7 +469,11 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
             in_e, in_d = D + Cn, self.off + L + Cn
             self.u_enc, self.u_dec = _f(d, B, 4, in_e), _f(d, B, 4, in_d)          # the masks uniforms [row][gate][input] (clv_dropout_rows)
             self._masks_given = False      # u_enc / u_dec hold nothing until a pass draws them (noise=...) or set_dropout_uniforms()
-            self.xm_e, self.xm_d = _f(d, 4, BT, D), _f(d, 4, BT, self.xz_ld)       # a gate's masked per-step inputs
+            # a gate's masked per-step inputs.  xm_d's rows are padded to xz_ld floats and the projection GEMM reads whole float4s of
+            # a row: the padding columns must be ZERO (they meet the kernel's label rows), which clv_dropout_rows never writes --
+            # torch.empty here passed every test on a fresh device and failed behind any process that had left other bytes there
+            self.xm_e = _f(d, 4, BT, D)
+            self.xm_d = torch.zeros(4, BT, self.xz_ld, dtype=torch.float32, device=d)
             self.wm_e, self.wm_d = _f(d, 4, B, Cn), _f(d, 4, B, Cn)                # ... and masked label rows
             self.dxg, self.dwg = _f(d, BT, self.xz_ld), _f(d, B, Cn)               # a gate's share of dL/d[Xp | Z], dL/dW
 
