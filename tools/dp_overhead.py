@@ -34,7 +34,7 @@ def main():
     w = bench.WORKLOADS[args.workload]
     B = w['B']
     modes = {'single': {}, 'split0': {'CLV_FORCE_DP_GRAPHS': '1'},
-             'split': {'CLV_FORCE_DP_GRAPHS': '1', 'CLV_DP_REAL_COLLECTIVES': '1'},
+             'split': {'CLV_FORCE_DP_GRAPHS': '1', 'CLV_DP_REAL_COLLECTIVES': '1', 'CLV_CAPTURE_COLLECTIVES': '0'},
              'whole': {'CLV_FORCE_DP_GRAPHS': '1', 'CLV_DP_REAL_COLLECTIVES': '1', 'CLV_CAPTURE_COLLECTIVES': '1'}}
     keys = sorted({k for m in modes.values() for k in m})
     steps = {}
