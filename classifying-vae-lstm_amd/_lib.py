@@ -61,6 +61,11 @@ class LabelStage(C.Structure):
                 ("w_src", _p), ("w_out", _p), ("X8", _p), ("Xh8", _p)]
 
 
+class FrameProj(C.Structure):
+    """clv_frame_proj (include/clvae.h)."""
+    _fields_ = [("T", C.c_int32), ("N", C.c_int32), ("ldo", C.c_int32), ("K_cur", _p), ("out_cur", _p), ("K_hist", _p), ("out_hist", _p)]
+
+
 class WgradProblem(C.Structure):
     """clv_wgrad_problem (include/clvae.h)."""
     _fields_ = [("K", C.c_int32), ("N", C.c_int32),
@@ -173,7 +178,8 @@ SIGNATURES = {
                                 _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "clv_vrnn_label_fwd_x": (_i, [_i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                  _p, _p, _p]),
+                                  _p, _p, _p, _p]),
+    "clv_vrnn_label_fwd_x_proj_supported": (_i, [_i, _i, _i, _i, _i]),
     "clv_vrnn_label_fwd_parts": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _p, _p]),
     "clv_dense_window_fwd_bf16_supported": (_i, [_i, _i, _i, _i, _i]),

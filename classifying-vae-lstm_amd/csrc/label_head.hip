@@ -180,20 +180,19 @@ struct LabelFwdXArgs {
     unsigned char* X8; unsigned char* Xh8;      // not null: the rows are copied as BYTES ([B, nx] each) instead of widened into X / Xh
   } stage;
 };
-__global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax) {
-  __shared__ float2 part[16][64];
-  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
+// the workgroup of batch row b (of a.B such workgroups in the launch)
+__device__ __forceinline__ void label_fwd_x_block(const LabelFwdXArgs& ax, const int b, float2 (*part)[64], float* s_h, float* s_wargs,
+                                                  float* s_w) {
   const LabelFwdArgs& a = ax.l;
   const int tid = threadIdx.x, lane = tid & 63;
   if (ax.pack.out) {
     // by-product: the pair LSTM kernels' lane-order weight pack (clv_lstm_pair_pack), a few elements per thread; the pair
     // forward kernel is the next launch but one and nothing in this kernel reads the pack
-    for (int i = blockIdx.x * 1024 + tid; i < PK_TOTAL; i += gridDim.x * 1024)
+    for (int i = b * 1024 + tid; i < PK_TOTAL; i += a.B * 1024)
       ax.pack.out[i] = pair_pack_element(i, ax.pack.L, ax.pack.U_e, ax.pack.U_d, ax.pack.Kz, ax.pack.Wz,
                                          [](const float* p) { return *p; });
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
   const int n2 = a.D / 2;
   const int lc = min(lane, n2 - 1);
   const float2* K2 = reinterpret_cast<const float2*>(ax.Kh);
@@ -291,6 +290,203 @@ __global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax
   }
   __syncthreads();
   label_fwd_row<1024>(a, b, tid, s_h, s_wargs, s_w, oh_row);
+}
+
+__global__ __launch_bounds__(1024) void vrnn_label_fwd_x_kernel(LabelFwdXArgs ax) {
+  __shared__ float2 part[16][64];
+  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
+  label_fwd_x_block(ax, (int)blockIdx.x, part, s_h, s_wargs, s_w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The label launch with the LSTMs' frame projections as its second half (round 6): x_t . K_x of the encoder and
+// x_{t-1} . K_x of the decoder (cl_vrnn/model.py:193-196, 218-226; sparse_proj.hip has the product and its reasons) for the
+// SAME mini-batch rows, read from the byte stores through the same clv_label_stage, so the product does not wait for the
+// label workgroups' copy of the batch.  Why one launch: the label path is a chain of L2 round trips (waves parked 3/4 of
+// the time), the projection is bound by its 92 MB of stores, and as two launches of a graph they run one after the other
+// (24 + 23 us at configuration 3; as parallel branches of the graph too -- hipGraph puts them on one queue; as two streams
+// they DO overlap: profiles/r06_front_overlap.txt).  Here workgroups 0..B-1 are the label rows and the rest projection
+// workgroups; both kinds fit a CU together (16 waves each, <= 64 registers, 13 + 62 KB of LDS), which is why a projection
+// workgroup holds HALF of the kernel's columns (176 of 352: 62 KB) where sparse_proj_kernel holds all of them.
+// Results: bit for bit those of vrnn_label_fwd_x_kernel and sparse_proj_kernel (same sums in the same order).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int FP_RMAX = 64;        // batch rows per projection workgroup
+constexpr int FP_NC = 4;           // output columns per lane, consecutive (half of N <= 256: 176 = 44 lanes x 4)
+#ifndef FP_PF
+#define FP_PF 4                    // frames of a wave whose bytes are in flight
+#endif
+#ifndef FP_ROUND
+#define FP_ROUND 1                 // notes per round of LDS reads
+#endif
+#ifndef FP_ABL
+#define FP_ABL 0                   // measurement builds (wrong results): 1 = no output stores, 2 = no note loop, 3 = frames not loaded after the first
+#endif
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct FrameProjArgs {
+  int T, N, ldo, wgs, nset;        // wgs: workgroups per (projection, column half)
+  const float* K[2];               // [D, N]: 0 = over the current frames, 1 = over the history frames
+  float* out[2];                   // [B*T, ldo]
+};
+
+__device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const FrameProjArgs& fp, const int u, float* Kl,
+                                                 const unsigned char** rowp) {
+  const LabelFwdXArgs::Stage& g = ax.stage;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = u / fp.wgs, w = u - grp * fp.wgs;
+  const bool second = grp >= 2;
+  const int nf = ax.l.D, B = ax.l.B;
+  const int nch = fp.N / 2, c0 = (grp & 1) * nch;
+  const float* K = second ? fp.K[1] : fp.K[0];
+  float* out = second ? fp.out[1] : fp.out[0];
+  {   // this half of the kernel's columns -> LDS [nf][nch]
+    const int q4 = nch / 4, nv = nf * q4;
+    float4* dst = reinterpret_cast<float4*>(Kl);
+    for (int i0 = tid; i0 < nv; i0 += 4 * 1024) {       // 4 loads in flight per thread
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = min(i0 + q * 1024, nv - 1), k = e / q4;
+        v[q] = *reinterpret_cast<const float4*>(K + (size_t)k * fp.N + c0 + 4 * (e - k * q4));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i0 + q * 1024 < nv) dst[i0 + q * 1024] = v[q];
+    }
+  }
+  // this workgroup's batch rows b = w, w + wgs, ..: where their frames are (the label workgroups resolve the same addresses)
+  const int nrows = w < B ? (B - w + fp.wgs - 1) / fp.wgs : 0;
+  if (tid < nrows) {
+    const int b = w + tid * fp.wgs;
+    long long base = 0;
+    if (g.step_dev) {
+      int j = (*g.step_dev - g.step0) % g.period;
+      j = j < 0 ? j + g.period : j;
+      base = (long long)j * g.cur_s + g.cur_o;
+    }
+    const long long sr = g.idx ? g.idx[base + b] : g.row0 + base + b;
+    rowp[tid] = second ? g.hist + (g.hist_table ? g.hist_table[sr] : sr) * g.hist_stride + g.hist_offset
+                       : g.cur + (g.cur_table ? g.cur_table[sr] : sr) * g.cur_stride + g.cur_offset;
+  }
+  __syncthreads();
+  const int nq = nrows * fp.T;                            // frames of this workgroup, row after row
+  if (nq == 0) return;
+  // lane l < nch / 4 owns columns 4 l .. 4 l + 3: one 16-byte LDS read per note, four FMAs, one 16-byte store per frame (the
+  // kernel is bound by the vector instructions it issues, 16 + 16 waves on a CU: tools/front_timeline.py with FP_ROUND > 1)
+  const int colb = min(lane, nch / 4 - 1) * 4;
+  const unsigned vo = lane < nch / 4 ? (unsigned)lane * 16u : 0x80000000u;
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)B * fp.T * fp.ldo * 4), 0x00020000);
+  const int k0 = min(lane, nf - 1), k1 = min(lane + 64, nf - 1);
+  const bool v0 = lane < nf, v1 = lane + 64 < nf;
+  // a frame's two inputs of this lane, as the BYTES they are: widened where they are used (a conversion here makes the
+  // compiler wait for the load at once, which is what sparse_proj_kernel's byte instance did until round 6)
+  // (loaded as the aligned dword that holds the byte -- frames start on 4-byte boundaries -- and extracted at the use)
+  typedef const __attribute__((address_space(1))) unsigned* gwords;
+  const int w0 = k0 >> 2, w1 = k1 >> 2, sh0 = 8 * (k0 & 3), sh1 = 8 * (k1 & 3);
+  auto frame = [&](int ri, int t, unsigned& x0, unsigned& x1) {
+    gwords bp = (gwords)(rowp[ri] + (size_t)t * nf);
+    x0 = bp[w0]; x1 = bp[w1];
+  };
+  // This wave's frames are q = wave, wave + 16, .. of the nq.  A frame's bytes are requested FP_PF of the wave's frames ahead:
+  // with one frame ahead (sparse_proj_kernel) an iteration lasts one global load (~1.2 us measured, for ~0.3 us of work).
+  auto advance = [&](int& r_, int& t_) { t_ += 16; while (t_ >= fp.T) { t_ -= fp.T; ++r_; } };
+  int ri = wave / fp.T, t = wave - ri * fp.T;             // (row, frame) being computed ...
+  int ra = ri, ta = t;                                    // ... and being requested
+  unsigned qx0[FP_PF], qx1[FP_PF];
+#pragma unroll
+  for (int j = 0; j < FP_PF; ++j) {
+    const bool ok = wave + 16 * j < nq;                   // (unconditional loads, clamped to frame 0 of the workgroup: a load
+    frame(ok ? ra : 0, ok ? ta : 0, qx0[j], qx1[j]);      // under a condition is waited for where it is issued)
+    // (as many stores -- out of range, dropped -- as a loop iteration has: the loop's first wait is the minimum over both ways
+    // into the loop of the operations issued since the request, and without these that minimum is the prologue's)
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, r_out, (int)0x80000000u, 0, 0);
+    advance(ra, ta);
+  }
+  for (int qb = wave; qb < nq; qb += 16 * FP_PF) {
+#pragma unroll
+    for (int j = 0; j < FP_PF; ++j) {
+      const int q = qb + 16 * j;
+      const bool live = q < nq;                           // (no break: the slots keep their registers)
+      const float fx0 = (float)((qx0[j] >> sh0) & 0xffu), fx1 = (float)((qx1[j] >> sh1) & 0xffu);
+      const bool more = q + 16 * FP_PF < nq;
+      if (FP_ABL != 3) frame(more ? ra : 0, more ? ta : 0, qx0[j], qx1[j]);
+      advance(ra, ta);
+      unsigned long long m0 = __ballot(live && v0 && fx0 != 0.f), m1 = __ballot(live && v1 && fx1 != 0.f);
+      float acc[FP_NC];
+#pragma unroll
+      for (int c = 0; c < FP_NC; ++c) acc[c] = 0.f;
+      // the notes that are on, ascending (the sums are sparse_proj_kernel's, term by term), FP_ROUND per round: their kernel
+      // rows' LDS reads are in flight together
+      auto rounds = [&](unsigned long long m, const float fx, const int kbase) {
+        while (m) {
+          float v[FP_ROUND], kv[FP_ROUND][FP_NC];
+          bool on[FP_ROUND];
+#pragma unroll
+          for (int r = 0; r < FP_ROUND; ++r) {
+            on[r] = m != 0;
+            const int k = on[r] ? __builtin_ctzll(m) : 0;
+            m &= m - 1;                                    // (0 stays 0)
+            v[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), k));
+            const float4 k4 = *reinterpret_cast<const float4*>(Kl + (kbase + k) * nch + colb);
+            kv[r][0] = k4.x; kv[r][1] = k4.y; kv[r][2] = k4.z; kv[r][3] = k4.w;
+          }
+#pragma unroll
+          for (int r = 0; r < FP_ROUND; ++r)
+#pragma unroll
+            for (int c = 0; c < FP_NC; ++c) acc[c] = (r == 0 || on[r]) ? fmaf(v[r], kv[r][c], acc[c]) : acc[c];
+        }
+      };
+      if (FP_ABL != 2) {
+        rounds(m0, fx0, 0);
+        rounds(m1, fx1, 64);
+      } else {
+        acc[0] = fx0; acc[1] = fx1;
+      }
+      // buffer stores, lanes without a column (and frames beyond the last) at an out-of-range offset: no branch around a
+      // store, so the number of memory operations between a request and its use is fixed and the wait in front of the use
+      // is a counted one (behind `if`s the compiler must assume the stores were skipped and waits for the newest of them)
+      const unsigned so = (unsigned)(((w + ri * fp.wgs) * fp.T + t) * fp.ldo + c0) * 4u;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(unsigned, acc[0]), __builtin_bit_cast(unsigned, acc[1]),
+                                                      __builtin_bit_cast(unsigned, acc[2]), __builtin_bit_cast(unsigned, acc[3])},
+                                             r_out, (int)((live && FP_ABL != 1) ? vo : 0x80000000u), (int)so, 0);
+      advance(ri, t);
+    }
+  }
+}
+
+// -DFRONT_STAMPS (tools/front_timeline.py): where and when each workgroup ran -- HW_ID / XCC_ID and the 100 MHz clock at its
+// start and end
+#ifdef FRONT_STAMPS
+__device__ unsigned long long g_front_wg[2048][4];
+#define FRONT_STAMP(k)                                                                                               \
+  do {                                                                                                               \
+    __syncthreads();                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {                                                                     \
+      unsigned long long t__;                                                                                        \
+      unsigned hw__, xcc__;                                                                                          \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__));                                          \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                                             \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));                                           \
+      g_front_wg[blockIdx.x][k] = t__;                                                                               \
+      g_front_wg[blockIdx.x][2] = hw__; g_front_wg[blockIdx.x][3] = xcc__;                                           \
+    }                                                                                                                \
+  } while (0)
+#else
+#define FRONT_STAMP(k)
+#endif
+
+// Two of these workgroups must fit a CU (a label row beside a projection workgroup): 16 waves each = 8 per SIMD, which the
+// hardware admits up to 64 VGPRs and ~80 SGPRs per wave (800 SGPRs per SIMD: tools/probes/coreside_probe.hip -- at 83 the
+// second workgroup waits for the first, measured) -- hence the SGPR cap (the compiler moves what does not fit to a VGPR's lanes).
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void vrnn_front_kernel(LabelFwdXArgs ax, FrameProjArgs fp) {
+  __shared__ float2 part[16][64];
+  __shared__ float s_h[128], s_wargs[2 * LH_MAXC], s_w[LH_MAXC];
+  __shared__ const unsigned char* rowp[FP_RMAX];
+  extern __shared__ __attribute__((aligned(16))) float fp_kl[];
+  FRONT_STAMP(0);
+  if ((int)blockIdx.x < ax.l.B) label_fwd_x_block(ax, (int)blockIdx.x, part, s_h, s_wargs, s_w);
+  else frame_proj_block(ax, fp, (int)blockIdx.x - ax.l.B, fp_kl, rowp);
+  FRONT_STAMP(1);
 }
 
 // The same with X . Kh handed in as split-K partial sums (ax.part: dense_window_fwd_bf16_kernel, outer_bf16.hip).  Summing a
@@ -400,12 +596,14 @@ extern "C" int clv_vrnn_label_bwd(int B, int D, int C, int G4, const float* dzsu
   return st;
 }
 
+extern "C" int clv_vrnn_label_fwd_x_proj_supported(int B, int D, int nx, int T, int N);
+
 static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh, const float* part,
                               int splits, const clv_label_stage* stage, const float* bh, float* hW_out, const float* Ka, const float* ba,
                               float* eps, const float* onehot, float prior_logvar,
                               const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                               float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                              const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+                              const clv_noise_draw* noise, const clv_pair_pack_src* pack, const clv_frame_proj* proj, void* stream) {
   if (pack && (pack->H != LH || !clv_lstm_pair_supported(pack->H, pack->L) || !pack->U_enc || !pack->U_dec || !pack->Kz ||
                !pack->Wz || !pack->pack || ((uintptr_t)pack->pack) % 16))
     return CLV_EINVAL;
@@ -448,10 +646,50 @@ static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int l
     a.l.noise.step_dev = noise->step_dev;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (proj) {         // the frame projections ride along: vrnn_front_kernel
+    if (!clv_vrnn_label_fwd_x_proj_supported(B, D, nx, proj->T, proj->N) || !stage || !stage->X8 || part || proj->ldo < proj->N ||
+        (size_t)B * proj->T * proj->ldo * 4 >= ((size_t)1 << 31) || proj->ldo % 4 || ((uintptr_t)proj->out_cur) % 16 || ((uintptr_t)proj->out_hist) % 16 ||
+        !proj->K_cur || !proj->out_cur || ((uintptr_t)proj->K_cur) % 16 || (proj->K_hist && (!proj->out_hist || !stage->hist ||
+        ((uintptr_t)proj->K_hist) % 16)))
+      return CLV_EINVAL;
+    FrameProjArgs fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.T = proj->T; fp.N = proj->N; fp.ldo = proj->ldo; fp.nset = proj->K_hist ? 2 : 1;
+    fp.K[0] = proj->K_cur; fp.out[0] = proj->out_cur; fp.K[1] = proj->K_hist; fp.out[1] = proj->out_hist;
+    // one projection workgroup per CU in all (each CU then holds one label row and one projection workgroup), no more of
+    // them than batch rows, no more than FP_RMAX rows each
+    const int groups = 2 * fp.nset;
+    int wgs = 256 / groups;
+    wgs = wgs > B ? B : wgs;
+    const int need = (B + FP_RMAX - 1) / FP_RMAX;
+    wgs = wgs < need ? need : wgs;
+    fp.wgs = wgs;
+    size_t lds = (size_t)D * (proj->N / 2) * sizeof(float);
+#ifdef FRONT_STAMPS
+    if (const char* e = getenv("CLV_EXP_FRONT_LDS")) lds = (size_t)atoi(e);      // placement experiments (wrong results below the real size)
+#endif
+    if (int e = clv::allow_dynamic_lds(reinterpret_cast<const void*>(vrnn_front_kernel), 64 * 1024)) return e;
+    ProfScope p("vrnn_front", s);
+    hipLaunchKernelGGL(vrnn_front_kernel, dim3(B + groups * wgs), dim3(1024), lds, s, a, fp);
+    return launch_status();
+  }
   ProfScope p("vrnn_label_fwd", s);
   if (part) hipLaunchKernelGGL(vrnn_label_fwd_parts_kernel, dim3(B), dim3(LH_T), 0, s, a);
   else hipLaunchKernelGGL(vrnn_label_fwd_x_kernel, dim3(B), dim3(1024), 0, s, a);
   return launch_status();
+}
+
+#ifdef FRONT_STAMPS
+extern "C" int clv_debug_front_wg(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_front_wg), sizeof(unsigned long long) * 2048 * 4);
+}
+#endif
+
+// proj of clv_vrnn_label_fwd_x: frames of D <= 128 bytes (a multiple of 4), T of them per batch row (nx = T * D), N = 4H output columns in two
+// halves of <= 256, half a kernel (D * N / 2 floats) in 64 KB of LDS
+extern "C" int clv_vrnn_label_fwd_x_proj_supported(int B, int D, int nx, int T, int N) {
+  return B >= 1 && D >= 4 && D <= 128 && D % 4 == 0 && T >= 1 && (long long)T * D == nx && N >= 8 && N % 8 == 0 && N / 2 <= 64 * clv::FP_NC &&      /* (and ldo, the outputs 16-byte aligned: the launcher) */
+         (size_t)D * (N / 2) * sizeof(float) <= 64 * 1024;
 }
 
 extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,
@@ -460,12 +698,14 @@ extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X,
                                     float* eps, const float* onehot, float prior_logvar,
                                     const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                                     float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                                    const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
+                                    const clv_noise_draw* noise, const clv_pair_pack_src* pack, const clv_frame_proj* proj,
+                                    void* stream) {
   if (stage)      // the launch assembles its mini-batch rows itself: X = stage->X is an output, the labels come from stage->w_src
     return label_fwd_x_launch(B, D, C, G4, stage->X, ldx, nx, Kh, nullptr, 0, stage, bh, hW_out, Ka, ba, eps, stage->w_src,
-                              prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
+                              prior_logvar, Kenc_w, benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, proj, stream);
+  if (proj) return CLV_EINVAL;       // the projections read the byte stores a stage names
   return label_fwd_x_launch(B, D, C, G4, X, ldx, nx, Kh, nullptr, 0, nullptr, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w, benc,
-                            Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
+                            Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, nullptr, stream);
 }
 
 extern "C" int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float* part, int splits,
@@ -476,6 +716,6 @@ extern "C" int clv_vrnn_label_fwd_parts(int B, int D, int C, int G4, const float
                                         const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream) {
   if (!part) return CLV_EINVAL;
   return label_fwd_x_launch(B, D, C, G4, nullptr, 0, 0, nullptr, part, splits, nullptr, bh, hW_out, Ka, ba, eps, onehot, prior_logvar, Kenc_w,
-                            benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, stream);
+                            benc, Kdec_w, bdec, wargs, W, rowloss, rb_enc, rb_dec, noise, pack, nullptr, stream);
 }
 

@@ -7,6 +7,7 @@
 // frame's nonzero inputs.  Exact for any float input (a dense frame just costs nx row additions); summation
 // order = ascending input index, like the dense product.
 #include "common.h"
+#include <type_traits>
 
 namespace clv {
 
@@ -66,16 +67,18 @@ __global__ __launch_bounds__(SP_NT) void sparse_proj_kernel(SparseProjArgs g) {
   for (int c = 0; c < SP_NC; ++c) colo[c] = min(lane + 64 * c, a.N - 1);
   const int k0 = min(lane, a.nx - 1), k1 = min(lane + 64, a.nx - 1);
   const bool v0 = lane < a.nx, v1 = lane + 64 < a.nx;
-  // a frame's two inputs of this lane (byte frames: widened here; a byte IS its float value)
-  auto frame = [&](int f, float& x0, float& x1) {
+  // a frame's two inputs of this lane, as loaded (byte frames: the bytes, widened where they are USED -- a byte IS its float
+  // value; converted here, the compiler waits for the load at once and the request one frame ahead hides nothing: round 6)
+  typedef typename std::conditional<XU8, unsigned, float>::type raw_t;
+  auto frame = [&](int f, raw_t& x0, raw_t& x1) {
     const size_t o = (size_t)min(f, a.R - 1) * a.ldx;
-    if (XU8) { const unsigned char* bp = static_cast<const unsigned char*>(a.X) + o; x0 = (float)bp[k0]; x1 = (float)bp[k1]; }
+    if constexpr (XU8) { const unsigned char* bp = static_cast<const unsigned char*>(a.X) + o; x0 = bp[k0]; x1 = bp[k1]; }
     else { const float* fp = static_cast<const float*>(a.X) + o; x0 = fp[k0]; x1 = fp[k1]; }
   };
-  float nx0, nx1;
+  raw_t nx0, nx1;
   frame(first + wave, nx0, nx1);
   for (int f = first + wave; f < last; f += SP_NW) {
-    const float fx0 = nx0, fx1 = nx1;
+    const float fx0 = (float)nx0, fx1 = (float)nx1;
     frame(f + SP_NW, nx0, nx1);                           // next frame of this wave (clamped, unconditional)
     unsigned long long m0 = __ballot(v0 && fx0 != 0.f), m1 = __ballot(v1 && fx1 != 0.f);
     float acc[SP_NC];

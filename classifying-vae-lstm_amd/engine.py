@@ -79,6 +79,7 @@ SWITCHES = {
     'fuse_latent':    ('CLV_FUSE_LATENT',      True,  "the latent head as GEMM + pointwise launches instead of csrc/latent_head.hip"),
     'lstm_mx':        ('CLV_USE_MX',           True,  "large batches on the generic chain instead of csrc/lstm_mx.hip"),
     'frames_u8':      ('CLV_FRAMES_U8',        True,  "the large-batch step widens its byte batch to float (rounds 4-5) instead of reading bytes"),
+    'front_fused':    ('CLV_FRONT_FUSED',      True,  "the frame projections as a launch of their own behind the label launch instead of workgroups of it (csrc/label_head.hip: vrnn_front_kernel)"),
     'fine_grid':      ('CLV_FINE_GRID',        False, "twice the workgroups, half the rows each, for the LSTM kernel gradients (what tune_dp_schedule may pick next to an all-reduce)"),
     'fuse_notes':     ('CLV_FUSE_NOTES',       False, "input projections gathered inside the pair forward from note lists (+48 us on MI355X: profiles/r03_notes_fusion_ab.txt)"),
 }
@@ -423,6 +424,7 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
         self.use_mx = sw('lstm_mx') and not self.fuse_pair and not self.dropout and self.sparse_inputs \
             and ops.lstm_mx_supported(B, D, L, H)
         self.frames_u8 = sw('frames_u8')
+        self.front_fused = sw('front_fused')
         # notes_valid: the note lists describe the frames now in X / XZ (TrainStep sets it per staged batch)
         self.fuse_notes = sw('fuse_notes') and self.fuse_pair and self.sparse_inputs and D == ops.NOTE_NONE
         self.notes_valid = False
@@ -612,7 +614,7 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
             not (self.dense_hw_fwd and ops.dense_window_fwd_bf16_supported(self.B, self.cfg['T'] * self.cfg['D'], self.cfg['D'],
                                                                          self.cfg['T'] * self.cfg['D'], self.cfg['D']))
 
-    def _label_forward(self, X, eps_W, w_true, pack=None, stage=None):
+    def _label_forward(self, X, eps_W, w_true, pack=None, stage=None, proj=None):
         """Label path (:174-191): hW Dense layer over the flattened window, Wargs head, logistic-normal sample, label
         losses and both per-row LSTM biases (W.K_w + b).  One launch when the window is handled sparsely."""
         cfg, P, B = self.cfg, self.P, self.B
@@ -632,7 +634,7 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
                     self.ws_hw = ops.Workspace(self.device)
                 parts = ops.dense_window_fwd_bf16(B, T * D, D, X, T * D, P.p('hW/kernel'), D, self.ws_hw)
             ops.vrnn_label_fwd_x(B, D, Cn, G4, X, T * D, T * D, P.p('hW/kernel'), P.p('hW/bias'), self.hW, *tail,
-                                 noise=nz[0] if nz else None, pack=pack, parts=parts, stage=stage)
+                                 noise=nz[0] if nz else None, pack=pack, parts=parts, stage=stage, proj=proj)
         else:
             ops.gemm(X, P.p('hW/kernel'), self.hW, B, D, T * D, bias=P.p('hW/bias'), act=ACT_RELU, ws=self.ws)
             ops.vrnn_label_fwd(B, D, Cn, G4, self.hW, *tail)
@@ -679,10 +681,18 @@ class VrnnEngine(VrnnDropout, VrnnGenerate, _EngineBase):
         f8 = self._f8
         if f8 is not None and stage is None:
             raise ValueError("frames8 on the pair path: the byte batch is what the label launch's own stage leaves (ops.label_stage)")
+        # the frame projections inside the label launch (csrc/label_head.hip: vrnn_front_kernel), from the byte stores the stage names
+        proj = None
+        if stage is not None and f8 is not None and self.front_fused and self.sparse_inputs and not self.fuse_notes and \
+                ops.vrnn_label_fwd_x_proj_supported(B, D, T * D, T, G4):
+            proj = (T, G4, P.p('encoder_h/kernel'), self.gates_enc, P.p('decoder_h/kernel') if off else None,
+                    self.gates_dec if off else None)
         if stage is not None:
-            self._label_forward(X, eps_W, w_true, pack=pack, stage=stage)
+            self._label_forward(X, eps_W, w_true, pack=pack, stage=stage, proj=proj)
         notes = None
-        if self.fuse_notes and self.notes_valid:      # the projections are gathered inside the pair kernel
+        if proj is not None:
+            pass
+        elif self.fuse_notes and self.notes_valid:      # the projections are gathered inside the pair kernel
             notes = (self.notes_enc, P.p('encoder_h/kernel'), self.notes_dec if off else None,
                      P.p('decoder_h/kernel') if off else None)
         elif self.sparse_inputs:     # piano-roll frames are ~4 % nonzero: add the kernel rows of the notes that are on

@@ -507,12 +507,24 @@ def label_stage(cur, hist, idx, row0, cursor, X, Xh, hist_chunk, hist_ld, w_src,
     return g
 
 
+def vrnn_label_fwd_x_proj_supported(B, D, nx, T, N):
+    return bool(_lib.lib().clv_vrnn_label_fwd_x_proj_supported(B, D, nx, T, N))
+
+
 def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, onehot, prior, Kenc_w, benc, Kdec_w, bdec, wargs,
-                     W, rowloss, rb_enc, rb_dec, noise=None, pack=None, parts=None, stage=None):
+                     W, rowloss, rb_enc, rb_dec, noise=None, pack=None, parts=None, stage=None, proj=None):
     """hW = relu(X . Kh + bh) over the nonzero inputs of each row, then vrnn_label_fwd, one workgroup per row.
     noise: a noise_draw(): eps is drawn in the kernel (and written to `eps`) instead of read.
     pack = (L, U_enc, U_dec, Kz, Wz, out): the launch also writes the pair LSTM kernels' weight pack (lstm_pair_pack).
-    parts = (buffer, splits): X . Kh was formed by dense_window_fwd_bf16 as split-K partial sums; X / Kh are not read."""
+    parts = (buffer, splits): X . Kh was formed by dense_window_fwd_bf16 as split-K partial sums; X / Kh are not read.
+    proj = (T, N, K_cur, out_cur, K_hist or None, out_hist or None): the launch also forms the LSTMs' frame projections of the
+    staged rows (sparse_proj2's outputs bit for bit; needs a stage with bytes_out)."""
+    pj = None
+    if proj is not None:
+        if stage is None or parts is not None:
+            raise ValueError("proj rides on a stage (the byte stores it names), not on parts")
+        T_, N_, kc, oc, kh, oh = proj
+        pj = _lib.FrameProj(int(T_), int(N_), int(N_), _ptr(kc), _ptr(oc), _ptr(kh), _ptr(oh))
     ps = None
     if pack is not None:
         L_, ue, ud, kz, wz, out = pack
@@ -524,7 +536,7 @@ def vrnn_label_fwd_x(B, D, Cn, G4, X, ldx, nx, Kh, bh, hW_out, Ka, ba, eps, oneh
         check(_lib.lib().clv_vrnn_label_fwd_parts(B, D, Cn, G4, _ptr(parts[0]), int(parts[1]), *tail), "clv_vrnn_label_fwd_parts")
     else:      # stage = a label_stage(): the launch assembles the mini-batch rows itself (X, history frames, labels)
         check(_lib.lib().clv_vrnn_label_fwd_x(B, D, Cn, G4, _ptr(X), ldx, nx, _ptr(Kh), C.byref(stage) if stage is not None else None,
-                                              *tail), "clv_vrnn_label_fwd_x")
+                                              *tail[:-1], C.byref(pj) if pj is not None else None, tail[-1]), "clv_vrnn_label_fwd_x")
 
 
 def dense_window_fwd_bf16_supported(Bn, nx, N, ldx, ldk):

@@ -93,6 +93,18 @@ typedef struct clv_label_stage {
                                             * later launches read frames as bytes (x_u8 / y_u8 / CLV_FRAMES_U8) */
 } clv_label_stage;
 
+/* clv_vrnn_label_fwd_x(proj != NULL; needs stage with X8): the launch ALSO forms the LSTMs' frame projections of the same
+ * mini-batch (clv_sparse_proj2's product, bit for bit) -- out_cur[b * T + t, :N] = frame t of the current row b . K_cur
+ * ([D, N]), out_hist likewise over the history rows and K_hist (NULL: none) -- in workgroups of their own that read the byte
+ * stores through the stage and run beside the label rows' workgroups on the same CUs (the label path waits on L2 round trips,
+ * the projection on its stores: configuration 3, 24 + 23 us as two launches, 33 us as one).  A frame is D bytes, nx = T * D;
+ * clv_vrnn_label_fwd_x_proj_supported says which shapes.  cl_vrnn/model.py:193-196, 218-226. */
+typedef struct clv_frame_proj {
+  int32_t T, N, ldo;
+  const float* K_cur; float* out_cur;
+  const float* K_hist; float* out_hist;
+} clv_frame_proj;
+
 /* ABI version = CLV_ABI_VERSION of the header the library was built from.  It changes whenever an existing entry point
  * changes its argument list or the size / meaning of a buffer (a caller built against an older header would still resolve
  * the symbol): the binding compares it at load time and refuses a mismatch.
@@ -483,7 +495,10 @@ int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, i
                          float* eps, const float* onehot, float prior_logvar,
                          const float* Kenc_w, const float* benc, const float* Kdec_w, const float* bdec,
                          float* wargs, float* W, float* rowloss, float* rb_enc, float* rb_dec,
-                         const clv_noise_draw* noise, const clv_pair_pack_src* pack, void* stream);
+                         const clv_noise_draw* noise, const clv_pair_pack_src* pack,
+                         const clv_frame_proj* proj,        /* NULL, or the LSTMs' frame projections in the same launch: clv_frame_proj */
+                         void* stream);
+int clv_vrnn_label_fwd_x_proj_supported(int B, int D, int nx, int T, int N);
 /* The hW layer's product as a DENSE one on the bf16 matrix cores, for inputs that are exactly representable in bf16 (the
  * caller's promise: 0/1 piano-roll frames, any uint8 value): part[c][b][:N] = sum over the inputs i of chunk c of
  * X[b,i] K[i,:], c < clv_dense_window_fwd_bf16_splits(Bn, nx) (split-K: the output is only [Bn,N]); X is one bf16 piece, K

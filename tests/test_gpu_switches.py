@@ -84,6 +84,7 @@ def test_switch_in_its_other_position_still_follows_the_oracle(dev, key):
 # position, three captured steps fed by the bound-batch cursor against an oracle loop with the Philox noise of the same keys.
 TRAIN_SWITCHES = [
     {'CLV_STAGE_IN_LABEL': '0'},                                   # the gather launch instead of the assembly inside the label launch
+    {'CLV_FRONT_FUSED': '0'},                                      # the frame projections as a launch of their own behind the label launch
     {'CLV_FAST_ADAM': '0'},                                        # the five-launch Adam-WN chain instead of the two-launch form
     {'CLV_FORCE_DP_GRAPHS': '1'},                                  # the data-parallel schedule (no-op collectives) on one GPU
     {'CLV_FORCE_DP_GRAPHS': '1', 'CLV_DP_EAGER_UPDATE': '0'},      # ... with the optimizer pieces as graphs of their own

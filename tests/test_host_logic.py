@@ -357,7 +357,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
              'AdamKnownSums': 'clv_adam_known_sums', 'ParamDesc': 'clv_param_desc', 'GemmProb': 'clv_gemm_prob',
              'ReduceJob': 'clv_reduce_job', 'SkinnyProduct': 'clv_skinny_product', 'LabelBwdRider': 'clv_label_bwd_rider',
              'ProfRecord': 'clv_prof_record', 'BatchCursor': 'clv_batch_cursor',
-             'WgradProblem': 'clv_wgrad_problem', 'LabelStage': 'clv_label_stage'}
+             'WgradProblem': 'clv_wgrad_problem', 'LabelStage': 'clv_label_stage', 'FrameProj': 'clv_frame_proj'}
     # every Structure of the module is covered
     mirrored = {n for n in dir(lib_py) if isinstance(getattr(lib_py, n), type) and issubclass(getattr(lib_py, n), C.Structure)
                 and getattr(lib_py, n) is not C.Structure}
