@@ -245,14 +245,20 @@ __device__ __forceinline__ void label_fwd_x_block(const LabelFwdXArgs& ax, const
   // wave pays one L2 round trip per PAIR of chunks (a window row has 176 chunks, 11 per wave).  (Four chunks per iteration,
   // 16 rows in flight per lane: 74 registers instead of 62, i.e. one workgroup per CU instead of two, and slower -- 24.9 us
   // against 22.8 at configuration 3, 131 against 119 at configuration 5.)
-  auto xload = [&](int ch) {
-    if (ch >= nchunk) return 0.f;
-    const int i = min(ch * 64 + lane, ax.nx - 1);
-    return xbytes ? (float)xbytes[i] : xr[i];
+  // The chunks are requested a round ahead as they lie in memory -- a byte as the aligned dword that holds it (the rows start on
+  // 4-byte boundaries) -- and made floats where they are USED: a conversion (or a branch) at the load makes the compiler wait
+  // for it on the spot, and the round ahead hid nothing (rounds 3-5: two L2 round trips per iteration instead of one).
+  // Unconditional: past the row's last chunk the last one is read again and not used.
+  typedef const __attribute__((address_space(1))) unsigned* gwords;
+  auto xload = [&](int ch) -> unsigned {
+    const int i = min(min(ch, nchunk - 1) * 64 + lane, ax.nx - 1);
+    return xbytes ? ((gwords)xbytes)[i >> 2] : __builtin_bit_cast(unsigned, xr[i]);
   };
-  float xa = xload(wave), xb = xload(wave + 16);
+  const int xsh = 8 * (lane & 3);          // (the clamped lanes of a row's last chunk are masked below)
+  auto xval = [&](unsigned raw) { return xbytes ? (float)((raw >> xsh) & 0xffu) : __builtin_bit_cast(float, raw); };
+  unsigned xa = xload(wave), xb = xload(wave + 16);
   for (int ch = wave; ch < nchunk; ch += 32) {
-    const float x0 = xa, x1 = xb;
+    const float x0 = xval(xa), x1 = xval(xb);
     const int j0 = ch * 64, j1 = (ch + 16) * 64;
     xa = xload(ch + 32); xb = xload(ch + 48);
     unsigned long long m0 = __ballot(j0 + lane < ax.nx && x0 != 0.f);
@@ -328,6 +334,27 @@ struct FrameProjArgs {
   float* out[2];                   // [B*T, ldo]
 };
 
+// -DFRONT_STAMPS (tools/front_timeline.py): where and when each workgroup ran -- HW_ID / XCC_ID and the 100 MHz clock at its
+// start and end
+#ifdef FRONT_STAMPS
+__device__ unsigned long long g_front_wg[2048][6];
+#define FRONT_STAMP(k)                                                                                               \
+  do {                                                                                                               \
+    __syncthreads();                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {                                                                     \
+      unsigned long long t__;                                                                                        \
+      unsigned hw__, xcc__;                                                                                          \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__));                                          \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                                             \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));                                           \
+      g_front_wg[blockIdx.x][k < 2 ? k : k + 2] = t__;                                                                \
+      g_front_wg[blockIdx.x][2] = hw__; g_front_wg[blockIdx.x][3] = xcc__;                                           \
+    }                                                                                                                \
+  } while (0)
+#else
+#define FRONT_STAMP(k)
+#endif
+
 __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const FrameProjArgs& fp, const int u, float* Kl,
                                                  const unsigned char** rowp) {
   const LabelFwdXArgs::Stage& g = ax.stage;
@@ -369,6 +396,7 @@ __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const 
                        : g.cur + (g.cur_table ? g.cur_table[sr] : sr) * g.cur_stride + g.cur_offset;
   }
   __syncthreads();
+  FRONT_STAMP(2);                                         // (slot 4: the kernel half and the row addresses are in LDS)
   const int nq = nrows * fp.T;                            // frames of this workgroup, row after row
   if (nq == 0) return;
   // lane l < nch / 4 owns columns 4 l .. 4 l + 3: one 16-byte LDS read per note, four FMAs, one 16-byte store per frame (the
@@ -415,8 +443,11 @@ __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const 
       float acc[FP_NC];
 #pragma unroll
       for (int c = 0; c < FP_NC; ++c) acc[c] = 0.f;
-      // the notes that are on, ascending (the sums are sparse_proj_kernel's, term by term), FP_ROUND per round: their kernel
-      // rows' LDS reads are in flight together
+      // the notes that are on, ascending (the sums are sparse_proj_kernel's, term by term), one LDS round trip each.  What was
+      // tried on this loop, co-running with the label rows (projection workgroups' duration, tools/front_timeline.py): FP_ROUND
+      // notes per round with the absent ones predicated off, 32 -> 39 (2) / 50 us (4); the next note's row requested before
+      // the current one is used (two register sets), 32 -> 34 us.  A wave issues at most one instruction per four cycles and
+      // every variant that hides latency adds instructions: the loop is bound by its instruction count.
       auto rounds = [&](unsigned long long m, const float fx, const int kbase) {
         while (m) {
           float v[FP_ROUND], kv[FP_ROUND][FP_NC];
@@ -453,27 +484,6 @@ __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const 
     }
   }
 }
-
-// -DFRONT_STAMPS (tools/front_timeline.py): where and when each workgroup ran -- HW_ID / XCC_ID and the 100 MHz clock at its
-// start and end
-#ifdef FRONT_STAMPS
-__device__ unsigned long long g_front_wg[2048][4];
-#define FRONT_STAMP(k)                                                                                               \
-  do {                                                                                                               \
-    __syncthreads();                                                                                                 \
-    if (threadIdx.x == 0 && blockIdx.x < 2048) {                                                                     \
-      unsigned long long t__;                                                                                        \
-      unsigned hw__, xcc__;                                                                                          \
-      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__));                                          \
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                                             \
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));                                           \
-      g_front_wg[blockIdx.x][k] = t__;                                                                               \
-      g_front_wg[blockIdx.x][2] = hw__; g_front_wg[blockIdx.x][3] = xcc__;                                           \
-    }                                                                                                                \
-  } while (0)
-#else
-#define FRONT_STAMP(k)
-#endif
 
 // Two of these workgroups must fit a CU (a label row beside a projection workgroup): 16 waves each = 8 per SIMD, which the
 // hardware admits up to 64 VGPRs and ~80 SGPRs per wave (800 SGPRs per SIMD: tools/probes/coreside_probe.hip -- at 83 the
@@ -681,7 +691,7 @@ static int label_fwd_x_launch(int B, int D, int C, int G4, const float* X, int l
 
 #ifdef FRONT_STAMPS
 extern "C" int clv_debug_front_wg(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_front_wg), sizeof(unsigned long long) * 2048 * 4);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(clv::g_front_wg), sizeof(unsigned long long) * 2048 * 6);
 }
 #endif
 

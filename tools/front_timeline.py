@@ -35,9 +35,9 @@ torch.cuda.synchronize()
 fn = _lib.lib().clv_debug_front_wg
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p]
-buf = (ctypes.c_ulonglong * (2048 * 4))()
+buf = (ctypes.c_ulonglong * (2048 * 6))()
 assert fn(buf) == 0
-w = np.array(buf[:], dtype=np.uint64).reshape(2048, 4)
+w = np.array(buf[:], dtype=np.uint64).reshape(2048, 6)
 nwg = int((w[:, 0] != 0).sum())
 w = w[:nwg]
 t0 = w[:, 0].min()
@@ -53,6 +53,8 @@ print("%d workgroups (%d label rows + %d projection), us since the first one sta
 for r, name in ((0, 'label'), (1, 'projection')):
     m = role == r
     print("  %-11s start %s | end %s | duration %s" % (name, q(st[m]), q(en[m]), q(en[m] - st[m])))
+m = role == 1
+print("  projection: kernel half + row addresses in LDS after %s us" % q((w[m, 4] - w[m, 0]).astype(np.float64) / 100.0))
 cus = sorted(set(place.tolist()))
 mix = {}
 for c in cus:
