@@ -330,14 +330,28 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
       s_hist[tid] = g.hist ? (g.hist_table ? g.hist_table[sr] : sr) * g.hist_stride + g.hist_offset : 0;
     }
     __syncthreads();
+    // The bytes are requested here and made floats BEHIND the zero fill (round 6: converted at the load, each of a thread's
+    // frame elements was waited for where it was requested -- three round trips in a row, the history frames' loads behind
+    // a condition one more each: 3 us of the launch).  All loads unconditional: without history frames the current ones
+    // are read twice.
+    const bool has_hist = a.use_xp && a.stage.hist;
+    const unsigned char* hsrc = has_hist ? a.stage.hist : a.stage.cur;
+    unsigned ux[FPT], up[FPT];
 #pragma unroll
     for (int u = 0; u < FPT; ++u) {
       const int i = min(tid + u * VNT, nvalid * D - 1);
       const int r = i / D, c = i - r * D;
-      fx[u] = (float)a.stage.cur[s_cur[r] + c];
-      fp[u] = (a.use_xp && a.stage.hist) ? (float)a.stage.hist[s_hist[r] + c] : 0.f;
+      ux[u] = a.stage.cur[s_cur[r] + c];
+      up[u] = hsrc[(has_hist ? s_hist[r] : s_cur[r]) + c];
+    }
+    for (int i = tid; i < M.total / 4; i += VNT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < FPT; ++u) {
+      fx[u] = (float)ux[u];
+      fp[u] = has_hist ? (float)up[u] : 0.f;
       fy[u] = 0.f;
-      if (tid + u * VNT < nvalid * D) {
+      const int i = tid + u * VNT;
+      if (i < nvalid * D) {
         const size_t g = (size_t)row0 * D + i;
         if (a.stage.x_out) a.stage.x_out[g] = fx[u];
         if (a.stage.xp_out && a.use_xp) a.stage.xp_out[g] = fp[u];
@@ -353,7 +367,8 @@ __global__ __launch_bounds__(VNT) void vae_fused_kernel(VaeArgs a) {
       fy[u] = a.y ? a.y[g] : 0.f;
     }
   }
-  for (int i = tid; i < M.total / 4; i += VNT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!a.stage.on)
+    for (int i = tid; i < M.total / 4; i += VNT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   lds_barrier();
 #pragma unroll
   for (int u = 0; u < FPT; ++u) {

@@ -1,7 +1,7 @@
 """Stage timeline of the fused cl_vae step (csrc/vae_fused.hip built with -DCLV_VAE_STAMPS): workgroup 0's wall clock at
 every stage boundary, median over a few launches.
   bash tools/build_variant.sh stamps "-DCLV_VAE_STAMPS" vae_fused.hip
-  CLV_LIB=$PWD/abtest/stamps/libclvae_hip.so python tools/vae_stamps.py"""
+  CLV_LIB=$PWD/abtest/stamps/libclvae_hip.so python tools/vae_stamps.py [staged]"""
 import ctypes
 import os
 import sys
@@ -36,8 +36,18 @@ fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rows = []
 raw = []
+STAGED = len(sys.argv) > 1 and sys.argv[1] == 'staged'      # the training step's own path: the launch assembles its byte rows
+if STAGED:
+    from clvae_amd.trainer import TrainStep
+    X_all, Xp_all, w_all = bench.synthetic_windows(w, 4 * B, 1234, dev)
+    ts = TrainStep(eng, seed=1234, use_graph=False)
+    ts.bind_batches(X_all, Xp_all, w_all, idx=None, period=4, stride=B)
+    print("staged path (TrainStep.bind_batches, eager)")
 for it in range(12):
-    eng.loss_and_grads(x, xp, oh, ew, ez)
+    if STAGED:
+        ts.step()
+    else:
+        eng.loss_and_grads(x, xp, oh, ew, ez)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     assert fn(buf, 64) == 0
