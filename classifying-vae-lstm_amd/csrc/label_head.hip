@@ -410,25 +410,48 @@ __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const 
   // compiler wait for the load at once, which is what sparse_proj_kernel's byte instance did until round 6)
   // (loaded as the aligned dword that holds the byte -- frames start on 4-byte boundaries -- and extracted at the use)
   typedef const __attribute__((address_space(1))) unsigned* gwords;
-  const int w0 = k0 >> 2, w1 = k1 >> 2, sh0 = 8 * (k0 & 3), sh1 = 8 * (k1 & 3);
-  auto frame = [&](int ri, int t, unsigned& x0, unsigned& x1) {
-    gwords bp = (gwords)(rowp[ri] + (size_t)t * nf);
+  const int w0 = k0 >> 2, w1 = k1 >> 2, sh0 = 8 * (k0 & 3), sh1 = 8 * (k1 & 3), nfw = nf / 4;
+  // The loop below is bound by the NUMBER of instructions a wave issues (one per four cycles at best; FP_ROUND / two register
+  // sets, see the note loop), so what is uniform stays in scalar registers and moves by additions: a row's address is
+  // fetched from LDS when the row changes, the store offset advances with the frame.
+  auto rowbase = [&](int r) -> gwords {
+    const unsigned long long p = (unsigned long long)rowp[min(r, nrows - 1)];
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    return (gwords)(((unsigned long long)hi << 32) | lo);
+  };
+  const gwords base0 = rowbase(0);
+  auto frame = [&](gwords base, int t, unsigned& x0, unsigned& x1) {
+    gwords bp = base + t * nfw;
     x0 = bp[w0]; x1 = bp[w1];
   };
   // This wave's frames are q = wave, wave + 16, .. of the nq.  A frame's bytes are requested FP_PF of the wave's frames ahead:
   // with one frame ahead (sparse_proj_kernel) an iteration lasts one global load (~1.2 us measured, for ~0.3 us of work).
-  auto advance = [&](int& r_, int& t_) { t_ += 16; while (t_ >= fp.T) { t_ -= fp.T; ++r_; } };
   int ri = wave / fp.T, t = wave - ri * fp.T;             // (row, frame) being computed ...
   int ra = ri, ta = t;                                    // ... and being requested
+  gwords base_a = rowbase(ra);
+  auto advance_a = [&]() {
+    ta += 16;
+    if (ta >= fp.T) {
+      do { ta -= fp.T; ++ra; } while (ta >= fp.T);
+      base_a = rowbase(ra);
+    }
+  };
+  // byte offset of the computed frame's outputs: row (w + ri wgs) T + t of [.., ldo], this workgroup's column half
+  const unsigned so_step = 16u * (unsigned)fp.ldo * 4u, so_wrap = (unsigned)(fp.wgs - 1) * (unsigned)fp.T * (unsigned)fp.ldo * 4u;
+  unsigned so = (unsigned)(((w + ri * fp.wgs) * fp.T + t) * fp.ldo + c0) * 4u;
+  auto advance_c = [&]() {
+    t += 16; so += so_step;
+    while (t >= fp.T) { t -= fp.T; so += so_wrap; }
+  };
   unsigned qx0[FP_PF], qx1[FP_PF];
 #pragma unroll
   for (int j = 0; j < FP_PF; ++j) {
     const bool ok = wave + 16 * j < nq;                   // (unconditional loads, clamped to frame 0 of the workgroup: a load
-    frame(ok ? ra : 0, ok ? ta : 0, qx0[j], qx1[j]);      // under a condition is waited for where it is issued)
+    frame(ok ? base_a : base0, ok ? ta : 0, qx0[j], qx1[j]);      // under a condition is waited for where it is issued)
     // (as many stores -- out of range, dropped -- as a loop iteration has: the loop's first wait is the minimum over both ways
     // into the loop of the operations issued since the request, and without these that minimum is the prologue's)
     __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, r_out, (int)0x80000000u, 0, 0);
-    advance(ra, ta);
+    advance_a();
   }
   for (int qb = wave; qb < nq; qb += 16 * FP_PF) {
 #pragma unroll
@@ -437,8 +460,8 @@ __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const 
       const bool live = q < nq;                           // (no break: the slots keep their registers)
       const float fx0 = (float)((qx0[j] >> sh0) & 0xffu), fx1 = (float)((qx1[j] >> sh1) & 0xffu);
       const bool more = q + 16 * FP_PF < nq;
-      if (FP_ABL != 3) frame(more ? ra : 0, more ? ta : 0, qx0[j], qx1[j]);
-      advance(ra, ta);
+      if (FP_ABL != 3) frame(more ? base_a : base0, more ? ta : 0, qx0[j], qx1[j]);
+      advance_a();
       unsigned long long m0 = __ballot(live && v0 && fx0 != 0.f), m1 = __ballot(live && v1 && fx1 != 0.f);
       float acc[FP_NC];
 #pragma unroll
@@ -449,6 +472,16 @@ __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const 
       // the current one is used (two register sets), 32 -> 34 us.  A wave issues at most one instruction per four cycles and
       // every variant that hides latency adds instructions: the loop is bound by its instruction count.
       auto rounds = [&](unsigned long long m, const float fx, const int kbase) {
+        if (FP_ROUND == 1) {
+          while (m) {
+            const int k = __builtin_ctzll(m);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(k));          // m &= ~(1 << k): one instruction, not three
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), k));
+            const float4 k4 = *reinterpret_cast<const float4*>(Kl + (kbase + k) * nch + colb);
+            acc[0] = fmaf(v, k4.x, acc[0]); acc[1] = fmaf(v, k4.y, acc[1]); acc[2] = fmaf(v, k4.z, acc[2]); acc[3] = fmaf(v, k4.w, acc[3]);
+          }
+          return;
+        }
         while (m) {
           float v[FP_ROUND], kv[FP_ROUND][FP_NC];
           bool on[FP_ROUND];
@@ -476,11 +509,10 @@ __device__ __forceinline__ void frame_proj_block(const LabelFwdXArgs& ax, const 
       // buffer stores, lanes without a column (and frames beyond the last) at an out-of-range offset: no branch around a
       // store, so the number of memory operations between a request and its use is fixed and the wait in front of the use
       // is a counted one (behind `if`s the compiler must assume the stores were skipped and waits for the newest of them)
-      const unsigned so = (unsigned)(((w + ri * fp.wgs) * fp.T + t) * fp.ldo + c0) * 4u;
       __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(unsigned, acc[0]), __builtin_bit_cast(unsigned, acc[1]),
                                                       __builtin_bit_cast(unsigned, acc[2]), __builtin_bit_cast(unsigned, acc[3])},
                                              r_out, (int)((live && FP_ABL != 1) ? vo : 0x80000000u), (int)so, 0);
-      advance(ri, t);
+      advance_c();
     }
   }
 }
