@@ -731,7 +731,7 @@ extern "C" int clv_debug_front_wg(unsigned long long* host_out) {
 // halves of <= 256, half a kernel (D * N / 2 floats) in 64 KB of LDS
 extern "C" int clv_vrnn_label_fwd_x_proj_supported(int B, int D, int nx, int T, int N) {
   return B >= 1 && D >= 4 && D <= 128 && D % 4 == 0 && T >= 1 && (long long)T * D == nx && N >= 8 && N % 8 == 0 && N / 2 <= 64 * clv::FP_NC &&      /* (and ldo, the outputs 16-byte aligned: the launcher) */
-         (size_t)D * (N / 2) * sizeof(float) <= 64 * 1024;
+         (size_t)D * (N / 2) * sizeof(float) <= 64 * 1024 && (size_t)B * T * N * sizeof(float) < ((size_t)1 << 31);      // (one buffer descriptor per output)
 }
 
 extern "C" int clv_vrnn_label_fwd_x(int B, int D, int C, int G4, const float* X, int ldx, int nx, const float* Kh,

@@ -116,6 +116,15 @@ __device__ __forceinline__ void zh_store_hs(float* myhs, int row0, int R, int la
     }
 }
 
+typedef __amdgpu_buffer_rsrc_t zh_rsrc_t;
+constexpr unsigned ZH_OOB = 0x80000000u;
+__device__ __forceinline__ zh_rsrc_t zh_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void zh_bstore(float v, zh_rsrc_t r, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, 0, 0);
+}
+
 template <int LP16>
 __global__ __launch_bounds__(64 * ZH_NW) void latent_head_fwd_kernel(LatentFwdArgs a) {
   constexpr int NTZ = 2 * LP16, NP = 16 * NTZ;
@@ -174,6 +183,13 @@ __global__ __launch_bounds__(64 * ZH_NW) void latent_head_fwd_kernel(LatentFwdAr
       fetch(blk + gridDim.x);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is wave-private: no barrier
+    // this block's valid rows of every output as buffer resources (an absent output: zero records, its stores are dropped)
+    const size_t rb0 = (size_t)blk * ZH_RB;
+    const unsigned nrow = (unsigned)min(ZH_RB, a.R - blk * ZH_RB);
+    const zh_rsrc_t r_za = zh_rsrc(a.zargs + rb0 * 2 * L, nrow * 2u * L * 4u);
+    const zh_rsrc_t r_z = zh_rsrc(a.Z + rb0 * a.ldz, nrow * (unsigned)a.ldz * 4u);      // (columns beyond L of a row are other data: masked per lane)
+    const zh_rsrc_t r_e = zh_rsrc(a.eps + rb0 * L, draw ? nrow * L * 4u : 0u);
+    const zh_rsrc_t r_kl = zh_rsrc(a.rowkl ? a.rowkl + rb0 : a.zargs, a.rowkl ? nrow * 4u : 0u);
 
     f32x4 acc[NTZ];
 #pragma unroll
@@ -215,18 +231,22 @@ __global__ __launch_bounds__(64 * ZH_NW) void latent_head_fwd_kernel(LatentFwdAr
         const float sd = expf(0.5f * lv);
         const float z = m + sd * ec[jm][reg];
         ssum += ok ? 1.f + lv - m * m - sd * sd : 0.f;
-        if (ok) {
-          a.zargs[(size_t)row * 2 * L + c] = m;
-          a.zargs[(size_t)row * 2 * L + L + c] = lv;
-          a.Z[(size_t)row * a.ldz + c] = z;
-          if (draw) a.eps[(size_t)row * L + c] = ec[jm][reg];
-        }
+        // Buffer stores over this block's valid rows; a lane without a column carries an out-of-range offset.  No branch
+        // around a store: the next block's hs rows were requested BEFORE these stores, and the wait in front of their use
+        // must be able to count the stores behind them -- behind `if`s it was vmcnt(0), i.e. every block ended by waiting
+        // for its own stores to be acknowledged (round 6, PERFLOG R6.14).
+        const unsigned rb = (unsigned)(wave * 16 + 4 * q + reg);
+        const unsigned oc = c < L ? 0u : ZH_OOB;
+        zh_bstore(m, r_za, (rb * 2u * L + c) * 4u | oc);
+        zh_bstore(lv, r_za, (rb * 2u * L + L + c) * 4u | oc);
+        zh_bstore(z, r_z, (rb * (unsigned)a.ldz + c) * 4u | oc);
+        zh_bstore(ec[jm][reg], r_e, (rb * L + c) * 4u | oc);
       }
       ssum += __shfl_xor(ssum, 8, 64);
       ssum += __shfl_xor(ssum, 4, 64);
       ssum += __shfl_xor(ssum, 2, 64);
       ssum += __shfl_xor(ssum, 1, 64);
-      if (a.rowkl && r == 0 && rok) a.rowkl[row] = -0.5f * ssum;
+      zh_bstore(-0.5f * ssum, r_kl, (unsigned)(wave * 16 + 4 * q + reg) * 4u | (r == 0 ? 0u : ZH_OOB));
     }
   }
 }

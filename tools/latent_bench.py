@@ -35,7 +35,8 @@ ws = ops.Workspace(dev)
 hs, Wz, bz, eps = torch.tanh(f(R, H)), f(H, 2 * L) * 0.2, f(2 * L) * 0.1, f(R, L)
 zargs, Z, rowkl = torch.empty(R, 2 * L, device=dev), torch.empty(R, L, device=dev), torch.empty(R, device=dev)
 dZ, dhs, dWz, dbz = f(R, L), torch.empty(R, H, device=dev), torch.empty(H, 2 * L, device=dev), torch.empty(2 * L, device=dev)
-tf = timeit(lambda: ops.latent_head_fwd(R, H, L, hs, Wz, bz, eps, zargs, Z, L, rowkl))
+nz = ops.noise_draw(7, 1, 0) if os.environ.get('NOISE') == '1' else None      # the training step's form: eps drawn in the kernel
+tf = timeit(lambda: ops.latent_head_fwd(R, H, L, hs, Wz, bz, eps, zargs, Z, L, rowkl, noise=nz))
 tb = timeit(lambda: ops.latent_head_bwd(R, H, L, hs, Wz, zargs, eps, dZ, L, 1.0 / R, dhs, dWz, dbz, ws))
 torch.cuda.synchronize()
 sums = [float(t.double().abs().sum()) for t in (zargs, Z, rowkl, dhs, dWz, dbz)]
