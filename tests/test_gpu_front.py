@@ -91,3 +91,38 @@ def test_projection_rider_needs_the_stage_it_reads_through(dev):
     with pytest.raises(ValueError):
         ops.vrnn_label_fwd_x(4, 88, 3, 352, z, 88, 88, z, z, z, z, z, z, z, 0.0, z, z, z, z, z, z, z, z, z,
                              proj=(1, 352, z, z, None, None))
+
+
+def test_front_launch_soak_200_steps_bit_for_bit(dev):
+    """BASELINE configuration 3's shape, 200 replayed steps over 8 different mini-batches: the merged launch (two kinds of workgroup
+    sharing every CU, frames requested four ahead, buffer stores) against the two launches -- every parameter bit for bit at the
+    end (a race or a stale prefetch would not survive 200 steps of an optimizer that amplifies a one-ulp difference)."""
+    from clvae_amd.engine import VrnnEngine
+    from clvae_amd.trainer import TrainStep
+    B, Tn, L, Cn, nb, steps = 256, 128, 2, 10, 8, 200
+    cfg = O.vrnn_config(latent_dim=L, seq_length=Tn, n_classes=Cn, use_x_prev=True)
+    rng = np.random.default_rng(77)
+    p0 = {k: np.asarray(v, np.float32) for k, v in O.vrnn_init_params(cfg, seed=8).items()}
+    n = nb * B
+    win = rng.random((n, Tn + 1, 88)) < 0.0443
+    cur, hist = u8(win[:, 1:].reshape(n, -1), dev), u8(win[:, :-1].reshape(n, -1), dev)
+    keys = torch.as_tensor(np.eye(Cn, dtype=np.float32)[rng.integers(0, Cn, n)], device=dev)
+    idx = torch.as_tensor(rng.permutation(n).astype(np.int64), device=dev)
+    out = []
+    for flag in ('1', '0'):
+        os.environ['CLV_FRONT_FUSED'] = flag
+        try:
+            eng = VrnnEngine(cfg, B, dev)
+            eng.P.set_weights(p0)
+            ts = TrainStep(eng, seed=21, use_graph=True)
+            ts.bind_batches(cur, hist, keys, idx=idx, period=nb, stride=B)
+            for _ in range(steps):
+                ts.step()
+            torch.cuda.synchronize()
+            out.append((dict(eng.losses()), {k: v.copy() for k, v in eng.P.get_weights().items()}))
+        finally:
+            os.environ.pop('CLV_FRONT_FUSED', None)
+    assert all(np.isfinite(v) for v in out[0][0].values())
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for k in out[0][1]:
+        np.testing.assert_array_equal(out[0][1][k], out[1][1][k], err_msg=k)
